@@ -1,0 +1,79 @@
+"""Builds libbrcnn_hip.so (every HIP kernel of the hot path + the C ABI) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU.  The shared object lands next to the sources
+(`boosting-r-cnn_amd/lib/libbrcnn_hip.so`): it is git-ignored but travels to the GPU box with
+the repository snapshot.
+"""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libbrcnn_hip.so')
+ARCH = 'gfx950'
+SOURCES = ['roi_align.hip', 'nms.hip', 'soft_nms.hip', 'focal_loss.hip', 'conv_igemm.hip',
+           'misc.hip', 'rpn.hip']
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-fvisibility=hidden', '-Wno-unused-result']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found: cannot build libbrcnn_hip.so')
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + \
+        sorted(f for f in os.listdir(CSRC) if f.endswith('.hip') and f not in SOURCES)
+
+
+def _stamp():
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)) + ['../../include/brcnn_hip.h']:
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p):
+            h.update(f.encode())
+            h.update(open(p, 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(LIBDIR, 'obj', src.replace('.hip', '.o'))
+    cmd = [hipcc()] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
+    return obj
+
+
+def build_library(force=False, verbose=False):
+    os.makedirs(os.path.join(LIBDIR, 'obj'), exist_ok=True)
+    stamp_file = os.path.join(LIBDIR, 'stamp')
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and \
+            open(stamp_file).read() == stamp:
+        return LIB
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
+    with open(stamp_file, 'w') as f:
+        f.write(stamp)
+    if verbose:
+        print('built', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv, verbose=True)

@@ -1,0 +1,226 @@
+// Small NHWC kernels around the conv stack (all HBM-bound streams, float4 per lane):
+//   max-pool 3x3/s2/p1 (resnet.py:611), GroupNorm(+ReLU) of the RetinaRPN tower
+//   (atss_rpn_head.py:118,150-190 -> ConvModule norm), FPN nearest-upsample-add
+//   (necks/pafpn.py:113-115), NCHW<->NHWC shuffles at the reference's tensor boundary,
+//   library info.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ y, int N, int H,
+                                                          int W, int C, int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * Ho * Wo * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        long long r = idx / c4n;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int kh = 0; kh < 3; kh++) {
+            const int hi = ho * 2 - 1 + kh;
+            if (hi < 0 || hi >= H) continue;
+            for (int kw = 0; kw < 3; kw++) {
+                const int wi = wo * 2 - 1 + kw;
+                if (wi < 0 || wi >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(
+                    x + (((size_t)n * H + hi) * W + wi) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(y + (size_t)idx * 4) = m;
+    }
+}
+
+// ---- GroupNorm: pass 1 = per (n, group) sum / sum of squares in double ------------------
+// grid (chunks, N); 256 threads; thread t owns channel t (+256j); rows strided by chunk.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x,
+                                                      double* __restrict__ stats, int HW, int C,
+                                                      int G, int rows_per_block) {
+    const int n = blockIdx.y;
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(HW, row0 + rows_per_block);
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f, ss = 0.f;
+        double ds = 0.0, dss = 0.0;
+        int cnt = 0;
+        for (int r = row0; r < row1; r++) {
+            const float v = x[((size_t)n * HW + r) * C + c];
+            s += v;
+            ss += v * v;
+            if (++cnt == 64) { ds += s; dss += ss; s = ss = 0.f; cnt = 0; }
+        }
+        ds += s; dss += ss;
+        const int g = c / cpg;
+        atomicAdd(&stats[((size_t)n * G + g) * 2 + 0], ds);
+        atomicAdd(&stats[((size_t)n * G + g) * 2 + 1], dss);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
+                                                      const double* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ y, int N, int HW, int C,
+                                                      int G, float eps, int relu) {
+    const int c4n = C >> 2, cpg = C / G;
+    const long long total = (long long)N * HW * c4n;
+    const double inv_cnt = 1.0 / ((double)HW * cpg);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const int n = (int)(idx / ((long long)HW * c4n));
+        float4 v = *reinterpret_cast<const float4*>(x + (size_t)idx * 4);
+        float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = c4 * 4 + e, g = c / cpg;
+            const double mean = stats[((size_t)n * G + g) * 2] * inv_cnt;
+            double var = stats[((size_t)n * G + g) * 2 + 1] * inv_cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            float o = (in[e] - (float)mean) * rstd * gamma[c] + beta[c];
+            if (relu) o = fmaxf(o, 0.f);
+            out[e] = o;
+        }
+        *reinterpret_cast<float4*>(y + (size_t)idx * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_add_kernel(float* __restrict__ dst,
+                                                          const float* __restrict__ src, int N,
+                                                          int Hd, int Wd, int Hs, int Ws, int C) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * Hd * Wd * c4n;
+    const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        long long r = idx / c4n;
+        const int wd = (int)(r % Wd); r /= Wd;
+        const int hd = (int)(r % Hd);
+        const int n = (int)(r / Hd);
+        const int hs = min((int)floorf(hd * sh), Hs - 1);
+        const int ws = min((int)floorf(wd * sw), Ws - 1);
+        const float4 s = *reinterpret_cast<const float4*>(
+            src + (((size_t)n * Hs + hs) * Ws + ws) * C + c4 * 4);
+        float4 d = *reinterpret_cast<float4*>(dst + (size_t)idx * 4);
+        d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+        *reinterpret_cast<float4*>(dst + (size_t)idx * 4) = d;
+    }
+}
+
+// (N, R, Cc) -> (N, Cc, R) tiled transpose through LDS: 32x32 tiles, 256 threads
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src,
+                                                       float* __restrict__ dst, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
+    const float* s = src + (size_t)n * R * Cc;
+    float* d = dst + (size_t)n * R * Cc;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < R && c < Cc) tile[j][tx] = s[(size_t)r * Cc + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < R && c < Cc) d[(size_t)c * R + r] = tile[tx][j];
+    }
+}
+
+inline int stream_grid(long long total) {
+    long long g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+BRCNN_API int brcnn_version(void) { return 100; }
+
+BRCNN_API int brcnn_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    return n;
+}
+
+BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int height, int width,
+                                      int channels, int dtype, void* stream) {
+    if (!x || !y || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
+        dtype != BRCNN_DT_F32)
+        return BRCNN_EINVAL;
+    const int Ho = (height + 2 - 3) / 2 + 1, Wo = (width + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * Ho * Wo * (channels >> 2);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)x, (float*)y, batch, height, width,
+                       channels, Ho, Wo);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y,
+                                   void* stats_ws, int batch, int hw, int channels, int groups,
+                                   float eps, int relu, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !stats_ws || batch <= 0 || hw <= 0 || channels <= 0 ||
+        groups <= 0 || channels % groups || (channels & 3) || dtype != BRCNN_DT_F32)
+        return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    BRCNN_HIP_CHECK(hipMemsetAsync(stats_ws, 0, (size_t)batch * groups * 2 * sizeof(double), s));
+    int chunks = (hw + 127) / 128;
+    if (chunks > 512) chunks = 512;
+    const int rows = (hw + chunks - 1) / chunks;
+    chunks = (hw + rows - 1) / rows;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, batch), dim3(256), 0, s, (const float*)x,
+                       (double*)stats_ws, hw, channels, groups, rows);
+    BRCNN_LAUNCH_CHECK();
+    const long long total = (long long)batch * hw * (channels >> 2);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
+                       (const double*)stats_ws, gamma, beta, (float*)y, batch, hw, channels, groups,
+                       eps, relu);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_upsample_nearest_add_nhwc(void* dst, const void* src, int batch, int hd, int wd,
+                                              int hs, int ws, int channels, int dtype,
+                                              void* stream) {
+    if (!dst || !src || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 ||
+        (channels & 3) || dtype != BRCNN_DT_F32)
+        return BRCNN_EINVAL;
+    const long long total = (long long)batch * hd * wd * (channels >> 2);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                       (hipStream_t)stream, (float*)dst, (const float*)src, batch, hd, wd, hs, ws,
+                       channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_nchw_to_nhwc(const float* src, void* dst, int batch, int channels, int hw,
+                                 int dst_dtype, void* stream) {
+    if (!src || !dst || batch <= 0 || channels <= 0 || hw <= 0 || dst_dtype != BRCNN_DT_F32)
+        return BRCNN_EINVAL;
+    // src viewed as (N, R=C, Cc=HW) -> dst (N, HW, C)
+    hipLaunchKernelGGL(transpose_kernel, dim3((hw + 31) / 32, (channels + 31) / 32, batch),
+                       dim3(256), 0, (hipStream_t)stream, src, (float*)dst, channels, hw);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_nhwc_to_nchw(const void* src, float* dst, int batch, int channels, int hw,
+                                 int src_dtype, void* stream) {
+    if (!src || !dst || batch <= 0 || channels <= 0 || hw <= 0 || src_dtype != BRCNN_DT_F32)
+        return BRCNN_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((channels + 31) / 32, (hw + 31) / 32, batch),
+                       dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, hw, channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,215 @@
+// Greedy NMS (segmented) for gfx950.
+//
+// Replaces mmcv.ops.nms (ext `nms`) reached through mmcv batched_nms at
+// mmdet/models/dense_heads/atss_rpn_head.py:756, rpn_head.py:245 and
+// mmdet/core/post_processing/bbox_nms.py:86.  Per segment the semantics are mmcv's
+// nms_cpu: order by score descending (ties: ascending original index), greedy, suppress
+// when inter / (area_i + area_j - inter) > thr evaluated in fp32 in exactly that operation
+// order (file compiled with -ffp-contract=off, correctly rounded division).
+//
+// Pipeline (all on the caller's stream, no host synchronisation):
+//   1. rocPRIM segmented radix sort (stable, descending) of (score, index) pairs;
+//   2. gather boxes into sorted order + areas;
+//   3. 64x64 IoU tiles -> bit mask, one wavefront per tile (wave64 == one 64-bit word per
+//      lane), upper triangle only;
+//   4. one wavefront per segment walks the mask 64 rows at a time: the in-chunk dependency
+//      is resolved with wave-uniform scalar ops on the diagonal words (v_readlane), the
+//      rows of the survivors are OR-ed into the LDS-resident `removed` vector.
+#include "common.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+__global__ void iota_kernel(int32_t* __restrict__ v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void gather_boxes_kernel(const float* __restrict__ boxes,
+                                    const int32_t* __restrict__ sorted_idx,
+                                    float* __restrict__ sboxes, float* __restrict__ sareas,
+                                    int64_t n, int offset) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)sorted_idx[i] * 4);
+    *reinterpret_cast<float4*>(sboxes + (size_t)i * 4) = b;
+    sareas[i] = (b.z - b.x + offset) * (b.w - b.y + offset);
+}
+
+// grid: (col_tile, row_tile, segment); block: 64 threads (one wavefront).
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes,
+                                                      const float* __restrict__ sareas,
+                                                      const int32_t* __restrict__ seg_offsets,
+                                                      unsigned long long* __restrict__ mask,
+                                                      int words, float thr, int offset) {
+    const int col_t = blockIdx.x, row_t = blockIdx.y, seg = blockIdx.z;
+    if (col_t < row_t) return;
+    const int beg = seg_offsets[seg], len = seg_offsets[seg + 1] - beg;
+    if (row_t * 64 >= len || col_t * 64 >= len) return;
+    __shared__ float4 cb[64];
+    __shared__ float ca[64];
+    const int lane = threadIdx.x;
+    const int cj = col_t * 64 + lane;
+    if (cj < len) {
+        cb[lane] = *reinterpret_cast<const float4*>(sboxes + (size_t)(beg + cj) * 4);
+        ca[lane] = sareas[beg + cj];
+    }
+    __syncthreads();
+    const int ri = row_t * 64 + lane;
+    if (ri >= len) return;
+    const float4 a = *reinterpret_cast<const float4*>(sboxes + (size_t)(beg + ri) * 4);
+    const float aarea = sareas[beg + ri];
+    const int ncol = min(64, len - col_t * 64);
+    unsigned long long bits = 0ull;
+    const int jstart = (row_t == col_t) ? lane + 1 : 0;
+    for (int j = jstart; j < ncol; j++) {
+        const float4 b = cb[j];
+        const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+        const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+        const float w = fmaxf(0.f, xx2 - xx1 + offset), h = fmaxf(0.f, yy2 - yy1 + offset);
+        const float inter = w * h;
+        const float ovr = inter / (aarea + ca[j] - inter);
+        if (ovr > thr) bits |= 1ull << j;
+    }
+    mask[(size_t)(beg + ri) * words + col_t] = bits;
+}
+
+// one wavefront per segment
+__global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
+                                                        const int32_t* __restrict__ sorted_idx,
+                                                        const int32_t* __restrict__ seg_offsets,
+                                                        int64_t* __restrict__ keep,
+                                                        int32_t* __restrict__ num_keep, int words,
+                                                        int max_keep) {
+    extern __shared__ unsigned long long remv[];
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int beg = seg_offsets[seg], len = seg_offsets[seg + 1] - beg;
+    const int nchunk = (len + 63) >> 6;
+    for (int w = lane; w < nchunk; w += 64) remv[w] = 0ull;
+    __syncthreads();
+    int count = 0;
+    for (int c = 0; c < nchunk; c++) {
+        const int row = c * 64 + lane;
+        const unsigned long long diag = (row < len) ? mask[(size_t)(beg + row) * words + c] : 0ull;
+        unsigned long long cur = remv[c];
+        const int nb = min(64, len - c * 64);
+        unsigned long long kept = 0ull;
+        const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
+        for (int b = 0; b < nb; b++) {
+            if (!((cur >> b) & 1ull)) {
+                kept |= 1ull << b;
+                const unsigned dlo = __builtin_amdgcn_readlane(lo, b);
+                const unsigned dhi = __builtin_amdgcn_readlane(hi, b);
+                cur |= ((unsigned long long)dhi << 32) | dlo;
+            }
+        }
+        // emit survivors of this chunk in order
+        const bool mine = (kept >> lane) & 1ull;
+        const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+        const int nk = __popcll(kept);
+        if (mine) {
+            const int pos = count + rank;
+            if (max_keep <= 0 || pos < max_keep) keep[beg + pos] = (int64_t)sorted_idx[beg + row];
+        }
+        count += nk;
+        if (max_keep > 0 && count >= max_keep) { count = max_keep; break; }
+        // OR the survivors' rows into the removed vector (words beyond this chunk)
+        unsigned long long k2 = kept;
+        while (k2) {
+            const int b = __ffsll((long long)k2) - 1;
+            k2 &= k2 - 1;
+            const unsigned long long* mrow = mask + (size_t)(beg + c * 64 + b) * words;
+            for (int w = c + 1 + lane; w < nchunk; w += 64) remv[w] |= mrow[w];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) num_keep[seg] = count;
+}
+
+struct NmsWs {
+    float* keys_out;
+    int32_t* idx_in;
+    int32_t* idx_out;
+    float* sboxes;
+    float* sareas;
+    unsigned long long* mask;
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+    size_t total;
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t sort_temp_bytes(int64_t n, int S) {
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_pairs_desc<rocprim::default_config, const float*, float*,
+                                             const int32_t*, int32_t*, const int32_t*>(
+        nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, (unsigned)S, nullptr,
+        nullptr, 0, 32, (hipStream_t)0, false);
+    return bytes;
+}
+
+NmsWs carve(void* base, int64_t n, int S, int words) {
+    NmsWs w;
+    size_t off = 0;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    w.keys_out = (float*)take(n * 4);
+    w.idx_in = (int32_t*)take(n * 4);
+    w.idx_out = (int32_t*)take(n * 4);
+    w.sboxes = (float*)take(n * 16);
+    w.sareas = (float*)take(n * 4);
+    w.mask = (unsigned long long*)take((size_t)n * words * 8);
+    w.sort_tmp_bytes = sort_temp_bytes(n, S);
+    w.sort_tmp = take(w.sort_tmp_bytes);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+BRCNN_API size_t brcnn_nms_workspace_bytes(int64_t n, int num_segments, int64_t max_segment_len) {
+    if (n <= 0 || num_segments <= 0) return 256;
+    if (max_segment_len <= 0 || max_segment_len > n) max_segment_len = n;
+    const int words = (int)((max_segment_len + 63) / 64);
+    return carve(nullptr, n, num_segments, words).total;
+}
+
+BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
+                        int num_segments, int64_t n, int64_t max_segment_len, float iou_threshold,
+                        int offset, int max_keep, int64_t* keep, int32_t* num_keep, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (n < 0 || num_segments <= 0 || (offset != 0 && offset != 1) || !seg_offsets || !num_keep)
+        return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        BRCNN_HIP_CHECK(hipMemsetAsync(num_keep, 0, sizeof(int32_t) * num_segments, s));
+        return 0;
+    }
+    if (!boxes || !scores || !keep || !workspace || max_segment_len <= 0 || max_segment_len > n)
+        return BRCNN_EINVAL;
+    if (n > 0x7fffffffLL) return BRCNN_EINVAL;
+    const int words = (int)((max_segment_len + 63) / 64);
+    NmsWs w = carve(workspace, n, num_segments, words);
+    if (w.total > workspace_bytes) return BRCNN_EINVAL;
+
+    hipLaunchKernelGGL(iota_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, w.idx_in, n);
+    BRCNN_LAUNCH_CHECK();
+    size_t tmp = w.sort_tmp_bytes;
+    BRCNN_HIP_CHECK((rocprim::segmented_radix_sort_pairs_desc(
+        w.sort_tmp, tmp, scores, w.keys_out, (const int32_t*)w.idx_in, w.idx_out, (unsigned)n,
+        (unsigned)num_segments, seg_offsets, seg_offsets + 1, 0, 32, s, false)));
+    hipLaunchKernelGGL(gather_boxes_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, boxes,
+                       (const int32_t*)w.idx_out, w.sboxes, w.sareas, n, offset);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, num_segments), dim3(64), 0, s,
+                       (const float*)w.sboxes, (const float*)w.sareas, seg_offsets, w.mask, words,
+                       iou_threshold, offset);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(num_segments), dim3(64), (size_t)words * 8, s,
+                       (const unsigned long long*)w.mask, (const int32_t*)w.idx_out, seg_offsets,
+                       keep, num_keep, words, max_keep);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,403 @@
+// RoIAlign forward/backward for gfx950 (CDNA4).
+//
+// Replaces mmcv.ops.roi_align_{forward,backward} (call sites:
+// mmdet/models/roi_heads/roi_extractors/base_roi_extractor.py:54-60,
+// single_level_roi_extractor.py:103).  Semantics = mmcv ROIAlign (aligned flag,
+// adaptive sampling grid, avg/max pooling); arithmetic order per output element is
+// the reference's: val = w1*v1 + w2*v2 + w3*v3 + w4*v4, sum over (iy, ix), / count,
+// compiled with -ffp-contract=off so results are bit-identical to the C oracle.
+//
+// HBM-bound gather.  NHWC kernel: one 64-lane wavefront per RoI bin, channels across
+// lanes (float4 per lane => one 1 KiB coalesced line per bilinear corner at C=256),
+// 4 bins per 256-thread workgroup, consecutive workgroups walk the bins of one RoI so
+// the corner lines shared by neighbouring bins/samples are L1/L2 hits.  NCHW kernel:
+// one thread per output element (the reference's own layout; uncoalesced by nature).
+#include "common.h"
+
+namespace {
+
+struct RoiGeom {
+    float start_h, start_w, bin_h, bin_w;
+    int gh, gw;
+    float count;
+    int batch;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float scale, int aligned,
+                                            int ph_n, int pw_n, int sampling_ratio) {
+    RoiGeom g;
+    g.batch = (int)roi[0];
+    float offset = aligned ? 0.5f : 0.0f;
+    float roi_start_w = roi[1] * scale - offset;
+    float roi_start_h = roi[2] * scale - offset;
+    float roi_end_w = roi[3] * scale - offset;
+    float roi_end_h = roi[4] * scale - offset;
+    float roi_width = roi_end_w - roi_start_w;
+    float roi_height = roi_end_h - roi_start_h;
+    if (!aligned) {
+        roi_width = fmaxf(roi_width, 1.f);
+        roi_height = fmaxf(roi_height, 1.f);
+    }
+    g.bin_h = roi_height / (float)ph_n;
+    g.bin_w = roi_width / (float)pw_n;
+    g.gh = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_height / (float)ph_n);
+    g.gw = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_width / (float)pw_n);
+    if (g.gh < 0) g.gh = 0;
+    if (g.gw < 0) g.gw = 0;
+    int c = g.gh * g.gw;
+    g.count = (float)(c < 1 ? 1 : c);
+    g.start_h = roi_start_h;
+    g.start_w = roi_start_w;
+    return g;
+}
+
+struct Tap {
+    int p1, p2, p3, p4;   // y*W+x of the four corners
+    float w1, w2, w3, w4;
+    bool valid;
+};
+
+__device__ __forceinline__ Tap bilinear_tap(float y, float x, int height, int width) {
+    Tap t;
+    if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+        t.valid = false;
+        t.p1 = t.p2 = t.p3 = t.p4 = 0;
+        t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+        return t;
+    }
+    t.valid = true;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; }
+    else y_high = y_low + 1;
+    if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; }
+    else x_high = x_low + 1;
+    float ly = y - y_low, lx = x - x_low;
+    float hy = 1.f - ly, hx = 1.f - lx;
+    t.w1 = hy * hx; t.w2 = hy * lx; t.w3 = ly * hx; t.w4 = ly * lx;
+    t.p1 = y_low * width + x_low;
+    t.p2 = y_low * width + x_high;
+    t.p3 = y_high * width + x_low;
+    t.p4 = y_high * width + x_high;
+    return t;
+}
+
+struct LevelTable {
+    const float* feat[BRCNN_MAX_LEVELS];
+    float* gfeat[BRCNN_MAX_LEVELS];
+    int height[BRCNN_MAX_LEVELS];
+    int width[BRCNN_MAX_LEVELS];
+    float scale[BRCNN_MAX_LEVELS];
+    int num_levels;
+    float finest_scale;
+};
+
+// SingleRoIExtractor.map_roi_levels (single_level_roi_extractor.py:36-55):
+//   scale = sqrt((x2-x1)*(y2-y1)); lvl = floor(log2(scale / finest_scale + 1e-6)) clamped.
+__device__ __forceinline__ int map_roi_level(const float* __restrict__ roi, float finest_scale,
+                                             int num_levels) {
+    float s = sqrtf((roi[3] - roi[1]) * (roi[4] - roi[2]));
+    float l = floorf(log2f(s / finest_scale + 1e-6f));
+    // clamp(min=0, max=L-1).long(); NaN (negative area) -> reference yields an
+    // undefined long; we send it to level 0.
+    if (!(l > 0.f)) l = 0.f;
+    if (l > (float)(num_levels - 1)) l = (float)(num_levels - 1);
+    return (int)l;
+}
+
+// ---------------------------------------------------------------------------------------
+// NHWC forward: one wave per (roi, ph, pw) bin; lane owns channels [4*lane + 256*j, +4).
+// ---------------------------------------------------------------------------------------
+template <bool MULTI>
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
+    const float* __restrict__ input, LevelTable lv, const float* __restrict__ rois,
+    float* __restrict__ output, int32_t* __restrict__ levels_out, int channels, int height,
+    int width, int n_rois, int ph_n, int pw_n, float spatial_scale, int sampling_ratio,
+    int aligned) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long bin = (long long)blockIdx.x * 4 + wave;
+    const int bins_per_roi = ph_n * pw_n;
+    if (bin >= (long long)n_rois * bins_per_roi) return;
+    const int k = (int)(bin / bins_per_roi);
+    const int r = (int)(bin - (long long)k * bins_per_roi);
+    const int ph = r / pw_n, pw = r - ph * pw_n;
+    const float* roi = rois + (size_t)k * 5;
+
+    const float* feat = input;
+    if (MULTI) {
+        int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
+        feat = lv.feat[l];
+        height = lv.height[l];
+        width = lv.width[l];
+        spatial_scale = lv.scale[l];
+        if (levels_out && r == 0 && lane == 0) levels_out[k] = l;
+    }
+    const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
+    const float* base = feat + (size_t)g.batch * height * width * channels;
+    float* out = output + (size_t)bin * channels;
+
+    for (int c0 = lane * 4; c0 < channels; c0 += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int iy = 0; iy < g.gh; iy++) {
+            const float y = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ix++) {
+                const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
+                const Tap t = bilinear_tap(y, x, height, width);
+                if (!t.valid) continue;   // contributes exactly +0.f in the reference
+                const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)t.p1 * channels + c0);
+                const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)t.p2 * channels + c0);
+                const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)t.p3 * channels + c0);
+                const float4 v4 = *reinterpret_cast<const float4*>(base + (size_t)t.p4 * channels + c0);
+                acc.x += t.w1 * v1.x + t.w2 * v2.x + t.w3 * v3.x + t.w4 * v4.x;
+                acc.y += t.w1 * v1.y + t.w2 * v2.y + t.w3 * v3.y + t.w4 * v4.y;
+                acc.z += t.w1 * v1.z + t.w2 * v2.z + t.w3 * v3.z + t.w4 * v4.z;
+                acc.w += t.w1 * v1.w + t.w2 * v2.w + t.w3 * v3.w + t.w4 * v4.w;
+            }
+        }
+        acc.x /= g.count; acc.y /= g.count; acc.z /= g.count; acc.w /= g.count;
+        *reinterpret_cast<float4*>(out + c0) = acc;
+    }
+}
+
+// NHWC backward (avg): same decomposition, atomicAdd of g*w/count to the four corners.
+template <bool MULTI>
+__global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(
+    const float* __restrict__ grad_output, LevelTable lv, const float* __restrict__ rois,
+    float* __restrict__ grad_input, int channels, int height, int width, int n_rois, int ph_n,
+    int pw_n, float spatial_scale, int sampling_ratio, int aligned) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long bin = (long long)blockIdx.x * 4 + wave;
+    const int bins_per_roi = ph_n * pw_n;
+    if (bin >= (long long)n_rois * bins_per_roi) return;
+    const int k = (int)(bin / bins_per_roi);
+    const int r = (int)(bin - (long long)k * bins_per_roi);
+    const int ph = r / pw_n, pw = r - ph * pw_n;
+    const float* roi = rois + (size_t)k * 5;
+    float* gfeat = grad_input;
+    if (MULTI) {
+        int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
+        gfeat = lv.gfeat[l];
+        height = lv.height[l];
+        width = lv.width[l];
+        spatial_scale = lv.scale[l];
+    }
+    const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
+    float* base = gfeat + (size_t)g.batch * height * width * channels;
+    const float* go = grad_output + (size_t)bin * channels;
+    for (int c = lane; c < channels; c += 64) {
+        const float gv = go[c];
+        for (int iy = 0; iy < g.gh; iy++) {
+            const float y = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ix++) {
+                const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
+                const Tap t = bilinear_tap(y, x, height, width);
+                if (!t.valid) continue;
+                atomicAdd(base + (size_t)t.p1 * channels + c, gv * t.w1 / g.count);
+                atomicAdd(base + (size_t)t.p2 * channels + c, gv * t.w2 / g.count);
+                atomicAdd(base + (size_t)t.p3 * channels + c, gv * t.w3 / g.count);
+                atomicAdd(base + (size_t)t.p4 * channels + c, gv * t.w4 / g.count);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// NCHW forward/backward: one thread per output element (n, c, ph, pw), grid-stride.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw_kernel(
+    const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output,
+    float* __restrict__ argmax_y, float* __restrict__ argmax_x, long long total, int channels,
+    int height, int width, int ph_n, int pw_n, float spatial_scale, int sampling_ratio,
+    int pool_mode, int aligned) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+         index += (long long)gridDim.x * blockDim.x) {
+        const int pw = (int)(index % pw_n);
+        const int ph = (int)((index / pw_n) % ph_n);
+        const int c = (int)((index / pw_n / ph_n) % channels);
+        const int k = (int)(index / pw_n / ph_n / channels);
+        const float* roi = rois + (size_t)k * 5;
+        const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
+        const float* in = input + ((size_t)g.batch * channels + c) * height * width;
+        float out = 0.f, maxval = -10000.f, my = -1.f, mx = -1.f;
+        for (int iy = 0; iy < g.gh; iy++) {
+            const float y = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ix++) {
+                const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
+                const Tap t = bilinear_tap(y, x, height, width);
+                float val = t.w1 * in[t.p1] + t.w2 * in[t.p2] + t.w3 * in[t.p3] + t.w4 * in[t.p4];
+                if (val > maxval) { maxval = val; my = y; mx = x; }
+                out += val;
+            }
+        }
+        if (pool_mode == 0) {
+            output[index] = maxval;
+            argmax_y[index] = my;
+            argmax_x[index] = mx;
+        } else {
+            output[index] = out / g.count;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_nchw_kernel(
+    const float* __restrict__ grad_output, const float* __restrict__ rois,
+    float* __restrict__ grad_input, long long total, int channels, int height, int width,
+    int ph_n, int pw_n, float spatial_scale, int sampling_ratio, int aligned) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+         index += (long long)gridDim.x * blockDim.x) {
+        const int pw = (int)(index % pw_n);
+        const int ph = (int)((index / pw_n) % ph_n);
+        const int c = (int)((index / pw_n / ph_n) % channels);
+        const int k = (int)(index / pw_n / ph_n / channels);
+        const float* roi = rois + (size_t)k * 5;
+        const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
+        float* gi = grad_input + ((size_t)g.batch * channels + c) * height * width;
+        const float gv = grad_output[index];
+        for (int iy = 0; iy < g.gh; iy++) {
+            const float y = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ix++) {
+                const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
+                const Tap t = bilinear_tap(y, x, height, width);
+                if (!t.valid) continue;
+                atomicAdd(gi + t.p1, gv * t.w1 / g.count);
+                atomicAdd(gi + t.p2, gv * t.w2 / g.count);
+                atomicAdd(gi + t.p3, gv * t.w3 / g.count);
+                atomicAdd(gi + t.p4, gv * t.w4 / g.count);
+            }
+        }
+    }
+}
+
+int check_common(int batch, int channels, int height, int width, int n_rois, int ph, int pw) {
+    if (batch < 0 || channels <= 0 || height <= 0 || width <= 0 || n_rois < 0 || ph <= 0 || pw <= 0)
+        return BRCNN_EINVAL;
+    return 0;
+}
+
+}  // namespace
+
+BRCNN_API int brcnn_roi_align_forward(const float* input, const float* rois, float* output,
+                                      float* argmax_y, float* argmax_x, int batch, int channels,
+                                      int height, int width, int n_rois, int pooled_h,
+                                      int pooled_w, float spatial_scale, int sampling_ratio,
+                                      int pool_mode, int aligned, int layout, void* stream) {
+    if (check_common(batch, channels, height, width, n_rois, pooled_h, pooled_w)) return BRCNN_EINVAL;
+    if (pool_mode != 0 && pool_mode != 1) return BRCNN_EINVAL;
+    if (n_rois == 0) return 0;
+    if (!input || !rois || !output) return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)n_rois * channels * pooled_h * pooled_w;
+    if (layout == BRCNN_LAYOUT_NHWC) {
+        if (pool_mode != 1 || (channels & 3)) return BRCNN_EINVAL;
+        LevelTable lv = {};
+        const long long bins = (long long)n_rois * pooled_h * pooled_w;
+        hipLaunchKernelGGL(roi_align_fwd_nhwc_kernel<false>, dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                           s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
+                           n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
+    } else if (layout == BRCNN_LAYOUT_NCHW) {
+        if (pool_mode == 0 && (!argmax_y || !argmax_x)) return BRCNN_EINVAL;
+        int grid = brcnn_cdiv(total, 256);
+        if (grid > 65536) grid = 65536;
+        hipLaunchKernelGGL(roi_align_fwd_nchw_kernel, dim3(grid), dim3(256), 0, s, input, rois,
+                           output, argmax_y, argmax_x, total, channels, height, width, pooled_h,
+                           pooled_w, spatial_scale, sampling_ratio, pool_mode, aligned);
+    } else {
+        return BRCNN_EINVAL;
+    }
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_roi_align_backward(const float* grad_output, const float* rois,
+                                       float* grad_input, int batch, int channels, int height,
+                                       int width, int n_rois, int pooled_h, int pooled_w,
+                                       float spatial_scale, int sampling_ratio, int aligned,
+                                       int layout, void* stream) {
+    if (check_common(batch, channels, height, width, n_rois, pooled_h, pooled_w)) return BRCNN_EINVAL;
+    if (n_rois == 0) return 0;
+    if (!grad_output || !rois || !grad_input) return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)n_rois * channels * pooled_h * pooled_w;
+    if (layout == BRCNN_LAYOUT_NHWC) {
+        LevelTable lv = {};
+        const long long bins = (long long)n_rois * pooled_h * pooled_w;
+        hipLaunchKernelGGL(roi_align_bwd_nhwc_kernel<false>, dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                           s, grad_output, lv, rois, grad_input, channels, height, width, n_rois,
+                           pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
+    } else if (layout == BRCNN_LAYOUT_NCHW) {
+        int grid = brcnn_cdiv(total, 256);
+        if (grid > 65536) grid = 65536;
+        hipLaunchKernelGGL(roi_align_bwd_nchw_kernel, dim3(grid), dim3(256), 0, s, grad_output, rois,
+                           grad_input, total, channels, height, width, pooled_h, pooled_w,
+                           spatial_scale, sampling_ratio, aligned);
+    } else {
+        return BRCNN_EINVAL;
+    }
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fill_levels(LevelTable& lv, const float* const* feats, float* const* gfeats,
+                       const int* heights, const int* widths, const float* scales, int num_levels,
+                       float finest_scale) {
+    if (num_levels <= 0 || num_levels > BRCNN_MAX_LEVELS || !heights || !widths || !scales)
+        return BRCNN_EINVAL;
+    lv.num_levels = num_levels;
+    lv.finest_scale = finest_scale;
+    for (int l = 0; l < num_levels; l++) {
+        lv.feat[l] = feats ? feats[l] : nullptr;
+        lv.gfeat[l] = gfeats ? gfeats[l] : nullptr;
+        lv.height[l] = heights[l];
+        lv.width[l] = widths[l];
+        lv.scale[l] = scales[l];
+        if (heights[l] <= 0 || widths[l] <= 0) return BRCNN_EINVAL;
+    }
+    return 0;
+}
+
+BRCNN_API int brcnn_roi_extract_forward(const float* const* feats_host, const int* heights_host,
+                                        const int* widths_host, const float* scales_host,
+                                        int num_levels, const float* rois, float* output,
+                                        int32_t* levels_out, int batch, int channels, int n_rois,
+                                        int pooled_h, int pooled_w, int sampling_ratio,
+                                        float finest_scale, void* stream) {
+    if (!feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
+        return BRCNN_EINVAL;
+    LevelTable lv = {};
+    if (fill_levels(lv, feats_host, nullptr, heights_host, widths_host, scales_host, num_levels,
+                    finest_scale))
+        return BRCNN_EINVAL;
+    if (n_rois == 0) return 0;
+    if (!rois || !output) return BRCNN_EINVAL;
+    const long long bins = (long long)n_rois * pooled_h * pooled_w;
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_kernel<true>, dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)nullptr, lv, rois, output, levels_out,
+                       channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_roi_extract_backward(float* const* grad_feats_host, const int* heights_host,
+                                         const int* widths_host, const float* scales_host,
+                                         int num_levels, const float* rois,
+                                         const float* grad_output, int batch, int channels,
+                                         int n_rois, int pooled_h, int pooled_w,
+                                         int sampling_ratio, float finest_scale, void* stream) {
+    if (!grad_feats_host || channels <= 0 || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
+        return BRCNN_EINVAL;
+    LevelTable lv = {};
+    if (fill_levels(lv, nullptr, grad_feats_host, heights_host, widths_host, scales_host,
+                    num_levels, finest_scale))
+        return BRCNN_EINVAL;
+    if (n_rois == 0) return 0;
+    if (!rois || !grad_output) return BRCNN_EINVAL;
+    const long long bins = (long long)n_rois * pooled_h * pooled_w;
+    hipLaunchKernelGGL(roi_align_bwd_nhwc_kernel<true>, dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                       (hipStream_t)stream, grad_output, lv, rois, (float*)nullptr, channels, 0, 0,
+                       n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,116 @@
+// RetinaRPN proposal stage kernels (ATSSRPNHead._get_bboxes_single,
+// mmdet/models/dense_heads/atss_rpn_head.py:688-760).
+//
+//   rpn_score : score = sqrt(sigmoid(cls) * sigmoid(iou))       (:712-725)   HBM stream
+//   rpn_decode: anchors regenerated on the fly (AnchorGenerator.single_level_grid_anchors,
+//               mmdet/core/anchor/anchor_generator.py:336-381: base_anchor + (x*stride_w,
+//               y*stride_h), row-major cells, A anchors contiguous per cell) -- the 201 600 x 4
+//               anchor tensor is never materialised -- then delta2bbox
+//               (mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:145-272) with the reference's
+//               operation order (no FMA contraction), border clip to [0,W]x[0,H], and the
+//               min_bbox_size validity flag (:747-754).
+// Head outputs are NHWC: cls/iou (N,H,W,A), bbox_pred (N,H,W,4A) == the reference's
+// permute(1,2,0).reshape(-1[,4]) order, so the flat anchor index is the same.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void rpn_score_kernel(const float* __restrict__ cls,
+                                                       const float* __restrict__ iou,
+                                                       float* __restrict__ score, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float a = 1.f / (1.f + expf(-cls[i]));
+        const float b = 1.f / (1.f + expf(-iou[i]));
+        score[i] = sqrtf(a * b);
+    }
+}
+
+struct DecodeParams {
+    float mean[4], std[4];
+    float max_ratio, max_h, max_w, min_size;
+    int clip;
+};
+
+// inds: (batch, count) flat anchor indices of one level; bbox_pred: (batch, H*W*A, 4)
+__global__ __launch_bounds__(256) void rpn_decode_kernel(
+    const int64_t* __restrict__ inds, const float* __restrict__ bbox_pred,
+    const float* __restrict__ base_anchors, int batch, int count, int hwA, int width, int A,
+    int stride_w, int stride_h, DecodeParams dp, float* __restrict__ proposals,
+    uint8_t* __restrict__ valid) {
+    const long long total = (long long)batch * count;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / count);
+        const long long idx = inds[t];
+        const int a = (int)(idx % A);
+        const long long cell = idx / A;
+        const int cx = (int)(cell % width), cy = (int)(cell / width);
+        const float sx = (float)(cx * stride_w), sy = (float)(cy * stride_h);
+        const float4 ba = *reinterpret_cast<const float4*>(base_anchors + a * 4);
+        const float x1 = ba.x + sx, y1 = ba.y + sy, x2 = ba.z + sx, y2 = ba.w + sy;
+        const float4 d = *reinterpret_cast<const float4*>(bbox_pred + ((size_t)b * hwA + idx) * 4);
+        const float dx = d.x * dp.std[0] + dp.mean[0];
+        const float dy = d.y * dp.std[1] + dp.mean[1];
+        float dw = d.z * dp.std[2] + dp.mean[2];
+        float dh = d.w * dp.std[3] + dp.mean[3];
+        const float px = (x1 + x2) * 0.5f, py = (y1 + y2) * 0.5f;
+        const float pw = x2 - x1, ph = y2 - y1;
+        const float dxw = pw * dx, dyh = ph * dy;
+        dw = fminf(fmaxf(dw, -dp.max_ratio), dp.max_ratio);
+        dh = fminf(fmaxf(dh, -dp.max_ratio), dp.max_ratio);
+        const float gw = pw * expf(dw), gh = ph * expf(dh);
+        const float gx = px + dxw, gy = py + dyh;
+        float ox1 = gx - gw * 0.5f, oy1 = gy - gh * 0.5f;
+        float ox2 = gx + gw * 0.5f, oy2 = gy + gh * 0.5f;
+        if (dp.clip) {
+            ox1 = ox1 < 0.f ? 0.f : ox1; ox1 = ox1 > dp.max_w ? dp.max_w : ox1;
+            oy1 = oy1 < 0.f ? 0.f : oy1; oy1 = oy1 > dp.max_h ? dp.max_h : oy1;
+            ox2 = ox2 < 0.f ? 0.f : ox2; ox2 = ox2 > dp.max_w ? dp.max_w : ox2;
+            oy2 = oy2 < 0.f ? 0.f : oy2; oy2 = oy2 > dp.max_h ? dp.max_h : oy2;
+        }
+        *reinterpret_cast<float4*>(proposals + (size_t)t * 4) = make_float4(ox1, oy1, ox2, oy2);
+        if (valid) valid[t] = ((ox2 - ox1) > dp.min_size && (oy2 - oy1) > dp.min_size) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+BRCNN_API int brcnn_rpn_score(const float* cls, const float* iou, float* score, int64_t n,
+                              void* stream) {
+    if (n < 0) return BRCNN_EINVAL;
+    if (n == 0) return 0;
+    if (!cls || !iou || !score) return BRCNN_EINVAL;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rpn_score_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, cls, iou,
+                       score, (long long)n);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
+                               const float* base_anchors, int batch, int count, int height,
+                               int width, int num_anchors, int stride_w, int stride_h,
+                               const float* means4_host, const float* stds4_host,
+                               double wh_ratio_clip, float max_h, float max_w, float min_size,
+                               float* proposals, uint8_t* valid, void* stream) {
+    if (batch < 0 || count < 0 || height <= 0 || width <= 0 || num_anchors <= 0 ||
+        !means4_host || !stds4_host || !(wh_ratio_clip > 0.0))
+        return BRCNN_EINVAL;
+    if (batch == 0 || count == 0) return 0;
+    if (!topk_inds || !bbox_pred || !base_anchors || !proposals) return BRCNN_EINVAL;
+    DecodeParams dp;
+    for (int i = 0; i < 4; i++) { dp.mean[i] = means4_host[i]; dp.std[i] = stds4_host[i]; }
+    dp.max_ratio = (float)fabs(log(wh_ratio_clip));
+    dp.clip = (max_h > 0.f && max_w > 0.f) ? 1 : 0;
+    dp.max_h = max_h; dp.max_w = max_w; dp.min_size = min_size;
+    const long long total = (long long)batch * count;
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
+                       topk_inds, bbox_pred, base_anchors, batch, count, height * width * num_anchors,
+                       width, num_anchors, stride_w, stride_h, dp, proposals, valid);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,79 @@
+"""ctypes binding of libbrcnn_hip.so (the C ABI declared in include/brcnn_hip.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  `load()` raises
+if the shared object is missing or does not load, `check()` raises on a non-zero status,
+and every wrapper in `ops.py` refuses tensors that are not on a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libbrcnn_hip.so')
+_lib = None
+
+c_int, c_i64, c_f32, c_f64, c_ptr, c_size = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                             ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t)
+
+# name -> (restype, argtypes); must list every symbol include/brcnn_hip.h declares
+SIGNATURES = {
+    'brcnn_version': (c_int, []),
+    'brcnn_device_count': (c_int, []),
+    'brcnn_roi_align_forward': (c_int, [c_ptr] * 5 + [c_int] * 7 + [c_f32] + [c_int] * 4 + [c_ptr]),
+    'brcnn_roi_align_backward': (c_int, [c_ptr] * 3 + [c_int] * 7 + [c_f32] + [c_int] * 3 + [c_ptr]),
+    'brcnn_roi_extract_forward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
+                                  [c_f32, c_ptr]),
+    'brcnn_roi_extract_backward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 +
+                                   [c_f32, c_ptr]),
+    'brcnn_nms_workspace_bytes': (c_size, [c_i64, c_int, c_i64]),
+    'brcnn_nms': (c_int, [c_ptr] * 3 + [c_int, c_i64, c_i64, c_f32, c_int, c_int, c_ptr, c_ptr,
+                                        c_ptr, c_size, c_ptr]),
+    'brcnn_softnms_workspace_bytes': (c_size, [c_i64, c_int]),
+    'brcnn_softnms': (c_int, [c_ptr] * 3 + [c_int, c_i64, c_f32, c_f32, c_f32, c_int, c_int,
+                                            c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'brcnn_sigmoid_focal_loss_forward': (c_int, [c_ptr] * 4 + [c_i64, c_i64, c_f32, c_f32, c_ptr]),
+    'brcnn_sigmoid_focal_loss_backward': (c_int, [c_ptr] * 4 + [c_i64, c_i64, c_f32, c_f32, c_ptr]),
+    'brcnn_conv2d_nhwc': (c_int, [c_ptr] * 6 + [c_int] * 11 + [c_ptr]),
+    'brcnn_maxpool3x3s2_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 5 + [c_ptr]),
+    'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
+    'brcnn_upsample_nearest_add_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 7 + [c_ptr]),
+    'brcnn_nchw_to_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
+    'brcnn_nhwc_to_nchw': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
+    'brcnn_rpn_score': (c_int, [c_ptr] * 3 + [c_i64, c_ptr]),
+    'brcnn_rpn_decode': (c_int, [c_ptr] * 3 + [c_int] * 7 + [c_ptr, c_ptr, c_f64, c_f32, c_f32,
+                                                             c_f32, c_ptr, c_ptr, c_ptr]),
+}
+
+
+class BrcnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BrcnnHipError(
+            f'{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or '
+            f'`python boosting-r-cnn_amd/build.py`); the HIP library is the product path and '
+            f'there is no CPU fallback')
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise BrcnnHipError(f'cannot load {LIB_PATH}: {e}')
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        if status == -22:
+            raise BrcnnHipError(f'{what}: invalid argument (status -22)')
+        if status <= -1000:
+            raise BrcnnHipError(f'{what}: HIP error {-status - 1000}')
+        raise BrcnnHipError(f'{what}: status {status}')

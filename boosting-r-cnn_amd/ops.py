@@ -1,0 +1,511 @@
+"""Operator seam: the `mmcv.ops` Python API the reference calls, served by libbrcnn_hip.so.
+
+Same names, argument meaning and error behaviour as mmcv 1.4.0's `RoIAlign / roi_align`,
+`nms`, `batched_nms`, `soft_nms`, `sigmoid_focal_loss` (reference call sites:
+roi_extractors/base_roi_extractor.py:54-60, single_level_roi_extractor.py:103,
+atss_rpn_head.py:756, core/post_processing/bbox_nms.py:86, losses/focal_loss.py:86), plus
+the conv-stack / RPN entry points that have no mmcv counterpart.
+
+Every function takes tensors that live on a HIP device and enqueues on torch's current
+stream.  There is no CPU path: CPU tensors raise.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib as _L
+
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+DT_F32, DT_BF16 = 0, 1
+
+
+# ----------------------------------------------------------------------------- helpers
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _L.BrcnnHipError(
+                'brcnn.ops run on the HIP device only (got a CPU tensor); there is no CPU fallback')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _pair(x):
+    if isinstance(x, int):
+        return (x, x)
+    assert len(x) == 2
+    return (int(x[0]), int(x[1]))
+
+
+def _is_nhwc(t):
+    """logical (N,C,H,W) tensor whose memory is (N,H,W,C) and not also plain-contiguous"""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and \
+        not t.is_contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------- RoIAlign
+class RoIAlignFunction(Function):
+    @staticmethod
+    def forward(ctx, input, rois, output_size, spatial_scale=1.0, sampling_ratio=0,
+                pool_mode='avg', aligned=True):
+        _require_gpu(input, rois)
+        ctx.output_size = _pair(output_size)
+        ctx.spatial_scale = float(spatial_scale)
+        ctx.sampling_ratio = int(sampling_ratio)
+        assert pool_mode in ('max', 'avg')
+        ctx.pool_mode = 0 if pool_mode == 'max' else 1
+        ctx.aligned = bool(aligned)
+        ctx.input_shape = input.size()
+        assert rois.size(1) == 5, 'RoI must be (idx, x1, y1, x2, y2)!'
+        assert input.dtype == torch.float32, 'roi_align: fp32 features expected'
+        rois = rois.contiguous().float()
+        n, c, h, w = input.shape
+        k = rois.size(0)
+        ph, pw = ctx.output_size
+        nhwc = _is_nhwc(input) and ctx.pool_mode == 1 and c % 4 == 0
+        ctx.nhwc = nhwc
+        if nhwc:
+            output = torch.zeros((k, c, ph, pw), dtype=input.dtype, device=input.device).contiguous(
+                memory_format=torch.channels_last)
+            x = input
+        else:
+            output = input.new_zeros((k, c, ph, pw))
+            x = input.contiguous()
+        argmax_y = argmax_x = None
+        if ctx.pool_mode == 0:
+            argmax_y = input.new_zeros(output.shape)
+            argmax_x = input.new_zeros(output.shape)
+        st = _L.load().brcnn_roi_align_forward(
+            _ptr(x), _ptr(rois), _ptr(output), _ptr(argmax_y), _ptr(argmax_x), n, c, h, w, k, ph,
+            pw, ctx.spatial_scale, ctx.sampling_ratio, ctx.pool_mode, int(ctx.aligned),
+            LAYOUT_NHWC if nhwc else LAYOUT_NCHW, _stream())
+        _L.check(st, 'brcnn_roi_align_forward')
+        ctx.save_for_backward(rois)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        if ctx.pool_mode != 1:
+            raise NotImplementedError('roi_align backward: avg pooling only on this path')
+        n, c, h, w = ctx.input_shape
+        ph, pw = ctx.output_size
+        if ctx.nhwc:
+            g = grad_output.contiguous(memory_format=torch.channels_last)
+            grad_input = torch.zeros((n, c, h, w), dtype=g.dtype, device=g.device).contiguous(
+                memory_format=torch.channels_last)
+        else:
+            g = grad_output.contiguous()
+            grad_input = g.new_zeros((n, c, h, w))
+        st = _L.load().brcnn_roi_align_backward(
+            _ptr(g), _ptr(rois), _ptr(grad_input), n, c, h, w, rois.size(0), ph, pw,
+            ctx.spatial_scale, ctx.sampling_ratio, int(ctx.aligned),
+            LAYOUT_NHWC if ctx.nhwc else LAYOUT_NCHW, _stream())
+        _L.check(st, 'brcnn_roi_align_backward')
+        return grad_input, None, None, None, None, None, None
+
+
+roi_align = RoIAlignFunction.apply
+
+
+class RoIAlign(nn.Module):
+    """mmcv.ops.RoIAlign: RoIAlign(output_size, spatial_scale=1.0, sampling_ratio=0,
+    pool_mode='avg', aligned=True, use_torchvision=False); forward(input (N,C,H,W),
+    rois (K,5)) -> (K,C,ph,pw).  A channels_last input selects the NHWC kernel and yields a
+    channels_last output (same logical shape, same values)."""
+
+    def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg',
+                 aligned=True, use_torchvision=False):
+        super().__init__()
+        self.output_size = _pair(output_size)
+        self.spatial_scale = float(spatial_scale)
+        self.sampling_ratio = int(sampling_ratio)
+        self.pool_mode = pool_mode
+        self.aligned = aligned
+        self.use_torchvision = use_torchvision
+
+    def forward(self, input, rois):
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio,
+                         self.pool_mode, self.aligned)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(output_size={self.output_size}, '
+                f'spatial_scale={self.spatial_scale}, sampling_ratio={self.sampling_ratio}, '
+                f'pool_mode={self.pool_mode}, aligned={self.aligned}, '
+                f'use_torchvision={self.use_torchvision})')
+
+
+def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56, sampling_ratio=0):
+    """Fused SingleRoIExtractor.forward (single_level_roi_extractor.py:57-115): level mapping
+    + RoIAlign of every RoI on its own level in one launch.  `feats_nhwc`: list of (N,H,W,C)
+    contiguous fp32 tensors.  Returns ((K,ph,pw,C) features, (K,) int32 levels)."""
+    _require_gpu(rois, *feats_nhwc)
+    import ctypes
+    L = len(feats_nhwc)
+    n, _, _, c = feats_nhwc[0].shape
+    ph, pw = _pair(output_size)
+    rois = rois.contiguous().float()
+    k = rois.size(0)
+    out = torch.empty((k, ph, pw, c), dtype=torch.float32, device=rois.device)
+    levels = torch.empty((k,), dtype=torch.int32, device=rois.device)
+    for f in feats_nhwc:
+        assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[0] == n and f.shape[3] == c
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats_nhwc])
+    hs = (ctypes.c_int * L)(*[f.shape[1] for f in feats_nhwc])
+    ws = (ctypes.c_int * L)(*[f.shape[2] for f in feats_nhwc])
+    sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
+    st = _L.load().brcnn_roi_extract_forward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out),
+                                             _ptr(levels), n, c, k, ph, pw, int(sampling_ratio),
+                                             float(finest_scale), _stream())
+    _L.check(st, 'brcnn_roi_extract_forward')
+    return out, levels
+
+
+# ----------------------------------------------------------------------------- NMS
+def nms_segments(boxes, scores, seg_offsets, max_segment_len, iou_threshold, offset=0,
+                 max_keep=-1):
+    """Segmented greedy NMS, no host sync.  Returns (keep (n,) int64, num_keep (S,) int32):
+    segment s's survivors (global indices, score order) sit at keep[seg_offsets[s]:][:num_keep[s]]."""
+    _require_gpu(boxes, scores, seg_offsets)
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    seg_offsets = seg_offsets.contiguous().to(torch.int32)
+    n = boxes.size(0)
+    S = seg_offsets.numel() - 1
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=boxes.device)
+    num_keep = torch.zeros((S,), dtype=torch.int32, device=boxes.device)
+    if n == 0:
+        return keep[:0], num_keep
+    lib = _L.load()
+    max_segment_len = max(1, min(int(max_segment_len), n))
+    wsb = lib.brcnn_nms_workspace_bytes(n, S, max_segment_len)
+    ws = _ws(wsb, boxes.device)
+    st = lib.brcnn_nms(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), S, n, max_segment_len,
+                       float(iou_threshold), int(offset), int(max_keep), _ptr(keep),
+                       _ptr(num_keep), _ptr(ws), wsb, _stream())
+    _L.check(st, 'brcnn_nms')
+    return keep, num_keep
+
+
+def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
+    """mmcv.ops.nms: returns (dets (k,5), inds (k,) int64), score-descending."""
+    assert isinstance(boxes, torch.Tensor) and isinstance(scores, torch.Tensor)
+    assert boxes.size(1) == 4
+    assert boxes.size(0) == scores.size(0)
+    assert offset in (0, 1)
+    _require_gpu(boxes, scores)
+    b, s = boxes, scores
+    valid_inds = None
+    if score_threshold > 0:
+        valid_mask = scores > score_threshold
+        b, s = boxes[valid_mask], scores[valid_mask]
+        valid_inds = torch.nonzero(valid_mask, as_tuple=False).squeeze(dim=1)
+    n = b.size(0)
+    if n == 0:
+        inds = torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    else:
+        seg = torch.tensor([0, n], dtype=torch.int32, device=boxes.device)
+        keep, num_keep = nms_segments(b, s, seg, n, iou_threshold, offset, max_num)
+        inds = keep[:int(num_keep.item())]
+    if max_num > 0:
+        inds = inds[:max_num]
+    if valid_inds is not None:
+        inds = valid_inds[inds]
+    dets = torch.cat((boxes[inds], scores[inds].reshape(-1, 1)), dim=1)
+    return dets, inds
+
+
+def soft_nms_segments(boxes, scores, seg_offsets, iou_threshold=0.3, sigma=0.5, min_score=1e-3,
+                      method=1, offset=0):
+    """Segmented soft-NMS, no host sync: (dets (n,5), inds (n,) int64, num_keep (S,) int32)."""
+    _require_gpu(boxes, scores, seg_offsets)
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    seg_offsets = seg_offsets.contiguous().to(torch.int32)
+    n, S = boxes.size(0), seg_offsets.numel() - 1
+    dets = torch.zeros((max(n, 1), 5), dtype=torch.float32, device=boxes.device)
+    inds = torch.zeros((max(n, 1),), dtype=torch.int64, device=boxes.device)
+    num_keep = torch.zeros((S,), dtype=torch.int32, device=boxes.device)
+    if n == 0:
+        return dets[:0], inds[:0], num_keep
+    lib = _L.load()
+    wsb = lib.brcnn_softnms_workspace_bytes(n, S)
+    ws = _ws(wsb, boxes.device)
+    st = lib.brcnn_softnms(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), S, n,
+                           float(iou_threshold), float(sigma), float(min_score), int(method),
+                           int(offset), _ptr(dets), _ptr(inds), _ptr(num_keep), _ptr(ws), wsb,
+                           _stream())
+    _L.check(st, 'brcnn_softnms')
+    return dets, inds, num_keep
+
+
+def soft_nms(boxes, scores, iou_threshold=0.3, sigma=0.5, min_score=1e-3, method='linear',
+             offset=0):
+    """mmcv.ops.soft_nms: returns (dets (k,5) with decayed scores, inds (k,)) in pick order.
+    (mmcv copies to the host and runs softnms_cpu; here the chain runs on the device.)"""
+    assert isinstance(boxes, torch.Tensor) and isinstance(scores, torch.Tensor)
+    assert boxes.size(1) == 4
+    assert boxes.size(0) == scores.size(0)
+    assert offset in (0, 1)
+    method_dict = {'naive': 0, 'linear': 1, 'gaussian': 2}
+    assert method in method_dict.keys()
+    _require_gpu(boxes, scores)
+    n = boxes.size(0)
+    if n == 0:
+        return boxes.new_zeros((0, 5)), torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    seg = torch.tensor([0, n], dtype=torch.int32, device=boxes.device)
+    dets, inds, num_keep = soft_nms_segments(boxes, scores, seg, iou_threshold, sigma, min_score,
+                                             method_dict[method], offset)
+    k = int(num_keep.item())
+    return dets[:k], inds[:k]
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    """mmcv.ops.batched_nms (Python logic restated from mmcv 1.4.0): coordinate-offset trick
+    below `split_thr` (default 10000) boxes, per-id NMS + re-sort above.  The per-id loop of
+    the reference becomes ONE segmented launch (ids -> segments)."""
+    nms_cfg_ = dict(nms_cfg)
+    class_agnostic = nms_cfg_.pop('class_agnostic', class_agnostic)
+    if class_agnostic:
+        boxes_for_nms = boxes
+    else:
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        boxes_for_nms = boxes + offsets[:, None]
+    nms_type = nms_cfg_.pop('type', 'nms')
+    if nms_type not in ('nms', 'soft_nms'):
+        raise KeyError(f'unsupported nms type {nms_type}')
+    nms_op = nms if nms_type == 'nms' else soft_nms
+    split_thr = nms_cfg_.pop('split_thr', 10000)
+    if boxes_for_nms.shape[0] < split_thr:
+        dets, keep = nms_op(boxes_for_nms, scores, **nms_cfg_)
+        boxes = boxes[keep]
+        scores = dets[:, 4]
+    else:
+        max_num = nms_cfg_.pop('max_num', -1)
+        # group by id: stable sort of ids keeps the original order inside a group
+        order = torch.sort(idxs, stable=True)[1]
+        ids_sorted = idxs[order]
+        uniq, counts = torch.unique_consecutive(ids_sorted, return_counts=True)
+        seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32, device=boxes.device)
+        seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        b_sorted, s_sorted = boxes_for_nms[order], scores[order]
+        max_len = int(counts.max().item())
+        total_mask = scores.new_zeros(scores.size(), dtype=torch.bool)
+        scores_after_nms = scores.new_zeros(scores.size())
+        if nms_type == 'nms':
+            keep_buf, num_keep = nms_segments(b_sorted, s_sorted, seg, max_len,
+                                              nms_cfg_.get('iou_threshold'),
+                                              nms_cfg_.get('offset', 0), -1)
+            pos = torch.arange(b_sorted.size(0), device=boxes.device)
+            seg_id = torch.repeat_interleave(torch.arange(uniq.numel(), device=boxes.device), counts)
+            valid = (pos - seg[:-1].long()[seg_id]) < num_keep.long()[seg_id]
+            kept_sorted = keep_buf[valid]
+            kept = order[kept_sorted]
+            total_mask[kept] = True
+            scores_after_nms[kept] = scores[kept]
+        else:
+            method = {'naive': 0, 'linear': 1, 'gaussian': 2}[nms_cfg_.get('method', 'linear')]
+            dets, inds, num_keep = soft_nms_segments(
+                b_sorted, s_sorted, seg, nms_cfg_.get('iou_threshold', 0.3),
+                nms_cfg_.get('sigma', 0.5), nms_cfg_.get('min_score', 1e-3), method,
+                nms_cfg_.get('offset', 0))
+            pos = torch.arange(b_sorted.size(0), device=boxes.device)
+            seg_id = torch.repeat_interleave(torch.arange(uniq.numel(), device=boxes.device), counts)
+            valid = (pos - seg[:-1].long()[seg_id]) < num_keep.long()[seg_id]
+            kept = order[inds[valid]]
+            total_mask[kept] = True
+            scores_after_nms[kept] = dets[valid, 4]
+        keep = total_mask.nonzero(as_tuple=False).view(-1)
+        scores, inds = scores_after_nms[keep].sort(descending=True, stable=True)
+        keep = keep[inds]
+        boxes = boxes[keep]
+        if max_num > 0:
+            keep = keep[:max_num]
+            boxes = boxes[:max_num]
+            scores = scores[:max_num]
+    return torch.cat([boxes, scores[:, None]], -1), keep
+
+
+# ----------------------------------------------------------------------------- focal loss
+class SigmoidFocalLossFunction(Function):
+    @staticmethod
+    def forward(ctx, input, target, gamma=2.0, alpha=0.25, weight=None, reduction='mean'):
+        _require_gpu(input, target, weight)
+        assert isinstance(target, (torch.LongTensor, torch.cuda.LongTensor))
+        assert input.dim() == 2
+        assert target.dim() == 1
+        assert input.size(0) == target.size(0)
+        if weight is None:
+            weight = input.new_empty(0)
+        else:
+            assert weight.dim() == 1
+            assert input.size(1) == weight.size(0)
+        ctx.reduction_dict = {'none': 0, 'mean': 1, 'sum': 2}
+        assert reduction in ctx.reduction_dict.keys()
+        ctx.gamma = float(gamma)
+        ctx.alpha = float(alpha)
+        ctx.reduction = ctx.reduction_dict[reduction]
+        input = input.contiguous().float()
+        target = target.contiguous()
+        output = input.new_zeros(input.size())
+        w = weight.contiguous().float() if weight.numel() > 0 else None
+        st = _L.load().brcnn_sigmoid_focal_loss_forward(
+            _ptr(input), _ptr(target), _ptr(w), _ptr(output), input.size(0), input.size(1),
+            ctx.gamma, ctx.alpha, _stream())
+        _L.check(st, 'brcnn_sigmoid_focal_loss_forward')
+        if ctx.reduction == ctx.reduction_dict['mean']:
+            output = output.sum() / input.size(0)
+        elif ctx.reduction == ctx.reduction_dict['sum']:
+            output = output.sum()
+        ctx.save_for_backward(input, target, weight)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, target, weight = ctx.saved_tensors
+        grad_input = input.new_zeros(input.size())
+        w = weight.contiguous().float() if weight.numel() > 0 else None
+        st = _L.load().brcnn_sigmoid_focal_loss_backward(
+            _ptr(input), _ptr(target), _ptr(w), _ptr(grad_input), input.size(0), input.size(1),
+            ctx.gamma, ctx.alpha, _stream())
+        _L.check(st, 'brcnn_sigmoid_focal_loss_backward')
+        grad_input *= grad_output
+        if ctx.reduction == ctx.reduction_dict['mean']:
+            grad_input /= input.size(0)
+        return grad_input, None, None, None, None, None
+
+
+sigmoid_focal_loss = SigmoidFocalLossFunction.apply
+
+
+# ----------------------------------------------------------------------------- conv stack
+def conv_out_size(h, w, kh, kw, stride, pad):
+    return (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+
+
+def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+    """y = act(conv(x, w) * scale + shift + residual); x (N,H,W,Cin), w (Cout,KH,KW,Cin),
+    y (N,Ho,Wo,Cout), all contiguous fp32 on the device."""
+    _require_gpu(x, w, scale, shift, residual)
+    assert x.dim() == 4 and w.dim() == 4 and x.is_contiguous() and w.is_contiguous()
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    n, h, wd, cin = x.shape
+    cout, kh, kw, cin2 = w.shape
+    assert cin == cin2, f'conv2d_nhwc: Cin mismatch {cin} vs {cin2}'
+    ho, wo = conv_out_size(h, wd, kh, kw, stride, pad)
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.is_contiguous()
+    st = _L.load().brcnn_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual),
+                                     _ptr(y), n, h, wd, cin, cout, kh, kw, int(stride), int(pad),
+                                     int(bool(relu)), DT_F32, _stream())
+    _L.check(st, 'brcnn_conv2d_nhwc')
+    return y
+
+
+def linear_nhwc(x, w, bias=None, relu=False):
+    """x (M,K) @ w (N,K)^T + bias: the 1x1 case of the implicit GEMM with H=W=1."""
+    m, k = x.shape
+    y = conv2d_nhwc(x.reshape(m, 1, 1, k), w.reshape(w.shape[0], 1, 1, k), None, bias, None, relu)
+    return y.reshape(m, w.shape[0])
+
+
+def maxpool3x3s2_nhwc(x):
+    _require_gpu(x)
+    n, h, w, c = x.shape
+    ho, wo = conv_out_size(h, w, 3, 3, 2, 1)
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    st = _L.load().brcnn_maxpool3x3s2_nhwc(_ptr(x), _ptr(y), n, h, w, c, DT_F32, _stream())
+    _L.check(st, 'brcnn_maxpool3x3s2_nhwc')
+    return y
+
+
+def groupnorm_nhwc(x, gamma, beta, groups, eps=1e-5, relu=False):
+    _require_gpu(x, gamma, beta)
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty((n * groups * 2,), dtype=torch.float64, device=x.device)
+    st = _L.load().brcnn_groupnorm_nhwc(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(ws), n,
+                                        h * w, c, int(groups), float(eps), int(bool(relu)), DT_F32,
+                                        _stream())
+    _L.check(st, 'brcnn_groupnorm_nhwc')
+    return y
+
+
+def upsample_nearest_add_nhwc_(dst, src):
+    """dst += nearest_upsample(src, size=dst.shape[1:3]) in place (FPN top-down step)."""
+    _require_gpu(dst, src)
+    n, hd, wd, c = dst.shape
+    _, hs, ws_, _ = src.shape
+    st = _L.load().brcnn_upsample_nearest_add_nhwc(_ptr(dst), _ptr(src), n, hd, wd, hs, ws_, c,
+                                                   DT_F32, _stream())
+    _L.check(st, 'brcnn_upsample_nearest_add_nhwc')
+    return dst
+
+
+def nchw_to_nhwc(x):
+    _require_gpu(x)
+    n, c, h, w = x.shape
+    x = x.contiguous().float()
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    st = _L.load().brcnn_nchw_to_nhwc(_ptr(x), _ptr(y), n, c, h * w, DT_F32, _stream())
+    _L.check(st, 'brcnn_nchw_to_nhwc')
+    return y
+
+
+def nhwc_to_nchw(x):
+    _require_gpu(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    st = _L.load().brcnn_nhwc_to_nchw(_ptr(x.contiguous()), _ptr(y), n, c, h * w, DT_F32, _stream())
+    _L.check(st, 'brcnn_nhwc_to_nchw')
+    return y
+
+
+# ----------------------------------------------------------------------------- RPN stage
+def rpn_score(cls, iou):
+    """sqrt(sigmoid(cls) * sigmoid(iou)) element-wise (atss_rpn_head.py:712-725)."""
+    _require_gpu(cls, iou)
+    cls, iou = cls.contiguous(), iou.contiguous()
+    out = torch.empty_like(cls)
+    st = _L.load().brcnn_rpn_score(_ptr(cls), _ptr(iou), _ptr(out), cls.numel(), _stream())
+    _L.check(st, 'brcnn_rpn_score')
+    return out
+
+
+def rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds, max_shape,
+               min_size, wh_ratio_clip=16 / 1000):
+    """topk_inds (B,k) int64 flat anchor indices of one level; bbox_pred (B,H,W,4A) NHWC.
+    Returns (proposals (B,k,4), valid (B,k) uint8)."""
+    import ctypes
+    _require_gpu(topk_inds, bbox_pred, base_anchors)
+    b, k = topk_inds.shape
+    h, w = feat_hw
+    a = base_anchors.size(0)
+    props = torch.empty((b, k, 4), dtype=torch.float32, device=bbox_pred.device)
+    valid = torch.empty((b, k), dtype=torch.uint8, device=bbox_pred.device)
+    m4 = (ctypes.c_float * 4)(*[float(v) for v in means])
+    s4 = (ctypes.c_float * 4)(*[float(v) for v in stds])
+    sw, sh = (stride, stride) if isinstance(stride, int) else stride
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    st = _L.load().brcnn_rpn_decode(_ptr(topk_inds.contiguous()), _ptr(bbox_pred.contiguous()),
+                                    _ptr(base_anchors.contiguous().float()), b, k, h, w, a,
+                                    int(sw), int(sh), m4, s4, float(wh_ratio_clip), mh, mw,
+                                    float(min_size), _ptr(props), _ptr(valid), _stream())
+    _L.check(st, 'brcnn_rpn_decode')
+    return props, valid

@@ -1,0 +1,199 @@
+/*
+ * brcnn_hip.h -- C ABI of libbrcnn_hip.so: the MI355X (gfx950) kernels of the
+ * Boosting R-CNN hot path.
+ *
+ * Conventions (the same the reference's operator seam uses):
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the caller owns and pre-allocates every buffer (mmcv does
+ *     `output = input.new_zeros(...)` before calling its native op);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued on it, nothing synchronises unless stated;
+ *   - return value: 0 on success, -22 (EINVAL) for a rejected argument,
+ *     -(1000 + hipError_t) when a HIP call failed.  No exceptions cross the ABI;
+ *   - thread-safe for calls on distinct streams with distinct workspaces.
+ *
+ * Each entry cites the reference interface it replaces.  The reference tree has
+ * no native code: those interfaces are the `mmcv.ops` Python functions
+ * (mmcv-full 1.4.0, un-vendored) whose call sites are given as
+ * /root/reference file:line.
+ */
+#ifndef BRCNN_HIP_H
+#define BRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRCNN_LAYOUT_NCHW 0 /* (N,C,H,W) contiguous, the reference's layout      */
+#define BRCNN_LAYOUT_NHWC 1 /* (N,H,W,C) contiguous == torch.channels_last       */
+
+#define BRCNN_DT_F32 0
+#define BRCNN_DT_BF16 1
+
+#define BRCNN_MAX_LEVELS 8
+
+/* library / device info -------------------------------------------------------- */
+int brcnn_version(void);
+/* number of HIP devices visible, or a negative status */
+int brcnn_device_count(void);
+
+/* ------------------------------------------------------------------------------
+ * RoIAlign.  Replaces mmcv.ops.roi_align_forward / roi_align_backward, reached at
+ * mmdet/models/roi_heads/roi_extractors/base_roi_extractor.py:54-60 (construction,
+ * `getattr(ops, 'RoIAlign')`) and single_level_roi_extractor.py:103 (call).
+ *   input  (N,C,H,W) logical shape, memory per `layout`
+ *   rois   (K,5) fp32 [batch_index, x1, y1, x2, y2]
+ *   output (K,C,ph,pw) logical shape, memory per `layout` ((K,ph,pw,C) for NHWC)
+ *   pool_mode 0 = max (argmax_y/argmax_x (K,C,ph,pw) required), 1 = avg
+ *   sampling_ratio 0 = adaptive grid ceil(roi_size / pooled_size)
+ * -------------------------------------------------------------------------- */
+int brcnn_roi_align_forward(const float *input, const float *rois, float *output,
+                            float *argmax_y, float *argmax_x, int batch, int channels,
+                            int height, int width, int n_rois, int pooled_h, int pooled_w,
+                            float spatial_scale, int sampling_ratio, int pool_mode, int aligned,
+                            int layout, void *stream);
+
+/* avg-mode backward; grad_input must be zero-filled by the caller. */
+int brcnn_roi_align_backward(const float *grad_output, const float *rois, float *grad_input,
+                             int batch, int channels, int height, int width, int n_rois,
+                             int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                             int aligned, int layout, void *stream);
+
+/* Fused SingleRoIExtractor.forward (single_level_roi_extractor.py:57-115 with
+ * map_roi_levels :36-55): every RoI picks its pyramid level
+ * clamp(floor(log2(sqrt(w*h)/finest_scale + 1e-6)), 0, L-1) in-kernel and is
+ * pooled from that level's map; NHWC only, avg, aligned.
+ *   feats[l]  (N,H_l,W_l,C) device pointers (host array of L pointers)
+ *   output    (K,ph,pw,C)
+ *   levels_out optional (K) int32: the level each RoI was mapped to */
+int brcnn_roi_extract_forward(const float *const *feats_host, const int *heights_host,
+                              const int *widths_host, const float *scales_host, int num_levels,
+                              const float *rois, float *output, int32_t *levels_out, int batch,
+                              int channels, int n_rois, int pooled_h, int pooled_w,
+                              int sampling_ratio, float finest_scale, void *stream);
+
+int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights_host,
+                               const int *widths_host, const float *scales_host, int num_levels,
+                               const float *rois, const float *grad_output, int batch,
+                               int channels, int n_rois, int pooled_h, int pooled_w,
+                               int sampling_ratio, float finest_scale, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * NMS.  Replaces mmcv.ops.nms (ext `nms(boxes, scores, iou_threshold, offset)`),
+ * reached through mmcv batched_nms at atss_rpn_head.py:756, rpn_head.py:245 and
+ * core/post_processing/bbox_nms.py:86.
+ * Segmented form: `num_segments` independent problems (images, or levels of the
+ * split_thr path) in one launch; segment s owns boxes [seg_offsets[s],
+ * seg_offsets[s+1]).  Semantics per segment = mmcv nms_cpu: order by score
+ * descending (ties: ascending index), greedy suppress when
+ * inter/(area_i+area_j-inter) > iou_threshold.
+ *   boxes (n,4) fp32, scores (n) fp32, seg_offsets (S+1) int32 on device
+ *   keep  (n) int64: for segment s the kept ORIGINAL global indices in score
+ *         order are written at keep[seg_offsets[s] ...]; num_keep (S) int32
+ *   max_keep > 0 stops each segment after that many survivors (mmcv `max_num`)
+ *   max_segment_len: an upper bound on the longest segment (sizes the bit mask:
+ *         n * ceil(max_segment_len/64) * 8 bytes)
+ *   workspace: brcnn_nms_workspace_bytes(n, S, max_segment_len) bytes of scratch
+ * -------------------------------------------------------------------------- */
+size_t brcnn_nms_workspace_bytes(int64_t n, int num_segments, int64_t max_segment_len);
+int brcnn_nms(const float *boxes, const float *scores, const int32_t *seg_offsets,
+              int num_segments, int64_t n, int64_t max_segment_len, float iou_threshold,
+              int offset, int max_keep, int64_t *keep, int32_t *num_keep, void *workspace,
+              size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Soft-NMS.  Replaces mmcv.ops.soft_nms (ext `softnms`, CPU-only in mmcv),
+ * selected by `nms=dict(type='soft_nms', ...)`
+ * (configs/boosting_rcnn/boosting_rcnn_r2_101_dcn_pafpn_mstrain_3x_coco.py:27)
+ * through bbox_nms.py:86.  Sequential pick-max / decay / discard semantics of
+ * softnms_cpu reproduced exactly, one workgroup per segment.
+ *   dets (n,5) out [x1,y1,x2,y2,decayed score] in pick order per segment
+ *   inds (n) int64 out: original global indices in pick order
+ *   method 0 naive, 1 linear, 2 gaussian
+ * -------------------------------------------------------------------------- */
+size_t brcnn_softnms_workspace_bytes(int64_t n, int num_segments);
+int brcnn_softnms(const float *boxes, const float *scores, const int32_t *seg_offsets,
+                  int num_segments, int64_t n, float iou_threshold, float sigma, float min_score,
+                  int method, int offset, float *dets, int64_t *inds, int32_t *num_keep,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Sigmoid focal loss, element-wise (reduction 'none').  Replaces
+ * mmcv.ops.sigmoid_focal_loss_forward/_backward reached at
+ * mmdet/models/losses/focal_loss.py:86.  input (n,c) fp32, target (n) int64 in
+ * [0,c] (c = background), weight (c) or NULL.
+ * -------------------------------------------------------------------------- */
+int brcnn_sigmoid_focal_loss_forward(const float *input, const int64_t *target,
+                                     const float *weight, float *output, int64_t n, int64_t c,
+                                     float gamma, float alpha, void *stream);
+int brcnn_sigmoid_focal_loss_backward(const float *input, const int64_t *target,
+                                      const float *weight, float *grad_input, int64_t n,
+                                      int64_t c, float gamma, float alpha, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Convolution / linear stack (no mmcv counterpart: torch.nn.Conv2d/Linear +
+ * BatchNorm(eval)/ReLU/residual in mmdet/models/backbones/resnet.py:263-302,
+ * necks/pafpn.py:100-158, dense_heads/atss_rpn_head.py:207-215,
+ * roi_heads/bbox_heads/convfc_bbox_head.py:154-192).
+ * Implicit-GEMM on MFMA, NHWC activations:
+ *   x  (N,H,W,Cin)   w (Cout,KH,KW,Cin)   y (N,Ho,Wo,Cout)
+ *   y = act( conv(x,w) * scale[c] + shift[c] + residual ),  act = relu if `relu`
+ *   scale/shift/residual may be NULL (scale -> 1, shift -> 0).
+ *   dtype BRCNN_DT_F32: fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 FMA
+ *   chain); BRCNN_DT_BF16: bf16 operands, fp32 accumulate, bf16 output.
+ * A linear layer is the 1x1 case with H=W=1.
+ * -------------------------------------------------------------------------- */
+int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const float *shift,
+                      const void *residual, void *y, int batch, int height, int width, int cin,
+                      int cout, int kh, int kw, int stride, int pad, int relu, int dtype,
+                      void *stream);
+
+/* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
+int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,
+                            int channels, int dtype, void *stream);
+
+/* GroupNorm(+ReLU) over NHWC (RPN tower ConvModule norm, atss_rpn_head.py:118,150-190):
+ * y = relu?((x-mean_g)/sqrt(var_g+eps)*gamma[c]+beta[c]); stats per (n, group). */
+int brcnn_groupnorm_nhwc(const void *x, const float *gamma, const float *beta, void *y,
+                         void *stats_ws /* batch*groups*2 doubles of device scratch */,
+                         int batch, int hw, int channels, int groups, float eps, int relu,
+                         int dtype, void *stream);
+
+/* FPN top-down path: dst[n,y,x,c] += src[n, y*Hs/Hd, x*Ws/Wd, c]  (nearest,
+ * F.interpolate(size=...) at necks/pafpn.py:113-115, fpn.py:178-181) */
+int brcnn_upsample_nearest_add_nhwc(void *dst, const void *src, int batch, int hd, int wd,
+                                    int hs, int ws, int channels, int dtype, void *stream);
+
+/* layout shuffles between the reference's NCHW boundary and the NHWC interior */
+int brcnn_nchw_to_nhwc(const float *src, void *dst, int batch, int channels, int hw,
+                       int dst_dtype, void *stream);
+int brcnn_nhwc_to_nchw(const void *src, float *dst, int batch, int channels, int hw,
+                       int src_dtype, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * RetinaRPN proposal stage (ATSSRPNHead._get_bboxes_single,
+ * atss_rpn_head.py:688-760, with AnchorGenerator.single_level_grid_anchors
+ * core/anchor/anchor_generator.py:336-381 and delta2bbox
+ * core/bbox/coder/delta_xywh_bbox_coder.py:145-272 fused in).
+ *
+ * brcnn_rpn_score: score[n, (y*W+x)*A + a] = sqrt(sigmoid(cls)*sigmoid(iou)) for one
+ *   level; cls/iou are the head outputs in NHWC (N,H,W,A) fp32.
+ * brcnn_rpn_decode: for `count` selected anchors (flat index into (H*W*A) of one
+ *   level) regenerate the anchor from base_anchors (A,4) + stride, apply
+ *   delta2bbox(means 0, stds `std4`, wh_ratio_clip) with max_shape clipping; writes
+ *   proposals (count,4) and valid (count) uint8 = w > min_size && h > min_size.
+ * -------------------------------------------------------------------------- */
+int brcnn_rpn_score(const float *cls, const float *iou, float *score, int64_t n, void *stream);
+int brcnn_rpn_decode(const int64_t *topk_inds, const float *bbox_pred, const float *base_anchors,
+                     int batch, int count, int height, int width, int num_anchors, int stride_w,
+                     int stride_h, const float *means4_host, const float *stds4_host,
+                     double wh_ratio_clip, float max_h, float max_w, float min_size,
+                     float *proposals, uint8_t *valid, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRCNN_HIP_H */

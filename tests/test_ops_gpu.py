@@ -1,0 +1,389 @@
+"""-m gpu parity tests: the HIP operators (called through the C ABI via brcnn.ops) against
+the CPU oracle (oracle/orc.py) on identical seeded inputs.  Bars: bit-exact for indices and
+for RoIAlign values (same fp32 operation order, no FMA contraction); 1e-5/1e-6 where a
+transcendental (expf/logf/powf) differs between device and host libm."""
+import numpy as np
+import pytest
+import torch
+
+import brcnn  # noqa: F401
+from brcnn import ops
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+# --------------------------------------------------------------------------- RoIAlign
+def _feat(n, c, h, w, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, c, h, w, generator=g)
+
+
+@pytest.mark.parametrize('aligned', [True, False])
+@pytest.mark.parametrize('sampling_ratio', [0, 2])
+def test_roi_align_nchw_bit_exact(aligned, sampling_ratio):
+    x = _feat(2, 16, 50, 84)
+    rois = util.rand_rois(300, 2, 84 * 16.0, 50 * 16.0, seed=1)
+    # adversarial: outside the map, tiny (grid 1), huge (grid >= 15), zero-size
+    rois = torch.cat([rois, torch.tensor([[0, -200., -200., -100., -100.], [1, 10., 10., 11., 11.],
+                                          [0, 0., 0., 1343., 799.], [1, 100., 100., 100., 100.],
+                                          [0, 1300., 700., 1500., 900.]])])
+    ref = orc.roi_align_forward(x, rois, 7, 1 / 16., sampling_ratio, 'avg', aligned)
+    out = ops.roi_align(x.to(DEV), rois.to(DEV), 7, 1 / 16., sampling_ratio, 'avg', aligned)
+    assert out.shape == ref.shape
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_roi_align_nhwc_bit_exact_c256():
+    x = _feat(2, 256, 25, 42, seed=3)
+    rois = util.rand_rois(256, 2, 42 * 32.0, 25 * 32.0, seed=4)
+    ref = orc.roi_align_forward(x, rois, 7, 1 / 32., 0, 'avg', True)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.roi_align(xg, rois.to(DEV), 7, 1 / 32., 0, 'avg', True)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out.cpu().contiguous(), ref)
+
+
+def test_roi_align_max_mode():
+    x = _feat(1, 8, 20, 20, seed=5)
+    rois = util.rand_rois(40, 1, 320., 320., seed=6)
+    ref = orc.roi_align_forward(x, rois, (3, 5), 1 / 16., 2, 'max', True)
+    out = ops.roi_align(x.to(DEV), rois.to(DEV), (3, 5), 1 / 16., 2, 'max', True)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_roi_align_known_answers():
+    # SURVEY 8c / mmcv's published unit vectors
+    x = torch.tensor([[[[1., 2.], [3., 4.]]]])
+    rois = torch.tensor([[0., 0., 0., 1., 1.]])
+    out = ops.roi_align(x.to(DEV), rois.to(DEV), 2, 1.0, 2, 'avg', True).cpu()
+    assert torch.allclose(out, torch.tensor([[[[1.0, 1.25], [1.5, 1.75]]]]))
+    x = torch.tensor([[[[1., 2., 5., 6.], [3., 4., 7., 8.], [9., 10., 13., 14.], [11., 12., 15., 16.]]]])
+    rois = torch.tensor([[0., 0., 0., 3., 3.]])
+    out = ops.roi_align(x.to(DEV), rois.to(DEV), 2, 1.0, 2, 'avg', True).cpu()
+    assert torch.allclose(out, torch.tensor([[[[1.9375, 4.75], [7.5625, 10.375]]]]))
+    out = ops.roi_align(x.to(DEV), rois.to(DEV), 2, 1.0, 2, 'avg', False).cpu()
+    assert torch.allclose(out, torch.tensor([[[[3.625, 6.875], [10.125, 13.375]]]]))
+
+
+def test_roi_align_empty_and_errors():
+    x = _feat(1, 4, 8, 8).to(DEV)
+    out = ops.roi_align(x, torch.zeros(0, 5, device=DEV), 7, 1.0, 0, 'avg', True)
+    assert out.shape == (0, 4, 7, 7)
+    with pytest.raises(AssertionError):
+        ops.roi_align(x, torch.zeros(3, 4, device=DEV), 7, 1.0, 0, 'avg', True)
+    with pytest.raises(RuntimeError):
+        ops.roi_align(x.cpu(), torch.zeros(3, 5), 7, 1.0, 0, 'avg', True)
+
+
+@pytest.mark.parametrize('nhwc', [False, True])
+def test_roi_align_backward(nhwc):
+    x = _feat(2, 32, 25, 42, seed=8)
+    rois = util.rand_rois(64, 2, 42 * 32.0, 25 * 32.0, seed=9)
+    g = torch.Generator().manual_seed(10)
+    go = torch.randn(64, 32, 7, 7, generator=g)
+    ref = orc.roi_align_backward(go, rois, x.shape, 7, 1 / 32., 0, True)
+    xg = x.to(DEV)
+    if nhwc:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg.requires_grad_(True)
+    out = ops.roi_align(xg, rois.to(DEV), 7, 1 / 32., 0, 'avg', True)
+    out.backward(go.to(DEV))
+    # atomics reorder the fp32 sums: tolerance, not bit equality
+    assert torch.allclose(xg.grad.cpu().contiguous(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_roi_extract_fused_matches_per_level():
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    feats = [_feat(2, 256, h, w, seed=20 + i) for i, (h, w) in enumerate(sizes)]
+    rois = util.rand_rois(512, 2, 1333., 800., seed=21, min_size=8., max_size=1200.)
+    # reference: map_roi_levels + per-level oracle RoIAlign (single_level_roi_extractor.py:36-115)
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lvls = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=4).long()
+    ref = torch.zeros(512, 256, 7, 7)
+    for i in range(5):
+        inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+        if inds.numel():
+            ref[inds] = orc.roi_align_forward(feats[i], rois[inds], 7, 1. / strides[i], 0, 'avg', True)
+    fg = [f.to(DEV).permute(0, 2, 3, 1).contiguous() for f in feats]
+    out, lv = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+    assert torch.equal(lv.cpu().long(), lvls)
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu().contiguous(), ref)
+
+
+# --------------------------------------------------------------------------- NMS
+def test_nms_known_answer():
+    boxes = torch.tensor([[6., 3., 8., 7.], [3., 6., 9., 11.], [3., 7., 10., 12.], [1., 4., 13., 7.]])
+    scores = torch.tensor([0.6, 0.9, 0.7, 0.2])
+    dets, inds = ops.nms(boxes.to(DEV), scores.to(DEV), 0.3)
+    assert inds.cpu().tolist() == [1, 0, 3]
+    assert torch.equal(dets.cpu(), torch.cat([boxes[[1, 0, 3]], scores[[1, 0, 3], None]], 1))
+
+
+@pytest.mark.parametrize('n,thr,offset', [(1, 0.5, 0), (63, 0.5, 0), (64, 0.5, 1), (65, 0.7, 0),
+                                          (1000, 0.7, 0), (4693, 0.7, 0), (9999, 0.5, 1)])
+def test_nms_indices_bit_exact(n, thr, offset):
+    boxes = util.clustered_boxes(n, seed=n)
+    scores = util.tie_free_scores(n, seed=n + 1)
+    _, ref = orc.nms(boxes, scores, thr, offset)
+    dets, inds = ops.nms(boxes.to(DEV), scores.to(DEV), thr, offset)
+    assert torch.equal(inds.cpu(), ref)
+    assert 0 < ref.numel() < n or n == 1
+
+
+def test_nms_ties_follow_index_order():
+    boxes = util.clustered_boxes(500, seed=3)
+    scores = torch.full((500,), 0.5)
+    scores[::7] = 0.9
+    _, ref = orc.nms(boxes, scores, 0.6)
+    _, inds = ops.nms(boxes.to(DEV), scores.to(DEV), 0.6)
+    assert torch.equal(inds.cpu(), ref)
+
+
+def test_nms_score_threshold_max_num_empty():
+    boxes = util.clustered_boxes(800, seed=5)
+    scores = util.tie_free_scores(800, seed=6)
+    dref, ref = orc.nms(boxes, scores, 0.5, 0, 0.3, 20)
+    dets, inds = ops.nms(boxes.to(DEV), scores.to(DEV), 0.5, 0, 0.3, 20)
+    assert torch.equal(inds.cpu(), ref) and torch.equal(dets.cpu(), dref)
+    dets, inds = ops.nms(torch.zeros(0, 4, device=DEV), torch.zeros(0, device=DEV), 0.5)
+    assert dets.shape == (0, 5) and inds.shape == (0,) and inds.dtype == torch.int64
+
+
+def test_nms_segments():
+    lens = [4693, 1, 0, 2500, 64]
+    seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+    n = int(seg[-1])
+    boxes = util.clustered_boxes(n, seed=11)
+    scores = util.tie_free_scores(n, seed=12)
+    keep, num = ops.nms_segments(boxes.to(DEV), scores.to(DEV), seg.to(DEV), max(lens), 0.7, 0, 256)
+    keep, num = keep.cpu(), num.cpu()
+    for s, ln in enumerate(lens):
+        b, e = int(seg[s]), int(seg[s + 1])
+        _, ref = orc.nms(boxes[b:e], scores[b:e], 0.7, 0, 0, 256)
+        assert int(num[s]) == ref.numel()
+        assert torch.equal(keep[b:b + ref.numel()], ref + b)
+
+
+@pytest.mark.parametrize('n', [3000, 12000])   # below / above split_thr=10000
+def test_batched_nms_matches_oracle(n):
+    boxes = util.clustered_boxes(n, seed=n)
+    scores = util.tie_free_scores(n, seed=n + 3)
+    g = torch.Generator().manual_seed(n)
+    ids = torch.randint(0, 5, (n,), generator=g)
+    cfg = dict(type='nms', iou_threshold=0.7)
+    dref, kref = orc.batched_nms(boxes, scores, ids, cfg)
+    dets, keep = ops.batched_nms(boxes.to(DEV), scores.to(DEV), ids.to(DEV), cfg)
+    assert torch.equal(keep.cpu(), kref)
+    assert torch.equal(dets.cpu(), dref)
+
+
+# --------------------------------------------------------------------------- soft-NMS
+def test_soft_nms_known_answers():
+    boxes = torch.tensor([[6., 3., 8., 7.], [3., 6., 9., 11.], [3., 7., 10., 12.], [1., 4., 13., 7.]])
+    scores = torch.tensor([0.6, 0.9, 0.7, 0.2])
+    b, s = boxes.to(DEV), scores.to(DEV)
+    dets, inds = ops.soft_nms(b, s, 0.3, 0.5, 1e-3, 'naive')
+    assert inds.cpu().tolist() == [1, 0, 3]
+    dets, inds = ops.soft_nms(b, s, 0.3, 0.5, 1e-3, 'linear')
+    assert inds.cpu().tolist() == [1, 0, 2, 3]
+    assert np.allclose(dets[:, 4].cpu().numpy(), [0.9, 0.6, 0.29024392, 0.2], atol=1e-6)
+    dets, inds = ops.soft_nms(b, s, 0.3, 0.5, 1e-3, 'gaussian')
+    assert inds.cpu().tolist() == [1, 0, 2, 3]
+    assert np.allclose(dets[:, 4].cpu().numpy(), [0.9, 0.59630775, 0.35275510, 0.18650459], atol=1e-6)
+
+
+@pytest.mark.parametrize('method', ['linear', 'naive'])
+@pytest.mark.parametrize('n,min_score', [(300, 0.0), (2000, 0.0), (2000, 0.05), (777, 0.3)])
+def test_soft_nms_bit_exact(method, n, min_score):
+    boxes = util.clustered_boxes(n, seed=n + 1)
+    scores = util.tie_free_scores(n, seed=n + 2)
+    dref, iref = orc.soft_nms(boxes, scores, 0.7, 0.5, min_score, method)
+    dets, inds = ops.soft_nms(boxes.to(DEV), scores.to(DEV), 0.7, 0.5, min_score, method)
+    assert torch.equal(inds.cpu(), iref)
+    assert torch.equal(dets.cpu(), dref)
+
+
+def test_soft_nms_gaussian_close():
+    n = 1500
+    boxes = util.clustered_boxes(n, seed=31)
+    scores = util.tie_free_scores(n, seed=32)
+    dref, iref = orc.soft_nms(boxes, scores, 0.3, 0.5, 1e-3, 'gaussian')
+    dets, inds = ops.soft_nms(boxes.to(DEV), scores.to(DEV), 0.3, 0.5, 1e-3, 'gaussian')
+    # device expf vs glibc expf: <= 1 ulp per decay step; the pick sets must agree and the
+    # scores must agree to 1e-6
+    assert inds.numel() == iref.numel()
+    assert set(inds.cpu().tolist()) == set(iref.tolist())
+    order = torch.argsort(inds.cpu())
+    oref = torch.argsort(iref)
+    assert torch.allclose(dets.cpu()[order, 4], dref[oref, 4], atol=1e-6)
+
+
+def test_soft_nms_ties_and_segments():
+    lens = [900, 0, 1, 1300]
+    seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+    n = int(seg[-1])
+    boxes = util.clustered_boxes(n, seed=41)
+    g = torch.Generator().manual_seed(42)
+    scores = (torch.randint(1, 20, (n,), generator=g).float() / 20.0)   # many exact ties
+    dets, inds, num = ops.soft_nms_segments(boxes.to(DEV), scores.to(DEV), seg.to(DEV), 0.5, 0.5,
+                                            0.1, 1, 0)
+    dets, inds, num = dets.cpu(), inds.cpu(), num.cpu()
+    for s, ln in enumerate(lens):
+        b, e = int(seg[s]), int(seg[s + 1])
+        dref, iref = orc.soft_nms(boxes[b:e], scores[b:e], 0.5, 0.5, 0.1, 'linear')
+        assert int(num[s]) == iref.numel()
+        assert torch.equal(inds[b:b + iref.numel()], iref + b)
+        assert torch.equal(dets[b:b + iref.numel()], dref)
+
+
+# --------------------------------------------------------------------------- focal loss
+@pytest.mark.parametrize('c', [1, 4, 80])
+def test_sigmoid_focal_loss_fwd_bwd(c):
+    n = 5000
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(n, c, generator=g) * 3
+    t = torch.randint(0, c + 1, (n,), generator=g)
+    ref = orc.sigmoid_focal_loss_forward(x, t, 2.0, 0.25)
+    gref = orc.sigmoid_focal_loss_backward(x, t, 2.0, 0.25)
+    xg = x.to(DEV).requires_grad_(True)
+    out = ops.sigmoid_focal_loss(xg, t.to(DEV), 2.0, 0.25, None, 'none')
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=1e-7)
+    out.sum().backward()
+    assert torch.allclose(xg.grad.cpu(), gref, rtol=1e-5, atol=1e-7)
+    # python form of the reference CPU path (focal_loss.py:12-57)
+    import torch.nn.functional as F
+    tt = F.one_hot(t, c + 1)[:, :c].float()
+    p = x.sigmoid()
+    pt = (1 - p) * tt + p * (1 - tt)
+    py = F.binary_cross_entropy_with_logits(x, tt, reduction='none') * (0.25 * tt + 0.75 * (1 - tt)) * pt.pow(2.0)
+    assert torch.allclose(out.detach().cpu(), py, rtol=1e-4, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- conv stack
+def _conv_ref(x_nchw, w, scale, shift, res, relu, stride, pad):
+    import torch.nn.functional as F
+    y = F.conv2d(x_nchw.double(), w.double(), None, stride, pad)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res.double()
+    if relu:
+        y = y.relu()
+    return y
+
+
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, H, W, Cout, k, stride, pad, scale, shift, residual, relu)
+    (2, 64, 24, 40, 64, 1, 1, 0, True, True, False, True),
+    (2, 64, 24, 40, 256, 1, 1, 0, True, True, True, True),
+    (1, 128, 30, 31, 128, 3, 1, 1, True, True, False, True),
+    (2, 256, 25, 42, 256, 3, 2, 1, False, True, False, False),
+    (1, 512, 13, 21, 1024, 1, 2, 0, True, True, False, False),
+    (2, 3, 64, 96, 64, 7, 2, 3, True, True, False, True),
+    (1, 256, 13, 21, 9, 3, 1, 1, False, True, False, False),
+    (1, 256, 13, 21, 36, 3, 1, 1, False, True, False, False),
+    (300, 12544 // 49, 7, 7, 130, 7, 1, 0, False, True, False, True),   # FC as a 7x7 "valid" conv
+])
+def test_conv2d_nhwc_vs_float64(cfg):
+    n, cin, h, w, cout, k, stride, pad, has_scale, has_shift, has_res, relu = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    scale = torch.rand(cout, generator=g) + 0.5 if has_scale else None
+    shift = torch.randn(cout, generator=g) if has_shift else None
+    ho, wo = ops.conv_out_size(h, w, k, k, stride, pad)
+    res = torch.randn(n, cout, ho, wo, generator=g) if has_res else None
+    ref = _conv_ref(x, wt, scale, shift, res, relu, stride, pad)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wg = wt.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rg = res.permute(0, 2, 3, 1).contiguous().to(DEV) if has_res else None
+    y = ops.conv2d_nhwc(xg, wg, scale.to(DEV) if has_scale else None,
+                        shift.to(DEV) if has_shift else None, rg, relu, stride, pad)
+    y = y.permute(0, 3, 1, 2).cpu().double()
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_linear_large_k():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(257, 12544, generator=g)
+    w = torch.randn(1024, 12544, generator=g) / 112.0
+    b = torch.randn(1024, generator=g)
+    ref = (x.double() @ w.double().t() + b.double()).relu()
+    y = ops.linear_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), True).cpu().double()
+    assert (y - ref).abs().max().item() < 5e-5
+
+
+def test_small_nhwc_kernels():
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 33, 47, generator=g)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.maxpool3x3s2_nhwc(xg).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(y, F.max_pool2d(x, 3, 2, 1))
+    # group norm + relu
+    x = torch.randn(2, 256, 25, 42, generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5).relu()
+    y = ops.groupnorm_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), gamma.to(DEV), beta.to(DEV),
+                           32, 1e-5, True).permute(0, 3, 1, 2).cpu().double()
+    assert (y - ref).abs().max().item() < 1e-5
+    # nearest upsample + add (exact 2x and ragged)
+    for (hd, wd, hs, ws) in [(50, 84, 25, 42), (13, 21, 7, 11), (25, 41, 13, 21)]:
+        d = torch.randn(2, 256, hd, wd, generator=g)
+        s = torch.randn(2, 256, hs, ws, generator=g)
+        ref = d + F.interpolate(s, size=(hd, wd), mode='nearest')
+        dg = d.permute(0, 2, 3, 1).contiguous().to(DEV)
+        ops.upsample_nearest_add_nhwc_(dg, s.permute(0, 2, 3, 1).contiguous().to(DEV))
+        assert torch.equal(dg.permute(0, 3, 1, 2).cpu(), ref)
+    # layout shuffles
+    x = torch.randn(3, 37, 19, 23, generator=g)
+    assert torch.equal(ops.nchw_to_nhwc(x.to(DEV)).cpu(), x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(x.permute(0, 2, 3, 1).contiguous().to(DEV)).cpu(), x)
+
+
+# --------------------------------------------------------------------------- RPN stage
+def test_rpn_score_and_decode():
+    g = torch.Generator().manual_seed(77)
+    cls, iou = torch.randn(2, 13, 21, 9, generator=g) * 3, torch.randn(2, 13, 21, 9, generator=g) * 3
+    ref = (cls.sigmoid() * iou.sigmoid()).sqrt()
+    out = ops.rpn_score(cls.to(DEV), iou.to(DEV)).cpu()
+    assert util.ulp_diff(out, ref).max().item() <= 2
+    # decode against the reference formulas (anchor grid + delta2bbox), CPU torch
+    A, H, W, stride = 9, 13, 21, 64
+    base = torch.randn(A, 4, generator=g) * 100
+    base = torch.stack([-base[:, 0].abs(), -base[:, 1].abs(), base[:, 2].abs(), base[:, 3].abs()], 1)
+    deltas = torch.randn(2, H, W, 4 * A, generator=g)
+    deltas[0, 0, 0, :8] = torch.tensor([0., 0., 9., -9., 50., -50., 0.3, 0.2])   # clamp edges
+    inds = torch.stack([torch.randperm(H * W * A, generator=g)[:500] for _ in range(2)])
+    sx = torch.arange(W) * stride
+    sy = torch.arange(H) * stride
+    yy, xx = torch.meshgrid(sy, sx, indexing='ij')
+    shifts = torch.stack([xx, yy, xx, yy], -1).reshape(-1, 1, 4).float()
+    anchors = (base[None] + shifts).reshape(-1, 4)
+    props, valid = ops.rpn_decode(inds.to(DEV), deltas.to(DEV), base.to(DEV), (H, W), stride,
+                                  (0., 0., 0., 0.), (1., 1., 1., 1.), (800, 1333, 3), 0.0)
+    for b in range(2):
+        a = anchors[inds[b]]
+        d = deltas[b].reshape(-1, 4)[inds[b]]
+        px, py = (a[:, 0] + a[:, 2]) * 0.5, (a[:, 1] + a[:, 3]) * 0.5
+        pw, ph = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+        mr = abs(np.log(16 / 1000))
+        dw, dh = d[:, 2].clamp(-mr, mr), d[:, 3].clamp(-mr, mr)
+        gw, gh = pw * dw.exp(), ph * dh.exp()
+        gx, gy = px + pw * d[:, 0], py + ph * d[:, 1]
+        ref = torch.stack([gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5], -1)
+        ref[:, 0::2] = ref[:, 0::2].clamp(0, 1333)
+        ref[:, 1::2] = ref[:, 1::2].clamp(0, 800)
+        got = props[b].cpu()
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-3)
+        v = ((ref[:, 2] - ref[:, 0]) > 0) & ((ref[:, 3] - ref[:, 1]) > 0)
+        agree = (valid[b].cpu().bool() == v)
+        assert agree.float().mean().item() > 0.995

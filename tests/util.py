@@ -1,0 +1,57 @@
+"""Shared helpers of the parity tests (seeded synthetic inputs, tolerant comparisons)."""
+import numpy as np
+import torch
+
+
+def rand_boxes(n, img_w=1333.0, img_h=800.0, seed=0, min_size=2.0, max_size=400.0):
+    g = torch.Generator().manual_seed(seed)
+    cx = torch.rand(n, generator=g) * img_w
+    cy = torch.rand(n, generator=g) * img_h
+    lw = torch.rand(n, generator=g) * (np.log(max_size) - np.log(min_size)) + np.log(min_size)
+    lh = lw + (torch.rand(n, generator=g) - 0.5) * 1.4
+    w, h = lw.exp(), lh.exp()
+    b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    b[:, 0::2].clamp_(0, img_w)
+    b[:, 1::2].clamp_(0, img_h)
+    return b.float()
+
+
+def clustered_boxes(n, n_clusters=40, seed=0, img_w=1333.0, img_h=800.0):
+    """many heavily overlapping boxes (what an RPN emits): NMS actually suppresses"""
+    g = torch.Generator().manual_seed(seed)
+    centers = rand_boxes(n_clusters, img_w, img_h, seed + 1, 16, 300)
+    idx = torch.randint(0, n_clusters, (n,), generator=g)
+    jit = (torch.rand(n, 4, generator=g) - 0.5) * 0.25
+    c = centers[idx]
+    wh = torch.stack([c[:, 2] - c[:, 0], c[:, 3] - c[:, 1]], 1).repeat(1, 2)
+    b = c + jit * wh
+    b[:, 0::2].clamp_(0, img_w)
+    b[:, 1::2].clamp_(0, img_h)
+    x1 = torch.minimum(b[:, 0], b[:, 2]); x2 = torch.maximum(b[:, 0], b[:, 2])
+    y1 = torch.minimum(b[:, 1], b[:, 3]); y2 = torch.maximum(b[:, 1], b[:, 3])
+    return torch.stack([x1, y1, x2, y2], 1).float()
+
+
+def tie_free_scores(n, seed=0):
+    """U(0,1) scores made pairwise distinct: a random permutation of a strictly
+    increasing fp32 ramp."""
+    g = torch.Generator().manual_seed(seed)
+    base = (torch.arange(n, dtype=torch.float64) + 0.5) / n
+    s = base[torch.randperm(n, generator=g)].float()
+    assert torch.unique(s).numel() == n
+    return s
+
+
+def rand_rois(k, batch, img_w=1333.0, img_h=800.0, seed=0, min_size=4.0, max_size=900.0):
+    b = rand_boxes(k, img_w, img_h, seed, min_size, max_size)
+    g = torch.Generator().manual_seed(seed + 7)
+    bi = torch.randint(0, batch, (k, 1), generator=g).float()
+    return torch.cat([bi, b], 1)
+
+
+def ulp_diff(a, b):
+    a = a.detach().cpu().float().contiguous().view(torch.int32).long()
+    b = b.detach().cpu().float().contiguous().view(torch.int32).long()
+    a = torch.where(a < 0, -(a & 0x7fffffff), a)
+    b = torch.where(b < 0, -(b & 0x7fffffff), b)
+    return (a - b).abs()
