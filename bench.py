@@ -1,0 +1,122 @@
+"""Benchmark of the Boosting R-CNN hot path on MI355X.
+
+A "step" is one inference pass (`model(return_loss=False, rescale=True, ...)`, the protocol of
+tools/analysis_tools/benchmark.py:98-131) of the UTDAC R50-PAFPN Boosting R-CNN over a batch
+of 8 synthetic 1333x800 images (BASELINE.json configs[1]), inputs resident in HBM.  Prints
+ONE JSON line (see the contract in the task statement) with `roofline` (dominant kernel: the
+fp32 MFMA implicit-GEMM conv) and `cpu_baseline` (the oracle pipeline on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def synthetic_batch(batch, device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(batch, 3, 800, 1344, generator=g).to(device)
+    metas = [dict(img_shape=(800, 1333, 3), pad_shape=(800, 1344, 3), ori_shape=(800, 1333, 3),
+                  scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), flip=False)
+             for _ in range(batch)]
+    return img, metas
+
+
+def build_model(device, seed=0):
+    import brcnn  # noqa: F401
+    from brcnn import Config, build_detector
+    from tests import util
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'boosting_rcnn',
+                                       'boosting_rcnn_r50_pafpn_1x_utdac.py'))
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=seed))
+    return m.to(device).eval(), cfg
+
+
+def conv_flops_per_image():
+    """algorithmic MACs of the conv/FC stack per image (170.0 GMAC at 256 RoIs, C=4)"""
+    return 2 * 170.0e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    model, cfg = build_model(device)
+    img, metas = synthetic_batch(args.batch, device, seed=rank)
+
+    def step():
+        with torch.no_grad():
+            return model.simple_test_device(img, metas, rescale=True)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        nd = out[2].cpu()        # results leave the device every step, as in benchmark.py
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel: the conv stack, timed live with HIP events --------
+    from brcnn import profiling
+    roof = profiling.conv_stack_roofline(model, img, metas, iters=3)
+
+    line = {
+        'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN inference',
+        'value': world * args.batch * args.steps / dt,
+        'unit': 'images/sec',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1000.0 * dt / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'boosting_rcnn_r50_pafpn_1x_utdac.py inference (simple_test, rescale), '
+                               f'batch {args.batch} x 3x800x1344 per GPU, fp32 MFMA conv stack, '
+                               '1000 pre-NMS / 256 proposals per image, seeded synthetic weights',
+                   'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
+        'roofline': roof,
+        'detections_last_step': int(nd.sum()),
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_pipeline
+            line['cpu_baseline'] = cpu_pipeline.timed_baseline(cfg, seed=0)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

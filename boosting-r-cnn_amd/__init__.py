@@ -8,3 +8,10 @@ __version__ = '0.1.0'
 
 from .registry import Registry, build_from_cfg  # noqa: F401
 from .config import Config, ConfigDict  # noqa: F401
+
+# registering the hot-path classes under the reference's names
+from . import core, losses, backbones, necks, dense_heads, roi_heads, detectors  # noqa: E402,F401
+from .registry import (MODELS, BACKBONES, NECKS, HEADS, LOSSES, DETECTORS, ROI_EXTRACTORS,  # noqa: E402,F401
+                       BBOX_ASSIGNERS, BBOX_SAMPLERS, BBOX_CODERS, PRIOR_GENERATORS,
+                       IOU_CALCULATORS, build_detector, build_backbone, build_neck, build_head,
+                       build_loss)

@@ -1,0 +1,169 @@
+"""ResNet-50/101 backbone, executed as NHWC implicit-GEMM convolutions with eval-mode BN,
+ReLU and the residual add folded into the conv epilogues.
+
+Mirrors `mmdet/models/backbones/resnet.py` (`Bottleneck` :97-302, `ResNet` :306-657) and
+`mmdet/models/utils/res_layer.py`: same constructor arguments as the configs pass
+(`depth, num_stages, out_indices, frozen_stages, norm_cfg, norm_eval, style, init_cfg`), the
+same state-dict key layout (`conv1/bn1/layer{1-4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,
+downsample.{0,1}}`), the same freeze / norm_eval behaviour in `train()`.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .blocks import PackedCache, build_norm_layer, conv_bn_act_nhwc, to_nchw_view, to_nhwc
+from .registry import BACKBONES
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style='pytorch',
+                 norm_cfg=dict(type='BN')):
+        super().__init__()
+        assert style in ('pytorch', 'caffe')
+        self.inplanes, self.planes, self.stride, self.style = inplanes, planes, stride, style
+        if style == 'pytorch':      # stride on the 3x3 (resnet.py:150-155)
+            self.conv1_stride, self.conv2_stride = 1, stride
+        else:
+            self.conv1_stride, self.conv2_stride = stride, 1
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=self.conv1_stride, bias=False)
+        self.add_module('bn1', build_norm_layer(norm_cfg, planes, 1)[1])
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=self.conv2_stride, padding=1, bias=False)
+        self.add_module('bn2', build_norm_layer(norm_cfg, planes, 2)[1])
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.add_module('bn3', build_norm_layer(norm_cfg, planes * self.expansion, 3)[1])
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self._c = [PackedCache() for _ in range(4)]
+
+    def forward_nhwc(self, x):
+        out = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True)
+        out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True)
+        identity = x
+        if self.downsample is not None:
+            identity = conv_bn_act_nhwc(x, self.downsample[0], self.downsample[1], self._c[3], False)
+        # relu(bn3(conv3(out)) + identity) in one epilogue (resnet.py:288-300)
+        return conv_bn_act_nhwc(out, self.conv3, self.bn3, self._c[2], True, residual=identity)
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
+
+
+class ResLayer(nn.Sequential):
+    """mmdet/models/utils/res_layer.py: first block carries the stride and the 1x1 downsample."""
+
+    def __init__(self, block, inplanes, planes, num_blocks, stride=1, style='pytorch',
+                 norm_cfg=dict(type='BN')):
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                build_norm_layer(norm_cfg, planes * block.expansion)[1])
+        layers = [block(inplanes, planes, stride, downsample, style, norm_cfg)]
+        inplanes = planes * block.expansion
+        for _ in range(1, num_blocks):
+            layers.append(block(inplanes, planes, 1, None, style, norm_cfg))
+        super().__init__(*layers)
+
+    def forward_nhwc(self, x):
+        for blk in self:
+            x = blk.forward_nhwc(x)
+        return x
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {50: (Bottleneck, (3, 4, 6, 3)), 101: (Bottleneck, (3, 4, 23, 3)),
+                     152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3),
+                 style='pytorch', deep_stem=False, avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True, pretrained=None, init_cfg=None):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet (hot path: 50/101/152)')
+        assert not deep_stem and not avg_down and dcn is None and plugins is None and \
+            conv_cfg is None, 'ResNetV1d / DCN / plugin variants are outside the hot path'
+        assert all(d == 1 for d in dilations)
+        assert 1 <= num_stages <= 4 and max(out_indices) < num_stages
+        self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
+        self.style, self.frozen_stages, self.norm_cfg, self.norm_eval = \
+            style, frozen_stages, norm_cfg, norm_eval
+        self.zero_init_residual = zero_init_residual
+        self.init_cfg = init_cfg
+        stem_channels = stem_channels or base_channels
+        self.block, stage_blocks = self.arch_settings[depth]
+        self.stage_blocks = stage_blocks[:num_stages]
+        self.inplanes = stem_channels
+        self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
+        self.add_module('bn1', build_norm_layer(norm_cfg, stem_channels, 1)[1])
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.res_layers = []
+        for i, num_blocks in enumerate(self.stage_blocks):
+            planes = base_channels * 2 ** i
+            layer = ResLayer(self.block, self.inplanes, planes, num_blocks, strides[i], style,
+                             norm_cfg)
+            self.inplanes = planes * self.block.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, layer)
+            self.res_layers.append(name)
+        self.feat_dim = self.block.expansion * base_channels * 2 ** (len(self.stage_blocks) - 1)
+        self._stem_cache = PackedCache()
+        self._freeze_stages()
+        self.init_weights()
+
+    def init_weights(self):
+        """Kaiming (fan_out, relu) for convs, constant 1 for norms, zero for the last BN of each
+        block (resnet.py:392-412).  `init_cfg=Pretrained torchvision://resnet50` needs the
+        network: seeded random init stands in (synthetic weights)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual and not (isinstance(self.init_cfg, dict) and
+                                            self.init_cfg.get('type') == 'Pretrained'):
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def forward_nhwc(self, x):
+        """x (N,H,W,3) -> tuple of (N,h,w,C) for out_indices"""
+        x = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._stem_cache, True)
+        x = ops.maxpool3x3s2_nhwc(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name).forward_nhwc(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def forward(self, x):
+        return tuple(to_nchw_view(o) for o in self.forward_nhwc(to_nhwc(x)))

@@ -1,0 +1,174 @@
+"""Parameter containers + NHWC execution of conv / norm / activation bricks.
+
+The reference builds its layers from mmcv's `ConvModule` / `build_conv_layer` /
+`build_norm_layer` / `Scale` (external).  Here a brick keeps its parameters in plain
+`nn.Conv2d` / `nn.BatchNorm2d` / `nn.GroupNorm` modules -- so the state-dict key layout is the
+reference's (`...conv.weight`, `...bn.weight`, `...gn.bias`, ...) and
+published checkpoints load -- but those modules' own forward is never used: execution goes
+through the HIP implicit-GEMM kernel on NHWC activations with BN (eval) / bias / residual /
+ReLU folded into its epilogue.
+
+Activations between bricks are (N,H,W,C) contiguous fp32 tensors ("nhwc").  `to_nchw_view`
+gives the zero-copy logical (N,C,H,W) view (== torch.channels_last) used at the public
+module boundaries.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def to_nchw_view(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def to_nhwc(x):
+    """logical (N,C,H,W) -> (N,H,W,C) contiguous; free when x is channels_last already."""
+    if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return x.permute(0, 2, 3, 1)
+    if x.shape[1] == 1 or (x.shape[2] == 1 and x.shape[3] == 1):
+        return x.permute(0, 2, 3, 1).contiguous()
+    return ops.nchw_to_nhwc(x)
+
+
+class PackedCache:
+    """Device-side packed operands of one conv (weights in (Cout,KH,KW,Cin) order, folded
+    per-channel scale/shift), rebuilt when any source parameter changes version."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, sources, builder):
+        key = tuple((s.data_ptr(), s._version, s.device) for s in sources if s is not None)
+        if key != self.key:
+            with torch.no_grad():
+                self.val = builder()
+            self.key = key
+        return self.val
+
+
+def pack_weight(w):
+    """(Cout,Cin,KH,KW) -> (Cout,KH,KW,Cin) contiguous fp32"""
+    return w.detach().float().permute(0, 2, 3, 1).contiguous()
+
+
+def fold_bn(bn):
+    """eval-mode BatchNorm as y = x*scale + shift (resnet.py:648-657: norm_eval=True keeps BN
+    in eval mode during training too)."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    """(name, module) like mmcv.cnn.build_norm_layer: BN -> 'bn', GN -> 'gn'."""
+    cfg = dict(cfg)
+    layer_type = cfg.pop('type')
+    requires_grad = cfg.pop('requires_grad', True)
+    cfg.setdefault('eps', 1e-5)
+    if layer_type in ('BN', 'BN2d', 'SyncBN'):
+        name, layer = 'bn', nn.BatchNorm2d(num_features, **cfg)
+    elif layer_type == 'GN':
+        assert 'num_groups' in cfg
+        name, layer = 'gn', nn.GroupNorm(num_channels=num_features, **cfg)
+    else:
+        raise KeyError(f'Unrecognized norm type {layer_type}')
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return name + str(postfix), layer
+
+
+def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
+    """act(bn(conv(x)) + residual) with everything folded into one kernel launch."""
+    if bn is not None and bn.training:
+        raise NotImplementedError('training-mode BatchNorm is not on the HIP path '
+                                  '(the reference runs BN in eval mode: norm_eval=True)')
+    srcs = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var]
+                                       if bn is not None else [])
+
+    def builder():
+        w = pack_weight(conv.weight)
+        if bn is not None:
+            scale, shift = fold_bn(bn)
+            if conv.bias is not None:
+                shift = shift + conv.bias.detach().float() * scale
+            return w, scale, shift
+        return w, None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+
+    w, scale, shift = cache.get(srcs, builder)
+    return ops.conv2d_nhwc(x, w, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> activation brick with mmcv.cnn.ConvModule's constructor and attribute
+    names (`conv`, `bn`/`gn`, `activate`); bias='auto' means "no bias when a norm follows"."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'),
+                 inplace=True, with_spectral_norm=False, padding_mode='zeros',
+                 order=('conv', 'norm', 'act')):
+        super().__init__()
+        assert conv_cfg is None or conv_cfg.get('type', 'Conv2d') in ('Conv2d', 'Conv'), \
+            'only plain Conv2d is on the hot path'
+        assert dilation == 1 and groups == 1 and padding_mode == 'zeros' and not with_spectral_norm
+        assert tuple(order) == ('conv', 'norm', 'act')
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if self.with_activation:
+            assert act_cfg.get('type') == 'ReLU', 'only ReLU activations are on the hot path'
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.with_bias = bias
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride,
+                              padding=padding, bias=bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm_name = None
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            self.activate = nn.ReLU(inplace=inplace)
+        self._cache = PackedCache()
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.norm_name else None
+
+    def init_weights(self):
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+        if self.conv.bias is not None:
+            nn.init.constant_(self.conv.bias, 0)
+        if self.with_norm:
+            nn.init.constant_(self.norm.weight, 1)
+            nn.init.constant_(self.norm.bias, 0)
+
+    def forward_nhwc(self, x, residual=None):
+        norm = self.norm
+        if norm is None or isinstance(norm, nn.BatchNorm2d):
+            return conv_bn_act_nhwc(x, self.conv, norm, self._cache, self.with_activation, residual)
+        # GroupNorm needs the statistics of the whole conv output: conv, then fused GN(+ReLU)
+        assert residual is None
+        y = conv_bn_act_nhwc(x, self.conv, None, self._cache, False)
+        return ops.groupnorm_nhwc(y, norm.weight.detach(), norm.bias.detach(), norm.num_groups,
+                                  norm.eps, self.with_activation)
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
+
+
+class Scale(nn.Module):
+    """learnable scalar (mmcv.cnn.Scale); state-dict key `scale`."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+def bias_init_with_prob(prior_prob):
+    import math
+    return float(-math.log((1 - prior_prob) / prior_prob))

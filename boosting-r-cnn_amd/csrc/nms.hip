@@ -21,9 +21,11 @@
 
 namespace {
 
-__global__ void iota_kernel(int32_t* __restrict__ v, int64_t n) {
+// both buffers: positions outside every segment are never written by the segmented sort,
+// so the output index buffer must hold valid indices there too
+__global__ void iota_kernel(int32_t* __restrict__ v, int32_t* __restrict__ v2, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (int32_t)i;
+    if (i < n) { v[i] = (int32_t)i; v2[i] = (int32_t)i; }
 }
 
 __global__ void gather_boxes_kernel(const float* __restrict__ boxes,
@@ -40,12 +42,13 @@ __global__ void gather_boxes_kernel(const float* __restrict__ boxes,
 // grid: (col_tile, row_tile, segment); block: 64 threads (one wavefront).
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes,
                                                       const float* __restrict__ sareas,
-                                                      const int32_t* __restrict__ seg_offsets,
+                                                      const int32_t* __restrict__ seg_begin,
+                                                      const int32_t* __restrict__ seg_end,
                                                       unsigned long long* __restrict__ mask,
                                                       int words, float thr, int offset) {
     const int col_t = blockIdx.x, row_t = blockIdx.y, seg = blockIdx.z;
     if (col_t < row_t) return;
-    const int beg = seg_offsets[seg], len = seg_offsets[seg + 1] - beg;
+    const int beg = seg_begin[seg], len = seg_end[seg] - beg;
     if (row_t * 64 >= len || col_t * 64 >= len) return;
     __shared__ float4 cb[64];
     __shared__ float ca[64];
@@ -78,13 +81,14 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 // one wavefront per segment
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
                                                         const int32_t* __restrict__ sorted_idx,
-                                                        const int32_t* __restrict__ seg_offsets,
+                                                        const int32_t* __restrict__ seg_begin,
+                                                        const int32_t* __restrict__ seg_end,
                                                         int64_t* __restrict__ keep,
                                                         int32_t* __restrict__ num_keep, int words,
                                                         int max_keep) {
     extern __shared__ unsigned long long remv[];
     const int seg = blockIdx.x, lane = threadIdx.x;
-    const int beg = seg_offsets[seg], len = seg_offsets[seg + 1] - beg;
+    const int beg = seg_begin[seg], len = seg_end[seg] - beg;
     const int nchunk = (len + 63) >> 6;
     for (int w = lane; w < nchunk; w += 64) remv[w] = 0ull;
     __syncthreads();
@@ -176,11 +180,11 @@ BRCNN_API size_t brcnn_nms_workspace_bytes(int64_t n, int num_segments, int64_t 
     return carve(nullptr, n, num_segments, words).total;
 }
 
-BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
-                        int num_segments, int64_t n, int64_t max_segment_len, float iou_threshold,
+BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* seg_begin,
+                        const int32_t* seg_end, int num_segments, int64_t n, int64_t max_segment_len, float iou_threshold,
                         int offset, int max_keep, int64_t* keep, int32_t* num_keep, void* workspace,
                         size_t workspace_bytes, void* stream) {
-    if (n < 0 || num_segments <= 0 || (offset != 0 && offset != 1) || !seg_offsets || !num_keep)
+    if (n < 0 || num_segments <= 0 || (offset != 0 && offset != 1) || !seg_begin || !seg_end || !num_keep)
         return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -194,21 +198,21 @@ BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* 
     NmsWs w = carve(workspace, n, num_segments, words);
     if (w.total > workspace_bytes) return BRCNN_EINVAL;
 
-    hipLaunchKernelGGL(iota_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, w.idx_in, n);
+    hipLaunchKernelGGL(iota_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, w.idx_in, w.idx_out, n);
     BRCNN_LAUNCH_CHECK();
     size_t tmp = w.sort_tmp_bytes;
     BRCNN_HIP_CHECK((rocprim::segmented_radix_sort_pairs_desc(
         w.sort_tmp, tmp, scores, w.keys_out, (const int32_t*)w.idx_in, w.idx_out, (unsigned)n,
-        (unsigned)num_segments, seg_offsets, seg_offsets + 1, 0, 32, s, false)));
+        (unsigned)num_segments, seg_begin, seg_end, 0, 32, s, false)));
     hipLaunchKernelGGL(gather_boxes_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, boxes,
                        (const int32_t*)w.idx_out, w.sboxes, w.sareas, n, offset);
     BRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, num_segments), dim3(64), 0, s,
-                       (const float*)w.sboxes, (const float*)w.sareas, seg_offsets, w.mask, words,
+                       (const float*)w.sboxes, (const float*)w.sareas, seg_begin, seg_end, w.mask, words,
                        iou_threshold, offset);
     BRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(num_segments), dim3(64), (size_t)words * 8, s,
-                       (const unsigned long long*)w.mask, (const int32_t*)w.idx_out, seg_offsets,
+                       (const unsigned long long*)w.mask, (const int32_t*)w.idx_out, seg_begin, seg_end,
                        keep, num_keep, words, max_keep);
     BRCNN_LAUNCH_CHECK();
     return 0;

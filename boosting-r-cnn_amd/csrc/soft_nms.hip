@@ -67,7 +67,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh, int* total) {
 
 __global__ __launch_bounds__(TPB) void softnms_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores,
-    const int32_t* __restrict__ seg_offsets, float* __restrict__ x1, float* __restrict__ y1,
+    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end,
+    float* __restrict__ x1, float* __restrict__ y1,
     float* __restrict__ x2, float* __restrict__ y2, float* __restrict__ sc, float* __restrict__ ar,
     int32_t* __restrict__ id, int32_t* __restrict__ holes, int32_t* __restrict__ donors,
     float* __restrict__ dets, int64_t* __restrict__ inds, int32_t* __restrict__ num_keep,
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(TPB) void softnms_kernel(
     __shared__ Best sh_b[4];
     __shared__ float sh_box[5];
     const int seg = blockIdx.x, tid = threadIdx.x;
-    const int beg = seg_offsets[seg];
-    int nboxes = seg_offsets[seg + 1] - beg;
+    const int beg = seg_begin[seg];
+    int nboxes = seg_end[seg] - beg;
     x1 += beg; y1 += beg; x2 += beg; y2 += beg; sc += beg; ar += beg; id += beg;
     holes += beg; donors += beg;
     for (int p = tid; p < nboxes; p += TPB) {
@@ -182,13 +183,13 @@ BRCNN_API size_t brcnn_softnms_workspace_bytes(int64_t n, int num_segments) {
     return 9 * align_up((size_t)n * 4);
 }
 
-BRCNN_API int brcnn_softnms(const float* boxes, const float* scores, const int32_t* seg_offsets,
-                            int num_segments, int64_t n, float iou_threshold, float sigma,
+BRCNN_API int brcnn_softnms(const float* boxes, const float* scores, const int32_t* seg_begin,
+                            const int32_t* seg_end, int num_segments, int64_t n, float iou_threshold, float sigma,
                             float min_score, int method, int offset, float* dets, int64_t* inds,
                             int32_t* num_keep, void* workspace, size_t workspace_bytes,
                             void* stream) {
     if (n < 0 || num_segments <= 0 || method < 0 || method > 2 || (offset != 0 && offset != 1) ||
-        !seg_offsets || !num_keep)
+        !seg_begin || !seg_end || !num_keep)
         return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -206,7 +207,7 @@ BRCNN_API int brcnn_softnms(const float* boxes, const float* scores, const int32
     int32_t* holes = (int32_t*)(p + 7 * st);
     int32_t* donors = (int32_t*)(p + 8 * st);
     hipLaunchKernelGGL(softnms_kernel, dim3(num_segments), dim3(TPB), 0, s, boxes, scores,
-                       seg_offsets, x1, y1, x2, y2, sc, ar, id, holes, donors, dets, inds, num_keep,
+                       seg_begin, seg_end, x1, y1, x2, y2, sc, ar, id, holes, donors, dets, inds, num_keep,
                        iou_threshold, sigma, min_score, method, offset);
     BRCNN_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,391 @@
+"""RetinaRPN (`ATSSRPNHead`): shared 4-conv GN tower + objectness / box / IoU heads, anchor
+target assignment + losses, and the proposal stage.
+
+Mirrors `mmdet/models/dense_heads/atss_rpn_head.py:109-783` on top of
+`anchor_head.py:37-268` and `rpn_head.py:16-34` (constructor arguments, parameter names
+`rpn_convs.{i}.{conv,gn}`, `rpn_cls/rpn_reg/rpn_iou`, `scales.{i}.scale`, loss definitions,
+proposal semantics).  Differences are in execution only:
+  * the tower and heads run as NHWC implicit-GEMM convolutions (GroupNorm+ReLU fused kernel;
+    the per-level `Scale` folded into the rpn_reg epilogue);
+  * `get_bboxes` processes the whole batch at once on the device: fused
+    sqrt(sigmoid*sigmoid) scoring, per-level top-k, on-the-fly anchor decode, one segmented
+    NMS launch for all images, a single host sync at the end (the reference loops over
+    images and levels in Python, atss_rpn_head.py:485,706).
+"""
+import copy
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .blocks import ConvModule, PackedCache, Scale, bias_init_with_prob, to_nhwc
+from .postprocess import batched_nms_images
+from .core import (anchor_inside_flags, bbox_overlaps, images_to_levels, multi_apply, unmap)
+from .registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder,
+                       build_loss, build_sampler)
+
+EPS = 1e-12
+
+
+def reduce_mean(tensor):
+    """mean over ranks (mmdet/core/utils/dist_utils.py:67-73); identity when not distributed"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return tensor
+
+
+class AnchorHead(nn.Module):
+    """Target assignment shared by anchor-based heads (anchor_head.py:37-268)."""
+
+    def __init__(self, num_classes, in_channels, feat_channels=256,
+                 anchor_generator=dict(type='AnchorGenerator', scales=[8, 16, 32],
+                                       ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16, 32, 64]),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True,
+                                 target_means=(.0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0)),
+                 reg_decoded_bbox=False,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 train_cfg=None, test_cfg=None, init_cfg=None):
+        super().__init__()
+        self.in_channels, self.num_classes, self.feat_channels = in_channels, num_classes, feat_channels
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.sampling = loss_cls['type'] not in ['FocalLoss', 'GHMC', 'QualityFocalLoss']
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
+        if self.cls_out_channels <= 0:
+            raise ValueError(f'num_classes={num_classes} is too small')
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if self.train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            if self.sampling and hasattr(self.train_cfg, 'sampler'):
+                sampler_cfg = self.train_cfg.sampler
+            else:
+                sampler_cfg = dict(type='PseudoSampler')
+            self.sampler = build_sampler(sampler_cfg, context=self)
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self._init_layers()
+
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        num_imgs = len(img_metas)
+        multi_level_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        anchor_list = [multi_level_anchors for _ in range(num_imgs)]
+        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, m['pad_shape'], device)
+                           for m in img_metas]
+        return anchor_list, valid_flag_list
+
+    def _get_targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore,
+                            gt_labels, img_meta, label_channels=1, unmap_outputs=True):
+        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
+                                           self.train_cfg.allowed_border)
+        if not inside_flags.any():
+            return (None,) * 7
+        anchors = flat_anchors[inside_flags, :]
+        assign_result = self.assigner.assign(anchors, gt_bboxes, gt_bboxes_ignore,
+                                             None if self.sampling else gt_labels)
+        sampling_result = self.sampler.sample(assign_result, anchors, gt_bboxes)
+        num_valid = anchors.shape[0]
+        bbox_targets = torch.zeros_like(anchors)
+        bbox_weights = torch.zeros_like(anchors)
+        labels = anchors.new_full((num_valid,), self.num_classes, dtype=torch.long)
+        label_weights = anchors.new_zeros(num_valid, dtype=torch.float)
+        pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
+        if len(pos_inds) > 0:
+            if not self.reg_decoded_bbox:
+                pos_bbox_targets = self.bbox_coder.encode(sampling_result.pos_bboxes,
+                                                          sampling_result.pos_gt_bboxes)
+            else:
+                pos_bbox_targets = sampling_result.pos_gt_bboxes
+            bbox_targets[pos_inds, :] = pos_bbox_targets
+            bbox_weights[pos_inds, :] = 1.0
+            if gt_labels is None:
+                labels[pos_inds] = 0
+            else:
+                labels[pos_inds] = gt_labels[sampling_result.pos_assigned_gt_inds]
+            label_weights[pos_inds] = 1.0 if self.train_cfg.pos_weight <= 0 \
+                else self.train_cfg.pos_weight
+        if len(neg_inds) > 0:
+            label_weights[neg_inds] = 1.0
+        if unmap_outputs:
+            n = flat_anchors.size(0)
+            labels = unmap(labels, n, inside_flags, fill=self.num_classes)
+            label_weights = unmap(label_weights, n, inside_flags)
+            bbox_targets = unmap(bbox_targets, n, inside_flags)
+            bbox_weights = unmap(bbox_weights, n, inside_flags)
+        return (labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds,
+                sampling_result)
+
+
+@HEADS.register_module()
+class ATSSRPNHead(AnchorHead):
+    def __init__(self, in_channels, num_classes=1, stacked_convs=4, conv_cfg=None, gamma=1,
+                 atss=False, bridge=False, last_conv='norm', aug_reg_loss=None,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=0.5),
+                 init_cfg=None, num_convs=1, **kwargs):
+        assert not atss, 'atss=True (ATSSAssigner targets) is outside the shipped boosting configs'
+        assert not bridge and last_conv == 'norm', 'bridge / dcn / aspp variants are out of scope'
+        self.stacked_convs, self.conv_cfg, self.norm_cfg = stacked_convs, conv_cfg, norm_cfg
+        self.last_conv = last_conv
+        super().__init__(num_classes, in_channels, init_cfg=init_cfg, **kwargs)
+        self.loss_centerness = build_loss(loss_centerness)
+        self.gamma, self.atss, self.bridge = gamma, atss, bridge
+        self.with_aug_loss = aug_reg_loss is not None
+        if self.with_aug_loss:
+            self.aug_loss = build_loss(aug_reg_loss)
+        self._head_caches = [PackedCache() for _ in range(8)]
+        self._base_anchor_cache = {}
+        self.init_weights()
+
+    def _init_layers(self):
+        self.rpn_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.rpn_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                                             conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        self.rpn_cls = nn.Conv2d(self.feat_channels, self.num_anchors * self.cls_out_channels, 3,
+                                 padding=1)
+        self.rpn_reg = nn.Conv2d(self.feat_channels, self.num_anchors * 4, 3, padding=1)
+        self.rpn_iou = nn.Conv2d(self.feat_channels, self.num_anchors * 1, 3, padding=1)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in self.anchor_generator.strides])
+
+    def init_weights(self):
+        """Normal(0, 0.01) convs, rpn_cls bias for prior 0.01 (atss_rpn_head.py:123-131)"""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.rpn_cls.bias, bias_init_with_prob(0.01))
+
+    # ------------------------------------------------------------------ forward
+    def forward_single_nhwc(self, x, level):
+        for conv in self.rpn_convs:
+            x = conv.forward_nhwc(x)
+        scale = self.scales[level].scale
+        cls = self._head_conv(x, self.rpn_cls, self._head_caches[0], None)
+        reg = self._head_conv(x, self.rpn_reg, self._head_caches[1 + level], scale)
+        iou = self._head_conv(x, self.rpn_iou, self._head_caches[7], None)
+        return cls, reg, iou
+
+    @staticmethod
+    def _head_conv(x, conv, cache, scale):
+        srcs = [conv.weight, conv.bias] + ([scale] if scale is not None else [])
+
+        def builder():
+            from .blocks import pack_weight
+            w = pack_weight(conv.weight)
+            b = conv.bias.detach().float()
+            if scale is None:
+                return w, None, b.contiguous()
+            s = scale.detach().float().expand(conv.out_channels).contiguous()
+            return w, s, (b * s).contiguous()   # scale*(conv+b) = conv*s + b*s
+
+        w, s, b = cache.get(srcs, builder)
+        return ops.conv2d_nhwc(x, w, s, b, None, False, 1, conv.padding[0])
+
+    def forward_nhwc(self, feats):
+        """feats: list of (N,h,w,C) -> 3 lists of (N,h,w,A | 4A | A) NHWC head outputs"""
+        outs = [self.forward_single_nhwc(f, i) for i, f in enumerate(feats)]
+        return tuple(map(list, zip(*outs)))
+
+    def forward(self, feats, bridge=False):
+        """reference signature: list of (N,C,h,w) -> lists of (N,A,h,w), (N,4A,h,w), (N,A,h,w)"""
+        cls, reg, iou = self.forward_nhwc([to_nhwc(f) for f in feats])
+        v = lambda lst: [t.permute(0, 3, 1, 2) for t in lst]  # noqa: E731
+        return v(cls), v(reg), v(iou)
+
+    # ------------------------------------------------------------------ train
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None,
+                      proposal_cfg=None, **kwargs):
+        outs = self(x)
+        if gt_labels is None:
+            loss_inputs = outs + (gt_bboxes, img_metas)
+        else:
+            loss_inputs = outs + (gt_bboxes, gt_labels, img_metas)
+        losses = self.loss(*loss_inputs, gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
+
+    def get_targets(self, anchor_list, valid_flag_list, gt_bboxes_list, img_metas,
+                    gt_bboxes_ignore_list=None, gt_labels_list=None, label_channels=1,
+                    unmap_outputs=True):
+        num_imgs = len(img_metas)
+        assert len(anchor_list) == len(valid_flag_list) == num_imgs
+        concat_anchor_list = [torch.cat(a) for a in anchor_list]
+        concat_valid_flag_list = [torch.cat(v) for v in valid_flag_list]
+        if gt_bboxes_ignore_list is None:
+            gt_bboxes_ignore_list = [None] * num_imgs
+        if gt_labels_list is None:
+            gt_labels_list = [None] * num_imgs
+        (labels, label_weights, bbox_targets, bbox_weights, _, _, sampling_result) = multi_apply(
+            self._get_targets_single, concat_anchor_list, concat_valid_flag_list, gt_bboxes_list,
+            gt_bboxes_ignore_list, gt_labels_list, img_metas, label_channels=1, unmap_outputs=True)
+        if any(l is None for l in labels):
+            return None
+        pos_inds = [((0 <= l) & (l < self.num_classes)).nonzero().view(-1) for l in labels]
+        gt_inds = [s.pos_assigned_gt_inds for s in sampling_result]
+        return (labels, label_weights, bbox_targets, bbox_weights, pos_inds, gt_inds,
+                concat_anchor_list, concat_valid_flag_list)
+
+    def loss_single(self, anchors, cls_score, bbox_pred, iou_pred, labels, label_weights,
+                    bbox_targets, num_total_samples):
+        anchors = anchors.reshape(-1, 4)
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels).contiguous()
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 4)
+        iou_pred = iou_pred.permute(0, 2, 3, 1).reshape(-1)
+        bbox_targets = bbox_targets.reshape(-1, 4)
+        labels = labels.reshape(-1)
+        label_weights = label_weights.reshape(-1)
+        pos_inds = ((labels >= 0) & (labels < self.num_classes)).nonzero().squeeze(1)
+        if len(pos_inds) > 0:
+            pos_bbox_targets = bbox_targets[pos_inds]
+            pos_bbox_pred = bbox_pred[pos_inds]
+            pos_anchors = anchors[pos_inds]
+            pos_ious = iou_pred[pos_inds]
+            if self.reg_decoded_bbox:
+                pos_decode_bbox_pred = self.bbox_coder.decode(pos_anchors, pos_bbox_pred)
+                pos_encode_bbox_targets = self.bbox_coder.encode(pos_anchors, pos_bbox_targets)
+                iou_target = bbox_overlaps(pos_decode_bbox_pred.detach(), pos_bbox_targets,
+                                           is_aligned=True)
+                if self.with_aug_loss:
+                    w_aug = torch.ones_like(pos_bbox_pred) * (iou_target ** self.gamma)[:, None]
+                    loss_bbox_aug = self.aug_loss(pos_bbox_pred, pos_encode_bbox_targets,
+                                                  w_aug.clamp(min=EPS), avg_factor=1.0)
+                bbox_weights = iou_target ** self.gamma
+                loss_bbox = self.loss_bbox(pos_decode_bbox_pred, pos_bbox_targets,
+                                           weight=bbox_weights.clamp(min=EPS), avg_factor=1.0)
+                if self.with_aug_loss:
+                    loss_bbox = (loss_bbox + loss_bbox_aug) * 0.5
+            else:
+                pos_decode_bbox_pred = self.bbox_coder.decode(pos_anchors, pos_bbox_pred)
+                pos_decode_bbox_targets = self.bbox_coder.decode(pos_anchors, pos_bbox_targets)
+                iou_target = bbox_overlaps(pos_decode_bbox_pred.detach(), pos_decode_bbox_targets,
+                                           is_aligned=True)
+                bbox_weights = torch.ones_like(pos_bbox_pred) * (iou_target ** self.gamma)[:, None]
+                loss_bbox = self.loss_bbox(pos_bbox_pred, pos_bbox_targets,
+                                           bbox_weights.clamp(min=EPS), avg_factor=1.0)
+            avg_factor = iou_target.sum()
+            loss_iou = self.loss_centerness(pos_ious, iou_target, avg_factor=num_total_samples)
+        else:
+            loss_bbox = bbox_pred.sum() * 0
+            loss_iou = iou_pred.sum() * 0
+            iou_target = bbox_targets.new_tensor(0.)
+            avg_factor = iou_target.sum()
+        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        return loss_cls, loss_bbox, loss_iou, avg_factor
+
+    def loss(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None):
+        featmap_sizes = [f.size()[-2:] for f in cls_scores]
+        assert len(featmap_sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
+        label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
+                                   gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None,
+                                   label_channels=label_channels)
+        if targets is None:
+            return None
+        (labels_list, label_weights_list, bbox_targets_list, _, pos_inds, _, anchor_list, _) = targets
+        labels_list = images_to_levels(labels_list, num_level_anchors)
+        label_weights_list = images_to_levels(label_weights_list, num_level_anchors)
+        anchor_list = images_to_levels(anchor_list, num_level_anchors)
+        bbox_targets_list = images_to_levels(bbox_targets_list, num_level_anchors)
+        num_total_pos = sum(p.numel() for p in pos_inds)
+        num_total_samples = reduce_mean(
+            torch.tensor(num_total_pos, dtype=torch.float, device=device)).item()
+        num_total_samples = max(num_total_samples, 1.0)
+        losses_cls, losses_bbox, losses_iou, bbox_avg_factor = multi_apply(
+            self.loss_single, anchor_list, cls_scores, bbox_preds, iou_preds, labels_list,
+            label_weights_list, bbox_targets_list, num_total_samples=num_total_samples)
+        bbox_avg_factor = sum(bbox_avg_factor)
+        bbox_avg_factor = reduce_mean(bbox_avg_factor).clamp_(min=1).item()
+        losses_bbox = [x / bbox_avg_factor for x in losses_bbox]
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox, loss_rpn_iou=losses_iou)
+
+    # ------------------------------------------------------------------ proposals
+    def _base_anchors(self, level, device):
+        key = (level, str(device))
+        if key not in self._base_anchor_cache:
+            self._base_anchor_cache[key] = self.anchor_generator.base_anchors[level].to(device)
+        return self._base_anchor_cache[key]
+
+    def get_bboxes_padded(self, cls_nhwc, reg_nhwc, iou_nhwc, img_metas, cfg=None):
+        """Device-resident proposal stage for the whole batch (no host sync).
+
+        Inputs are the NHWC head outputs per level: (B,h,w,A), (B,h,w,4A), (B,h,w,A).
+        Returns (dets (B, max_per_img, 5) zero-padded, num (B,) int32)."""
+        cfg = copy.deepcopy(self.test_cfg if cfg is None else cfg)
+        assert self.use_sigmoid_cls and self.cls_out_channels == 1
+        nms_cfg = dict(cfg.nms)
+        assert nms_cfg.pop('type', 'nms') == 'nms', 'RPN proposals use greedy NMS'
+        B = cls_nhwc[0].shape[0]
+        device = cls_nhwc[0].device
+        shapes = {tuple(m['img_shape'][:2]) for m in img_metas}
+        A = self.num_anchors
+        sc_l, pr_l, va_l, id_l = [], [], [], []
+        for lvl in range(len(cls_nhwc)):
+            h, w = cls_nhwc[lvl].shape[1:3]
+            n = h * w * A
+            score = ops.rpn_score(cls_nhwc[lvl], iou_nhwc[lvl]).view(B, n)
+            if cfg.nms_pre > 0 and n > cfg.nms_pre:
+                # descending, ties by ascending index (the shared tie rule)
+                ranked, rank_inds = score.sort(dim=1, descending=True, stable=True)
+                topk_inds = rank_inds[:, :cfg.nms_pre].contiguous()
+                score = ranked[:, :cfg.nms_pre]
+            else:
+                topk_inds = torch.arange(n, device=device).expand(B, n).contiguous()
+            stride = self.anchor_generator.strides[lvl]
+            if len(shapes) == 1:
+                max_shape = next(iter(shapes))
+                props, valid = ops.rpn_decode(topk_inds, reg_nhwc[lvl], self._base_anchors(lvl, device),
+                                              (h, w), stride, self.bbox_coder.means,
+                                              self.bbox_coder.stds, max_shape, cfg.min_bbox_size)
+            else:   # per-image clip border
+                pl, vl = [], []
+                for b in range(B):
+                    p1, v1 = ops.rpn_decode(topk_inds[b:b + 1], reg_nhwc[lvl][b:b + 1],
+                                            self._base_anchors(lvl, device), (h, w), stride,
+                                            self.bbox_coder.means, self.bbox_coder.stds,
+                                            img_metas[b]['img_shape'][:2], cfg.min_bbox_size)
+                    pl.append(p1)
+                    vl.append(v1)
+                props, valid = torch.cat(pl), torch.cat(vl)
+            if cfg.min_bbox_size < 0:
+                valid = torch.ones_like(valid)
+            sc_l.append(score)
+            pr_l.append(props)
+            va_l.append(valid.bool())
+            id_l.append(torch.full((B, score.shape[1]), lvl, dtype=torch.long, device=device))
+        scores = torch.cat(sc_l, 1)            # (B, T)
+        props = torch.cat(pr_l, 1)             # (B, T, 4)
+        valid = torch.cat(va_l, 1)             # (B, T)  `proposals[valid_mask]` (:750-754)
+        ids = torch.cat(id_l, 1)
+        assert scores.shape[1] < nms_cfg.get('split_thr', 10000), \
+            'device-resident path covers mmcv batched_nms below split_thr'
+        dets, _, num = batched_nms_images(props, scores, ids, valid, nms_cfg['iou_threshold'],
+                                          cfg.max_per_img, nms_cfg.get('offset', 0))
+        return dets, num
+
+    def get_bboxes(self, cls_scores, bbox_preds, iou_preds, img_metas, cfg=None, rescale=False,
+                   with_nms=True):
+        """reference signature (atss_rpn_head.py:466-503): per-level (N,A,h,w) / (N,4A,h,w) /
+        (N,A,h,w) -> list of (k,5) proposals per image."""
+        assert with_nms, '``with_nms`` in RPNHead should always True'
+        assert len(cls_scores) == len(bbox_preds)
+        f = lambda lst: [to_nhwc(t.detach()).contiguous() for t in lst]  # noqa: E731
+        dets, num = self.get_bboxes_padded(f(cls_scores), f(bbox_preds), f(iou_preds), img_metas, cfg)
+        num = num.tolist()   # the one host sync of the proposal stage
+        return [dets[i, :num[i]] for i in range(len(img_metas))]
+
+    def simple_test_rpn(self, x, img_metas):
+        cls_scores, bbox_preds, iou_preds = self(x)
+        return self.get_bboxes(cls_scores, bbox_preds, iou_preds, img_metas)

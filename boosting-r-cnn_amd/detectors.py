@@ -1,0 +1,183 @@
+"""Detector shell: `FasterRCNN` (a `TwoStageDetector`) wiring backbone -> neck -> RetinaRPN
+-> Boosting RoI head, with the reference's calling conventions.
+
+Mirrors mmdet/models/detectors/{base.py:112-244, two_stage.py:18-182, faster_rcnn.py:24-43}:
+`detector(img=..., img_metas=..., return_loss=..., **gt)`, `forward_test` (list-of-aug inputs,
+sets `batch_input_shape`), `simple_test -> list[list[ndarray(k,5)]]`,
+`train_step(data, optimizer) -> dict(loss, log_vars, num_samples)`, `_parse_losses` (sum of
+every entry whose key contains 'loss'; log scalars averaged over ranks).
+
+`simple_test` keeps the whole batch on the device between stages (NHWC feature maps, padded
+proposals with counts) and synchronises with the host once, when results are copied out.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .blocks import to_nchw_view, to_nhwc
+from .core import bbox2result
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+class BaseDetector(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+        self.fp16_enabled = False
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    @property
+    def with_rpn(self):
+        return hasattr(self, 'rpn_head') and self.rpn_head is not None
+
+    @property
+    def with_roi_head(self):
+        return hasattr(self, 'roi_head') and self.roi_head is not None
+
+    def init_weights(self):
+        pass   # submodules initialise themselves at construction (seeded synthetic weights)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        num_augs = len(imgs)
+        if num_augs != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) '
+                             f'!= num of image meta ({len(img_metas)})')
+        for img, img_meta in zip(imgs, img_metas):
+            for img_id in range(len(img_meta)):
+                img_meta[img_id]['batch_input_shape'] = tuple(img.size()[-2:])
+        if num_augs == 1:
+            if 'proposals' in kwargs:
+                kwargs['proposals'] = kwargs['proposals'][0]
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        raise NotImplementedError('test-time augmentation is outside the hot path')
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def _parse_losses(self, losses):
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        names = list(log_vars.keys())
+        vals = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
+        if dist.is_available() and dist.is_initialized():
+            # the reference issues one all-reduce per scalar (base.py:202-207); same values,
+            # one fused collective
+            vals = vals.clone()
+            dist.all_reduce(vals.div_(dist.get_world_size()))
+        for k, v in zip(names, vals.tolist()):
+            log_vars[k] = v
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    def val_step(self, data, optimizer=None):
+        return self.train_step(data, optimizer)
+
+
+@DETECTORS.register_module()
+class TwoStageDetector(BaseDetector):
+    def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None,
+                 test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        if rpn_head is not None:
+            rpn_train_cfg = train_cfg.rpn if train_cfg is not None else None
+            rpn_head_ = rpn_head.copy()
+            rpn_head_.update(train_cfg=rpn_train_cfg, test_cfg=test_cfg.rpn)
+            self.rpn_head = build_head(rpn_head_)
+        if roi_head is not None:
+            rcnn_train_cfg = train_cfg.rcnn if train_cfg is not None else None
+            roi_head = roi_head.copy()
+            roi_head.update(train_cfg=rcnn_train_cfg)
+            roi_head.update(test_cfg=test_cfg.rcnn)
+            self.roi_head = build_head(roi_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    # ---- features ----------------------------------------------------------------------
+    def extract_feat_nhwc(self, img):
+        x = self.backbone.forward_nhwc(to_nhwc(img))
+        if self.with_neck:
+            x = self.neck.forward_nhwc(x)
+        return x
+
+    def extract_feat(self, img):
+        return tuple(to_nchw_view(f) for f in self.extract_feat_nhwc(img))
+
+    # ---- train ---------------------------------------------------------------------------
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
+                      gt_masks=None, proposals=None, **kwargs):
+        x = self.extract_feat(img)
+        losses = dict()
+        if self.with_rpn:
+            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            rpn_losses, proposal_list = self.rpn_head.forward_train(
+                x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=gt_bboxes_ignore,
+                proposal_cfg=proposal_cfg, **kwargs)
+            losses.update(rpn_losses)
+        else:
+            proposal_list = proposals
+        roi_losses = self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
+                                                 gt_bboxes_ignore, gt_masks, **kwargs)
+        losses.update(roi_losses)
+        return losses
+
+    # ---- test ----------------------------------------------------------------------------
+    def simple_test_device(self, img, img_metas, rescale=False):
+        """Whole inference pass with no host synchronisation: returns device tensors
+        (det_bboxes (B,M,5), det_labels (B,M), num_dets (B,))."""
+        feats = self.extract_feat_nhwc(img)
+        cls, reg, iou = self.rpn_head.forward_nhwc(list(feats))
+        dets, num = self.rpn_head.get_bboxes_padded(cls, reg, iou, img_metas)
+        return self.roi_head.simple_test_padded(feats, dets, num, img_metas, rescale=rescale)
+
+    def simple_test(self, img, img_metas, proposals=None, rescale=False):
+        assert self.with_roi_head, 'Bbox head must be implemented.'
+        if proposals is None and self._device_path_ok():
+            det, lab, nd = self.simple_test_device(img, img_metas, rescale)
+            det, lab, nd = det.cpu(), lab.cpu(), nd.tolist()   # the one host sync
+            nc = self.roi_head.bbox_head.num_classes
+            return [bbox2result(det[i, :nd[i]], lab[i, :nd[i]], nc) for i in range(len(img_metas))]
+        x = self.extract_feat(img)
+        proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+
+    def _device_path_ok(self):
+        rc, rp = self.test_cfg.rcnn, self.test_cfg.rpn
+        k, c = rp.max_per_img, self.roi_head.bbox_head.num_classes
+        return rc.nms.get('type', 'nms') == 'nms' and rp.nms.get('type', 'nms') == 'nms' and \
+            k * c < rc.nms.get('split_thr', 10000)
+
+
+@DETECTORS.register_module()
+class FasterRCNN(TwoStageDetector):
+    """mmdet/models/detectors/faster_rcnn.py:24-43 (the fork's DG/EMA research variants in the
+    same file are outside the hot path)."""
+
+    def __init__(self, backbone, rpn_head, roi_head, train_cfg, test_cfg, neck=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__(backbone=backbone, neck=neck, rpn_head=rpn_head, roi_head=roi_head,
+                         train_cfg=train_cfg, test_cfg=test_cfg, pretrained=pretrained,
+                         init_cfg=init_cfg)

@@ -1,0 +1,141 @@
+"""FPN / PAFPN necks on NHWC activations.
+
+Mirrors `mmdet/models/necks/fpn.py:63-204` and `mmdet/models/necks/pafpn.py:12-158`
+(constructor arguments, `lateral_convs / fpn_convs / downsample_convs / pafpn_convs`
+ModuleLists of ConvModules -> the reference's state-dict keys, forward data flow).  The
+top-down `laterals[i-1] += interpolate(laterals[i])` is one fused nearest-upsample-add
+kernel; the bottom-up `inter_outs[i+1] += downsample_conv(inter_outs[i])` is the residual
+operand of the stride-2 conv's epilogue.
+"""
+import torch.nn as nn
+
+from . import ops
+from .blocks import ConvModule, to_nchw_view, to_nhwc
+from .registry import NECKS
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1,
+                 add_extra_convs=False, relu_before_extra_convs=False, no_norm_on_lateral=False,
+                 conv_cfg=None, norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest'),
+                 init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform')):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        assert upsample_cfg.get('mode', 'nearest') == 'nearest' and 'scale_factor' not in upsample_cfg
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.relu_before_extra_convs = relu_before_extra_convs
+        self.no_norm_on_lateral = no_norm_on_lateral
+        if end_level == -1:
+            self.backbone_end_level = self.num_ins
+            assert num_outs >= self.num_ins - start_level
+        else:
+            self.backbone_end_level = end_level
+            assert end_level <= len(in_channels)
+            assert num_outs == end_level - start_level
+        self.start_level, self.end_level = start_level, end_level
+        self.add_extra_convs = add_extra_convs
+        assert isinstance(add_extra_convs, (str, bool))
+        if isinstance(add_extra_convs, str):
+            assert add_extra_convs in ('on_input', 'on_lateral', 'on_output')
+        elif add_extra_convs:
+            self.add_extra_convs = 'on_input'
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(
+                in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
+                norm_cfg=norm_cfg if not no_norm_on_lateral else None, act_cfg=act_cfg,
+                inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1,
+                                             conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg,
+                                             inplace=False))
+        extra_levels = num_outs - self.backbone_end_level + self.start_level
+        if self.add_extra_convs and extra_levels >= 1:
+            for i in range(extra_levels):
+                if i == 0 and self.add_extra_convs == 'on_input':
+                    cin = self.in_channels[self.backbone_end_level - 1]
+                else:
+                    cin = out_channels
+                self.fpn_convs.append(ConvModule(cin, out_channels, 3, stride=2, padding=1,
+                                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                                 act_cfg=act_cfg, inplace=False))
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight, gain=1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _laterals(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [conv.forward_nhwc(inputs[i + self.start_level])
+                    for i, conv in enumerate(self.lateral_convs)]
+        for i in range(len(laterals) - 1, 0, -1):
+            ops.upsample_nearest_add_nhwc_(laterals[i - 1], laterals[i])
+        return laterals
+
+    def _extra(self, inputs, laterals, outs):
+        used = len(laterals)
+        if self.num_outs > len(outs):
+            if not self.add_extra_convs:
+                for _ in range(self.num_outs - used):
+                    outs.append(outs[-1][:, ::2, ::2, :].contiguous())   # max_pool2d(k=1, s=2)
+            else:
+                if self.add_extra_convs == 'on_input':
+                    src = inputs[self.backbone_end_level - 1]
+                elif self.add_extra_convs == 'on_lateral':
+                    src = laterals[-1]
+                else:
+                    src = outs[-1]
+                outs.append(self.fpn_convs[used].forward_nhwc(src))
+                for i in range(used + 1, self.num_outs):
+                    x = outs[-1].relu() if self.relu_before_extra_convs else outs[-1]
+                    outs.append(self.fpn_convs[i].forward_nhwc(x))
+        return outs
+
+    def forward_nhwc(self, inputs):
+        laterals = self._laterals(inputs)
+        outs = [self.fpn_convs[i].forward_nhwc(laterals[i]) for i in range(len(laterals))]
+        return tuple(self._extra(inputs, laterals, outs))
+
+    def forward(self, inputs):
+        return tuple(to_nchw_view(o) for o in self.forward_nhwc([to_nhwc(x) for x in inputs]))
+
+
+@NECKS.register_module()
+class PAFPN(FPN):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1,
+                 add_extra_convs=False, relu_before_extra_convs=False, no_norm_on_lateral=False,
+                 conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform')):
+        super().__init__(in_channels, out_channels, num_outs, start_level, end_level,
+                         add_extra_convs, relu_before_extra_convs, no_norm_on_lateral, conv_cfg,
+                         norm_cfg, act_cfg, init_cfg=init_cfg)
+        self.downsample_convs = nn.ModuleList()
+        self.pafpn_convs = nn.ModuleList()
+        for i in range(self.start_level + 1, self.backbone_end_level):
+            self.downsample_convs.append(ConvModule(out_channels, out_channels, 3, stride=2,
+                                                    padding=1, conv_cfg=conv_cfg,
+                                                    norm_cfg=norm_cfg, act_cfg=act_cfg,
+                                                    inplace=False))
+            self.pafpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1,
+                                               conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                               act_cfg=act_cfg, inplace=False))
+        self.init_weights()
+
+    def forward_nhwc(self, inputs):
+        laterals = self._laterals(inputs)
+        used = len(laterals)
+        inter = [self.fpn_convs[i].forward_nhwc(laterals[i]) for i in range(used)]
+        for i in range(used - 1):
+            d = self.downsample_convs[i]
+            if d.with_norm or d.with_activation:
+                inter[i + 1] = inter[i + 1] + d.forward_nhwc(inter[i])
+            else:   # inter[i+1] += conv(inter[i]) as the conv epilogue's residual operand
+                inter[i + 1] = d.forward_nhwc(inter[i], residual=inter[i + 1])
+        outs = [inter[0]] + [self.pafpn_convs[i - 1].forward_nhwc(inter[i]) for i in range(1, used)]
+        return tuple(self._extra(inputs, laterals, outs))

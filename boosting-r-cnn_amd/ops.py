@@ -177,14 +177,23 @@ def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56,
 # ----------------------------------------------------------------------------- NMS
 def nms_segments(boxes, scores, seg_offsets, max_segment_len, iou_threshold, offset=0,
                  max_keep=-1):
-    """Segmented greedy NMS, no host sync.  Returns (keep (n,) int64, num_keep (S,) int32):
-    segment s's survivors (global indices, score order) sit at keep[seg_offsets[s]:][:num_keep[s]]."""
-    _require_gpu(boxes, scores, seg_offsets)
+    """back-to-back segments given as (S+1) offsets; see nms_ranges"""
+    seg_offsets = seg_offsets.contiguous().to(torch.int32)
+    ranges = torch.stack([seg_offsets[:-1], seg_offsets[1:]], 1)
+    return nms_ranges(boxes, scores, ranges, max_segment_len, iou_threshold, offset, max_keep)
+
+
+def nms_ranges(boxes, scores, ranges, max_segment_len, iou_threshold, offset=0, max_keep=-1):
+    """Segmented greedy NMS, no host sync.  `ranges` (S,2) int32 [begin, end) per segment.
+    Returns (keep (n,) int64, num_keep (S,) int32): segment s's survivors (global indices,
+    score order) sit at keep[begin_s:][:num_keep[s]]."""
+    _require_gpu(boxes, scores, ranges)
     boxes = boxes.contiguous().float()
     scores = scores.contiguous().float()
-    seg_offsets = seg_offsets.contiguous().to(torch.int32)
+    ranges = ranges.to(torch.int32)
+    seg_begin, seg_end = ranges[:, 0].contiguous(), ranges[:, 1].contiguous()
     n = boxes.size(0)
-    S = seg_offsets.numel() - 1
+    S = seg_begin.numel()
     keep = torch.empty((max(n, 1),), dtype=torch.int64, device=boxes.device)
     num_keep = torch.zeros((S,), dtype=torch.int32, device=boxes.device)
     if n == 0:
@@ -193,7 +202,8 @@ def nms_segments(boxes, scores, seg_offsets, max_segment_len, iou_threshold, off
     max_segment_len = max(1, min(int(max_segment_len), n))
     wsb = lib.brcnn_nms_workspace_bytes(n, S, max_segment_len)
     ws = _ws(wsb, boxes.device)
-    st = lib.brcnn_nms(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), S, n, max_segment_len,
+    st = lib.brcnn_nms(_ptr(boxes), _ptr(scores), _ptr(seg_begin), _ptr(seg_end), S, n,
+                       max_segment_len,
                        float(iou_threshold), int(offset), int(max_keep), _ptr(keep),
                        _ptr(num_keep), _ptr(ws), wsb, _stream())
     _L.check(st, 'brcnn_nms')
@@ -244,7 +254,8 @@ def soft_nms_segments(boxes, scores, seg_offsets, iou_threshold=0.3, sigma=0.5, 
     lib = _L.load()
     wsb = lib.brcnn_softnms_workspace_bytes(n, S)
     ws = _ws(wsb, boxes.device)
-    st = lib.brcnn_softnms(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), S, n,
+    sb, se = seg_offsets[:-1].contiguous(), seg_offsets[1:].contiguous()
+    st = lib.brcnn_softnms(_ptr(boxes), _ptr(scores), _ptr(sb), _ptr(se), S, n,
                            float(iou_threshold), float(sigma), float(min_score), int(method),
                            int(offset), _ptr(dets), _ptr(inds), _ptr(num_keep), _ptr(ws), wsb,
                            _stream())

@@ -1,0 +1,476 @@
+"""Boosting R-CNN second stage: RoI feature extraction, the 2-FC box head, the boosting
+re-weighted loss and the prior-fused test-time scoring.
+
+Mirrors mmdet/models/roi_heads/{prob_roi_head.py:10-283 (ProbRoIHead),
+standard_roi_head.py, base_roi_head.py}, roi_extractors/{base_roi_extractor.py:37-60,
+single_level_roi_extractor.py:36-115}, bbox_heads/{bbox_head.py:19-253,
+convfc_bbox_head.py:25-192,283-451 (ProbConvFCBBoxHead)}: same registry names, constructor
+arguments and parameter names (`bbox_head.{shared_fcs.{i},fc_cls,fc_reg}`).  Execution:
+  * RoI extraction = one fused launch (level mapping + RoIAlign on NHWC maps);
+  * the FCs are MFMA GEMMs on the (K,7,7,C) RoI tensor; the first FC's weight columns are
+    permuted once from the reference's (C,7,7) flatten order to (7,7,C);
+  * test-time: sqrt(softmax * prior), per-class decode, threshold, class-aware NMS for the
+    whole batch stay on the device (postprocess.batched_nms_images).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .blocks import PackedCache, to_nhwc
+from .core import bbox2result, bbox2roi, bbox_overlaps, multi_apply, multiclass_nms
+from .losses import accuracy
+from .postprocess import batched_nms_images
+from .registry import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head,
+                       build_loss, build_roi_extractor, build_sampler)
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+# ----------------------------------------------------------------------------- extractor
+@ROI_EXTRACTORS.register_module()
+class SingleRoIExtractor(nn.Module):
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56, init_cfg=None):
+        super().__init__()
+        self.roi_layers = self.build_roi_layers(roi_layer, featmap_strides)
+        self.out_channels = out_channels
+        self.featmap_strides = featmap_strides
+        self.finest_scale = finest_scale
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def build_roi_layers(self, layer_cfg, featmap_strides):
+        """`getattr(ops, type)`: the plugin seam of base_roi_extractor.py:54-60, resolved
+        against this package's operator namespace."""
+        cfg = dict(layer_cfg)
+        layer_type = cfg.pop('type')
+        assert hasattr(ops, layer_type)
+        layer_cls = getattr(ops, layer_type)
+        return nn.ModuleList([layer_cls(spatial_scale=1 / s, **cfg) for s in featmap_strides])
+
+    def map_roi_levels(self, rois, num_levels):
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        target_lvls = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
+        return target_lvls.clamp(min=0, max=num_levels - 1).long()
+
+    def _fusable(self):
+        l0 = self.roi_layers[0]
+        return all(isinstance(l, ops.RoIAlign) and l.pool_mode == 'avg' and l.aligned and
+                   l.output_size == l0.output_size and l.sampling_ratio == l0.sampling_ratio
+                   for l in self.roi_layers)
+
+    def forward_nhwc(self, feats_nhwc, rois):
+        """(K, ph, pw, C) RoI features from NHWC maps, one launch."""
+        assert self._fusable()
+        l0 = self.roi_layers[0]
+        out, _ = ops.roi_extract(list(feats_nhwc[:self.num_inputs]), rois, l0.output_size,
+                                 self.featmap_strides, self.finest_scale, l0.sampling_ratio)
+        return out
+
+    def forward(self, feats, rois, roi_scale_factor=None):
+        """reference signature: feats tuple of (N,C,h,w), rois (K,5) -> (K,C,ph,pw)"""
+        assert roi_scale_factor is None
+        if self._fusable() and feats[0].shape[1] % 4 == 0:
+            out = self.forward_nhwc([to_nhwc(f).contiguous() for f in feats], rois)
+            return out.permute(0, 3, 1, 2)
+        out_size = self.roi_layers[0].output_size
+        num_levels = len(feats)
+        roi_feats = feats[0].new_zeros(rois.size(0), self.out_channels, *out_size)
+        if num_levels == 1:
+            return roi_feats if len(rois) == 0 else self.roi_layers[0](feats[0], rois)
+        target_lvls = self.map_roi_levels(rois, num_levels)
+        for i in range(num_levels):
+            inds = (target_lvls == i).nonzero(as_tuple=False).squeeze(1)
+            if inds.numel() > 0:
+                roi_feats[inds] = self.roi_layers[i](feats[i], rois[inds])
+        return roi_feats
+
+
+# ----------------------------------------------------------------------------- bbox head
+@HEADS.register_module()
+class ProbConvFCBBoxHead(nn.Module):
+    """ConvFCBBoxHead restricted to what the boosting configs build (shared FCs only;
+    the VOC config's cls-FC / reg-conv GN branches are a later row)."""
+
+    def __init__(self, num_shared_convs=0, num_shared_fcs=0, num_cls_convs=0, num_cls_fcs=0,
+                 num_reg_convs=0, num_reg_fcs=0, conv_out_channels=256, fc_out_channels=1024,
+                 conv_cfg=None, norm_cfg=None, init_cfg=None, focal_reg=False, gamma=1,
+                 with_avg_pool=False, with_cls=True, with_reg=True, roi_feat_size=7,
+                 in_channels=256, num_classes=80,
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True,
+                                 target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2]),
+                 reg_class_agnostic=False, reg_decoded_bbox=False,
+                 reg_predictor_cfg=dict(type='Linear'), cls_predictor_cfg=dict(type='Linear'),
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)):
+        super().__init__()
+        assert with_cls and with_reg and not with_avg_pool
+        assert num_shared_convs == num_cls_convs == num_reg_convs == 0 and \
+            num_cls_fcs == num_reg_fcs == 0 and num_shared_fcs > 0, \
+            'hot path: shared-FC box head (num_shared_fcs=2)'
+        assert reg_predictor_cfg.get('type') == 'Linear' and cls_predictor_cfg.get('type') == 'Linear'
+        self.with_cls, self.with_reg, self.with_avg_pool = with_cls, with_reg, with_avg_pool
+        self.roi_feat_size = _pair(roi_feat_size)
+        self.roi_feat_area = self.roi_feat_size[0] * self.roi_feat_size[1]
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.reg_class_agnostic, self.reg_decoded_bbox = reg_class_agnostic, reg_decoded_bbox
+        self.num_shared_fcs, self.fc_out_channels = num_shared_fcs, fc_out_channels
+        self.focal_reg, self.gamma = focal_reg, gamma
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.shared_fcs = nn.ModuleList()
+        last = in_channels * self.roi_feat_area
+        for i in range(num_shared_fcs):
+            self.shared_fcs.append(nn.Linear(last if i == 0 else fc_out_channels, fc_out_channels))
+        self.shared_out_channels = fc_out_channels
+        self.relu = nn.ReLU(inplace=True)
+        self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
+        self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
+        self._caches = [PackedCache() for _ in range(num_shared_fcs + 1)]
+        self.init_weights()
+
+    custom_cls_channels = False
+    custom_activation = False
+    custom_accuracy = False
+
+    def init_weights(self):
+        """Xavier for shared_fcs (convfc_bbox_head.py:102-112), Normal .01/.001 for fc_cls/fc_reg
+        (bbox_head.py:83-94)"""
+        for fc in self.shared_fcs:
+            nn.init.xavier_normal_(fc.weight, gain=1)
+            nn.init.constant_(fc.bias, 0)
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01)
+        nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001)
+        nn.init.constant_(self.fc_reg.bias, 0)
+
+    # ---- execution -------------------------------------------------------------------
+    def forward_nhwc(self, roi_feats):
+        """roi_feats (K, ph, pw, C) -> (cls_score (K,C+1), bbox_pred (K,4C))"""
+        k, ph, pw, c = roi_feats.shape
+        x = roi_feats.reshape(k, ph * pw * c)
+        for i, fc in enumerate(self.shared_fcs):
+            if i == 0:
+                def builder(fc=fc):   # (out, C*ph*pw) columns -> (ph,pw,C) order
+                    w = fc.weight.detach().float().view(-1, c, ph, pw).permute(0, 2, 3, 1)
+                    return w.reshape(fc.out_features, -1).contiguous(), \
+                        fc.bias.detach().float().contiguous()
+            else:
+                def builder(fc=fc):
+                    return fc.weight.detach().float().contiguous(), \
+                        fc.bias.detach().float().contiguous()
+            w, b = self._caches[i].get([fc.weight, fc.bias], builder)
+            x = ops.linear_nhwc(x, w, b, True)
+
+        def head_builder():   # fc_cls and fc_reg share the input: one GEMM
+            w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0).detach().float().contiguous()
+            b = torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0).detach().float().contiguous()
+            return w, b
+        w, b = self._caches[-1].get([self.fc_cls.weight, self.fc_cls.bias, self.fc_reg.weight,
+                                     self.fc_reg.bias], head_builder)
+        y = ops.linear_nhwc(x, w, b, False)
+        nc = self.fc_cls.out_features
+        return y[:, :nc], y[:, nc:]
+
+    def forward(self, x):
+        """reference signature: x (K,C,ph,pw) -> cls_score, bbox_pred"""
+        return self.forward_nhwc(to_nhwc(x).contiguous())
+
+    # ---- targets / loss ----------------------------------------------------------------
+    def _get_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, cfg):
+        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
+        num_samples = num_pos + num_neg
+        labels = pos_bboxes.new_full((num_samples,), self.num_classes, dtype=torch.long)
+        label_weights = pos_bboxes.new_zeros(num_samples)
+        bbox_targets = pos_bboxes.new_zeros(num_samples, 4)
+        bbox_weights = pos_bboxes.new_zeros(num_samples, 4)
+        if num_pos > 0:
+            labels[:num_pos] = pos_gt_labels
+            label_weights[:num_pos] = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
+            if not self.reg_decoded_bbox:
+                pos_bbox_targets = self.bbox_coder.encode(pos_bboxes, pos_gt_bboxes)
+            else:
+                pos_bbox_targets = pos_gt_bboxes
+            bbox_targets[:num_pos, :] = pos_bbox_targets
+            bbox_weights[:num_pos, :] = 1
+        if num_neg > 0:
+            label_weights[-num_neg:] = 1.0
+        return labels, label_weights, bbox_targets, bbox_weights
+
+    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        out = multi_apply(self._get_target_single,
+                          [r.pos_bboxes for r in sampling_results],
+                          [r.neg_bboxes for r in sampling_results],
+                          [r.pos_gt_bboxes for r in sampling_results],
+                          [r.pos_gt_labels for r in sampling_results], cfg=rcnn_train_cfg)
+        if concat:
+            out = tuple(torch.cat(o, 0) for o in out)
+        return out
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
+             reduction_override=None):
+        losses = dict()
+        if bbox_pred is not None:
+            bg = self.num_classes
+            pos = ((labels >= 0) & (labels < bg)).type(torch.bool)
+            if pos.any():
+                if self.reg_decoded_bbox:
+                    bbox_pred = self.bbox_coder.decode(rois[:, 1:], bbox_pred)
+                if self.reg_class_agnostic:
+                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), 4)[pos]
+                else:
+                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), -1, 4)[pos, labels[pos]]
+                if self.focal_reg:
+                    # (the reference evaluates iou_target unconditionally but only uses it here)
+                    if self.reg_decoded_bbox:
+                        iou_target = bbox_overlaps(pos_bbox_pred.detach(), bbox_targets[pos],
+                                                   is_aligned=True)
+                    else:
+                        dp = self.bbox_coder.decode(rois[pos, 1:], pos_bbox_pred)
+                        dt = self.bbox_coder.decode(rois[pos, 1:], bbox_targets[pos])
+                        iou_target = bbox_overlaps(dp.detach(), dt, is_aligned=True)
+                    bw = bbox_weights[pos] * iou_target[pos, None] ** self.gamma
+                    losses['loss_bbox'] = self.loss_bbox(
+                        pos_bbox_pred, bbox_targets[pos], bw.clamp(min=1e-12),
+                        avg_factor=iou_target[pos].sum(), reduction_override=reduction_override)
+                else:
+                    losses['loss_bbox'] = self.loss_bbox(
+                        pos_bbox_pred, bbox_targets[pos], bbox_weights[pos],
+                        avg_factor=bbox_targets.size(0), reduction_override=reduction_override)
+            else:
+                losses['loss_bbox'] = bbox_pred[pos].sum()
+        if cls_score is not None:
+            avg_factor = max(torch.sum(label_weights > 0).float().item(), 1.)
+            if cls_score.numel() > 0:
+                losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights,
+                                                   avg_factor=avg_factor,
+                                                   reduction_override=reduction_override)
+                losses['acc'] = accuracy(cls_score, labels)
+        return losses
+
+    # ---- test ------------------------------------------------------------------------
+    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False,
+                   cfg=None):
+        """ProbConvFCBBoxHead.get_bboxes (convfc_bbox_head.py:294-330): scores arrive already
+        fused (no softmax here)."""
+        scores = cls_score
+        if bbox_pred is not None:
+            bboxes = self.bbox_coder.decode(rois[..., 1:], bbox_pred, max_shape=img_shape)
+        else:
+            bboxes = rois[:, 1:].clone()
+            if img_shape is not None:
+                bboxes[:, [0, 2]].clamp_(min=0, max=img_shape[1])
+                bboxes[:, [1, 3]].clamp_(min=0, max=img_shape[0])
+        if rescale and bboxes.size(0) > 0:
+            scale_factor = bboxes.new_tensor(scale_factor)
+            bboxes = (bboxes.view(bboxes.size(0), -1, 4) / scale_factor).view(bboxes.size()[0], -1)
+        if cfg is None:
+            return bboxes, scores
+        return multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms, cfg.max_per_img)
+
+
+# ----------------------------------------------------------------------------- roi head
+@HEADS.register_module()
+class ProbRoIHead(nn.Module):
+    def __init__(self, alpha=0, gamma=0.1, boost=False, prob=True, ams=False, quality=False,
+                 iou_gamma=0, reg_norm='bbox_num', bbox_roi_extractor=None, bbox_head=None,
+                 mask_roi_extractor=None, mask_head=None, shared_head=None, train_cfg=None,
+                 test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        assert mask_head is None and shared_head is None and not ams, \
+            'mask / shared heads are outside the hot path'
+        self.alpha, self.gamma, self.boost, self.prob = alpha, gamma, boost, prob
+        self.quality, self.iou_gamma, self.reg_norm = quality, iou_gamma, reg_norm
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+        self.bbox_head = build_head(bbox_head)
+        self.bbox_assigner = self.bbox_sampler = None
+        if self.train_cfg:
+            self.bbox_assigner = build_assigner(self.train_cfg.assigner)
+            self.bbox_sampler = build_sampler(self.train_cfg.sampler, context=self)
+
+    with_bbox = True
+    with_mask = False
+    with_shared_head = False
+
+    # ---- train -------------------------------------------------------------------------
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels,
+                      gt_bboxes_ignore=None, gt_masks=None):
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        sampling_results, priors, ious = [], [], []
+        for i in range(num_imgs):
+            assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i],
+                                                      gt_bboxes_ignore[i], gt_labels[i])
+            sampling_result = self.bbox_sampler.sample(assign_result, proposal_list[i],
+                                                       gt_bboxes[i], gt_labels[i],
+                                                       feats=[lvl[i][None] for lvl in x])
+            sampling_results.append(sampling_result)
+            # prior extraction (prob_roi_head.py:51-64): assumes the first num_gts sampled
+            # positives are the GT boxes themselves
+            num_gts = assign_result.num_gts
+            pos_inds = sampling_result.pos_inds[num_gts:].clone() - num_gts
+            neg_inds = sampling_result.neg_inds.clone() - num_gts
+            pos_prior = proposal_list[i][pos_inds, -1].clone()
+            neg_prior = 1 - proposal_list[i][neg_inds, -1].clone()
+            gt_weights = pos_prior.new_zeros(num_gts)
+            if self.quality:
+                pos_ious = assign_result.max_overlaps[sampling_result.pos_inds]
+                neg_ious = 1 - assign_result.max_overlaps[sampling_result.neg_inds]
+                ious.append(torch.cat([pos_ious, neg_ious], dim=0).detach())
+            priors.append(torch.cat([gt_weights, pos_prior, neg_prior], dim=0).detach())
+        priors = torch.cat(priors, dim=0)
+        ious = torch.cat(ious, dim=0) if self.quality else None
+        losses = dict()
+        if self.boost:
+            bbox_results = self._bbox_forward_train_boost(x, sampling_results, gt_bboxes, gt_labels,
+                                                          img_metas, priors, ious)
+        else:
+            bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels,
+                                                    img_metas)
+        losses.update(bbox_results['loss_bbox'])
+        return losses
+
+    def _bbox_forward(self, x, rois):
+        bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+
+    def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas):
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(x, rois)
+        bbox_targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels,
+                                                  self.train_cfg)
+        loss_bbox = self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                        *bbox_targets)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
+
+    def boost_weights(self, cls_score, labels, priors, ious=None):
+        """label_weights_new of prob_roi_head.py:116-129"""
+        if ious is not None:
+            p = torch.gather(cls_score.clone().softmax(1).detach(), 1, labels.reshape(-1, 1))
+            w = (ious - p).abs() ** self.iou_gamma * (1 - priors) ** self.gamma
+        else:
+            w = (1 - priors) ** self.gamma
+        if self.alpha != 0:
+            w = w * self.alpha
+        return w
+
+    def _bbox_forward_train_boost(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
+                                  priors, ious=None):
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(x, rois)
+        labels, label_weights, bbox, bbox_weights = self.bbox_head.get_targets(
+            sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        label_weights_new = self.boost_weights(bbox_results['cls_score'], labels, priors, ious)
+        # NB: the un-boosted label_weights go into the head loss (prob_roi_head.py:130)
+        loss_bbox = self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                        labels, label_weights, bbox, bbox_weights,
+                                        reduction_override='none')
+        loss_bbox['loss_cls'] = self.norm_loss(loss_bbox['loss_cls'], label_weights_new,
+                                               label_weights_new.shape[0])
+        if self.reg_norm == 'mean':
+            loss_bbox['loss_bbox'] = loss_bbox['loss_bbox'].mean()
+        else:
+            loss_bbox['loss_bbox'] = loss_bbox['loss_bbox'].sum() / bbox.size(0)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
+
+    @staticmethod
+    def norm_loss(loss, weights, avg_factor):
+        new_weights = weights * (loss.sum() / (weights * loss).sum())
+        return (loss * new_weights.detach()).sum() / avg_factor
+
+    # ---- test --------------------------------------------------------------------------
+    def fuse_scores(self, cls_score, prior):
+        """sqrt(softmax(cls_score) * prior) over all C+1 columns (prob_roi_head.py:232-240)"""
+        if not self.prob:
+            return cls_score
+        return (cls_score.softmax(1) * prior.reshape(-1, 1)) ** 0.5
+
+    def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
+        rois = bbox2roi(proposals)
+        prior = torch.cat([boxes[:, -1] for boxes in proposals], dim=0)
+        if rois.shape[0] == 0:
+            batch_size = len(proposals)
+            det_bbox = rois.new_zeros(0, 5)
+            det_label = rois.new_zeros((0,), dtype=torch.long)
+            if rcnn_test_cfg is None:
+                det_bbox = det_bbox[:, :4]
+                det_label = rois.new_zeros((0, self.bbox_head.fc_cls.out_features))
+            return [det_bbox] * batch_size, [det_label] * batch_size
+        bbox_results = self._bbox_forward(x, rois)
+        img_shapes = tuple(meta['img_shape'] for meta in img_metas)
+        scale_factors = tuple(meta['scale_factor'] for meta in img_metas)
+        cls_score = self.fuse_scores(bbox_results['cls_score'], prior)
+        bbox_pred = bbox_results['bbox_pred']
+        num_per_img = tuple(len(p) for p in proposals)
+        rois = rois.split(num_per_img, 0)
+        cls_score = cls_score.split(num_per_img, 0)
+        bbox_pred = bbox_pred.split(num_per_img, 0)
+        det_bboxes, det_labels = [], []
+        for i in range(len(proposals)):
+            if rois[i].shape[0] == 0:
+                det_bbox = rois[i].new_zeros(0, 5)
+                det_label = rois[i].new_zeros((0,), dtype=torch.long)
+                if rcnn_test_cfg is None:
+                    det_bbox = det_bbox[:, :4]
+                    det_label = rois[i].new_zeros((0, self.bbox_head.fc_cls.out_features))
+            else:
+                det_bbox, det_label = self.bbox_head.get_bboxes(
+                    rois[i], cls_score[i], bbox_pred[i], img_shapes[i], scale_factors[i],
+                    rescale=rescale, cfg=rcnn_test_cfg)
+            det_bboxes.append(det_bbox)
+            det_labels.append(det_label)
+        return det_bboxes, det_labels
+
+    def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False):
+        det_bboxes, det_labels = self.simple_test_bboxes(x, img_metas, proposal_list, self.test_cfg,
+                                                         rescale=rescale)
+        return [bbox2result(det_bboxes[i], det_labels[i], self.bbox_head.num_classes)
+                for i in range(len(det_bboxes))]
+
+    def simple_test_padded(self, feats_nhwc, dets, num, img_metas, rescale=False):
+        """Device-resident second stage for the whole batch: `dets` (B,K,5) zero-padded RPN
+        proposals with `num` (B,) valid rows.  Returns (det_bboxes (B,M,5), det_labels (B,M)
+        long (-1 padded), num_dets (B,) int32), no host sync."""
+        cfg = self.test_cfg
+        nms_cfg = dict(cfg.nms)
+        nms_type = nms_cfg.pop('type', 'nms')
+        head = self.bbox_head
+        B, K, _ = dets.shape
+        C = head.num_classes
+        device = dets.device
+        assert nms_type == 'nms' and K * C < nms_cfg.get('split_thr', 10000) and \
+            not nms_cfg.get('class_agnostic', False) and not head.reg_class_agnostic
+        bidx = torch.arange(B, device=device, dtype=dets.dtype).view(B, 1, 1).expand(B, K, 1)
+        rois = torch.cat([bidx, dets[..., :4]], -1).view(B * K, 5)
+        prior = dets[..., 4].reshape(-1)
+        roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, rois)
+        cls_score, bbox_pred = head.forward_nhwc(roi_feats)
+        scores = self.fuse_scores(cls_score, prior).view(B, K, C + 1)
+        # per-image clip border / rescale (image shapes are host metadata)
+        max_shape = torch.tensor([m['img_shape'][:2] for m in img_metas], dtype=dets.dtype,
+                                 device=device)
+        bboxes = head.bbox_coder.decode(rois[:, 1:].view(B, K, 4), bbox_pred.view(B, K, 4 * C),
+                                        max_shape=max_shape)
+        if rescale:
+            sf = torch.tensor([list(m['scale_factor']) for m in img_metas], dtype=dets.dtype,
+                              device=device)
+            bboxes = (bboxes.view(B, K, C, 4) / sf.view(B, 1, 1, 4)).view(B, K, 4 * C)
+        row_ok = torch.arange(K, device=device)[None, :] < num[:, None]
+        s = scores[..., :C]
+        valid = (s > cfg.score_thr) & row_ok[..., None]
+        labels = torch.arange(C, device=device).view(1, 1, C).expand(B, K, C)
+        det, lab, nd = batched_nms_images(bboxes.reshape(B, K * C, 4), s.reshape(B, K * C),
+                                          labels.reshape(B, K * C), valid.reshape(B, K * C),
+                                          nms_cfg['iou_threshold'], cfg.max_per_img,
+                                          nms_cfg.get('offset', 0))
+        return det, lab, nd

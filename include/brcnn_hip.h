@@ -86,21 +86,21 @@ int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights
  * reached through mmcv batched_nms at atss_rpn_head.py:756, rpn_head.py:245 and
  * core/post_processing/bbox_nms.py:86.
  * Segmented form: `num_segments` independent problems (images, or levels of the
- * split_thr path) in one launch; segment s owns boxes [seg_offsets[s],
- * seg_offsets[s+1]).  Semantics per segment = mmcv nms_cpu: order by score
+ * split_thr path) in one launch; segment s owns boxes [seg_begin[s], seg_end[s])
+ * (for back-to-back segments pass offsets and offsets+1; gaps are allowed).  Semantics per segment = mmcv nms_cpu: order by score
  * descending (ties: ascending index), greedy suppress when
  * inter/(area_i+area_j-inter) > iou_threshold.
- *   boxes (n,4) fp32, scores (n) fp32, seg_offsets (S+1) int32 on device
+ *   boxes (n,4) fp32, scores (n) fp32, seg_begin/seg_end (S) int32 on device
  *   keep  (n) int64: for segment s the kept ORIGINAL global indices in score
- *         order are written at keep[seg_offsets[s] ...]; num_keep (S) int32
+ *         order are written at keep[seg_begin[s] ...]; num_keep (S) int32
  *   max_keep > 0 stops each segment after that many survivors (mmcv `max_num`)
  *   max_segment_len: an upper bound on the longest segment (sizes the bit mask:
  *         n * ceil(max_segment_len/64) * 8 bytes)
  *   workspace: brcnn_nms_workspace_bytes(n, S, max_segment_len) bytes of scratch
  * -------------------------------------------------------------------------- */
 size_t brcnn_nms_workspace_bytes(int64_t n, int num_segments, int64_t max_segment_len);
-int brcnn_nms(const float *boxes, const float *scores, const int32_t *seg_offsets,
-              int num_segments, int64_t n, int64_t max_segment_len, float iou_threshold,
+int brcnn_nms(const float *boxes, const float *scores, const int32_t *seg_begin,
+              const int32_t *seg_end, int num_segments, int64_t n, int64_t max_segment_len, float iou_threshold,
               int offset, int max_keep, int64_t *keep, int32_t *num_keep, void *workspace,
               size_t workspace_bytes, void *stream);
 
@@ -115,8 +115,8 @@ int brcnn_nms(const float *boxes, const float *scores, const int32_t *seg_offset
  *   method 0 naive, 1 linear, 2 gaussian
  * -------------------------------------------------------------------------- */
 size_t brcnn_softnms_workspace_bytes(int64_t n, int num_segments);
-int brcnn_softnms(const float *boxes, const float *scores, const int32_t *seg_offsets,
-                  int num_segments, int64_t n, float iou_threshold, float sigma, float min_score,
+int brcnn_softnms(const float *boxes, const float *scores, const int32_t *seg_begin,
+                  const int32_t *seg_end, int num_segments, int64_t n, float iou_threshold, float sigma, float min_score,
                   int method, int offset, float *dets, int64_t *inds, int32_t *num_keep,
                   void *workspace, size_t workspace_bytes, void *stream);
 

@@ -1,0 +1,164 @@
+"""TEST INFRASTRUCTURE ONLY -- the CPU restatement of the whole inference pipeline, used as
+(a) the checker for end-to-end plumbing tests on CPU and (b) bench.py's `cpu_baseline` leg.
+
+It runs the SAME host-side module graph as the product but with every `brcnn.ops` entry
+point swapped (inside the `patched()` context only) for a CPU restatement: PyTorch-CPU
+convolutions / linear layers (what the reference itself executes on CPU) and the C oracle
+for RoIAlign / NMS.  The product never imports this module and never selects it by itself.
+"""
+import contextlib
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import orc
+
+
+def _conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, stride, pad)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = y.relu()
+    return y.contiguous()
+
+
+def _linear_nhwc(x, w, bias=None, relu=False):
+    y = F.linear(x, w, bias)
+    return y.relu() if relu else y
+
+
+def _maxpool(x):
+    return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+
+
+def _groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False):
+    y = F.group_norm(x.permute(0, 3, 1, 2), groups, gamma, beta, eps)
+    if relu:
+        y = y.relu()
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _upsample_add_(dst, src):
+    up = F.interpolate(src.permute(0, 3, 1, 2), size=dst.shape[1:3], mode='nearest')
+    dst += up.permute(0, 2, 3, 1)
+    return dst
+
+
+def _nchw_to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nhwc_to_nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56, sampling_ratio=0):
+    """single_level_roi_extractor.py:36-115 with the C oracle's RoIAlign per level"""
+    k, c = rois.size(0), feats_nhwc[0].shape[3]
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    out = torch.zeros(k, c, ph, pw)
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lvls = torch.floor(torch.log2(scale / finest_scale + 1e-6)).clamp(min=0, max=len(feats_nhwc) - 1).long()
+    for i, f in enumerate(feats_nhwc):
+        inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+        if inds.numel():
+            out[inds] = orc.roi_align_forward(f.permute(0, 3, 1, 2).contiguous(), rois[inds], (ph, pw),
+                                              1.0 / featmap_strides[i], sampling_ratio, 'avg', True)
+    return out.permute(0, 2, 3, 1).contiguous(), lvls.to(torch.int32)
+
+
+def _nms_ranges(boxes, scores, ranges, max_segment_len, iou_threshold, offset=0, max_keep=-1):
+    n = boxes.size(0)
+    keep = torch.zeros(max(n, 1), dtype=torch.int64)
+    num = torch.zeros(ranges.size(0), dtype=torch.int32)
+    for s in range(ranges.size(0)):
+        b, e = int(ranges[s, 0]), int(ranges[s, 1])
+        if e > b:
+            _, k = orc.nms(boxes[b:e], scores[b:e], iou_threshold, offset, 0, max_keep)
+            keep[b:b + k.numel()] = k + b
+            num[s] = k.numel()
+    return keep, num
+
+
+def _rpn_score(cls, iou):
+    return (cls.sigmoid() * iou.sigmoid()).sqrt()
+
+
+def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds, max_shape,
+                min_size, wh_ratio_clip=16 / 1000):
+    from brcnn.core import delta2bbox
+    b, k = topk_inds.shape
+    h, w = feat_hw
+    a = base_anchors.size(0)
+    sw, sh = (stride, stride) if isinstance(stride, int) else stride
+    cell = topk_inds // a
+    ai = topk_inds % a
+    sx = ((cell % w) * sw).to(base_anchors)
+    sy = ((cell // w) * sh).to(base_anchors)
+    anchors = base_anchors[ai] + torch.stack([sx, sy, sx, sy], -1)
+    d = torch.gather(bbox_pred.reshape(b, -1, 4), 1, topk_inds[..., None].expand(b, k, 4))
+    props = delta2bbox(anchors.view(-1, 4), d.view(-1, 4), means, stds, max_shape, wh_ratio_clip).view(b, k, 4)
+    valid = ((props[..., 2] - props[..., 0]) > min_size) & ((props[..., 3] - props[..., 1]) > min_size)
+    return props, valid.to(torch.uint8)
+
+
+_PATCH = dict(conv2d_nhwc=_conv2d_nhwc, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
+              groupnorm_nhwc=_groupnorm, upsample_nearest_add_nhwc_=_upsample_add_,
+              nchw_to_nhwc=_nchw_to_nhwc, nhwc_to_nchw=_nhwc_to_nchw, roi_extract=_roi_extract,
+              nms_ranges=_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode,
+              nms=orc.nms, soft_nms=orc.soft_nms, batched_nms=orc.batched_nms,
+              roi_align=orc.roi_align, RoIAlign=orc.RoIAlign)
+
+
+@contextlib.contextmanager
+def patched():
+    """swap brcnn.ops entry points for the CPU restatements (tests / cpu_baseline only)"""
+    import brcnn  # noqa: F401
+    from brcnn import ops
+    saved = {k: getattr(ops, k) for k in _PATCH}
+    for k, v in _PATCH.items():
+        setattr(ops, k, v)
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+
+
+def timed_baseline(cfg, seed=0, batch=1, budget_s=20.0, threads=None):
+    """`cpu_baseline` object of the bench line: the oracle pipeline on the host cores, on a
+    bounded sample (a few 1333x800 images) of the same workload."""
+    import os
+    from brcnn import build_detector
+    from tests import util
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    with patched():
+        m = build_detector(cfg.model)
+        m.load_state_dict(util.seeded_state_dict(m, seed=seed))
+        m.eval()
+        g = torch.Generator().manual_seed(seed)
+        img = torch.randn(batch, 3, 800, 1344, generator=g)
+        metas = [dict(img_shape=(800, 1333, 3), pad_shape=(800, 1344, 3), ori_shape=(800, 1333, 3),
+                      scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), flip=False)
+                 for _ in range(batch)]
+        with torch.no_grad():
+            m.simple_test(img, metas, rescale=True)          # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                m.simple_test(img, metas, rescale=True)
+                n += batch
+                if time.perf_counter() - t0 > budget_s or n >= 16:
+                    break
+            dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} synthetic 1333x800 images (batch {batch}), same model/config/weights, '
+                      f'PyTorch-CPU conv/linear + C oracle RoIAlign/NMS, {dt:.1f} s'}

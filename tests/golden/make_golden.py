@@ -1,0 +1,348 @@
+"""Generates tests/golden/*.npz by IMPORTING THE REFERENCE (/root/reference) in the authoring
+container, on CPU, under the test-only mmcv shim (tests/golden/_mmcv_shim.py), with mmcv's
+native ops served by this repo's C oracle.  The fixtures are data (inputs + expected
+outputs); no reference source is stored.  Run:  python tests/golden/make_golden.py
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import _mmcv_shim  # noqa: E402
+
+_mmcv_shim.install()
+from tests import util  # noqa: E402
+import brcnn  # noqa: E402,F401
+from brcnn.config import Config  # noqa: E402
+
+REF_CFG = '/root/reference/configs/boosting_rcnn/boosting_rcnn_r50_pafpn_1x_utdac.py'
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def cfgdict(x):
+    return _mmcv_shim.ConfigDict.wrap(x)
+
+
+def g1_anchors():
+    from mmdet.core.anchor.anchor_generator import AnchorGenerator
+    ag = AnchorGenerator(strides=[8, 16, 32, 64, 128], ratios=[0.5, 1.0, 2.0], octave_base_scale=4,
+                         scales_per_octave=3)
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    anchors = ag.grid_anchors(sizes, device='cpu')
+    flags = ag.valid_flags(sizes, (800, 1344, 3), device='cpu')
+    d = {f'base{i}': b for i, b in enumerate(ag.base_anchors)}
+    for i, a in enumerate(anchors):
+        d[f'head{i}'] = a[:64]
+        d[f'tail{i}'] = a[-64:]
+        d[f'sum{i}'] = a.double().sum(0)
+        d[f'n{i}'] = a.shape[0]
+        d[f'flags{i}'] = int(flags[i].sum())
+    # a ragged pad_shape exercises valid_flags
+    flags2 = ag.valid_flags(sizes, (790, 1300, 3), device='cpu')
+    d['flags_ragged'] = np.array([int(f.sum()) for f in flags2])
+    npz('g1_anchors', **d)
+
+
+def g2_coder():
+    from mmdet.core.bbox.coder.delta_xywh_bbox_coder import bbox2delta, delta2bbox
+    g = torch.Generator().manual_seed(2)
+    rois = util.rand_boxes(4096, seed=2)
+    deltas = torch.randn(4096, 4, generator=g)
+    deltas[:64] *= 6           # clamp edges
+    deltas16 = torch.randn(4096, 16, generator=g)
+    gts = util.rand_boxes(4096, seed=3)
+    npz('g2_coder', rois=rois, deltas=deltas, deltas16=deltas16, gts=gts,
+        dec=delta2bbox(rois, deltas, max_shape=(800, 1333, 3)),
+        dec_noclip=delta2bbox(rois, deltas),
+        dec16=delta2bbox(rois, deltas16, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2), (800, 1333, 3)),
+        enc=bbox2delta(rois, gts, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)))
+
+
+def g3_overlaps():
+    from mmdet.core.bbox.iou_calculators import bbox_overlaps
+    a, b = util.rand_boxes(20, seed=4), util.clustered_boxes(4096, seed=5)
+    c = util.clustered_boxes(4096, seed=6)
+    npz('g3_overlaps', a=a, b=b, c=c, iou=bbox_overlaps(a, b), aligned=bbox_overlaps(b, c, is_aligned=True),
+        giou=bbox_overlaps(b, c, mode='giou', is_aligned=True), iof=bbox_overlaps(a, b, mode='iof'))
+
+
+def g4_assign_sample():
+    from mmdet.core.bbox.assigners import MaxIoUAssigner
+    from mmdet.core.bbox.samplers import RandomSampler
+    boxes = util.clustered_boxes(3000, n_clusters=25, seed=7)
+    gts = util.clustered_boxes(12, n_clusters=25, seed=7)
+    labels = torch.arange(12) % 4
+    d = dict(boxes=boxes, gts=gts, labels=labels)
+    for name, kw in [('rpn', dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0, match_low_quality=True,
+                                  ignore_iof_thr=-1)),
+                     ('rcnn', dict(pos_iou_thr=0.6, neg_iou_thr=0.6, min_pos_iou=0.6,
+                                   match_low_quality=False, ignore_iof_thr=-1))]:
+        r = MaxIoUAssigner(**kw).assign(boxes, gts, None, labels)
+        d[name + '_gt_inds'] = r.gt_inds
+        d[name + '_max_overlaps'] = r.max_overlaps
+        d[name + '_labels'] = r.labels
+    props = torch.cat([boxes, torch.rand(3000, 1, generator=torch.Generator().manual_seed(8))], 1)
+    r = MaxIoUAssigner(pos_iou_thr=0.6, neg_iou_thr=0.6, min_pos_iou=0.6, match_low_quality=False,
+                       ignore_iof_thr=-1).assign(props, gts, None, labels)
+    torch.manual_seed(1234)
+    s = RandomSampler(num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True).sample(
+        r, props, gts, labels)
+    d.update(props=props, s_pos_inds=s.pos_inds, s_neg_inds=s.neg_inds, s_pos_is_gt=s.pos_is_gt,
+             s_pos_assigned=s.pos_assigned_gt_inds, s_bboxes=s.bboxes)
+    npz('g4_assign_sample', **d)
+
+
+def _fake_rpn_head(cfg):
+    """a reference ATSSRPNHead built from the UTDAC config"""
+    from mmdet.models.dense_heads.atss_rpn_head import ATSSRPNHead
+    c = copy.deepcopy(cfg.model.rpn_head.to_dict())
+    c.pop('type')
+    c.update(train_cfg=cfgdict(cfg.model.train_cfg.rpn.to_dict()), test_cfg=cfgdict(cfg.model.test_cfg.rpn.to_dict()))
+    return ATSSRPNHead(**cfgdict(c))
+
+
+def g5_rpn_get_bboxes(cfg):
+    """ATSSRPNHead._get_bboxes_single at reduced map sizes (same 5-level structure), test and
+    train proposal cfg, plus the pre-NMS candidates captured at the batched_nms call."""
+    import mmdet.models.dense_heads.atss_rpn_head as M
+    head = _fake_rpn_head(cfg)
+    sizes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    cls = [torch.randn(B, 9, h, w, generator=g) * 2 for h, w in sizes]
+    reg = [torch.randn(B, 36, h, w, generator=g) * 0.5 for h, w in sizes]
+    iou = [torch.randn(B, 9, h, w, generator=g) * 2 for h, w in sizes]
+    metas = [dict(img_shape=(320, 509, 3), scale_factor=np.ones(4, np.float32), pad_shape=(320, 512, 3))
+             for _ in range(B)]
+    d = {}
+    for i in range(5):
+        d[f'cls{i}'], d[f'reg{i}'], d[f'iou{i}'] = cls[i], reg[i], iou[i]
+    captured = []
+    orig = M.batched_nms
+
+    def spy(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+        captured.append((boxes.clone(), scores.clone(), idxs.clone()))
+        return orig(boxes, scores, idxs, nms_cfg, class_agnostic)
+    M.batched_nms = spy
+    try:
+        for name, pc in [('test', cfg.model.test_cfg.rpn.to_dict()),
+                         ('train', dict(cfg.model.train_cfg.rpn_proposal.to_dict(), nms_pre=1500, max_per_img=700)),
+                         ('small', dict(nms_pre=300, max_per_img=64, nms=dict(type='nms', iou_threshold=0.7),
+                                        min_bbox_size=0))]:
+            captured.clear()
+            res = head.get_bboxes(cls, reg, iou, metas, cfg=cfgdict(pc))
+            d[name + '_cfg'] = json.dumps(pc)
+            for b in range(B):
+                d[f'{name}_props{b}'] = res[b]
+                d[f'{name}_pre_boxes{b}'], d[f'{name}_pre_scores{b}'], d[f'{name}_pre_ids{b}'] = captured[b]
+    finally:
+        M.batched_nms = orig
+    npz('g5_rpn_get_bboxes', **d)
+
+
+def g6_rpn_loss(cfg):
+    head = _fake_rpn_head(cfg)
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    g = torch.Generator().manual_seed(6)
+    B = 2
+    cls = [(torch.randn(B, 9, h, w, generator=g)).requires_grad_() for h, w in sizes]
+    reg = [(torch.randn(B, 36, h, w, generator=g) * 0.3).requires_grad_() for h, w in sizes]
+    iou = [(torch.randn(B, 9, h, w, generator=g)).requires_grad_() for h, w in sizes]
+    _, metas, gts, _ = util.demo_inputs(B, 128, 192, seed=6)
+    d = dict(gt0=gts[0], gt1=gts[1])
+    for gamma in (0.5, 2):
+        head.gamma = gamma
+        losses = head.loss(cls, reg, iou, gts, metas)
+        tot = sum(sum(v) for v in losses.values())
+        grads = torch.autograd.grad(tot, cls + reg + iou)
+        for k, v in losses.items():
+            d[f'g{gamma}_{k}'] = torch.stack(v)
+        for i in range(5):
+            d[f'g{gamma}_dcls{i}'], d[f'g{gamma}_dreg{i}'], d[f'g{gamma}_diou{i}'] = \
+                grads[i], grads[5 + i], grads[10 + i]
+    for i in range(5):
+        d[f'cls{i}'], d[f'reg{i}'], d[f'iou{i}'] = cls[i], reg[i], iou[i]
+    npz('g6_rpn_loss', **d)
+
+
+def g7_boost_loss(cfg):
+    """ProbRoIHead._bbox_forward_train_boost tail + ProbConvFCBBoxHead.loss: values and the
+    autograd gradient w.r.t. cls_score / bbox_pred (the only place the boosting weights show)."""
+    from mmdet.models.roi_heads.bbox_heads.convfc_bbox_head import ProbConvFCBBoxHead
+    from mmdet.models.roi_heads.prob_roi_head import ProbRoIHead
+    hc = copy.deepcopy(cfg.model.roi_head.bbox_head.to_dict())
+    hc.pop('type')
+    head = ProbConvFCBBoxHead(**cfgdict(hc))
+    g = torch.Generator().manual_seed(7)
+    n, C = 1024, 4
+    cls_score = (torch.randn(n, C + 1, generator=g) * 2).requires_grad_()
+    bbox_pred = (torch.randn(n, 4 * C, generator=g) * 0.5).requires_grad_()
+    labels = torch.randint(0, C + 1, (n,), generator=g)
+    labels[n // 2:] = C
+    label_weights = torch.ones(n)
+    rois = torch.cat([torch.zeros(n, 1), util.rand_boxes(n, seed=70)], 1)
+    bbox_targets = torch.randn(n, 4, generator=g)
+    bbox_weights = (labels < C).float()[:, None].expand(n, 4).contiguous()
+    priors = torch.rand(n, generator=g)
+    priors[:8] = 0.0
+    d = dict(cls_score=cls_score, bbox_pred=bbox_pred, labels=labels, label_weights=label_weights,
+             rois=rois, bbox_targets=bbox_targets, bbox_weights=bbox_weights, priors=priors)
+    for gamma in (0.5, 0.1):
+        lw_new = (1 - priors) ** gamma
+        lb = head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
+                       reduction_override='none')
+        loss_cls = ProbRoIHead.norm_loss(None, lb['loss_cls'], lw_new, lw_new.shape[0])
+        loss_bbox = lb['loss_bbox'].sum() / bbox_targets.size(0)
+        gc, gb = torch.autograd.grad(loss_cls + loss_bbox, [cls_score, bbox_pred])
+        d.update({f'g{gamma}_loss_cls': loss_cls, f'g{gamma}_loss_bbox': loss_bbox,
+                  f'g{gamma}_acc': lb['acc'], f'g{gamma}_dcls': gc, f'g{gamma}_dbbox': gb})
+    npz('g7_boost_loss', **d)
+
+
+def g8_g9_test_head(cfg):
+    from mmdet.models.roi_heads.bbox_heads.convfc_bbox_head import ProbConvFCBBoxHead
+    from mmdet.models.roi_heads.roi_extractors import SingleRoIExtractor
+    hc = copy.deepcopy(cfg.model.roi_head.bbox_head.to_dict())
+    hc.pop('type')
+    head = ProbConvFCBBoxHead(**cfgdict(hc))
+    g = torch.Generator().manual_seed(8)
+    n, C = 256, 4
+    rois = torch.cat([torch.zeros(n, 1), util.clustered_boxes(n, n_clusters=12, seed=80)], 1)
+    cls_score = torch.randn(n, C + 1, generator=g) * 2
+    bbox_pred = torch.randn(n, 4 * C, generator=g) * 0.3
+    prior = torch.rand(n, generator=g)
+    fused = (cls_score.softmax(1) * prior.reshape(-1, 1)) ** 0.5
+    sf = np.array([1.1, 1.2, 1.1, 1.2], np.float32)
+    bboxes, scores = head.get_bboxes(rois, fused, bbox_pred, (800, 1333, 3), sf, rescale=True, cfg=None)
+    det, lab = head.get_bboxes(rois, fused, bbox_pred, (800, 1333, 3), sf, rescale=True,
+                               cfg=cfgdict(cfg.model.test_cfg.rcnn.to_dict()))
+    ex = SingleRoIExtractor(roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=0),
+                            out_channels=256, featmap_strides=[8, 16, 32, 64, 128])
+    r10k = util.rand_rois(10000, 4, seed=9, min_size=2, max_size=1300)
+    npz('g8_g9_test_head', rois=rois, cls_score=cls_score, bbox_pred=bbox_pred, prior=prior, fused=fused,
+        bboxes=bboxes, scores=scores, det=det, lab=lab, r10k=r10k, lvls10k=ex.map_roi_levels(r10k, 5))
+
+
+def g10_model(cfg):
+    """Whole reference FasterRCNN (R50-PAFPN, UTDAC config) on a 2 x 3 x 128 x 192 batch with
+    seeded synthetic weights: stage outputs + end-to-end detections, and the train losses."""
+    from mmdet.models import build_detector
+    m = build_detector(cfgdict(copy.deepcopy(cfg.model.to_dict())))
+    m.load_state_dict(util.seeded_state_dict(m, seed=10))
+    m.eval()
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    d = dict(state_keys=np.array(sorted(m.state_dict().keys())))
+    with torch.no_grad():
+        c = m.backbone(img)
+        p = m.neck(c)
+        cls, reg, iou = m.rpn_head(p)
+        for i, t in enumerate(c):
+            d[f'c{i}_stat'] = np.array([t.double().mean(), t.double().std(), t.double().abs().max()])
+            d[f'c{i}_slice'] = t[:, :8, :4, :4]
+        for i, t in enumerate(p):
+            d[f'p{i}'] = t[:, :16]
+            d[f'p{i}_sum'] = t.double().sum((2, 3))
+        for i in range(5):
+            d[f'cls{i}'], d[f'reg{i}'], d[f'iou{i}'] = cls[i], reg[i], iou[i]
+        props = m.rpn_head.get_bboxes(cls, reg, iou, metas)
+        for b in range(2):
+            d[f'props{b}'] = props[b]
+        rois_all = torch.cat([torch.cat([torch.full((len(q), 1), float(b)), q[:, :4]], 1)
+                              for b, q in enumerate(props)])
+        feats = m.roi_head.bbox_roi_extractor(p, rois_all)
+        d['roi_feats_sum'] = feats.double().sum((2, 3))
+        cs, bp = m.roi_head.bbox_head(feats)
+        d['cls_score'], d['bbox_pred'] = cs, bp
+        res = m.simple_test(img, metas, rescale=True)
+        for b in range(2):
+            for c_ in range(4):
+                d[f'res{b}_{c_}'] = res[b][c_]
+    npz('g10_model', **d)
+    # training losses of the same model (CPU reference path), seeded sampler
+    m.train()
+    torch.manual_seed(77)
+    losses = m.forward_train(img, metas, gts, gls)
+    npz('g10_train_losses', **{k: (torch.stack(v) if isinstance(v, list) else v) for k, v in losses.items()})
+
+
+def kat():
+    """known-answer vectors of the mmcv ops, re-derived here in float64"""
+    boxes = [[6, 3, 8, 7], [3, 6, 9, 11], [3, 7, 10, 12], [1, 4, 13, 7]]
+    scores = [0.6, 0.9, 0.7, 0.2]
+    b, s = np.array(boxes, np.float64), np.array(scores, np.float64)
+
+    def iou(x, y):
+        w = max(0., min(x[2], y[2]) - max(x[0], y[0]))
+        h = max(0., min(x[3], y[3]) - max(x[1], y[1]))
+        i = w * h
+        return i / ((x[2] - x[0]) * (x[3] - x[1]) + (y[2] - y[0]) * (y[3] - y[1]) - i)
+
+    def soft(method, thr=0.3, sigma=0.5, min_score=1e-3):
+        bb, ss, idx = b.copy(), s.copy(), list(range(4))
+        out = []
+        while len(idx):
+            m = int(np.argmax(ss))
+            out.append((idx[m], ss[m]))
+            mb = bb[m]
+            bb, ss, idx = np.delete(bb, m, 0), np.delete(ss, m), [x for j, x in enumerate(idx) if j != m]
+            for j in range(len(idx)):
+                o = iou(mb, bb[j])
+                wgt = {'naive': 0. if o >= thr else 1., 'linear': 1 - o if o >= thr else 1.,
+                       'gaussian': np.exp(-o * o / sigma)}[method]
+                ss[j] *= wgt
+            keep = ss >= min_score
+            bb, ss, idx = bb[keep], ss[keep], [x for j, x in enumerate(idx) if keep[j]]
+        return [o[0] for o in out], [float(o[1]) for o in out]
+    order = np.argsort(-s)
+    keep = []
+    for i in order:
+        if all(iou(b[i], b[j]) <= 0.3 for j in keep):
+            keep.append(int(i))
+    d = dict(boxes=boxes, scores=scores, nms_keep=keep)
+    for m in ('naive', 'linear', 'gaussian'):
+        ii, ss = soft(m)
+        d[f'soft_{m}_inds'], d[f'soft_{m}_scores'] = ii, ss
+    d['roialign'] = [
+        dict(input=[[1, 2], [3, 4]], roi=[0, 0, 0, 1, 1], aligned=[[1.0, 1.25], [1.5, 1.75]],
+             legacy=[[1.75, 2.25], [2.75, 3.25]]),
+        dict(input=[[1, 2, 5, 6], [3, 4, 7, 8], [9, 10, 13, 14], [11, 12, 15, 16]], roi=[0, 0, 0, 3, 3],
+             aligned=[[1.9375, 4.75], [7.5625, 10.375]], legacy=[[3.625, 6.875], [10.125, 13.375]])]
+    with open(os.path.join(HERE, 'kat_mmcv_ops.json'), 'w') as f:
+        json.dump(d, f, indent=1)
+    print('kat_mmcv_ops.json', d['nms_keep'], d['soft_linear_inds'], d['soft_linear_scores'])
+
+
+def main():
+    torch.set_num_threads(8)
+    cfg = Config.fromfile(REF_CFG)
+    kat()
+    g1_anchors()
+    g2_coder()
+    g3_overlaps()
+    g4_assign_sample()
+    g5_rpn_get_bboxes(cfg)
+    g6_rpn_loss(cfg)
+    g7_boost_loss(cfg)
+    g8_g9_test_head(cfg)
+    g10_model(cfg)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,133 @@
+"""-m gpu: the device path of the host modules against the golden fixtures produced by the
+imported reference (tests/golden/make_golden.py): RPN proposal stage, box-head post-processing
+and the whole R50-PAFPN detector with seeded synthetic weights."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import brcnn  # noqa: F401
+from brcnn import Config, build_detector, ops
+from tests import util
+from tests.test_host_cpu import CFG, T, load
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _match_dets(got, ref, box_tol=1e-2, score_tol=1e-3):
+    """fraction of reference detections that have a counterpart (same place, same score)"""
+    if len(ref) == 0:
+        return 1.0 if len(got) == 0 else 0.0
+    if len(got) == 0:
+        return 0.0
+    d = np.abs(ref[:, None, :4] - got[None, :, :4]).max(-1)
+    s = np.abs(ref[:, None, 4] - got[None, :, 4])
+    ok = ((d < box_tol) & (s < score_tol)).any(1)
+    return ok.mean()
+
+
+def test_rpn_get_bboxes_golden():
+    g = load('g5_rpn_get_bboxes')
+    cfg = Config.fromfile(CFG)
+    c = cfg.model.rpn_head.copy()
+    c.update(train_cfg=cfg.model.train_cfg.rpn, test_cfg=cfg.model.test_cfg.rpn)
+    head = brcnn.build_head(c).to(DEV)
+    cls = [T(g[f'cls{i}']).to(DEV) for i in range(5)]
+    reg = [T(g[f'reg{i}']).to(DEV) for i in range(5)]
+    iou = [T(g[f'iou{i}']).to(DEV) for i in range(5)]
+    metas = [dict(img_shape=(320, 509, 3), scale_factor=np.ones(4, np.float32), pad_shape=(320, 512, 3))
+             for _ in range(2)]
+    from brcnn.config import ConfigDict
+    for name in ('test', 'train', 'small'):
+        pc = ConfigDict(json.loads(str(g[name + '_cfg'])))
+        res = head.get_bboxes(cls, reg, iou, metas, cfg=pc)
+        for b in range(2):
+            ref = T(g[f'{name}_props{b}'])
+            got = res[b].cpu()
+            assert got.shape == ref.shape, (name, got.shape, ref.shape)
+            # identical proposals in identical order; device expf may differ from the host's
+            # by an ulp inside sigmoid / exp(dw): allow 1e-4 px and 1e-6 score
+            assert torch.allclose(got[:, :4], ref[:, :4], rtol=0, atol=2e-4), (name, b)
+            assert torch.allclose(got[:, 4], ref[:, 4], rtol=0, atol=1e-6), (name, b)
+
+
+def test_box_head_postprocess_golden():
+    g = load('g8_g9_test_head')
+    cfg = Config.fromfile(CFG)
+    rh = brcnn.build_head(dict(cfg.model.roi_head, train_cfg=None, test_cfg=cfg.model.test_cfg.rcnn)).to(DEV)
+    fused = rh.fuse_scores(T(g['cls_score']).to(DEV), T(g['prior']).to(DEV))
+    assert torch.allclose(fused.cpu(), T(g['fused']), atol=1e-6)
+    sf = np.array([1.1, 1.2, 1.1, 1.2], np.float32)
+    # use the golden fused scores so the NMS input is bit-identical
+    det, lab = rh.bbox_head.get_bboxes(T(g['rois']).to(DEV), T(g['fused']).to(DEV), T(g['bbox_pred']).to(DEV),
+                                       (800, 1333, 3), sf, rescale=True, cfg=cfg.model.test_cfg.rcnn)
+    assert torch.equal(lab.cpu(), T(g['lab']))
+    assert torch.allclose(det.cpu(), T(g['det']), atol=2e-4)
+    lv = rh.bbox_roi_extractor.map_roi_levels(T(g['r10k']).to(DEV), 5)
+    assert (lv.cpu() != T(g['lvls10k'])).sum().item() == 0
+
+
+@pytest.fixture(scope='module')
+def model():
+    cfg = Config.fromfile(CFG)
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=10))
+    return m.to(DEV).eval()
+
+
+def test_model_stages_golden(model):
+    g = load('g10_model')
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=10)
+    with torch.no_grad():
+        c = model.backbone(img.to(DEV))
+        p = model.neck(c)
+        cls, reg, iou = model.rpn_head(p)
+    for i, t in enumerate(c):
+        t = t.cpu()
+        stat = np.array([t.double().mean(), t.double().std(), t.double().abs().max()])
+        assert np.allclose(stat, g[f'c{i}_stat'], rtol=1e-4), (i, stat, g[f'c{i}_stat'])
+        assert torch.allclose(t[:, :8, :4, :4], T(g[f'c{i}_slice']), rtol=1e-3, atol=1e-4)
+    for i, t in enumerate(p):
+        t = t.cpu()
+        assert torch.allclose(t[:, :16], T(g[f'p{i}']), rtol=1e-3, atol=1e-4), i
+        assert np.allclose(t.double().sum((2, 3)).numpy(), g[f'p{i}_sum'], rtol=1e-3, atol=1e-2)
+    for i in range(5):
+        assert torch.allclose(cls[i].cpu(), T(g[f'cls{i}']), rtol=1e-3, atol=1e-3), i
+        assert torch.allclose(reg[i].cpu(), T(g[f'reg{i}']), rtol=1e-3, atol=1e-3), i
+        assert torch.allclose(iou[i].cpu(), T(g[f'iou{i}']), rtol=1e-3, atol=1e-3), i
+    # second stage on the GOLDEN proposals: RoI features + FC head
+    props = [T(g[f'props{b}']).to(DEV) for b in range(2)]
+    rois = torch.cat([torch.cat([torch.full((len(q), 1), float(b), device=DEV), q[:, :4]], 1)
+                      for b, q in enumerate(props)])
+    with torch.no_grad():
+        feats = model.roi_head.bbox_roi_extractor(p, rois)
+        cs, bp = model.roi_head.bbox_head(feats)
+    assert np.allclose(feats.double().sum((2, 3)).cpu().numpy(), g['roi_feats_sum'], rtol=1e-3, atol=1e-2)
+    assert torch.allclose(cs.cpu(), T(g['cls_score']), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(bp.cpu(), T(g['bbox_pred']), rtol=1e-3, atol=1e-3)
+
+
+def test_model_end_to_end_golden(model):
+    g = load('g10_model')
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=10)
+    with torch.no_grad():
+        res = model(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
+        # the reference-signature path (per-image python flow) must agree with the device path
+        x = model.extract_feat(img.to(DEV))
+        pl = model.rpn_head.simple_test_rpn(x, metas)
+        res2 = model.roi_head.simple_test(x, pl, metas, rescale=True)
+    n_ref = sum(len(g[f'res{b}_{c}']) for b in range(2) for c in range(4))
+    assert n_ref > 20
+    for b in range(2):
+        # RPN proposals (score-ordered): the bulk must coincide with the reference's
+        ref_p, got_p = g[f'props{b}'], pl[b].cpu().numpy()
+        assert _match_dets(got_p, ref_p, 5e-2, 1e-3) > 0.97
+        for c in range(4):
+            ref = g[f'res{b}_{c}']
+            assert res[b][c].dtype == np.float32 and res[b][c].shape[1] == 5
+            assert _match_dets(res[b][c], ref) >= 0.9, (b, c, len(ref), len(res[b][c]))
+            assert _match_dets(ref, res[b][c]) >= 0.9
+            assert np.array_equal(res[b][c], res2[b][c])

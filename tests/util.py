@@ -55,3 +55,62 @@ def ulp_diff(a, b):
     a = torch.where(a < 0, -(a & 0x7fffffff), a)
     b = torch.where(b < 0, -(b & 0x7fffffff), b)
     return (a - b).abs()
+
+
+def seeded_state_dict(module, seed=0):
+    """Deterministic synthetic weights (no checkpoint download is possible): every tensor of
+    `module.state_dict()` is drawn, in sorted key order, from a CPU generator.  The golden
+    generator applies the same function to the reference model, so both sides hold
+    identical weights without shipping 184 MB of parameters."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    out = {}
+    for k in sorted(sd.keys()):
+        v = sd[k]
+        if k.endswith('num_batches_tracked'):
+            out[k] = torch.zeros_like(v)
+            continue
+        if k.endswith('running_mean'):
+            out[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif k.endswith('running_var'):
+            out[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith('.scale'):
+            out[k] = torch.tensor(1.0 + 0.1 * float(torch.randn((), generator=g)))
+        elif v.dim() >= 2:       # conv / linear weights: He-style fan-in scaling
+            fan_in = v[0].numel()
+            std = (2.0 / fan_in) ** 0.5
+            if 'rpn_cls' in k or 'rpn_iou' in k or 'rpn_reg' in k:
+                std *= 0.5
+            if 'fc_reg' in k:
+                std *= 0.1
+            out[k] = torch.randn(v.shape, generator=g) * std
+        elif 'bn3.weight' in k:  # damp the residual branches so 16 blocks stay bounded
+            out[k] = torch.rand(v.shape, generator=g) * 0.3 + 0.2
+        elif k.endswith('.weight'):   # norm scales
+            out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        elif 'rpn_cls.bias' in k:
+            out[k] = torch.randn(v.shape, generator=g) * 0.5 - 1.0
+        else:                     # biases / norm shifts
+            out[k] = torch.randn(v.shape, generator=g) * 0.05
+        out[k] = out[k].to(v.dtype)
+    return out
+
+
+def demo_inputs(batch=2, h=128, w=192, num_classes=4, seed=0, num_gt=5):
+    """synthetic batch in the style of tests/test_models/test_forward.py:438-513"""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(batch, 3, h, w, generator=g)
+    img_metas = [{'img_shape': (h, w - 3, 3), 'ori_shape': (h, w - 3, 3), 'pad_shape': (h, w, 3),
+                  'scale_factor': np.array([1.1, 1.2, 1.1, 1.2], dtype=np.float32), 'flip': False,
+                  'filename': '<demo>.png'} for _ in range(batch)]
+    gt_bboxes, gt_labels = [], []
+    for _ in range(batch):
+        cx = torch.rand(num_gt, generator=g) * (w - 3)
+        cy = torch.rand(num_gt, generator=g) * h
+        bw = torch.rand(num_gt, generator=g) * (w - 3) * 0.5 + 8
+        bh = torch.rand(num_gt, generator=g) * h * 0.5 + 8
+        b = torch.stack([(cx - bw / 2).clamp(0, w - 3), (cy - bh / 2).clamp(0, h),
+                         (cx + bw / 2).clamp(0, w - 3), (cy + bh / 2).clamp(0, h)], 1)
+        gt_bboxes.append(b)
+        gt_labels.append(torch.randint(0, num_classes, (num_gt,), generator=g))
+    return img, img_metas, gt_bboxes, gt_labels
