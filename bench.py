@@ -37,7 +37,7 @@ def build_model(device, seed=0):
                                        'boosting_rcnn_r50_pafpn_1x_utdac.py'))
     m = build_detector(cfg.model)
     m.load_state_dict(util.seeded_state_dict(m, seed=seed))
-    return m.to(device).eval(), cfg
+    return m.to(device).eval().freeze_for_inference(), cfg
 
 
 def conv_flops_per_image():

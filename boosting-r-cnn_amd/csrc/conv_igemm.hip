@@ -29,7 +29,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_STRIDE = 36;
+constexpr int BM = 128, BK = 32, LDS_STRIDE = 36;
 
 struct ConvParams {
     const float* x;
@@ -42,6 +42,13 @@ struct ConvParams {
     int M, K;
     int relu;
     int tiles_m, tiles_n;
+    int pitch;                       // floats between adjacent input pixels (== Cin normally)
+    // multi-segment launches (pyramid levels sharing one set of weights): segment s covers
+    // output rows [seg_m0[s], seg_m0[s+1]) and has its own spatial geometry / input offset
+    int nseg;
+    int seg_m0[BRCNN_MAX_LEVELS + 1];
+    int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
+    long long seg_xoff[BRCNN_MAX_LEVELS];   // element offset of the segment's input in x
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -52,8 +59,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + loc;
 }
 
-template <bool FAST>   // FAST: Cin % 32 == 0 (a K tile never straddles a filter tap)
+// FAST: Cin % 32 == 0 (a K tile never straddles a filter tap).
+// NT = number of 32-wide MFMA column tiles per wave: NT=2 -> block tile 128x128 (waves 2x2,
+// each 64x64), NT=1 -> block tile 128x64 for Cout <= 64 (waves 2x2, each 64x32).
+template <bool FAST, int NT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
+    constexpr int BN = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDS_STRIDE]
     float* Bs = smem + 2 * BM * LDS_STRIDE;    // [2][BN][LDS_STRIDE]
@@ -61,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const float* __restrict__ xin = p.x;
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
@@ -70,36 +82,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     // ---- staging assignment: float4 column c4 of rows r0 + 32*j -------------------------
     const int c4 = tid & 7;
     const int r0 = tid >> 3;
-    int a_base[4], a_hw[4];   // a_hw packs (hi0 + 4096) << 16 | (wi0 + 4096); a_base < 0: row invalid
-    const float* b_ptr[4];
-    bool b_ok[4];
+    // a_hw packs (hi0 + 4096) << 16 | (wi0 + 4096); a_base < 0: row invalid
+    long long a_base[4];
+    int a_hw[4], a_H[4], a_W[4];
+    const float* b_ptr[2 * NT];
+    bool b_ok[2 * NT];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int m = m0 + r0 + 32 * j;
         if (m < p.M) {
-            const int n = m / (p.Ho * p.Wo);
-            const int rem = m - n * (p.Ho * p.Wo);
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            a_base[j] = n * p.H * p.W;
+            int sg = 0;
+#pragma unroll
+            for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+            const int ml = m - p.seg_m0[sg];
+            const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg];
+            a_H[j] = p.seg_H[sg];
+            a_W[j] = p.seg_W[sg];
+            const int n = ml / (Ho * Wo);
+            const int rem = ml - n * (Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            a_base[j] = p.seg_xoff[sg] + (long long)n * a_H[j] * a_W[j] * p.pitch;
             a_hw[j] = ((ho * p.stride - p.pad + 4096) << 16) | (wo * p.stride - p.pad + 4096);
         } else {
             a_base[j] = -1;
             a_hw[j] = 0;
+            a_H[j] = a_W[j] = 0;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * NT; j++) {
         const int co = n0 + r0 + 32 * j;
         b_ok[j] = co < p.Cout;
         b_ptr[j] = p.w + (size_t)(b_ok[j] ? co : 0) * p.K;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < NT; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    float4 ra[4], rb[4];
+    float4 ra[4], rb[2 * NT];
     const int nk = (p.K + BK - 1) / BK;
 
     auto load_tile = [&](int kt) {
@@ -112,12 +138,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             for (int j = 0; j < 4; j++) {
                 const int hi = (a_hw[j] >> 16) - 4096 + kh;
                 const int wi = (a_hw[j] & 0xffff) - 4096 + kw;
-                const bool ok = a_base[j] >= 0 && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                const bool ok = a_base[j] >= 0 && hi >= 0 && hi < a_H[j] && wi >= 0 && wi < a_W[j];
                 if (ok)
                     ra[j] = *reinterpret_cast<const float4*>(
-                        p.x + ((size_t)(a_base[j] + hi * p.W + wi)) * p.Cin + ci);
+                        xin + a_base[j] + ((long long)(hi * a_W[j] + wi)) * p.pitch + ci);
                 else
                     ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * NT; j++) {
                 if (b_ok[j])
                     rb[j] = *reinterpret_cast<const float4*>(b_ptr[j] + k0 + c4 * 4);
                 else
@@ -126,23 +155,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float va[4], vb[4];
+                float va[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int k = k0 + c4 * 4 + e;
                     va[e] = 0.f;
-                    vb[e] = 0.f;
                     if (k < p.K) {
                         const int tap = k / p.Cin, ci = k - tap * p.Cin;
                         const int kh = tap / p.KW, kw = tap - kh * p.KW;
                         const int hi = (a_hw[j] >> 16) - 4096 + kh;
                         const int wi = (a_hw[j] & 0xffff) - 4096 + kw;
-                        if (a_base[j] >= 0 && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
-                            va[e] = p.x[((size_t)(a_base[j] + hi * p.W + wi)) * p.Cin + ci];
-                        if (b_ok[j]) vb[e] = b_ptr[j][k];
+                        if (a_base[j] >= 0 && hi >= 0 && hi < a_H[j] && wi >= 0 && wi < a_W[j])
+                            va[e] = xin[a_base[j] + ((long long)(hi * a_W[j] + wi)) * p.pitch + ci];
                     }
                 }
                 ra[j] = make_float4(va[0], va[1], va[2], va[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * NT; j++) {
+                float vb[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k = k0 + c4 * 4 + e;
+                    vb[e] = (k < p.K && b_ok[j]) ? b_ptr[j][k] : 0.f;
+                }
                 rb[j] = make_float4(vb[0], vb[1], vb[2], vb[3]);
             }
         }
@@ -151,10 +187,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         float* as = As + buf * BM * LDS_STRIDE;
         float* bs = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 4; j++)
             *reinterpret_cast<float4*>(as + (r0 + 32 * j) * LDS_STRIDE + c4 * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 2 * NT; j++)
             *reinterpret_cast<float4*>(bs + (r0 + 32 * j) * LDS_STRIDE + c4 * 4) = rb[j];
-        }
     };
 
     load_tile(0);
@@ -166,22 +203,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     for (int kt = 0; kt < nk; kt++) {
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* as = As + cur * BM * LDS_STRIDE + (wm * 64 + li) * LDS_STRIDE + lh * 4;
-        const float* bs = Bs + cur * BN * LDS_STRIDE + (wn * 64 + li) * LDS_STRIDE + lh * 4;
+        const float* bs = Bs + cur * BN * LDS_STRIDE + (wn * 32 * NT + li) * LDS_STRIDE + lh * 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; kk++) {
             const float4 a0 = *reinterpret_cast<const float4*>(as + kk * 8);
             const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDS_STRIDE + kk * 8);
-            const float4 b0 = *reinterpret_cast<const float4*>(bs + kk * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(bs + 32 * LDS_STRIDE + kk * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            float bv[NT][4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+            for (int t = 0; t < NT; t++) {
+                const float4 b = *reinterpret_cast<const float4*>(bs + t * 32 * LDS_STRIDE + kk * 8);
+                bv[t][0] = b.x; bv[t][1] = b.y; bv[t][2] = b.z; bv[t][3] = b.w;
             }
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][e], bv[t][e],
+                                                                          acc[tm][t], 0, 0, 0);
         }
         if (kt + 1 < nk) {
             store_tile(cur ^ 1);
@@ -190,29 +231,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         }
     }
 
-    // ---- epilogue: scale/shift, residual, relu; D layout col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    // ---- epilogue: scale/shift, residual, relu.  D layout: col = lane&31,
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual operand of one 32x32 tile is
+    // fetched as a batch (16 independent loads in flight) before any store is issued: the
+    // output and residual pointers are __restrict__, otherwise every load would have to
+    // wait behind the previous store.
+    const float* __restrict__ res = p.residual;
+    float* __restrict__ yout = p.y;
 #pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
-        const int co = n0 + wn * 64 + tn * 32 + li;
-        if (co >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[co] : 1.f;
-        const float sh = p.shift ? p.shift[co] : 0.f;
+    for (int tn = 0; tn < NT; tn++) {
+        const int co = n0 + wn * 32 * NT + tn * 32 + li;
+        const bool cok = co < p.Cout;
+        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
+            const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                rv[r] = (res && cok && m < p.M) ? res[(size_t)m * p.Cout + co] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
                 float v = acc[tm][tn][r];
                 if (p.scale) v = v * sc;
                 v = v + sh;
-                const size_t o = (size_t)m * p.Cout + co;
-                if (p.residual) v += p.residual[o];
+                v = v + rv[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                p.y[o] = v;
+                if (cok && m < p.M) yout[(size_t)m * p.Cout + co] = v;
             }
         }
     }
+}
+
+template <bool FAST, int NT>
+int launch_conv(const ConvParams& p, hipStream_t s) {
+    const size_t lds = (size_t)2 * (BM + 64 * NT) * LDS_STRIDE * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<FAST, NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<FAST, NT>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds,
+                       s, p);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+int dispatch_conv(ConvParams& p, hipStream_t s) {
+    const int nt = (p.Cout <= 64) ? 1 : 2;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + 64 * nt - 1) / (64 * nt);
+    const bool fast = (p.Cin % 32 == 0);
+    if (fast) return nt == 1 ? launch_conv<true, 1>(p, s) : launch_conv<true, 2>(p, s);
+    return nt == 1 ? launch_conv<false, 1>(p, s) : launch_conv<false, 2>(p, s);
 }
 
 }  // namespace
@@ -221,46 +297,43 @@ BRCNN_API int brcnn_conv2d_nhwc(const void* x, const void* w, const float* scale
                                 const void* residual, void* y, int batch, int height, int width,
                                 int cin, int cout, int kh, int kw, int stride, int pad, int relu,
                                 int dtype, void* stream) {
-    if (!x || !w || !y || batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 ||
-        kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
+    const int hs[1] = {height}, ws[1] = {width};
+    return brcnn_conv2d_nhwc_multi(x, w, scale, shift, residual, y, batch, 1, hs, ws, cin, cout, kh,
+                                   kw, stride, pad, relu, dtype, stream);
+}
+
+BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float* scale,
+                                      const float* shift, const void* residual, void* y, int batch,
+                                      int num_segments, const int* heights_host,
+                                      const int* widths_host, int cin, int cout, int kh, int kw,
+                                      int stride, int pad, int relu, int dtype, void* stream) {
+    if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
+        pad < 0 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS || !heights_host ||
+        !widths_host)
         return BRCNN_EINVAL;
-    if (dtype != BRCNN_DT_F32) return BRCNN_EINVAL;   // bf16 path: see conv_igemm_bf16.hip
-    ConvParams p;
+    if (dtype != BRCNN_DT_F32) return BRCNN_EINVAL;
+    ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
-    p.batch = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
-    p.stride = stride; p.pad = pad;
-    p.Ho = (height + 2 * pad - kh) / stride + 1;
-    p.Wo = (width + 2 * pad - kw) / stride + 1;
-    if (p.Ho <= 0 || p.Wo <= 0) return BRCNN_EINVAL;
-    if (height + pad >= 4096 || width + pad >= 4096) return BRCNN_EINVAL;
-    const long long M = (long long)batch * p.Ho * p.Wo;
-    if (M > 0x7fffffffLL || (long long)batch * height * width > 0x7fffffffLL) return BRCNN_EINVAL;
-    p.M = (int)M;
+    p.batch = batch; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
+    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = num_segments;
+    long long m_total = 0, x_off = 0;
+    for (int sgi = 0; sgi < num_segments; sgi++) {
+        const int H = heights_host[sgi], W = widths_host[sgi];
+        if (H <= 0 || W <= 0 || H + pad >= 4096 || W + pad >= 4096) return BRCNN_EINVAL;
+        const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+        if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+        p.seg_H[sgi] = H; p.seg_W[sgi] = W; p.seg_Ho[sgi] = Ho; p.seg_Wo[sgi] = Wo;
+        p.seg_m0[sgi] = (int)m_total;
+        p.seg_xoff[sgi] = x_off;
+        m_total += (long long)batch * Ho * Wo;
+        x_off += (long long)batch * H * W * cin;
+        if (m_total > 0x7fffffffLL) return BRCNN_EINVAL;
+    }
+    for (int sgi = num_segments; sgi <= BRCNN_MAX_LEVELS; sgi++) p.seg_m0[sgi] = (int)m_total;
+    p.H = p.seg_H[0]; p.W = p.seg_W[0]; p.Ho = p.seg_Ho[0]; p.Wo = p.seg_Wo[0];
+    p.M = (int)m_total;
     p.K = kh * kw * cin;
     p.relu = relu;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    const int grid = p.tiles_m * p.tiles_n;
-    hipStream_t s = (hipStream_t)stream;
-    if (cin % 32 == 0) {
-        static bool attr_fast = false;
-        if (!attr_fast) {
-            BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_fast = true;
-        }
-        hipLaunchKernelGGL(conv_igemm_f32_kernel<true>, dim3(grid), dim3(256), lds, s, p);
-    } else {
-        static bool attr_gen = false;
-        if (!attr_gen) {
-            BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_gen = true;
-        }
-        hipLaunchKernelGGL(conv_igemm_f32_kernel<false>, dim3(grid), dim3(256), lds, s, p);
-    }
-    BRCNN_LAUNCH_CHECK();
-    return 0;
+    return dispatch_conv(p, (hipStream_t)stream);
 }

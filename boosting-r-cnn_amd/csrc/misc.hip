@@ -36,29 +36,39 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
     }
 }
 
-// ---- GroupNorm: pass 1 = per (n, group) sum / sum of squares in double ------------------
-// grid (chunks, N); 256 threads; thread t owns channel t (+256j); rows strided by chunk.
+// ---- GroupNorm over one or several back-to-back NHWC segments (pyramid levels) -----------
+struct GnSegs {
+    int nseg;
+    int hw[BRCNN_MAX_LEVELS];
+    long long row0[BRCNN_MAX_LEVELS + 1];   // first row of segment s in the concatenated (rows, C)
+};
+
+// pass 1: per (segment, n, group) sum / sum of squares, accumulated in double.
+// grid (chunks, N * nseg); 256 threads; thread t owns channel t (+256j); rows strided by chunk.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x,
-                                                      double* __restrict__ stats, int HW, int C,
-                                                      int G, int rows_per_block) {
-    const int n = blockIdx.y;
+                                                      double* __restrict__ stats, GnSegs sg, int N,
+                                                      int C, int G, int rows_per_block) {
+    const int seg = blockIdx.y / N, n = blockIdx.y - seg * N;
+    const int HW = sg.hw[seg];
     const int row0 = blockIdx.x * rows_per_block;
+    if (row0 >= HW) return;
     const int row1 = min(HW, row0 + rows_per_block);
+    const float* xs = x + (size_t)(sg.row0[seg] + (long long)n * HW) * C;
     const int cpg = C / G;
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f, ss = 0.f;
         double ds = 0.0, dss = 0.0;
         int cnt = 0;
         for (int r = row0; r < row1; r++) {
-            const float v = x[((size_t)n * HW + r) * C + c];
+            const float v = xs[(size_t)r * C + c];
             s += v;
             ss += v * v;
             if (++cnt == 64) { ds += s; dss += ss; s = ss = 0.f; cnt = 0; }
         }
         ds += s; dss += ss;
         const int g = c / cpg;
-        atomicAdd(&stats[((size_t)n * G + g) * 2 + 0], ds);
-        atomicAdd(&stats[((size_t)n * G + g) * 2 + 1], dss);
+        atomicAdd(&stats[((size_t)blockIdx.y * G + g) * 2 + 0], ds);
+        atomicAdd(&stats[((size_t)blockIdx.y * G + g) * 2 + 1], dss);
     }
 }
 
@@ -66,22 +76,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                       const double* __restrict__ stats,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
-                                                      float* __restrict__ y, int N, int HW, int C,
+                                                      float* __restrict__ y, GnSegs sg, int N, int C,
                                                       int G, float eps, int relu) {
     const int c4n = C >> 2, cpg = C / G;
-    const long long total = (long long)N * HW * c4n;
-    const double inv_cnt = 1.0 / ((double)HW * cpg);
+    const long long total = sg.row0[sg.nseg] * c4n;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % c4n);
-        const int n = (int)(idx / ((long long)HW * c4n));
+        const long long row = idx / c4n;
+        int seg = 0;
+#pragma unroll
+        for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+            if (t < sg.nseg && row >= sg.row0[t]) seg = t;
+        const int HW = sg.hw[seg];
+        const int n = (int)((row - sg.row0[seg]) / HW);
+        const double inv_cnt = 1.0 / ((double)HW * cpg);
+        const size_t sbase = ((size_t)(seg * N + n)) * G;
         float4 v = *reinterpret_cast<const float4*>(x + (size_t)idx * 4);
         float in[4] = {v.x, v.y, v.z, v.w}, out[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int c = c4 * 4 + e, g = c / cpg;
-            const double mean = stats[((size_t)n * G + g) * 2] * inv_cnt;
-            double var = stats[((size_t)n * G + g) * 2 + 1] * inv_cnt - mean * mean;
+            const double mean = stats[(sbase + g) * 2] * inv_cnt;
+            double var = stats[(sbase + g) * 2 + 1] * inv_cnt - mean * mean;
             if (var < 0.0) var = 0.0;
             const float rstd = (float)(1.0 / sqrt(var + (double)eps));
             float o = (in[e] - (float)mean) * rstd * gamma[c] + beta[c];
@@ -167,27 +184,50 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int hei
     return 0;
 }
 
-BRCNN_API int brcnn_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y,
-                                   void* stats_ws, int batch, int hw, int channels, int groups,
-                                   float eps, int relu, int dtype, void* stream) {
-    if (!x || !y || !gamma || !beta || !stats_ws || batch <= 0 || hw <= 0 || channels <= 0 ||
-        groups <= 0 || channels % groups || (channels & 3) || dtype != BRCNN_DT_F32)
+BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, const float* beta,
+                                         void* y, void* stats_ws, int batch, int num_segments,
+                                         const int* hw_host, int channels, int groups, float eps,
+                                         int relu, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !stats_ws || batch <= 0 || num_segments <= 0 ||
+        num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || groups <= 0 ||
+        channels % groups || (channels & 3) || dtype != BRCNN_DT_F32)
         return BRCNN_EINVAL;
+    GnSegs sg = {};
+    sg.nseg = num_segments;
+    long long rows = 0;
+    int max_hw = 0;
+    for (int i = 0; i < num_segments; i++) {
+        if (hw_host[i] <= 0) return BRCNN_EINVAL;
+        sg.hw[i] = hw_host[i];
+        sg.row0[i] = rows;
+        rows += (long long)batch * hw_host[i];
+        if (hw_host[i] > max_hw) max_hw = hw_host[i];
+    }
+    for (int i = num_segments; i <= BRCNN_MAX_LEVELS; i++) sg.row0[i] = rows;
     hipStream_t s = (hipStream_t)stream;
-    BRCNN_HIP_CHECK(hipMemsetAsync(stats_ws, 0, (size_t)batch * groups * 2 * sizeof(double), s));
-    int chunks = (hw + 127) / 128;
+    BRCNN_HIP_CHECK(hipMemsetAsync(stats_ws, 0,
+                                   (size_t)batch * num_segments * groups * 2 * sizeof(double), s));
+    int chunks = (max_hw + 127) / 128;
     if (chunks > 512) chunks = 512;
-    const int rows = (hw + chunks - 1) / chunks;
-    chunks = (hw + rows - 1) / rows;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, batch), dim3(256), 0, s, (const float*)x,
-                       (double*)stats_ws, hw, channels, groups, rows);
+    const int rpb = (max_hw + chunks - 1) / chunks;
+    chunks = (max_hw + rpb - 1) / rpb;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+                       (const float*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
     BRCNN_LAUNCH_CHECK();
-    const long long total = (long long)batch * hw * (channels >> 2);
+    const long long total = rows * (channels >> 2);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
-                       (const double*)stats_ws, gamma, beta, (float*)y, batch, hw, channels, groups,
+                       (const double*)stats_ws, gamma, beta, (float*)y, sg, batch, channels, groups,
                        eps, relu);
     BRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+BRCNN_API int brcnn_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y,
+                                   void* stats_ws, int batch, int hw, int channels, int groups,
+                                   float eps, int relu, int dtype, void* stream) {
+    const int hws[1] = {hw};
+    return brcnn_groupnorm_nhwc_multi(x, gamma, beta, y, stats_ws, batch, 1, hws, channels, groups,
+                                      eps, relu, dtype, stream);
 }
 
 BRCNN_API int brcnn_upsample_nearest_add_nhwc(void* dst, const void* src, int batch, int hd, int wd,

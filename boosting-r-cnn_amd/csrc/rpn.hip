@@ -15,13 +15,19 @@
 
 namespace {
 
+// cls / iou: `rows` pixels of A channels each, consecutive pixels `cls_stride` / `iou_stride`
+// floats apart (the fused 54-channel head output is read in place); score (rows, A) dense.
 __global__ __launch_bounds__(256) void rpn_score_kernel(const float* __restrict__ cls,
                                                        const float* __restrict__ iou,
-                                                       float* __restrict__ score, long long n) {
+                                                       float* __restrict__ score, long long rows,
+                                                       int A, int cls_stride, int iou_stride) {
+    const long long n = rows * A;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        const float a = 1.f / (1.f + expf(-cls[i]));
-        const float b = 1.f / (1.f + expf(-iou[i]));
+        const long long r = i / A;
+        const int c = (int)(i - r * A);
+        const float a = 1.f / (1.f + expf(-cls[r * cls_stride + c]));
+        const float b = 1.f / (1.f + expf(-iou[r * iou_stride + c]));
         score[i] = sqrtf(a * b);
     }
 }
@@ -29,6 +35,8 @@ __global__ __launch_bounds__(256) void rpn_score_kernel(const float* __restrict_
 struct DecodeParams {
     float mean[4], std[4];
     float max_ratio, max_h, max_w, min_size;
+    float pred_scale;     // the level's learnable `Scale` (atss_rpn_head.py:211), 1 if pre-applied
+    int pred_stride;      // floats between consecutive pixels of bbox_pred (4A when dense)
     int clip;
 };
 
@@ -49,7 +57,11 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
         const float sx = (float)(cx * stride_w), sy = (float)(cy * stride_h);
         const float4 ba = *reinterpret_cast<const float4*>(base_anchors + a * 4);
         const float x1 = ba.x + sx, y1 = ba.y + sy, x2 = ba.z + sx, y2 = ba.w + sy;
-        const float4 d = *reinterpret_cast<const float4*>(bbox_pred + ((size_t)b * hwA + idx) * 4);
+        const float* dptr = bbox_pred + ((size_t)b * (hwA / A) + cell) * dp.pred_stride + a * 4;
+        float4 d = make_float4(dptr[0], dptr[1], dptr[2], dptr[3]);
+        if (dp.pred_scale != 1.f) {
+            d.x *= dp.pred_scale; d.y *= dp.pred_scale; d.z *= dp.pred_scale; d.w *= dp.pred_scale;
+        }
         const float dx = d.x * dp.std[0] + dp.mean[0];
         const float dy = d.y * dp.std[1] + dp.mean[1];
         float dw = d.z * dp.std[2] + dp.mean[2];
@@ -76,26 +88,29 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
 
 }  // namespace
 
-BRCNN_API int brcnn_rpn_score(const float* cls, const float* iou, float* score, int64_t n,
-                              void* stream) {
-    if (n < 0) return BRCNN_EINVAL;
-    if (n == 0) return 0;
+BRCNN_API int brcnn_rpn_score(const float* cls, const float* iou, float* score, int64_t rows,
+                              int num_anchors, int cls_stride, int iou_stride, void* stream) {
+    if (rows < 0 || num_anchors <= 0 || cls_stride < num_anchors || iou_stride < num_anchors)
+        return BRCNN_EINVAL;
+    if (rows == 0) return 0;
     if (!cls || !iou || !score) return BRCNN_EINVAL;
-    long long g = (n + 255) / 256;
+    long long g = (rows * num_anchors + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(rpn_score_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, cls, iou,
-                       score, (long long)n);
+                       score, (long long)rows, num_anchors, cls_stride, iou_stride);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
 BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
-                               const float* base_anchors, int batch, int count, int height,
-                               int width, int num_anchors, int stride_w, int stride_h,
+                               int pred_stride, float pred_scale, const float* base_anchors,
+                               int batch, int count, int height, int width, int num_anchors,
+                               int stride_w, int stride_h,
                                const float* means4_host, const float* stds4_host,
                                double wh_ratio_clip, float max_h, float max_w, float min_size,
                                float* proposals, uint8_t* valid, void* stream) {
     if (batch < 0 || count < 0 || height <= 0 || width <= 0 || num_anchors <= 0 ||
+        pred_stride < 4 * num_anchors ||
         !means4_host || !stds4_host || !(wh_ratio_clip > 0.0))
         return BRCNN_EINVAL;
     if (batch == 0 || count == 0) return 0;
@@ -105,6 +120,7 @@ BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
     dp.max_ratio = (float)fabs(log(wh_ratio_clip));
     dp.clip = (max_h > 0.f && max_w > 0.f) ? 1 : 0;
     dp.max_h = max_h; dp.max_w = max_w; dp.min_size = min_size;
+    dp.pred_scale = pred_scale; dp.pred_stride = pred_stride;
     const long long total = (long long)batch * count;
     long long g = (total + 255) / 256;
     if (g > 4096) g = 4096;

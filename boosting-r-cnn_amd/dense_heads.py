@@ -19,7 +19,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
-from .blocks import ConvModule, PackedCache, Scale, bias_init_with_prob, to_nhwc
+from .blocks import (ConvModule, PackedCache, Scale, bias_init_with_prob, pack_weight, to_nhwc)
 from .postprocess import batched_nms_images
 from .core import (anchor_inside_flags, bbox_overlaps, images_to_levels, multi_apply, unmap)
 from .registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder,
@@ -140,6 +140,8 @@ class ATSSRPNHead(AnchorHead):
         if self.with_aug_loss:
             self.aug_loss = build_loss(aug_reg_loss)
         self._head_caches = [PackedCache() for _ in range(8)]
+        self._tower_caches = [PackedCache() for _ in range(stacked_convs)]
+        self._fused_head_cache = PackedCache()
         self._base_anchor_cache = {}
         self.init_weights()
 
@@ -194,6 +196,44 @@ class ATSSRPNHead(AnchorHead):
         """feats: list of (N,h,w,C) -> 3 lists of (N,h,w,A | 4A | A) NHWC head outputs"""
         outs = [self.forward_single_nhwc(f, i) for i, f in enumerate(feats)]
         return tuple(map(list, zip(*outs)))
+
+    def forward_fused(self, feats):
+        """All pyramid levels in ONE launch per layer (the tower and the heads share their
+        weights across levels, atss_rpn_head.py:296-297), and the three 3x3 heads as ONE
+        54-channel conv (cls 9 | reg 36 | iou 9).  Returns per level a (N,h,w,54) tensor whose
+        channel slices are the raw head outputs; the per-level `Scale` of rpn_reg is applied by
+        the consumer (`scale(self.rpn_reg(x))` == raw * scale)."""
+        B = feats[0].shape[0]
+        sizes = [tuple(f.shape[1:3]) for f in feats]
+        x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
+        for i, conv in enumerate(self.rpn_convs):
+            assert isinstance(conv.norm, nn.GroupNorm) and conv.conv.bias is None
+            w = self._tower_caches[i].get([conv.conv.weight], lambda c=conv: pack_weight(c.conv.weight))
+            x, _ = ops.conv2d_nhwc_multi(x, w, B, sizes, None, None, None, False, 1, 1)
+            x = ops.groupnorm_nhwc_multi(x, conv.norm.weight.detach(), conv.norm.bias.detach(),
+                                         conv.norm.num_groups, B, sizes, conv.norm.eps,
+                                         conv.with_activation)
+        heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
+
+        def builder():
+            return (torch.cat([pack_weight(h.weight) for h in heads], 0).contiguous(),
+                    torch.cat([h.bias.detach().float() for h in heads], 0).contiguous())
+        w, b = self._fused_head_cache.get([t for h in heads for t in (h.weight, h.bias)], builder)
+        y, _ = ops.conv2d_nhwc_multi(x, w, B, sizes, None, b, None, False, 1, 1)
+        outs, r0 = [], 0
+        for (h, wd) in sizes:
+            n = B * h * wd
+            outs.append(y[r0:r0 + n].view(B, h, wd, y.shape[1]))
+            r0 += n
+        return outs
+
+    def split_fused(self, fused):
+        """(cls, reg_raw, iou) channel-slice views of the fused head outputs + per-level scales"""
+        a, c = self.num_anchors, self.cls_out_channels
+        cls = [f[..., :a * c] for f in fused]
+        reg = [f[..., a * c:a * c + 4 * a] for f in fused]
+        iou = [f[..., a * c + 4 * a:] for f in fused]
+        return cls, reg, iou
 
     def forward(self, feats, bridge=False):
         """reference signature: list of (N,C,h,w) -> lists of (N,A,h,w), (N,4A,h,w), (N,A,h,w)"""
@@ -318,10 +358,12 @@ class ATSSRPNHead(AnchorHead):
             self._base_anchor_cache[key] = self.anchor_generator.base_anchors[level].to(device)
         return self._base_anchor_cache[key]
 
-    def get_bboxes_padded(self, cls_nhwc, reg_nhwc, iou_nhwc, img_metas, cfg=None):
+    def get_bboxes_padded(self, cls_nhwc, reg_nhwc, iou_nhwc, img_metas, cfg=None, reg_scales=None):
         """Device-resident proposal stage for the whole batch (no host sync).
 
-        Inputs are the NHWC head outputs per level: (B,h,w,A), (B,h,w,4A), (B,h,w,A).
+        Inputs are the NHWC head outputs per level: (B,h,w,A), (B,h,w,4A), (B,h,w,A) (dense or
+        channel-slice views of the fused head output; then `reg_scales` carries the per-level
+        Scale still to be applied to the raw deltas).
         Returns (dets (B, max_per_img, 5) zero-padded, num (B,) int32)."""
         cfg = copy.deepcopy(self.test_cfg if cfg is None else cfg)
         assert self.use_sigmoid_cls and self.cls_out_channels == 1
@@ -344,18 +386,21 @@ class ATSSRPNHead(AnchorHead):
             else:
                 topk_inds = torch.arange(n, device=device).expand(B, n).contiguous()
             stride = self.anchor_generator.strides[lvl]
+            rs = 1.0 if reg_scales is None else reg_scales[lvl]
             if len(shapes) == 1:
                 max_shape = next(iter(shapes))
                 props, valid = ops.rpn_decode(topk_inds, reg_nhwc[lvl], self._base_anchors(lvl, device),
                                               (h, w), stride, self.bbox_coder.means,
-                                              self.bbox_coder.stds, max_shape, cfg.min_bbox_size)
+                                              self.bbox_coder.stds, max_shape, cfg.min_bbox_size,
+                                              pred_scale=rs)
             else:   # per-image clip border
                 pl, vl = [], []
                 for b in range(B):
                     p1, v1 = ops.rpn_decode(topk_inds[b:b + 1], reg_nhwc[lvl][b:b + 1],
                                             self._base_anchors(lvl, device), (h, w), stride,
                                             self.bbox_coder.means, self.bbox_coder.stds,
-                                            img_metas[b]['img_shape'][:2], cfg.min_bbox_size)
+                                            img_metas[b]['img_shape'][:2], cfg.min_bbox_size,
+                                            pred_scale=rs)
                     pl.append(p1)
                     vl.append(v1)
                 props, valid = torch.cat(pl), torch.cat(vl)

@@ -115,6 +115,13 @@ class TwoStageDetector(BaseDetector):
             roi_head.update(test_cfg=test_cfg.rcnn)
             self.roi_head = build_head(roi_head)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self._rpn_scale_cache = None    # host copy of rpn_head.scales (freeze_for_inference)
+
+    def freeze_for_inference(self):
+        """read the (tiny) host-side constants once so that `simple_test_device` issues no
+        device->host copies: the five learnable rpn_reg scales."""
+        self._rpn_scale_cache = [float(m.scale.detach().cpu()) for m in self.rpn_head.scales]
+        return self
 
     # ---- features ----------------------------------------------------------------------
     def extract_feat_nhwc(self, img):
@@ -149,8 +156,11 @@ class TwoStageDetector(BaseDetector):
         """Whole inference pass with no host synchronisation: returns device tensors
         (det_bboxes (B,M,5), det_labels (B,M), num_dets (B,))."""
         feats = self.extract_feat_nhwc(img)
-        cls, reg, iou = self.rpn_head.forward_nhwc(list(feats))
-        dets, num = self.rpn_head.get_bboxes_padded(cls, reg, iou, img_metas)
+        rpn = self.rpn_head
+        cls, reg, iou = rpn.split_fused(rpn.forward_fused(list(feats)))
+        scales = [float(s) for s in torch.stack([m.scale.detach() for m in rpn.scales]).tolist()] \
+            if self._rpn_scale_cache is None else self._rpn_scale_cache
+        dets, num = rpn.get_bboxes_padded(cls, reg, iou, img_metas, reg_scales=scales)
         return self.roi_head.simple_test_padded(feats, dets, num, img_metas, rescale=rescale)
 
     def simple_test(self, img, img_metas, proposals=None, rescale=False):

@@ -33,13 +33,17 @@ SIGNATURES = {
     'brcnn_sigmoid_focal_loss_forward': (c_int, [c_ptr] * 4 + [c_i64, c_i64, c_f32, c_f32, c_ptr]),
     'brcnn_sigmoid_focal_loss_backward': (c_int, [c_ptr] * 4 + [c_i64, c_i64, c_f32, c_f32, c_ptr]),
     'brcnn_conv2d_nhwc': (c_int, [c_ptr] * 6 + [c_int] * 11 + [c_ptr]),
+    'brcnn_conv2d_nhwc_multi': (c_int, [c_ptr] * 6 + [c_int, c_int, c_ptr, c_ptr] + [c_int] * 8 +
+                                [c_ptr]),
     'brcnn_maxpool3x3s2_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 5 + [c_ptr]),
     'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
+    'brcnn_groupnorm_nhwc_multi': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_int, c_int, c_f32,
+                                                          c_int, c_int, c_ptr]),
     'brcnn_upsample_nearest_add_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 7 + [c_ptr]),
     'brcnn_nchw_to_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
     'brcnn_nhwc_to_nchw': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
-    'brcnn_rpn_score': (c_int, [c_ptr] * 3 + [c_i64, c_ptr]),
-    'brcnn_rpn_decode': (c_int, [c_ptr] * 3 + [c_int] * 7 + [c_ptr, c_ptr, c_f64, c_f32, c_f32,
+    'brcnn_rpn_score': (c_int, [c_ptr] * 3 + [c_i64, c_int, c_int, c_int, c_ptr]),
+    'brcnn_rpn_decode': (c_int, [c_ptr] * 2 + [c_int, c_f32, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr, c_f64, c_f32, c_f32,
                                                              c_f32, c_ptr, c_ptr, c_ptr]),
 }
 

@@ -429,6 +429,49 @@ def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=
     return y
 
 
+def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
+                      stride=1, pad=0):
+    """The same conv over several back-to-back segments that share the weights (pyramid
+    levels).  x_cat (sum_l batch*H_l*W_l, Cin) rows; `sizes` = [(H_l, W_l)].  Returns
+    (y_cat (sum_l batch*Ho_l*Wo_l, Cout), [(Ho_l, Wo_l)])."""
+    import ctypes
+    _require_gpu(x_cat, w, scale, shift, residual)
+    assert x_cat.dim() == 2 and x_cat.is_contiguous() and w.is_contiguous()
+    cout, kh, kw, cin = w.shape
+    assert x_cat.shape[1] == cin and x_cat.shape[0] == sum(batch * h * ww for h, ww in sizes)
+    out_sizes = [conv_out_size(h, ww, kh, kw, stride, pad) for h, ww in sizes]
+    rows = sum(batch * h * ww for h, ww in out_sizes)
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x_cat.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.is_contiguous()
+    L = len(sizes)
+    hs = (ctypes.c_int * L)(*[h for h, _ in sizes])
+    ws = (ctypes.c_int * L)(*[ww for _, ww in sizes])
+    st = _L.load().brcnn_conv2d_nhwc_multi(_ptr(x_cat), _ptr(w), _ptr(scale), _ptr(shift),
+                                           _ptr(residual), _ptr(y), batch, L, hs, ws, cin, cout, kh,
+                                           kw, int(stride), int(pad), int(bool(relu)), DT_F32,
+                                           _stream())
+    _L.check(st, 'brcnn_conv2d_nhwc_multi')
+    return y, out_sizes
+
+
+def groupnorm_nhwc_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, relu=False):
+    """GroupNorm(+ReLU) with statistics per (segment, image, group) over a concatenation of
+    NHWC segments (rows, C)."""
+    import ctypes
+    _require_gpu(x_cat, gamma, beta)
+    L = len(sizes)
+    c = x_cat.shape[1]
+    y = torch.empty_like(x_cat)
+    ws = torch.empty((batch * L * groups * 2,), dtype=torch.float64, device=x_cat.device)
+    hw = (ctypes.c_int * L)(*[h * w for h, w in sizes])
+    st = _L.load().brcnn_groupnorm_nhwc_multi(_ptr(x_cat), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(ws),
+                                              batch, L, hw, c, int(groups), float(eps),
+                                              int(bool(relu)), DT_F32, _stream())
+    _L.check(st, 'brcnn_groupnorm_nhwc_multi')
+    return y
+
+
 def linear_nhwc(x, w, bias=None, relu=False):
     """x (M,K) @ w (N,K)^T + bias: the 1x1 case of the implicit GEMM with H=W=1."""
     m, k = x.shape
@@ -489,32 +532,51 @@ def nhwc_to_nchw(x):
 
 
 # ----------------------------------------------------------------------------- RPN stage
+def _last_dim_strided(t):
+    """(rows, A) view info of a tensor whose last dim is dense and whose other dims collapse to
+    one row stride (a channel slice of an NHWC tensor): returns (rows, A, row_stride)"""
+    a = t.shape[-1]
+    assert t.stride(-1) == 1
+    rows = t.numel() // a
+    rs = t.stride(-2) if t.dim() > 1 else a
+    for d in range(t.dim() - 2, 0, -1):          # collapsible: stride[d-1] == stride[d]*shape[d]
+        assert t.stride(d - 1) == t.stride(d) * t.shape[d], 'rpn ops need row-collapsible views'
+    return rows, a, rs
+
+
 def rpn_score(cls, iou):
-    """sqrt(sigmoid(cls) * sigmoid(iou)) element-wise (atss_rpn_head.py:712-725)."""
+    """sqrt(sigmoid(cls) * sigmoid(iou)) element-wise (atss_rpn_head.py:712-725).  cls / iou
+    may be channel slices of a wider NHWC tensor (read in place); the result is dense."""
     _require_gpu(cls, iou)
-    cls, iou = cls.contiguous(), iou.contiguous()
-    out = torch.empty_like(cls)
-    st = _L.load().brcnn_rpn_score(_ptr(cls), _ptr(iou), _ptr(out), cls.numel(), _stream())
+    rows, a, cs = _last_dim_strided(cls)
+    rows2, a2, is_ = _last_dim_strided(iou)
+    assert (rows, a) == (rows2, a2)
+    out = torch.empty(cls.shape, dtype=torch.float32, device=cls.device)
+    st = _L.load().brcnn_rpn_score(_ptr(cls), _ptr(iou), _ptr(out), rows, a, cs, is_, _stream())
     _L.check(st, 'brcnn_rpn_score')
     return out
 
 
 def rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds, max_shape,
-               min_size, wh_ratio_clip=16 / 1000):
-    """topk_inds (B,k) int64 flat anchor indices of one level; bbox_pred (B,H,W,4A) NHWC.
+               min_size, wh_ratio_clip=16 / 1000, pred_scale=1.0):
+    """topk_inds (B,k) int64 flat anchor indices of one level; bbox_pred (B,H,W,4A) NHWC, possibly
+    a channel slice of a wider tensor; deltas are multiplied by `pred_scale` first.
     Returns (proposals (B,k,4), valid (B,k) uint8)."""
     import ctypes
     _require_gpu(topk_inds, bbox_pred, base_anchors)
     b, k = topk_inds.shape
     h, w = feat_hw
     a = base_anchors.size(0)
+    _, a4, pstride = _last_dim_strided(bbox_pred)
+    assert a4 == 4 * a
     props = torch.empty((b, k, 4), dtype=torch.float32, device=bbox_pred.device)
     valid = torch.empty((b, k), dtype=torch.uint8, device=bbox_pred.device)
     m4 = (ctypes.c_float * 4)(*[float(v) for v in means])
     s4 = (ctypes.c_float * 4)(*[float(v) for v in stds])
     sw, sh = (stride, stride) if isinstance(stride, int) else stride
     mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
-    st = _L.load().brcnn_rpn_decode(_ptr(topk_inds.contiguous()), _ptr(bbox_pred.contiguous()),
+    st = _L.load().brcnn_rpn_decode(_ptr(topk_inds.contiguous()), _ptr(bbox_pred), int(pstride),
+                                    float(pred_scale),
                                     _ptr(base_anchors.contiguous().float()), b, k, h, w, a,
                                     int(sw), int(sh), m4, s4, float(wh_ratio_clip), mh, mw,
                                     float(min_size), _ptr(props), _ptr(valid), _stream())

@@ -151,6 +151,15 @@ int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const fl
                       int cout, int kh, int kw, int stride, int pad, int relu, int dtype,
                       void *stream);
 
+/* The same convolution over `num_segments` feature maps that share one set of weights (the
+ * RetinaRPN tower and heads run over 5 pyramid levels, atss_rpn_head.py:296-297): x and y hold
+ * the segments back to back ((N,H_s,W_s,Cin) then the next), one launch covers all of them. */
+int brcnn_conv2d_nhwc_multi(const void *x, const void *w, const float *scale, const float *shift,
+                            const void *residual, void *y, int batch, int num_segments,
+                            const int *heights_host, const int *widths_host, int cin, int cout,
+                            int kh, int kw, int stride, int pad, int relu, int dtype,
+                            void *stream);
+
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,
                             int channels, int dtype, void *stream);
@@ -161,6 +170,11 @@ int brcnn_groupnorm_nhwc(const void *x, const float *gamma, const float *beta, v
                          void *stats_ws /* batch*groups*2 doubles of device scratch */,
                          int batch, int hw, int channels, int groups, float eps, int relu,
                          int dtype, void *stream);
+
+int brcnn_groupnorm_nhwc_multi(const void *x, const float *gamma, const float *beta, void *y,
+                               void *stats_ws /* batch*num_segments*groups*2 doubles */,
+                               int batch, int num_segments, const int *hw_host, int channels,
+                               int groups, float eps, int relu, int dtype, void *stream);
 
 /* FPN top-down path: dst[n,y,x,c] += src[n, y*Hs/Hd, x*Ws/Wd, c]  (nearest,
  * F.interpolate(size=...) at necks/pafpn.py:113-115, fpn.py:178-181) */
@@ -179,15 +193,20 @@ int brcnn_nhwc_to_nchw(const void *src, float *dst, int batch, int channels, int
  * core/anchor/anchor_generator.py:336-381 and delta2bbox
  * core/bbox/coder/delta_xywh_bbox_coder.py:145-272 fused in).
  *
- * brcnn_rpn_score: score[n, (y*W+x)*A + a] = sqrt(sigmoid(cls)*sigmoid(iou)) for one
- *   level; cls/iou are the head outputs in NHWC (N,H,W,A) fp32.
+ * brcnn_rpn_score: score[r*A + a] = sqrt(sigmoid(cls)*sigmoid(iou)) over `rows` pixels of
+ *   NHWC head output; consecutive pixels are cls_stride / iou_stride floats apart (A when the
+ *   tensor is dense, 54 when the fused cls|reg|iou head output is read in place).
+ *   bbox_pred likewise has pred_stride floats per pixel and is multiplied by pred_scale
+ *   (the level's learnable Scale) before decoding.
  * brcnn_rpn_decode: for `count` selected anchors (flat index into (H*W*A) of one
  *   level) regenerate the anchor from base_anchors (A,4) + stride, apply
  *   delta2bbox(means 0, stds `std4`, wh_ratio_clip) with max_shape clipping; writes
  *   proposals (count,4) and valid (count) uint8 = w > min_size && h > min_size.
  * -------------------------------------------------------------------------- */
-int brcnn_rpn_score(const float *cls, const float *iou, float *score, int64_t n, void *stream);
-int brcnn_rpn_decode(const int64_t *topk_inds, const float *bbox_pred, const float *base_anchors,
+int brcnn_rpn_score(const float *cls, const float *iou, float *score, int64_t rows,
+                    int num_anchors, int cls_stride, int iou_stride, void *stream);
+int brcnn_rpn_decode(const int64_t *topk_inds, const float *bbox_pred, int pred_stride,
+                     float pred_scale, const float *base_anchors,
                      int batch, int count, int height, int width, int num_anchors, int stride_w,
                      int stride_h, const float *means4_host, const float *stds4_host,
                      double wh_ratio_clip, float max_h, float max_w, float min_size,

@@ -30,6 +30,27 @@ def _conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride
     return y.contiguous()
 
 
+def _split_rows(x_cat, batch, sizes):
+    out, r0 = [], 0
+    for h, w in sizes:
+        n = batch * h * w
+        out.append(x_cat[r0:r0 + n].view(batch, h, w, x_cat.shape[1]))
+        r0 += n
+    return out
+
+
+def _conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
+                       stride=1, pad=0):
+    assert residual is None
+    ys = [_conv2d_nhwc(x, w, scale, shift, None, relu, stride, pad) for x in _split_rows(x_cat, batch, sizes)]
+    return torch.cat([y.reshape(-1, y.shape[3]) for y in ys], 0), [tuple(y.shape[1:3]) for y in ys]
+
+
+def _groupnorm_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, relu=False):
+    ys = [_groupnorm(x, gamma, beta, groups, eps, relu) for x in _split_rows(x_cat, batch, sizes)]
+    return torch.cat([y.reshape(-1, y.shape[3]) for y in ys], 0)
+
+
 def _linear_nhwc(x, w, bias=None, relu=False):
     y = F.linear(x, w, bias)
     return y.relu() if relu else y
@@ -93,7 +114,7 @@ def _rpn_score(cls, iou):
 
 
 def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds, max_shape,
-                min_size, wh_ratio_clip=16 / 1000):
+                min_size, wh_ratio_clip=16 / 1000, pred_scale=1.0):
     from brcnn.core import delta2bbox
     b, k = topk_inds.shape
     h, w = feat_hw
@@ -105,17 +126,34 @@ def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds
     sy = ((cell // w) * sh).to(base_anchors)
     anchors = base_anchors[ai] + torch.stack([sx, sy, sx, sy], -1)
     d = torch.gather(bbox_pred.reshape(b, -1, 4), 1, topk_inds[..., None].expand(b, k, 4))
+    if pred_scale != 1.0:
+        d = d * pred_scale
     props = delta2bbox(anchors.view(-1, 4), d.view(-1, 4), means, stds, max_shape, wh_ratio_clip).view(b, k, 4)
     valid = ((props[..., 2] - props[..., 0]) > min_size) & ((props[..., 3] - props[..., 1]) > min_size)
     return props, valid.to(torch.uint8)
 
 
-_PATCH = dict(conv2d_nhwc=_conv2d_nhwc, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
+_PATCH = dict(conv2d_nhwc=_conv2d_nhwc, conv2d_nhwc_multi=_conv2d_nhwc_multi,
+              groupnorm_nhwc_multi=_groupnorm_multi, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
               groupnorm_nhwc=_groupnorm, upsample_nearest_add_nhwc_=_upsample_add_,
               nchw_to_nhwc=_nchw_to_nhwc, nhwc_to_nchw=_nhwc_to_nchw, roi_extract=_roi_extract,
               nms_ranges=_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode,
               nms=orc.nms, soft_nms=orc.soft_nms, batched_nms=orc.batched_nms,
               roi_align=orc.roi_align, RoIAlign=orc.RoIAlign)
+
+
+def available_cpus():
+    """host cores this process may actually use: min(affinity mask, cgroup cpu quota)"""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 @contextlib.contextmanager
@@ -139,7 +177,7 @@ def timed_baseline(cfg, seed=0, batch=1, budget_s=20.0, threads=None):
     import os
     from brcnn import build_detector
     from tests import util
-    threads = threads or os.cpu_count()
+    threads = threads or available_cpus()
     torch.set_num_threads(threads)
     with patched():
         m = build_detector(cfg.model)

@@ -29,6 +29,23 @@ def _match_dets(got, ref, box_tol=1e-2, score_tol=1e-3):
     return ok.mean()
 
 
+def _canon(p):
+    """rows with EXACTLY equal scores may come in either order (the reference's sort is not
+    stable, ours breaks ties by index): order such runs by coordinates before comparing"""
+    p = p.clone()
+    i = 0
+    while i < len(p):
+        j = i + 1
+        while j < len(p) and p[j, 4] == p[i, 4]:
+            j += 1
+        if j - i > 1:
+            blk = p[i:j]
+            key = blk[:, 0] * 1e6 + blk[:, 1]
+            p[i:j] = blk[torch.argsort(key)]
+        i = j
+    return p
+
+
 def test_rpn_get_bboxes_golden():
     g = load('g5_rpn_get_bboxes')
     cfg = Config.fromfile(CFG)
@@ -131,3 +148,16 @@ def test_model_end_to_end_golden(model):
             assert _match_dets(res[b][c], ref) >= 0.9, (b, c, len(ref), len(res[b][c]))
             assert _match_dets(ref, res[b][c]) >= 0.9
             assert np.array_equal(res[b][c], res2[b][c])
+
+
+def test_fused_rpn_head_equals_per_level(model):
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=10)
+    with torch.no_grad():
+        feats = model.extract_feat_nhwc(img.to(DEV))
+        cls, reg, iou = model.rpn_head.forward_nhwc(list(feats))
+        fc, fr, fi = model.rpn_head.split_fused(model.rpn_head.forward_fused(list(feats)))
+    for l in range(5):
+        s = float(model.rpn_head.scales[l].scale)
+        assert torch.allclose(fc[l], cls[l], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(fi[l], iou[l], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(fr[l] * s, reg[l], rtol=1e-5, atol=1e-5)

@@ -389,3 +389,34 @@ def test_rpn_score_and_decode():
         v = ((ref[:, 2] - ref[:, 0]) > 0) & ((ref[:, 3] - ref[:, 1]) > 0)
         agree = (valid[b].cpu().bool() == v)
         assert agree.float().mean().item() > 0.995
+
+
+def test_multi_level_conv_and_groupnorm_match_per_level():
+    sizes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    B, C = 2, 64
+    g = torch.Generator().manual_seed(3)
+    feats = [torch.randn(B, h, w, C, generator=g).to(DEV) for h, w in sizes]
+    w = (torch.randn(54, 3, 3, C, generator=g) / 24).to(DEV)
+    b = torch.randn(54, generator=g).to(DEV)
+    x = torch.cat([f.reshape(-1, C) for f in feats], 0)
+    y, osz = ops.conv2d_nhwc_multi(x, w, B, sizes, None, b, None, False, 1, 1)
+    assert osz == sizes
+    r0 = 0
+    for f, (h, wd) in zip(feats, sizes):
+        ref = ops.conv2d_nhwc(f, w, None, b, None, False, 1, 1)
+        n = B * h * wd
+        assert torch.equal(y[r0:r0 + n].view(B, h, wd, 54), ref)
+        r0 += n
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    z = ops.groupnorm_nhwc_multi(x, gamma, beta, 32, B, sizes, 1e-5, True)
+    r0 = 0
+    for f, (h, wd) in zip(feats, sizes):
+        ref = ops.groupnorm_nhwc(f, gamma, beta, 32, 1e-5, True)
+        n = B * h * wd
+        assert torch.allclose(z[r0:r0 + n].view(B, h, wd, C), ref, atol=1e-6)
+        r0 += n
+    # strided (channel-slice) inputs of the rpn kernels
+    full = torch.randn(2, 5, 7, 54, generator=g).to(DEV)
+    s1 = ops.rpn_score(full[..., :9], full[..., 45:])
+    s2 = ops.rpn_score(full[..., :9].contiguous(), full[..., 45:].contiguous())
+    assert torch.equal(s1, s2)
