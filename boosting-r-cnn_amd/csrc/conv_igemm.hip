@@ -13,23 +13,35 @@
 //
 // fp32 path: v_mfma_f32_32x32x2_f32 -- an exact fp32 FMA chain (no TF32 on gfx950) at the
 // fp32 vector rate (157 TF/s chip peak), so the results track the reference CPU path to fp32
-// round-off.  Workgroup = 256 threads = 4 waves (2x2), tile 128(M) x 128(N) x 32(K), each
-// wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  Operands are staged
-// global -> registers -> LDS (issue the next tile's loads before the MFMA block, write them
-// after it), LDS rows padded to 36 floats so the ds_read_b128 fragment reads are
-// bank-conflict free; each lane reads 4 consecutive k per b128 and the K order inside an
-// 8-deep group is permuted identically for A and W (lane half h takes k = 4h..4h+3), which
-// leaves every product paired correctly and needs one LDS read per 4 MFMAs per operand.
-// Epilogue fused: per-channel scale/shift (folded BN or bias), residual add, ReLU.
-// Block ids are remapped so that each XCD's L2 sees a contiguous run of tiles (the N tiles
-// of one M tile share the gathered A rows).
+// round-off.  A workgroup is WM x 2 waves, each wave owning a 64 x (32*NT) output tile
+// (2 x NT MFMA tiles); block tile = (64*WM) x (64*NT), K tile 32:
+//     WM=2 NT=2 : 128x128, 256 threads, 2 workgroups / CU      (default)
+//     WM=2 NT=1 : 128x64  for Cout <= 64
+//     WM=4 NT=2 : 256x128, 512 threads, 1 workgroup / CU       (large M: fewer L2->LDS bytes
+//                                                               per FLOP)
+// Operands are staged global -> registers -> LDS (the next tile's loads are issued before the
+// MFMA block and written after it); LDS rows are padded to 36 floats so the ds_read_b128
+// fragment reads are bank-conflict free; each lane reads 4 consecutive k per b128 and the K
+// order inside an 8-deep group is permuted identically for A and W (lane half h takes
+// k = 4h..4h+3), which keeps every product paired correctly and needs one LDS read per 4
+// MFMAs per operand.  Epilogue fused: per-channel scale/shift (folded BN or bias), residual
+// add, ReLU; the residual tile is prefetched into registers before the K loop so that its
+// latency hides under the MFMAs.  Block ids are remapped so that each XCD's L2 sees a
+// contiguous run of tiles (the N tiles of one M tile share the gathered A rows).
+// Several feature maps that share one set of weights (pyramid levels) run as ONE launch: the
+// output rows of the segments are concatenated and each row carries its own geometry.
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BK = 32, LDS_STRIDE = 36;
+// any byte offset >= the buffer extent makes a raw buffer load return zeros: the zero padding
+// of the convolution and the M / Cout tails cost no branch and no select
+constexpr int OOB = 0x7fffffff;
+
+constexpr int BK = 32, LDS_STRIDE = 36;
 
 struct ConvParams {
     const float* x;
@@ -38,13 +50,13 @@ struct ConvParams {
     const float* shift;
     const float* residual;
     float* y;
-    int batch, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int batch, Cin, Cout, KH, KW, stride, pad;
     int M, K;
     int relu;
     int tiles_m, tiles_n;
     int pitch;                       // floats between adjacent input pixels (== Cin normally)
-    // multi-segment launches (pyramid levels sharing one set of weights): segment s covers
-    // output rows [seg_m0[s], seg_m0[s+1]) and has its own spatial geometry / input offset
+    unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
+    // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
     int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
@@ -59,12 +71,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + loc;
 }
 
-// FAST: Cin % 32 == 0 (a K tile never straddles a filter tap).
-// NT = number of 32-wide MFMA column tiles per wave: NT=2 -> block tile 128x128 (waves 2x2,
-// each 64x64), NT=1 -> block tile 128x64 for Cout <= 64 (waves 2x2, each 64x32).
-template <bool FAST, int NT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
-    constexpr int BN = 64 * NT;
+// FAST: Cin % 32 == 0 (a K tile never straddles a filter tap).  RES: residual operand present.
+template <bool FAST, int WM, int NT, bool RES>
+__global__ __launch_bounds__(128 * WM, 2) void conv_igemm_f32_kernel(ConvParams p) {
+    constexpr int THREADS = 128 * WM;
+    constexpr int BM = 64 * WM, BN = 64 * NT;
+    constexpr int RPP = THREADS / 8;            // tile rows staged per pass (8 float4 per row)
+    constexpr int AJ = BM / RPP;                // == 4
+    constexpr int BJ = (BN + RPP - 1) / RPP;    // 1, 2 or 4
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDS_STRIDE]
     float* Bs = smem + 2 * BM * LDS_STRIDE;    // [2][BN][LDS_STRIDE]
@@ -72,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
     const float* __restrict__ xin = p.x;
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -79,17 +94,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- staging assignment: float4 column c4 of rows r0 + 32*j -------------------------
+    // ---- staging assignment: float4 column c4 of rows r0 + RPP*j --------------------------
     const int c4 = tid & 7;
     const int r0 = tid >> 3;
-    // a_hw packs (hi0 + 4096) << 16 | (wi0 + 4096); a_base < 0: row invalid
-    long long a_base[4];
-    int a_hw[4], a_H[4], a_W[4];
-    const float* b_ptr[2 * NT];
-    bool b_ok[2 * NT];
+    int a_base[AJ];                // element offset of the row's image; < 0: row outside M
+    int a_hw[AJ], a_H[AJ], a_W[AJ];   // a_hw packs (hi0 + 4096) << 16 | (wi0 + 4096)
+    const float* b_ptr[BJ];
+    int b_off[BJ];                 // element offset of the weight row; < 0: outside Cout
+    bool b_ok[BJ];
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int m = m0 + r0 + 32 * j;
+    for (int j = 0; j < AJ; j++) {
+        const int m = m0 + r0 + RPP * j;
         if (m < p.M) {
             int sg = 0;
 #pragma unroll
@@ -102,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             const int n = ml / (Ho * Wo);
             const int rem = ml - n * (Ho * Wo);
             const int ho = rem / Wo, wo = rem - ho * Wo;
-            a_base[j] = p.seg_xoff[sg] + (long long)n * a_H[j] * a_W[j] * p.pitch;
+            a_base[j] = (int)p.seg_xoff[sg] + n * a_H[j] * a_W[j] * p.pitch;
             a_hw[j] = ((ho * p.stride - p.pad + 4096) << 16) | (wo * p.stride - p.pad + 4096);
         } else {
             a_base[j] = -1;
@@ -111,10 +128,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2 * NT; j++) {
-        const int co = n0 + r0 + 32 * j;
-        b_ok[j] = co < p.Cout;
+    for (int j = 0; j < BJ; j++) {
+        const int row = r0 + RPP * j;
+        const int co = n0 + row;
+        b_ok[j] = (row < BN) && (co < p.Cout);
         b_ptr[j] = p.w + (size_t)(b_ok[j] ? co : 0) * p.K;
+        b_off[j] = b_ok[j] ? co * p.K + c4 * 4 : -1;
     }
 
     f32x16 acc[2][NT];
@@ -125,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    float4 ra[4], rb[2 * NT];
+    float4 ra[AJ], rb[BJ];
     const int nk = (p.K + BK - 1) / BK;
 
     auto load_tile = [&](int kt) {
@@ -135,26 +154,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             const int ci = k0 - tap * p.Cin + c4 * 4;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < AJ; j++) {
                 const int hi = (a_hw[j] >> 16) - 4096 + kh;
                 const int wi = (a_hw[j] & 0xffff) - 4096 + kw;
-                const bool ok = a_base[j] >= 0 && hi >= 0 && hi < a_H[j] && wi >= 0 && wi < a_W[j];
-                if (ok)
-                    ra[j] = *reinterpret_cast<const float4*>(
-                        xin + a_base[j] + ((long long)(hi * a_W[j] + wi)) * p.pitch + ci);
-                else
-                    ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool ok = (a_base[j] >= 0) & ((unsigned)hi < (unsigned)a_H[j]) &
+                                ((unsigned)wi < (unsigned)a_W[j]);
+                const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci) * 4 : OOB;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
+                ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                                    __uint_as_float(v.w));
             }
 #pragma unroll
-            for (int j = 0; j < 2 * NT; j++) {
-                if (b_ok[j])
-                    rb[j] = *reinterpret_cast<const float4*>(b_ptr[j] + k0 + c4 * 4);
-                else
-                    rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < BJ; j++) {
+                const int off = (b_off[j] >= 0) ? (b_off[j] + k0) * 4 : OOB;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);
+                rb[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                                    __uint_as_float(v.w));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < AJ; j++) {
                 float va[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -166,13 +185,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
                         const int hi = (a_hw[j] >> 16) - 4096 + kh;
                         const int wi = (a_hw[j] & 0xffff) - 4096 + kw;
                         if (a_base[j] >= 0 && hi >= 0 && hi < a_H[j] && wi >= 0 && wi < a_W[j])
-                            va[e] = xin[a_base[j] + ((long long)(hi * a_W[j] + wi)) * p.pitch + ci];
+                            va[e] = xin[(long long)a_base[j] + ((long long)(hi * a_W[j] + wi)) * p.pitch + ci];
                     }
                 }
                 ra[j] = make_float4(va[0], va[1], va[2], va[3]);
             }
 #pragma unroll
-            for (int j = 0; j < 2 * NT; j++) {
+            for (int j = 0; j < BJ; j++) {
                 float vb[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -187,56 +206,78 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         float* as = As + buf * BM * LDS_STRIDE;
         float* bs = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<float4*>(as + (r0 + 32 * j) * LDS_STRIDE + c4 * 4) = ra[j];
+        for (int j = 0; j < AJ; j++)
+            *reinterpret_cast<float4*>(as + (r0 + RPP * j) * LDS_STRIDE + c4 * 4) = ra[j];
 #pragma unroll
-        for (int j = 0; j < 2 * NT; j++)
-            *reinterpret_cast<float4*>(bs + (r0 + 32 * j) * LDS_STRIDE + c4 * 4) = rb[j];
+        for (int j = 0; j < BJ; j++)
+            if (BJ * RPP == BN || r0 + RPP * j < BN)
+                *reinterpret_cast<float4*>(bs + (r0 + RPP * j) * LDS_STRIDE + c4 * 4) = rb[j];
     };
 
     load_tile(0);
-    store_tile(0);
-    __syncthreads();
 
-    const int li = lane & 31, lh = lane >> 5;
-    int cur = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const float* as = As + cur * BM * LDS_STRIDE + (wm * 64 + li) * LDS_STRIDE + lh * 4;
-        const float* bs = Bs + cur * BN * LDS_STRIDE + (wn * 32 * NT + li) * LDS_STRIDE + lh * 4;
+    // ---- residual prefetch: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const float* __restrict__ res = p.residual;
+    float rv[2][NT][16];
+    if (RES) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; kk++) {
-            const float4 a0 = *reinterpret_cast<const float4*>(as + kk * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDS_STRIDE + kk * 8);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-            float bv[NT][4];
+        for (int tn = 0; tn < NT; tn++) {
+            const int co = n0 + wn * 32 * NT + tn * 32 + li;
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float4 b = *reinterpret_cast<const float4*>(bs + t * 32 * LDS_STRIDE + kk * 8);
-                bv[t][0] = b.x; bv[t][1] = b.y; bv[t][2] = b.z; bv[t][3] = b.w;
+            for (int tm = 0; tm < 2; tm++) {
+                const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    rv[tm][tn][r] = (co < p.Cout && m < p.M) ? res[(size_t)m * p.Cout + co] : 0.f;
+                }
             }
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-#pragma unroll
-                for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-                    for (int t = 0; t < NT; t++)
-                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][e], bv[t][e],
-                                                                          acc[tm][t], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            store_tile(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
         }
     }
 
-    // ---- epilogue: scale/shift, residual, relu.  D layout: col = lane&31,
-    // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The residual operand of one 32x32 tile is
-    // fetched as a batch (16 independent loads in flight) before any store is issued: the
-    // output and residual pointers are __restrict__, otherwise every load would have to
-    // wait behind the previous store.
-    const float* __restrict__ res = p.residual;
+    store_tile(0);
+    __syncthreads();
+
+    auto mfma_group = [&](const float* as, const float* bs, int kk) {
+        const float4 a0 = *reinterpret_cast<const float4*>(as + kk * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDS_STRIDE + kk * 8);
+        const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        float bv[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float4 b = *reinterpret_cast<const float4*>(bs + t * 32 * LDS_STRIDE + kk * 8);
+            bv[t][0] = b.x; bv[t][1] = b.y; bv[t][2] = b.z; bv[t][3] = b.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][e], bv[t][e], acc[tm][t],
+                                                                      0, 0, 0);
+    };
+
+    // K loop.  Per iteration: the next tile's buffer loads are issued first, half of the MFMAs
+    // run, the (by then landed) registers are written to the other LDS buffer, the second half
+    // of the MFMAs runs, one barrier.  No branches inside: the scheduler is free to slot the
+    // address arithmetic and the LDS writes into the 64-cycle shadows of the MFMAs.
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        const float* as = As + cur * BM * LDS_STRIDE + (wm * 64 + li) * LDS_STRIDE + lh * 4;
+        const float* bs = Bs + cur * BN * LDS_STRIDE + (wn * 32 * NT + li) * LDS_STRIDE + lh * 4;
+        mfma_group(as, bs, 0);
+        mfma_group(as, bs, 1);
+        if (more) store_tile(cur ^ 1);
+        mfma_group(as, bs, 2);
+        mfma_group(as, bs, 3);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: scale/shift, residual, relu ----------------------------------------------
     float* __restrict__ yout = p.y;
 #pragma unroll
     for (int tn = 0; tn < NT; tn++) {
@@ -247,19 +288,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
             const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                rv[r] = (res && cok && m < p.M) ? res[(size_t)m * p.Cout + co] : 0.f;
-            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 float v = acc[tm][tn][r];
                 if (p.scale) v = v * sc;
                 v = v + sh;
-                v = v + rv[r];
+                if (RES) v = v + rv[tm][tn][r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (cok && m < p.M) yout[(size_t)m * p.Cout + co] = v;
             }
@@ -267,31 +302,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     }
 }
 
-template <bool FAST, int NT>
+template <bool FAST, int WM, int NT, bool RES>
 int launch_conv(const ConvParams& p, hipStream_t s) {
-    const size_t lds = (size_t)2 * (BM + 64 * NT) * LDS_STRIDE * sizeof(float);
+    const size_t lds = (size_t)2 * (64 * WM + 64 * NT) * LDS_STRIDE * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<FAST, NT>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<FAST, WM, NT, RES>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<FAST, NT>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds,
-                       s, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<FAST, WM, NT, RES>), dim3(p.tiles_m * p.tiles_n),
+                       dim3(128 * WM), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
+template <bool FAST, int WM, int NT>
+int launch_res(const ConvParams& p, hipStream_t s) {
+    return p.residual ? launch_conv<FAST, WM, NT, true>(p, s) : launch_conv<FAST, WM, NT, false>(p, s);
+}
+
+int g_force_wm = 0;   // tuning hook (brcnn_conv_set_tile): 0 = heuristic
+
 int dispatch_conv(ConvParams& p, hipStream_t s) {
     const int nt = (p.Cout <= 64) ? 1 : 2;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.Cout + 64 * nt - 1) / (64 * nt);
     const bool fast = (p.Cin % 32 == 0);
-    if (fast) return nt == 1 ? launch_conv<true, 1>(p, s) : launch_conv<true, 2>(p, s);
-    return nt == 1 ? launch_conv<false, 1>(p, s) : launch_conv<false, 2>(p, s);
+    // measured on MI355X (profiles/r01_conv_tiles.txt): the 256-row tile never beats 128x128
+    // for this network (the kernel is MFMA-issue bound, not L2->LDS bound), so it is only
+    // reachable through the tuning hook
+    int wm = 2;
+    if (g_force_wm == 4 && fast && nt == 2) wm = 4;
+    p.tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
+    p.tiles_n = (p.Cout + 64 * nt - 1) / (64 * nt);
+    if (!fast) return nt == 1 ? launch_res<false, 2, 1>(p, s) : launch_res<false, 2, 2>(p, s);
+    if (nt == 1) return launch_res<true, 2, 1>(p, s);
+    return wm == 4 ? launch_res<true, 4, 2>(p, s) : launch_res<true, 2, 2>(p, s);
 }
 
 }  // namespace
+
+BRCNN_API int brcnn_conv_set_tile(int wm) {
+    if (wm != 0 && wm != 2 && wm != 4) return BRCNN_EINVAL;
+    g_force_wm = wm;
+    return 0;
+}
 
 BRCNN_API int brcnn_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* shift,
                                 const void* residual, void* y, int batch, int height, int width,
@@ -331,7 +385,9 @@ BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float*
         if (m_total > 0x7fffffffLL) return BRCNN_EINVAL;
     }
     for (int sgi = num_segments; sgi <= BRCNN_MAX_LEVELS; sgi++) p.seg_m0[sgi] = (int)m_total;
-    p.H = p.seg_H[0]; p.W = p.seg_W[0]; p.Ho = p.seg_Ho[0]; p.Wo = p.seg_Wo[0];
+    if (x_off * 4 >= 0x7fffffffLL || (long long)cout * kh * kw * cin * 4 >= 0x7fffffffLL) return BRCNN_EINVAL;
+    p.x_bytes = (unsigned)(x_off * 4);
+    p.w_bytes = (unsigned)((long long)cout * kh * kw * cin * 4);
     p.M = (int)m_total;
     p.K = kh * kw * cin;
     p.relu = relu;

@@ -30,11 +30,25 @@ def record_conv_launches(records):
         nbytes = 4 * (x.numel() + w.numel() + y.numel() + (residual.numel() if residual is not None else 0))
         records.append((s, e, 2.0 * m * k * w.shape[0], nbytes, (m, w.shape[0], k)))
         return y
+    orig_multi = ops.conv2d_nhwc_multi
+
+    def wrapped_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
+                      stride=1, pad=0):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        y, osz = orig_multi(x_cat, w, batch, sizes, scale, shift, residual, relu, stride, pad)
+        e.record()
+        k = w.shape[1] * w.shape[2] * w.shape[3]
+        nbytes = 4 * (x_cat.numel() + w.numel() + y.numel())
+        records.append((s, e, 2.0 * y.shape[0] * k * w.shape[0], nbytes, (y.shape[0], w.shape[0], k)))
+        return y, osz
     ops.conv2d_nhwc = wrapped
+    ops.conv2d_nhwc_multi = wrapped_multi
     try:
         yield
     finally:
         ops.conv2d_nhwc = orig
+        ops.conv2d_nhwc_multi = orig_multi
 
 
 def conv_stack_roofline(model, img, metas, iters=3):

@@ -151,6 +151,10 @@ int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const fl
                       int cout, int kh, int kw, int stride, int pad, int relu, int dtype,
                       void *stream);
 
+/* Tuning hook: force the M extent of the workgroup tile (2 -> 128 rows, 4 -> 256 rows,
+ * 0 -> built-in heuristic).  Process-wide; used by the autotuning / benchmarking scripts. */
+int brcnn_conv_set_tile(int wm);
+
 /* The same convolution over `num_segments` feature maps that share one set of weights (the
  * RetinaRPN tower and heads run over 5 pyramid levels, atss_rpn_head.py:296-297): x and y hold
  * the segments back to back ((N,H_s,W_s,Cin) then the next), one launch covers all of them. */

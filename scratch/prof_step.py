@@ -1,0 +1,10 @@
+import sys, os, torch
+sys.path.insert(0, os.getcwd())
+import bench
+m, cfg = bench.build_model('cuda')
+img, metas = bench.synthetic_batch(8, 'cuda')
+for _ in range(4):
+    with torch.no_grad():
+        out = m.simple_test_device(img, metas, rescale=True)
+    out[2].cpu()
+torch.cuda.synchronize()
