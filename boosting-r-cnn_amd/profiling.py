@@ -65,10 +65,22 @@ def conv_stack_roofline(model, img, metas, iters=3):
     ms, recs = best
     flops = sum(r[2] for r in recs)
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC summary of the same workload
+        import json
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        cands = sorted(f for f in os.listdir(os.path.join(root, 'profiles')) if f.endswith('_conv_traffic.json'))
+        t = json.load(open(os.path.join(root, 'profiles', cands[-1])))
+        traffic = t['kernels']['conv_igemm_f32_kernel']['hbm_bytes_per_launch']
+    except Exception:
+        pass
     return {
         'bound': 'mfma', 'kernel': 'conv_igemm_f32_kernel (all conv/FC launches of one pass)',
         'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/*_conv_traffic.json)',
+        'algorithmic_bytes_per_launch': sum(r[3] for r in recs) / max(len(recs), 1),
         'launches': len(recs), 'avg_launch_us': 1000.0 * ms / max(len(recs), 1),
         'algorithmic_gflop_per_pass': flops / 1e9, 'kernel_ms_per_pass': ms,
     }

@@ -1,0 +1,26 @@
+"""Summarise the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs of
+scratch/prof_step.py = 4 inference passes) into profiles/r01_conv_traffic.json.
+Units/corrections per MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE
+reports half of the bytes of wide coalesced reads -> doubled."""
+import collections, csv, json, sys
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(int)
+for name in ('fetch', 'write'):
+    for r in csv.DictReader(open(f'gpurun_out/{rnd}/pmc_{name}/step_counter_collection.csv')):
+        k = 'conv_igemm_f32_kernel' if 'conv_igemm' in r['Kernel_Name'] else r['Kernel_Name'].split('(')[0][-40:]
+        tot[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if name == 'fetch':
+            cnt[k] += 1
+out = {}
+for k, v in tot.items():
+    n = max(cnt[k], 1)
+    fetch_b = 2.0 * v.get('FETCH_SIZE', 0.0) * 1024
+    write_b = v.get('WRITE_SIZE', 0.0) * 1024
+    out[k] = dict(launches=n, fetch_bytes_per_launch=fetch_b / n, write_bytes_per_launch=write_b / n,
+                  hbm_bytes_per_launch=(fetch_b + write_b) / n)
+top = dict(sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12])
+json.dump(dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on scratch/prof_step.py, '
+                      '4 inference passes of batch 8; FETCH_SIZE doubled per MI355X_MICROARCH.md',
+               kernels=top), open(f'profiles/{rnd}_conv_traffic.json', 'w'), indent=1)
+print(json.dumps(top['conv_igemm_f32_kernel'], indent=1))

@@ -1,0 +1,72 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes.  The hot path shards by image with no
+data-path collective at inference; training couples ranks only through `reduce_mean` of the
+RPN normalisers (atss_rpn_head.py:441-444,458-460) and the fused log-scalar all-reduce of
+`_parse_losses` (base.py:202-207).  Both are exercised here."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn import Config
+        from brcnn.dense_heads import reduce_mean
+        from brcnn.detectors import BaseDetector
+        from tests import util
+        from tests.test_host_cpu import CFG
+        # reduce_mean: mean over ranks
+        t = torch.tensor(float(rank + 1))
+        assert reduce_mean(t).item() == pytest.approx((1 + world) / 2)
+        # the RPN loss on rank-local images with the cross-rank normaliser
+        cfg = Config.fromfile(CFG)
+        c = cfg.model.rpn_head.copy()
+        c.update(train_cfg=cfg.model.train_cfg.rpn, test_cfg=cfg.model.test_cfg.rpn)
+        head = brcnn.build_head(c)
+        sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+        g = torch.Generator().manual_seed(100 + rank)
+        cls = [torch.randn(1, 9, h, w, generator=g) for h, w in sizes]
+        reg = [torch.randn(1, 36, h, w, generator=g) * 0.3 for h, w in sizes]
+        iou = [torch.randn(1, 9, h, w, generator=g) for h, w in sizes]
+        _, metas, gts, _ = util.demo_inputs(1, 128, 192, seed=100 + rank, num_gt=2 + 5 * rank)
+        losses = head.loss(cls, reg, iou, gts, metas)
+        # _parse_losses: one fused all-reduce, values averaged over ranks
+        det = BaseDetector()
+        loss, log_vars = det._parse_losses(losses)
+        local = sum(sum(v) for v in losses.values()).item()
+        gathered = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([local]))
+        assert log_vars['loss'] == pytest.approx(sum(x.item() for x in gathered) / world, rel=1e-5)
+        assert loss.item() == pytest.approx(local, rel=1e-6)
+        # image sharding: rank r owns images [r*b, (r+1)*b) of the global batch
+        b, glob = 2, list(range(world * 2))
+        mine = glob[rank * b:(rank + 1) * b]
+        allm = [None] * world
+        dist.all_gather_object(allm, mine)
+        assert sorted(sum(allm, [])) == glob
+        ret[rank] = float(log_vars['loss'])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_training_couplings():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == 2 and ret[0] == pytest.approx(ret[1], rel=1e-6)   # same averaged scalar
