@@ -1,0 +1,145 @@
+"""Differentiable wrappers of the HIP convolution / linear / RoI-extraction kernels.
+
+The reference trains through torch autograd over cuDNN/cuBLAS and mmcv's
+`RoIAlignFunction`; here the forward, data-gradient and weight-gradient of every trainable
+conv / FC are the MFMA implicit-GEMM kernels (`conv_igemm.hip`, `conv_wgrad.hip`) and the RoI
+feature gradient is `brcnn_roi_extract_backward`.  Cheap element-wise steps of the training
+graph (eval-BN affine, ReLU, adds) stay ordinary differentiable torch ops.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib as _L
+from . import ops
+from .ops import DT_F32, _ptr, _require_gpu, _stream, conv_out_size
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+class ConvNHWCFunction(Function):
+    """y = conv(x, w) + b over one or several NHWC segments.
+
+    x_cat (rows, Cin) [rows = sum_l batch*H_l*W_l], weight (Cout,Cin,KH,KW) in the reference's
+    parameter layout, bias (Cout) or None.  Returns y_cat (rows_out, Cout)."""
+
+    @staticmethod
+    def forward(ctx, x_cat, weight, bias, batch, sizes, stride, pad):
+        _require_gpu(x_cat, weight, bias)
+        w_p = weight.detach().float().permute(0, 2, 3, 1).contiguous()
+        x_cat = x_cat.contiguous()
+        y, out_sizes = ops.conv2d_nhwc_multi(x_cat, w_p, batch, sizes, None,
+                                             bias.detach().float().contiguous() if bias is not None else None,
+                                             None, False, stride, pad)
+        ctx.save_for_backward(x_cat, weight)
+        ctx.cfg = (batch, tuple(sizes), tuple(out_sizes), stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x_cat, weight = ctx.saved_tensors
+        batch, sizes, out_sizes, stride, pad, has_bias = ctx.cfg
+        cout, cin, kh, kw = weight.shape
+        dy = dy.contiguous()
+        lib = _L.load()
+        L = len(sizes)
+        hs, ws = _ints([h for h, _ in sizes]), _ints([w for _, w in sizes])
+        ohs, ows = _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).contiguous()   # (Cin,KH,KW,Cout)
+            dx = torch.empty_like(x_cat)
+            st = lib.brcnn_conv2d_dgrad_nhwc_multi(_ptr(dy), _ptr(w_t), _ptr(dx), batch, L, hs, ws, ohs,
+                                                   ows, cin, cout, kh, kw, stride, pad, DT_F32, _stream())
+            _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
+            st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
+                                                   cin, cout, kh, kw, stride, pad, DT_F32, _stream())
+            _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
+            dw = dwp.permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None, None, None, None
+
+
+def _pad_cout(weight, bias, mult=32):
+    """zero-pad the output channels to a multiple of `mult` (differentiable): keeps the
+    gradient kernels on their vector-load paths (dY rows 16-byte aligned, dgrad Cin % 32 == 0)"""
+    cout = weight.shape[0]
+    extra = (-cout) % mult
+    if extra == 0:
+        return weight, bias, cout
+    weight = torch.cat([weight, weight.new_zeros((extra,) + tuple(weight.shape[1:]))], 0)
+    if bias is not None:
+        bias = torch.cat([bias, bias.new_zeros(extra)], 0)
+    return weight, bias, cout
+
+
+def conv2d_nhwc_autograd(x, weight, bias, stride, pad):
+    """x (N,H,W,Cin) -> (N,Ho,Wo,Cout), differentiable"""
+    n, h, w, cin = x.shape
+    kh, kw = weight.shape[2], weight.shape[3]
+    ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
+    weight, bias, cout = _pad_cout(weight, bias)
+    y = ConvNHWCFunction.apply(x.reshape(n * h * w, cin), weight, bias, n, ((h, w),), stride, pad)
+    y = y.view(n, ho, wo, weight.shape[0])
+    return y if cout == weight.shape[0] else y[..., :cout]
+
+
+def linear_autograd(x, weight, bias):
+    """x (M,K) @ weight(N,K)^T + bias, differentiable (the 1x1 case with H=W=1)"""
+    weight, bias, cout = _pad_cout(weight, bias)
+    y = ConvNHWCFunction.apply(x.contiguous(), weight.view(weight.shape[0], weight.shape[1], 1, 1),
+                               bias, x.shape[0], ((1, 1),), 1, 0)
+    return y if cout == weight.shape[0] else y[:, :cout]
+
+
+class RoIExtractFunction(Function):
+    """Fused SingleRoIExtractor on NHWC maps with the RoIAlign feature gradient."""
+
+    @staticmethod
+    def forward(ctx, rois, output_size, strides, finest_scale, sampling_ratio, *feats):
+        out, _ = ops.roi_extract(list(feats), rois, output_size, strides, finest_scale, sampling_ratio)
+        ctx.save_for_backward(rois)
+        ctx.cfg = (output_size, tuple(strides), finest_scale, sampling_ratio,
+                   [tuple(f.shape) for f in feats])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        output_size, strides, finest_scale, sampling_ratio, shapes = ctx.cfg
+        ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+        L = len(shapes)
+        grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
+        ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grads])
+        hs, ws = _ints([s[1] for s in shapes]), _ints([s[2] for s in shapes])
+        sc = (ctypes.c_float * L)(*[1.0 / s for s in strides])
+        g = grad_out.contiguous()
+        st = _L.load().brcnn_roi_extract_backward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
+                                                  shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
+                                                  float(finest_scale), _stream())
+        _L.check(st, 'brcnn_roi_extract_backward')
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=56, sampling_ratio=0):
+    return RoIExtractFunction.apply(rois.contiguous().float(), output_size, strides, finest_scale,
+                                    sampling_ratio, *[f.contiguous() for f in feats_nhwc])
+
+
+def wants_grad(x, *params):
+    """True when the op must be recorded for backward (grad mode on and some input or
+    parameter is trainable); frozen layers keep using the fused inference kernels."""
+    if not torch.is_grad_enabled():
+        return False
+    if x is not None and x.requires_grad:
+        return True
+    return any(p is not None and p.requires_grad for p in params)

@@ -80,10 +80,22 @@ def build_norm_layer(cfg, num_features, postfix=''):
 
 
 def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
-    """act(bn(conv(x)) + residual) with everything folded into one kernel launch."""
+    """act(bn(conv(x)) + residual).  Inference / frozen layers: everything folded into one
+    kernel launch.  Trainable layers under grad mode: the differentiable conv kernel followed
+    by the (cheap, element-wise) eval-BN affine / add / ReLU as torch ops."""
     if bn is not None and bn.training:
         raise NotImplementedError('training-mode BatchNorm is not on the HIP path '
                                   '(the reference runs BN in eval mode: norm_eval=True)')
+    from .autograd import conv2d_nhwc_autograd, wants_grad
+    if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
+                  residual if residual is not None and residual.requires_grad else None):
+        y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+        if bn is not None:
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            y = y * scale + (bn.bias - bn.running_mean * scale)
+        if residual is not None:
+            y = y + residual
+        return y.relu() if relu else y
     srcs = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var]
                                        if bn is not None else [])
 
@@ -151,6 +163,11 @@ class ConvModule(nn.Module):
         # GroupNorm needs the statistics of the whole conv output: conv, then fused GN(+ReLU)
         assert residual is None
         y = conv_bn_act_nhwc(x, self.conv, None, self._cache, False)
+        if y.requires_grad:
+            import torch.nn.functional as F
+            z = F.group_norm(y.permute(0, 3, 1, 2), norm.num_groups, norm.weight, norm.bias, norm.eps)
+            z = z.permute(0, 2, 3, 1)
+            return (z.relu() if self.with_activation else z).contiguous()
         return ops.groupnorm_nhwc(y, norm.weight.detach(), norm.bias.detach(), norm.num_groups,
                                   norm.eps, self.with_activation)
 

@@ -56,6 +56,7 @@ struct ConvParams {
     int tiles_m, tiles_n;
     int pitch;                       // floats between adjacent input pixels (== Cin normally)
     unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
+    int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
@@ -155,10 +156,17 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_igemm_f32_kernel(ConvParams 
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int j = 0; j < AJ; j++) {
-                const int hi = (a_hw[j] >> 16) - 4096 + kh;
-                const int wi = (a_hw[j] & 0xffff) - 4096 + kw;
-                const bool ok = (a_base[j] >= 0) & ((unsigned)hi < (unsigned)a_H[j]) &
-                                ((unsigned)wi < (unsigned)a_W[j]);
+                int hi = (a_hw[j] >> 16) - 4096 + kh;
+                int wi = (a_hw[j] & 0xffff) - 4096 + kw;
+                bool ok = a_base[j] >= 0;
+                if (p.dilate > 1) {      // zero-stuffed input: only multiples of `dilate` exist
+                    ok = ok & (hi >= 0) & (wi >= 0);
+                    const int qh = hi / p.dilate, qw = wi / p.dilate;
+                    ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
+                    hi = qh;
+                    wi = qw;
+                }
+                ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
                 const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci) * 4 : OOB;
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0);
                 ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
@@ -356,27 +364,30 @@ BRCNN_API int brcnn_conv2d_nhwc(const void* x, const void* w, const float* scale
                                    kw, stride, pad, relu, dtype, stream);
 }
 
-BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float* scale,
-                                      const float* shift, const void* residual, void* y, int batch,
-                                      int num_segments, const int* heights_host,
-                                      const int* widths_host, int cin, int cout, int kh, int kw,
-                                      int stride, int pad, int relu, int dtype, void* stream) {
+static int conv_setup_and_launch(const void* x, const void* w, const float* scale, const float* shift,
+                                 const void* residual, void* y, int batch, int num_segments,
+                                 const int* heights_host, const int* widths_host,
+                                 const int* out_heights_host, const int* out_widths_host, int cin,
+                                 int cout, int kh, int kw, int stride, int pad, int dilate, int relu,
+                                 int dtype, void* stream) {
     if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
-        pad < 0 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS || !heights_host ||
-        !widths_host)
+        pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
+        !heights_host || !widths_host)
         return BRCNN_EINVAL;
     if (dtype != BRCNN_DT_F32) return BRCNN_EINVAL;
+    if (dilate > 1 && (cin % 32 != 0 || stride != 1)) return BRCNN_EINVAL;
     ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
     p.batch = batch; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
-    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = num_segments;
+    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = num_segments; p.dilate = dilate;
     long long m_total = 0, x_off = 0;
     for (int sgi = 0; sgi < num_segments; sgi++) {
         const int H = heights_host[sgi], W = widths_host[sgi];
-        if (H <= 0 || W <= 0 || H + pad >= 4096 || W + pad >= 4096) return BRCNN_EINVAL;
-        const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
-        if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+        if (H <= 0 || W <= 0 || H * dilate + pad >= 4096 || W * dilate + pad >= 4096) return BRCNN_EINVAL;
+        int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+        if (out_heights_host && out_widths_host) { Ho = out_heights_host[sgi]; Wo = out_widths_host[sgi]; }
+        if (Ho <= 0 || Wo <= 0 || Ho >= 4096 || Wo >= 4096) return BRCNN_EINVAL;
         p.seg_H[sgi] = H; p.seg_W[sgi] = W; p.seg_Ho[sgi] = Ho; p.seg_Wo[sgi] = Wo;
         p.seg_m0[sgi] = (int)m_total;
         p.seg_xoff[sgi] = x_off;
@@ -392,4 +403,30 @@ BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float*
     p.K = kh * kw * cin;
     p.relu = relu;
     return dispatch_conv(p, (hipStream_t)stream);
+}
+
+BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float* scale,
+                                      const float* shift, const void* residual, void* y, int batch,
+                                      int num_segments, const int* heights_host,
+                                      const int* widths_host, int cin, int cout, int kh, int kw,
+                                      int stride, int pad, int relu, int dtype, void* stream) {
+    return conv_setup_and_launch(x, w, scale, shift, residual, y, batch, num_segments, heights_host,
+                                 widths_host, nullptr, nullptr, cin, cout, kh, kw, stride, pad, 1,
+                                 relu, dtype, stream);
+}
+
+// Data gradient of conv(x (N,H,W,Cin), w, stride, pad) -> y (N,Ho,Wo,Cout):
+//   dx[n,hi,wi,ci] = sum_{kh,kw,co} dy[n,(hi+pad-kh)/s,(wi+pad-kw)/s,co] * w[co,kh,kw,ci]
+// = a stride-1 convolution of the zero-stuffed dy with the flipped, (co<->ci)-transposed
+// weights `w_t` (Cin,KH,KW,Cout) [w_t[ci,a,b,co] = w[co,KH-1-a,KW-1-b,ci]] and padding K-1-pad.
+BRCNN_API int brcnn_conv2d_dgrad_nhwc_multi(const void* dy, const void* w_t, void* dx, int batch,
+                                            int num_segments, const int* in_heights_host,
+                                            const int* in_widths_host, const int* out_heights_host,
+                                            const int* out_widths_host, int cin, int cout, int kh,
+                                            int kw, int stride, int pad, int dtype, void* stream) {
+    if (pad > kh - 1 || pad > kw - 1 || !out_heights_host || !out_widths_host) return BRCNN_EINVAL;
+    // roles swap: the kernel's "input" is dy (Ho,Wo,Cout), its "output" is dx (H,W,Cin)
+    return conv_setup_and_launch(dy, w_t, nullptr, nullptr, nullptr, dx, batch, num_segments,
+                                 out_heights_host, out_widths_host, in_heights_host, in_widths_host,
+                                 cout, cin, kh, kw, 1, kh - 1 - pad, stride, 0, dtype, stream);
 }

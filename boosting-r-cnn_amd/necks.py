@@ -75,7 +75,13 @@ class FPN(nn.Module):
         laterals = [conv.forward_nhwc(inputs[i + self.start_level])
                     for i, conv in enumerate(self.lateral_convs)]
         for i in range(len(laterals) - 1, 0, -1):
-            ops.upsample_nearest_add_nhwc_(laterals[i - 1], laterals[i])
+            if laterals[i].requires_grad or laterals[i - 1].requires_grad:
+                import torch.nn.functional as F
+                up = F.interpolate(laterals[i].permute(0, 3, 1, 2), size=laterals[i - 1].shape[1:3],
+                                   mode='nearest').permute(0, 2, 3, 1)
+                laterals[i - 1] = laterals[i - 1] + up
+            else:
+                ops.upsample_nearest_add_nhwc_(laterals[i - 1], laterals[i])
         return laterals
 
     def _extra(self, inputs, laterals, outs):

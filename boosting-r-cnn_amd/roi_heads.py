@@ -67,6 +67,10 @@ class SingleRoIExtractor(nn.Module):
         """(K, ph, pw, C) RoI features from NHWC maps, one launch."""
         assert self._fusable()
         l0 = self.roi_layers[0]
+        if torch.is_grad_enabled() and any(f.requires_grad for f in feats_nhwc):
+            from .autograd import roi_extract_autograd
+            return roi_extract_autograd(list(feats_nhwc[:self.num_inputs]), rois, l0.output_size,
+                                        self.featmap_strides, self.finest_scale, l0.sampling_ratio)
         out, _ = ops.roi_extract(list(feats_nhwc[:self.num_inputs]), rois, l0.output_size,
                                  self.featmap_strides, self.finest_scale, l0.sampling_ratio)
         return out
@@ -154,6 +158,17 @@ class ProbConvFCBBoxHead(nn.Module):
         """roi_feats (K, ph, pw, C) -> (cls_score (K,C+1), bbox_pred (K,4C))"""
         k, ph, pw, c = roi_feats.shape
         x = roi_feats.reshape(k, ph * pw * c)
+        from .autograd import linear_autograd, wants_grad
+        if wants_grad(x, self.fc_cls.weight, self.shared_fcs[0].weight):
+            for i, fc in enumerate(self.shared_fcs):
+                w = fc.weight
+                if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable view
+                    w = w.view(-1, c, ph, pw).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
+                x = linear_autograd(x, w, fc.bias).relu()
+            y = linear_autograd(x, torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0),
+                                torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0))
+            nc = self.fc_cls.out_features
+            return y[:, :nc], y[:, nc:]
         for i, fc in enumerate(self.shared_fcs):
             if i == 0:
                 def builder(fc=fc):   # (out, C*ph*pw) columns -> (ph,pw,C) order

@@ -164,6 +164,23 @@ int brcnn_conv2d_nhwc_multi(const void *x, const void *w, const float *scale, co
                             int kh, int kw, int stride, int pad, int relu, int dtype,
                             void *stream);
 
+/* Backward of the convolution (autograd of the trainable convs / FCs; the reference gets these
+ * from cuDNN/cuBLAS through torch autograd).
+ * dgrad: dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout) and w_t (Cin,KH,KW,Cout) =
+ *   flipped + transposed weights (w_t[ci,a,b,co] = w[co,KH-1-a,KW-1-b,ci]); in_* are the
+ *   forward-input sizes (of dx), out_* the forward-output sizes (of dy).
+ * wgrad: dw (Cout,KH,KW,Cin) += sum over pixels of dy x im2col(x); dw must be zero-filled
+ *   by the caller (fp32 atomics across the slices of the pixel dimension). */
+int brcnn_conv2d_dgrad_nhwc_multi(const void *dy, const void *w_t, void *dx, int batch,
+                                  int num_segments, const int *in_heights_host,
+                                  const int *in_widths_host, const int *out_heights_host,
+                                  const int *out_widths_host, int cin, int cout, int kh, int kw,
+                                  int stride, int pad, int dtype, void *stream);
+int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int batch,
+                                  int num_segments, const int *heights_host,
+                                  const int *widths_host, int cin, int cout, int kh, int kw,
+                                  int stride, int pad, int dtype, void *stream);
+
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,
                             int channels, int dtype, void *stream);

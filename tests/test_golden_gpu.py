@@ -168,3 +168,30 @@ def test_fused_rpn_head_equals_per_level(model):
         assert torch.allclose(fc[l], cls[l], rtol=1e-5, atol=1e-5)
         assert torch.allclose(fi[l], iou[l], rtol=1e-5, atol=1e-5)
         assert torch.allclose(fr[l] * s, reg[l], rtol=1e-5, atol=1e-5)
+
+
+def test_train_step_losses_golden():
+    """forward_train of the whole detector on the device (HIP conv fwd, focal loss, RoIAlign)
+    against the reference's CPU losses on the same seeded weights / inputs / sampler seed, then a
+    backward pass through the HIP dgrad / wgrad kernels."""
+    g = load('g10_train_losses')
+    cfg = Config.fromfile(CFG)
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=10))
+    m = m.to(DEV).train()
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    torch.manual_seed(77)
+    losses = m.forward_train(img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    for k, ref in g.items():
+        got = torch.stack(losses[k]) if isinstance(losses[k], list) else losses[k]
+        assert torch.allclose(got.detach().cpu().float(), T(ref).float(), rtol=2e-3, atol=1e-4), \
+            (k, got.detach().cpu(), ref)
+    out = m.train_step(dict(img=img.to(DEV), img_metas=metas, gt_bboxes=[b.to(DEV) for b in gts],
+                            gt_labels=[l.to(DEV) for l in gls]), None)
+    out['loss'].backward()
+    assert out['num_samples'] == 2 and 'loss_rpn_cls' in out['log_vars']
+    n_grad = sum(1 for p in m.parameters() if p.requires_grad and p.grad is not None)
+    n_train = sum(1 for p in m.parameters() if p.requires_grad)
+    assert n_grad == n_train, (n_grad, n_train)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert m.backbone.conv1.weight.grad is None and m.backbone.layer1[0].conv1.weight.grad is None

@@ -420,3 +420,71 @@ def test_multi_level_conv_and_groupnorm_match_per_level():
     s1 = ops.rpn_score(full[..., :9], full[..., 45:])
     s2 = ops.rpn_score(full[..., :9].contiguous(), full[..., 45:].contiguous())
     assert torch.equal(s1, s2)
+
+
+# --------------------------------------------------------------------------- conv backward
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, H, W, Cout, k, stride, pad, bias)
+    (2, 64, 20, 28, 64, 3, 1, 1, True),
+    (2, 128, 17, 23, 256, 1, 1, 0, False),
+    (2, 64, 20, 28, 128, 3, 2, 1, True),
+    (1, 256, 13, 21, 512, 1, 2, 0, False),
+    (2, 256, 13, 21, 54, 3, 1, 1, True),      # padded output channels
+    (2, 32, 15, 16, 32, 3, 2, 1, True),       # odd H: output_padding case of the data gradient
+])
+def test_conv_autograd_matches_torch(cfg):
+    from brcnn.autograd import conv2d_nhwc_autograd
+    import torch.nn.functional as F
+    n, cin, h, w, cout, k, stride, pad, has_bias = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:8]))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) if has_bias else None
+    xr = x.double().requires_grad_(); wr = wt.double().requires_grad_()
+    br = b.double().requires_grad_() if has_bias else None
+    yr = F.conv2d(xr, wr, br, stride, pad)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+    wg = wt.to(DEV).requires_grad_()
+    bg = b.to(DEV).requires_grad_() if has_bias else None
+    y = conv2d_nhwc_autograd(xg, wg, bg, stride, pad)
+    y.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
+    def rel(a, ref):
+        return (a.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+    assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-5
+    assert rel(xg.grad.permute(0, 3, 1, 2), xr.grad) < 5e-5
+    assert rel(wg.grad, wr.grad) < 5e-5
+    if has_bias:
+        assert rel(bg.grad, br.grad) < 5e-5
+
+
+def test_linear_and_roi_extract_autograd():
+    from brcnn.autograd import linear_autograd, roi_extract_autograd
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(300, 1024, generator=g); w = torch.randn(21, 1024, generator=g) / 32; b = torch.randn(21, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = xr @ wr.t() + br
+    go = torch.randn(300, 21, generator=g)
+    yr.backward(go.double())
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = linear_autograd(xg, wg, bg)
+    y.backward(go.to(DEV))
+    for a, r in ((y.detach(), yr.detach()), (xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        assert (a.double().cpu() - r).abs().max().item() < 5e-5 * max(r.abs().max().item(), 1.0)
+    # RoI extraction gradient vs the oracle's per-level RoIAlign backward
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
+    feats = [torch.randn(2, 16, h, w_, generator=g) for h, w_ in sizes]
+    rois = util.rand_rois(100, 2, 512., 320., seed=5, min_size=8., max_size=600.)
+    go = torch.randn(100, 7, 7, 16, generator=g)
+    fg = [f.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_() for f in feats]
+    out = roi_extract_autograd(fg, rois.to(DEV), 7, strides, 56, 0)
+    out.backward(go.to(DEV))
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lvls = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=4).long()
+    for i in range(5):
+        inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+        ref = orc.roi_align_backward(go[inds].permute(0, 3, 1, 2).contiguous(), rois[inds], feats[i].shape, 7,
+                                     1. / strides[i], 0, True) if inds.numel() else torch.zeros_like(feats[i])
+        assert torch.allclose(fg[i].grad.permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=1e-5), i
