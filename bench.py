@@ -40,6 +40,81 @@ def build_model(device, seed=0):
     return m.to(device).eval().freeze_for_inference(), cfg
 
 
+def synthetic_gt(batch, device, num_classes, seed=0, num_gt=20):
+    """20 boxes / image in the style of tests/test_models/test_forward.py:481-492"""
+    rng = np.random.RandomState(seed)
+    boxes, labels = [], []
+    for _ in range(batch):
+        cx, cy = rng.rand(num_gt) * 1333, rng.rand(num_gt) * 800
+        bw, bh = rng.rand(num_gt) * 1333 * 0.5 + 8, rng.rand(num_gt) * 800 * 0.5 + 8
+        b = np.stack([(cx - bw / 2).clip(0, 1333), (cy - bh / 2).clip(0, 800),
+                      (cx + bw / 2).clip(0, 1333), (cy + bh / 2).clip(0, 800)], 1).astype(np.float32)
+        boxes.append(torch.from_numpy(b).to(device))
+        labels.append(torch.from_numpy(rng.randint(0, num_classes, num_gt)).long().to(device))
+    return boxes, labels
+
+
+def train_bench(args, world, rank, device):
+    """full train step of boosting_rcnn_r50_pafpn_1x_coco.py (80 classes), fp32, SGD + clip"""
+    import brcnn  # noqa: F401
+    from brcnn import Config, build_detector
+    from tests import util
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'boosting_rcnn', 'boosting_rcnn_r50_pafpn_1x_coco.py'))
+    model = build_detector(cfg.model)
+    model.load_state_dict(util.seeded_state_dict(model, seed=0))
+    model = model.to(device).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
+                          weight_decay=cfg.optimizer.weight_decay)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index],
+                                                        broadcast_buffers=False)
+    img, metas = synthetic_batch(args.batch, device, seed=rank)
+    gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+        loss, log_vars = model._parse_losses(losses)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=35, norm_type=2)
+        opt.step()
+        return log_vars
+
+    for _ in range(args.warmup):
+        lv = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lv = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN train step',
+            'value': world * args.batch * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'boosting_rcnn_r50_pafpn_1x_coco.py full train step, batch {args.batch} x '
+                                   '3x800x1344 per GPU, 20 GT/img, 512 RoIs/img, SGD+clip',
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
+            'loss': lv['loss']}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def conv_flops_per_image():
     """algorithmic MACs of the conv/FC stack per image (170.0 GMAC at 256 RoIs, C=4)"""
     return 2 * 170.0e9
@@ -52,6 +127,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
+                    help="'train' times the full train step (BASELINE configs[2]/[3]): forward_train, "
+                         'backward through the HIP dgrad/wgrad kernels, gradient all-reduce (DDP over '
+                         'RCCL when N>1), grad-clip, SGD')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -63,6 +142,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
+    if args.mode == 'train':
+        return train_bench(args, world, rank, device)
     model, cfg = build_model(device)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
 
