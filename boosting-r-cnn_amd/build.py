@@ -19,7 +19,9 @@ ARCH = 'gfx950'
 SOURCES = ['roi_align.hip', 'nms.hip', 'soft_nms.hip', 'focal_loss.hip', 'conv_igemm.hip', 'conv_wgrad.hip',
            'misc.hip', 'rpn.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
-         '-fhip-fp32-correctly-rounded-divide-sqrt', '-fvisibility=hidden', '-Wno-unused-result']
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-fvisibility=hidden', '-Wno-unused-result',
+         # hardware fp32 atomic add (global_atomic_add_f32) instead of a CAS loop for the gradient scatters
+         '-munsafe-fp-atomics']
 
 
 def hipcc():

@@ -330,11 +330,30 @@ int launch_res(const ConvParams& p, hipStream_t s) {
     return p.residual ? launch_conv<FAST, WM, NT, true>(p, s) : launch_conv<FAST, WM, NT, false>(p, s);
 }
 
-int g_force_wm = 0;   // tuning hook (brcnn_conv_set_tile): 0 = heuristic
+int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 = heuristic
+
+// Workgroup slots of the chip for this kernel family: 256 CUs x 2 resident workgroups.
+constexpr int SLOTS = 512;
 
 int dispatch_conv(ConvParams& p, hipStream_t s) {
-    const int nt = (p.Cout <= 64) ? 1 : 2;
     const bool fast = (p.Cin % 32 == 0);
+    const int tm = (p.M + 127) / 128;
+    int nt = (p.Cout <= 64) ? 1 : 2;
+    if (nt == 2 && fast) {
+        // Tile-count quantisation: the launch takes ceil(tiles / SLOTS) rounds of resident
+        // workgroups, each round costing ~NT units of MFMA time.  When the 128x128 grid leaves
+        // the last round nearly empty (e.g. 526 tiles), the 128x64 tile (twice the tiles, half
+        // the work each, ~8 % less efficient per FLOP) finishes earlier.
+        const long long t2 = (long long)tm * ((p.Cout + 127) / 128), t1 = (long long)tm * ((p.Cout + 63) / 64);
+        const double c2 = (double)((t2 + SLOTS - 1) / SLOTS) * 2.0;
+        const double c1 = (double)((t1 + SLOTS - 1) / SLOTS) * 1.08;
+        if (c1 < c2) nt = 1;
+        // under two rounds the 128x128 grid leaves CUs with a single resident workgroup (no
+        // second wave per SIMD to cover the staging phases): measured 8-40 % slower than 128x64
+        // (profiles/r01_conv_tiles.txt), except with a residual operand (register pressure)
+        if (t2 < 2 * SLOTS && !p.residual) nt = 1;
+    }
+    if (g_force_nt == 1 || (g_force_nt == 2 && p.Cout > 64)) nt = g_force_nt;
     // measured on MI355X (profiles/r01_conv_tiles.txt): the 256-row tile never beats 128x128
     // for this network (the kernel is MFMA-issue bound, not L2->LDS bound), so it is only
     // reachable through the tuning hook
@@ -349,9 +368,10 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
-BRCNN_API int brcnn_conv_set_tile(int wm) {
-    if (wm != 0 && wm != 2 && wm != 4) return BRCNN_EINVAL;
+BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
+    if ((wm != 0 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
     g_force_wm = wm;
+    g_force_nt = nt;
     return 0;
 }
 

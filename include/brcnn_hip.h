@@ -151,9 +151,10 @@ int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const fl
                       int cout, int kh, int kw, int stride, int pad, int relu, int dtype,
                       void *stream);
 
-/* Tuning hook: force the M extent of the workgroup tile (2 -> 128 rows, 4 -> 256 rows,
- * 0 -> built-in heuristic).  Process-wide; used by the autotuning / benchmarking scripts. */
-int brcnn_conv_set_tile(int wm);
+/* Tuning hook: force the workgroup tile (wm: 2 -> 128 rows, 4 -> 256 rows; nt: 1 -> 64
+ * columns, 2 -> 128 columns; 0 -> built-in heuristic).  Process-wide; used by the
+ * benchmarking scripts (tools/conv_bench.py). */
+int brcnn_conv_set_tile(int wm, int nt);
 
 /* The same convolution over `num_segments` feature maps that share one set of weights (the
  * RetinaRPN tower and heads run over 5 pyramid levels, atss_rpn_head.py:296-297): x and y hold

@@ -15,6 +15,9 @@ shapes = [  # name, N,H,W,Cin,Cout,k,stride,pad,res
  ('s3 1x1 256->1024 +res', 8,50,84,256,1024,1,1,0,True),
  ('s4 3x3 512->512', 8,25,42,512,512,3,1,1,False),
  ('fc 12544->1024', 2048,1,1,12544,1024,1,1,0,False),
+ ('s4 1x1 512->2048 +res', 8,25,42,512,2048,1,1,0,True),
+ ('s4 1x1 2048->512', 8,25,42,2048,512,1,1,0,False),
+ ('s3 3x3 s2 256->256', 8,100,168,256,256,3,2,1,False),
 ]
 def bench(fn, n=10):
     for _ in range(3): fn()
@@ -31,9 +34,9 @@ for name,N,H,W,Ci,Co,k,st,pd,res in shapes:
     r = torch.randn(N,Ho,Wo,Co,device='cuda') if res else None
     fl = 2.0*N*Ho*Wo*Co*k*k*Ci
     out = []
-    for wm in (2,4):
-        L.brcnn_conv_set_tile(wm)
+    for wm, nt in ((2,2),(2,1),(0,0)):
+        L.brcnn_conv_set_tile(wm, nt)
         ms = bench(lambda: ops.conv2d_nhwc(x,w,sc,sh,r,True,st,pd))
-        out.append(f'wm{wm}: {ms*1000:8.1f} us {fl/ms/1e9:6.1f} TF')
-    L.brcnn_conv_set_tile(0)
+        out.append(f'wm{wm}nt{nt}: {ms*1000:8.1f} us {fl/ms/1e9:6.1f} TF')
+    L.brcnn_conv_set_tile(0, 0)
     print(f'{name:28s} M={N*Ho*Wo:7d} ' + ' | '.join(out))

@@ -1,0 +1,106 @@
+"""Op-level roofline report on MI355X (north_star: achieved HBM GB/s on RoIAlign / NMS):
+RoIAlign fwd/bwd at the configs' RoI counts on the real pyramid shapes, NMS on RPN-sized
+candidate sets, soft-NMS on per-class segments, focal loss on all anchors.  Algorithmic bytes
+follow SURVEY.md section 8(d).  Prints one JSON object."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import brcnn  # noqa: F401
+from brcnn import ops
+from brcnn.autograd import roi_extract_autograd
+from tests import util
+
+DEV = 'cuda'
+HBM = 8000.0
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e-3
+
+
+def roialign_bytes(rois, strides, sizes, C=256, out=7):
+    """sum_rois C*4*fp_h*fp_w (footprint clipped to the map) + K*C*49*4 + K*20"""
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lv = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(0, 4).long()
+    tot = 0.0
+    for l in range(5):
+        r = rois[lv == l]
+        if not len(r):
+            continue
+        s = 1.0 / strides[l]
+        h, w = sizes[l]
+        x1, y1, x2, y2 = r[:, 1] * s - .5, r[:, 2] * s - .5, r[:, 3] * s - .5, r[:, 4] * s - .5
+        fw = (torch.floor(x2).clamp(max=w - 1) + 2 - torch.floor(x1).clamp(min=0)).clamp(min=1, max=w)
+        fh = (torch.floor(y2).clamp(max=h - 1) + 2 - torch.floor(y1).clamp(min=0)).clamp(min=1, max=h)
+        tot += float((fw * fh).sum()) * C * 4
+    return tot + len(rois) * C * out * out * 4 + len(rois) * 20
+
+
+def main():
+    B = 8
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    g = torch.Generator().manual_seed(0)
+    feats = [torch.randn(B, h, w, 256, generator=g).to(DEV) for h, w in sizes]
+    res = {}
+    for per_img in (256, 512, 2000):
+        K = per_img * B
+        # log-uniform scale 16-800 px, aspect 0.5-2, uniform centres
+        rois = util.rand_rois(K, B, 1333., 800., seed=per_img, min_size=16., max_size=800.)
+        rg = rois.to(DEV)
+        t = timed(lambda: ops.roi_extract(feats, rg, 7, strides, 56, 0))
+        by = roialign_bytes(rois, strides, sizes)
+        res[f'roialign_fwd_{per_img}x{B}'] = dict(us=t * 1e6, algorithmic_MB=by / 1e6, GBs=by / t / 1e9,
+                                                  frac_hbm=by / t / 1e9 / HBM)
+        fr = [f.clone().requires_grad_() for f in feats]
+        go = torch.randn(K, 7, 7, 256, device=DEV)
+
+        def fb():
+            out = roi_extract_autograd(fr, rg, 7, strides, 56, 0)
+            out.backward(go)
+        tfb = timed(fb, 5)
+        res[f'roialign_fwd+bwd_{per_img}x{B}'] = dict(us=tfb * 1e6, GBs=2 * by / tfb / 1e9,
+                                                      frac_hbm=2 * by / tfb / 1e9 / HBM)
+    # NMS: RPN test (8 x 4693), RPN train level segments (8 x 5 x ~3000), R-CNN (8 x 1024)
+    for name, lens, keepn in (('rpn_test_8x4693', [4693] * 8, 256), ('rpn_train_40x3030', [3030] * 40, -1),
+                              ('rcnn_8x1024', [1024] * 8, 100)):
+        n = sum(lens)
+        seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
+        boxes = util.clustered_boxes(n, n_clusters=60 * len(lens), seed=3).to(DEV)
+        scores = util.tie_free_scores(n, seed=4).to(DEV)
+        t = timed(lambda: ops.nms_segments(boxes, scores, seg, max(lens), 0.7, 0, keepn))
+        words = (max(lens) + 63) // 64
+        by = n * 20 + n * words * 8 * 2
+        res['nms_' + name] = dict(us=t * 1e6, boxes_per_s=n / t, algorithmic_MB=by / 1e6, GBs=by / t / 1e9,
+                                  frac_hbm=by / t / 1e9 / HBM,
+                                  note='latency bound: one wavefront per segment resolves the greedy chain')
+    # soft-NMS: 80 classes x 8 images, 250 boxes per segment (config #5 scale / 8)
+    lens = [250] * 640
+    n = sum(lens)
+    seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
+    boxes = util.clustered_boxes(n, n_clusters=6400, seed=5).to(DEV)
+    scores = util.tie_free_scores(n, seed=6).to(DEV)
+    t = timed(lambda: ops.soft_nms_segments(boxes, scores, seg, 0.7, 0.5, 0.0, 1, 0), 5)
+    res['softnms_640x250'] = dict(us=t * 1e6, boxes_per_s=n / t, updates_per_s=sum(l * l / 2 for l in lens) / t,
+                                  note='dependent chain per segment; parallel across segments')
+    # focal loss over all anchors of 8 images
+    x = torch.randn(201600 * B, 1, device=DEV)
+    tg = torch.randint(0, 2, (201600 * B,), device=DEV)
+    t = timed(lambda: ops.sigmoid_focal_loss(x, tg, 2.0, 0.25, None, 'none'))
+    by = x.numel() * (4 + 4 + 8)
+    res['focal_fwd_1.6M'] = dict(us=t * 1e6, GBs=by / t / 1e9, frac_hbm=by / t / 1e9 / HBM)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()
