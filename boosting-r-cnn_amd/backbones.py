@@ -114,6 +114,7 @@ class ResNet(nn.Module):
             self.res_layers.append(name)
         self.feat_dim = self.block.expansion * base_channels * 2 ** (len(self.stage_blocks) - 1)
         self._stem_cache = PackedCache()
+        self._stem_cache2 = PackedCache()
         self._freeze_stages()
         self.init_weights()
 
@@ -153,6 +154,38 @@ class ResNet(nn.Module):
                 if isinstance(m, nn.modules.batchnorm._BatchNorm):
                     m.eval()
         return self
+
+    def _stem_fast_ok(self):
+        c = self.conv1
+        return c.kernel_size == (7, 7) and c.stride == (2, 2) and c.padding == (3, 3) and \
+            c.in_channels == 3 and c.bias is None and not c.weight.requires_grad
+
+    def stem_from_nchw(self, img):
+        """frozen stem straight from the NCHW image (no NHWC copy of the input): repack +
+        vector-path 7x7 conv + folded BN + ReLU, then the 3x3/s2 max-pool"""
+        def builder():
+            from .blocks import fold_bn
+            scale, shift = fold_bn(self.bn1)
+            return ops.pack_stem_weight(self.conv1.weight), scale, shift
+        w, scale, shift = self._stem_cache2.get(
+            [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var],
+            builder)
+        return ops.maxpool3x3s2_nhwc(ops.stem7x7s2_nchw(img, w, scale, shift, True))
+
+    def forward_from_nchw(self, img):
+        """(N,3,H,W) NCHW image -> tuple of NHWC stage outputs"""
+        if self._stem_fast_ok() and not self.bn1.training and img.is_contiguous() and \
+                img.shape[2] >= 7 and img.shape[3] >= 7:
+            return self._stages(self.stem_from_nchw(img))
+        return self.forward_nhwc(to_nhwc(img))
+
+    def _stages(self, x):
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name).forward_nhwc(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
 
     def forward_nhwc(self, x):
         """x (N,H,W,3) -> tuple of (N,h,w,C) for out_indices"""

@@ -389,7 +389,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
                                  const int* heights_host, const int* widths_host,
                                  const int* out_heights_host, const int* out_widths_host, int cin,
                                  int cout, int kh, int kw, int stride, int pad, int dilate, int relu,
-                                 int dtype, void* stream) {
+                                 int dtype, void* stream, int pitch = 0) {
     if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
         pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
         !heights_host || !widths_host)
@@ -400,7 +400,8 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
     p.batch = batch; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
-    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = num_segments; p.dilate = dilate;
+    if (pitch <= 0) pitch = cin;
+    p.stride = stride; p.pad = pad; p.pitch = pitch; p.nseg = num_segments; p.dilate = dilate;
     long long m_total = 0, x_off = 0;
     for (int sgi = 0; sgi < num_segments; sgi++) {
         const int H = heights_host[sgi], W = widths_host[sgi];
@@ -412,7 +413,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
         p.seg_m0[sgi] = (int)m_total;
         p.seg_xoff[sgi] = x_off;
         m_total += (long long)batch * Ho * Wo;
-        x_off += (long long)batch * H * W * cin;
+        x_off += (long long)batch * H * W * pitch;
         if (m_total > 0x7fffffffLL) return BRCNN_EINVAL;
     }
     for (int sgi = num_segments; sgi <= BRCNN_MAX_LEVELS; sgi++) p.seg_m0[sgi] = (int)m_total;
@@ -449,4 +450,55 @@ BRCNN_API int brcnn_conv2d_dgrad_nhwc_multi(const void* dy, const void* w_t, voi
     return conv_setup_and_launch(dy, w_t, nullptr, nullptr, nullptr, dx, batch, num_segments,
                                  out_heights_host, out_widths_host, in_heights_host, in_widths_host,
                                  cout, cin, kh, kw, 1, kh - 1 - pad, stride, 0, dtype, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ResNet stem (7x7 / stride 2 / pad 3 on the 3-channel image, resnet.py:599-611) on the
+// vector-load path: the NCHW image is re-packed once to a zero-bordered (N, H+6, W+6, 4)
+// buffer; a filter row (7 taps x 3 channels) is then 28 of the 32 contiguous floats that
+// start at pixel (ho*2+kh, wo*2), so the stem is a KH=7, KW=1, "Cin"=32 convolution whose
+// input pixels are 4 floats apart (pitch 4) -- no per-element gather, no bounds tests.
+// Weights arrive packed as (Cout, 7, 1, 32) with zeros at tap 7 / channel 3.
+namespace {
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ img,
+                                                       float* __restrict__ out, int N, int H, int W) {
+    const int Hp = H + 6, Wp = W + 6;
+    const long long total = (long long)N * Hp * Wp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int wp = (int)(i % Wp);
+        const int hp = (int)((i / Wp) % Hp);
+        const int n = (int)(i / ((long long)Wp * Hp));
+        const int h = hp - 3, w = wp - 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const size_t b = ((size_t)n * 3 * H + h) * W + w;
+            v.x = img[b]; v.y = img[b + (size_t)H * W]; v.z = img[b + 2 * (size_t)H * W];
+        }
+        *reinterpret_cast<float4*>(out + (size_t)i * 4) = v;
+    }
+}
+}  // namespace
+
+BRCNN_API size_t brcnn_stem_workspace_bytes(int batch, int height, int width) {
+    return (size_t)batch * (height + 6) * (width + 6) * 4 * sizeof(float) + 256;
+}
+
+BRCNN_API int brcnn_stem7x7s2_nchw(const float* img, const float* w_packed, const float* scale,
+                                   const float* shift, float* y, void* workspace, int batch,
+                                   int height, int width, int cout, int relu, void* stream) {
+    if (!img || !w_packed || !y || !workspace || batch <= 0 || height < 7 || width < 7 || cout <= 0)
+        return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int Hp = height + 6, Wp = width + 6;
+    const long long total = (long long)batch * Hp * Wp;
+    long long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((int)g), dim3(256), 0, s, img, (float*)workspace, batch,
+                       height, width);
+    BRCNN_LAUNCH_CHECK();
+    const int Ho = (height + 6 - 7) / 2 + 1, Wo = (width + 6 - 7) / 2 + 1;
+    const int hs[1] = {Hp}, ws[1] = {Wp}, ohs[1] = {Ho}, ows[1] = {Wo};
+    return conv_setup_and_launch(workspace, w_packed, scale, shift, nullptr, y, batch, 1, hs, ws, ohs,
+                                 ows, 32, cout, 7, 1, 2, 0, 1, relu, BRCNN_DT_F32, stream, 4);
 }

@@ -125,7 +125,10 @@ class TwoStageDetector(BaseDetector):
 
     # ---- features ----------------------------------------------------------------------
     def extract_feat_nhwc(self, img):
-        x = self.backbone.forward_nhwc(to_nhwc(img))
+        if hasattr(self.backbone, 'forward_from_nchw'):
+            x = self.backbone.forward_from_nchw(img)
+        else:
+            x = self.backbone.forward_nhwc(to_nhwc(img))
         if self.with_neck:
             x = self.neck.forward_nhwc(x)
         return x

@@ -40,6 +40,8 @@ SIGNATURES = {
                                       [c_ptr]),
     'brcnn_conv2d_wgrad_nhwc_multi': (c_int, [c_ptr] * 3 + [c_int, c_int] + [c_ptr] * 2 + [c_int] * 7 +
                                       [c_ptr]),
+    'brcnn_stem_workspace_bytes': (c_size, [c_int, c_int, c_int]),
+    'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 5 + [c_ptr]),
     'brcnn_maxpool3x3s2_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 5 + [c_ptr]),
     'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
     'brcnn_groupnorm_nhwc_multi': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_int, c_int, c_f32,

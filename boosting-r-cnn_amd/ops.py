@@ -472,6 +472,31 @@ def groupnorm_nhwc_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, rel
     return y
 
 
+def pack_stem_weight(w):
+    """(Cout,3,7,7) parameter -> (Cout,7,1,32): [co, kh, 0, kw*4 + c], zeros at kw=7 / c=3"""
+    cout = w.shape[0]
+    p = torch.zeros((cout, 7, 8, 4), dtype=torch.float32, device=w.device)
+    p[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
+    return p.reshape(cout, 7, 1, 32).contiguous()
+
+
+def stem7x7s2_nchw(img, w_packed, scale=None, shift=None, relu=True):
+    """ResNet stem on the NCHW image: conv 7x7/s2/p3 (+scale/shift, ReLU) -> (N,Ho,Wo,Cout) NHWC"""
+    _require_gpu(img, w_packed, scale, shift)
+    n, c, h, w = img.shape
+    assert c == 3 and img.dtype == torch.float32
+    img = img.contiguous()
+    cout = w_packed.shape[0]
+    ho, wo = conv_out_size(h, w, 7, 7, 2, 3)
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=img.device)
+    lib = _L.load()
+    ws = _ws(lib.brcnn_stem_workspace_bytes(n, h, w), img.device)
+    st = lib.brcnn_stem7x7s2_nchw(_ptr(img), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(y), _ptr(ws),
+                                  n, h, w, cout, int(bool(relu)), _stream())
+    _L.check(st, 'brcnn_stem7x7s2_nchw')
+    return y
+
+
 def linear_nhwc(x, w, bias=None, relu=False):
     """x (M,K) @ w (N,K)^T + bias: the 1x1 case of the implicit GEMM with H=W=1."""
     m, k = x.shape

@@ -182,6 +182,15 @@ int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int b
                                   const int *widths_host, int cin, int cout, int kh, int kw,
                                   int stride, int pad, int dtype, void *stream);
 
+/* ResNet stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel NCHW image + folded BN +
+ * ReLU (resnet.py:599-611,631-636) -> y (N,Ho,Wo,Cout) NHWC.  w_packed (Cout,7,1,32):
+ * w_packed[co,kh,0,kw*4+c] = w[co,c,kh,kw] (zeros at kw=7 / c=3).  workspace:
+ * brcnn_stem_workspace_bytes() bytes (zero-bordered NHWC4 repack of the image). */
+size_t brcnn_stem_workspace_bytes(int batch, int height, int width);
+int brcnn_stem7x7s2_nchw(const float *img, const float *w_packed, const float *scale,
+                         const float *shift, float *y, void *workspace, int batch, int height,
+                         int width, int cout, int relu, void *stream);
+
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,
                             int channels, int dtype, void *stream);

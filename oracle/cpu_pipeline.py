@@ -56,6 +56,21 @@ def _linear_nhwc(x, w, bias=None, relu=False):
     return y.relu() if relu else y
 
 
+def _pack_stem_weight(w):
+    return w.detach().float()          # the CPU restatement convolves the NCHW image directly
+
+
+def _stem7x7s2_nchw(img, w_packed, scale=None, shift=None, relu=True):
+    y = F.conv2d(img, w_packed, None, 2, 3)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.view(1, -1, 1, 1)
+    if relu:
+        y = y.relu()
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
 def _maxpool(x):
     return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
 
@@ -133,7 +148,8 @@ def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds
     return props, valid.to(torch.uint8)
 
 
-_PATCH = dict(conv2d_nhwc=_conv2d_nhwc, conv2d_nhwc_multi=_conv2d_nhwc_multi,
+_PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw,
+              conv2d_nhwc=_conv2d_nhwc, conv2d_nhwc_multi=_conv2d_nhwc_multi,
               groupnorm_nhwc_multi=_groupnorm_multi, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
               groupnorm_nhwc=_groupnorm, upsample_nearest_add_nhwc_=_upsample_add_,
               nchw_to_nhwc=_nchw_to_nhwc, nhwc_to_nchw=_nhwc_to_nchw, roi_extract=_roi_extract,

@@ -488,3 +488,18 @@ def test_linear_and_roi_extract_autograd():
         ref = orc.roi_align_backward(go[inds].permute(0, 3, 1, 2).contiguous(), rois[inds], feats[i].shape, 7,
                                      1. / strides[i], 0, True) if inds.numel() else torch.zeros_like(feats[i])
         assert torch.allclose(fg[i].grad.permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=1e-5), i
+
+
+def test_stem_vector_path_matches_float64():
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(12)
+    for (n, h, w) in [(2, 64, 96), (1, 75, 83), (2, 800 // 4, 1344 // 4)]:
+        img = torch.randn(n, 3, h, w, generator=g)
+        wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        ref = (F.conv2d(img.double(), wt.double(), None, 2, 3) * sc.double().view(1, -1, 1, 1) +
+               sh.double().view(1, -1, 1, 1)).relu()
+        y = ops.stem7x7s2_nchw(img.to(DEV), ops.pack_stem_weight(wt.to(DEV)), sc.to(DEV), sh.to(DEV), True)
+        y = y.permute(0, 3, 1, 2).cpu().double()
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
