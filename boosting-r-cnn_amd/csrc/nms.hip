@@ -78,57 +78,72 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     mask[(size_t)(beg + ri) * words + col_t] = bits;
 }
 
-// one wavefront per segment
-__global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
-                                                        const int32_t* __restrict__ sorted_idx,
-                                                        const int32_t* __restrict__ seg_begin,
-                                                        const int32_t* __restrict__ seg_end,
-                                                        int64_t* __restrict__ keep,
-                                                        int32_t* __restrict__ num_keep, int words,
-                                                        int max_keep) {
-    extern __shared__ unsigned long long remv[];
-    const int seg = blockIdx.x, lane = threadIdx.x;
+// One 256-thread workgroup per segment.  Wave 0 resolves the greedy chain of the current
+// 64-row chunk (wave-uniform scalar walk over the diagonal mask words) and publishes the
+// survivor bits; then all four waves OR the survivors' mask rows into the LDS-resident
+// `removed` vector, each wave taking every fourth survivor (LDS atomics), so the row fetches of
+// a chunk (up to 64 x `words` x 8 B) are spread over 4x the load slots.
+__global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
+                                                         const int32_t* __restrict__ sorted_idx,
+                                                         const int32_t* __restrict__ seg_begin,
+                                                         const int32_t* __restrict__ seg_end,
+                                                         int64_t* __restrict__ keep,
+                                                         int32_t* __restrict__ num_keep, int words,
+                                                         int max_keep) {
+    extern __shared__ unsigned long long remv[];     // [words] + 1 word for the survivor bits
+    __shared__ int sh_count;
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int beg = seg_begin[seg], len = seg_end[seg] - beg;
     const int nchunk = (len + 63) >> 6;
-    for (int w = lane; w < nchunk; w += 64) remv[w] = 0ull;
+    unsigned long long* kept_sh = remv + words;
+    for (int w = tid; w < nchunk; w += 256) remv[w] = 0ull;
+    if (tid == 0) sh_count = 0;
     __syncthreads();
     int count = 0;
     for (int c = 0; c < nchunk; c++) {
-        const int row = c * 64 + lane;
-        const unsigned long long diag = (row < len) ? mask[(size_t)(beg + row) * words + c] : 0ull;
-        unsigned long long cur = remv[c];
-        const int nb = min(64, len - c * 64);
-        unsigned long long kept = 0ull;
-        const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
-        for (int b = 0; b < nb; b++) {
-            if (!((cur >> b) & 1ull)) {
-                kept |= 1ull << b;
-                const unsigned dlo = __builtin_amdgcn_readlane(lo, b);
-                const unsigned dhi = __builtin_amdgcn_readlane(hi, b);
-                cur |= ((unsigned long long)dhi << 32) | dlo;
+        if (wave == 0) {
+            const int row = c * 64 + lane;
+            const unsigned long long diag = (row < len) ? mask[(size_t)(beg + row) * words + c] : 0ull;
+            unsigned long long cur = remv[c];
+            const int nb = min(64, len - c * 64);
+            unsigned long long kept = 0ull;
+            const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
+            for (int b = 0; b < nb; b++) {
+                if (!((cur >> b) & 1ull)) {
+                    kept |= 1ull << b;
+                    const unsigned dlo = __builtin_amdgcn_readlane(lo, b);
+                    const unsigned dhi = __builtin_amdgcn_readlane(hi, b);
+                    cur |= ((unsigned long long)dhi << 32) | dlo;
+                }
             }
+            const bool mine = (kept >> lane) & 1ull;
+            const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+            if (mine) {
+                const int pos = count + rank;
+                if (max_keep <= 0 || pos < max_keep) keep[beg + pos] = (int64_t)sorted_idx[beg + row];
+            }
+            count += __popcll(kept);
+            if (lane == 0) { *kept_sh = kept; sh_count = count; }
         }
-        // emit survivors of this chunk in order
-        const bool mine = (kept >> lane) & 1ull;
-        const int rank = __popcll(kept & ((1ull << lane) - 1ull));
-        const int nk = __popcll(kept);
-        if (mine) {
-            const int pos = count + rank;
-            if (max_keep <= 0 || pos < max_keep) keep[beg + pos] = (int64_t)sorted_idx[beg + row];
-        }
-        count += nk;
+        __syncthreads();
+        count = sh_count;
         if (max_keep > 0 && count >= max_keep) { count = max_keep; break; }
-        // OR the survivors' rows into the removed vector (words beyond this chunk)
-        unsigned long long k2 = kept;
+        unsigned long long k2 = *kept_sh;
+        int j = 0;
         while (k2) {
             const int b = __ffsll((long long)k2) - 1;
             k2 &= k2 - 1;
-            const unsigned long long* mrow = mask + (size_t)(beg + c * 64 + b) * words;
-            for (int w = c + 1 + lane; w < nchunk; w += 64) remv[w] |= mrow[w];
+            if ((j++ & 3) == wave) {
+                const unsigned long long* mrow = mask + (size_t)(beg + c * 64 + b) * words;
+                for (int w = c + 1 + lane; w < nchunk; w += 64) {
+                    const unsigned long long m = mrow[w];
+                    if (m) atomicOr(&remv[w], m);
+                }
+            }
         }
         __syncthreads();
     }
-    if (lane == 0) num_keep[seg] = count;
+    if (tid == 0) num_keep[seg] = count;
 }
 
 struct NmsWs {
@@ -211,7 +226,7 @@ BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* 
                        (const float*)w.sboxes, (const float*)w.sareas, seg_begin, seg_end, w.mask, words,
                        iou_threshold, offset);
     BRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(num_segments), dim3(64), (size_t)words * 8, s,
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(num_segments), dim3(256), (size_t)(words + 1) * 8, s,
                        (const unsigned long long*)w.mask, (const int32_t*)w.idx_out, seg_begin, seg_end,
                        keep, num_keep, words, max_keep);
     BRCNN_LAUNCH_CHECK();

@@ -195,3 +195,39 @@ def test_train_step_losses_golden():
     assert n_grad == n_train, (n_grad, n_train)
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
     assert m.backbone.conv1.weight.grad is None and m.backbone.layer1[0].conv1.weight.grad is None
+
+
+@pytest.mark.parametrize('cfg_name', ['boosting_rcnn_r101_pafpn_softnms_coco.py',
+                                      'boosting_rcnn_r50_pafpn_1x_coco.py'])
+def test_other_configs_device_vs_cpu_oracle_pipeline(cfg_name):
+    """BASELINE configs #3/#5 at test time: COCO heads (80 classes) and the ResNet-101 +
+    soft-NMS recipe (2000 proposals, score_thr 1e-4) -- device path against the CPU oracle
+    pipeline (same module graph, PyTorch-CPU convs + C oracle RoIAlign/NMS/soft-NMS)."""
+    import os
+    from oracle import cpu_pipeline
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), cfg_name))
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=3)
+    with cpu_pipeline.patched():
+        m = build_detector(cfg.model)
+        sd = util.seeded_state_dict(m, seed=5)
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            ref = m(return_loss=False, rescale=True, img=[img], img_metas=[[dict(x) for x in metas]])
+    m = build_detector(cfg.model)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        got = m(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
+    n_ref = sum(len(r) for b in ref for r in b)
+    assert n_ref > 10
+    hit = tot = 0
+    for b in range(2):
+        for c in range(80):
+            r, g_ = ref[b][c], got[b][c]
+            tot += len(r)
+            if len(r) and len(g_):
+                d = np.abs(r[:, None, :4] - g_[None, :, :4]).max(-1)
+                s = np.abs(r[:, None, 4] - g_[None, :, 4])
+                hit += int(((d < 1e-2) & (s < 1e-3)).any(1).sum())
+    assert hit >= 0.9 * tot, (hit, tot)
