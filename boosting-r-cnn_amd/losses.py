@@ -289,3 +289,51 @@ def accuracy(pred, target, topk=1, thresh=None):
         correct_k = correct[:k].reshape(-1).float().sum(0, keepdim=True)
         res.append(correct_k.mul_(100.0 / pred.size(0)))
     return res[0] if return_single else res
+
+
+# ----------------------------------------------------------------------------- CIoU
+@weighted_loss
+def ciou_loss(pred, target, eps=1e-7):
+    """Complete-IoU loss (iou_loss.py:175-236): 1 - (IoU - rho^2/c^2 - alpha*v), clamped"""
+    import math
+    lt = torch.max(pred[:, :2], target[:, :2])
+    rb = torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    union = ap + ag - overlap + eps
+    ious = overlap / union
+    enclose_wh = (torch.max(pred[:, 2:], target[:, 2:]) - torch.min(pred[:, :2], target[:, :2])).clamp(min=0)
+    c2 = enclose_wh[:, 0] ** 2 + enclose_wh[:, 1] ** 2 + eps
+    w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
+    w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
+    left = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4
+    right = ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
+    rho2 = left + right
+    factor = 4 / math.pi ** 2
+    v = factor * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+    with torch.no_grad():
+        alpha = (ious > 0.5).float() * v / (1 - ious + v)
+    cious = ious - (rho2 / c2 + alpha * v)
+    return 1 - cious.clamp(min=-1.0, max=1.0)
+
+
+@LOSSES.register_module()
+class CIoULoss(nn.Module):
+    def __init__(self, eps=1e-6, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.eps, self.reduction, self.loss_weight = eps, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        if weight is not None and not torch.any(weight > 0):
+            if pred.dim() == weight.dim() + 1:
+                weight = weight.unsqueeze(1)
+            return (pred * weight).sum()
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        if weight is not None and weight.dim() > 1:
+            assert weight.shape == pred.shape
+            weight = weight.mean(-1)
+        return self.loss_weight * ciou_loss(pred, target, weight, eps=self.eps, reduction=reduction,
+                                            avg_factor=avg_factor, **kwargs)

@@ -282,6 +282,29 @@ def g10_model(cfg):
     npz('g10_train_losses', **{k: (torch.stack(v) if isinstance(v, list) else v) for k, v in losses.items()})
 
 
+def g11_fpn_config():
+    """boosting_rcnn_r50_fpn_1x_coco.py (FPN neck, CIoU on encoded deltas, 80 classes): train
+    losses and test detections of the reference on the demo batch"""
+    from mmdet.models import build_detector
+    cfg = Config.fromfile('/root/reference/configs/boosting_rcnn/boosting_rcnn_r50_fpn_1x_coco.py')
+    m = build_detector(cfgdict(copy.deepcopy(cfg.model.to_dict())))
+    m.load_state_dict(util.seeded_state_dict(m, seed=11))
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, num_classes=80, seed=11)
+    m.eval()
+    d = {}
+    with torch.no_grad():
+        res = m.simple_test(img, metas, rescale=True)
+    for b in range(2):
+        d[f'det{b}'] = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, np.float32)], 1)
+                                       for c, r in enumerate(res[b])], 0)
+    m.train()
+    torch.manual_seed(78)
+    losses = m.forward_train(img, metas, gts, gls)
+    for k, v in losses.items():
+        d['loss_' + k] = torch.stack(v) if isinstance(v, list) else v
+    npz('g11_fpn_config', **d)
+
+
 def kat():
     """known-answer vectors of the mmcv ops, re-derived here in float64"""
     boxes = [[6, 3, 8, 7], [3, 6, 9, 11], [3, 7, 10, 12], [1, 4, 13, 7]]
@@ -342,6 +365,7 @@ def main():
     g7_boost_loss(cfg)
     g8_g9_test_head(cfg)
     g10_model(cfg)
+    g11_fpn_config()
 
 
 if __name__ == '__main__':
