@@ -310,6 +310,210 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_igemm_f32_kernel(ConvParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FAST-path kernel with LDS-DMA staging (`buffer_load_dwordx4 ... lds`): the operand tiles go
+// HBM/L2 -> LDS without passing through VGPRs, so the K loop has no ds_write pass and no
+// staging registers; one `s_waitcnt vmcnt(0)` + barrier per K tile.  A DMA instruction writes
+// the wave's 64 x 16 B contiguously, so the LDS tile is unpadded [row][8 chunks of 16 B] and the
+// bank-conflict-free read pattern comes from an XOR swizzle applied on the SOURCE side: the
+// lane that lands at physical chunk c' of row r fetches logical chunk c' ^ ((r >> 1) & 7); the
+// fragment reads apply the same involution.  Tile 128 x (64*NT) x 32, 4 waves (2x2).
+template <int NT, bool RES>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p) {
+    constexpr int BM = 128, BN = 64 * NT;
+    constexpr int AG = BM / 8 / 4;      // 8-row groups of the A tile per wave (4)
+    constexpr int BG = BN / 8 / 4;      // 8-row groups of the W tile per wave (4 or 2)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][BM][32]
+    float* Bs = smem + 2 * BM * 32;     // [2][BN][32]
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- DMA assignment: wave w moves row groups w*AG+j; lane -> (row in group, physical chunk)
+    const int rg = lane >> 3, pc = lane & 7;
+    int a_base[AG], a_hw[AG], a_H[AG], a_W[AG], a_lc[AG];
+    int b_off[BG];
+#pragma unroll
+    for (int j = 0; j < AG; j++) {
+        const int r = (wave * AG + j) * 8 + rg;
+        a_lc[j] = (pc ^ ((r >> 1) & 7)) * 4;          // logical k offset (floats) of this lane's chunk
+        const int m = m0 + r;
+        if (m < p.M) {
+            int sg = 0;
+#pragma unroll
+            for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+            const int ml = m - p.seg_m0[sg];
+            const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg];
+            a_H[j] = p.seg_H[sg];
+            a_W[j] = p.seg_W[sg];
+            const int n = ml / (Ho * Wo);
+            const int rem = ml - n * (Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            a_base[j] = (int)p.seg_xoff[sg] + n * a_H[j] * a_W[j] * p.pitch;
+            a_hw[j] = ((ho * p.stride - p.pad + 4096) << 16) | (wo * p.stride - p.pad + 4096);
+        } else {
+            a_base[j] = -1;
+            a_hw[j] = 0;
+            a_H[j] = a_W[j] = 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BG; j++) {
+        const int r = (wave * BG + j) * 8 + rg;
+        const int co = n0 + r;
+        b_off[j] = (co < p.Cout) ? co * p.K + (pc ^ ((r >> 1) & 7)) * 4 : -1;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+
+    auto dma_tile = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cin;
+        const int ci0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int j = 0; j < AG; j++) {
+            int hi = (a_hw[j] >> 16) - 4096 + kh;
+            int wi = (a_hw[j] & 0xffff) - 4096 + kw;
+            bool ok = a_base[j] >= 0;
+            if (p.dilate > 1) {
+                ok = ok & (hi >= 0) & (wi >= 0);
+                const int qh = hi / p.dilate, qw = wi / p.dilate;
+                ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
+                hi = qh;
+                wi = qw;
+            }
+            ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
+            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j]) * 4 : OOB;
+            float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BG; j++) {
+            const int off = (b_off[j] >= 0) ? (b_off[j] + k0) * 4 : OOB;
+            float* dst = Bs + buf * BN * 32 + (wave * BG + j) * 8 * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    dma_tile(0, 0);
+
+    // residual prefetch (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    const float* __restrict__ res = p.residual;
+    float rv[2][NT][16];
+    if (RES) {
+#pragma unroll
+        for (int tn = 0; tn < NT; tn++) {
+            const int co = n0 + wn * 32 * NT + tn * 32 + li;
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++) {
+                const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    rv[tm][tn][r] = (co < p.Cout && m < p.M) ? res[(size_t)m * p.Cout + co] : 0.f;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment addressing: row R = base + li, logical chunk c = 2*kk + lh, physical c ^ ((R>>1)&7);
+    // all row bases are multiples of 32, so (R>>1)&7 == (li>>1)&7
+    const int sw = (li >> 1) & 7;
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
+        const float* as = As + cur * BM * 32 + (wm * 64 + li) * 32;
+        const float* bs = Bs + cur * BN * 32 + (wn * 32 * NT + li) * 32;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; kk++) {
+            const int ch = ((2 * kk + lh) ^ sw) * 4;
+            const float4 a0 = *reinterpret_cast<const float4*>(as + ch);
+            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * 32 + ch);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            float bv[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const float4 b = *reinterpret_cast<const float4*>(bs + t * 32 * 32 + ch);
+                bv[t][0] = b.x; bv[t][1] = b.y; bv[t][2] = b.z; bv[t][3] = b.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][e], bv[t][e],
+                                                                          acc[tm][t], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* __restrict__ yout = p.y;
+#pragma unroll
+    for (int tn = 0; tn < NT; tn++) {
+        const int co = n0 + wn * 32 * NT + tn * 32 + li;
+        const bool cok = co < p.Cout;
+        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[tm][tn][r];
+                if (p.scale) v = v * sc;
+                v = v + sh;
+                if (RES) v = v + rv[tm][tn][r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (cok && m < p.M) yout[(size_t)m * p.Cout + co] = v;
+            }
+        }
+    }
+}
+
+template <int NT, bool RES>
+int launch_dma(const ConvParams& p, hipStream_t s) {
+    const size_t lds = (size_t)2 * (128 + 64 * NT) * 32 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_dma_kernel<NT, RES>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_f32_dma_kernel<NT, RES>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds,
+                       s, p);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool FAST, int WM, int NT, bool RES>
 int launch_conv(const ConvParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * (64 * WM + 64 * NT) * LDS_STRIDE * sizeof(float);
@@ -330,6 +534,7 @@ int launch_res(const ConvParams& p, hipStream_t s) {
     return p.residual ? launch_conv<FAST, WM, NT, true>(p, s) : launch_conv<FAST, WM, NT, false>(p, s);
 }
 
+int g_use_dma = 1;                      // LDS-DMA staged kernel for the FAST path
 int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 = heuristic
 
 // Workgroup slots of the chip for this kernel family: 256 CUs x 2 resident workgroups.
@@ -362,6 +567,14 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
     p.tiles_n = (p.Cout + 64 * nt - 1) / (64 * nt);
     if (!fast) return nt == 1 ? launch_res<false, 2, 1>(p, s) : launch_res<false, 2, 2>(p, s);
+    // LDS-DMA staging wins 8-18 % wherever a second resident workgroup covers the per-tile
+    // `vmcnt(0)`; with ~1 workgroup per CU (few tiles) or in the short-K residual layers (HBM
+    // bound) the register-staged kernel is as fast or faster (profiles/r01_conv_tiles.txt)
+    const bool dma_ok = (long long)p.tiles_m * p.tiles_n > 320 && !(p.residual && p.K <= 256);
+    if (g_use_dma == 2 || (g_use_dma == 1 && dma_ok && wm == 2)) {
+        if (nt == 1) return p.residual ? launch_dma<1, true>(p, s) : launch_dma<1, false>(p, s);
+        return p.residual ? launch_dma<2, true>(p, s) : launch_dma<2, false>(p, s);
+    }
     if (nt == 1) return launch_res<true, 2, 1>(p, s);
     return wm == 4 ? launch_res<true, 4, 2>(p, s) : launch_res<true, 2, 2>(p, s);
 }
@@ -369,6 +582,7 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 }  // namespace
 
 BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
+    if (wm == -1) { g_use_dma = nt; return 0; }   // (-1, 0/1/2): register-staged / heuristic / always LDS-DMA
     if ((wm != 0 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
     g_force_wm = wm;
     g_force_nt = nt;

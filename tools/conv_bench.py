@@ -34,9 +34,9 @@ for name,N,H,W,Ci,Co,k,st,pd,res in shapes:
     r = torch.randn(N,Ho,Wo,Co,device='cuda') if res else None
     fl = 2.0*N*Ho*Wo*Co*k*k*Ci
     out = []
-    for wm, nt in ((2,2),(2,1),(0,0)):
-        L.brcnn_conv_set_tile(wm, nt)
+    for dma in (0, 2, 1):
+        L.brcnn_conv_set_tile(-1, dma)
         ms = bench(lambda: ops.conv2d_nhwc(x,w,sc,sh,r,True,st,pd))
-        out.append(f'wm{wm}nt{nt}: {ms*1000:8.1f} us {fl/ms/1e9:6.1f} TF')
-    L.brcnn_conv_set_tile(0, 0)
+        out.append(f'{("reg","auto","dma")[dma]}: {ms*1000:8.1f} us {fl/ms/1e9:6.1f} TF')
+    L.brcnn_conv_set_tile(-1, 1)
     print(f'{name:28s} M={N*Ho*Wo:7d} ' + ' | '.join(out))
