@@ -570,7 +570,7 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
     // LDS-DMA staging wins 8-18 % wherever a second resident workgroup covers the per-tile
     // `vmcnt(0)`; with ~1 workgroup per CU (few tiles) or in the short-K residual layers (HBM
     // bound) the register-staged kernel is as fast or faster (profiles/r01_conv_tiles.txt)
-    const bool dma_ok = (long long)p.tiles_m * p.tiles_n > 320 && !(p.residual && p.K <= 256);
+    const bool dma_ok = (long long)p.tiles_m * p.tiles_n > 320 && !(p.residual && p.K <= 128);
     if (g_use_dma == 2 || (g_use_dma == 1 && dma_ok && wm == 2)) {
         if (nt == 1) return p.residual ? launch_dma<1, true>(p, s) : launch_dma<1, false>(p, s);
         return p.residual ? launch_dma<2, true>(p, s) : launch_dma<2, false>(p, s);
