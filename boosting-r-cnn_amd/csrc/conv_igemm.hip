@@ -537,41 +537,22 @@ int launch_res(const ConvParams& p, hipStream_t s) {
 int g_use_dma = 1;                      // LDS-DMA staged kernel for the FAST path
 int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 = heuristic
 
-// Workgroup slots of the chip for this kernel family: 256 CUs x 2 resident workgroups.
-constexpr int SLOTS = 512;
-
 int dispatch_conv(ConvParams& p, hipStream_t s) {
     const bool fast = (p.Cin % 32 == 0);
-    const int tm = (p.M + 127) / 128;
-    int nt = (p.Cout <= 64) ? 1 : 2;
-    if (nt == 2 && fast) {
-        // Tile-count quantisation: the launch takes ceil(tiles / SLOTS) rounds of resident
-        // workgroups, each round costing ~NT units of MFMA time.  When the 128x128 grid leaves
-        // the last round nearly empty (e.g. 526 tiles), the 128x64 tile (twice the tiles, half
-        // the work each, ~8 % less efficient per FLOP) finishes earlier.
-        const long long t2 = (long long)tm * ((p.Cout + 127) / 128), t1 = (long long)tm * ((p.Cout + 63) / 64);
-        const double c2 = (double)((t2 + SLOTS - 1) / SLOTS) * 2.0;
-        const double c1 = (double)((t1 + SLOTS - 1) / SLOTS) * 1.08;
-        if (c1 < c2) nt = 1;
-        // under two rounds the 128x128 grid leaves CUs with a single resident workgroup (no
-        // second wave per SIMD to cover the staging phases): measured 8-40 % slower than 128x64
-        // (profiles/r01_conv_tiles.txt), except with a residual operand (register pressure)
-        if (t2 < 2 * SLOTS && !p.residual) nt = 1;
-    }
+    // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the 128x64 tile
+    // (48 KiB LDS -> 3 resident workgroups / CU, twice the tiles -> less tail quantisation)
+    // is at least as fast as 128x128 on every layer of the network, so it is the default.
+    // With ~1 workgroup per CU (few tiles: the 12544-deep FC) nothing covers the per-tile
+    // `vmcnt(0)` of the DMA kernel and the register-staged kernel wins.
+    int nt = (fast || p.Cout <= 64) ? 1 : 2;
     if (g_force_nt == 1 || (g_force_nt == 2 && p.Cout > 64)) nt = g_force_nt;
-    // measured on MI355X (profiles/r01_conv_tiles.txt): the 256-row tile never beats 128x128
-    // for this network (the kernel is MFMA-issue bound, not L2->LDS bound), so it is only
-    // reachable through the tuning hook
     int wm = 2;
     if (g_force_wm == 4 && fast && nt == 2) wm = 4;
     p.tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
     p.tiles_n = (p.Cout + 64 * nt - 1) / (64 * nt);
     if (!fast) return nt == 1 ? launch_res<false, 2, 1>(p, s) : launch_res<false, 2, 2>(p, s);
-    // LDS-DMA staging wins 8-18 % wherever a second resident workgroup covers the per-tile
-    // `vmcnt(0)`; with ~1 workgroup per CU (few tiles) or in the short-K residual layers (HBM
-    // bound) the register-staged kernel is as fast or faster (profiles/r01_conv_tiles.txt)
-    const bool dma_ok = (long long)p.tiles_m * p.tiles_n > 320 && !(p.residual && p.K <= 128);
-    if (g_use_dma == 2 || (g_use_dma == 1 && dma_ok && wm == 2)) {
+    const bool dma_ok = (long long)p.tiles_m * p.tiles_n > 320;
+    if (wm == 2 && (g_use_dma == 2 || (g_use_dma == 1 && dma_ok))) {
         if (nt == 1) return p.residual ? launch_dma<1, true>(p, s) : launch_dma<1, false>(p, s);
         return p.residual ? launch_dma<2, true>(p, s) : launch_dma<2, false>(p, s);
     }

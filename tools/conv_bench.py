@@ -34,9 +34,11 @@ for name,N,H,W,Ci,Co,k,st,pd,res in shapes:
     r = torch.randn(N,Ho,Wo,Co,device='cuda') if res else None
     fl = 2.0*N*Ho*Wo*Co*k*k*Ci
     out = []
-    for dma in (0, 2, 1):
+    for dma, nt in ((0, 0), (2, 2), (2, 1), (1, 0)):
         L.brcnn_conv_set_tile(-1, dma)
+        L.brcnn_conv_set_tile(0, nt)
         ms = bench(lambda: ops.conv2d_nhwc(x,w,sc,sh,r,True,st,pd))
-        out.append(f'{("reg","auto","dma")[dma]}: {ms*1000:8.1f} us {fl/ms/1e9:6.1f} TF')
+        out.append(f'{("reg","auto","dma")[dma]}{nt if nt else ""}: {ms*1000:7.1f} us {fl/ms/1e9:6.1f} TF')
     L.brcnn_conv_set_tile(-1, 1)
+    L.brcnn_conv_set_tile(0, 0)
     print(f'{name:28s} M={N*Ho*Wo:7d} ' + ' | '.join(out))
