@@ -318,9 +318,9 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_igemm_f32_kernel(ConvParams 
 // bank-conflict-free read pattern comes from an XOR swizzle applied on the SOURCE side: the
 // lane that lands at physical chunk c' of row r fetches logical chunk c' ^ ((r >> 1) & 7); the
 // fragment reads apply the same involution.  Tile 128 x (64*NT) x 32, 4 waves (2x2).
-template <int NT, bool RES>
+template <int MT, int NT, bool RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p) {
-    constexpr int BM = 128, BN = 64 * NT;
+    constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int AG = BM / 8 / 4;      // 8-row groups of the A tile per wave (4)
     constexpr int BG = BN / 8 / 4;      // 8-row groups of the W tile per wave (4 or 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -378,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
         b_off[j] = (co < p.Cout) ? co * p.K + (pc ^ ((r >> 1) & 7)) * 4 : -1;
     }
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < NT; b++)
 #pragma unroll
@@ -422,14 +422,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 
     // residual prefetch (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     const float* __restrict__ res = p.residual;
-    float rv[2][NT][16];
+    float rv[MT][NT][16];
     if (RES) {
 #pragma unroll
         for (int tn = 0; tn < NT; tn++) {
             const int co = n0 + wn * 32 * NT + tn * 32 + li;
 #pragma unroll
-            for (int tm = 0; tm < 2; tm++) {
-                const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
+            for (int tm = 0; tm < MT; tm++) {
+                const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -447,14 +447,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     int cur = 0;
     for (int kt = 0; kt < nk; kt++) {
         if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
-        const float* as = As + cur * BM * 32 + (wm * 64 + li) * 32;
+        const float* as = As + cur * BM * 32 + (wm * 32 * MT + li) * 32;
         const float* bs = Bs + cur * BN * 32 + (wn * 32 * NT + li) * 32;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; kk++) {
             const int ch = ((2 * kk + lh) ^ sw) * 4;
-            const float4 a0 = *reinterpret_cast<const float4*>(as + ch);
-            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * 32 + ch);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            float av[MT][4];
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const float4 a = *reinterpret_cast<const float4*>(as + t * 32 * 32 + ch);
+                av[t][0] = a.x; av[t][1] = a.y; av[t][2] = a.z; av[t][3] = a.w;
+            }
             float bv[NT][4];
 #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int tm = 0; tm < 2; tm++)
+                for (int tm = 0; tm < MT; tm++)
 #pragma unroll
                     for (int t = 0; t < NT; t++)
                         acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][e], bv[t][e],
@@ -483,8 +486,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
         const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
         const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            const int mb = m0 + wm * 64 + tm * 32 + 4 * lh;
+        for (int tm = 0; tm < MT; tm++) {
+            const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -499,16 +502,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     }
 }
 
-template <int NT, bool RES>
+template <int MT, int NT, bool RES>
 int launch_dma(const ConvParams& p, hipStream_t s) {
-    const size_t lds = (size_t)2 * (128 + 64 * NT) * 32 * sizeof(float);
+    const size_t lds = (size_t)2 * (64 * MT + 64 * NT) * 32 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_dma_kernel<NT, RES>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_f32_dma_kernel<MT, NT, RES>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32_dma_kernel<NT, RES>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds,
+    hipLaunchKernelGGL((conv_igemm_f32_dma_kernel<MT, NT, RES>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds,
                        s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -539,11 +542,17 @@ int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 =
 
 int dispatch_conv(ConvParams& p, hipStream_t s) {
     const bool fast = (p.Cin % 32 == 0);
-    // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the 128x64 tile
-    // (48 KiB LDS -> 3 resident workgroups / CU, twice the tiles -> less tail quantisation)
-    // is at least as fast as 128x128 on every layer of the network, so it is the default.
-    // With ~1 workgroup per CU (few tiles: the 12544-deep FC) nothing covers the per-tile
-    // `vmcnt(0)` of the DMA kernel and the register-staged kernel wins.
+    // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the SMALLEST tile,
+    // 64x64 (4 waves x one 32x32 MFMA tile, 32 KiB LDS -> up to 5 resident workgroups / CU,
+    // 4x the tiles of 128x128 -> hardly any tail quantisation), is the fastest on every layer
+    // of the network, the 12544-deep FC included: the kernel is bound by MFMA issue and
+    // latency hiding, not by L2->LDS bytes, so it is the default.  The other shapes stay
+    // reachable through brcnn_conv_set_tile (tools/conv_bench.py).
+    if (fast && g_use_dma && g_force_wm == 0 && g_force_nt == 0) {
+        p.tiles_m = (p.M + 63) / 64;
+        p.tiles_n = (p.Cout + 63) / 64;
+        return p.residual ? launch_dma<1, 1, true>(p, s) : launch_dma<1, 1, false>(p, s);
+    }
     int nt = (fast || p.Cout <= 64) ? 1 : 2;
     if (g_force_nt == 1 || (g_force_nt == 2 && p.Cout > 64)) nt = g_force_nt;
     int wm = 2;
@@ -551,10 +560,14 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
     p.tiles_n = (p.Cout + 64 * nt - 1) / (64 * nt);
     if (!fast) return nt == 1 ? launch_res<false, 2, 1>(p, s) : launch_res<false, 2, 2>(p, s);
-    const bool dma_ok = (long long)p.tiles_m * p.tiles_n > 320;
-    if (wm == 2 && (g_use_dma == 2 || (g_use_dma == 1 && dma_ok))) {
-        if (nt == 1) return p.residual ? launch_dma<1, true>(p, s) : launch_dma<1, false>(p, s);
-        return p.residual ? launch_dma<2, true>(p, s) : launch_dma<2, false>(p, s);
+    if (wm == 2 && g_use_dma) {
+        if (g_force_wm == 1) {
+            p.tiles_m = (p.M + 63) / 64;
+            p.tiles_n = (p.Cout + 63) / 64;
+            return p.residual ? launch_dma<1, 1, true>(p, s) : launch_dma<1, 1, false>(p, s);
+        }
+        if (nt == 1) return p.residual ? launch_dma<2, 1, true>(p, s) : launch_dma<2, 1, false>(p, s);
+        return p.residual ? launch_dma<2, 2, true>(p, s) : launch_dma<2, 2, false>(p, s);
     }
     if (nt == 1) return launch_res<true, 2, 1>(p, s);
     return wm == 4 ? launch_res<true, 4, 2>(p, s) : launch_res<true, 2, 2>(p, s);
@@ -564,7 +577,7 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
     if (wm == -1) { g_use_dma = nt; return 0; }   // (-1, 0/1/2): register-staged / heuristic / always LDS-DMA
-    if ((wm != 0 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
+    if ((wm != 0 && wm != 1 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
     g_force_wm = wm;
     g_force_nt = nt;
     return 0;

@@ -34,11 +34,11 @@ for name,N,H,W,Ci,Co,k,st,pd,res in shapes:
     r = torch.randn(N,Ho,Wo,Co,device='cuda') if res else None
     fl = 2.0*N*Ho*Wo*Co*k*k*Ci
     out = []
-    for dma, nt in ((0, 0), (2, 2), (2, 1), (1, 0)):
+    for dma, nt, wm in ((0, 1, 0), (2, 2, 2), (2, 1, 2), (1, 0, 0)):
         L.brcnn_conv_set_tile(-1, dma)
-        L.brcnn_conv_set_tile(0, nt)
+        L.brcnn_conv_set_tile(wm, nt)
         ms = bench(lambda: ops.conv2d_nhwc(x,w,sc,sh,r,True,st,pd))
-        out.append(f'{("reg","auto","dma")[dma]}{nt if nt else ""}: {ms*1000:7.1f} us {fl/ms/1e9:6.1f} TF')
+        out.append(f'{("reg","auto","dma")[dma]}{nt if nt else ""}{"" if wm == 0 else "m%d" % wm}: {ms*1000:7.1f} us {fl/ms/1e9:6.1f} TF')
     L.brcnn_conv_set_tile(-1, 1)
     L.brcnn_conv_set_tile(0, 0)
     print(f'{name:28s} M={N*Ho*Wo:7d} ' + ' | '.join(out))
