@@ -264,3 +264,58 @@ def test_fpn_ciou_config_golden():
         # proposal flipping across the 0.6 IoU threshold (fp32 round-off) shifts them by ~1/1024
         tol = 1e-2 if k in ('loss_cls', 'loss_bbox', 'acc') else 2e-3
         assert torch.allclose(got.detach().cpu().float(), T(g['loss_' + k]).float(), rtol=tol, atol=1e-4), k
+
+
+def test_device_path_edge_cases(model):
+    """empty / ragged situations the reference tests in test_forward.py:260-340: no proposal
+    survives, different image shapes in one batch, batch of one."""
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=21)
+    # (a) images of different valid shapes in one padded batch -> per-image clip borders
+    metas[1] = dict(metas[1], img_shape=(100, 150, 3), ori_shape=(100, 150, 3))
+    with torch.no_grad():
+        res = model(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
+        x = model.extract_feat(img.to(DEV))
+        ref = model.roi_head.simple_test(x, model.rpn_head.simple_test_rpn(x, metas), metas, rescale=True)
+    for b in range(2):
+        for c in range(4):
+            assert _match_dets(res[b][c], ref[b][c]) >= 0.95 and _match_dets(ref[b][c], res[b][c]) >= 0.95
+            if len(res[b][c]):
+                lim = np.array(metas[b]['img_shape'][:2][::-1] * 2) / metas[b]['scale_factor']
+                assert (res[b][c][:, :4] <= lim + 1e-3).all()
+    # (b) batch of one
+    with torch.no_grad():
+        r1 = model(return_loss=False, rescale=True, img=[img[:1].to(DEV)], img_metas=[[metas[0]]])
+    assert len(r1) == 1 and len(r1[0]) == 4
+    # (c) nothing passes the score threshold -> empty (0,5) float32 arrays per class
+    old = model.roi_head.test_cfg.score_thr
+    model.roi_head.test_cfg.score_thr = 2.0
+    try:
+        with torch.no_grad():
+            r0 = model(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
+    finally:
+        model.roi_head.test_cfg.score_thr = old
+    assert all(a.shape == (0, 5) and a.dtype == np.float32 for b in r0 for a in b)
+    # (d) no proposals at all: min_bbox_size larger than any box
+    from brcnn.config import ConfigDict
+    cfg = ConfigDict(dict(model.rpn_head.test_cfg.to_dict(), min_bbox_size=1e6))
+    with torch.no_grad():
+        cls, reg, iou = model.rpn_head(model.extract_feat(img.to(DEV)))
+        props = model.rpn_head.get_bboxes(cls, reg, iou, metas, cfg=cfg)
+    assert all(p.shape == (0, 5) for p in props)
+    out = model.roi_head.simple_test(x, props, metas, rescale=True)
+    assert all(a.shape == (0, 5) for b in out for a in b)
+
+
+def test_train_step_empty_gt_image():
+    """an image without ground truth in the batch (test_forward.py empty-GT case)"""
+    cfg = Config.fromfile(CFG)
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=10))
+    m = m.to(DEV).train()
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    gts[1], gls[1] = gts[1][:0], gls[1][:0]
+    torch.manual_seed(1)
+    losses = m.forward_train(img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    loss, log_vars = m._parse_losses(losses)
+    assert torch.isfinite(loss) and loss.item() > 0
+    loss.backward()
