@@ -8,12 +8,11 @@
 //
 // GEMM with the reduction over the M = N*Ho*Wo output pixels (up to 537 600) and a small
 // (Cout x K) result, so the reduction is split: grid = (co tiles x k tiles) x S slices of M,
-// every workgroup reduces its slice into a 128x128 fp32 tile on v_mfma_f32_32x32x2_f32 and
-// adds it to dW with fp32 atomics (dW zero-filled by the caller).  Both operands are
+// every workgroup reduces its slice into a 64x64 fp32 tile on v_mfma_f32_32x32x2_f32 and adds
+// it to dW with fp32 atomics (dW zero-filled by the caller).  Both operands are
 // "reduction-major" in memory ((M,Cout) and (M,K) rows), which is exactly the MFMA operand
-// order lane -> column: the LDS tiles are stored [m][128 columns] unpadded (ds_write_b128 of
-// coalesced rows, conflict-free ds_read_b32 of 32 consecutive columns), one read per operand
-// per MFMA.
+// order lane -> column: the LDS tiles are stored [m][64 columns] unpadded (conflict-free
+// ds_read_b32 of 32 consecutive columns), one read per operand per MFMA.
 #include "common.h"
 
 namespace {
@@ -22,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = 0x7fffffff;
 constexpr int TM = 32;          // reduction (m) rows per LDS tile
-constexpr int TC = 128;         // columns per operand tile
+constexpr int TC = 64;          // columns per operand tile (output tile TC x TC)
 
 struct WgradParams {
     const float* dy;    // (M, Cout)
@@ -35,19 +34,42 @@ struct WgradParams {
     int seg_m0[BRCNN_MAX_LEVELS + 1];
     int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
     long long seg_xoff[BRCNN_MAX_LEVELS];
+    // division by the invariant Ho*Wo / Wo as multiply-high + shift (the row -> pixel decode runs
+    // for every staged row of every tile; two hardware-emulated integer divisions per row made
+    // the kernel VALU bound)
+    unsigned seg_mhw[BRCNN_MAX_LEVELS], seg_shw[BRCNN_MAX_LEVELS], seg_mw[BRCNN_MAX_LEVELS], seg_sw[BRCNN_MAX_LEVELS];
 };
 
+__device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned magic, unsigned shift) {
+    return (unsigned)(((unsigned long long)__umulhi(x, magic) + x) >> shift);
+}
+
+// 64 x 64 output tile, 4 waves x one 32x32 MFMA tile; both operand tiles ([32 m][64 cols] fp32,
+// 256-byte rows) are staged by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no
+// ds_write pass), double buffered, one `vmcnt(0)` + barrier per 32 reduction rows.
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) float Ya[2][TM][TC];   // dY tile  [m][co]
     __shared__ __attribute__((aligned(16))) float Xa[2][TM][TC];   // im2col tile [m][k]
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    int b = blockIdx.x;
-    const int slice = b % p.slices; b /= p.slices;
+    // Block order: all (co, k) tiles of one M slice are adjacent and each XCD owns a contiguous
+    // run of blocks, so the dY rows (shared by the k tiles) and the x pixels (shared by the co
+    // tiles and by neighbouring filter taps) of a slice are fetched into one L2 once.
+    const int nwg = p.tiles_co * p.tiles_k * p.slices;
+    int b;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        b = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles = p.tiles_co * p.tiles_k;
+    const int slice = b / tiles;
+    b -= slice * tiles;
     const int tk = b % p.tiles_k, tco = b / p.tiles_k;
     const int co0 = tco * TC, k0 = tk * TC;
     const int m_begin = slice * p.rows_per_slice;
@@ -57,9 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
 
-    // staging: thread owns float4 column c4 (0..31) of rows r0 + 8*j (j = 0..3) of both tiles
-    const int c4 = tid & 31;
-    const int r0 = tid >> 5;
+    // DMA assignment: a wave instruction moves 4 rows x 256 B; wave w owns rows (2w+j)*4 .. +4
+    const int c4 = lane & 15, rr = lane >> 4;
     const int co = co0 + c4 * 4;
     const bool co_ok = co < p.Cout;                 // Cout % 4 == 0 enforced by the host
     const int k = k0 + c4 * 4;
@@ -68,19 +89,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
     const int ci = k - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
-    f32x16 acc[2][2];
+    f32x16 acc;
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-    float4 ry[4], rx[4];
-    auto load_tile = [&](int mt) {
+    auto dma_tile = [&](int mt, int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int m = mt + r0 + 8 * j;
+        for (int j = 0; j < 2; j++) {
+            const int row = (wave * 2 + j) * 4 + rr;
+            const int m = mt + row;
             int offy = OOB, offx = OOB;
             if (m < m_end) {
                 if (co_ok) offy = (m * p.Cout + co) * 4;
@@ -91,69 +108,56 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
                         if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
                     const int ml = m - p.seg_m0[sg];
                     const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg], H = p.seg_H[sg], W = p.seg_W[sg];
-                    const int n = ml / (Ho * Wo);
+                    const int n = (int)fastdiv((unsigned)ml, p.seg_mhw[sg], p.seg_shw[sg]);
                     const int rem = ml - n * (Ho * Wo);
-                    const int ho = rem / Wo, wo = rem - ho * Wo;
+                    const int ho = (int)fastdiv((unsigned)rem, p.seg_mw[sg], p.seg_sw[sg]);
+                    const int wo = rem - ho * Wo;
                     const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
                     if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
                         offx = ((int)p.seg_xoff[sg] + ((n * H + hi) * W + wi) * p.Cin + ci) * 4;
                 }
             }
-            const u32x4 vy = __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, offy, 0, 0);
-            const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, offx, 0, 0);
-            ry[j] = make_float4(__uint_as_float(vy.x), __uint_as_float(vy.y), __uint_as_float(vy.z), __uint_as_float(vy.w));
-            rx[j] = make_float4(__uint_as_float(vx.x), __uint_as_float(vx.y), __uint_as_float(vx.z), __uint_as_float(vx.w));
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            *reinterpret_cast<float4*>(&Ya[buf][r0 + 8 * j][c4 * 4]) = ry[j];
-            *reinterpret_cast<float4*>(&Xa[buf][r0 + 8 * j][c4 * 4]) = rx[j];
-        }
-    };
-    // one MFMA step consumes reduction rows (2s, 2s+1): lane half lh takes row 2s + lh
-    auto mfma_steps = [&](int buf, int s0, int s1) {
-#pragma unroll
-        for (int s = s0; s < s1; s++) {
-            const int row = 2 * s + lh;
-            const float a0 = Ya[buf][row][wm * 64 + li], a1 = Ya[buf][row][wm * 64 + 32 + li];
-            const float b0 = Xa[buf][row][wn * 64 + li], b1 = Xa[buf][row][wn * 64 + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)&Ya[buf][(wave * 2 + j) * 4][0], 16, offy, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)&Xa[buf][(wave * 2 + j) * 4][0], 16, offx, 0, 0, 0);
         }
     };
 
-    load_tile(m_begin);
-    store_tile(0);
+    dma_tile(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int mt = m_begin; mt < m_end; mt += TM) {
-        const bool more = mt + TM < m_end;
-        if (more) load_tile(mt + TM);
-        mfma_steps(cur, 0, 8);
-        if (more) store_tile(cur ^ 1);
-        mfma_steps(cur, 8, 16);
+        if (mt + TM < m_end) dma_tile(mt + TM, cur ^ 1);
+        // one MFMA step consumes reduction rows (2s, 2s+1): lane half lh takes row 2s + lh
+#pragma unroll
+        for (int s = 0; s < TM / 2; s++) {
+            const int row = 2 * s + lh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ya[cur][row][wm * 32 + li], Xa[cur][row][wn * 32 + li],
+                                                       acc, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
 
     // D[row = co][col = k]:  col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int kk = k0 + wn * 32 + li;
+    if (kk < p.K) {
 #pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
-        const int kk = k0 + wn * 64 + tn * 32 + li;
-        if (kk >= p.K) continue;
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int c = co0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (c < p.Cout) atomicAdd(p.dw + (size_t)c * p.K + kk, acc[tm][tn][r]);
-            }
+        for (int r = 0; r < 16; r++) {
+            const int c = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (c < p.Cout) atomicAdd(p.dw + (size_t)c * p.K + kk, acc[r]);
         }
     }
+}
+
+// q = (mulhi(x, magic) + x) >> shift == x / d for every x < 2^32 (Granlund-Montgomery, round-up
+// variant with the implicit 2^32 term)
+void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
+    unsigned l = 0;
+    while ((1ull << l) < d) l++;
+    *magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *shift = l;
 }
 
 }  // namespace
@@ -178,6 +182,8 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
         p.seg_H[s] = H; p.seg_W[s] = W; p.seg_Ho[s] = Ho; p.seg_Wo[s] = Wo;
         p.seg_m0[s] = (int)m_total;
         p.seg_xoff[s] = x_off;
+        magic_for((unsigned)(Ho * Wo), &p.seg_mhw[s], &p.seg_shw[s]);
+        magic_for((unsigned)Wo, &p.seg_mw[s], &p.seg_sw[s]);
         m_total += (long long)batch * Ho * Wo;
         x_off += (long long)batch * H * W * cin;
     }
@@ -189,9 +195,9 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
     p.x_bytes = (unsigned)(x_off * 4);
     p.tiles_co = (cout + TC - 1) / TC;
     p.tiles_k = (p.K + TC - 1) / TC;
-    // enough slices of M to fill the chip ~4x over, each at least 256 rows deep
+    // enough slices of M to fill the chip ~8x over, each at least 256 rows deep
     const int tiles = p.tiles_co * p.tiles_k;
-    int slices = (2048 + tiles - 1) / tiles;
+    int slices = (8192 + tiles - 1) / tiles;
     const int max_slices = (p.M + 255) / 256;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
