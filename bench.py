@@ -127,6 +127,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="arithmetic type of the conv stack at inference: 'f32' (BASELINE configs[1], the "
+                         "parity path, default) or 'bf16' (bf16 MFMA, fp32 accumulate; proposal stage, "
+                         'heads outputs and NMS stay fp32)')
     ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
                     help="'train' times the full train step (BASELINE configs[2]/[3]): forward_train, "
                          'backward through the HIP dgrad/wgrad kernels, gradient all-reduce (DDP over '
@@ -145,6 +149,7 @@ def main():
     if args.mode == 'train':
         return train_bench(args, world, rank, device)
     model, cfg = build_model(device)
+    model.set_compute_dtype(args.dtype)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
 
     def step():
@@ -173,7 +178,7 @@ def main():
 
     # ---- roofline of the dominant kernel: the conv stack, timed live with HIP events --------
     from brcnn import profiling
-    roof = profiling.conv_stack_roofline(model, img, metas, iters=3)
+    roof = profiling.conv_stack_roofline(model, img, metas, iters=3, dtype=args.dtype)
 
     line = {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN inference',
@@ -182,9 +187,9 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1000.0 * dt / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'boosting_rcnn_r50_pafpn_1x_utdac.py inference (simple_test, rescale), '
-                               f'batch {args.batch} x 3x800x1344 per GPU, fp32 MFMA conv stack, '
+                               f'batch {args.batch} x 3x800x1344 per GPU, {args.dtype} MFMA conv stack, '
                                '1000 pre-NMS / 256 proposals per image, seeded synthetic weights',
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         'roofline': roof,

@@ -166,7 +166,8 @@ class ResNet(nn.Module):
         def builder():
             from .blocks import fold_bn
             scale, shift = fold_bn(self.bn1)
-            return ops.pack_stem_weight(self.conv1.weight), scale, shift
+            from .blocks import compute_dtype
+            return ops.pack_stem_weight(self.conv1.weight, compute_dtype()), scale, shift
         w, scale, shift = self._stem_cache2.get(
             [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var],
             builder)

@@ -18,6 +18,23 @@ import torch.nn as nn
 from . import ops
 
 
+# Arithmetic type of the conv stack at inference: torch.float32 (exact-fp32 MFMA, the parity
+# path and the default) or torch.bfloat16 (bf16 MFMA, fp32 accumulate).  Process-wide; set
+# through `TwoStageDetector.set_compute_dtype`.  Training always runs fp32.
+_COMPUTE_DTYPE = torch.float32
+
+
+def set_compute_dtype(dtype):
+    global _COMPUTE_DTYPE
+    dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}.get(dtype, dtype)
+    assert dtype in (torch.float32, torch.bfloat16)
+    _COMPUTE_DTYPE = dtype
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
 def to_nchw_view(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2)
 
@@ -40,7 +57,8 @@ class PackedCache:
         self.val = None
 
     def get(self, sources, builder):
-        key = tuple((s.data_ptr(), s._version, s.device) for s in sources if s is not None)
+        key = tuple((s.data_ptr(), s._version, s.device) for s in sources if s is not None) + \
+            (_COMPUTE_DTYPE,)
         if key != self.key:
             with torch.no_grad():
                 self.val = builder()
@@ -100,7 +118,7 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
                                        if bn is not None else [])
 
     def builder():
-        w = pack_weight(conv.weight)
+        w = pack_weight(conv.weight).to(x.dtype)
         if bn is not None:
             scale, shift = fold_bn(bn)
             if conv.bias is not None:

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libbrcnn_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['roi_align.hip', 'nms.hip', 'soft_nms.hip', 'focal_loss.hip', 'conv_igemm.hip', 'conv_wgrad.hip',
+SOURCES = ['roi_align.hip', 'nms.hip', 'soft_nms.hip', 'focal_loss.hip', 'conv_igemm.hip', 'conv_igemm_bf16.hip', 'conv_wgrad.hip',
            'misc.hip', 'rpn.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-fvisibility=hidden', '-Wno-unused-result',

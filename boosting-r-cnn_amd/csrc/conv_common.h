@@ -1,0 +1,51 @@
+// Shared declarations of the implicit-GEMM convolution kernels (fp32: conv_igemm.hip,
+// bf16: conv_igemm_bf16.hip).
+#pragma once
+#include "common.h"
+
+namespace brcnn_conv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// any byte offset >= the buffer extent makes a raw buffer load return zeros: the zero padding
+// of the convolution and the M / Cout tails cost no branch and no select
+constexpr int OOB = 0x7fffffff;
+
+constexpr int BK = 32, LDS_STRIDE = 36;
+
+struct ConvParams {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    int batch, Cin, Cout, KH, KW, stride, pad;
+    int M, K;
+    int relu;
+    int tiles_m, tiles_n;
+    int pitch;                       // floats between adjacent input pixels (== Cin normally)
+    unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
+    int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
+    int out_f32;                     // bf16 compute path: write the result as fp32 (head outputs)
+    // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
+    int nseg;
+    int seg_m0[BRCNN_MAX_LEVELS + 1];
+    int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
+    long long seg_xoff[BRCNN_MAX_LEVELS];   // element offset of the segment's input in x
+};
+
+__device__ __forceinline__ static int xcd_remap(int bid, int nwg) {
+    // bijective: XCD x (= bid % 8) owns a contiguous chunk of logical tile ids
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+
+// bf16 dispatch (conv_igemm_bf16.hip)
+int dispatch_conv_bf16(ConvParams& p, hipStream_t s);
+
+}  // namespace brcnn_conv

@@ -30,47 +30,10 @@
 // contiguous run of tiles (the N tiles of one M tile share the gathered A rows).
 // Several feature maps that share one set of weights (pyramid levels) run as ONE launch: the
 // output rows of the segments are concatenated and each row carries its own geometry.
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// any byte offset >= the buffer extent makes a raw buffer load return zeros: the zero padding
-// of the convolution and the M / Cout tails cost no branch and no select
-constexpr int OOB = 0x7fffffff;
-
-constexpr int BK = 32, LDS_STRIDE = 36;
-
-struct ConvParams {
-    const float* x;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* residual;
-    float* y;
-    int batch, Cin, Cout, KH, KW, stride, pad;
-    int M, K;
-    int relu;
-    int tiles_m, tiles_n;
-    int pitch;                       // floats between adjacent input pixels (== Cin normally)
-    unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
-    int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
-    // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
-    int nseg;
-    int seg_m0[BRCNN_MAX_LEVELS + 1];
-    int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
-    long long seg_xoff[BRCNN_MAX_LEVELS];   // element offset of the segment's input in x
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // bijective: XCD x (= bid % 8) owns a contiguous chunk of logical tile ids
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + loc;
-}
+using namespace brcnn_conv;
 
 // FAST: Cin % 32 == 0 (a K tile never straddles a filter tap).  RES: residual operand present.
 template <bool FAST, int WM, int NT, bool RES>
@@ -602,7 +565,10 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
         pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
         !heights_host || !widths_host)
         return BRCNN_EINVAL;
-    if (dtype != BRCNN_DT_F32) return BRCNN_EINVAL;
+    const int esize = (dtype == BRCNN_DT_F32) ? 4 : 2;
+    const bool bf16 = (dtype == BRCNN_DT_BF16 || dtype == BRCNN_DT_BF16_OUT_F32);
+    if (dtype != BRCNN_DT_F32 && !bf16) return BRCNN_EINVAL;
+    if (bf16 && cin % 64 != 0) return BRCNN_EINVAL;
     if (dilate > 1 && (cin % 32 != 0 || stride != 1)) return BRCNN_EINVAL;
     ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
@@ -625,12 +591,14 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
         if (m_total > 0x7fffffffLL) return BRCNN_EINVAL;
     }
     for (int sgi = num_segments; sgi <= BRCNN_MAX_LEVELS; sgi++) p.seg_m0[sgi] = (int)m_total;
-    if (x_off * 4 >= 0x7fffffffLL || (long long)cout * kh * kw * cin * 4 >= 0x7fffffffLL) return BRCNN_EINVAL;
-    p.x_bytes = (unsigned)(x_off * 4);
-    p.w_bytes = (unsigned)((long long)cout * kh * kw * cin * 4);
+    if (x_off * esize >= 0x7fffffffLL || (long long)cout * kh * kw * cin * esize >= 0x7fffffffLL) return BRCNN_EINVAL;
+    p.x_bytes = (unsigned)(x_off * esize);
+    p.w_bytes = (unsigned)((long long)cout * kh * kw * cin * esize);
+    p.out_f32 = (dtype == BRCNN_DT_BF16_OUT_F32);
     p.M = (int)m_total;
     p.K = kh * kw * cin;
     p.relu = relu;
+    if (bf16) return dispatch_conv_bf16(p, (hipStream_t)stream);
     return dispatch_conv(p, (hipStream_t)stream);
 }
 
@@ -668,9 +636,13 @@ BRCNN_API int brcnn_conv2d_dgrad_nhwc_multi(const void* dy, const void* w_t, voi
 // input pixels are 4 floats apart (pitch 4) -- no per-element gather, no bounds tests.
 // Weights arrive packed as (Cout, 7, 1, 32) with zeros at tap 7 / channel 3.
 namespace {
+// EXTRA = zero pixels appended to each row beyond the 3+3 border (so that the last window's
+// full 32-float / 64-bf16 K row stays inside the row); bf16 variant packs 4 x bf16 per pixel.
+template <bool BF16>
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ img,
-                                                       float* __restrict__ out, int N, int H, int W) {
-    const int Hp = H + 6, Wp = W + 6;
+                                                       void* __restrict__ out, int N, int H, int W,
+                                                       int Wp) {
+    const int Hp = H + 6;
     const long long total = (long long)N * Hp * Wp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -683,30 +655,41 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
             const size_t b = ((size_t)n * 3 * H + h) * W + w;
             v.x = img[b]; v.y = img[b + (size_t)H * W]; v.z = img[b + 2 * (size_t)H * W];
         }
-        *reinterpret_cast<float4*>(out + (size_t)i * 4) = v;
+        if (BF16) {
+            auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
+            uint2 u;
+            u.x = bf(v.x) | (bf(v.y) << 16);
+            u.y = bf(v.z);
+            reinterpret_cast<uint2*>(out)[i] = u;
+        } else {
+            reinterpret_cast<float4*>(out)[i] = v;
+        }
     }
 }
 }  // namespace
 
 BRCNN_API size_t brcnn_stem_workspace_bytes(int batch, int height, int width) {
-    return (size_t)batch * (height + 6) * (width + 6) * 4 * sizeof(float) + 256;
+    return (size_t)batch * (height + 6) * (width + 14) * 4 * sizeof(float) + 256;
 }
 
-BRCNN_API int brcnn_stem7x7s2_nchw(const float* img, const float* w_packed, const float* scale,
-                                   const float* shift, float* y, void* workspace, int batch,
-                                   int height, int width, int cout, int relu, void* stream) {
-    if (!img || !w_packed || !y || !workspace || batch <= 0 || height < 7 || width < 7 || cout <= 0)
+BRCNN_API int brcnn_stem7x7s2_nchw(const float* img, const void* w_packed, const float* scale,
+                                   const float* shift, void* y, void* workspace, int batch,
+                                   int height, int width, int cout, int relu, int dtype, void* stream) {
+    if (!img || !w_packed || !y || !workspace || batch <= 0 || height < 7 || width < 7 || cout <= 0 ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int Hp = height + 6, Wp = width + 6;
+    const bool bf = dtype == BRCNN_DT_BF16;
+    const int kelems = bf ? 64 : 32;                 // K row = 128 bytes of 4-element pixels
+    const int Hp = height + 6, Wp = width + 6 + (kelems / 4 - 8);
     const long long total = (long long)batch * Hp * Wp;
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(stem_pack_kernel, dim3((int)g), dim3(256), 0, s, img, (float*)workspace, batch,
-                       height, width);
+    if (bf) hipLaunchKernelGGL(stem_pack_kernel<true>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
+    else hipLaunchKernelGGL(stem_pack_kernel<false>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
     BRCNN_LAUNCH_CHECK();
     const int Ho = (height + 6 - 7) / 2 + 1, Wo = (width + 6 - 7) / 2 + 1;
     const int hs[1] = {Hp}, ws[1] = {Wp}, ohs[1] = {Ho}, ows[1] = {Wo};
     return conv_setup_and_launch(workspace, w_packed, scale, shift, nullptr, y, batch, 1, hs, ws, ohs,
-                                 ows, 32, cout, 7, 1, 2, 0, 1, relu, BRCNN_DT_F32, stream, 4);
+                                 ows, kelems, cout, 7, 1, 2, 0, 1, relu, dtype, stream, 4);
 }

@@ -7,8 +7,30 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x,
-                                                          float* __restrict__ y, int N, int H,
+// element types of the NHWC activations: fp32 or bf16 (stored as unsigned short)
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = f2bf(v.x) | (f2bf(v.y) << 16);
+    u.y = f2bf(v.z) | (f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x,
+                                                          T* __restrict__ y, int N, int H,
                                                           int W, int C, int Ho, int Wo) {
     const int c4n = C >> 2;
     const long long total = (long long)N * Ho * Wo * c4n;
@@ -26,13 +48,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
             for (int kw = 0; kw < 3; kw++) {
                 const int wi = wo * 2 - 1 + kw;
                 if (wi < 0 || wi >= W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(
-                    x + (((size_t)n * H + hi) * W + wi) * C + c4 * 4);
+                const float4 v = ld4(x + (((size_t)n * H + hi) * W + wi) * C + c4 * 4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
                 m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(y + (size_t)idx * 4) = m;
+        st4(y + (size_t)idx * 4, m);
     }
 }
 
@@ -48,7 +69,8 @@ struct GnSegs {
 // float4 rows (16 loads in flight per thread), partial sums are folded to double every 32 rows,
 // the 4 row lanes are combined through LDS and one double atomic pair per (group) leaves the
 // workgroup.  C <= 256, C % 4 == 0, (C/G) % 4 == 0 or 4 % (C/G) == 0 handled generally below.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x,
                                                       double* __restrict__ stats, GnSegs sg, int N,
                                                       int C, int G, int rows_per_block) {
     __shared__ double red[4][256][2];     // [row lane][channel][sum, sumsq]
@@ -57,7 +79,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     const int row0 = blockIdx.x * rows_per_block;
     if (row0 >= HW) return;
     const int row1 = min(HW, row0 + rows_per_block);
-    const float* xs = x + (size_t)(sg.row0[seg] + (long long)n * HW) * C;
+    const T* xs = x + (size_t)(sg.row0[seg] + (long long)n * HW) * C;
     const int c4n = C >> 2;
     const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
     for (int q0 = q; q0 < c4n; q0 += 64) {
@@ -68,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
             for (int i = 0; i < 32; i++) {
                 const int r = rb + 4 * i;
                 if (r < row1) {
-                    const float4 v = *reinterpret_cast<const float4*>(xs + (size_t)r * C + q0 * 4);
+                    const float4 v = ld4(xs + (size_t)r * C + q0 * 4);
                     s[0] += v.x; ss[0] += v.x * v.x; s[1] += v.y; ss[1] += v.y * v.y;
                     s[2] += v.z; ss[2] += v.z * v.z; s[3] += v.w; ss[3] += v.w * v.w;
                 }
@@ -94,11 +116,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x,
                                                       const double* __restrict__ stats,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
-                                                      float* __restrict__ y, GnSegs sg, int N, int C,
+                                                      T* __restrict__ y, GnSegs sg, int N, int C,
                                                       int G, float eps, int relu) {
     const int c4n = C >> 2, cpg = C / G;
     const long long total = sg.row0[sg.nseg] * c4n;
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const int n = (int)((row - sg.row0[seg]) / HW);
         const double inv_cnt = 1.0 / ((double)HW * cpg);
         const size_t sbase = ((size_t)(seg * N + n)) * G;
-        float4 v = *reinterpret_cast<const float4*>(x + (size_t)idx * 4);
+        float4 v = ld4(x + (size_t)idx * 4);
         float in[4] = {v.x, v.y, v.z, v.w}, out[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -127,12 +150,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             if (relu) o = fmaxf(o, 0.f);
             out[e] = o;
         }
-        *reinterpret_cast<float4*>(y + (size_t)idx * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        st4(y + (size_t)idx * 4, make_float4(out[0], out[1], out[2], out[3]));
     }
 }
 
-__global__ __launch_bounds__(256) void upsample_add_kernel(float* __restrict__ dst,
-                                                          const float* __restrict__ src, int N,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_kernel(T* __restrict__ dst,
+                                                          const T* __restrict__ src, int N,
                                                           int Hd, int Wd, int Hs, int Ws, int C) {
     const int c4n = C >> 2;
     const long long total = (long long)N * Hd * Wd * c4n;
@@ -146,11 +170,10 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(float* __restrict__ d
         const int n = (int)(r / Hd);
         const int hs = min((int)floorf(hd * sh), Hs - 1);
         const int ws = min((int)floorf(wd * sw), Ws - 1);
-        const float4 s = *reinterpret_cast<const float4*>(
-            src + (((size_t)n * Hs + hs) * Ws + ws) * C + c4 * 4);
-        float4 d = *reinterpret_cast<float4*>(dst + (size_t)idx * 4);
+        const float4 s = ld4(src + (((size_t)n * Hs + hs) * Ws + ws) * C + c4 * 4);
+        float4 d = ld4(dst + (size_t)idx * 4);
         d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-        *reinterpret_cast<float4*>(dst + (size_t)idx * 4) = d;
+        st4(dst + (size_t)idx * 4, d);
     }
 }
 
@@ -195,13 +218,18 @@ BRCNN_API int brcnn_device_count(void) {
 BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int height, int width,
                                       int channels, int dtype, void* stream) {
     if (!x || !y || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
-        dtype != BRCNN_DT_F32)
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
     const int Ho = (height + 2 - 3) / 2 + 1, Wo = (width + 2 - 3) / 2 + 1;
     const long long total = (long long)batch * Ho * Wo * (channels >> 2);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(stream_grid(total)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)x, (float*)y, batch, height, width,
-                       channels, Ho, Wo);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, (const float*)x, (float*)y, batch, height, width,
+                           channels, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, batch, height, width,
+                           channels, Ho, Wo);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -212,7 +240,7 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
                                          int relu, int dtype, void* stream) {
     if (!x || !y || !gamma || !beta || !stats_ws || batch <= 0 || num_segments <= 0 ||
         num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || channels > 256 || groups <= 0 ||
-        channels % groups || (channels & 3) || dtype != BRCNN_DT_F32)
+        channels % groups || (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
     GnSegs sg = {};
     sg.nseg = num_segments;
@@ -233,13 +261,22 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
     if (chunks > 512) chunks = 512;
     const int rpb = (max_hw + chunks - 1) / chunks;
     chunks = (max_hw + rpb - 1) / rpb;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, batch * num_segments), dim3(256), 0, s,
-                       (const float*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
-    BRCNN_LAUNCH_CHECK();
     const long long total = rows * (channels >> 2);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
-                       (const double*)stats_ws, gamma, beta, (float*)y, sg, batch, channels, groups,
-                       eps, relu);
+    if (dtype == BRCNN_DT_F32) {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+                           (const float*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
+        BRCNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s,
+                           (const float*)x, (const double*)stats_ws, gamma, beta, (float*)y, sg, batch,
+                           channels, groups, eps, relu);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+                           (const bf16_t*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
+        BRCNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s,
+                           (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y, sg, batch,
+                           channels, groups, eps, relu);
+    }
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -256,12 +293,17 @@ BRCNN_API int brcnn_upsample_nearest_add_nhwc(void* dst, const void* src, int ba
                                               int hs, int ws, int channels, int dtype,
                                               void* stream) {
     if (!dst || !src || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 ||
-        (channels & 3) || dtype != BRCNN_DT_F32)
+        (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
     const long long total = (long long)batch * hd * wd * (channels >> 2);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(stream_grid(total)), dim3(256), 0,
-                       (hipStream_t)stream, (float*)dst, (const float*)src, batch, hd, wd, hs, ws,
-                       channels);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, (float*)dst, (const float*)src, batch, hd, wd, hs, ws,
+                           channels);
+    else
+        hipLaunchKernelGGL(upsample_add_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, batch, hd, wd, hs, ws,
+                           channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

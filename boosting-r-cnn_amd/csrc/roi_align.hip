@@ -16,6 +16,27 @@
 
 namespace {
 
+// NHWC element types: fp32 or bf16 (as unsigned short), 4 channels per lane
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = f2bf(v.x) | (f2bf(v.y) << 16);
+    u.y = f2bf(v.z) | (f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
 struct RoiGeom {
     float start_h, start_w, bin_h, bin_w;
     int gh, gw;
@@ -109,10 +130,10 @@ __device__ __forceinline__ int map_roi_level(const float* __restrict__ roi, floa
 // ---------------------------------------------------------------------------------------
 // NHWC forward: one wave per (roi, ph, pw) bin; lane owns channels [4*lane + 256*j, +4).
 // ---------------------------------------------------------------------------------------
-template <bool MULTI>
+template <bool MULTI, typename T = float>
 __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
-    const float* __restrict__ input, LevelTable lv, const float* __restrict__ rois,
-    float* __restrict__ output, int32_t* __restrict__ levels_out, int channels, int height,
+    const T* __restrict__ input, LevelTable lv, const float* __restrict__ rois,
+    T* __restrict__ output, int32_t* __restrict__ levels_out, int channels, int height,
     int width, int n_rois, int ph_n, int pw_n, float spatial_scale, int sampling_ratio,
     int aligned) {
     const int lane = threadIdx.x & 63;
@@ -125,18 +146,18 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
     const int ph = r / pw_n, pw = r - ph * pw_n;
     const float* roi = rois + (size_t)k * 5;
 
-    const float* feat = input;
+    const T* feat = input;
     if (MULTI) {
         int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
-        feat = lv.feat[l];
+        feat = reinterpret_cast<const T*>(lv.feat[l]);
         height = lv.height[l];
         width = lv.width[l];
         spatial_scale = lv.scale[l];
         if (levels_out && r == 0 && lane == 0) levels_out[k] = l;
     }
     const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
-    const float* base = feat + (size_t)g.batch * height * width * channels;
-    float* out = output + (size_t)bin * channels;
+    const T* base = feat + (size_t)g.batch * height * width * channels;
+    T* out = output + (size_t)bin * channels;
 
     for (int c0 = lane * 4; c0 < channels; c0 += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -146,10 +167,10 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
                 const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
                 const Tap t = bilinear_tap(y, x, height, width);
                 if (!t.valid) continue;   // contributes exactly +0.f in the reference
-                const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)t.p1 * channels + c0);
-                const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)t.p2 * channels + c0);
-                const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)t.p3 * channels + c0);
-                const float4 v4 = *reinterpret_cast<const float4*>(base + (size_t)t.p4 * channels + c0);
+                const float4 v1 = ld4(base + (size_t)t.p1 * channels + c0);
+                const float4 v2 = ld4(base + (size_t)t.p2 * channels + c0);
+                const float4 v3 = ld4(base + (size_t)t.p3 * channels + c0);
+                const float4 v4 = ld4(base + (size_t)t.p4 * channels + c0);
                 acc.x += t.w1 * v1.x + t.w2 * v2.x + t.w3 * v3.x + t.w4 * v4.x;
                 acc.y += t.w1 * v1.y + t.w2 * v2.y + t.w3 * v3.y + t.w4 * v4.y;
                 acc.z += t.w1 * v1.z + t.w2 * v2.z + t.w3 * v3.z + t.w4 * v4.z;
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
             }
         }
         acc.x /= g.count; acc.y /= g.count; acc.z /= g.count; acc.w /= g.count;
-        *reinterpret_cast<float4*>(out + c0) = acc;
+        st4(out + c0, acc);
     }
 }
 
@@ -294,7 +315,7 @@ BRCNN_API int brcnn_roi_align_forward(const float* input, const float* rois, flo
         if (pool_mode != 1 || (channels & 3)) return BRCNN_EINVAL;
         LevelTable lv = {};
         const long long bins = (long long)n_rois * pooled_h * pooled_w;
-        hipLaunchKernelGGL(roi_align_fwd_nhwc_kernel<false>, dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+        hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<false, float>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
                            s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
                            n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
     } else if (layout == BRCNN_LAYOUT_NCHW) {
@@ -358,23 +379,29 @@ static int fill_levels(LevelTable& lv, const float* const* feats, float* const* 
     return 0;
 }
 
-BRCNN_API int brcnn_roi_extract_forward(const float* const* feats_host, const int* heights_host,
+BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int* heights_host,
                                         const int* widths_host, const float* scales_host,
-                                        int num_levels, const float* rois, float* output,
+                                        int num_levels, const float* rois, void* output,
                                         int32_t* levels_out, int batch, int channels, int n_rois,
                                         int pooled_h, int pooled_w, int sampling_ratio,
-                                        float finest_scale, void* stream) {
+                                        float finest_scale, int dtype, void* stream) {
+    if (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) return BRCNN_EINVAL;
     if (!feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
         return BRCNN_EINVAL;
     LevelTable lv = {};
-    if (fill_levels(lv, feats_host, nullptr, heights_host, widths_host, scales_host, num_levels,
-                    finest_scale))
+    if (fill_levels(lv, (const float* const*)feats_host, nullptr, heights_host, widths_host, scales_host,
+                    num_levels, finest_scale))
         return BRCNN_EINVAL;
     if (n_rois == 0) return 0;
     if (!rois || !output) return BRCNN_EINVAL;
     const long long bins = (long long)n_rois * pooled_h * pooled_w;
-    hipLaunchKernelGGL(roi_align_fwd_nhwc_kernel<true>, dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)nullptr, lv, rois, output, levels_out,
+    if (dtype == BRCNN_DT_BF16)
+        hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, bf16_t>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                           (hipStream_t)stream, (const bf16_t*)nullptr, lv, rois, (bf16_t*)output, levels_out,
+                           channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    else
+    hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, float>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)nullptr, lv, rois, (float*)output, levels_out,
                        channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
     BRCNN_LAUNCH_CHECK();
     return 0;

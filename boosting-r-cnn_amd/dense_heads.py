@@ -220,7 +220,8 @@ class ATSSRPNHead(AnchorHead):
         x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
         for i, conv in enumerate(self.rpn_convs):
             assert isinstance(conv.norm, nn.GroupNorm) and conv.conv.bias is None
-            w = self._tower_caches[i].get([conv.conv.weight], lambda c=conv: pack_weight(c.conv.weight))
+            w = self._tower_caches[i].get([conv.conv.weight],
+                                          lambda c=conv: pack_weight(c.conv.weight).to(x.dtype))
             x, _ = ops.conv2d_nhwc_multi(x, w, B, sizes, None, None, None, False, 1, 1)
             x = ops.groupnorm_nhwc_multi(x, conv.norm.weight.detach(), conv.norm.bias.detach(),
                                          conv.norm.num_groups, B, sizes, conv.norm.eps,
@@ -228,10 +229,11 @@ class ATSSRPNHead(AnchorHead):
         heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
 
         def builder():
-            return (torch.cat([pack_weight(h.weight) for h in heads], 0).contiguous(),
+            return (torch.cat([pack_weight(h.weight) for h in heads], 0).to(x.dtype).contiguous(),
                     torch.cat([h.bias.detach().float() for h in heads], 0).contiguous())
         w, b = self._fused_head_cache.get([t for h in heads for t in (h.weight, h.bias)], builder)
-        y, _ = ops.conv2d_nhwc_multi(x, w, B, sizes, None, b, None, False, 1, 1)
+        # fp32 result in either mode: the proposal stage scores / decodes in fp32
+        y, _ = ops.conv2d_nhwc_multi(x, w, B, sizes, None, b, None, False, 1, 1, out_f32=True)
         outs, r0 = [], 0
         for (h, wd) in sizes:
             n = B * h * wd

@@ -117,6 +117,13 @@ class TwoStageDetector(BaseDetector):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self._rpn_scale_cache = None    # host copy of rpn_head.scales (freeze_for_inference)
 
+    def set_compute_dtype(self, dtype):
+        """'f32' (default: exact-fp32 MFMA, the parity path) or 'bf16' (bf16 MFMA conv stack with
+        fp32 accumulation; heads, proposal stage and NMS stay fp32).  Inference only."""
+        from . import blocks
+        blocks.set_compute_dtype(dtype)
+        return self
+
     def freeze_for_inference(self):
         """read the (tiny) host-side constants once so that `simple_test_device` issues no
         device->host copies: the five learnable rpn_reg scales."""

@@ -21,7 +21,7 @@ SIGNATURES = {
     'brcnn_roi_align_forward': (c_int, [c_ptr] * 5 + [c_int] * 7 + [c_f32] + [c_int] * 4 + [c_ptr]),
     'brcnn_roi_align_backward': (c_int, [c_ptr] * 3 + [c_int] * 7 + [c_f32] + [c_int] * 3 + [c_ptr]),
     'brcnn_roi_extract_forward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
-                                  [c_f32, c_ptr]),
+                                  [c_f32, c_int, c_ptr]),
     'brcnn_roi_extract_backward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 +
                                    [c_f32, c_ptr]),
     'brcnn_nms_workspace_bytes': (c_size, [c_i64, c_int, c_i64]),
@@ -41,7 +41,8 @@ SIGNATURES = {
     'brcnn_conv2d_wgrad_nhwc_multi': (c_int, [c_ptr] * 3 + [c_int, c_int] + [c_ptr] * 2 + [c_int] * 7 +
                                       [c_ptr]),
     'brcnn_stem_workspace_bytes': (c_size, [c_int, c_int, c_int]),
-    'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 5 + [c_ptr]),
+    'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 6 + [c_ptr]),
+    'brcnn_conv_set_tile_bf16': (c_int, [c_int]),
     'brcnn_maxpool3x3s2_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 5 + [c_ptr]),
     'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
     'brcnn_groupnorm_nhwc_multi': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_int, c_int, c_f32,

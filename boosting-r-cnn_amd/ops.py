@@ -19,7 +19,16 @@ from torch.autograd.function import once_differentiable
 from . import lib as _L
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_BF16_OUT_F32 = 0, 1, 2
+
+
+def _dt(t):
+    """C-ABI dtype code of an activation tensor (fp32, or bf16 for the bf16 MFMA path)"""
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise _L.BrcnnHipError(f'unsupported activation dtype {t.dtype} (fp32 or bf16)')
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -159,17 +168,18 @@ def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56,
     ph, pw = _pair(output_size)
     rois = rois.contiguous().float()
     k = rois.size(0)
-    out = torch.empty((k, ph, pw, c), dtype=torch.float32, device=rois.device)
+    dt = _dt(feats_nhwc[0])
+    out = torch.empty((k, ph, pw, c), dtype=feats_nhwc[0].dtype, device=rois.device)
     levels = torch.empty((k,), dtype=torch.int32, device=rois.device)
     for f in feats_nhwc:
-        assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[0] == n and f.shape[3] == c
+        assert f.is_contiguous() and f.dtype == feats_nhwc[0].dtype and f.shape[0] == n and f.shape[3] == c
     ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats_nhwc])
     hs = (ctypes.c_int * L)(*[f.shape[1] for f in feats_nhwc])
     ws = (ctypes.c_int * L)(*[f.shape[2] for f in feats_nhwc])
     sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
     st = _L.load().brcnn_roi_extract_forward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out),
                                              _ptr(levels), n, c, k, ph, pw, int(sampling_ratio),
-                                             float(finest_scale), _stream())
+                                             float(finest_scale), dt, _stream())
     _L.check(st, 'brcnn_roi_extract_forward')
     return out, levels
 
@@ -409,28 +419,35 @@ def conv_out_size(h, w, kh, kw, stride, pad):
     return (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
 
 
-def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0,
+                out_f32=False):
     """y = act(conv(x, w) * scale + shift + residual); x (N,H,W,Cin), w (Cout,KH,KW,Cin),
-    y (N,Ho,Wo,Cout), all contiguous fp32 on the device."""
+    y (N,Ho,Wo,Cout), contiguous on the device.  fp32 tensors run the fp32 MFMA kernel; bf16
+    x / w / residual (scale, shift stay fp32) run the bf16 kernel with fp32 accumulation and a
+    bf16 result, or an fp32 result with `out_f32`."""
     _require_gpu(x, w, scale, shift, residual)
     assert x.dim() == 4 and w.dim() == 4 and x.is_contiguous() and w.is_contiguous()
-    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    assert x.dtype == w.dtype, f'conv2d_nhwc: x {x.dtype} vs w {w.dtype}'
+    dt = _dt(x)
     n, h, wd, cin = x.shape
     cout, kh, kw, cin2 = w.shape
     assert cin == cin2, f'conv2d_nhwc: Cin mismatch {cin} vs {cin2}'
     ho, wo = conv_out_size(h, wd, kh, kw, stride, pad)
-    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    if dt == DT_BF16 and out_f32:
+        dt = DT_BF16_OUT_F32
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32 if dt != DT_BF16 else torch.bfloat16,
+                    device=x.device)
     if residual is not None:
-        assert residual.shape == y.shape and residual.is_contiguous()
+        assert residual.shape == y.shape and residual.is_contiguous() and residual.dtype == x.dtype
     st = _L.load().brcnn_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual),
                                      _ptr(y), n, h, wd, cin, cout, kh, kw, int(stride), int(pad),
-                                     int(bool(relu)), DT_F32, _stream())
+                                     int(bool(relu)), dt, _stream())
     _L.check(st, 'brcnn_conv2d_nhwc')
     return y
 
 
 def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
-                      stride=1, pad=0):
+                      stride=1, pad=0, out_f32=False):
     """The same conv over several back-to-back segments that share the weights (pyramid
     levels).  x_cat (sum_l batch*H_l*W_l, Cin) rows; `sizes` = [(H_l, W_l)].  Returns
     (y_cat (sum_l batch*Ho_l*Wo_l, Cout), [(Ho_l, Wo_l)])."""
@@ -441,7 +458,12 @@ def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=N
     assert x_cat.shape[1] == cin and x_cat.shape[0] == sum(batch * h * ww for h, ww in sizes)
     out_sizes = [conv_out_size(h, ww, kh, kw, stride, pad) for h, ww in sizes]
     rows = sum(batch * h * ww for h, ww in out_sizes)
-    y = torch.empty((rows, cout), dtype=torch.float32, device=x_cat.device)
+    dt = _dt(x_cat)
+    assert w.dtype == x_cat.dtype
+    if dt == DT_BF16 and out_f32:
+        dt = DT_BF16_OUT_F32
+    y = torch.empty((rows, cout), dtype=torch.float32 if dt != DT_BF16 else torch.bfloat16,
+                    device=x_cat.device)
     if residual is not None:
         assert residual.shape == y.shape and residual.is_contiguous()
     L = len(sizes)
@@ -449,7 +471,7 @@ def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=N
     ws = (ctypes.c_int * L)(*[ww for _, ww in sizes])
     st = _L.load().brcnn_conv2d_nhwc_multi(_ptr(x_cat), _ptr(w), _ptr(scale), _ptr(shift),
                                            _ptr(residual), _ptr(y), batch, L, hs, ws, cin, cout, kh,
-                                           kw, int(stride), int(pad), int(bool(relu)), DT_F32,
+                                           kw, int(stride), int(pad), int(bool(relu)), dt,
                                            _stream())
     _L.check(st, 'brcnn_conv2d_nhwc_multi')
     return y, out_sizes
@@ -467,17 +489,19 @@ def groupnorm_nhwc_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, rel
     hw = (ctypes.c_int * L)(*[h * w for h, w in sizes])
     st = _L.load().brcnn_groupnorm_nhwc_multi(_ptr(x_cat), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(ws),
                                               batch, L, hw, c, int(groups), float(eps),
-                                              int(bool(relu)), DT_F32, _stream())
+                                              int(bool(relu)), _dt(x_cat), _stream())
     _L.check(st, 'brcnn_groupnorm_nhwc_multi')
     return y
 
 
-def pack_stem_weight(w):
-    """(Cout,3,7,7) parameter -> (Cout,7,1,32): [co, kh, 0, kw*4 + c], zeros at kw=7 / c=3"""
+def pack_stem_weight(w, dtype=torch.float32):
+    """(Cout,3,7,7) parameter -> (Cout,7,1,32) fp32 or (Cout,7,1,64) bf16: [co, kh, 0, kw*4 + c],
+    zeros elsewhere (a K row is 128 bytes of 4-element pixels)"""
     cout = w.shape[0]
-    p = torch.zeros((cout, 7, 8, 4), dtype=torch.float32, device=w.device)
+    px = 8 if dtype == torch.float32 else 16
+    p = torch.zeros((cout, 7, px, 4), dtype=torch.float32, device=w.device)
     p[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
-    return p.reshape(cout, 7, 1, 32).contiguous()
+    return p.reshape(cout, 7, 1, px * 4).to(dtype).contiguous()
 
 
 def stem7x7s2_nchw(img, w_packed, scale=None, shift=None, relu=True):
@@ -488,19 +512,20 @@ def stem7x7s2_nchw(img, w_packed, scale=None, shift=None, relu=True):
     img = img.contiguous()
     cout = w_packed.shape[0]
     ho, wo = conv_out_size(h, w, 7, 7, 2, 3)
-    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=img.device)
+    y = torch.empty((n, ho, wo, cout), dtype=w_packed.dtype, device=img.device)
     lib = _L.load()
     ws = _ws(lib.brcnn_stem_workspace_bytes(n, h, w), img.device)
     st = lib.brcnn_stem7x7s2_nchw(_ptr(img), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(y), _ptr(ws),
-                                  n, h, w, cout, int(bool(relu)), _stream())
+                                  n, h, w, cout, int(bool(relu)), _dt(y), _stream())
     _L.check(st, 'brcnn_stem7x7s2_nchw')
     return y
 
 
-def linear_nhwc(x, w, bias=None, relu=False):
+def linear_nhwc(x, w, bias=None, relu=False, out_f32=False):
     """x (M,K) @ w (N,K)^T + bias: the 1x1 case of the implicit GEMM with H=W=1."""
     m, k = x.shape
-    y = conv2d_nhwc(x.reshape(m, 1, 1, k), w.reshape(w.shape[0], 1, 1, k), None, bias, None, relu)
+    y = conv2d_nhwc(x.reshape(m, 1, 1, k), w.reshape(w.shape[0], 1, 1, k), None, bias, None, relu,
+                    out_f32=out_f32)
     return y.reshape(m, w.shape[0])
 
 
@@ -509,7 +534,7 @@ def maxpool3x3s2_nhwc(x):
     n, h, w, c = x.shape
     ho, wo = conv_out_size(h, w, 3, 3, 2, 1)
     y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
-    st = _L.load().brcnn_maxpool3x3s2_nhwc(_ptr(x), _ptr(y), n, h, w, c, DT_F32, _stream())
+    st = _L.load().brcnn_maxpool3x3s2_nhwc(_ptr(x), _ptr(y), n, h, w, c, _dt(x), _stream())
     _L.check(st, 'brcnn_maxpool3x3s2_nhwc')
     return y
 
@@ -520,7 +545,7 @@ def groupnorm_nhwc(x, gamma, beta, groups, eps=1e-5, relu=False):
     y = torch.empty_like(x)
     ws = torch.empty((n * groups * 2,), dtype=torch.float64, device=x.device)
     st = _L.load().brcnn_groupnorm_nhwc(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(ws), n,
-                                        h * w, c, int(groups), float(eps), int(bool(relu)), DT_F32,
+                                        h * w, c, int(groups), float(eps), int(bool(relu)), _dt(x),
                                         _stream())
     _L.check(st, 'brcnn_groupnorm_nhwc')
     return y
@@ -532,7 +557,7 @@ def upsample_nearest_add_nhwc_(dst, src):
     n, hd, wd, c = dst.shape
     _, hs, ws_, _ = src.shape
     st = _L.load().brcnn_upsample_nearest_add_nhwc(_ptr(dst), _ptr(src), n, hd, wd, hs, ws_, c,
-                                                   DT_F32, _stream())
+                                                   _dt(dst), _stream())
     _L.check(st, 'brcnn_upsample_nearest_add_nhwc')
     return dst
 

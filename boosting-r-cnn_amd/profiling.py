@@ -13,6 +13,7 @@ import torch
 from . import ops
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 v_mfma_f32_32x32x16_bf16 (16x the f32 rate)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -20,26 +21,27 @@ HBM_PEAK_GBS = 8000.0
 def record_conv_launches(records):
     orig = ops.conv2d_nhwc
 
-    def wrapped(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+    def wrapped(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, out_f32=False):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        y = orig(x, w, scale, shift, residual, relu, stride, pad)
+        y = orig(x, w, scale, shift, residual, relu, stride, pad, out_f32)
         e.record()
         m = y.shape[0] * y.shape[1] * y.shape[2]
         k = w.shape[1] * w.shape[2] * w.shape[3]
-        nbytes = 4 * (x.numel() + w.numel() + y.numel() + (residual.numel() if residual is not None else 0))
+        nbytes = x.element_size() * (x.numel() + w.numel() + (residual.numel() if residual is not None else 0)) + \
+            y.element_size() * y.numel()
         records.append((s, e, 2.0 * m * k * w.shape[0], nbytes, (m, w.shape[0], k)))
         return y
     orig_multi = ops.conv2d_nhwc_multi
 
     def wrapped_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
-                      stride=1, pad=0):
+                      stride=1, pad=0, out_f32=False):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        y, osz = orig_multi(x_cat, w, batch, sizes, scale, shift, residual, relu, stride, pad)
+        y, osz = orig_multi(x_cat, w, batch, sizes, scale, shift, residual, relu, stride, pad, out_f32)
         e.record()
         k = w.shape[1] * w.shape[2] * w.shape[3]
-        nbytes = 4 * (x_cat.numel() + w.numel() + y.numel())
+        nbytes = x_cat.element_size() * (x_cat.numel() + w.numel()) + y.element_size() * y.numel()
         records.append((s, e, 2.0 * y.shape[0] * k * w.shape[0], nbytes, (y.shape[0], w.shape[0], k)))
         return y, osz
     ops.conv2d_nhwc = wrapped
@@ -51,7 +53,7 @@ def record_conv_launches(records):
         ops.conv2d_nhwc_multi = orig_multi
 
 
-def conv_stack_roofline(model, img, metas, iters=3):
+def conv_stack_roofline(model, img, metas, iters=3, dtype='f32'):
     """returns the `roofline` object of the bench line for the conv/FC stack"""
     best = None
     for _ in range(iters):
@@ -72,13 +74,15 @@ def conv_stack_roofline(model, img, metas, iters=3):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         cands = sorted(f for f in os.listdir(os.path.join(root, 'profiles')) if f.endswith('_conv_traffic.json'))
         t = json.load(open(os.path.join(root, 'profiles', cands[-1])))
-        traffic = t['kernels']['conv_igemm_f32_kernel']['hbm_bytes_per_launch']
+        traffic = t['kernels']['conv_igemm_f32_kernel' if dtype == 'f32' else
+                               'conv_igemm_bf16_dma_kernel']['hbm_bytes_per_launch']
     except Exception:
         pass
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     return {
-        'bound': 'mfma', 'kernel': 'conv_igemm_f32_kernel (all conv/FC launches of one pass)',
-        'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+        'bound': 'mfma', 'kernel': f'conv_igemm_{dtype}*_kernel (all conv/FC launches of one pass)',
+        'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': achieved / peak, 'traffic': traffic,
         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/*_conv_traffic.json)',
         'algorithmic_bytes_per_launch': sum(r[3] for r in recs) / max(len(recs), 1),
         'launches': len(recs), 'avg_launch_us': 1000.0 * ms / max(len(recs), 1),

@@ -173,22 +173,22 @@ class ProbConvFCBBoxHead(nn.Module):
             if i == 0:
                 def builder(fc=fc):   # (out, C*ph*pw) columns -> (ph,pw,C) order
                     w = fc.weight.detach().float().view(-1, c, ph, pw).permute(0, 2, 3, 1)
-                    return w.reshape(fc.out_features, -1).contiguous(), \
+                    return w.reshape(fc.out_features, -1).to(x.dtype).contiguous(), \
                         fc.bias.detach().float().contiguous()
             else:
                 def builder(fc=fc):
-                    return fc.weight.detach().float().contiguous(), \
+                    return fc.weight.detach().float().to(x.dtype).contiguous(), \
                         fc.bias.detach().float().contiguous()
             w, b = self._caches[i].get([fc.weight, fc.bias], builder)
             x = ops.linear_nhwc(x, w, b, True)
 
         def head_builder():   # fc_cls and fc_reg share the input: one GEMM
-            w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0).detach().float().contiguous()
+            w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0).detach().float().to(x.dtype).contiguous()
             b = torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0).detach().float().contiguous()
             return w, b
         w, b = self._caches[-1].get([self.fc_cls.weight, self.fc_cls.bias, self.fc_reg.weight,
                                      self.fc_reg.bias], head_builder)
-        y = ops.linear_nhwc(x, w, b, False)
+        y = ops.linear_nhwc(x, w, b, False, out_f32=True)   # fp32 scores / deltas in either mode
         nc = self.fc_cls.out_features
         return y[:, :nc], y[:, nc:]
 

@@ -31,7 +31,8 @@ extern "C" {
 #define BRCNN_LAYOUT_NHWC 1 /* (N,H,W,C) contiguous == torch.channels_last       */
 
 #define BRCNN_DT_F32 0
-#define BRCNN_DT_BF16 1
+#define BRCNN_DT_BF16 1          /* bf16 operands, fp32 accumulate, bf16 result */
+#define BRCNN_DT_BF16_OUT_F32 2  /* bf16 operands, fp32 accumulate, fp32 result  */
 
 #define BRCNN_MAX_LEVELS 8
 
@@ -69,11 +70,13 @@ int brcnn_roi_align_backward(const float *grad_output, const float *rois, float 
  *   feats[l]  (N,H_l,W_l,C) device pointers (host array of L pointers)
  *   output    (K,ph,pw,C)
  *   levels_out optional (K) int32: the level each RoI was mapped to */
-int brcnn_roi_extract_forward(const float *const *feats_host, const int *heights_host,
+int brcnn_roi_extract_forward(const void *const *feats_host, const int *heights_host,
                               const int *widths_host, const float *scales_host, int num_levels,
-                              const float *rois, float *output, int32_t *levels_out, int batch,
+                              const float *rois, void *output, int32_t *levels_out, int batch,
                               int channels, int n_rois, int pooled_h, int pooled_w,
-                              int sampling_ratio, float finest_scale, void *stream);
+                              int sampling_ratio, float finest_scale,
+                              int dtype /* of feats and output: BRCNN_DT_F32 | BRCNN_DT_BF16 */,
+                              void *stream);
 
 int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights_host,
                                const int *widths_host, const float *scales_host, int num_levels,
@@ -156,6 +159,9 @@ int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const fl
  * benchmarking scripts (tools/conv_bench.py). */
 int brcnn_conv_set_tile(int wm, int nt);
 
+/* Tuning hook of the bf16 kernel: 0 heuristic, 11 / 21 / 22 = 64x64 / 128x64 / 128x128 tile. */
+int brcnn_conv_set_tile_bf16(int mtnt);
+
 /* The same convolution over `num_segments` feature maps that share one set of weights (the
  * RetinaRPN tower and heads run over 5 pyramid levels, atss_rpn_head.py:296-297): x and y hold
  * the segments back to back ((N,H_s,W_s,Cin) then the next), one launch covers all of them. */
@@ -183,13 +189,13 @@ int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int b
                                   int stride, int pad, int dtype, void *stream);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel NCHW image + folded BN +
- * ReLU (resnet.py:599-611,631-636) -> y (N,Ho,Wo,Cout) NHWC.  w_packed (Cout,7,1,32):
- * w_packed[co,kh,0,kw*4+c] = w[co,c,kh,kw] (zeros at kw=7 / c=3).  workspace:
+ * ReLU (resnet.py:599-611,631-636) -> y (N,Ho,Wo,Cout) NHWC.  w_packed (Cout,7,1,32) fp32 or
+ * (Cout,7,1,64) bf16: w_packed[co,kh,0,kw*4+c] = w[co,c,kh,kw] (zeros elsewhere).  workspace:
  * brcnn_stem_workspace_bytes() bytes (zero-bordered NHWC4 repack of the image). */
 size_t brcnn_stem_workspace_bytes(int batch, int height, int width);
-int brcnn_stem7x7s2_nchw(const float *img, const float *w_packed, const float *scale,
-                         const float *shift, float *y, void *workspace, int batch, int height,
-                         int width, int cout, int relu, void *stream);
+int brcnn_stem7x7s2_nchw(const float *img, const void *w_packed, const float *scale,
+                         const float *shift, void *y, void *workspace, int batch, int height,
+                         int width, int cout, int relu, int dtype, void *stream);
 
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,

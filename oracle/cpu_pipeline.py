@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from . import orc
 
 
-def _conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+def _conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, out_f32=False):
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, stride, pad)
     if scale is not None:
         y = y * scale.view(1, -1, 1, 1)
@@ -40,7 +40,7 @@ def _split_rows(x_cat, batch, sizes):
 
 
 def _conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
-                       stride=1, pad=0):
+                       stride=1, pad=0, out_f32=False):
     assert residual is None
     ys = [_conv2d_nhwc(x, w, scale, shift, None, relu, stride, pad) for x in _split_rows(x_cat, batch, sizes)]
     return torch.cat([y.reshape(-1, y.shape[3]) for y in ys], 0), [tuple(y.shape[1:3]) for y in ys]
@@ -51,12 +51,12 @@ def _groupnorm_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, relu=Fa
     return torch.cat([y.reshape(-1, y.shape[3]) for y in ys], 0)
 
 
-def _linear_nhwc(x, w, bias=None, relu=False):
+def _linear_nhwc(x, w, bias=None, relu=False, out_f32=False):
     y = F.linear(x, w, bias)
     return y.relu() if relu else y
 
 
-def _pack_stem_weight(w):
+def _pack_stem_weight(w, dtype=torch.float32):
     return w.detach().float()          # the CPU restatement convolves the NCHW image directly
 
 

@@ -1,0 +1,169 @@
+"""-m gpu: the optional bf16 MFMA inference mode (north_star: "bf16 MFMA backbone").  The bf16
+kernels multiply bf16 operands exactly and accumulate in fp32, so against an fp64 reference fed
+the SAME bf16-rounded operands the only differences are fp32 accumulation order and the final
+round-to-nearest-even to bf16 (relative 2^-9).  Tolerances below say exactly that.  The fp32
+path stays the parity path; bf16 is checked against it at the detector level with the loose
+tolerance bf16 activations warrant."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import brcnn  # noqa: F401
+from brcnn import Config, build_detector, blocks, ops
+from tests import util
+from tests.test_host_cpu import CFG
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+BF = torch.bfloat16
+HALF_ULP = 2.0 ** -8     # bf16 keeps 8 significand bits: round-to-nearest-even moves a value by <= 2^-8 |v|
+
+
+def _rne_close(y, ref, acc_tol=2e-5):
+    """elementwise: |y - ref| <= 2^-8 |ref| (the one rounding to bf16) + fp32 accumulation slack"""
+    mag = max(1.0, ref.abs().max().item())
+    bad = (y - ref).abs() > HALF_ULP * ref.abs() * 1.001 + acc_tol * mag
+    return not bad.any().item()
+
+
+def _bf(x):
+    return x.to(BF).float()
+
+
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, H, W, Cout, k, stride, pad, scale, residual, relu, out_f32)
+    (2, 64, 24, 40, 64, 1, 1, 0, True, False, True, False),
+    (2, 64, 24, 40, 256, 1, 1, 0, True, True, True, False),
+    (1, 128, 30, 31, 128, 3, 1, 1, True, False, True, False),
+    (2, 256, 25, 42, 256, 3, 2, 1, False, False, False, False),
+    (1, 512, 13, 21, 1024, 1, 2, 0, True, False, False, False),
+    (1, 256, 13, 21, 54, 3, 1, 1, False, False, False, True),
+    (300, 256, 7, 7, 130, 7, 1, 0, False, False, True, True),
+])
+def test_conv2d_nhwc_bf16(cfg):
+    n, cin, h, w, cout, k, stride, pad, has_scale, has_res, relu, out_f32 = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = _bf(torch.randn(n, cin, h, w, generator=g))
+    wt = _bf(torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k))
+    scale = torch.rand(cout, generator=g) + 0.5 if has_scale else None
+    shift = torch.randn(cout, generator=g)
+    ho, wo = ops.conv_out_size(h, w, k, k, stride, pad)
+    res = _bf(torch.randn(n, cout, ho, wo, generator=g)) if has_res else None
+    ref = F.conv2d(x.double(), wt.double(), None, stride, pad)
+    if has_scale:
+        ref = ref * scale.double().view(1, -1, 1, 1)
+    ref = ref + shift.double().view(1, -1, 1, 1)
+    if has_res:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.relu()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+    wg = wt.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+    rg = res.permute(0, 2, 3, 1).contiguous().to(DEV, BF) if has_res else None
+    y = ops.conv2d_nhwc(xg, wg, scale.to(DEV) if has_scale else None, shift.to(DEV), rg, relu, stride, pad,
+                        out_f32=out_f32)
+    assert y.dtype == (torch.float32 if out_f32 else BF)
+    y = y.permute(0, 3, 1, 2).cpu().double()
+    if out_f32:
+        assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    else:
+        assert _rne_close(y, ref)
+
+
+def test_small_kernels_bf16():
+    g = torch.Generator().manual_seed(9)
+    x = _bf(torch.randn(2, 64, 33, 47, generator=g))
+    y = ops.maxpool3x3s2_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV, BF))
+    assert y.dtype == BF and torch.equal(y.float().permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 3, 2, 1))
+    # group norm (fp32 statistics of the bf16 tensor) + relu
+    x = _bf(torch.randn(2, 256, 25, 42, generator=g) * 2 + 0.3)
+    gamma, beta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5).relu()
+    y = ops.groupnorm_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV, BF), gamma.to(DEV), beta.to(DEV),
+                           32, 1e-5, True)
+    assert y.dtype == BF
+    y = y.float().permute(0, 3, 1, 2).cpu().double()
+    assert _rne_close(y, ref)
+    # upsample + add: fp32 add of two bf16 values, one RNE
+    for (hd, wd, hs, ws) in [(50, 84, 25, 42), (13, 21, 7, 11)]:
+        d = _bf(torch.randn(2, 256, hd, wd, generator=g))
+        s = _bf(torch.randn(2, 256, hs, ws, generator=g))
+        ref = (d + F.interpolate(s, size=(hd, wd), mode='nearest')).to(BF)
+        dg = d.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+        ops.upsample_nearest_add_nhwc_(dg, s.permute(0, 2, 3, 1).contiguous().to(DEV, BF))
+        assert torch.equal(dg.permute(0, 3, 1, 2).cpu(), ref)
+
+
+def test_multi_level_bf16_matches_per_level():
+    g = torch.Generator().manual_seed(4)
+    sizes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
+    B, C = 2, 256
+    feats = [torch.randn(B, h, w, C, generator=g).to(DEV, BF) for h, w in sizes]
+    wt = (torch.randn(C, 3, 3, C, generator=g) / 48).to(DEV, BF)
+    b = torch.randn(C, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    xc = torch.cat([f.reshape(-1, C) for f in feats], 0)
+    y, osz = ops.conv2d_nhwc_multi(xc, wt, B, sizes, None, b, None, False, 1, 1)
+    yn = ops.groupnorm_nhwc_multi(y, gamma, beta, 32, B, osz, 1e-5, True)
+    o = 0
+    for f, (h, w) in zip(feats, sizes):
+        m = B * h * w
+        r = ops.conv2d_nhwc(f, wt, None, b, None, False, 1, 1)
+        assert torch.equal(y[o:o + m].reshape(B, h, w, C), r)
+        rn = ops.groupnorm_nhwc(r, gamma, beta, 32, 1e-5, True)
+        assert torch.equal(yn[o:o + m].reshape(B, h, w, C), rn)
+        o += m
+
+
+def test_stem_and_roi_extract_bf16():
+    g = torch.Generator().manual_seed(12)
+    for (n, h, w) in [(2, 64, 96), (1, 75, 83)]:
+        img = torch.randn(n, 3, h, w, generator=g)
+        wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        ref = (F.conv2d(_bf(img).double(), _bf(wt).double(), None, 2, 3) * sc.double().view(1, -1, 1, 1) +
+               sh.double().view(1, -1, 1, 1)).relu()
+        y = ops.stem7x7s2_nchw(img.to(DEV), ops.pack_stem_weight(wt.to(DEV), BF), sc.to(DEV), sh.to(DEV), True)
+        assert y.dtype == BF
+        y = y.float().permute(0, 3, 1, 2).cpu().double()
+        assert _rne_close(y, ref)
+    # RoI extract on bf16 maps: fp32 bilinear blend of bf16 samples, one RNE => equals the fp32
+    # kernel run on the same (bf16-representable) maps, rounded once
+    strides = [4, 8, 16, 32]
+    feats = [_bf(torch.randn(2, 200 // s, 304 // s, 256, generator=g)).to(DEV) for s in strides]
+    rois = util.rand_rois(300, 2, 304.0, 200.0, seed=3).to(DEV)
+    o32, l32 = ops.roi_extract(feats, rois, 7, strides, 56, 0)
+    o16, l16 = ops.roi_extract([f.to(BF) for f in feats], rois, 7, strides, 56, 0)
+    assert o16.dtype == BF and torch.equal(l16, l32)
+    assert torch.equal(o16, o32.to(BF))
+
+
+def test_detector_bf16_close_to_fp32():
+    cfg = Config.fromfile(CFG)
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=10))
+    m = m.to(DEV).eval()
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=10)
+    try:
+        with torch.no_grad():
+            f32 = [f.float() for f in m.extract_feat_nhwc(img.to(DEV))]
+            r32 = m.simple_test(img.to(DEV), metas)
+            m.set_compute_dtype('bf16')
+            f16 = m.extract_feat_nhwc(img.to(DEV))
+            assert all(f.dtype == BF for f in f16)
+            r16 = m.simple_test(img.to(DEV), metas)
+    finally:
+        blocks.set_compute_dtype('f32')
+    # pyramid features: ~50 stacked bf16 roundings; a few percent of the map's magnitude
+    for a, b in zip(f16, f32):
+        rel = (a.float() - b).abs().max().item() / b.abs().max().item()
+        assert rel < 0.05, rel
+    # detections: same count scale and most boxes found again within a pixel / 0.05 score
+    n32 = sum(len(c) for r in r32 for c in r)
+    n16 = sum(len(c) for r in r16 for c in r)
+    assert n32 > 0 and abs(n16 - n32) <= 0.2 * n32 + 5, (n16, n32)
+    d = np.concatenate([c for r in r32 for c in r]), np.concatenate([c for r in r16 for c in r])
+    dist = np.abs(d[0][:, None, :4] - d[1][None, :, :4]).max(-1)
+    ds = np.abs(d[0][:, None, 4] - d[1][None, :, 4])
+    assert ((dist < 2.0) & (ds < 0.05)).any(1).mean() > 0.7
