@@ -80,9 +80,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 
 // One 256-thread workgroup per segment.  Wave 0 resolves the greedy chain of the current
 // 64-row chunk (wave-uniform scalar walk over the diagonal mask words) and publishes the
-// survivor bits; then all four waves OR the survivors' mask rows into the LDS-resident
-// `removed` vector, each wave taking every fourth survivor (LDS atomics), so the row fetches of
-// a chunk (up to 64 x `words` x 8 B) are spread over 4x the load slots.
+// survivor bits; then every thread ORs the survivors' words of its own mask columns into the
+// LDS-resident `removed` vector (coalesced across the workgroup, 16 loads in flight per thread).
 __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
                                                          const int32_t* __restrict__ sorted_idx,
                                                          const int32_t* __restrict__ seg_begin,
@@ -128,18 +127,25 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
         __syncthreads();
         count = sh_count;
         if (max_keep > 0 && count >= max_keep) { count = max_keep; break; }
-        unsigned long long k2 = *kept_sh;
-        int j = 0;
-        while (k2) {
-            const int b = __ffsll((long long)k2) - 1;
-            k2 &= k2 - 1;
-            if ((j++ & 3) == wave) {
-                const unsigned long long* mrow = mask + (size_t)(beg + c * 64 + b) * words;
-                for (int w = c + 1 + lane; w < nchunk; w += 64) {
-                    const unsigned long long m = mrow[w];
-                    if (m) atomicOr(&remv[w], m);
+        // every thread owns mask columns w = c+1+tid (+256k): the survivors' words of a column
+        // are independent loads, issued 16 deep (a spent bit set re-reads the last row: OR is
+        // idempotent), OR-ed in registers and folded into `removed` without atomics
+        const unsigned long long k2 = *kept_sh;
+        const unsigned long long* mchunk = mask + (size_t)(beg + c * 64) * words;
+        for (int w = c + 1 + tid; w < nchunk; w += 256) {
+            unsigned long long acc = 0ull, k = k2;
+            int b = 0;
+            while (k) {
+                unsigned long long v[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (k) { b = __ffsll((long long)k) - 1; k &= k - 1; }
+                    v[j] = mchunk[(size_t)b * words + w];
                 }
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc |= v[j];
             }
+            remv[w] |= acc;
         }
         __syncthreads();
     }

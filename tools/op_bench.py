@@ -73,7 +73,7 @@ def main():
                                                       frac_hbm=2 * by / tfb / 1e9 / HBM)
     # NMS: RPN test (8 x 4693), RPN train level segments (8 x 5 x ~3000), R-CNN (8 x 1024)
     for name, lens, keepn in (('rpn_test_8x4693', [4693] * 8, 256), ('rpn_train_40x3030', [3030] * 40, -1),
-                              ('rcnn_8x1024', [1024] * 8, 100)):
+                              ('rcnn_8x1024', [1024] * 8, 100), ('train_image_2x10000', [10000] * 2, 2000)):
         n = sum(lens)
         seg = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
         boxes = util.clustered_boxes(n, n_clusters=60 * len(lens), seed=3).to(DEV)
