@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams 
     constexpr int BG = BN / 8 / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][32 dwords = 128 B]
-    float* Bs = smem + 2 * BM * 32;     // [2][BN][32 dwords]
+    const int nk = p.K / BKE;
+    const int nbuf = nk > 1 ? 2 : 1;    // a single K tile needs no second buffer: more workgroups per CU
+    float* Bs = smem + nbuf * BM * 32;  // [nbuf][BN][32 dwords]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,8 +96,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    const int nk = p.K / BKE;
-
     auto dma_tile = [&](int kt, int buf) {
         const int k0 = kt * BKE;
         const int tap = k0 / p.Cin;
@@ -121,23 +121,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams 
 
     dma_tile(0, 0);
 
-    // residual prefetch (bf16), D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // residual rows (bf16, 16 B = 8 channels of one pixel per lane, the read-out mapping of the
+    // epilogue), issued before the K loop so that their latency hides behind it
+    constexpr int LPR = 4 * NT;                   // lanes per output row (8 channels each)
+    constexpr int RPI = 64 / LPR;                 // rows per read-out iteration
+    const int cw0 = n0 + wn * 32 * NT;            // first channel of this wave
+    const bool vec_ok = (p.Cout & 7) == 0;
+    const int rl = lane / LPR, cl = (lane % LPR) * 8;
     const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(p.residual);
-    float rv[MT][NT][16];
+    uint4 rq[MT][32 / RPI];
     if (RES) {
 #pragma unroll
-        for (int tn = 0; tn < NT; tn++) {
-            const int co = n0 + wn * 32 * NT + tn * 32 + li;
+        for (int tm = 0; tm < MT; tm++)
 #pragma unroll
-            for (int tm = 0; tm < MT; tm++) {
-                const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    rv[tm][tn][r] = (co < p.Cout && m < p.M) ? bf2f(res[(size_t)m * p.Cout + co]) : 0.f;
-                }
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int m = m0 + wm * 32 * MT + tm * 32 + it * RPI + rl, co = cw0 + cl;
+                rq[tm][it] = make_uint4(0, 0, 0, 0);
+                if (vec_ok && m < p.M && co < p.Cout)
+                    rq[tm][it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.Cout + co);
             }
-        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -166,48 +168,113 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams 
             for (int tm = 0; tm < MT; tm++)
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tm], bv[t], acc[tm][t], 0, 0, 0);
+                    acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[t], av[tm], acc[tm][t], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
 
+    // ---- epilogue.  The MFMA ran as D^T = W A^T, so lane l holds pixel m = l&31 and, per
+    // register group g, four consecutive channels co = 8g + 4(l>>5) + (0..3).  Scale/shift are
+    // applied in the accumulators; each wave transposes one 32-row slab at a time through its
+    // private LDS region (pitch 32*NT*4+16 B: ds_write_b128 / ds_read_b128 conflict-free) so
+    // that a lane ends up with 8 consecutive channels of one pixel: the residual is read and
+    // the result written as full 16-byte (bf16) / 32-byte (fp32) pieces of whole NHWC rows.
+    constexpr int PITCH = 32 * NT + 4;            // floats
+    float* cs = smem + wave * 32 * PITCH;
+    float4 scv[NT][4], shv[NT][4];
+#pragma unroll
+    for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int co = cw0 + tn * 32 + 8 * g + 4 * lh;
+            float sc4[4], sh4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = co + e < p.Cout;
+                sc4[e] = (p.scale && ok) ? p.scale[co + e] : 1.f;
+                sh4[e] = (p.shift && ok) ? p.shift[co + e] : 0.f;
+            }
+            scv[tn][g] = make_float4(sc4[0], sc4[1], sc4[2], sc4[3]);
+            shv[tn][g] = make_float4(sh4[0], sh4[1], sh4[2], sh4[3]);
+        }
     unsigned short* __restrict__ yh = reinterpret_cast<unsigned short*>(p.y);
     float* __restrict__ yf = p.y;
 #pragma unroll
-    for (int tn = 0; tn < NT; tn++) {
-        const int co = n0 + wn * 32 * NT + tn * 32 + li;
-        const bool cok = co < p.Cout;
-        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
-        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
+    for (int tm = 0; tm < MT; tm++) {
+        const int mw = m0 + wm * 32 * MT + tm * 32;
 #pragma unroll
-        for (int tm = 0; tm < MT; tm++) {
-            const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
+        for (int tn = 0; tn < NT; tn++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = acc[tm][tn][r];
-                if (p.scale) v = v * sc;
-                v = v + sh;
-                if (RES) v = v + rv[tm][tn][r];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (cok && m < p.M) {
-                    if (OUTF32) yf[(size_t)m * p.Cout + co] = v;
-                    else yh[(size_t)m * p.Cout + co] = f2bf(v);
+            for (int g = 0; g < 4; g++) {
+                float4 v;
+                v.x = acc[tm][tn][4 * g + 0] * scv[tn][g].x + shv[tn][g].x;
+                v.y = acc[tm][tn][4 * g + 1] * scv[tn][g].y + shv[tn][g].y;
+                v.z = acc[tm][tn][4 * g + 2] * scv[tn][g].z + shv[tn][g].z;
+                v.w = acc[tm][tn][4 * g + 3] * scv[tn][g].w + shv[tn][g].w;
+                *reinterpret_cast<float4*>(cs + li * PITCH + tn * 32 + 8 * g + 4 * lh) = v;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the slab is wave-private
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; it++) {
+            const int row = it * RPI + rl;
+            const int m = mw + row, co = cw0 + cl;
+            const float4 lo = *reinterpret_cast<const float4*>(cs + row * PITCH + cl);
+            const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (m >= p.M || co >= p.Cout) continue;
+            if (vec_ok) {
+                if (RES) {
+                    const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[2 * e] += __uint_as_float(rr[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (OUTF32) {
+                    float4* dst = reinterpret_cast<float4*>(yf + (size_t)m * p.Cout + co);
+                    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    uint4 o;
+                    o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                    o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(yh + (size_t)m * p.Cout + co) = o;
+                }
+            } else {       // ragged channel count (fused heads: 54, 21): element-wise tail
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    if (co + e >= p.Cout) break;
+                    float t = v[e];
+                    if (RES) t += bf2f(res[(size_t)m * p.Cout + co + e]);
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (OUTF32) yf[(size_t)m * p.Cout + co + e] = t;
+                    else yh[(size_t)m * p.Cout + co + e] = f2bf(t);
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 template <int MT, int NT, bool RES, bool OUTF32>
 int launch(const ConvParams& p, hipStream_t s) {
-    const size_t lds = (size_t)2 * (64 * MT + 64 * NT) * 32 * sizeof(float);
+    const size_t lds_full = (size_t)2 * (64 * MT + 64 * NT) * 32 * sizeof(float);
+    const size_t lds_epi = (size_t)4 * 32 * (32 * NT + 4) * sizeof(float);
+    const size_t lds = p.K / BKE > 1 ? lds_full : (lds_full / 2 > lds_epi ? lds_full / 2 : lds_epi);
     static bool attr_done = false;
     if (!attr_done) {
         BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32>), dim3(p.tiles_m * p.tiles_n),
