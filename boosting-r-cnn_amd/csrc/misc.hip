@@ -116,41 +116,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x,
     }
 }
 
-template <typename T>
+// pass 2: the (sum, sumsq) doubles of every (segment, n, group) become (mean, rstd) floats in
+// place (first 8 bytes of the 16-byte entry), so that the streaming pass does no fp64 math
+__global__ void gn_finalize_kernel(double* __restrict__ stats, GnSegs sg, int N, int C, int G,
+                                   float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sg.nseg * N * G) return;
+    const int seg = i / (N * G);
+    const double inv_cnt = 1.0 / ((double)sg.hw[seg] * (C / G));
+    const double mean = stats[(size_t)i * 2] * inv_cnt;
+    double var = stats[(size_t)i * 2 + 1] * inv_cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    reinterpret_cast<float2*>(stats + (size_t)i * 2)[0] = make_float2((float)mean, rstd);
+}
+
+// pass 3: y = (x - mean) * rstd * gamma + beta (+ReLU); Q channel quads (16 bytes) per thread
+template <typename T, int Q>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x,
                                                       const double* __restrict__ stats,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
                                                       T* __restrict__ y, GnSegs sg, int N, int C,
-                                                      int G, float eps, int relu) {
-    const int c4n = C >> 2, cpg = C / G;
-    const long long total = sg.row0[sg.nseg] * c4n;
+                                                      int G, int relu) {
+    const int cvn = C / (4 * Q), cpg = C / G;
+    const long long total = sg.row0[sg.nseg] * cvn;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % c4n);
-        const long long row = idx / c4n;
+        const int cv = (int)(idx % cvn);
+        const long long row = idx / cvn;
         int seg = 0;
 #pragma unroll
         for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
             if (t < sg.nseg && row >= sg.row0[t]) seg = t;
-        const int HW = sg.hw[seg];
-        const int n = (int)((row - sg.row0[seg]) / HW);
-        const double inv_cnt = 1.0 / ((double)HW * cpg);
+        const int n = (int)((row - sg.row0[seg]) / sg.hw[seg]);
         const size_t sbase = ((size_t)(seg * N + n)) * G;
-        float4 v = ld4(x + (size_t)idx * 4);
-        float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+        float4 v[Q];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int c = c4 * 4 + e, g = c / cpg;
-            const double mean = stats[(sbase + g) * 2] * inv_cnt;
-            double var = stats[(sbase + g) * 2 + 1] * inv_cnt - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            float o = (in[e] - (float)mean) * rstd * gamma[c] + beta[c];
-            if (relu) o = fmaxf(o, 0.f);
-            out[e] = o;
+        for (int q = 0; q < Q; q++) v[q] = ld4(x + (size_t)idx * 4 * Q + 4 * q);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int c0 = (cv * Q + q) * 4;
+            const float in[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            float out[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int c = c0 + e;
+                const float2 mr = reinterpret_cast<const float2*>(stats + (sbase + c / cpg) * 2)[0];
+                float o = (in[e] - mr.x) * mr.y * gamma[c] + beta[c];
+                if (relu) o = fmaxf(o, 0.f);
+                out[e] = o;
+            }
+            v[q] = make_float4(out[0], out[1], out[2], out[3]);
         }
-        st4(y + (size_t)idx * 4, make_float4(out[0], out[1], out[2], out[3]));
+#pragma unroll
+        for (int q = 0; q < Q; q++) st4(y + (size_t)idx * 4 * Q + 4 * q, v[q]);
     }
 }
 
@@ -262,20 +282,34 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
     const int rpb = (max_hw + chunks - 1) / chunks;
     chunks = (max_hw + rpb - 1) / rpb;
     const long long total = rows * (channels >> 2);
+    const int nstat = num_segments * batch * groups;
     if (dtype == BRCNN_DT_F32) {
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
                            (const float*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
         BRCNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s,
+        BRCNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s,
+                           (double*)stats_ws, sg, batch, channels, groups, eps);
+        BRCNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL((gn_apply_kernel<float, 1>), dim3(stream_grid(total)), dim3(256), 0, s,
                            (const float*)x, (const double*)stats_ws, gamma, beta, (float*)y, sg, batch,
-                           channels, groups, eps, relu);
+                           channels, groups, relu);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
                            (const bf16_t*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
         BRCNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s,
-                           (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y, sg, batch,
-                           channels, groups, eps, relu);
+        BRCNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s,
+                           (double*)stats_ws, sg, batch, channels, groups, eps);
+        BRCNN_LAUNCH_CHECK();
+        if (channels & 7)
+            hipLaunchKernelGGL((gn_apply_kernel<bf16_t, 1>), dim3(stream_grid(total)), dim3(256), 0, s,
+                               (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y, sg,
+                               batch, channels, groups, relu);
+        else
+            hipLaunchKernelGGL((gn_apply_kernel<bf16_t, 2>), dim3(stream_grid(total / 2)), dim3(256), 0,
+                               s, (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y,
+                               sg, batch, channels, groups, relu);
     }
     BRCNN_LAUNCH_CHECK();
     return 0;

@@ -86,6 +86,125 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
     }
 }
 
+
+// ---- per-(image, level) top-k of the proposal scores (atss_rpn_head.py:727-737 sorts the
+// level and keeps nms_pre; the shared tie rule is descending score, ascending index) --------
+// One 1024-thread workgroup per (image, level).  Four 8-bit radix-select passes over the
+// order-preserving key find the k-th key exactly; one more pass collects the k winners as
+// (key << 32 | index) composites -- ties at the threshold are taken in index order -- and a
+// bitonic sort of the <= 4096 composites in LDS puts them in (score desc, index asc) order.
+struct TopkLevels {
+    const float* score[BRCNN_MAX_LEVELS];
+    float* out_score[BRCNN_MAX_LEVELS];
+    int64_t* out_idx[BRCNN_MAX_LEVELS];
+    int n[BRCNN_MAX_LEVELS];
+};
+
+// descending key: larger score <=> smaller key; -0.0 == +0.0
+__device__ __forceinline__ unsigned desc_key(float x) {
+    unsigned u = __float_as_uint(x);
+    if (u == 0x80000000u) u = 0u;
+    const unsigned asc = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    return ~asc;
+}
+
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, int KP) {
+    extern __shared__ unsigned long long sel[];     // [KP]
+    __shared__ int hist[256];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_need, s_cnt, s_ties;
+    __shared__ int wsum[16];
+    const int lvl = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const int n = lv.n[lvl];
+    const int kk = min(k, n);
+    const float* __restrict__ sc = lv.score[lvl] + (size_t)b * n;
+    float* __restrict__ os = lv.out_score[lvl] + (size_t)b * kk;
+    int64_t* __restrict__ oi = lv.out_idx[lvl] + (size_t)b * kk;
+    if (n <= k) {       // the reference keeps the level unsorted in this case
+        for (int i = tid; i < n; i += 1024) { os[i] = sc[i]; oi[i] = i; }
+        return;
+    }
+    unsigned prefix = 0u, mask = 0u;
+    int need = k;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned dk = desc_key(sc[i]);
+            if ((dk & mask) == prefix) atomicAdd(&hist[(dk >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, bin = 0;
+            for (; bin < 255; bin++) {
+                if (cum + hist[bin] >= need) break;
+                cum += hist[bin];
+            }
+            s_prefix = prefix | ((unsigned)bin << shift);
+            s_need = need - cum;
+            s_ties = hist[bin];
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        need = s_need;
+        mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    const unsigned T = prefix;          // key of the k-th element; `need` of the s_ties equal keys are in
+    const int ties = s_ties;
+    const int nless = k - need;
+    if (tid == 0) s_cnt = 0;
+    for (int i = k + tid; i < KP; i += 1024) sel[i] = ~0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned dk = desc_key(sc[i]);
+        if (dk < T) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            sel[pos] = ((unsigned long long)dk << 32) | (unsigned)i;
+        } else if (dk == T && ties == need) {
+            const int pos = nless + atomicAdd(&s_ties, -1) - 1;      // any order: all ties are in
+            sel[pos] = ((unsigned long long)dk << 32) | (unsigned)i;
+        }
+    }
+    if (ties != need) {                 // more ties than room: the lowest indices win
+        const int lane = tid & 63, wave = tid >> 6;
+        int base = 0;
+        for (int c0 = 0; c0 < n && base < need; c0 += 1024) {
+            const int i = c0 + tid;
+            const bool f = i < n && desc_key(sc[i]) == T;
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) wsum[wave] = __popcll(bal);
+            __syncthreads();
+            int off = __popcll(bal & ((1ull << lane) - 1ull)), tot = 0;
+            for (int w = 0; w < 16; w++) {
+                if (w < wave) off += wsum[w];
+                tot += wsum[w];
+            }
+            if (f && base + off < need) sel[nless + base + off] = ((unsigned long long)T << 32) | (unsigned)i;
+            base += tot;
+            __syncthreads();
+        }
+    }
+    // bitonic sort, ascending composites
+    for (int size = 2; size <= KP; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (KP >> 1); t += 1024) {
+                const int pos = 2 * t - (t & (stride - 1));
+                const unsigned long long a = sel[pos], c = sel[pos + stride];
+                const bool up = (pos & size) == 0;
+                if ((a > c) == up) { sel[pos] = c; sel[pos + stride] = a; }
+            }
+        }
+    __syncthreads();
+    for (int j = tid; j < k; j += 1024) {
+        const unsigned idx = (unsigned)(sel[j] & 0xffffffffull);
+        oi[j] = (int64_t)idx;
+        os[j] = sc[idx];
+    }
+}
+
 }  // namespace
 
 BRCNN_API int brcnn_rpn_score(const float* cls, const float* iou, float* score, int64_t rows,
@@ -127,6 +246,29 @@ BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
     hipLaunchKernelGGL(rpn_decode_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
                        topk_inds, bbox_pred, base_anchors, batch, count, height * width * num_anchors,
                        width, num_anchors, stride_w, stride_h, dp, proposals, valid);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_rpn_topk(const float* const* score_levels, const int* n_host, int num_levels,
+                             int batch, int k, float* const* out_score, int64_t* const* out_idx,
+                             void* stream) {
+    if (num_levels <= 0 || num_levels > BRCNN_MAX_LEVELS || batch < 0 || k <= 0 || k > 4096 ||
+        !score_levels || !n_host || !out_score || !out_idx)
+        return BRCNN_EINVAL;
+    if (batch == 0) return 0;
+    TopkLevels lv = {};
+    for (int l = 0; l < num_levels; l++) {
+        if (n_host[l] <= 0 || !score_levels[l] || !out_score[l] || !out_idx[l]) return BRCNN_EINVAL;
+        lv.score[l] = score_levels[l];
+        lv.out_score[l] = out_score[l];
+        lv.out_idx[l] = out_idx[l];
+        lv.n[l] = n_host[l];
+    }
+    int KP = 2;
+    while (KP < k) KP <<= 1;
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(batch, num_levels), dim3(1024), (size_t)KP * 8,
+                       (hipStream_t)stream, lv, k, KP);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

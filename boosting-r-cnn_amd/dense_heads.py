@@ -388,17 +388,22 @@ class ATSSRPNHead(AnchorHead):
         shapes = {tuple(m['img_shape'][:2]) for m in img_metas}
         A = self.num_anchors
         sc_l, pr_l, va_l, id_l = [], [], [], []
+        raw = [ops.rpn_score(cls_nhwc[lvl], iou_nhwc[lvl]).view(B, -1) for lvl in range(len(cls_nhwc))]
+        if 0 < cfg.nms_pre <= 4096:
+            # descending, ties by ascending index (the shared tie rule), all levels in one launch
+            picked = ops.rpn_topk(raw, cfg.nms_pre)
+        else:
+            picked = []
+            for score in raw:
+                n = score.shape[1]
+                if cfg.nms_pre > 0 and n > cfg.nms_pre:
+                    ranked, rank_inds = score.sort(dim=1, descending=True, stable=True)
+                    picked.append((ranked[:, :cfg.nms_pre], rank_inds[:, :cfg.nms_pre].contiguous()))
+                else:
+                    picked.append((score, torch.arange(n, device=device).expand(B, n).contiguous()))
         for lvl in range(len(cls_nhwc)):
             h, w = cls_nhwc[lvl].shape[1:3]
-            n = h * w * A
-            score = ops.rpn_score(cls_nhwc[lvl], iou_nhwc[lvl]).view(B, n)
-            if cfg.nms_pre > 0 and n > cfg.nms_pre:
-                # descending, ties by ascending index (the shared tie rule)
-                ranked, rank_inds = score.sort(dim=1, descending=True, stable=True)
-                topk_inds = rank_inds[:, :cfg.nms_pre].contiguous()
-                score = ranked[:, :cfg.nms_pre]
-            else:
-                topk_inds = torch.arange(n, device=device).expand(B, n).contiguous()
+            score, topk_inds = picked[lvl]
             stride = self.anchor_generator.strides[lvl]
             rs = 1.0 if reg_scales is None else reg_scales[lvl]
             if len(shapes) == 1:

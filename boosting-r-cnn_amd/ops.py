@@ -607,6 +607,30 @@ def rpn_score(cls, iou):
     return out
 
 
+def rpn_topk(scores, k):
+    """Per level top-k of the proposal scores (atss_rpn_head.py:727-737: sort descending, keep
+    nms_pre) for all levels and images in one launch.  `scores`: list of (B, n_l) dense fp32;
+    returns per level (score (B, min(k,n_l)), index (B, min(k,n_l)) int64) in (score
+    descending, index ascending) order; a level with n_l <= k passes through unsorted."""
+    import ctypes
+    _require_gpu(*scores)
+    L = len(scores)
+    B = scores[0].shape[0]
+    ns = [int(s.shape[1]) for s in scores]
+    for s in scores:
+        assert s.dim() == 2 and s.shape[0] == B and s.is_contiguous() and s.dtype == torch.float32
+    if not 0 < k <= 4096:
+        raise _L.BrcnnHipError(f'rpn_topk: k={k} outside (0, 4096]')
+    dev = scores[0].device
+    out_s = [torch.empty((B, min(k, n)), dtype=torch.float32, device=dev) for n in ns]
+    out_i = [torch.empty((B, min(k, n)), dtype=torch.int64, device=dev) for n in ns]
+    pa = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
+    st = _L.load().brcnn_rpn_topk(pa(scores), (ctypes.c_int * L)(*ns), L, B, int(k), pa(out_s), pa(out_i),
+                                  _stream())
+    _L.check(st, 'brcnn_rpn_topk')
+    return list(zip(out_s, out_i))
+
+
 def rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds, max_shape,
                min_size, wh_ratio_clip=16 / 1000, pred_scale=1.0):
     """topk_inds (B,k) int64 flat anchor indices of one level; bbox_pred (B,H,W,4A) NHWC, possibly

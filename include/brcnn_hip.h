@@ -239,6 +239,12 @@ int brcnn_nhwc_to_nchw(const void *src, float *dst, int batch, int channels, int
  *   level) regenerate the anchor from base_anchors (A,4) + stride, apply
  *   delta2bbox(means 0, stds `std4`, wh_ratio_clip) with max_shape clipping; writes
  *   proposals (count,4) and valid (count) uint8 = w > min_size && h > min_size.
+ * brcnn_rpn_topk: for every (image, level) the `k` best scores of the level's `n` anchors in
+ *   (score descending, index ascending) order -- the reference sorts the whole level and keeps
+ *   nms_pre (atss_rpn_head.py:727-737); exact radix select + an in-LDS sort of the winners.
+ *   score_levels / out_score / out_idx are HOST arrays of device pointers, one per level:
+ *   score (batch, n_l), out_score / out_idx (batch, min(k, n_l)).  A level with n_l <= k is
+ *   passed through in index order, as the reference does.  k <= 4096.
  * -------------------------------------------------------------------------- */
 int brcnn_rpn_score(const float *cls, const float *iou, float *score, int64_t rows,
                     int num_anchors, int cls_stride, int iou_stride, void *stream);
@@ -248,6 +254,9 @@ int brcnn_rpn_decode(const int64_t *topk_inds, const float *bbox_pred, int pred_
                      int stride_h, const float *means4_host, const float *stds4_host,
                      double wh_ratio_clip, float max_h, float max_w, float min_size,
                      float *proposals, uint8_t *valid, void *stream);
+int brcnn_rpn_topk(const float *const *score_levels, const int *n_host, int num_levels,
+                   int batch, int k, float *const *out_score, int64_t *const *out_idx,
+                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,19 @@ def _rpn_score(cls, iou):
     return (cls.sigmoid() * iou.sigmoid()).sqrt()
 
 
+def _rpn_topk(scores, k):
+    """atss_rpn_head.py:727-737: stable descending sort of the level, first nms_pre"""
+    out = []
+    for sc in scores:
+        n = sc.shape[1]
+        if n > k:
+            ranked, inds = sc.sort(dim=1, descending=True, stable=True)
+            out.append((ranked[:, :k].contiguous(), inds[:, :k].contiguous()))
+        else:
+            out.append((sc, torch.arange(n).expand(sc.shape[0], n).contiguous()))
+    return out
+
+
 def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds, max_shape,
                 min_size, wh_ratio_clip=16 / 1000, pred_scale=1.0):
     from brcnn.core import delta2bbox
@@ -153,7 +166,7 @@ _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw
               groupnorm_nhwc_multi=_groupnorm_multi, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
               groupnorm_nhwc=_groupnorm, upsample_nearest_add_nhwc_=_upsample_add_,
               nchw_to_nhwc=_nchw_to_nhwc, nhwc_to_nchw=_nhwc_to_nchw, roi_extract=_roi_extract,
-              nms_ranges=_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode,
+              nms_ranges=_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode, rpn_topk=_rpn_topk,
               nms=orc.nms, soft_nms=orc.soft_nms, batched_nms=orc.batched_nms,
               roi_align=orc.roi_align, RoIAlign=orc.RoIAlign)
 

@@ -352,6 +352,32 @@ def test_small_nhwc_kernels():
 
 
 # --------------------------------------------------------------------------- RPN stage
+def test_rpn_topk_matches_stable_sort():
+    """bit-exact indices against torch's stable descending sort on the host (the tie rule):
+    distinct scores, heavy ties (quantised scores), all-equal rows, +-0, n <= k pass-through"""
+    g = torch.Generator().manual_seed(21)
+    B = 3
+    levels = [torch.rand(B, 151200, generator=g), torch.rand(B, 37800, generator=g),
+              (torch.rand(B, 9450, generator=g) * 50).floor() / 50,          # ~190 ties per value
+              torch.full((B, 2394), 0.25), torch.rand(B, 630, generator=g)]
+    levels[1][:, ::7] = 0.0
+    levels[1][:, 1::14] = -0.0
+    levels[0][0, 5000:9000] = levels[0][0, 4999]                             # a 4000-long run of ties
+    for k in (1000, 2000, 37):
+        got = ops.rpn_topk([l.to(DEV) for l in levels], k)
+        for l, (gs, gi) in zip(levels, got):
+            n = l.shape[1]
+            if n > k:
+                rs, ri = l.sort(dim=1, descending=True, stable=True)
+                rs, ri = rs[:, :k], ri[:, :k]
+            else:
+                rs, ri = l, torch.arange(n).expand(B, n)
+            assert torch.equal(gi.cpu(), ri), (n, k)
+            assert torch.equal(gs.cpu(), rs)
+    with pytest.raises(Exception):
+        ops.rpn_topk([levels[0].to(DEV)], 5000)
+
+
 def test_rpn_score_and_decode():
     g = torch.Generator().manual_seed(77)
     cls, iou = torch.randn(2, 13, 21, 9, generator=g) * 3, torch.randn(2, 13, 21, 9, generator=g) * 3

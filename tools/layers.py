@@ -3,6 +3,7 @@ sys.path.insert(0, os.getcwd())
 import bench
 from brcnn import profiling
 m, cfg = bench.build_model('cuda')
+m.set_compute_dtype(os.environ.get('BRCNN_DTYPE', 'f32'))
 img, metas = bench.synthetic_batch(8, 'cuda')
 for _ in range(2):
     with torch.no_grad(): m.simple_test_device(img, metas, rescale=True)

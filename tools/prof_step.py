@@ -2,6 +2,7 @@ import sys, os, torch
 sys.path.insert(0, os.getcwd())
 import bench
 m, cfg = bench.build_model('cuda')
+m.set_compute_dtype(os.environ.get('BRCNN_DTYPE', 'f32'))
 img, metas = bench.synthetic_batch(8, 'cuda')
 for _ in range(4):
     with torch.no_grad():
