@@ -15,3 +15,8 @@ from .registry import (MODELS, BACKBONES, NECKS, HEADS, LOSSES, DETECTORS, ROI_E
                        BBOX_ASSIGNERS, BBOX_SAMPLERS, BBOX_CODERS, PRIOR_GENERATORS,
                        IOU_CALCULATORS, build_detector, build_backbone, build_neck, build_head,
                        build_loss)
+
+# data side and drivers: registries PIPELINES / DATASETS, apis
+from . import pipelines, datasets, evaluation, apis  # noqa: E402,F401
+from .pipelines import PIPELINES, Compose  # noqa: E402,F401
+from .datasets import DATASETS, build_dataset, build_dataloader  # noqa: E402,F401

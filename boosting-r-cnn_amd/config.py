@@ -13,6 +13,7 @@ Rules reproduced:
     `_delete_` entry that PseudoSampler(**kwargs) swallows);
   * `--cfg-options a.b=1` style overrides via `merge_from_dict`.
 """
+import argparse
 import ast
 import copy
 import os
@@ -183,3 +184,77 @@ class Config:
             d[keys[-1]] = v
         merged = _merge_a_into_b(option_cfg, self._cfg_dict.to_dict())
         object.__setattr__(self, '_cfg_dict', ConfigDict(merged))
+
+    # ---- text form (mmcv Config.pretty_text / dump): a python file that round-trips ------
+    @property
+    def pretty_text(self):
+        import pprint
+        lines = []
+        for k, v in self._cfg_dict.to_dict().items():
+            lines.append(f'{k} = {pprint.pformat(v, width=100, sort_dicts=False)}')
+        return '\n'.join(lines) + '\n'
+
+    def dump(self, file=None):
+        text = self.pretty_text
+        if file is None:
+            return text
+        with open(file, 'w', encoding='utf-8') as f:
+            f.write(text)
+
+    def __repr__(self):
+        return f'Config (path: {self.filename}): {self._cfg_dict.to_dict()!r}'
+
+
+class DictAction(argparse.Action):
+    """`--cfg-options a.b=1 c=x,y d="[1,2]"` -> {'a.b': 1, 'c': ['x','y'], 'd': [1,2]}
+    (the argparse action the reference's tools take from mmcv)"""
+
+    @staticmethod
+    def _parse_scalar(val):
+        for cast in (int, float):
+            try:
+                return cast(val)
+            except ValueError:
+                pass
+        if val.lower() in ('true', 'false'):
+            return val.lower() == 'true'
+        if val == 'None':
+            return None
+        return val
+
+    @staticmethod
+    def _split_top(s):
+        """split on commas that are not nested in () / []"""
+        out, depth, cur = [], 0, ''
+        for ch in s:
+            if ch in '([':
+                depth += 1
+            elif ch in ')]':
+                depth -= 1
+            if ch == ',' and depth == 0:
+                out.append(cur)
+                cur = ''
+            else:
+                cur += ch
+        out.append(cur)
+        return out
+
+    @classmethod
+    def _parse_value(cls, val):
+        val = val.strip().strip('\'"').replace(' ', '')
+        is_tuple = False
+        if val.startswith('(') and val.endswith(')'):
+            is_tuple, val = True, val[1:-1]
+        elif val.startswith('[') and val.endswith(']'):
+            val = val[1:-1]
+        elif ',' not in val:
+            return cls._parse_scalar(val)
+        items = [cls._parse_value(v) for v in cls._split_top(val) if v != '']
+        return tuple(items) if is_tuple else items
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        options = {}
+        for kv in values:
+            key, val = kv.split('=', maxsplit=1)
+            options[key] = self._parse_value(val)
+        setattr(namespace, self.dest, options)

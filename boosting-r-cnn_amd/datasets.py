@@ -1,0 +1,530 @@
+"""COCO-format dataset, samplers, collate and dataloader builder without
+pycocotools / mmcv: the data side of `configs/_base_/datasets/*_coco.py`.
+
+Mirrors mmdet/datasets/{custom.py,coco.py,builder.py,samplers/group_sampler.py,
+samplers/distributed_sampler.py} and mmcv.parallel.collate for the fields the Boosting R-CNN
+path consumes (img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore).
+"""
+import copy
+import json
+import math
+import os.path as osp
+from collections import defaultdict
+from functools import partial
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset, Sampler
+
+from .pipelines import Compose, DataContainer
+from .registry import Registry, build_from_cfg
+
+DATASETS = Registry('dataset')
+
+
+class COCO:
+    """the part of pycocotools.coco.COCO the reference's CocoDataset calls
+    (datasets/api_wrappers/coco_api.py:11-46): index of images / annotations / categories"""
+
+    def __init__(self, annotation_file=None):
+        self.dataset, self.anns, self.cats, self.imgs = {}, {}, {}, {}
+        self.imgToAnns, self.catToImgs = defaultdict(list), defaultdict(list)
+        if annotation_file is not None:
+            with open(annotation_file) as f:
+                self.dataset = json.load(f)
+            assert isinstance(self.dataset, dict), 'annotation file format not supported'
+            self.createIndex()
+
+    def createIndex(self):
+        for ann in self.dataset.get('annotations', []):
+            self.imgToAnns[ann['image_id']].append(ann)
+            self.anns[ann['id']] = ann
+        for img in self.dataset.get('images', []):
+            self.imgs[img['id']] = img
+        for cat in self.dataset.get('categories', []):
+            self.cats[cat['id']] = cat
+        for ann in self.dataset.get('annotations', []):
+            self.catToImgs[ann['category_id']].append(ann['image_id'])
+
+    def get_cat_ids(self, cat_names=()):
+        cats = self.dataset.get('categories', [])
+        if len(cat_names):
+            cats = [c for c in cats if c['name'] in cat_names]
+        return [c['id'] for c in cats]
+
+    def get_img_ids(self):
+        return list(self.imgs.keys())
+
+    def get_ann_ids(self, img_ids=()):
+        img_ids = img_ids if isinstance(img_ids, (list, tuple)) else [img_ids]
+        return [a['id'] for i in img_ids for a in self.imgToAnns.get(i, [])]
+
+    def load_anns(self, ids):
+        return [self.anns[i] for i in ids]
+
+    def load_imgs(self, ids):
+        return [self.imgs[i] for i in ids]
+
+    def load_cats(self, ids):
+        return [self.cats[i] for i in ids]
+
+    def loadRes(self, results):
+        """detections (list of dict image_id/bbox/score/category_id) as a COCO index"""
+        res = COCO()
+        res.dataset['images'] = list(self.dataset['images'])
+        res.dataset['categories'] = copy.deepcopy(self.dataset['categories'])
+        anns = copy.deepcopy(results)
+        for i, ann in enumerate(anns):
+            x, y, w, h = ann['bbox']
+            ann['area'] = w * h
+            ann['id'] = i + 1
+            ann['iscrowd'] = 0
+        res.dataset['annotations'] = anns
+        res.createIndex()
+        return res
+
+
+@DATASETS.register_module()
+class CustomDataset(Dataset):
+    """datasets/custom.py:15-330 (annotation parsing left to the subclass)"""
+    CLASSES = None
+
+    def __init__(self, ann_file, pipeline, classes=None, data_root=None, img_prefix='', seg_prefix=None,
+                 proposal_file=None, test_mode=False, filter_empty_gt=True):
+        self.ann_file = ann_file
+        self.data_root = data_root
+        self.img_prefix = img_prefix
+        self.test_mode = test_mode
+        self.filter_empty_gt = filter_empty_gt
+        self.CLASSES = self.get_classes(classes)
+        if self.data_root is not None:
+            if not osp.isabs(self.ann_file):
+                self.ann_file = osp.join(self.data_root, self.ann_file)
+            if not (self.img_prefix is None or osp.isabs(self.img_prefix)):
+                self.img_prefix = osp.join(self.data_root, self.img_prefix)
+        self.data_infos = self.load_annotations(self.ann_file)
+        self.proposals = None
+        if not test_mode:
+            valid_inds = self._filter_imgs()
+            self.data_infos = [self.data_infos[i] for i in valid_inds]
+            self._set_group_flag()
+        self.pipeline = Compose(pipeline)
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    @classmethod
+    def get_classes(cls, classes=None):
+        if classes is None:
+            return cls.CLASSES
+        if isinstance(classes, str):
+            with open(classes) as f:
+                return [ln.strip() for ln in f if ln.strip()]
+        if isinstance(classes, (tuple, list)):
+            return classes
+        raise ValueError(f'Unsupported type {type(classes)} of classes.')
+
+    def pre_pipeline(self, results):
+        results['img_prefix'] = self.img_prefix
+        results['seg_prefix'] = None
+        results['proposal_file'] = None
+        results['bbox_fields'] = []
+        results['mask_fields'] = []
+        results['seg_fields'] = []
+
+    def _filter_imgs(self, min_size=32):
+        return [i for i, info in enumerate(self.data_infos) if min(info['width'], info['height']) >= min_size]
+
+    def _set_group_flag(self):
+        """images with aspect ratio > 1 form group 1, the rest group 0"""
+        self.flag = np.zeros(len(self), dtype=np.uint8)
+        for i in range(len(self)):
+            info = self.data_infos[i]
+            if info['width'] / info['height'] > 1:
+                self.flag[i] = 1
+
+    def _rand_another(self, idx):
+        pool = np.where(self.flag == self.flag[idx])[0]
+        return np.random.choice(pool)
+
+    def __getitem__(self, idx):
+        if self.test_mode:
+            return self.prepare_test_img(idx)
+        while True:
+            data = self.prepare_train_img(idx)
+            if data is None:
+                idx = self._rand_another(idx)
+                continue
+            return data
+
+    def prepare_train_img(self, idx):
+        results = dict(img_info=self.data_infos[idx], ann_info=self.get_ann_info(idx))
+        self.pre_pipeline(results)
+        return self.pipeline(results)
+
+    def prepare_test_img(self, idx):
+        results = dict(img_info=self.data_infos[idx])
+        self.pre_pipeline(results)
+        return self.pipeline(results)
+
+
+@DATASETS.register_module()
+class CocoDataset(CustomDataset):
+    """datasets/coco.py:22-560 (bbox annotations, result json, bbox mAP)"""
+    CLASSES = ('person', 'bicycle', 'car', 'motorcycle', 'airplane', 'bus', 'train', 'truck', 'boat',
+               'traffic light', 'fire hydrant', 'stop sign', 'parking meter', 'bench', 'bird', 'cat', 'dog',
+               'horse', 'sheep', 'cow', 'elephant', 'bear', 'zebra', 'giraffe', 'backpack', 'umbrella',
+               'handbag', 'tie', 'suitcase', 'frisbee', 'skis', 'snowboard', 'sports ball', 'kite',
+               'baseball bat', 'baseball glove', 'skateboard', 'surfboard', 'tennis racket', 'bottle',
+               'wine glass', 'cup', 'fork', 'knife', 'spoon', 'bowl', 'banana', 'apple', 'sandwich',
+               'orange', 'broccoli', 'carrot', 'hot dog', 'pizza', 'donut', 'cake', 'chair', 'couch',
+               'potted plant', 'bed', 'dining table', 'toilet', 'tv', 'laptop', 'mouse', 'remote',
+               'keyboard', 'cell phone', 'microwave', 'oven', 'toaster', 'sink', 'refrigerator', 'book',
+               'clock', 'vase', 'scissors', 'teddy bear', 'hair drier', 'toothbrush')
+
+    def load_annotations(self, ann_file):
+        self.coco = COCO(ann_file)
+        self.cat_ids = self.coco.get_cat_ids(cat_names=self.CLASSES)
+        self.cat2label = {cat_id: i for i, cat_id in enumerate(self.cat_ids)}
+        self.img_ids = self.coco.get_img_ids()
+        data_infos, total_ann_ids = [], []
+        for i in self.img_ids:
+            info = self.coco.load_imgs([i])[0]
+            info['filename'] = info['file_name']
+            data_infos.append(info)
+            total_ann_ids.extend(self.coco.get_ann_ids(img_ids=[i]))
+        assert len(set(total_ann_ids)) == len(total_ann_ids), f"Annotation ids in '{ann_file}' are not unique!"
+        return data_infos
+
+    def get_ann_info(self, idx):
+        img_id = self.data_infos[idx]['id']
+        ann_info = self.coco.load_anns(self.coco.get_ann_ids(img_ids=[img_id]))
+        return self._parse_ann_info(self.data_infos[idx], ann_info)
+
+    def _filter_imgs(self, min_size=32):
+        valid_inds = []
+        ids_with_ann = set(a['image_id'] for a in self.coco.anns.values())
+        ids_in_cat = set()
+        for class_id in self.cat_ids:
+            ids_in_cat |= set(self.coco.catToImgs[class_id])
+        ids_in_cat &= ids_with_ann
+        valid_img_ids = []
+        for i, info in enumerate(self.data_infos):
+            img_id = self.img_ids[i]
+            if self.filter_empty_gt and img_id not in ids_in_cat:
+                continue
+            if min(info['width'], info['height']) >= min_size:
+                valid_inds.append(i)
+                valid_img_ids.append(img_id)
+        self.img_ids = valid_img_ids
+        return valid_inds
+
+    def _parse_ann_info(self, img_info, ann_info):
+        gt_bboxes, gt_labels, gt_bboxes_ignore = [], [], []
+        for ann in ann_info:
+            if ann.get('ignore', False):
+                continue
+            x1, y1, w, h = ann['bbox']
+            inter_w = max(0, min(x1 + w, img_info['width']) - max(x1, 0))
+            inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
+            if inter_w * inter_h == 0:
+                continue
+            if ann['area'] <= 0 or w < 1 or h < 1:
+                continue
+            if ann['category_id'] not in self.cat_ids:
+                continue
+            bbox = [x1, y1, x1 + w, y1 + h]
+            if ann.get('iscrowd', False):
+                gt_bboxes_ignore.append(bbox)
+            else:
+                gt_bboxes.append(bbox)
+                gt_labels.append(self.cat2label[ann['category_id']])
+        if gt_bboxes:
+            gt_bboxes = np.array(gt_bboxes, dtype=np.float32)
+            gt_labels = np.array(gt_labels, dtype=np.int64)
+        else:
+            gt_bboxes = np.zeros((0, 4), dtype=np.float32)
+            gt_labels = np.array([], dtype=np.int64)
+        if gt_bboxes_ignore:
+            gt_bboxes_ignore = np.array(gt_bboxes_ignore, dtype=np.float32)
+        else:
+            gt_bboxes_ignore = np.zeros((0, 4), dtype=np.float32)
+        return dict(bboxes=gt_bboxes, labels=gt_labels, bboxes_ignore=gt_bboxes_ignore, masks=[],
+                    seg_map=img_info['filename'].replace('jpg', 'png'))
+
+    # ---- results ------------------------------------------------------------------------
+    @staticmethod
+    def xyxy2xywh(bbox):
+        b = bbox.tolist()
+        return [b[0], b[1], b[2] - b[0], b[3] - b[1]]
+
+    def _det2json(self, results):
+        json_results = []
+        for idx in range(len(self)):
+            img_id = self.img_ids[idx]
+            for label, bboxes in enumerate(results[idx]):
+                for i in range(bboxes.shape[0]):
+                    json_results.append(dict(image_id=img_id, bbox=self.xyxy2xywh(bboxes[i]),
+                                             score=float(bboxes[i][4]), category_id=self.cat_ids[label]))
+        return json_results
+
+    def results2json(self, results, outfile_prefix):
+        assert isinstance(results[0], list), 'bbox results (list per class) expected'
+        out = f'{outfile_prefix}.bbox.json'
+        with open(out, 'w') as f:
+            json.dump(self._det2json(results), f)
+        return dict(bbox=out, proposal=out)
+
+    def format_results(self, results, jsonfile_prefix=None, **kwargs):
+        assert isinstance(results, list), 'results must be a list'
+        assert len(results) == len(self), (
+            f'The length of results is not equal to the dataset len: {len(results)} != {len(self)}')
+        tmp_dir = None
+        if jsonfile_prefix is None:
+            import tempfile
+            tmp_dir = tempfile.TemporaryDirectory()
+            jsonfile_prefix = osp.join(tmp_dir.name, 'results')
+        return self.results2json(results, jsonfile_prefix), tmp_dir
+
+    def evaluate(self, results, metric='bbox', logger=None, jsonfile_prefix=None, classwise=False,
+                 proposal_nums=(100, 300, 1000), iou_thrs=None, metric_items=None):
+        """coco.py:362-560, bbox metric: COCO mAP through this repo's COCOeval restatement"""
+        from .evaluation import COCOeval
+        metrics = metric if isinstance(metric, list) else [metric]
+        for m in metrics:
+            if m != 'bbox':
+                raise KeyError(f'metric {m} is not supported (bbox only on this path)')
+        if iou_thrs is None:
+            iou_thrs = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
+        eval_results = {}
+        dets = self._det2json(results)
+        if jsonfile_prefix is not None:
+            with open(f'{jsonfile_prefix}.bbox.json', 'w') as f:
+                json.dump(dets, f)
+        if len(dets) == 0:
+            if logger is not None:
+                logger.error('The testing results of the whole dataset is empty.')
+            return eval_results
+        coco_dt = self.coco.loadRes(dets)
+        ev = COCOeval(self.coco, coco_dt, 'bbox')
+        ev.params.catIds = self.cat_ids
+        ev.params.imgIds = self.img_ids
+        ev.params.maxDets = list(proposal_nums)
+        ev.params.iouThrs = iou_thrs
+        names = {'mAP': 0, 'mAP_50': 1, 'mAP_75': 2, 'mAP_s': 3, 'mAP_m': 4, 'mAP_l': 5,
+                 'AR@100': 6, 'AR@300': 7, 'AR@1000': 8, 'AR_s@1000': 9, 'AR_m@1000': 10, 'AR_l@1000': 11}
+        ev.evaluate()
+        ev.accumulate()
+        text = ev.summarize()
+        if logger is not None:
+            logger.info('\n' + text)
+        if classwise:
+            precisions = ev.eval['precision']      # (T, R, K, A, M)
+            per_class = {}
+            for idx, cat_id in enumerate(self.cat_ids):
+                pr = precisions[:, :, idx, 0, -1]
+                pr = pr[pr > -1]
+                per_class[self.coco.load_cats([cat_id])[0]['name']] = float(np.mean(pr)) if pr.size else float('nan')
+            eval_results['bbox_classwise'] = per_class
+        if metric_items is None:
+            metric_items = ['mAP', 'mAP_50', 'mAP_75', 'mAP_s', 'mAP_m', 'mAP_l']
+        for item in metric_items:
+            eval_results[f'bbox_{item}'] = float(f'{ev.stats[names[item]]:.3f}')
+        ap = ev.stats[:6]
+        eval_results['bbox_mAP_copypaste'] = ' '.join(f'{v:.3f}' for v in ap)
+        return eval_results
+
+
+# --------------------------------------------------------------------------- samplers
+class GroupSampler(Sampler):
+    """samplers/group_sampler.py:11-53"""
+
+    def __init__(self, dataset, samples_per_gpu=1):
+        assert hasattr(dataset, 'flag')
+        self.dataset = dataset
+        self.samples_per_gpu = samples_per_gpu
+        self.flag = dataset.flag.astype(np.int64)
+        self.group_sizes = np.bincount(self.flag)
+        self.num_samples = 0
+        for size in self.group_sizes:
+            self.num_samples += int(np.ceil(size / self.samples_per_gpu)) * self.samples_per_gpu
+
+    def __iter__(self):
+        indices = []
+        for i, size in enumerate(self.group_sizes):
+            if size == 0:
+                continue
+            indice = np.where(self.flag == i)[0]
+            assert len(indice) == size
+            np.random.shuffle(indice)
+            num_extra = int(np.ceil(size / self.samples_per_gpu)) * self.samples_per_gpu - len(indice)
+            indice = np.concatenate([indice, np.random.choice(indice, num_extra)])
+            indices.append(indice)
+        indices = np.concatenate(indices)
+        spg = self.samples_per_gpu
+        indices = [indices[i * spg:(i + 1) * spg] for i in np.random.permutation(range(len(indices) // spg))]
+        indices = np.concatenate(indices).astype(np.int64).tolist()
+        assert len(indices) == self.num_samples
+        return iter(indices)
+
+    def __len__(self):
+        return self.num_samples
+
+
+class DistributedGroupSampler(Sampler):
+    """samplers/group_sampler.py:56-148: aspect-ratio groups, every rank gets whole
+    same-group batches, deterministic in (seed, epoch)"""
+
+    def __init__(self, dataset, samples_per_gpu=1, num_replicas=None, rank=None, seed=0):
+        if num_replicas is None or rank is None:
+            import torch.distributed as dist
+            ws, rk = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
+            num_replicas = ws if num_replicas is None else num_replicas
+            rank = rk if rank is None else rank
+        self.dataset = dataset
+        self.samples_per_gpu = samples_per_gpu
+        self.num_replicas = num_replicas
+        self.rank = rank
+        self.epoch = 0
+        self.seed = seed if seed is not None else 0
+        assert hasattr(self.dataset, 'flag')
+        self.flag = self.dataset.flag
+        self.group_sizes = np.bincount(self.flag)
+        self.num_samples = 0
+        for size in self.group_sizes:
+            self.num_samples += int(math.ceil(size * 1.0 / self.samples_per_gpu / self.num_replicas)) * \
+                self.samples_per_gpu
+        self.total_size = self.num_samples * self.num_replicas
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.epoch + self.seed)
+        indices = []
+        for i, size in enumerate(self.group_sizes):
+            if size > 0:
+                indice = np.where(self.flag == i)[0]
+                assert len(indice) == size
+                indice = indice[list(torch.randperm(int(size), generator=g).numpy())].tolist()
+                extra = int(math.ceil(size * 1.0 / self.samples_per_gpu / self.num_replicas)) * \
+                    self.samples_per_gpu * self.num_replicas - len(indice)
+                tmp = indice.copy()
+                for _ in range(extra // size):
+                    indice.extend(tmp)
+                indice.extend(tmp[:extra % size])
+                indices.extend(indice)
+        assert len(indices) == self.total_size
+        spg = self.samples_per_gpu
+        indices = [indices[j] for i in list(torch.randperm(len(indices) // spg, generator=g))
+                   for j in range(i * spg, (i + 1) * spg)]
+        offset = self.num_samples * self.rank
+        indices = indices[offset:offset + self.num_samples]
+        assert len(indices) == self.num_samples
+        return iter(indices)
+
+    def __len__(self):
+        return self.num_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+class DistributedSampler(Sampler):
+    """samplers/distributed_sampler.py:8-39 (test-time: in-order round-robin shards, padded)"""
+
+    def __init__(self, dataset, num_replicas, rank, shuffle=False, seed=0):
+        self.dataset, self.num_replicas, self.rank = dataset, num_replicas, rank
+        self.shuffle, self.seed, self.epoch = shuffle, seed if seed is not None else 0, 0
+        self.num_samples = int(math.ceil(len(dataset) / num_replicas))
+        self.total_size = self.num_samples * num_replicas
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.epoch + self.seed)
+            indices = torch.randperm(len(self.dataset), generator=g).tolist()
+        else:
+            indices = torch.arange(len(self.dataset)).tolist()
+        indices = (indices * math.ceil(self.total_size / max(len(indices), 1)))[:self.total_size]
+        assert len(indices) == self.total_size
+        indices = indices[self.rank:self.total_size:self.num_replicas]
+        assert len(indices) == self.num_samples
+        return iter(indices)
+
+    def __len__(self):
+        return self.num_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+# --------------------------------------------------------------------------- collate
+def _pad_stack(tensors, pad_dims, padding_value):
+    ndim = tensors[0].dim()
+    max_shape = [0] * pad_dims
+    for d in range(1, pad_dims + 1):
+        max_shape[d - 1] = max(t.size(-d) for t in tensors)
+    out = []
+    for t in tensors:
+        assert t.dim() == ndim
+        pad = [0] * (pad_dims * 2)
+        for d in range(1, pad_dims + 1):
+            pad[2 * d - 1] = max_shape[d - 1] - t.size(-d)
+        out.append(torch.nn.functional.pad(t, pad, value=padding_value) if any(pad) else t)
+    return torch.stack(out, 0)
+
+
+def collate(batch, samples_per_gpu=1):
+    """mmcv.parallel.collate followed by the one-device scatter of MMDataParallel: stacked
+    DataContainers become one zero-padded tensor, cpu_only ones a list of python objects, the
+    others a list of tensors; sequences (test-time aug lists) are collated element-wise."""
+    if not isinstance(batch, (list, tuple)):
+        raise TypeError(f'{type(batch)} is not supported.')
+    first = batch[0]
+    if isinstance(first, DataContainer):
+        assert len(batch) <= samples_per_gpu or len(batch) % samples_per_gpu == 0
+        if first.cpu_only:
+            return [s.data for s in batch]
+        if first.stack:
+            assert isinstance(first.data, torch.Tensor)
+            if first.pad_dims is not None:
+                return _pad_stack([s.data for s in batch], first.pad_dims, first.padding_value)
+            return torch.stack([s.data for s in batch], 0)
+        return [s.data for s in batch]
+    if isinstance(first, (list, tuple)):
+        return [collate(list(samples), samples_per_gpu) for samples in zip(*batch)]
+    if isinstance(first, dict):
+        return {key: collate([d[key] for d in batch], samples_per_gpu) for key in first}
+    if isinstance(first, torch.Tensor):
+        return _pad_stack(list(batch), 2, 0) if first.dim() >= 2 else torch.stack(list(batch), 0)
+    return torch.utils.data.dataloader.default_collate(batch)
+
+
+def worker_init_fn(worker_id, num_workers, rank, seed):
+    worker_seed = num_workers * rank + worker_id + seed
+    np.random.seed(worker_seed)
+    import random
+    random.seed(worker_seed)
+
+
+def build_dataset(cfg, default_args=None):
+    if isinstance(cfg, (list, tuple)):
+        raise NotImplementedError('ConcatDataset configs are outside the Boosting R-CNN recipes')
+    return build_from_cfg(cfg, DATASETS, default_args)
+
+
+def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist=True, shuffle=True,
+                     seed=None, rank=0, world_size=1, **kwargs):
+    """datasets/builder.py:90-165"""
+    if dist:
+        if shuffle:
+            sampler = DistributedGroupSampler(dataset, samples_per_gpu, world_size, rank, seed=seed)
+        else:
+            sampler = DistributedSampler(dataset, world_size, rank, shuffle=False, seed=seed)
+        batch_size, num_workers = samples_per_gpu, workers_per_gpu
+    else:
+        sampler = GroupSampler(dataset, samples_per_gpu) if shuffle else None
+        batch_size, num_workers = num_gpus * samples_per_gpu, num_gpus * workers_per_gpu
+    init_fn = partial(worker_init_fn, num_workers=num_workers, rank=rank, seed=seed) if seed is not None else None
+    return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+                      collate_fn=partial(collate, samples_per_gpu=samples_per_gpu), pin_memory=False,
+                      worker_init_fn=init_fn, **kwargs)

@@ -656,3 +656,24 @@ def rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds,
                                     float(min_size), _ptr(props), _ptr(valid), _stream())
     _L.check(st, 'brcnn_rpn_decode')
     return props, valid
+
+
+# --------------------------------------------------------------------------- input front door
+_FLIP_CODE = {None: 0, 'horizontal': 1, 'vertical': 2, 'diagonal': 3}
+
+
+def preprocess_u8(src_u8, out, new_w, new_h, flip_direction, mean, std, to_rgb=True):
+    """Resize(new_w,new_h) -> flip -> Normalize -> Pad of one decoded uint8 BGR image
+    (transforms.py Resize/RandomFlip/Normalize/Pad) in one pass.  `src_u8` (H,W,3) uint8 on the
+    device, `out` (3,PH,PW) fp32 on the device (PH >= new_h, PW >= new_w; the rest is zeroed)."""
+    import ctypes
+    _require_gpu(src_u8, out)
+    assert src_u8.dtype == torch.uint8 and src_u8.dim() == 3 and src_u8.shape[2] == 3 and src_u8.is_contiguous()
+    assert out.dtype == torch.float32 and out.dim() == 3 and out.shape[0] == 3 and out.is_contiguous()
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    st = _L.load().brcnn_preprocess_u8(_ptr(src_u8), src_u8.shape[0], src_u8.shape[1], _ptr(out), int(new_h),
+                                       int(new_w), out.shape[1], out.shape[2], _FLIP_CODE[flip_direction],
+                                       m3, s3, int(bool(to_rgb)), _stream())
+    _L.check(st, 'brcnn_preprocess_u8')
+    return out

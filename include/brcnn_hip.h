@@ -258,6 +258,21 @@ int brcnn_rpn_topk(const float *const *score_levels, const int *n_host, int num_
                    int batch, int k, float *const *out_score, int64_t *const *out_idx,
                    void *stream);
 
+/* ------------------------------------------------------------------------------
+ * Input front door: the reference's Resize -> RandomFlip -> Normalize -> Pad
+ * transforms (mmdet/datasets/pipelines/transforms.py:31-315,318-470,700-739,625-697; the image
+ * arithmetic is mmcv.imresize = cv2.resize INTER_LINEAR on uint8, mmcv.imflip,
+ * mmcv.imnormalize, mmcv.impad) of ONE decoded image as one pass.
+ *   src  (src_h, src_w, 3) uint8, BGR, dense        dst (3, pad_h, pad_w) fp32, CHW
+ *   the image is resized to (new_h, new_w) with OpenCV's 8-bit fixed-point bilinear, flipped
+ *   (flip: 0 none, 1 horizontal, 2 vertical, 3 diagonal), converted BGR->RGB when to_rgb,
+ *   normalised (v - mean[c]) * fp32(1/std[c]) (mean/std in the OUTPUT channel order, host
+ *   arrays of 3) and zero-padded at the bottom / right to (pad_h, pad_w).
+ * -------------------------------------------------------------------------- */
+int brcnn_preprocess_u8(const uint8_t *src, int src_h, int src_w, float *dst, int new_h,
+                        int new_w, int pad_h, int pad_w, int flip, const float *mean3_host,
+                        const float *std3_host, int to_rgb, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

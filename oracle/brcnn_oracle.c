@@ -392,3 +392,62 @@ ORC_API int orc_roi_align_forward_range(const float *input, const float *rois, f
                                  height, width, k1 - k0, ph_n, pw_n, spatial_scale,
                                  sampling_ratio, 1, aligned);
 }
+
+/* ------------------------------------------------------------------------- */
+/* Input front door: Resize -> RandomFlip -> Normalize -> Pad of one decoded  */
+/* uint8 BGR image (mmdet/datasets/pipelines/transforms.py:31-315, 318-470,   */
+/* 700-739, 625-697).  The image arithmetic lives in mmcv 1.4.0 -> OpenCV     */
+/* (both absent): cv::resize INTER_LINEAR on CV_8U (imgproc/resize.cpp:       */
+/* resizeGeneric_, HResizeLinear<uchar,int,short>, VResizeLinear<uchar,int,   */
+/* short,FixedPtCast<int,uchar,22>> with INTER_RESIZE_COEF_BITS = 11),        */
+/* mmcv.imnormalize (fp32 subtract / multiply by fp32(1/std)).                */
+/* PARITY UNPINNED for the resize: no cv2 and no reference golden vector of   */
+/* it here; restated from the published algorithm, cross-checked against the  */
+/* independent numpy restatement in the package (tests/test_pipeline_data_cpu)*/
+/* ------------------------------------------------------------------------- */
+static void orc_axis_coeff(int d, double scale, int src, int *s, int *c0, int *c1)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= src - 1) { f = 0.f; si = src - 1; }
+    *s = si;
+    *c0 = (int)rintf((1.f - f) * 2048.f);
+    *c1 = (int)rintf(f * 2048.f);
+}
+
+ORC_API int orc_preprocess_u8(const uint8_t *src, int sh, int sw, float *dst, int nh, int nw,
+                              int ph, int pw, int flip, const float *mean3, const float *std3,
+                              int to_rgb)
+{
+    if (!src || !dst || sh <= 0 || sw <= 0 || nh <= 0 || nw <= 0 || ph < nh || pw < nw) return -22;
+    const double scale_x = 1.0 / ((double)nw / (double)sw);
+    const double scale_y = 1.0 / ((double)nh / (double)sh);
+    float stdinv[3];
+    for (int c = 0; c < 3; c++) stdinv[c] = (float)(1.0 / (double)std3[c]);
+    const size_t plane = (size_t)ph * pw;
+    for (int y = 0; y < ph; y++)
+        for (int x = 0; x < pw; x++) {
+            float *o = dst + (size_t)y * pw + x;
+            if (x >= nw || y >= nh) { o[0] = o[plane] = o[2 * plane] = 0.f; continue; }
+            const int rx = (flip & 1) ? nw - 1 - x : x;
+            const int ry = (flip & 2) ? nh - 1 - y : y;
+            int sx, a0, a1, sy, b0, b1;
+            orc_axis_coeff(rx, scale_x, sw, &sx, &a0, &a1);
+            orc_axis_coeff(ry, scale_y, sh, &sy, &b0, &b1);
+            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            const int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+            const uint8_t *r0 = src + (size_t)sy * sw * 3, *r1 = src + (size_t)sy1 * sw * 3;
+            for (int c = 0; c < 3; c++) {
+                const int sc = to_rgb ? 2 - c : c;
+                const int h0 = (int)r0[sx * 3 + sc] * a0 + (int)r0[sx1 * 3 + sc] * a1;
+                const int h1 = (int)r1[sx * 3 + sc] * a0 + (int)r1[sx1 * 3 + sc] * a1;
+                int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                if (v < 0) v = 0;
+                if (v > 255) v = 255;
+                o[c * plane] = ((float)v - mean3[c]) * stdinv[c];
+            }
+        }
+    return 0;
+}

@@ -49,6 +49,8 @@ def lib():
         for fn in (L.orc_sigmoid_focal_loss_forward, L.orc_sigmoid_focal_loss_backward):
             fn.argtypes = [f32p, i64p, f32p, f32p, ctypes.c_int64, ctypes.c_int64,
                            ctypes.c_float, ctypes.c_float]
+        L.orc_preprocess_u8.argtypes = [f32p, ctypes.c_int, ctypes.c_int, f32p] + [ctypes.c_int] * 5 + \
+            [f32p, f32p, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -315,4 +317,22 @@ def roi_align_f64(input, rois, output_size, spatial_scale, sampling_ratio=0, ali
                         acc += (hy * hx * x[b, :, yl, xl] + hy * lx * x[b, :, yl, xh] +
                                 ly * hx * x[b, :, yh, xl] + ly * lx * x[b, :, yh, xh])
                 out[k, :, ph, pw] = acc / cnt
+    return out
+
+
+_FLIP = {None: 0, 'horizontal': 1, 'vertical': 2, 'diagonal': 3}
+
+
+def preprocess_u8(img_u8, new_w, new_h, pad_h, pad_w, flip_direction, mean, std, to_rgb=True):
+    """Resize -> RandomFlip -> Normalize -> Pad of one uint8 BGR HxWx3 image: (3,pad_h,pad_w) fp32"""
+    import numpy as np
+    src = torch.as_tensor(np.ascontiguousarray(img_u8))
+    assert src.dtype == torch.uint8 and src.dim() == 3 and src.shape[2] == 3
+    out = torch.empty((3, pad_h, pad_w), dtype=torch.float32)
+    m = torch.tensor([float(v) for v in mean], dtype=torch.float32)
+    sd = torch.tensor([float(v) for v in std], dtype=torch.float32)
+    st = lib().orc_preprocess_u8(src.data_ptr(), src.shape[0], src.shape[1], out.data_ptr(), int(new_h),
+                                 int(new_w), int(pad_h), int(pad_w), _FLIP[flip_direction], m.data_ptr(),
+                                 sd.data_ptr(), int(bool(to_rgb)))
+    assert st == 0, st
     return out

@@ -326,6 +326,38 @@ def _populate(m):
         m.is_list_of = lambda seq, t: isinstance(seq, list) and all(isinstance(s, t) for s in seq)
         m.is_seq_of = lambda seq, t, seq_type=None: all(isinstance(s, t) for s in seq)
         m.is_str = lambda x: isinstance(x, str)
+        # image arithmetic (mmcv -> OpenCV, both absent): this repo's restatement, so that the
+        # reference's TRANSFORM LOGIC (scales, boxes, flips, metas) can be pinned around it
+        from brcnn import pipelines as _P
+        m.imrescale = lambda img, scale, return_scale=False, interpolation='bilinear', backend=None: \
+            _P.imrescale(img, scale, return_scale)
+        m.imresize = lambda img, size, return_scale=False, interpolation='bilinear', out=None, backend=None: \
+            _P.imresize(img, size, return_scale)
+        m.imflip = _P.imflip
+        m.imnormalize = _P.imnormalize
+        m.impad = lambda img, shape=None, padding=None, pad_val=0, padding_mode='constant': \
+            _P.impad(img, shape, pad_val)
+        m.impad_to_multiple = _P.impad_to_multiple
+    elif name == 'mmcv.parallel':
+        from brcnn import pipelines as _P
+        m.DataContainer = _P.DataContainer
+    elif name in ('pycocotools.coco', 'pycocotools'):
+        from brcnn import datasets as _D
+
+        class COCO(_D.COCO):      # camelCase surface of pycocotools.coco.COCO over this repo's index
+            def getCatIds(self, catNms=(), supNms=(), catIds=()):
+                return _D.COCO.get_cat_ids(self, catNms)
+
+            def getImgIds(self, imgIds=(), catIds=()):
+                return _D.COCO.get_img_ids(self)
+
+            def getAnnIds(self, imgIds=(), catIds=(), areaRng=(), iscrowd=None):
+                return _D.COCO.get_ann_ids(self, imgIds)
+
+            loadAnns = _D.COCO.load_anns
+            loadImgs = _D.COCO.load_imgs
+            loadCats = _D.COCO.load_cats
+        m.COCO = COCO
     elif name == 'mmcv.utils':
         m.Registry = Registry
         m.build_from_cfg = build_from_cfg

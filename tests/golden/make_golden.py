@@ -352,7 +352,129 @@ def kat():
     print('kat_mmcv_ops.json', d['nms_keep'], d['soft_linear_inds'], d['soft_linear_scores'])
 
 
+from synth import synthetic_coco  # noqa: E402
+
+
+def g12_pipeline(cfg):
+    """The reference's Resize / RandomFlip / Normalize / Pad / DefaultFormatBundle / Collect /
+    MultiScaleFlipAug on a synthetic image + boxes (the pixel arithmetic is this repo's
+    restatement through the shim; scales, box maths, flip draws and metas are the reference's)."""
+    from mmdet.datasets.pipelines import Compose
+    rng = np.random.RandomState(5)
+    d = {}
+    train = [dict(type='Resize', img_scale=[(160, 96), (200, 128)], multiscale_mode='range', keep_ratio=True),
+             dict(type='RandomFlip', flip_ratio=0.5, direction=['horizontal', 'vertical']),
+             dict(type='Normalize', mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+             dict(type='Pad', size_divisor=32),
+             dict(type='DefaultFormatBundle'),
+             dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels'])]
+    test = [dict(type='MultiScaleFlipAug', img_scale=(160, 96), flip=False,
+                 transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'),
+                             dict(type='Normalize', mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375],
+                                  to_rgb=True),
+                             dict(type='Pad', size_divisor=32), dict(type='ImageToTensor', keys=['img']),
+                             dict(type='Collect', keys=['img'])])]
+    img = rng.randint(0, 256, (75, 113, 3), dtype=np.uint8)
+    boxes = np.array([[10, 12, 60, 50], [0, 0, 113, 75], [100, 60, 112.5, 74.2]], dtype=np.float32)
+    labels = np.array([0, 3, 1], dtype=np.int64)
+    d['img'], d['boxes'], d['labels'] = img, boxes, labels
+    d['train_cfg'] = np.array(json.dumps(train))
+    d['test_cfg'] = np.array(json.dumps(test))
+
+    def fresh():
+        return dict(img=img.copy(), img_shape=img.shape, ori_shape=img.shape, img_fields=['img'],
+                    filename='x.npy', ori_filename='x.npy', gt_bboxes=boxes.copy(), gt_labels=labels.copy(),
+                    bbox_fields=['gt_bboxes'])
+    pipe = Compose(train)
+    for s in range(6):
+        np.random.seed(40 + s)
+        out = pipe(fresh())
+        meta = out['img_metas'].data
+        t = out['img'].data
+        d[f'tr{s}_img_shape'] = np.array(t.shape)
+        d[f'tr{s}_img_crop'] = t[:, :24, :24]
+        d[f'tr{s}_img_sum'] = t.double().sum((1, 2))
+        d[f'tr{s}_img_tail'] = t[:, -40:, -40:]
+        d[f'tr{s}_boxes'] = out['gt_bboxes'].data
+        d[f'tr{s}_labels'] = out['gt_labels'].data
+        d[f'tr{s}_meta'] = np.array(json.dumps(dict(
+            img_shape=list(meta['img_shape']), pad_shape=list(meta['pad_shape']), ori_shape=list(meta['ori_shape']),
+            scale_factor=[float(v) for v in meta['scale_factor']], flip=bool(meta['flip']),
+            flip_direction=meta['flip_direction'])))
+    out = Compose(test)(fresh())
+    d['te_img_shape'] = np.array(out['img'][0].shape)
+    d['te_img_crop'] = out['img'][0][:, :24, :24]
+    d['te_img_sum'] = out['img'][0].double().sum((1, 2))
+    m = out['img_metas'][0].data
+    d['te_meta'] = np.array(json.dumps(dict(img_shape=list(m['img_shape']), pad_shape=list(m['pad_shape']),
+                                            scale_factor=[float(v) for v in m['scale_factor']], flip=bool(m['flip']))))
+    npz('g12_pipeline', **d)
+
+
+def g13_samplers():
+    """GroupSampler / DistributedGroupSampler / DistributedSampler index streams"""
+    from mmdet.datasets.samplers import DistributedGroupSampler, DistributedSampler, GroupSampler
+
+    class DS:
+        def __init__(self, flag):
+            self.flag = flag
+
+        def __len__(self):
+            return len(self.flag)
+    flag = (np.random.RandomState(1).rand(37) > 0.35).astype(np.uint8)
+    d = dict(flag=flag)
+    np.random.seed(11)
+    d['group_spg2'] = np.array(list(GroupSampler(DS(flag), samples_per_gpu=2)))
+    np.random.seed(12)
+    d['group_spg3'] = np.array(list(GroupSampler(DS(flag), samples_per_gpu=3)))
+    for world in (2, 4):
+        for rank in range(world):
+            s = DistributedGroupSampler(DS(flag), samples_per_gpu=2, num_replicas=world, rank=rank, seed=7)
+            s.set_epoch(3)
+            d[f'dgroup_w{world}_r{rank}'] = np.array(list(s))
+            t = DistributedSampler(DS(flag), num_replicas=world, rank=rank, shuffle=False)
+            d[f'dtest_w{world}_r{rank}'] = np.array(list(t))
+    npz('g13_samplers', **d)
+
+
+def g14_coco_dataset():
+    """the reference's CocoDataset (load_annotations / _filter_imgs / _parse_ann_info / flag /
+    results2json records) on the synthetic dataset of `synthetic_coco`"""
+    import tempfile
+    from mmdet.datasets import CocoDataset
+    with tempfile.TemporaryDirectory() as root:
+        ann_file, prefix = synthetic_coco(root)
+        classes = ('echinus', 'starfish', 'holothurian', 'scallop')
+        d = {}
+        for mode in ('train', 'test'):
+            ds = CocoDataset(ann_file=ann_file, pipeline=[], classes=classes, img_prefix=prefix,
+                             test_mode=(mode == 'test'))
+            d[f'{mode}_img_ids'] = np.array(ds.img_ids)
+            d[f'{mode}_len'] = np.array(len(ds))
+            if mode == 'train':
+                d['train_flag'] = ds.flag
+            for i in range(len(ds)):
+                a = ds.get_ann_info(i)
+                d[f'{mode}_{i}_bboxes'] = a['bboxes']
+                d[f'{mode}_{i}_labels'] = a['labels']
+                d[f'{mode}_{i}_ignore'] = a['bboxes_ignore']
+        rng = np.random.RandomState(9)
+        results = [[np.concatenate([np.sort(rng.rand(k, 2) * 50, 0), 50 + rng.rand(k, 2) * 40, rng.rand(k, 1)], 1)
+                    .astype(np.float32) for k in rng.randint(0, 3, 4)] for _ in range(len(ds))]
+        js = ds._det2json(results)
+        d['det_json'] = np.array(json.dumps(js))
+        for i, r in enumerate(results):
+            for c, x in enumerate(r):
+                d[f'res_{i}_{c}'] = x
+    npz('g14_coco_dataset', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'data':
+        g12_pipeline(None)
+        g13_samplers()
+        g14_coco_dataset()
+        return
     torch.set_num_threads(8)
     cfg = Config.fromfile(REF_CFG)
     kat()
