@@ -161,6 +161,37 @@ def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds
     return props, valid.to(torch.uint8)
 
 
+# ---- differentiable CPU restatements of brcnn.autograd (training path of the oracle pipeline) ---
+def _conv2d_nhwc_autograd(x, weight, bias, stride, pad):
+    y = F.conv2d(x.permute(0, 3, 1, 2), weight, bias, stride, pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _linear_autograd(x, weight, bias):
+    return F.linear(x, weight, bias)
+
+
+def _roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=56, sampling_ratio=0):
+    k, c = rois.size(0), feats_nhwc[0].shape[3]
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    rois = rois.float()
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lvls = torch.floor(torch.log2(scale / finest_scale + 1e-6)).clamp(min=0, max=len(feats_nhwc) - 1).long()
+    out = feats_nhwc[0].new_zeros(k, c, ph, pw)
+    for i, f in enumerate(feats_nhwc):
+        inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+        if inds.numel():
+            r = orc.roi_align(f.permute(0, 3, 1, 2).contiguous(), rois[inds], (ph, pw), 1.0 / strides[i],
+                              sampling_ratio, 'avg', True)
+            out = out.index_copy(0, inds, r)
+        else:
+            out = out + f.sum() * 0.          # keeps every level in the graph, as the reference does
+    return out.permute(0, 2, 3, 1).contiguous()
+
+
+_PATCH_AUTOGRAD = dict(conv2d_nhwc_autograd=_conv2d_nhwc_autograd, linear_autograd=_linear_autograd,
+                       roi_extract_autograd=_roi_extract_autograd)
+
 _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw,
               conv2d_nhwc=_conv2d_nhwc, conv2d_nhwc_multi=_conv2d_nhwc_multi,
               groupnorm_nhwc_multi=_groupnorm_multi, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
@@ -168,7 +199,7 @@ _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw
               nchw_to_nhwc=_nchw_to_nhwc, nhwc_to_nchw=_nhwc_to_nchw, roi_extract=_roi_extract,
               nms_ranges=_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode, rpn_topk=_rpn_topk,
               nms=orc.nms, soft_nms=orc.soft_nms, batched_nms=orc.batched_nms,
-              roi_align=orc.roi_align, RoIAlign=orc.RoIAlign)
+              roi_align=orc.roi_align, RoIAlign=orc.RoIAlign, sigmoid_focal_loss=orc.sigmoid_focal_loss)
 
 
 def available_cpus():
@@ -190,14 +221,20 @@ def patched():
     """swap brcnn.ops entry points for the CPU restatements (tests / cpu_baseline only)"""
     import brcnn  # noqa: F401
     from brcnn import ops
+    from brcnn import autograd as ag
     saved = {k: getattr(ops, k) for k in _PATCH}
+    saved_ag = {k: getattr(ag, k) for k in _PATCH_AUTOGRAD}
     for k, v in _PATCH.items():
         setattr(ops, k, v)
+    for k, v in _PATCH_AUTOGRAD.items():
+        setattr(ag, k, v)
     try:
         yield
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
+        for k, v in saved_ag.items():
+            setattr(ag, k, v)
 
 
 def timed_baseline(cfg, seed=0, batch=1, budget_s=20.0, threads=None):

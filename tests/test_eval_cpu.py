@@ -1,0 +1,115 @@
+"""not-gpu: COCO bbox mAP (brcnn.evaluation, restating pycocotools' COCOeval which is not
+installed: parity unpinned against the package itself) on known-answer cases worked out by
+hand from the algorithm: 101-point interpolated precision, 10 IoU thresholds, crowd / area
+range / maxDets handling."""
+import numpy as np
+import pytest
+
+import brcnn  # noqa: F401
+from brcnn.datasets import COCO
+from brcnn.evaluation import COCOeval, bbox_iou_xywh
+
+
+def _gt(images, anns, cats=(1,)):
+    c = COCO()
+    c.dataset = dict(images=[dict(id=i, width=500, height=500, file_name=f'{i}.npy') for i in images],
+                     categories=[dict(id=k, name=f'c{k}') for k in cats],
+                     annotations=[dict(id=j + 1, image_id=a[0], category_id=a[1], bbox=list(a[2]),
+                                       area=a[2][2] * a[2][3], iscrowd=a[3] if len(a) > 3 else 0)
+                                  for j, a in enumerate(anns)])
+    c.createIndex()
+    return c
+
+
+def _run(gt, dets, max_dets=(1, 10, 100)):
+    dt = gt.loadRes([dict(image_id=d[0], category_id=d[1], bbox=list(d[2]), score=d[3]) for d in dets])
+    ev = COCOeval(gt, dt, 'bbox')
+    ev.params.maxDets = list(max_dets)
+    ev.evaluate()
+    ev.accumulate()
+    ev.summarize()
+    return ev
+
+
+def test_iou_xywh_and_crowd():
+    iou = bbox_iou_xywh([[0, 0, 10, 10]], [[0, 0, 10, 10], [5, 0, 10, 10], [20, 20, 5, 5], [0, 0, 100, 100]],
+                        [0, 0, 0, 1])
+    assert iou[0, 0] == 1.0 and iou[0, 1] == pytest.approx(50 / 150) and iou[0, 2] == 0.0
+    assert iou[0, 3] == 1.0        # crowd: intersection over the DETECTION's area
+
+
+def test_perfect_detections():
+    gt = _gt([1, 2], [(1, 1, (10, 10, 50, 50)), (2, 1, (20, 20, 100, 100)), (2, 1, (200, 200, 20, 20))])
+    ev = _run(gt, [(1, 1, (10, 10, 50, 50), .9), (2, 1, (20, 20, 100, 100), .8), (2, 1, (200, 200, 20, 20), .7)])
+    assert ev.stats[0] == pytest.approx(1.0) and ev.stats[1] == pytest.approx(1.0) and ev.stats[2] == pytest.approx(1.0)
+    assert ev.stats[3] == pytest.approx(1.0)      # small: the 20x20 box
+    assert ev.stats[4] == pytest.approx(1.0)      # medium: 50x50 (area 2500)
+    assert ev.stats[5] == pytest.approx(1.0)      # large: 100x100
+    assert ev.stats[8] == pytest.approx(1.0)
+    assert ev.stats[6] == pytest.approx((1 + 0.5) / 2 if False else 2 / 3)   # AR@1: 1 of 1 + 1 of 2 gts -> 2/3
+
+
+def test_false_positive_ranked_first_halves_precision():
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50))])
+    ev = _run(gt, [(1, 1, (300, 300, 50, 50), .95), (1, 1, (10, 10, 50, 50), .9)])
+    assert ev.stats[0] == pytest.approx(0.5)         # precision 1/2 at every recall level
+    ev = _run(gt, [(1, 1, (300, 300, 50, 50), .5), (1, 1, (10, 10, 50, 50), .9)])
+    assert ev.stats[0] == pytest.approx(1.0)         # FP after the TP does not touch the envelope
+
+
+def test_half_recall_gives_51_of_101_points():
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50)), (1, 1, (200, 200, 50, 50))])
+    ev = _run(gt, [(1, 1, (10, 10, 50, 50), .9)])
+    assert ev.stats[0] == pytest.approx(51 / 101)    # recall thresholds 0, .01, ..., .50 reached
+    assert ev.stats[8] == pytest.approx(0.5)
+
+
+def test_iou_thresholds():
+    # detection shifted so that IoU = 40*50 / (2*2500 - 2000) = 2/3: TP for .50 .55 .60 .65 only
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50))])
+    ev = _run(gt, [(1, 1, (20, 10, 50, 50), .9)])
+    assert ev.stats[0] == pytest.approx(4 / 10)
+    assert ev.stats[1] == pytest.approx(1.0) and ev.stats[2] == 0.0
+
+
+def test_crowd_and_area_ranges_and_maxdets():
+    # a detection on a crowd region is ignored (neither TP nor FP)
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50)), (1, 1, (200, 200, 100, 100), 1)])
+    ev = _run(gt, [(1, 1, (10, 10, 50, 50), .8), (1, 1, (210, 210, 30, 30), .9), (1, 1, (220, 220, 30, 30), .85)])
+    assert ev.stats[0] == pytest.approx(1.0)
+    # small gt only counts in the 'small' range; ranges without gt report -1
+    gt = _gt([1], [(1, 1, (10, 10, 20, 20))])
+    ev = _run(gt, [(1, 1, (10, 10, 20, 20), .9)])
+    assert ev.stats[3] == pytest.approx(1.0) and ev.stats[4] == -1 and ev.stats[5] == -1
+    # maxDets: with 1 detection per image allowed only the top-scored (a miss) is kept
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50))])
+    ev = _run(gt, [(1, 1, (300, 300, 50, 50), .95), (1, 1, (10, 10, 50, 50), .9)])
+    assert ev.stats[6] == 0.0 and ev.stats[7] == pytest.approx(1.0)
+    # two categories are averaged
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50)), (1, 2, (100, 100, 50, 50))], cats=(1, 2))
+    ev = _run(gt, [(1, 1, (10, 10, 50, 50), .9)])
+    assert ev.stats[0] == pytest.approx(0.5)
+
+
+def test_dataset_evaluate_roundtrip(tmp_path):
+    from brcnn.datasets import CocoDataset
+    from tests.golden.synth import synthetic_coco
+    ann_file, prefix = synthetic_coco(str(tmp_path))
+    classes = ('echinus', 'starfish', 'holothurian', 'scallop')
+    ds = CocoDataset(ann_file=ann_file, pipeline=[], classes=classes, img_prefix=prefix, test_mode=True)
+    results = []
+    for i in range(len(ds)):        # every annotation COCOeval counts as ground truth, detected exactly
+        anns = [a for a in ds.coco.imgToAnns.get(ds.img_ids[i], []) if a['category_id'] in ds.cat_ids]
+        per_cls = []
+        for c in range(4):
+            b = [[a['bbox'][0], a['bbox'][1], a['bbox'][0] + a['bbox'][2], a['bbox'][1] + a['bbox'][3], 0.9]
+                 for a in anns if ds.cat2label[a['category_id']] == c and not a.get('iscrowd', 0)]
+            per_cls.append(np.array(b, dtype=np.float32).reshape(-1, 5))
+        results.append(per_cls)
+    out = ds.evaluate(results, metric='bbox', classwise=True, jsonfile_prefix=str(tmp_path / 'res'))
+    assert out['bbox_mAP'] == pytest.approx(1.0) and out['bbox_mAP_50'] == pytest.approx(1.0)
+    assert set(out['bbox_classwise']) == set(classes)
+    assert len(out['bbox_mAP_copypaste'].split()) == 6
+    assert (tmp_path / 'res.bbox.json').exists()
+    empty = [[np.zeros((0, 5), np.float32)] * 4 for _ in range(len(ds))]
+    assert ds.evaluate(empty) == {}
