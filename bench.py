@@ -63,6 +63,7 @@ def train_bench(args, world, rank, device):
     model = build_detector(cfg.model)
     model.load_state_dict(util.seeded_state_dict(model, seed=0))
     model = model.to(device).train()
+    model.set_compute_dtype(args.dtype)     # bf16: conv stack fwd/dgrad/wgrad on bf16 MFMA, fp32 master weights
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
                           weight_decay=cfg.optimizer.weight_decay)
@@ -105,10 +106,10 @@ def train_bench(args, world, rank, device):
             'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN train step',
             'value': world * args.batch * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': f'boosting_rcnn_r50_pafpn_1x_coco.py full train step, batch {args.batch} x '
-                                   '3x800x1344 per GPU, 20 GT/img, 512 RoIs/img, SGD+clip',
+                                   f'3x800x1344 per GPU, 20 GT/img, 512 RoIs/img, SGD+clip, {args.dtype} conv stack',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
             'loss': lv['loss']}))
     if world > 1:

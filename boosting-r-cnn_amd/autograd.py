@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 
 from . import lib as _L
 from . import ops
-from .ops import DT_F32, _ptr, _require_gpu, _stream, conv_out_size
+from .ops import DT_F32, DT_BF16, _ptr, _require_gpu, _stream, conv_out_size
 
 
 def _ints(vals):
@@ -30,7 +30,9 @@ class ConvNHWCFunction(Function):
     @staticmethod
     def forward(ctx, x_cat, weight, bias, batch, sizes, stride, pad):
         _require_gpu(x_cat, weight, bias)
-        w_p = weight.detach().float().permute(0, 2, 3, 1).contiguous()
+        # fp32 activations: exact-fp32 MFMA; bf16 activations: bf16 MFMA with fp32 accumulation
+        # (weights are cast per step from the fp32 master copy, gradients of weights stay fp32)
+        w_p = weight.detach().float().permute(0, 2, 3, 1).to(x_cat.dtype).contiguous()
         x_cat = x_cat.contiguous()
         y, out_sizes = ops.conv2d_nhwc_multi(x_cat, w_p, batch, sizes, None,
                                              bias.detach().float().contiguous() if bias is not None else None,
@@ -45,26 +47,27 @@ class ConvNHWCFunction(Function):
         x_cat, weight = ctx.saved_tensors
         batch, sizes, out_sizes, stride, pad, has_bias = ctx.cfg
         cout, cin, kh, kw = weight.shape
-        dy = dy.contiguous()
+        dy = dy.to(x_cat.dtype).contiguous()
+        dt = DT_F32 if x_cat.dtype == torch.float32 else DT_BF16
         lib = _L.load()
         L = len(sizes)
         hs, ws = _ints([h for h, _ in sizes]), _ints([w for _, w in sizes])
         ohs, ows = _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).contiguous()   # (Cin,KH,KW,Cout)
+            w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).to(x_cat.dtype).contiguous()   # (Cin,KH,KW,Cout)
             dx = torch.empty_like(x_cat)
             st = lib.brcnn_conv2d_dgrad_nhwc_multi(_ptr(dy), _ptr(w_t), _ptr(dx), batch, L, hs, ws, ohs,
-                                                   ows, cin, cout, kh, kw, stride, pad, DT_F32, _stream())
+                                                   ows, cin, cout, kh, kw, stride, pad, dt, _stream())
             _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
-                                                   cin, cout, kh, kw, stride, pad, DT_F32, _stream())
+                                                   cin, cout, kh, kw, stride, pad, dt, _stream())
             _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
             dw = dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0)
+            db = dy.float().sum(0)
         return dx, dw, db, None, None, None, None
 
 
@@ -86,7 +89,7 @@ def conv2d_nhwc_autograd(x, weight, bias, stride, pad):
     n, h, w, cin = x.shape
     kh, kw = weight.shape[2], weight.shape[3]
     ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
-    weight, bias, cout = _pad_cout(weight, bias)
+    weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)
     y = ConvNHWCFunction.apply(x.reshape(n * h * w, cin), weight, bias, n, ((h, w),), stride, pad)
     y = y.view(n, ho, wo, weight.shape[0])
     return y if cout == weight.shape[0] else y[..., :cout]
@@ -94,7 +97,7 @@ def conv2d_nhwc_autograd(x, weight, bias, stride, pad):
 
 def linear_autograd(x, weight, bias):
     """x (M,K) @ weight(N,K)^T + bias, differentiable (the 1x1 case with H=W=1)"""
-    weight, bias, cout = _pad_cout(weight, bias)
+    weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)
     y = ConvNHWCFunction.apply(x.contiguous(), weight.view(weight.shape[0], weight.shape[1], 1, 1),
                                bias, x.shape[0], ((1, 1),), 1, 0)
     return y if cout == weight.shape[0] else y[:, :cout]

@@ -110,7 +110,9 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
         y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
         if bn is not None:
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-            y = y * scale + (bn.bias - bn.running_mean * scale)
+            shift = bn.bias - bn.running_mean * scale
+            # bf16 activations stay bf16 (the affine parameters are rounded once per step)
+            y = y * scale.to(y.dtype) + shift.to(y.dtype)
         if residual is not None:
             y = y + residual
         return y.relu() if relu else y
@@ -183,8 +185,8 @@ class ConvModule(nn.Module):
         y = conv_bn_act_nhwc(x, self.conv, None, self._cache, False)
         if y.requires_grad:
             import torch.nn.functional as F
-            z = F.group_norm(y.permute(0, 3, 1, 2), norm.num_groups, norm.weight, norm.bias, norm.eps)
-            z = z.permute(0, 2, 3, 1)
+            z = F.group_norm(y.permute(0, 3, 1, 2).float(), norm.num_groups, norm.weight, norm.bias, norm.eps)
+            z = z.permute(0, 2, 3, 1).to(y.dtype)
             return (z.relu() if self.with_activation else z).contiguous()
         return ops.groupnorm_nhwc(y, norm.weight.detach(), norm.bias.detach(), norm.num_groups,
                                   norm.eps, self.with_activation)

@@ -570,6 +570,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     if (dtype != BRCNN_DT_F32 && !bf16) return BRCNN_EINVAL;
     if (bf16 && cin % 64 != 0) return BRCNN_EINVAL;
     if (dilate > 1 && (cin % 32 != 0 || stride != 1)) return BRCNN_EINVAL;
+    if (bf16 && (cout & 7) && dtype == BRCNN_DT_BF16 && residual) return BRCNN_EINVAL;
     ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;

@@ -103,10 +103,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams 
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
         for (int j = 0; j < AG; j++) {
-            const int hi = (a_hw[j] >> 16) - 4096 + kh;
-            const int wi = (a_hw[j] & 0xffff) - 4096 + kw;
-            const bool ok = (a_base[j] >= 0) & ((unsigned)hi < (unsigned)a_H[j]) &
-                            ((unsigned)wi < (unsigned)a_W[j]);
+            int hi = (a_hw[j] >> 16) - 4096 + kh;
+            int wi = (a_hw[j] & 0xffff) - 4096 + kw;
+            bool ok = a_base[j] >= 0;
+            if (p.dilate > 1) {      // zero-stuffed input (data gradient of a strided conv)
+                ok = ok & (hi >= 0) & (wi >= 0);
+                const int qh = hi / p.dilate, qw = wi / p.dilate;
+                ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
+                hi = qh;
+                wi = qw;
+            }
+            ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
             const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j]) * 2 : OOB;
             float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
@@ -297,7 +304,6 @@ int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT
 
 namespace brcnn_conv {
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
-    if (p.dilate != 1) return BRCNN_EINVAL;      // inference path only this round
     int t = g_bf16_tile;
     if (t == 0) {
         // enough 128x128 tiles to give every CU >= 4 workgroups -> the big tile; else smaller

@@ -162,14 +162,22 @@ void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
 
 }  // namespace
 
+int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch, int num_segments,
+                              const int* heights_host, const int* widths_host, int cin, int cout,
+                              int kh, int kw, int stride, int pad, hipStream_t stream);   // conv_wgrad_bf16.hip
+
 BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void* dw, int batch,
                                             int num_segments, const int* heights_host,
                                             const int* widths_host, int cin, int cout, int kh,
                                             int kw, int stride, int pad, int dtype, void* stream) {
     if (!x || !dy || !dw || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || pad < 0 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
-        !heights_host || !widths_host || dtype != BRCNN_DT_F32 || (cin & 3) || (cout & 3))
+        !heights_host || !widths_host || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) || (cin & 3) ||
+        (cout & 3))
         return BRCNN_EINVAL;
+    if (dtype == BRCNN_DT_BF16)
+        return brcnn_wgrad_bf16_dispatch(x, dy, dw, batch, num_segments, heights_host, widths_host, cin, cout,
+                                         kh, kw, stride, pad, (hipStream_t)stream);
     WgradParams p = {};
     p.dy = (const float*)dy; p.x = (const float*)x; p.dw = (float*)dw;
     p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;

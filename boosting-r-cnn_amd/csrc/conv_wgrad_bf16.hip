@@ -1,0 +1,273 @@
+// bf16 weight gradient of the NHWC convolution / linear layer (BASELINE configs[2]: "bf16 MFMA
+// backbone, full train step"):   dW[co, k] (fp32) += sum_m dY[m, co] * A[m, k],  dY / x in bf16.
+//
+// Same split-M decomposition as the fp32 kernel (conv_wgrad.hip): grid = (co tiles x k tiles) x
+// slices of the M = N*Ho*Wo reduction, fp32 atomics into a zero-filled dW.  The difference is
+// the operand fetch: v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE reduction elements per lane,
+// but both operands are reduction-MAJOR in memory ((M,Cout) and (M,K) rows).  The tiles are
+// therefore staged exactly as they lie ([m][64 columns] = 128-byte rows, LDS-DMA, XOR-swizzled
+// 16-byte chunks) and read with the gfx950 transposing LDS load `ds_read_b64_tr_b16`: a
+// 16-lane group presents the 8-byte pieces of a [4 m][16 columns] block (lane t: row t>>2,
+// columns 4(t&3)..+3) and lane t receives column t of the 4 rows.  Two such reads give a lane the
+// 8 reduction elements of its column -- the MFMA A (co) and B (k) fragments -- with no
+// ds_write / shuffle pass.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+constexpr int OOB = 0x7fffffff;
+constexpr int TM = 64;          // reduction rows per LDS tile
+
+struct WgradHParams {
+    const unsigned short* dy;   // (M, Cout) bf16
+    const unsigned short* x;    // (N, H, W, Cin) bf16 segments back to back
+    float* dw;                  // (Cout, K) fp32
+    int Cin, Cout, KH, KW, stride, pad, M, K;
+    int tiles_co, tiles_k, slices, rows_per_slice;
+    unsigned dy_bytes, x_bytes;
+    int nseg;
+    int seg_m0[BRCNN_MAX_LEVELS + 1];
+    int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
+    long long seg_xoff[BRCNN_MAX_LEVELS];
+    unsigned seg_mhw[BRCNN_MAX_LEVELS], seg_shw[BRCNN_MAX_LEVELS], seg_mw[BRCNN_MAX_LEVELS], seg_sw[BRCNN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned magic, unsigned shift) {
+    return (unsigned)(((unsigned long long)__umulhi(x, magic) + x) >> shift);
+}
+
+// Output tile (64*WT) x (64*WT); 4 waves 2x2, each WT x WT MFMA tiles.  LDS per operand and
+// buffer: WT column blocks of [64 m][64 columns] bf16 (128-byte rows, physical 16-byte chunk
+// c' of row r holds logical chunk c' ^ ((r>>1)&7)).
+template <int WT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    constexpr int BLK = TM * 64;                     // elements of one [64][64] block
+    unsigned short* Ya = smem;                       // [2][WT][64][64]
+    unsigned short* Xa = smem + 2 * WT * BLK;        // [2][WT][64][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_co * p.tiles_k * p.slices;
+    int b;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        b = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tiles = p.tiles_co * p.tiles_k;
+    const int slice = b / tiles;
+    b -= slice * tiles;
+    const int tk = b % p.tiles_k, tco = b / p.tiles_k;
+    const int co0 = tco * 64 * WT, k0 = tk * 64 * WT;
+    const int m_begin = slice * p.rows_per_slice;
+    const int m_end = min(p.M, m_begin + p.rows_per_slice);
+    if (m_begin >= m_end) return;
+
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+
+    // DMA: one wave instruction fills 8 rows x 128 B of one block; wave w owns row groups 2w, 2w+1
+    const int rg_row = lane >> 3, pc = lane & 7;
+    int y_col[WT], x_ci[WT], x_kh[WT], x_kw[WT];
+    bool y_ok[WT], x_ok[WT];
+
+    f32x16 acc[WT][WT];
+#pragma unroll
+    for (int a = 0; a < WT; a++)
+#pragma unroll
+        for (int c = 0; c < WT; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+    auto dma_tile = [&](int mt, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int row = (wave * 2 + j) * 8 + rg_row;
+            const int lc = (pc ^ ((row >> 1) & 7)) * 8;          // logical column of this lane's chunk
+            const int m = mt + row;
+            const bool m_ok = m < m_end;
+            int n = 0, hi0 = 0, wi0 = 0, H = 0, W = 0, xb = 0;
+            if (m_ok) {
+                int sg = 0;
+#pragma unroll
+                for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                    if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+                const int ml = m - p.seg_m0[sg];
+                const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg];
+                H = p.seg_H[sg]; W = p.seg_W[sg];
+                n = (int)fastdiv((unsigned)ml, p.seg_mhw[sg], p.seg_shw[sg]);
+                const int rem = ml - n * (Ho * Wo);
+                const int ho = (int)fastdiv((unsigned)rem, p.seg_mw[sg], p.seg_sw[sg]);
+                const int wo = rem - ho * Wo;
+                hi0 = ho * p.stride - p.pad;
+                wi0 = wo * p.stride - p.pad;
+                xb = (int)p.seg_xoff[sg] + n * H * W * p.Cin;
+            }
+#pragma unroll
+            for (int cb = 0; cb < WT; cb++) {
+                const int co = co0 + cb * 64 + lc;
+                const int offy = (m_ok && co < p.Cout) ? (m * p.Cout + co) * 2 : OOB;
+                const int k = k0 + cb * 64 + lc;
+                int offx = OOB;
+                if (m_ok && k < p.K) {
+                    const int tap = k / p.Cin;
+                    const int ci = k - tap * p.Cin;
+                    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                    const int hi = hi0 + kh, wi = wi0 + kw;
+                    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                        offx = (xb + (hi * W + wi) * p.Cin + ci) * 2;
+                }
+                unsigned short* dy_dst = Ya + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
+                unsigned short* x_dst = Xa + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)dy_dst, 16, offy, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)x_dst, 16, offx, 0, 0, 0);
+            }
+        }
+    };
+    (void)y_col; (void)x_ci; (void)x_kh; (void)x_kw; (void)y_ok; (void)x_ok;
+
+    // transposing read of one 8-element fragment: 32 columns starting at tile-local column
+    // `col0`, reduction rows ks*16 + 8*lh + (0..7)
+    const int g = lane >> 4, t = lane & 15;
+    auto frag = [&](const unsigned short* base, int col0, int ks) -> bf16x8 {
+        const int col = col0 + 16 * (g & 1) + 4 * (t & 3);      // tile-local column of this lane's piece
+        const unsigned short* blk = base + (col >> 6) * BLK;
+        const int cc = col & 63;
+        s16x4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int row = ks * 16 + 8 * (g >> 1) + 4 * q + (t >> 2);
+            const int off = row * 64 + (((cc >> 3) ^ ((row >> 1) & 7)) << 3) + (cc & 4);
+            v[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(blk + off));
+        }
+        union { s16x4 h[2]; bf16x8 f; } u;
+        u.h[0] = v[0];
+        u.h[1] = v[1];
+        return u.f;
+    };
+
+    dma_tile(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int mt = m_begin; mt < m_end; mt += TM) {
+        if (mt + TM < m_end) dma_tile(mt + TM, cur ^ 1);
+        const unsigned short* ya = Ya + cur * WT * BLK;
+        const unsigned short* xa = Xa + cur * WT * BLK;
+#pragma unroll
+        for (int ks = 0; ks < TM / 16; ks++) {
+            bf16x8 af[WT], bfr[WT];
+#pragma unroll
+            for (int a = 0; a < WT; a++) af[a] = frag(ya, (wm * WT + a) * 32, ks);
+#pragma unroll
+            for (int c = 0; c < WT; c++) bfr[c] = frag(xa, (wn * WT + c) * 32, ks);
+#pragma unroll
+            for (int a = 0; a < WT; a++)
+#pragma unroll
+                for (int c = 0; c < WT; c++)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // D[row = co][col = k]:  col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int c = 0; c < WT; c++) {
+        const int kk = k0 + (wn * WT + c) * 32 + li;
+        if (kk >= p.K) continue;
+#pragma unroll
+        for (int a = 0; a < WT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + (wm * WT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.K + kk, acc[a][c][r]);
+            }
+    }
+}
+
+void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
+    unsigned l = 0;
+    while ((1ull << l) < d) l++;
+    *magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *shift = l;
+}
+
+template <int WT>
+int launch(WgradHParams& p, hipStream_t s) {
+    const int T = 64 * WT;
+    p.tiles_co = (p.Cout + T - 1) / T;
+    p.tiles_k = (p.K + T - 1) / T;
+    const int tiles = p.tiles_co * p.tiles_k;
+    int slices = (4096 + tiles - 1) / tiles;
+    const int max_slices = (p.M + 511) / 512;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    int rps = (p.M + slices - 1) / slices;
+    rps = (rps + TM - 1) / TM * TM;
+    p.slices = (p.M + rps - 1) / rps;
+    p.rows_per_slice = rps;
+    const size_t lds = (size_t)2 * 2 * WT * TM * 64 * sizeof(unsigned short);
+    static bool attr_done = false;
+    if (!attr_done) {
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<WT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<WT>, dim3(tiles * p.slices), dim3(256), lds, s, p);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+int g_wgrad_bf16_tile = 0;      // tuning hook: 0 heuristic, 1 = 64x64, 2 = 128x128
+
+}  // namespace
+
+// entry used by brcnn_conv2d_wgrad_nhwc_multi for dtype == BRCNN_DT_BF16
+int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch, int num_segments,
+                              const int* heights_host, const int* widths_host, int cin, int cout,
+                              int kh, int kw, int stride, int pad, hipStream_t stream) {
+    if ((cin & 7) || (cout & 7)) return BRCNN_EINVAL;
+    WgradHParams p = {};
+    p.dy = (const unsigned short*)dy; p.x = (const unsigned short*)x; p.dw = (float*)dw;
+    p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.nseg = num_segments;
+    long long m_total = 0, x_off = 0;
+    for (int s = 0; s < num_segments; s++) {
+        const int H = heights_host[s], W = widths_host[s];
+        const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+        if (H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+        p.seg_H[s] = H; p.seg_W[s] = W; p.seg_Ho[s] = Ho; p.seg_Wo[s] = Wo;
+        p.seg_m0[s] = (int)m_total;
+        p.seg_xoff[s] = x_off;
+        magic_for((unsigned)(Ho * Wo), &p.seg_mhw[s], &p.seg_shw[s]);
+        magic_for((unsigned)Wo, &p.seg_mw[s], &p.seg_sw[s]);
+        m_total += (long long)batch * Ho * Wo;
+        x_off += (long long)batch * H * W * cin;
+    }
+    for (int s = num_segments; s <= BRCNN_MAX_LEVELS; s++) p.seg_m0[s] = (int)m_total;
+    if (m_total * cout * 2 >= 0x7fffffffLL || x_off * 2 >= 0x7fffffffLL) return BRCNN_EINVAL;
+    p.M = (int)m_total;
+    p.K = kh * kw * cin;
+    p.dy_bytes = (unsigned)(m_total * cout * 2);
+    p.x_bytes = (unsigned)(x_off * 2);
+    int wt = g_wgrad_bf16_tile;
+    if (wt == 0) wt = (cout >= 128 && p.K >= 128) ? 2 : 1;
+    return wt == 2 ? launch<2>(p, stream) : launch<1>(p, stream);
+}
+
+BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
+    if (wt < 0 || wt > 2) return BRCNN_EINVAL;
+    g_wgrad_bf16_tile = wt;
+    return 0;
+}

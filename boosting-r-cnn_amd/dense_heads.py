@@ -176,7 +176,7 @@ class ATSSRPNHead(AnchorHead):
             # training: the three heads as one differentiable 54-channel conv
             heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
             y = conv2d_nhwc_autograd(x, torch.cat([h.weight for h in heads], 0),
-                                     torch.cat([h.bias for h in heads], 0), 1, self.rpn_cls.padding[0])
+                                     torch.cat([h.bias for h in heads], 0), 1, self.rpn_cls.padding[0]).float()
             a, c = self.num_anchors, self.cls_out_channels
             return (y[..., :a * c], y[..., a * c:a * c + 4 * a] * scale, y[..., a * c + 4 * a:])
         cls = self._head_conv(x, self.rpn_cls, self._head_caches[0], None)
@@ -199,7 +199,7 @@ class ATSSRPNHead(AnchorHead):
 
         from .autograd import conv2d_nhwc_autograd, wants_grad
         if wants_grad(x, conv.weight, conv.bias, scale):
-            y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, 1, conv.padding[0])
+            y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, 1, conv.padding[0]).float()
             return y * scale if scale is not None else y
         w, s, b = cache.get(srcs, builder)
         return ops.conv2d_nhwc(x, w, s, b, None, False, 1, conv.padding[0])

@@ -187,6 +187,8 @@ int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int b
                                   int num_segments, const int *heights_host,
                                   const int *widths_host, int cin, int cout, int kh, int kw,
                                   int stride, int pad, int dtype, void *stream);
+/* tuning hook of the bf16 wgrad kernel: 0 heuristic, 1 = 64x64 output tile, 2 = 128x128 */
+int brcnn_conv_set_tile_wgrad_bf16(int wt);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel NCHW image + folded BN +
  * ReLU (resnet.py:599-611,631-636) -> y (N,Ho,Wo,Cout) NHWC.  w_packed (Cout,7,1,32) fp32 or

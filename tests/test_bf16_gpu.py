@@ -167,3 +167,105 @@ def test_detector_bf16_close_to_fp32():
     dist = np.abs(d[0][:, None, :4] - d[1][None, :, :4]).max(-1)
     ds = np.abs(d[0][:, None, 4] - d[1][None, :, 4])
     assert ((dist < 2.0) & (ds < 0.05)).any(1).mean() > 0.7
+
+
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, H, W, Cout, k, stride, pad)
+    (2, 64, 24, 40, 64, 1, 1, 0),
+    (2, 64, 24, 40, 256, 3, 1, 1),
+    (1, 128, 30, 31, 128, 3, 2, 1),
+    (2, 256, 25, 42, 512, 1, 2, 0),
+    (1, 256, 13, 21, 54, 3, 1, 1),         # ragged Cout: padded to 64 inside
+    (3, 512, 9, 14, 128, 3, 1, 1),
+])
+def test_conv_autograd_bf16(cfg):
+    """bf16 forward / dgrad (bf16 MFMA, zero-stuffed dy for stride 2) / wgrad (transposing LDS
+    reads) against the fp64 gradients of the same bf16-rounded operands"""
+    from brcnn.autograd import conv2d_nhwc_autograd
+    n, cin, h, w, cout, k, stride, pad = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 997)
+    x = _bf(torch.randn(n, cin, h, w, generator=g))
+    wt = _bf(torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g)
+    xr = x.double().requires_grad_()
+    wr = wt.double().requires_grad_()
+    br = b.double().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride, pad)
+    go = _bf(torch.randn(ref.shape, generator=g))
+    ref.backward(go.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV, BF).requires_grad_()
+    wg = wt.to(DEV).requires_grad_()          # fp32 master weight whose values are bf16-representable
+    bg = b.to(DEV).requires_grad_()
+    y = conv2d_nhwc_autograd(xg, wg, bg, stride, pad)
+    assert y.dtype == BF and xg.grad is None
+    y.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV, BF))
+    assert _rne_close(y.detach().float().permute(0, 3, 1, 2).cpu().double(), ref.detach())
+    assert xg.grad.dtype == BF and wg.grad.dtype == torch.float32
+    assert _rne_close(xg.grad.float().permute(0, 3, 1, 2).cpu().double(), xr.grad)
+    dw, db = wg.grad.cpu().double(), bg.grad.cpu().double()
+    assert (dw - wr.grad).abs().max().item() <= 2e-4 * max(1.0, wr.grad.abs().max().item())
+    assert (db - br.grad).abs().max().item() <= 2e-4 * max(1.0, br.grad.abs().max().item())
+
+
+def test_wgrad_bf16_tiles_and_multi_level_agree():
+    """64x64 and 128x128 output tiles, one multi-level launch vs per-level launches"""
+    from brcnn import lib
+    from brcnn.autograd import ConvNHWCFunction
+    g = torch.Generator().manual_seed(6)
+    sizes = [(20, 32), (10, 16), (5, 8)]
+    B, C = 2, 256
+    feats = [torch.randn(B * h * w, C, generator=g).to(DEV, BF) for h, w in sizes]
+    wt = (torch.randn(C, C, 3, 3, generator=g) / 48).to(DEV)
+    outs = {}
+    for tile in (1, 2):
+        lib.load().brcnn_conv_set_tile_wgrad_bf16(tile)
+        w1 = wt.clone().requires_grad_()
+        xc = torch.cat(feats, 0).requires_grad_()
+        y = ConvNHWCFunction.apply(xc, w1, None, B, tuple(sizes), 1, 1)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(DEV, BF)
+        y.backward(gy)
+        outs[tile] = (w1.grad.clone(), xc.grad.clone())
+    lib.load().brcnn_conv_set_tile_wgrad_bf16(0)
+    assert torch.allclose(outs[1][0], outs[2][0], rtol=1e-4, atol=1e-3)      # atomics order differs
+    assert torch.equal(outs[1][1], outs[2][1])
+    acc, o = torch.zeros_like(wt), 0
+    for f, (h, w) in zip(feats, sizes):
+        w2 = wt.clone().requires_grad_()
+        x2 = f.clone().requires_grad_()
+        y2 = ConvNHWCFunction.apply(x2, w2, None, B, ((h, w),), 1, 1)
+        y2.backward(gy[o:o + B * h * w])
+        assert torch.equal(x2.grad, outs[2][1][o:o + B * h * w])
+        acc += w2.grad
+        o += B * h * w
+    assert torch.allclose(acc, outs[2][0], rtol=1e-4, atol=1e-3)
+
+
+def test_train_step_bf16_close_to_fp32():
+    cfg = Config.fromfile(CFG)
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    res = {}
+    try:
+        for mode in ('f32', 'bf16'):
+            m = build_detector(cfg.model)
+            m.load_state_dict(util.seeded_state_dict(m, seed=10))
+            m = m.to(DEV).train()
+            m.set_compute_dtype(mode)
+            torch.manual_seed(77)
+            losses = m.forward_train(img.to(DEV), metas, [g_.to(DEV) for g_ in gts], [l.to(DEV) for l in gls])
+            loss, log_vars = m._parse_losses(losses)
+            loss.backward()
+            grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+            res[mode] = (log_vars, grads)
+    finally:
+        blocks.set_compute_dtype('f32')
+    lf, lb = res['f32'][0], res['bf16'][0]
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_rpn_iou', 'loss_bbox', 'loss'):
+        assert abs(lb[k] - lf[k]) <= 0.05 * abs(lf[k]) + 1e-3, (k, lb[k], lf[k])
+    gf, gb = res['f32'][1], res['bf16'][1]
+    assert set(gf) == set(gb)
+    for k in ('backbone.layer2.0.conv1.weight', 'backbone.layer4.2.conv3.weight', 'neck.lateral_convs.0.conv.weight',
+              'rpn_head.rpn_convs.3.conv.weight', 'rpn_head.rpn_cls.weight', 'backbone.layer3.0.bn1.weight'):
+        a, b = gf[k].flatten(), gb[k].flatten()
+        assert torch.isfinite(b).all()
+        cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-20)
+        assert cos > 0.9, (k, cos.item())
