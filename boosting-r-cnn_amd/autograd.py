@@ -138,6 +138,58 @@ def roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=56
                                     sampling_ratio, *[f.contiguous() for f in feats_nhwc])
 
 
+class BnActFunction(Function):
+    """out = [relu](z * scale + shift [+ res]) over NHWC rows, one kernel each way
+    (`brcnn_bn_act_forward/backward`); scale / shift are the (C,) fp32 eval-BN affine."""
+
+    @staticmethod
+    def forward(ctx, z, scale, shift, res, relu):
+        _require_gpu(z, scale, shift, res)
+        z = z.contiguous()
+        c = z.shape[-1]
+        rows = z.numel() // c
+        dt = DT_F32 if z.dtype == torch.float32 else DT_BF16
+        sc, sh = scale.detach().float().contiguous(), shift.detach().float().contiguous()
+        r = res.contiguous() if res is not None else None
+        out = torch.empty_like(z)
+        st = _L.load().brcnn_bn_act_forward(_ptr(z), _ptr(sc), _ptr(sh), _ptr(r), _ptr(out), rows, c,
+                                            int(relu), dt, _stream())
+        _L.check(st, 'brcnn_bn_act_forward')
+        ctx.save_for_backward(z, sc, out if relu else None)
+        ctx.cfg = (relu, res is not None, dt, rows, c)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        z, sc, out = ctx.saved_tensors
+        relu, has_res, dt, rows, c = ctx.cfg
+        dout = dout.to(z.dtype).contiguous()
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[3] else None
+        dscale = torch.empty(c, dtype=torch.float32, device=z.device)
+        dshift = torch.empty(c, dtype=torch.float32, device=z.device)
+        lib = _L.load()
+        nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
+        ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
+        st = lib.brcnn_bn_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(sc), _ptr(dz), _ptr(dres),
+                                       _ptr(dscale), _ptr(dshift), _ptr(ws), nb, rows, c, int(relu), dt, _stream())
+        _L.check(st, 'brcnn_bn_act_backward')
+        return dz, dscale, dshift, dres, None
+
+
+def bn_act_supported(z):
+    """channel-vector count a power of two (every BatchNorm width of the ResNet family)"""
+    c = z.shape[-1]
+    v = 4 if z.dtype == torch.float32 else 8
+    n = c // v
+    return c % v == 0 and n > 0 and (n & (n - 1)) == 0 and z.dtype in (torch.float32, torch.bfloat16)
+
+
+def bn_act_autograd(z, scale, shift, res=None, relu=True):
+    return BnActFunction.apply(z, scale, shift, res, relu)
+
+
 def wants_grad(x, *params):
     """True when the op must be recorded for backward (grad mode on and some input or
     parameter is trainable); frozen layers keep using the fused inference kernels."""

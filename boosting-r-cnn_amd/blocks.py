@@ -111,6 +111,9 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
         if bn is not None:
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale
+            from .autograd import bn_act_autograd, bn_act_supported
+            if bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
+                return bn_act_autograd(y, scale, shift, residual, relu)     # one kernel each way
             # bf16 activations stay bf16 (the affine parameters are rounded once per step)
             y = y * scale.to(y.dtype) + shift.to(y.dtype)
         if residual is not None:

@@ -145,10 +145,18 @@ class AnchorGenerator:
         return (base_anchors[None, :, :] + shifts[:, None, :]).view(-1, 4)
 
     def grid_anchors(self, featmap_sizes, device='cuda'):
+        """anchors of all levels; cached per (map sizes, device): they are constants of the
+        geometry, and rebuilding them every step costs an H2D copy (a stream sync) per level"""
         assert self.num_levels == len(featmap_sizes)
-        return [self.single_level_grid_anchors(self.base_anchors[i].to(device), featmap_sizes[i],
-                                               self.strides[i], device=device)
-                for i in range(self.num_levels)]
+        key = (tuple(tuple(int(v) for v in s) for s in featmap_sizes), str(device))
+        cache = self.__dict__.setdefault('_grid_cache', {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = [self.single_level_grid_anchors(self.base_anchors[i].to(device), featmap_sizes[i],
+                                                         self.strides[i], device=device)
+                          for i in range(self.num_levels)]
+        return list(cache[key])
 
     grid_priors = grid_anchors
 
@@ -164,8 +172,25 @@ class AnchorGenerator:
         valid = xx & yy
         return valid[:, None].expand(valid.size(0), num_base_anchors).contiguous().view(-1)
 
+    def all_valid(self, featmap_sizes, pad_shape):
+        """host-side knowledge: True when `valid_flags` would be all ones (the padded image
+        covers every cell of every level) -- lets the target code skip the masked gather /
+        scatter and their device->host syncs"""
+        h, w = pad_shape[:2]
+        for i, (feat_h, feat_w) in enumerate(featmap_sizes):
+            stride = self.strides[i]
+            if int(np.ceil(h / stride[1])) < feat_h or int(np.ceil(w / stride[0])) < feat_w:
+                return False
+        return True
+
     def valid_flags(self, featmap_sizes, pad_shape, device='cuda'):
         assert self.num_levels == len(featmap_sizes)
+        key = (tuple(tuple(int(v) for v in s) for s in featmap_sizes), tuple(int(v) for v in pad_shape[:2]), str(device))
+        cache = self.__dict__.setdefault('_flag_cache', {})
+        if key in cache:
+            return list(cache[key])
+        if len(cache) > 256:
+            cache.clear()
         flags = []
         for i in range(self.num_levels):
             stride = self.strides[i]
@@ -176,7 +201,23 @@ class AnchorGenerator:
             flags.append(self.single_level_valid_flags((feat_h, feat_w),
                                                        (valid_feat_h, valid_feat_w),
                                                        self.num_base_anchors[i], device=device))
-        return flags
+        cache[key] = flags
+        return list(flags)
+
+
+_CONST_CACHE = {}
+
+
+def const_like(values, like):
+    """small constant tensor on `like`'s device / dtype, uploaded once (new_tensor of a python
+    list is an H2D copy, i.e. a stream sync, on every call)"""
+    key = (tuple(float(v) for v in values), str(like.device), like.dtype)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 256:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = like.new_tensor(list(values))
+    return t
 
 
 # ----------------------------------------------------------------------------- coder
@@ -197,15 +238,15 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     dw = torch.log(gw / pw)
     dh = torch.log(gh / ph)
     deltas = torch.stack([dx, dy, dw, dh], dim=-1)
-    means = deltas.new_tensor(means).unsqueeze(0)
-    stds = deltas.new_tensor(stds).unsqueeze(0)
+    means = const_like(means, deltas).unsqueeze(0)
+    stds = const_like(stds, deltas).unsqueeze(0)
     return deltas.sub_(means).div_(stds)
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
                wh_ratio_clip=16 / 1000, clip_border=True, add_ctr_clamp=False, ctr_clamp=32):
-    means = deltas.new_tensor(means).view(1, -1).repeat(1, deltas.size(-1) // 4)
-    stds = deltas.new_tensor(stds).view(1, -1).repeat(1, deltas.size(-1) // 4)
+    means = const_like(means, deltas).view(1, -1).repeat(1, deltas.size(-1) // 4)
+    stds = const_like(stds, deltas).view(1, -1).repeat(1, deltas.size(-1) // 4)
     denorm = deltas * stds + means
     dx, dy, dw, dh = denorm[..., 0::4], denorm[..., 1::4], denorm[..., 2::4], denorm[..., 3::4]
     x1, y1, x2, y2 = rois[..., 0], rois[..., 1], rois[..., 2], rois[..., 3]
@@ -235,12 +276,13 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     bboxes = torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
     if clip_border and max_shape is not None:
         if not isinstance(max_shape, torch.Tensor):
-            max_shape = x1.new_tensor(max_shape)
+            flat = all(not isinstance(v, (list, tuple, np.ndarray)) for v in max_shape)
+            max_shape = const_like(max_shape, x1) if flat else x1.new_tensor(max_shape)
         max_shape = max_shape[..., :2].type_as(x1)
         if max_shape.ndim == 2:
             assert bboxes.ndim == 3
             assert max_shape.size(0) == bboxes.size(0)
-        min_xy = x1.new_tensor(0)
+        min_xy = const_like([0], x1)[0]
         max_xy = torch.cat([max_shape] * (deltas.size(-1) // 2), dim=-1).flip(-1).unsqueeze(-2)
         bboxes = torch.where(bboxes < min_xy, min_xy, bboxes)
         bboxes = torch.where(bboxes > max_xy, max_xy, bboxes)
@@ -300,7 +342,7 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
         if mode == 'giou':
             enclosed_lt = torch.min(bboxes1[..., :, None, :2], bboxes2[..., None, :, :2])
             enclosed_rb = torch.max(bboxes1[..., :, None, 2:], bboxes2[..., None, :, 2:])
-    eps = union.new_tensor([eps])
+    eps = const_like([eps], union)
     union = torch.max(union, eps)
     ious = overlap / union
     if mode in ['iou', 'iof']:
@@ -378,13 +420,16 @@ class MaxIoUAssigner:
             return AssignResult(num_gts, assigned, max_overlaps, labels=labels)
         max_overlaps, argmax_overlaps = overlaps.max(dim=0)
         gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
+        # masked assignments as `where` (same values; boolean index_put_ would sync with the host)
+        zero = assigned.new_zeros(())
         if isinstance(self.neg_iou_thr, float):
-            assigned[(max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr)] = 0
+            assigned = torch.where((max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr), zero, assigned)
         elif isinstance(self.neg_iou_thr, tuple):
             assert len(self.neg_iou_thr) == 2
-            assigned[(max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1])] = 0
+            assigned = torch.where((max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1]),
+                                   zero, assigned)
         pos_inds = max_overlaps >= self.pos_iou_thr
-        assigned[pos_inds] = argmax_overlaps[pos_inds] + 1
+        assigned = torch.where(pos_inds, argmax_overlaps + 1, assigned)
         if self.match_low_quality:
             # the reference loops over gts in order, later gts overriding earlier ones
             # (max_iou_assigner.py:194-200); the same result without a host loop:
@@ -398,10 +443,8 @@ class MaxIoUAssigner:
                 for i in torch.nonzero(ok, as_tuple=False).flatten().tolist():
                     assigned[gt_argmax_overlaps[i]] = i + 1
         if gt_labels is not None:
-            labels = assigned.new_full((num_bboxes,), -1)
-            pos = torch.nonzero(assigned > 0, as_tuple=False).squeeze()
-            if pos.numel() > 0:
-                labels[pos] = gt_labels[assigned[pos] - 1]
+            labels = torch.where(assigned > 0, gt_labels[(assigned - 1).clamp(min=0)],
+                                 assigned.new_full((), -1))
         else:
             labels = None
         return AssignResult(num_gts, assigned, max_overlaps, labels=labels)

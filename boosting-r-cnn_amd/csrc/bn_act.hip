@@ -1,0 +1,234 @@
+// Element-wise tail of a trainable conv block in training (resnet.py Bottleneck.forward:263-302
+// with norm_eval=True: BatchNorm in eval mode is the per-channel affine scale = gamma/sqrt(var+eps),
+// shift = beta - mean*scale whose gamma / beta still train), fused into one pass each way:
+//   forward   out = [relu]( z * scale[c] + shift[c] [+ res] )
+//   backward  dpre = dout * (out > 0)            (relu mask from the saved output)
+//             dz = dpre * scale[c],  dres = dpre,  dscale[c] = sum_m dpre*z,  dshift[c] = sum_m dpre
+// HBM-bound streams over (rows, C) NHWC tensors, 16 bytes per lane; the per-channel sums are
+// reduced per thread over a strip of rows, across the row lanes of a workgroup through LDS, and
+// leave with one fp32 atomic per channel and workgroup.  The reference reaches the same
+// arithmetic through ~9 separate torch kernels per block (mul, add, add, relu; threshold_backward,
+// mul, mul, 2 x sum).
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+template <typename T> struct Vec;
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ void ldv(const float* p, float v[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void ldv(const bf16_t* p, float v[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        v[2 * e] = __uint_as_float(w[e] << 16);
+        v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ unsigned f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void stv(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stv(bf16_t* p, const float v[8]) {
+    uint4 u;
+    u.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
+    u.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
+    u.z = f2bf(v[4]) | (f2bf(v[5]) << 16);
+    u.w = f2bf(v[6]) | (f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ z,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const T* __restrict__ res, T* __restrict__ out,
+                                                        long long rows, int C, int relu) {
+    constexpr int V = Vec<T>::N;
+    const int cvn = C / V;
+    const long long total = rows * cvn;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(idx % cvn) * V;
+        float v[V], r[V];
+        ldv(z + idx * V, v);
+        if (res) ldv(res + idx * V, r);
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            float o = v[e] * scale[c0 + e] + shift[c0 + e];
+            if (res) o += r[e];
+            if (relu) o = fmaxf(o, 0.f);
+            v[e] = o;
+        }
+        stv(out + idx * V, v);
+    }
+}
+
+// grid (row strips, channel chunks of 256 vectors); block 256 threads = RL row lanes x CW
+// channel vectors (CW = min(256, C/V), power of two)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ dout,
+                                                        const T* __restrict__ out,
+                                                        const T* __restrict__ z,
+                                                        const float* __restrict__ scale,
+                                                        T* __restrict__ dz, T* __restrict__ dres,
+                                                        float* __restrict__ partial, long long rows,
+                                                        int C, int relu, int rows_per_block, int CW) {
+    constexpr int V = Vec<T>::N;
+    __shared__ float red[2][256][V];
+    const int cvn = C / V;
+    const int cv = blockIdx.y * CW + (threadIdx.x % CW);
+    const int rl = threadIdx.x / CW, RL = 256 / CW;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    float ss[V], sh[V], sc[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) { ss[e] = 0.f; sh[e] = 0.f; sc[e] = (cv < cvn) ? scale[cv * V + e] : 0.f; }
+    if (cv < cvn) {
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            const long long idx = (r * cvn + cv) * V;
+            float g[V], o[V], zz[V], gz[V];
+            ldv(dout + idx, g);
+            if (relu) ldv(out + idx, o);
+            ldv(z + idx, zz);
+#pragma unroll
+            for (int e = 0; e < V; e++) {
+                const float d = (!relu || o[e] > 0.f) ? g[e] : 0.f;
+                g[e] = d;
+                ss[e] += d * zz[e];
+                sh[e] += d;
+                gz[e] = d * sc[e];
+            }
+            stv(dz + idx, gz);
+            if (dres) stv(dres + idx, g);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) { red[0][threadIdx.x][e] = ss[e]; red[1][threadIdx.x][e] = sh[e]; }
+    __syncthreads();
+    if (rl == 0 && cv < cvn) {
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < RL; k++) { a += red[0][k * CW + threadIdx.x][e]; b += red[1][k * CW + threadIdx.x][e]; }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + cv * V + e] = a;      // [strip][dscale | dshift][C]
+            partial[((size_t)blockIdx.x * 2 + 1) * C + cv * V + e] = b;
+        }
+    }
+}
+
+// second stage: deterministic column sums of the per-strip partials
+__global__ __launch_bounds__(1024) void bn_act_reduce_kernel(const float* __restrict__ partial,
+                                                            float* __restrict__ dscale,
+                                                            float* __restrict__ dshift, int strips, int C) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int which = blockIdx.y;
+    float a = 0.f;
+    if (col < C)
+        for (int s = sl; s < strips; s += 16) a += partial[((size_t)s * 2 + which) * C + col];
+    red[sl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (sl == 0 && col < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][threadIdx.x];
+        (which ? dshift : dscale)[col] = t;
+    }
+}
+
+struct BwdPlan { int CW, chunks; long long strips, rpb; };
+inline bool bwd_plan(long long rows, int channels, int V, BwdPlan* pl) {
+    const int cvn = channels / V;
+    int CW = 1;
+    while (CW < cvn && CW < 256) CW <<= 1;
+    if (cvn < 256 && CW != cvn) return false;      // channel-vector count must be a power of two
+    pl->CW = CW;
+    pl->chunks = (cvn + CW - 1) / CW;
+    long long strips = 512 / pl->chunks;           // ~512 workgroups, strips of at least 64 rows
+    if (strips < 1) strips = 1;
+    long long rpb = (rows + strips - 1) / strips;
+    if (rpb < 64) rpb = 64;
+    pl->rpb = rpb;
+    pl->strips = rows > 0 ? (rows + rpb - 1) / rpb : 0;
+    return true;
+}
+
+inline int stream_grid(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+BRCNN_API int brcnn_bn_act_forward(const void* z, const float* scale, const float* shift,
+                                   const void* residual, void* out, int64_t rows, int channels,
+                                   int relu, int dtype, void* stream) {
+    if (!z || !scale || !shift || !out || rows < 0 || channels <= 0 ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
+    if (channels % V) return BRCNN_EINVAL;
+    if (rows == 0) return 0;
+    const long long total = rows * (channels / V);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)z, scale, shift, (const float*)residual, (float*)out, (long long)rows,
+                           channels, relu);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)z, scale, shift, (const bf16_t*)residual, (bf16_t*)out, (long long)rows,
+                           channels, relu);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API size_t brcnn_bn_act_backward_workspace_bytes(int64_t rows, int channels, int dtype) {
+    BwdPlan pl;
+    const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
+    if (rows < 0 || channels <= 0 || channels % V || !bwd_plan(rows, channels, V, &pl)) return 0;
+    return (size_t)(pl.strips > 0 ? pl.strips : 1) * 2 * channels * sizeof(float);
+}
+
+BRCNN_API int brcnn_bn_act_backward(const void* dout, const void* out, const void* z, const float* scale,
+                                    void* dz, void* dres, float* dscale, float* dshift, void* workspace,
+                                    size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
+                                    void* stream) {
+    if (!dout || !z || !scale || !dz || !dscale || !dshift || !workspace || rows < 0 || channels <= 0 ||
+        (relu && !out) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
+    if (channels % V) return BRCNN_EINVAL;
+    BwdPlan pl;
+    if (!bwd_plan(rows, channels, V, &pl)) return BRCNN_EINVAL;
+    if (workspace_bytes < brcnn_bn_act_backward_workspace_bytes(rows, channels, dtype)) return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        BRCNN_HIP_CHECK(hipMemsetAsync(dscale, 0, (size_t)channels * sizeof(float), s));
+        BRCNN_HIP_CHECK(hipMemsetAsync(dshift, 0, (size_t)channels * sizeof(float), s));
+        return 0;
+    }
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
+                           (const float*)dout, (const float*)out, (const float*)z, scale, (float*)dz, (float*)dres,
+                           (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
+                           (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)z, scale, (bf16_t*)dz,
+                           (bf16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_act_reduce_kernel, dim3((channels + 63) / 64, 2), dim3(1024), 0, s,
+                       (const float*)workspace, dscale, dshift, (int)pl.strips, channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -78,15 +78,24 @@ class AnchorHead(nn.Module):
         anchor_list = [multi_level_anchors for _ in range(num_imgs)]
         valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, m['pad_shape'], device)
                            for m in img_metas]
+        # remembered for get_targets: images whose flags are all ones by construction
+        self._all_valid = [self.anchor_generator.all_valid(featmap_sizes, m['pad_shape']) for m in img_metas]
         return anchor_list, valid_flag_list
 
     def _get_targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore,
-                            gt_labels, img_meta, label_channels=1, unmap_outputs=True):
-        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
-                                           self.train_cfg.allowed_border)
-        if not inside_flags.any():
-            return (None,) * 7
-        anchors = flat_anchors[inside_flags, :]
+                            gt_labels, img_meta, all_valid=False, label_channels=1, unmap_outputs=True):
+        # every anchor valid and no border test: the masked gather / scatter of the reference are
+        # identities -- skip them (and the host syncs of `.any()` and boolean indexing)
+        identity = bool(all_valid) and self.train_cfg.allowed_border < 0
+        if identity:
+            anchors = flat_anchors
+            unmap_outputs = False
+        else:
+            inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
+                                               self.train_cfg.allowed_border)
+            if not inside_flags.any():
+                return (None,) * 7
+            anchors = flat_anchors[inside_flags, :]
         assign_result = self.assigner.assign(anchors, gt_bboxes, gt_bboxes_ignore,
                                              None if self.sampling else gt_labels)
         sampling_result = self.sampler.sample(assign_result, anchors, gt_bboxes)
@@ -279,9 +288,13 @@ class ATSSRPNHead(AnchorHead):
             gt_bboxes_ignore_list = [None] * num_imgs
         if gt_labels_list is None:
             gt_labels_list = [None] * num_imgs
+        all_valid = getattr(self, '_all_valid', None)
+        if all_valid is None or len(all_valid) != num_imgs:
+            all_valid = [False] * num_imgs
         (labels, label_weights, bbox_targets, bbox_weights, _, _, sampling_result) = multi_apply(
             self._get_targets_single, concat_anchor_list, concat_valid_flag_list, gt_bboxes_list,
-            gt_bboxes_ignore_list, gt_labels_list, img_metas, label_channels=1, unmap_outputs=True)
+            gt_bboxes_ignore_list, gt_labels_list, img_metas, all_valid, label_channels=1, unmap_outputs=True)
+        self._all_valid = None
         if any(l is None for l in labels):
             return None
         pos_inds = [((0 <= l) & (l < self.num_classes)).nonzero().view(-1) for l in labels]

@@ -332,7 +332,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
                                               nms_cfg_.get('iou_threshold'),
                                               nms_cfg_.get('offset', 0), -1)
             pos = torch.arange(b_sorted.size(0), device=boxes.device)
-            seg_id = torch.repeat_interleave(torch.arange(uniq.numel(), device=boxes.device), counts)
+            seg_id = torch.searchsorted(seg[1:].long(), pos, right=True)      # segment of each sorted row, no host sync
             valid = (pos - seg[:-1].long()[seg_id]) < num_keep.long()[seg_id]
             kept_sorted = keep_buf[valid]
             kept = order[kept_sorted]
@@ -345,7 +345,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
                 nms_cfg_.get('sigma', 0.5), nms_cfg_.get('min_score', 1e-3), method,
                 nms_cfg_.get('offset', 0))
             pos = torch.arange(b_sorted.size(0), device=boxes.device)
-            seg_id = torch.repeat_interleave(torch.arange(uniq.numel(), device=boxes.device), counts)
+            seg_id = torch.searchsorted(seg[1:].long(), pos, right=True)      # segment of each sorted row, no host sync
             valid = (pos - seg[:-1].long()[seg_id]) < num_keep.long()[seg_id]
             kept = order[inds[valid]]
             total_mask[kept] = True

@@ -215,6 +215,21 @@ int brcnn_groupnorm_nhwc_multi(const void *x, const float *gamma, const float *b
                                int batch, int num_segments, const int *hw_host, int channels,
                                int groups, float eps, int relu, int dtype, void *stream);
 
+/* Element-wise tail of a trainable conv block in training (eval-mode BatchNorm = per-channel
+ * affine whose gamma / beta still train, resnet.py:263-302 with norm_eval=True):
+ *   forward   out = [relu](z * scale[c] + shift[c] [+ residual])          (rows, C) NHWC rows
+ *   backward  dpre = dout * (out > 0);  dz = dpre * scale[c];  dres = dpre (optional);
+ *             dscale[c] = sum_rows dpre * z;  dshift[c] = sum_rows dpre    (fp32; two-stage,
+ *             deterministic: per-strip partials in `workspace`, then a column reduction)
+ * C % 4 == 0 (fp32) / C % 8 == 0 (bf16); backward needs C/vec to be a power of two or >= 256. */
+int brcnn_bn_act_forward(const void *z, const float *scale, const float *shift, const void *residual,
+                         void *out, int64_t rows, int channels, int relu, int dtype, void *stream);
+size_t brcnn_bn_act_backward_workspace_bytes(int64_t rows, int channels, int dtype);
+int brcnn_bn_act_backward(const void *dout, const void *out, const void *z, const float *scale,
+                          void *dz, void *dres, float *dscale, float *dshift, void *workspace,
+                          size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
+                          void *stream);
+
 /* FPN top-down path: dst[n,y,x,c] += src[n, y*Hs/Hd, x*Ws/Wd, c]  (nearest,
  * F.interpolate(size=...) at necks/pafpn.py:113-115, fpn.py:178-181) */
 int brcnn_upsample_nearest_add_nhwc(void *dst, const void *src, int batch, int hd, int wd,

@@ -189,7 +189,14 @@ def _roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=5
     return out.permute(0, 2, 3, 1).contiguous()
 
 
-_PATCH_AUTOGRAD = dict(conv2d_nhwc_autograd=_conv2d_nhwc_autograd, linear_autograd=_linear_autograd,
+def _bn_act_autograd(z, scale, shift, res=None, relu=True):
+    y = z * scale.to(z.dtype) + shift.to(z.dtype)
+    if res is not None:
+        y = y + res
+    return y.relu() if relu else y
+
+
+_PATCH_AUTOGRAD = dict(bn_act_autograd=_bn_act_autograd, conv2d_nhwc_autograd=_conv2d_nhwc_autograd, linear_autograd=_linear_autograd,
                        roi_extract_autograd=_roi_extract_autograd)
 
 _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw,

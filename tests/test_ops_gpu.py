@@ -529,3 +529,39 @@ def test_stem_vector_path_matches_float64():
         y = y.permute(0, 3, 1, 2).cpu().double()
         assert y.shape == ref.shape
         assert (y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bn_act_fused_forward_backward(dtype):
+    """fused eval-BN affine (+residual) + ReLU and its backward against the torch ops it replaces"""
+    from brcnn.autograd import bn_act_autograd
+    g = torch.Generator().manual_seed(31)
+    for (rows, c, has_res, relu) in [(1000, 64, False, True), (777, 256, True, True), (130, 2048, True, True),
+                                     (513, 128, False, False), (64, 1024, True, False)]:
+        z = torch.randn(rows, c, generator=g).to(DEV, dtype)
+        res = torch.randn(rows, c, generator=g).to(DEV, dtype) if has_res else None
+        scale = (torch.rand(c, generator=g) + 0.5).to(DEV).requires_grad_()
+        shift = torch.randn(c, generator=g).to(DEV).requires_grad_()
+        go = torch.randn(rows, c, generator=g).to(DEV, dtype)
+        z1 = z.clone().requires_grad_()
+        r1 = res.clone().requires_grad_() if has_res else None
+        out = bn_act_autograd(z1, scale, shift, r1, relu)
+        out.backward(go)
+        # reference in fp64 on the same (dtype-representable) inputs
+        z2 = z.double().requires_grad_()
+        r2 = res.double().requires_grad_() if has_res else None
+        s2, h2 = scale.detach().double().requires_grad_(), shift.detach().double().requires_grad_()
+        ref = z2 * s2 + h2
+        if has_res:
+            ref = ref + r2
+        if relu:
+            ref = ref.relu()
+        ref.backward(go.double())
+        tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+        mag = lambda t: max(1.0, t.abs().max().item())   # noqa: E731
+        assert (out.double() - ref).abs().max().item() <= tol * mag(ref) * 1.01
+        assert (z1.grad.double() - z2.grad).abs().max().item() <= tol * mag(z2.grad) * 1.01
+        if has_res:
+            assert (r1.grad.double() - r2.grad).abs().max().item() <= tol * mag(r2.grad) * 1.01
+        assert (scale.grad.double() - s2.grad).abs().max().item() <= 2e-5 * mag(s2.grad) * (rows ** 0.5)
+        assert (shift.grad.double() - h2.grad).abs().max().item() <= 2e-5 * mag(h2.grad) * (rows ** 0.5)
