@@ -447,27 +447,14 @@ class ATSSRPNHead(AnchorHead):
         valid = torch.cat(va_l, 1)             # (B, T)  `proposals[valid_mask]` (:750-754)
         ids = torch.cat(id_l, 1)
         if scores.shape[1] >= nms_cfg.get('split_thr', 10000):
-            # mmcv batched_nms switches to its per-id loop at >= split_thr candidates (the
-            # training proposal cfg: 15 150 per image); which branch runs depends on the
-            # per-image count after the validity filter, so this path reads it on the host,
-            # as the reference does (atss_rpn_head.py:750-756)
-            K = cfg.max_per_img
-            dets = props.new_zeros((B, K, 5))
-            num = torch.zeros((B,), dtype=torch.int32, device=device)
-            full_cfg = dict(cfg.nms)
-            for b in range(B):
-                v = valid[b]
-                if bool(v.all()):
-                    pb, sb, ib = props[b], scores[b], ids[b]
-                else:
-                    pb, sb, ib = props[b][v], scores[b][v], ids[b][v]
-                if pb.numel() == 0:
-                    continue
-                d, _ = ops.batched_nms(pb, sb, ib, full_cfg)
-                d = d[:K]
-                dets[b, :d.shape[0]] = d
-                num[b] = d.shape[0]
-            return dets, num
+            # mmcv batched_nms switches to its per-id (per-level) loop at >= split_thr candidates
+            # (the training proposal cfg: 15 150 per image).  Both of its branches keep the same
+            # boxes in the same order (the coordinate offsets already isolate the levels), so the
+            # whole batch runs as one segmented launch over (image, level) segments.
+            from .postprocess import batched_nms_images_by_level
+            return batched_nms_images_by_level(props, scores, ids, valid, [s_.shape[1] for s_ in sc_l],
+                                               nms_cfg['iou_threshold'], cfg.max_per_img,
+                                               nms_cfg.get('offset', 0))
         dets, _, num = batched_nms_images(props, scores, ids, valid, nms_cfg['iou_threshold'],
                                           cfg.max_per_img, nms_cfg.get('offset', 0))
         return dets, num

@@ -52,3 +52,62 @@ def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offse
     ids_kept = torch.where(kmask, c_ids.reshape(-1)[keep.reshape(-1)].view(B, K),
                            torch.full((B, K), -1, dtype=c_ids.dtype, device=device))
     return dets, ids_kept, num
+
+
+def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_threshold, max_keep, offset=0):
+    """mmcv `batched_nms` above `split_thr` for a whole mini-batch, no host sync: NMS per id
+    (pyramid level) on the offset boxes, survivors re-sorted by score, first `max_keep`
+    (mmcv/ops/nms.py batched_nms, the `for id in torch.unique(idxs)` branch).  Column ranges
+    of the (B,T) candidate slots belong to the levels in order (`level_sizes`, host ints,
+    sum == T), so after the order-preserving compaction every (image, level) is one contiguous
+    segment and ONE segmented launch serves all images and levels.
+    Returns dets (B,K,5) zero padded and num (B,) int32."""
+    B, T = scores.shape
+    L = len(level_sizes)
+    assert sum(level_sizes) == T
+    device = scores.device
+    K = min(max_keep, T) if max_keep > 0 else T
+    cnt = valid.sum(1)
+    dest = torch.cumsum(valid, 1) - 1
+    dest = torch.where(valid, dest, torch.full_like(dest, T))
+
+    def compact(x):
+        out = torch.zeros((B, T + 1) + tuple(x.shape[2:]), dtype=x.dtype, device=device)
+        idx = dest.view(B, T, *([1] * (x.dim() - 2))).expand_as(x)
+        out.scatter_(1, idx, x)
+        return out[:, :T].contiguous()
+
+    c_boxes, c_scores, c_ids = compact(boxes), compact(scores), compact(ids)
+    pos = torch.arange(T, device=device)[None, :]
+    in_range = pos < cnt[:, None]
+    lowest = torch.finfo(c_boxes.dtype).min
+    max_coord = torch.where(in_range[..., None], c_boxes, c_boxes.new_full((), lowest)).amax((1, 2))
+    offs = c_ids.to(c_boxes) * (max_coord + torch.tensor(1).to(c_boxes))[:, None]
+    boxes_for_nms = c_boxes + offs[..., None]
+    # per-(image, level) survivor counts of the validity filter -> contiguous segments
+    bounds = [0]
+    for n in level_sizes:
+        bounds.append(bounds[-1] + int(n))
+    csum = torch.cat([valid.new_zeros((B, 1), dtype=torch.long), torch.cumsum(valid, 1)], 1)   # (B, T+1)
+    ends = csum[:, bounds[1:]]                      # (B, L) within-image end of level l
+    begins = csum[:, bounds[:-1]]
+    base = (torch.arange(B, device=device) * T)[:, None]
+    ranges = torch.stack([(begins + base).reshape(-1), (ends + base).reshape(-1)], 1).to(torch.int32)
+    keep, num = ops.nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges, max(level_sizes),
+                               iou_threshold, offset, -1)
+    num = num.view(B, L).long()
+    lvl = torch.searchsorted(ends.contiguous(), pos.expand(B, T).contiguous(), right=True).clamp(max=L - 1)
+    is_kept_slot = in_range & ((pos - torch.gather(begins, 1, lvl)) < torch.gather(num, 1, lvl))
+    kept_idx = torch.where(is_kept_slot, keep.view(B, T), torch.full((), B * T, dtype=torch.long, device=device))
+    mask = torch.zeros(B * T + 1, dtype=torch.bool, device=device)
+    mask.scatter_(0, kept_idx.reshape(-1), is_kept_slot.reshape(-1))
+    mask = mask[:B * T].view(B, T)
+    # survivors by descending score (ties: ascending index, the shared tie rule), first K
+    key = torch.where(mask, c_scores, c_scores.new_full((), float('-inf')))
+    _, order = key.sort(dim=1, descending=True, stable=True)
+    order = order[:, :K]
+    n_kept = torch.clamp(mask.sum(1), max=K).to(torch.int32)
+    kmask = torch.arange(K, device=device)[None, :] < n_kept[:, None]
+    dets = torch.cat([torch.gather(c_boxes, 1, order[..., None].expand(B, K, 4)),
+                      torch.gather(c_scores, 1, order)[..., None]], 2) * kmask[..., None]
+    return dets, n_kept
