@@ -507,8 +507,23 @@ def worker_init_fn(worker_id, num_workers, rank, seed):
 
 
 def build_dataset(cfg, default_args=None):
+    """datasets/builder.py:62-87"""
     if isinstance(cfg, (list, tuple)):
-        raise NotImplementedError('ConcatDataset configs are outside the Boosting R-CNN recipes')
+        return ConcatDataset([build_dataset(c, default_args) for c in cfg])
+    if cfg['type'] == 'ConcatDataset':
+        return ConcatDataset([build_dataset(c, default_args) for c in cfg['datasets']], cfg.get('separate_eval', True))
+    if cfg['type'] == 'RepeatDataset':
+        return RepeatDataset(build_dataset(cfg['dataset'], default_args), cfg['times'])
+    if isinstance(cfg.get('ann_file'), (list, tuple)):
+        import copy
+        parts = []
+        for i, ann in enumerate(cfg['ann_file']):
+            c = copy.deepcopy(dict(cfg))
+            c['ann_file'] = ann
+            if isinstance(cfg.get('img_prefix'), (list, tuple)):
+                c['img_prefix'] = cfg['img_prefix'][i]
+            parts.append(build_dataset(c, default_args))
+        return ConcatDataset(parts, cfg.get('separate_eval', True))
     return build_from_cfg(cfg, DATASETS, default_args)
 
 
@@ -528,3 +543,152 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
     return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
                       collate_fn=partial(collate, samples_per_gpu=samples_per_gpu), pin_memory=False,
                       worker_init_fn=init_fn, **kwargs)
+
+
+# --------------------------------------------------------------------------- PASCAL VOC
+@DATASETS.register_module()
+class XMLDataset(CustomDataset):
+    """datasets/xml_style.py:12-170: image ids from a list file, one Annotations/<id>.xml each"""
+
+    def __init__(self, min_size=None, img_subdir='JPEGImages', ann_subdir='Annotations', **kwargs):
+        assert self.CLASSES or kwargs.get('classes', None), 'CLASSES in `XMLDataset` can not be None.'
+        self.img_subdir, self.ann_subdir = img_subdir, ann_subdir
+        super().__init__(**kwargs)
+        self.cat2label = {cat: i for i, cat in enumerate(self.CLASSES)}
+        self.min_size = min_size
+
+    def _root(self, img_id):
+        import xml.etree.ElementTree as ET
+        return ET.parse(osp.join(self.img_prefix, self.ann_subdir, f'{img_id}.xml')).getroot()
+
+    def load_annotations(self, ann_file):
+        data_infos = []
+        with open(ann_file) as f:
+            img_ids = [ln.rstrip('\n\r') for ln in f]
+        for img_id in img_ids:
+            filename = osp.join(self.img_subdir, f'{img_id}.jpg')
+            size = self._root(img_id).find('size')
+            if size is not None:
+                width, height = int(size.find('width').text), int(size.find('height').text)
+            else:
+                from .pipelines import imread
+                height, width = imread(osp.join(self.img_prefix, filename)).shape[:2]
+            data_infos.append(dict(id=img_id, filename=filename, width=width, height=height))
+        return data_infos
+
+    def _filter_imgs(self, min_size=32):
+        valid_inds = []
+        for i, info in enumerate(self.data_infos):
+            if min(info['width'], info['height']) < min_size:
+                continue
+            if self.filter_empty_gt:
+                for obj in self._root(info['id']).findall('object'):
+                    if obj.find('name').text in self.CLASSES:
+                        valid_inds.append(i)
+                        break
+            else:
+                valid_inds.append(i)
+        return valid_inds
+
+    def get_ann_info(self, idx):
+        bboxes, labels, bboxes_ignore, labels_ignore = [], [], [], []
+        for obj in self._root(self.data_infos[idx]['id']).findall('object'):
+            name = obj.find('name').text
+            if name not in self.CLASSES:
+                continue
+            label = self.cat2label[name]
+            difficult = obj.find('difficult')
+            difficult = 0 if difficult is None else int(difficult.text)
+            bb = obj.find('bndbox')
+            bbox = [int(float(bb.find(k).text)) for k in ('xmin', 'ymin', 'xmax', 'ymax')]
+            ignore = False
+            if self.min_size:
+                assert not self.test_mode
+                if bbox[2] - bbox[0] < self.min_size or bbox[3] - bbox[1] < self.min_size:
+                    ignore = True
+            if difficult or ignore:
+                bboxes_ignore.append(bbox)
+                labels_ignore.append(label)
+            else:
+                bboxes.append(bbox)
+                labels.append(label)
+        if not bboxes:
+            bboxes, labels = np.zeros((0, 4)), np.zeros((0,))
+        else:
+            bboxes, labels = np.array(bboxes, ndmin=2) - 1, np.array(labels)
+        if not bboxes_ignore:
+            bboxes_ignore, labels_ignore = np.zeros((0, 4)), np.zeros((0,))
+        else:
+            bboxes_ignore, labels_ignore = np.array(bboxes_ignore, ndmin=2) - 1, np.array(labels_ignore)
+        return dict(bboxes=bboxes.astype(np.float32), labels=labels.astype(np.int64),
+                    bboxes_ignore=bboxes_ignore.astype(np.float32), labels_ignore=labels_ignore.astype(np.int64))
+
+
+@DATASETS.register_module()
+class VOCDataset(XMLDataset):
+    """datasets/voc.py:11-93"""
+    CLASSES = ('aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car', 'cat', 'chair', 'cow',
+               'diningtable', 'dog', 'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train',
+               'tvmonitor')
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        if 'VOC2007' in self.img_prefix:
+            self.year = 2007
+        elif 'VOC2012' in self.img_prefix:
+            self.year = 2012
+        else:
+            raise ValueError('Cannot infer dataset year from img_prefix')
+
+    def evaluate(self, results, metric='mAP', logger=None, proposal_nums=(100, 300, 1000), iou_thr=0.5,
+                 scale_ranges=None):
+        from collections import OrderedDict
+        from .evaluation import eval_map
+        if not isinstance(metric, str):
+            assert len(metric) == 1
+            metric = metric[0]
+        if metric != 'mAP':
+            raise KeyError(f'metric {metric} is not supported')
+        annotations = [self.get_ann_info(i) for i in range(len(self))]
+        eval_results = OrderedDict()
+        iou_thrs = [iou_thr] if isinstance(iou_thr, float) else iou_thr
+        ds_name = 'voc07' if self.year == 2007 else self.CLASSES
+        mean_aps = []
+        for thr in iou_thrs:
+            mean_ap, _ = eval_map(results, annotations, scale_ranges=None, iou_thr=thr, dataset=ds_name,
+                                  logger=logger, use_legacy_coordinate=True)
+            mean_aps.append(mean_ap)
+            eval_results[f'AP{int(thr * 100):02d}'] = round(mean_ap, 3)
+        eval_results['mAP'] = sum(mean_aps) / len(mean_aps)
+        return eval_results
+
+
+@DATASETS.register_module()
+class RepeatDataset:
+    """datasets/dataset_wrappers.py:173-230: the dataset repeated `times` times per epoch"""
+
+    def __init__(self, dataset, times):
+        self.dataset = build_dataset(dataset) if isinstance(dataset, dict) else dataset
+        self.times = times
+        self.CLASSES = self.dataset.CLASSES
+        if hasattr(self.dataset, 'flag'):
+            self.flag = np.tile(self.dataset.flag, times)
+        self._ori_len = len(self.dataset)
+
+    def __getitem__(self, idx):
+        return self.dataset[idx % self._ori_len]
+
+    def __len__(self):
+        return self.times * self._ori_len
+
+
+@DATASETS.register_module()
+class ConcatDataset(torch.utils.data.ConcatDataset):
+    """datasets/dataset_wrappers.py:13-60 (joint evaluation is not needed by the recipes)"""
+
+    def __init__(self, datasets, separate_eval=True):
+        super().__init__([build_dataset(d) if isinstance(d, dict) else d for d in datasets])
+        self.CLASSES = self.datasets[0].CLASSES
+        self.separate_eval = separate_eval
+        if hasattr(self.datasets[0], 'flag'):
+            self.flag = np.concatenate([d.flag for d in self.datasets])

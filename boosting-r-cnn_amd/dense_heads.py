@@ -346,7 +346,14 @@ class ATSSRPNHead(AnchorHead):
             loss_iou = iou_pred.sum() * 0
             iou_target = bbox_targets.new_tensor(0.)
             avg_factor = iou_target.sum()
-        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        from .losses import VarifocalLoss
+        if isinstance(self.loss_cls, VarifocalLoss):      # atss_rpn_head.py:393-397
+            cls_iou_targets = torch.zeros_like(cls_score)
+            if len(pos_inds) > 0:
+                cls_iou_targets[pos_inds] = iou_target.unsqueeze(-1)
+            loss_cls = self.loss_cls(cls_score, cls_iou_targets, avg_factor=num_total_samples)
+        else:
+            loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
         return loss_cls, loss_bbox, loss_iou, avg_factor
 
     def loss(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None):

@@ -208,3 +208,168 @@ class COCOeval:
             lines.append(line)
         self.stats = stats
         return '\n'.join(lines)
+
+
+# ------------------------------------------------------------------------------------------
+# PASCAL VOC style mAP (mmdet/core/evaluation/mean_ap.py: average_precision:13-60,
+# tpfp_default:159-267, get_cls_results:270-294, eval_map:297-420), as `VOCDataset.evaluate`
+# calls it (datasets/voc.py:60-76: iou_thr 0.5, legacy +1 box extents, 11-point AP for VOC2007).
+# The reference is importable here, so this part is pinned by a golden fixture (g15).
+# ------------------------------------------------------------------------------------------
+def bbox_overlaps_np(bboxes1, bboxes2, mode='iou', eps=1e-6, use_legacy_coordinate=False):
+    """core/evaluation/bbox_overlaps.py:5-65"""
+    assert mode in ('iou', 'iof')
+    extra = 1. if use_legacy_coordinate else 0.
+    bboxes1 = bboxes1.astype(np.float32)
+    bboxes2 = bboxes2.astype(np.float32)
+    rows, cols = bboxes1.shape[0], bboxes2.shape[0]
+    ious = np.zeros((rows, cols), dtype=np.float32)
+    if rows * cols == 0:
+        return ious
+    exchange = False
+    if bboxes1.shape[0] > bboxes2.shape[0]:
+        bboxes1, bboxes2 = bboxes2, bboxes1
+        ious = np.zeros((cols, rows), dtype=np.float32)
+        exchange = True
+    area1 = (bboxes1[:, 2] - bboxes1[:, 0] + extra) * (bboxes1[:, 3] - bboxes1[:, 1] + extra)
+    area2 = (bboxes2[:, 2] - bboxes2[:, 0] + extra) * (bboxes2[:, 3] - bboxes2[:, 1] + extra)
+    for i in range(bboxes1.shape[0]):
+        x_start = np.maximum(bboxes1[i, 0], bboxes2[:, 0])
+        y_start = np.maximum(bboxes1[i, 1], bboxes2[:, 1])
+        x_end = np.minimum(bboxes1[i, 2], bboxes2[:, 2])
+        y_end = np.minimum(bboxes1[i, 3], bboxes2[:, 3])
+        overlap = np.maximum(x_end - x_start + extra, 0) * np.maximum(y_end - y_start + extra, 0)
+        union = area1[i] + area2 - overlap if mode == 'iou' else (area1[i] if not exchange else area2)
+        union = np.maximum(union, eps)
+        ious[i, :] = overlap / union
+    return ious.T if exchange else ious
+
+
+def average_precision(recalls, precisions, mode='area'):
+    no_scale = recalls.ndim == 1
+    if no_scale:
+        recalls, precisions = recalls[np.newaxis, :], precisions[np.newaxis, :]
+    assert recalls.shape == precisions.shape and recalls.ndim == 2
+    num_scales = recalls.shape[0]
+    ap = np.zeros(num_scales, dtype=np.float32)
+    if mode == 'area':
+        zeros = np.zeros((num_scales, 1), dtype=recalls.dtype)
+        ones = np.ones((num_scales, 1), dtype=recalls.dtype)
+        mrec = np.hstack((zeros, recalls, ones))
+        mpre = np.hstack((zeros, precisions, zeros))
+        for i in range(mpre.shape[1] - 1, 0, -1):
+            mpre[:, i - 1] = np.maximum(mpre[:, i - 1], mpre[:, i])
+        for i in range(num_scales):
+            ind = np.where(mrec[i, 1:] != mrec[i, :-1])[0]
+            ap[i] = np.sum((mrec[i, ind + 1] - mrec[i, ind]) * mpre[i, ind + 1])
+    elif mode == '11points':
+        for i in range(num_scales):
+            for thr in np.arange(0, 1 + 1e-3, 0.1):
+                precs = precisions[i, recalls[i, :] >= thr]
+                ap[i] += precs.max() if precs.size > 0 else 0
+        ap /= 11
+    else:
+        raise ValueError('Unrecognized mode, only "area" and "11points" are supported')
+    return ap[0] if no_scale else ap
+
+
+def tpfp_default(det_bboxes, gt_bboxes, gt_bboxes_ignore=None, iou_thr=0.5, area_ranges=None,
+                 use_legacy_coordinate=False):
+    extra = 1. if use_legacy_coordinate else 0.
+    gt_ignore_inds = np.concatenate((np.zeros(gt_bboxes.shape[0], dtype=bool),
+                                     np.ones(gt_bboxes_ignore.shape[0], dtype=bool)))
+    gt_bboxes = np.vstack((gt_bboxes, gt_bboxes_ignore))
+    num_dets, num_gts = det_bboxes.shape[0], gt_bboxes.shape[0]
+    if area_ranges is None:
+        area_ranges = [(None, None)]
+    tp = np.zeros((len(area_ranges), num_dets), dtype=np.float32)
+    fp = np.zeros((len(area_ranges), num_dets), dtype=np.float32)
+    if gt_bboxes.shape[0] == 0:
+        if area_ranges == [(None, None)]:
+            fp[...] = 1
+        else:
+            det_areas = (det_bboxes[:, 2] - det_bboxes[:, 0] + extra) * (det_bboxes[:, 3] - det_bboxes[:, 1] + extra)
+            for i, (lo, hi) in enumerate(area_ranges):
+                fp[i, (det_areas >= lo) & (det_areas < hi)] = 1
+        return tp, fp
+    ious = bbox_overlaps_np(det_bboxes, gt_bboxes, use_legacy_coordinate=use_legacy_coordinate)
+    ious_max, ious_argmax = ious.max(axis=1), ious.argmax(axis=1)
+    sort_inds = np.argsort(-det_bboxes[:, -1])
+    for k, (lo, hi) in enumerate(area_ranges):
+        gt_covered = np.zeros(num_gts, dtype=bool)
+        if lo is None:
+            gt_area_ignore = np.zeros_like(gt_ignore_inds, dtype=bool)
+        else:
+            gt_areas = (gt_bboxes[:, 2] - gt_bboxes[:, 0] + extra) * (gt_bboxes[:, 3] - gt_bboxes[:, 1] + extra)
+            gt_area_ignore = (gt_areas < lo) | (gt_areas >= hi)
+        for i in sort_inds:
+            if ious_max[i] >= iou_thr:
+                m = ious_argmax[i]
+                if not (gt_ignore_inds[m] or gt_area_ignore[m]):
+                    if not gt_covered[m]:
+                        gt_covered[m] = True
+                        tp[k, i] = 1
+                    else:
+                        fp[k, i] = 1
+            elif lo is None:
+                fp[k, i] = 1
+            else:
+                b = det_bboxes[i, :4]
+                area = (b[2] - b[0] + extra) * (b[3] - b[1] + extra)
+                if lo <= area < hi:
+                    fp[k, i] = 1
+    return tp, fp
+
+
+def eval_map(det_results, annotations, scale_ranges=None, iou_thr=0.5, dataset=None, logger=None,
+             use_legacy_coordinate=False):
+    """(mAP, per-class dicts {num_gts, num_dets, recall, precision, ap})"""
+    assert len(det_results) == len(annotations)
+    extra = 1. if use_legacy_coordinate else 0.
+    num_scales = len(scale_ranges) if scale_ranges is not None else 1
+    num_classes = len(det_results[0])
+    area_ranges = [(r[0] ** 2, r[1] ** 2) for r in scale_ranges] if scale_ranges is not None else None
+    eval_results = []
+    for c in range(num_classes):
+        cls_dets = [img_res[c] for img_res in det_results]
+        cls_gts, cls_gts_ignore = [], []
+        for ann in annotations:
+            cls_gts.append(ann['bboxes'][ann['labels'] == c, :])
+            if ann.get('labels_ignore', None) is not None:
+                cls_gts_ignore.append(ann['bboxes_ignore'][ann['labels_ignore'] == c, :])
+            else:
+                cls_gts_ignore.append(np.empty((0, 4), dtype=np.float32))
+        tpfp = [tpfp_default(d, g, gi, iou_thr, area_ranges, use_legacy_coordinate)
+                for d, g, gi in zip(cls_dets, cls_gts, cls_gts_ignore)]
+        tp, fp = tuple(zip(*tpfp))
+        num_gts = np.zeros(num_scales, dtype=int)
+        for bbox in cls_gts:
+            if area_ranges is None:
+                num_gts[0] += bbox.shape[0]
+            else:
+                areas = (bbox[:, 2] - bbox[:, 0] + extra) * (bbox[:, 3] - bbox[:, 1] + extra)
+                for k, (lo, hi) in enumerate(area_ranges):
+                    num_gts[k] += np.sum((areas >= lo) & (areas < hi))
+        cls_dets = np.vstack(cls_dets)
+        sort_inds = np.argsort(-cls_dets[:, -1])
+        tp = np.cumsum(np.hstack(tp)[:, sort_inds], axis=1)
+        fp = np.cumsum(np.hstack(fp)[:, sort_inds], axis=1)
+        eps = np.finfo(np.float32).eps
+        recalls = tp / np.maximum(num_gts[:, np.newaxis], eps)
+        precisions = tp / np.maximum((tp + fp), eps)
+        if scale_ranges is None:
+            recalls, precisions, n_gt = recalls[0, :], precisions[0, :], num_gts.item()
+        else:
+            n_gt = num_gts
+        ap = average_precision(recalls, precisions, 'area' if dataset != 'voc07' else '11points')
+        eval_results.append(dict(num_gts=n_gt, num_dets=cls_dets.shape[0], recall=recalls, precision=precisions, ap=ap))
+    if scale_ranges is not None:
+        all_ap = np.vstack([r['ap'] for r in eval_results])
+        all_gt = np.vstack([r['num_gts'] for r in eval_results])
+        mean_ap = [all_ap[all_gt[:, i] > 0, i].mean() if np.any(all_gt[:, i] > 0) else 0.0 for i in range(num_scales)]
+    else:
+        aps = [r['ap'] for r in eval_results if r['num_gts'] > 0]
+        mean_ap = np.array(aps).mean().item() if aps else 0.0
+    if logger is not None:
+        logger.info(f'mAP@{iou_thr}: {mean_ap}')
+    return mean_ap, eval_results

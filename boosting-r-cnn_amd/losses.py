@@ -104,6 +104,43 @@ class FocalLoss(nn.Module):
 
 
 # ----------------------------------------------------------------------------- cross entropy
+def varifocal_loss(pred, target, weight=None, alpha=0.75, gamma=2.0, iou_weighted=True, reduction='mean',
+                   avg_factor=None):
+    """losses/varifocal_loss.py:10-58: BCE-with-logits against the IoU-aware target, positives
+    weighted by the target, negatives by alpha * |sigmoid - target|^gamma"""
+    assert pred.size() == target.size()
+    pred_sigmoid = pred.sigmoid()
+    target = target.type_as(pred)
+    pos = (target > 0.0).float()
+    neg = (target <= 0.0).float()
+    if iou_weighted:
+        focal_weight = target * pos + alpha * (pred_sigmoid - target).abs().pow(gamma) * neg
+    else:
+        focal_weight = pos + alpha * (pred_sigmoid - target).abs().pow(gamma) * neg
+    loss = F.binary_cross_entropy_with_logits(pred, target, reduction='none') * focal_weight
+    return weight_reduce_loss(loss, weight, reduction, avg_factor)
+
+
+@LOSSES.register_module()
+class VarifocalLoss(nn.Module):
+    """losses/varifocal_loss.py:61-134 (the RPN classification loss of the VOC recipe)"""
+
+    def __init__(self, use_sigmoid=True, alpha=0.75, gamma=2.0, iou_weighted=True, reduction='mean',
+                 loss_weight=1.0):
+        super().__init__()
+        assert use_sigmoid is True, 'Only sigmoid varifocal loss supported now.'
+        assert alpha >= 0.0
+        self.use_sigmoid, self.alpha, self.gamma = use_sigmoid, alpha, gamma
+        self.iou_weighted, self.reduction, self.loss_weight = iou_weighted, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        return self.loss_weight * varifocal_loss(pred, target, weight, alpha=self.alpha, gamma=self.gamma,
+                                                 iou_weighted=self.iou_weighted, reduction=reduction,
+                                                 avg_factor=avg_factor)
+
+
 def cross_entropy(pred, label, weight=None, reduction='mean', avg_factor=None, class_weight=None,
                   ignore_index=-100):
     ignore_index = -100 if ignore_index is None else ignore_index

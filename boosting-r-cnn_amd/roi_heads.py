@@ -100,8 +100,10 @@ class SingleRoIExtractor(nn.Module):
 # ----------------------------------------------------------------------------- bbox head
 @HEADS.register_module()
 class ProbConvFCBBoxHead(nn.Module):
-    """ConvFCBBoxHead restricted to what the boosting configs build (shared FCs only;
-    the VOC config's cls-FC / reg-conv GN branches are a later row)."""
+    """ConvFCBBoxHead (convfc_bbox_head.py:15-200): shared convs -> shared fcs, then separate
+    cls / reg branches of convs and fcs.  The COCO / UTDAC recipes build two shared FCs (fast
+    path: the two predictors share one GEMM); the VOC recipe builds 2 cls FCs and 4 GN reg
+    convs (general path: ConvModules on the NHWC RoI features, FCs on the MFMA linear kernel)."""
 
     def __init__(self, num_shared_convs=0, num_shared_fcs=0, num_cls_convs=0, num_cls_fcs=0,
                  num_reg_convs=0, num_reg_fcs=0, conv_out_channels=256, fc_out_channels=1024,
@@ -116,9 +118,9 @@ class ProbConvFCBBoxHead(nn.Module):
                  loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)):
         super().__init__()
         assert with_cls and with_reg and not with_avg_pool
-        assert num_shared_convs == num_cls_convs == num_reg_convs == 0 and \
-            num_cls_fcs == num_reg_fcs == 0 and num_shared_fcs > 0, \
-            'hot path: shared-FC box head (num_shared_fcs=2)'
+        assert num_shared_convs + num_shared_fcs + num_cls_convs + num_cls_fcs + num_reg_convs + num_reg_fcs > 0
+        if num_cls_convs > 0 or num_reg_convs > 0:
+            assert num_shared_fcs == 0
         assert reg_predictor_cfg.get('type') == 'Linear' and cls_predictor_cfg.get('type') == 'Linear'
         self.with_cls, self.with_reg, self.with_avg_pool = with_cls, with_reg, with_avg_pool
         self.roi_feat_size = _pair(roi_feat_size)
@@ -130,14 +132,27 @@ class ProbConvFCBBoxHead(nn.Module):
         self.bbox_coder = build_bbox_coder(bbox_coder)
         self.loss_cls = build_loss(loss_cls)
         self.loss_bbox = build_loss(loss_bbox)
-        self.shared_fcs = nn.ModuleList()
-        last = in_channels * self.roi_feat_area
-        for i in range(num_shared_fcs):
-            self.shared_fcs.append(nn.Linear(last if i == 0 else fc_out_channels, fc_out_channels))
-        self.shared_out_channels = fc_out_channels
+        self.num_shared_convs, self.num_cls_convs, self.num_cls_fcs = num_shared_convs, num_cls_convs, num_cls_fcs
+        self.num_reg_convs, self.num_reg_fcs = num_reg_convs, num_reg_fcs
+        self.conv_out_channels, self.conv_cfg, self.norm_cfg = conv_out_channels, conv_cfg, norm_cfg
+        self.shared_convs, self.shared_fcs, last = self._add_conv_fc_branch(
+            num_shared_convs, num_shared_fcs, in_channels, True)
+        self.shared_out_channels = last
+        self.cls_convs, self.cls_fcs, self.cls_last_dim = self._add_conv_fc_branch(
+            num_cls_convs, num_cls_fcs, self.shared_out_channels)
+        self.reg_convs, self.reg_fcs, self.reg_last_dim = self._add_conv_fc_branch(
+            num_reg_convs, num_reg_fcs, self.shared_out_channels)
+        if num_shared_fcs == 0:
+            if num_cls_fcs == 0:
+                self.cls_last_dim *= self.roi_feat_area
+            if num_reg_fcs == 0:
+                self.reg_last_dim *= self.roi_feat_area
         self.relu = nn.ReLU(inplace=True)
-        self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
-        self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
+        self.fc_cls = nn.Linear(self.cls_last_dim, num_classes + 1)
+        self.fc_reg = nn.Linear(self.reg_last_dim, 4 if reg_class_agnostic else 4 * num_classes)
+        self._simple = (num_shared_convs == num_cls_convs == num_reg_convs == 0 and
+                        num_cls_fcs == num_reg_fcs == 0 and num_shared_fcs > 0)
+        self._fc_caches = {}
         self._caches = [PackedCache() for _ in range(num_shared_fcs + 1)]
         self.init_weights()
 
@@ -145,10 +160,29 @@ class ProbConvFCBBoxHead(nn.Module):
     custom_activation = False
     custom_accuracy = False
 
+    def _add_conv_fc_branch(self, num_branch_convs, num_branch_fcs, in_channels, is_shared=False):
+        """convfc_bbox_head.py:114-152"""
+        from .blocks import ConvModule
+        last = in_channels
+        convs = nn.ModuleList()
+        for i in range(num_branch_convs):
+            convs.append(ConvModule(last if i == 0 else self.conv_out_channels, self.conv_out_channels, 3,
+                                    padding=1, conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        if num_branch_convs > 0:
+            last = self.conv_out_channels
+        fcs = nn.ModuleList()
+        if num_branch_fcs > 0:
+            if is_shared or self.num_shared_fcs == 0:
+                last *= self.roi_feat_area
+            for i in range(num_branch_fcs):
+                fcs.append(nn.Linear(last if i == 0 else self.fc_out_channels, self.fc_out_channels))
+            last = self.fc_out_channels
+        return convs, fcs, last
+
     def init_weights(self):
-        """Xavier for shared_fcs (convfc_bbox_head.py:102-112), Normal .01/.001 for fc_cls/fc_reg
-        (bbox_head.py:83-94)"""
-        for fc in self.shared_fcs:
+        """Xavier for shared / cls / reg fcs (convfc_bbox_head.py:102-112), Normal .01/.001 for
+        fc_cls/fc_reg (bbox_head.py:83-94)"""
+        for fc in list(self.shared_fcs) + list(self.cls_fcs) + list(self.reg_fcs):
             nn.init.xavier_normal_(fc.weight, gain=1)
             nn.init.constant_(fc.bias, 0)
         nn.init.normal_(self.fc_cls.weight, 0, 0.01)
@@ -159,6 +193,8 @@ class ProbConvFCBBoxHead(nn.Module):
     # ---- execution -------------------------------------------------------------------
     def forward_nhwc(self, roi_feats):
         """roi_feats (K, ph, pw, C) -> (cls_score (K,C+1), bbox_pred (K,4C))"""
+        if not self._simple:
+            return self._forward_general(roi_feats)
         k, ph, pw, c = roi_feats.shape
         x = roi_feats.reshape(k, ph * pw * c)
         from .autograd import linear_autograd, wants_grad
@@ -194,6 +230,58 @@ class ProbConvFCBBoxHead(nn.Module):
         y = ops.linear_nhwc(x, w, b, False, out_f32=True)   # fp32 scores / deltas in either mode
         nc = self.fc_cls.out_features
         return y[:, :nc], y[:, nc:]
+
+    # ---- general ConvFC structure (VOC recipe) ------------------------------------------
+    def _fc(self, x, fc, relu, spatial=None, out_f32=False):
+        """x (K, features) through nn.Linear `fc` on the MFMA linear kernel.  `spatial` =
+        (ph, pw, C) when x is a flattened NHWC map: the reference flattens (C, ph, pw), so the
+        weight columns are permuted once to the NHWC order."""
+        from .autograd import linear_autograd, wants_grad
+        if wants_grad(x, fc.weight, fc.bias):
+            w = fc.weight
+            if spatial is not None:
+                ph, pw, c = spatial
+                w = w.view(-1, c, ph, pw).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
+            y = linear_autograd(x.float(), w, fc.bias)
+            return y.relu() if relu else y
+        cache = self._fc_caches.setdefault(id(fc), PackedCache())
+
+        def builder():
+            w = fc.weight.detach().float()
+            if spatial is not None:
+                ph, pw, c = spatial
+                w = w.view(-1, c, ph, pw).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
+            return w.to(x.dtype).contiguous(), fc.bias.detach().float().contiguous()
+        w, b = cache.get([fc.weight, fc.bias], builder)
+        return ops.linear_nhwc(x.contiguous(), w, b, relu, out_f32=out_f32)
+
+    def _branch(self, x, spatial, convs, fcs):
+        for conv in convs:
+            x = conv.forward_nhwc(x)
+            spatial = (x.shape[1], x.shape[2], x.shape[3])
+        if x.dim() > 2:
+            x = x.reshape(x.shape[0], -1)
+        for i, fc in enumerate(fcs):
+            x = self._fc(x, fc, True, spatial if i == 0 else None)
+            spatial = None
+        return x, spatial
+
+    def _forward_general(self, roi_feats):
+        k, ph, pw, c = roi_feats.shape
+        x, spatial = roi_feats, (ph, pw, c)
+        for conv in self.shared_convs:
+            x = conv.forward_nhwc(x)
+            spatial = (x.shape[1], x.shape[2], x.shape[3])
+        if self.num_shared_fcs > 0:
+            x = x.reshape(k, -1)
+            for i, fc in enumerate(self.shared_fcs):
+                x = self._fc(x, fc, True, spatial if i == 0 else None)
+            spatial = None
+        x_cls, sp_cls = self._branch(x, spatial, self.cls_convs, self.cls_fcs)
+        x_reg, sp_reg = self._branch(x, spatial, self.reg_convs, self.reg_fcs)
+        cls_score = self._fc(x_cls, self.fc_cls, False, sp_cls, out_f32=True)
+        bbox_pred = self._fc(x_reg, self.fc_reg, False, sp_reg, out_f32=True)
+        return cls_score.float(), bbox_pred.float()
 
     def forward(self, x):
         """reference signature: x (K,C,ph,pw) -> cls_score, bbox_pred"""

@@ -326,6 +326,7 @@ def _populate(m):
         m.is_list_of = lambda seq, t: isinstance(seq, list) and all(isinstance(s, t) for s in seq)
         m.is_seq_of = lambda seq, t, seq_type=None: all(isinstance(s, t) for s in seq)
         m.is_str = lambda x: isinstance(x, str)
+        m.list_from_file = lambda f, **k: [ln.rstrip('\n\r') for ln in open(f)]
         # image arithmetic (mmcv -> OpenCV, both absent): this repo's restatement, so that the
         # reference's TRANSFORM LOGIC (scales, boxes, flips, metas) can be pinned around it
         from brcnn import pipelines as _P
@@ -338,6 +339,15 @@ def _populate(m):
         m.impad = lambda img, shape=None, padding=None, pad_val=0, padding_mode='constant': \
             _P.impad(img, shape, pad_val)
         m.impad_to_multiple = _P.impad_to_multiple
+    elif name == 'terminaltables':
+        class AsciiTable:
+            def __init__(self, data, title=None):
+                self.table_data, self.inner_footing_row_border = data, False
+
+            @property
+            def table(self):
+                return '\n'.join(' | '.join(str(c) for c in row) for row in self.table_data)
+        m.AsciiTable = AsciiTable
     elif name == 'mmcv.parallel':
         from brcnn import pipelines as _P
         m.DataContainer = _P.DataContainer

@@ -352,7 +352,7 @@ def kat():
     print('kat_mmcv_ops.json', d['nms_keep'], d['soft_linear_inds'], d['soft_linear_scores'])
 
 
-from synth import synthetic_coco  # noqa: E402
+from synth import synthetic_coco, synthetic_voc  # noqa: E402
 
 
 def g12_pipeline(cfg):
@@ -469,7 +469,95 @@ def g14_coco_dataset():
     npz('g14_coco_dataset', **d)
 
 
+def g15_voc():
+    """VOC recipe pieces through the reference: VarifocalLoss values + gradient, the ConvFC box
+    head with cls FCs / GN reg convs (forward on seeded weights), RPN loss with VarifocalLoss,
+    XMLDataset annotation parsing, eval_map (VOC07 11-point and area AP)."""
+    import tempfile
+    from mmdet.models.losses import VarifocalLoss
+    from mmdet.models import build_head
+    from mmdet.core.evaluation.mean_ap import eval_map
+    from mmdet.datasets import VOCDataset
+    d = {}
+    g = torch.Generator().manual_seed(15)
+    pred = torch.randn(300, 1, generator=g).requires_grad_()
+    target = torch.zeros(300, 1)
+    target[::7, 0] = torch.rand(43, generator=g)
+    for iw in (True, False):
+        loss = VarifocalLoss(use_sigmoid=True, alpha=0.75, gamma=2.0, iou_weighted=iw, loss_weight=1.5)(
+            pred, target, avg_factor=37.0)
+        grad, = torch.autograd.grad(loss, pred)
+        d[f'vfl_{int(iw)}'], d[f'vfl_grad_{int(iw)}'] = loss.detach(), grad
+    d['vfl_pred'], d['vfl_target'] = pred.detach(), target
+    # box head of the VOC recipe
+    head_cfg = dict(type='ProbConvFCBBoxHead', num_cls_fcs=2, num_reg_convs=4,
+                    norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), in_channels=256,
+                    fc_out_channels=1024, roi_feat_size=7, num_classes=20,
+                    bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.],
+                                    target_stds=[0.1, 0.1, 0.2, 0.2]),
+                    reg_class_agnostic=False, loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=2.0),
+                    loss_bbox=dict(type='L1Loss', loss_weight=2.0))
+    head = build_head(cfgdict(copy.deepcopy(head_cfg)))
+    head.load_state_dict(util.seeded_state_dict(head, seed=15))
+    head.eval()
+    feats = torch.randn(12, 256, 7, 7, generator=torch.Generator().manual_seed(151))   # regenerated by the test
+    with torch.no_grad():
+        cs, bp = head(feats)
+    d['head_cfg'] = np.array(json.dumps(head_cfg))
+    d['head_keys'] = np.array(sorted(head.state_dict().keys()))
+    d['head_cls'], d['head_reg'] = cs, bp
+    # RPN loss with VarifocalLoss (VOC recipe's rpn_head / train_cfg.rpn)
+    vcfg = Config.fromfile(os.path.join(ROOT, 'configs', 'boosting_rcnn', 'boosting_rcnn_r50_pafpn_1x_voc.py'))
+    rc = vcfg.model.rpn_head.to_dict()
+    rc.update(train_cfg=vcfg.model.train_cfg.rpn.to_dict(), test_cfg=vcfg.model.test_cfg.rpn.to_dict())
+    rpn = build_head(cfgdict(copy.deepcopy(rc)))
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    cls = [torch.randn(2, 1, h, w, generator=g) for h, w in sizes]
+    reg = [torch.randn(2, 4, h, w, generator=g) * 0.3 for h, w in sizes]
+    iou = [torch.randn(2, 1, h, w, generator=g) for h, w in sizes]
+    _, metas, gts, _ = util.demo_inputs(2, 128, 192, seed=15, num_gt=4)
+    losses = rpn.loss(cls, reg, iou, gts, metas)
+    for i in range(5):
+        d[f'rpn_cls{i}'], d[f'rpn_reg{i}'], d[f'rpn_iou{i}'] = cls[i], reg[i], iou[i]
+    for k, v in losses.items():
+        d['rpn_' + k] = torch.stack([x.detach() for x in v])
+    # dataset + evaluation
+    with tempfile.TemporaryDirectory() as root:
+        lst, prefix = synthetic_voc(root)
+        ds = VOCDataset(ann_file=lst, img_prefix=prefix, pipeline=[], test_mode=True)
+        d['voc_len'] = np.array(len(ds))
+        rng = np.random.RandomState(3)
+        results = []
+        for i in range(len(ds)):
+            a = ds.get_ann_info(i)
+            for k in ('bboxes', 'labels', 'bboxes_ignore', 'labels_ignore'):
+                d[f'voc_{i}_{k}'] = a[k]
+            per = []
+            for c in range(20):
+                gt = a['bboxes'][a['labels'] == c]
+                det = [np.concatenate([b + rng.uniform(-6, 6, 4), [rng.rand()]]) for b in gt if rng.rand() < 0.8]
+                det += [np.concatenate([np.sort(rng.uniform(0, 90, 2)), np.sort(rng.uniform(0, 90, 2))])[[0, 2, 1, 3]].tolist()
+                        + [rng.rand()] for _ in range(rng.randint(0, 2))]
+                per.append(np.array(det, dtype=np.float32).reshape(-1, 5))
+            results.append(per)
+        for i, per in enumerate(results):
+            for c, x in enumerate(per):
+                d[f'res_{i}_{c}'] = x
+        anns = [ds.get_ann_info(i) for i in range(len(ds))]
+        for name, kw in (('voc07', dict(dataset='voc07', use_legacy_coordinate=True)),
+                         ('area', dict(dataset=None, use_legacy_coordinate=False)),
+                         ('thr75', dict(dataset='voc07', use_legacy_coordinate=True, iou_thr=0.75))):
+            m, res = eval_map(results, anns, nproc=1, **kw)
+            d[f'map_{name}'] = np.array(m)
+            d[f'aps_{name}'] = np.array([r['ap'] for r in res])
+        d['voc_eval'] = np.array(json.dumps(ds.evaluate(results, metric='mAP')))
+    npz('g15_voc', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'voc':
+        g15_voc()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'data':
         g12_pipeline(None)
         g13_samplers()

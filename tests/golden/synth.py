@@ -40,3 +40,32 @@ def synthetic_coco(root, n_img=7, seed=3, classes=('echinus', 'starfish', 'holot
     ann_file = os.path.join(root, 'ann.json')
     json.dump(dict(images=images, annotations=anns, categories=cats), open(ann_file, 'w'))
     return ann_file, os.path.join(root, 'imgs')
+
+
+def synthetic_voc(root, n_img=6, seed=4):
+    """tiny VOC2007-style tree: JPEGImages/<id>.jpg.npy is NOT used (annotations only carry sizes),
+    Annotations/<id>.xml with difficult / foreign-class / tiny objects, ImageSets/Main/test.txt"""
+    rng = np.random.RandomState(seed)
+    base = os.path.join(root, 'VOC2007')
+    os.makedirs(os.path.join(base, 'Annotations'), exist_ok=True)
+    os.makedirs(os.path.join(base, 'ImageSets', 'Main'), exist_ok=True)
+    names = ['aeroplane', 'bicycle', 'bird', 'person', 'dog', 'unicorn']
+    ids = []
+    for i in range(n_img):
+        img_id = f'{i:06d}'
+        ids.append(img_id)
+        w, h = int(rng.randint(100, 300)), int(rng.randint(100, 300))
+        objs = []
+        for j in range(rng.randint(0 if i == 3 else 1, 5)):
+            bw, bh = rng.randint(4, w // 2), rng.randint(4, h // 2)
+            x, y = rng.randint(1, w - bw), rng.randint(1, h - bh)
+            objs.append(f'<object><name>{names[rng.randint(len(names))]}</name>'
+                        f'<difficult>{int(rng.rand() < 0.25)}</difficult><bndbox><xmin>{x}</xmin><ymin>{y}</ymin>'
+                        f'<xmax>{x + bw}</xmax><ymax>{y + bh}.0</ymax></bndbox></object>')
+        size = f'<size><width>{w}</width><height>{h}</height><depth>3</depth></size>' if i != 2 else \
+            f'<size><width>{w}</width><height>20</height><depth>3</depth></size>'
+        open(os.path.join(base, 'Annotations', img_id + '.xml'), 'w').write(
+            f'<annotation><filename>{img_id}.jpg</filename>{size}{"".join(objs)}</annotation>')
+    lst = os.path.join(base, 'ImageSets', 'Main', 'test.txt')
+    open(lst, 'w').write('\n'.join(ids) + '\n')
+    return lst, base + '/'

@@ -223,3 +223,67 @@ def test_collate_and_loader(tmp_path):
     assert isinstance(data['img'], list) and data['img'][0].shape[0] == 1
     assert isinstance(data['img_metas'], list) and isinstance(data['img_metas'][0], list)
     assert data['img_metas'][0][0]['ori_filename'] == '000.npy'
+
+
+# --------------------------------------------------------------------------- VOC recipe (g15)
+def test_voc_dataset_and_eval_map_match_reference_golden(tmp_path):
+    from brcnn.evaluation import eval_map
+    from tests.golden.synth import synthetic_voc
+    g = load('g15_voc')
+    lst, prefix = synthetic_voc(str(tmp_path))
+    ds = D.VOCDataset(ann_file=lst, img_prefix=prefix, pipeline=[], test_mode=True)
+    assert len(ds) == int(g['voc_len']) and ds.year == 2007
+    for i in range(len(ds)):
+        a = ds.get_ann_info(i)
+        for k in ('bboxes', 'labels', 'bboxes_ignore', 'labels_ignore'):
+            assert np.array_equal(a[k], g[f'voc_{i}_{k}']) and a[k].dtype == g[f'voc_{i}_{k}'].dtype, (i, k)
+    results = [[g[f'res_{i}_{c}'] for c in range(20)] for i in range(len(ds))]
+    anns = [ds.get_ann_info(i) for i in range(len(ds))]
+    for name, kw in (('voc07', dict(dataset='voc07', use_legacy_coordinate=True)),
+                     ('area', dict(dataset=None, use_legacy_coordinate=False)),
+                     ('thr75', dict(dataset='voc07', use_legacy_coordinate=True, iou_thr=0.75))):
+        m, res = eval_map(results, anns, **kw)
+        assert m == pytest.approx(float(g[f'map_{name}']), abs=1e-7)
+        assert np.allclose(np.array([r['ap'] for r in res]), g[f'aps_{name}'], atol=1e-7)
+    assert ds.evaluate(results, metric='mAP') == pytest.approx(json.loads(str(g['voc_eval'])))
+    tr = D.VOCDataset(ann_file=lst, img_prefix=prefix, pipeline=[], min_size=8)
+    assert len(tr) < len(ds)                       # empty-gt and too-small images are filtered
+    rep = D.build_dataset(dict(type='RepeatDataset', times=3,
+                               dataset=dict(type='VOCDataset', ann_file=lst, img_prefix=prefix, pipeline=[])))
+    assert len(rep) == 3 * len(tr) and len(rep.flag) == len(rep)
+    cat = D.build_dataset(dict(type='VOCDataset', ann_file=[lst, lst], img_prefix=[prefix, prefix], pipeline=[]))
+    assert len(cat) == 2 * len(tr) and len(cat.flag) == len(cat)
+
+
+def test_varifocal_loss_and_voc_rpn_loss_match_reference_golden():
+    from brcnn import Config
+    from brcnn.losses import VarifocalLoss
+    from tests import util
+    g = load('g15_voc')
+    pred = torch.from_numpy(g['vfl_pred']).requires_grad_()
+    target = torch.from_numpy(g['vfl_target'])
+    for iw in (True, False):
+        loss = VarifocalLoss(use_sigmoid=True, alpha=0.75, gamma=2.0, iou_weighted=iw, loss_weight=1.5)(
+            pred, target, avg_factor=37.0)
+        grad, = torch.autograd.grad(loss, pred)
+        assert torch.allclose(loss.detach(), torch.from_numpy(g[f'vfl_{int(iw)}']), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(grad, torch.from_numpy(g[f'vfl_grad_{int(iw)}']), rtol=1e-5, atol=1e-8)
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                       'configs/boosting_rcnn/boosting_rcnn_r50_pafpn_1x_voc.py'))
+    c = cfg.model.rpn_head.copy()
+    c.update(train_cfg=cfg.model.train_cfg.rpn, test_cfg=cfg.model.test_cfg.rpn)
+    head = brcnn.build_head(c)
+    cls = [torch.from_numpy(g[f'rpn_cls{i}']) for i in range(5)]
+    reg = [torch.from_numpy(g[f'rpn_reg{i}']) for i in range(5)]
+    iou = [torch.from_numpy(g[f'rpn_iou{i}']) for i in range(5)]
+    _, metas, gts, _ = util.demo_inputs(2, 128, 192, seed=15, num_gt=4)
+    losses = head.loss(cls, reg, iou, gts, metas)
+    for k, v in losses.items():
+        assert torch.allclose(torch.stack(v), torch.from_numpy(g['rpn_' + k]), rtol=1e-5, atol=1e-6), k
+
+
+def test_voc_box_head_structure():
+    g = load('g15_voc')
+    head = brcnn.build_head(json.loads(str(g['head_cfg'])))
+    assert sorted(head.state_dict().keys()) == g['head_keys'].tolist()
+    assert not head._simple and head.fc_reg.in_features == 256 * 49 and head.fc_cls.in_features == 1024

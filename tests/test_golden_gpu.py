@@ -198,7 +198,8 @@ def test_train_step_losses_golden():
 
 
 @pytest.mark.parametrize('cfg_name', ['boosting_rcnn_r101_pafpn_softnms_coco.py',
-                                      'boosting_rcnn_r50_pafpn_1x_coco.py'])
+                                      'boosting_rcnn_r50_pafpn_1x_coco.py',
+                                      'boosting_rcnn_r50_pafpn_1x_voc.py'])
 def test_other_configs_device_vs_cpu_oracle_pipeline(cfg_name):
     """BASELINE configs #3/#5 at test time: COCO heads (80 classes) and the ResNet-101 +
     soft-NMS recipe (2000 proposals, score_thr 1e-4) -- device path against the CPU oracle
@@ -223,7 +224,7 @@ def test_other_configs_device_vs_cpu_oracle_pipeline(cfg_name):
     assert n_ref > 10
     hit = tot = 0
     for b in range(2):
-        for c in range(80):
+        for c in range(len(ref[b])):
             r, g_ = ref[b][c], got[b][c]
             tot += len(r)
             if len(r) and len(g_):
@@ -319,3 +320,34 @@ def test_train_step_empty_gt_image():
     loss, log_vars = m._parse_losses(losses)
     assert torch.isfinite(loss) and loss.item() > 0
     loss.backward()
+
+
+def test_voc_box_head_golden_and_train_step():
+    """VOC recipe: ConvFC box head with 2 cls FCs + 4 GroupNorm reg convs on
+    the HIP path against the reference's own forward (golden g15), and one train step of the
+    whole VOC detector (VarifocalLoss RPN) with finite gradients on every trainable tensor."""
+    import os
+    g = load('g15_voc')
+    head = brcnn.build_head(json.loads(str(g['head_cfg'])))
+    head.load_state_dict(util.seeded_state_dict(head, seed=15))
+    head = head.to(DEV).eval()
+    feats = torch.randn(12, 256, 7, 7, generator=torch.Generator().manual_seed(151)).to(DEV)
+    with torch.no_grad():
+        cs, bp = head(feats)
+    assert _close(cs, T(g['head_cls'])) and _close(bp, T(g['head_reg']))
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), 'boosting_rcnn_r50_pafpn_1x_voc.py'))
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=4))
+    m = m.to(DEV).train()
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, num_classes=20, seed=4)
+    torch.manual_seed(3)
+    losses = m.forward_train(img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    loss, log_vars = m._parse_losses(losses)
+    assert np.isfinite(log_vars['loss']) and 'loss_rpn_cls' in log_vars
+    loss.backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if p.requires_grad and not k.startswith(('backbone.conv1', 'backbone.bn1', 'backbone.layer1')):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            n += 1
+    assert n > 100
