@@ -402,7 +402,12 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     assert runner_cfg['type'] == 'EpochBasedRunner'
     runner = EpochBasedRunner(model, optimizer, cfg.work_dir, logger, runner_cfg['max_epochs'], meta)
     runner.timestamp = timestamp
-    assert cfg.get('fp16', None) is None, 'fp16 loss-scaling hook is not part of this path (bf16 needs none)'
+    if cfg.get('fp16', None) is not None:
+        # the recipe asks for mmcv's Fp16OptimizerHook (fp16 + loss scaling); the MI355X path's
+        # reduced-precision mode is bf16 MFMA with fp32 master weights, which needs no loss scale
+        logger.info(f'fp16={dict(cfg.fp16)} in the config: training with the bf16 conv stack instead '
+                    '(no loss scaling needed)')
+        (model.module if hasattr(model, 'module') else model).set_compute_dtype('bf16')
     runner.register_training_hooks(cfg.lr_config, cfg.get('optimizer_config', None),
                                    cfg.get('checkpoint_config', None), cfg.get('log_config', None))
     for hook in cfg.get('custom_hooks', None) or []:

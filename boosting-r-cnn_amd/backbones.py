@@ -54,16 +54,16 @@ class ResLayer(nn.Sequential):
     """mmdet/models/utils/res_layer.py: first block carries the stride and the 1x1 downsample."""
 
     def __init__(self, block, inplanes, planes, num_blocks, stride=1, style='pytorch',
-                 norm_cfg=dict(type='BN')):
+                 norm_cfg=dict(type='BN'), **block_kwargs):
         downsample = None
         if stride != 1 or inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
                 build_norm_layer(norm_cfg, planes * block.expansion)[1])
-        layers = [block(inplanes, planes, stride, downsample, style, norm_cfg)]
+        layers = [block(inplanes, planes, stride, downsample, style, norm_cfg, **block_kwargs)]
         inplanes = planes * block.expansion
         for _ in range(1, num_blocks):
-            layers.append(block(inplanes, planes, 1, None, style, norm_cfg))
+            layers.append(block(inplanes, planes, 1, None, style, norm_cfg, **block_kwargs))
         super().__init__(*layers)
 
     def forward_nhwc(self, x):
@@ -107,7 +107,7 @@ class ResNet(nn.Module):
         for i, num_blocks in enumerate(self.stage_blocks):
             planes = base_channels * 2 ** i
             layer = ResLayer(self.block, self.inplanes, planes, num_blocks, strides[i], style,
-                             norm_cfg)
+                             norm_cfg, **self.block_kwargs())
             self.inplanes = planes * self.block.expansion
             name = f'layer{i + 1}'
             self.add_module(name, layer)
@@ -117,6 +117,10 @@ class ResNet(nn.Module):
         self._stem_cache2 = PackedCache()
         self._freeze_stages()
         self.init_weights()
+
+    def block_kwargs(self):
+        """extra constructor arguments of the residual block (ResNeXt: groups / base_width)"""
+        return {}
 
     def init_weights(self):
         """Kaiming (fan_out, relu) for convs, constant 1 for norms, zero for the last BN of each
@@ -201,3 +205,37 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         return tuple(to_nchw_view(o) for o in self.forward_nhwc(to_nhwc(x)))
+
+
+# --------------------------------------------------------------------------- ResNeXt
+class BottleneckX(Bottleneck):
+    """resnext.py:10-84: conv1 / conv2 / conv3 run at `width = floor(planes * base_width /
+    base_channels) * groups`, conv2 is a grouped 3x3"""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style='pytorch', norm_cfg=dict(type='BN'),
+                 groups=1, base_width=4, base_channels=64):
+        super().__init__(inplanes, planes, stride, downsample, style, norm_cfg)
+        import math
+        width = planes if groups == 1 else math.floor(planes * (base_width / base_channels)) * groups
+        self.groups, self.width = groups, width
+        self.conv1 = nn.Conv2d(inplanes, width, 1, stride=self.conv1_stride, bias=False)
+        self.bn1 = build_norm_layer(norm_cfg, width, 1)[1]
+        self.conv2 = nn.Conv2d(width, width, 3, stride=self.conv2_stride, padding=1, groups=groups, bias=False)
+        self.bn2 = build_norm_layer(norm_cfg, width, 2)[1]
+        self.conv3 = nn.Conv2d(width, planes * self.expansion, 1, bias=False)
+
+
+@BACKBONES.register_module()
+class ResNeXt(ResNet):
+    """mmdet/models/backbones/resnext.py:87-153 (the x101 64x4d recipe); the grouped 3x3 convs run
+    as block-diagonal 64-channel tiles on the MFMA kernel (`brcnn_conv2d_nhwc_grouped`)"""
+    arch_settings = {50: (BottleneckX, (3, 4, 6, 3)), 101: (BottleneckX, (3, 4, 23, 3)),
+                     152: (BottleneckX, (3, 8, 36, 3))}
+
+    def __init__(self, groups=1, base_width=4, **kwargs):
+        self.groups, self.base_width = groups, base_width
+        self._base_channels = kwargs.get('base_channels', 64)
+        super().__init__(**kwargs)
+
+    def block_kwargs(self):
+        return dict(groups=self.groups, base_width=self.base_width, base_channels=self._base_channels)

@@ -105,6 +105,8 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
         raise NotImplementedError('training-mode BatchNorm is not on the HIP path '
                                   '(the reference runs BN in eval mode: norm_eval=True)')
     from .autograd import conv2d_nhwc_autograd, wants_grad
+    if conv.groups > 1:
+        return _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual)
     if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                   residual if residual is not None and residual.requires_grad else None):
         y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
@@ -133,6 +135,31 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
 
     w, scale, shift = cache.get(srcs, builder)
     return ops.conv2d_nhwc(x, w, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
+
+
+def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):
+    """grouped conv (ResNeXt conv2) + folded eval-BN + ReLU in one launch; inference / frozen only"""
+    from .autograd import wants_grad
+    if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None):
+        raise NotImplementedError('grouped convolution has no HIP backward yet (ResNeXt trains next round); '
+                                  'run it under torch.no_grad() or freeze the stage')
+    if x.dtype != torch.float32:
+        raise NotImplementedError('grouped convolution runs in fp32 only this round')
+    srcs = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var]
+                                       if bn is not None else [])
+
+    def builder():
+        w, window = ops.pack_grouped_weight(conv.weight, conv.groups)
+        scale = shift = None
+        if bn is not None:
+            scale, shift = fold_bn(bn)
+            if conv.bias is not None:
+                shift = shift + conv.bias.detach().float() * scale
+        elif conv.bias is not None:
+            shift = conv.bias.detach().float().contiguous()
+        return w, window, scale, shift
+    w, window, scale, shift = cache.get(srcs, builder)
+    return ops.conv2d_nhwc_grouped(x, w, window, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
 
 
 class ConvModule(nn.Module):

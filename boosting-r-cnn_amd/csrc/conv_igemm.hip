@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
                 wi = qw;
             }
             ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
-            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j]) * 4 : OOB;
+            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j] + tile_n * p.gstep) * 4 : OOB;
             float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
         }
@@ -601,6 +601,45 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     p.relu = relu;
     if (bf16) return dispatch_conv_bf16(p, (hipStream_t)stream);
     return dispatch_conv(p, (hipStream_t)stream);
+}
+
+// Grouped convolution (ResNeXt, resnext.py:10-84: conv2 of every bottleneck has `groups` = 32 / 64).
+// An output tile of 64 channels covers 64/cg_out whole groups whose input channels form ONE
+// contiguous window of `window` = 64 * cg_in / cg_out channels, so the tile is a dense 64 x
+// (KH*KW*window) GEMM on block-diagonal weights: the 64x64 LDS-DMA kernel runs unchanged with
+// its A operand shifted by tile_n * window channels.  `w_tiles` (Cout, KH, KW, window) holds,
+// for output channel co of tile t = co / 64, the filter taps at window position
+// (co / cg_out) * cg_in - t * window + ci and zeros elsewhere (brcnn.ops.pack_grouped_weight).
+BRCNN_API int brcnn_conv2d_nhwc_grouped(const void* x, const void* w_tiles, const float* scale,
+                                        const float* shift, const void* residual, void* y, int batch,
+                                        int height, int width, int cin, int cout, int kh, int kw,
+                                        int stride, int pad, int window, int relu, int dtype,
+                                        void* stream) {
+    if (!x || !w_tiles || !y || batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || kh <= 0 ||
+        kw <= 0 || stride <= 0 || pad < 0 || dtype != BRCNN_DT_F32 || window <= 0 || (window % 32) ||
+        (cout % 64) || (cout / 64) * window != cin || height + pad >= 4096 || width + pad >= 4096)
+        return BRCNN_EINVAL;
+    const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+    ConvParams p = {};
+    p.x = (const float*)x; p.w = (const float*)w_tiles; p.scale = scale; p.shift = shift;
+    p.residual = (const float*)residual; p.y = (float*)y;
+    p.batch = batch; p.Cin = window; p.Cout = cout; p.KH = kh; p.KW = kw;
+    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = 1; p.dilate = 1; p.gstep = window;
+    p.seg_H[0] = height; p.seg_W[0] = width; p.seg_Ho[0] = Ho; p.seg_Wo[0] = Wo;
+    p.seg_m0[0] = 0; p.seg_xoff[0] = 0;
+    const long long m_total = (long long)batch * Ho * Wo, x_elems = (long long)batch * height * width * cin;
+    for (int sgi = 1; sgi <= BRCNN_MAX_LEVELS; sgi++) p.seg_m0[sgi] = (int)m_total;
+    p.K = kh * kw * window;
+    if (x_elems * 4 >= 0x7fffffffLL || (long long)cout * p.K * 4 >= 0x7fffffffLL || m_total > 0x7fffffffLL)
+        return BRCNN_EINVAL;
+    p.x_bytes = (unsigned)(x_elems * 4);
+    p.w_bytes = (unsigned)((long long)cout * p.K * 4);
+    p.M = (int)m_total;
+    p.relu = relu;
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = cout / 64;
+    return p.residual ? launch_dma<1, 1, true>(p, (hipStream_t)stream) : launch_dma<1, 1, false>(p, (hipStream_t)stream);
 }
 
 BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float* scale,

@@ -446,6 +446,41 @@ def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=
     return y
 
 
+def pack_grouped_weight(weight, groups):
+    """(Cout, Cin/g, KH, KW) grouped-conv parameter -> (Cout, KH, KW, window) block-diagonal tiles
+    for `conv2d_nhwc_grouped` (window = input channels seen by one 64-channel output tile)"""
+    cout, cg_in, kh, kw = weight.shape
+    cg_out = cout // groups
+    assert cout % 64 == 0 and 64 % cg_out == 0, 'grouped conv: Cout % 64 == 0 and 64 % (Cout/groups) == 0'
+    window = (64 // cg_out) * cg_in
+    assert window % 32 == 0
+    w = weight.detach().float().permute(0, 2, 3, 1)                       # (Cout, KH, KW, cg_in)
+    out = torch.zeros((cout, kh, kw, window), dtype=torch.float32, device=weight.device)
+    co = torch.arange(cout, device=weight.device)
+    start = ((co // cg_out) * cg_in) - (co // 64) * window               # window position of each filter
+    idx = (start[:, None] + torch.arange(cg_in, device=weight.device)[None, :])   # (Cout, cg_in)
+    out.scatter_(3, idx[:, None, None, :].expand(cout, kh, kw, cg_in), w)
+    return out.contiguous(), window
+
+
+def conv2d_nhwc_grouped(x, w_tiles, window, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+    """grouped conv on the MFMA kernel; `w_tiles`, `window` from pack_grouped_weight"""
+    _require_gpu(x, w_tiles, scale, shift, residual)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and w_tiles.is_contiguous()
+    n, h, wd, cin = x.shape
+    cout, kh, kw, win = w_tiles.shape
+    assert win == window
+    ho, wo = conv_out_size(h, wd, kh, kw, stride, pad)
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.is_contiguous()
+    st = _L.load().brcnn_conv2d_nhwc_grouped(_ptr(x), _ptr(w_tiles), _ptr(scale), _ptr(shift), _ptr(residual),
+                                             _ptr(y), n, h, wd, cin, cout, kh, kw, int(stride), int(pad),
+                                             int(window), int(bool(relu)), DT_F32, _stream())
+    _L.check(st, 'brcnn_conv2d_nhwc_grouped')
+    return y
+
+
 def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=None, relu=False,
                       stride=1, pad=0, out_f32=False):
     """The same conv over several back-to-back segments that share the weights (pyramid

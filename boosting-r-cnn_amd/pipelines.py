@@ -14,11 +14,12 @@ restated: `imresize_u8` is OpenCV's 8-bit INTER_LINEAR (11-bit fixed-point coeff
 `cv::resize` resizeGeneric_ / HResizeLinear / VResizeLinear<uchar,int,short>), `imnormalize`
 is mmcv.imnormalize (fp32 subtract, multiply by fp32(1/std)).  PARITY UNPINNED for the resize:
 neither cv2 nor a golden vector of it exists in this container; the restatement follows the
-published algorithm and is cross-checked by its invariants (tests/test_pipeline_data_cpu.py).
+published algorithm and is cross-checked by its invariants (tests/test_data_cpu.py); the
+transform LOGIC around it is pinned by golden fixtures from the imported reference (g12, g16).
 
 `FusedResizeNormalizePad` is the device form of Resize+RandomFlip+Normalize+Pad for one
 decoded uint8 image (HIP kernel `brcnn_preprocess_u8`, csrc/preprocess.hip), bit-identical to
-the host chain above; `DeviceBatchPreprocessor` applies it at collate time.
+the host chain above; `fuse_device_pipeline` rewrites a pipeline config to use it.
 """
 import collections
 import os.path as osp
@@ -476,6 +477,100 @@ class Pad:
     def __repr__(self):
         return (f'{self.__class__.__name__}(size={self.size}, size_divisor={self.size_divisor}, '
                 f'pad_val={self.pad_val})')
+
+
+@PIPELINES.register_module()
+class RandomCrop:
+    """transforms.py:742-896 (image + boxes + labels; masks / seg maps are outside the path)"""
+
+    def __init__(self, crop_size, crop_type='absolute', allow_negative_crop=False, recompute_bbox=False,
+                 bbox_clip_border=True):
+        if crop_type not in ['relative_range', 'relative', 'absolute', 'absolute_range']:
+            raise ValueError(f'Invalid crop_type {crop_type}.')
+        if crop_type in ['absolute', 'absolute_range']:
+            assert crop_size[0] > 0 and crop_size[1] > 0
+            assert isinstance(crop_size[0], int) and isinstance(crop_size[1], int)
+        else:
+            assert 0 < crop_size[0] <= 1 and 0 < crop_size[1] <= 1
+        self.crop_size, self.crop_type = tuple(crop_size), crop_type
+        self.allow_negative_crop, self.bbox_clip_border = allow_negative_crop, bbox_clip_border
+        self.recompute_bbox = recompute_bbox
+        self.bbox2label = {'gt_bboxes': 'gt_labels', 'gt_bboxes_ignore': 'gt_labels_ignore'}
+
+    def _crop_data(self, results, crop_size, allow_negative_crop):
+        assert crop_size[0] > 0 and crop_size[1] > 0
+        for key in results.get('img_fields', ['img']):
+            img = results[key]
+            margin_h = max(img.shape[0] - crop_size[0], 0)
+            margin_w = max(img.shape[1] - crop_size[1], 0)
+            offset_h = np.random.randint(0, margin_h + 1)
+            offset_w = np.random.randint(0, margin_w + 1)
+            crop_y1, crop_y2 = offset_h, offset_h + crop_size[0]
+            crop_x1, crop_x2 = offset_w, offset_w + crop_size[1]
+            img = img[crop_y1:crop_y2, crop_x1:crop_x2, ...]
+            img_shape = img.shape
+            results[key] = img
+        results['img_shape'] = img_shape
+        for key in results.get('bbox_fields', []):
+            bbox_offset = np.array([offset_w, offset_h, offset_w, offset_h], dtype=np.float32)
+            bboxes = results[key] - bbox_offset
+            if self.bbox_clip_border:
+                bboxes[:, 0::2] = np.clip(bboxes[:, 0::2], 0, img_shape[1])
+                bboxes[:, 1::2] = np.clip(bboxes[:, 1::2], 0, img_shape[0])
+            valid_inds = (bboxes[:, 2] > bboxes[:, 0]) & (bboxes[:, 3] > bboxes[:, 1])
+            if key == 'gt_bboxes' and not valid_inds.any() and not allow_negative_crop:
+                return None
+            results[key] = bboxes[valid_inds, :]
+            label_key = self.bbox2label.get(key)
+            if label_key in results:
+                results[label_key] = results[label_key][valid_inds]
+        return results
+
+    def _get_crop_size(self, image_size):
+        h, w = image_size
+        if self.crop_type == 'absolute':
+            return min(self.crop_size[0], h), min(self.crop_size[1], w)
+        if self.crop_type == 'absolute_range':
+            assert self.crop_size[0] <= self.crop_size[1]
+            crop_h = np.random.randint(min(h, self.crop_size[0]), min(h, self.crop_size[1]) + 1)
+            crop_w = np.random.randint(min(w, self.crop_size[0]), min(w, self.crop_size[1]) + 1)
+            return crop_h, crop_w
+        if self.crop_type == 'relative':
+            crop_h, crop_w = self.crop_size
+            return int(h * crop_h + 0.5), int(w * crop_w + 0.5)
+        crop_size = np.asarray(self.crop_size, dtype=np.float32)
+        crop_h, crop_w = crop_size + np.random.rand(2) * (1 - crop_size)
+        return int(h * crop_h + 0.5), int(w * crop_w + 0.5)
+
+    def __call__(self, results):
+        crop_size = self._get_crop_size(results['img'].shape[:2])
+        return self._crop_data(results, crop_size, self.allow_negative_crop)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(crop_size={self.crop_size}, crop_type={self.crop_type}, '
+                f'allow_negative_crop={self.allow_negative_crop}, bbox_clip_border={self.bbox_clip_border})')
+
+
+@PIPELINES.register_module()
+class AutoAugment:
+    """auto_augment.py:44-109: one of several transform sequences, drawn per sample"""
+
+    def __init__(self, policies):
+        import copy
+        assert isinstance(policies, list) and len(policies) > 0, 'Policies must be a non-empty list.'
+        for policy in policies:
+            assert isinstance(policy, list) and len(policy) > 0, 'Each policy in policies must be a non-empty list.'
+            for augment in policy:
+                assert isinstance(augment, dict) and 'type' in augment
+        self.policies = copy.deepcopy(policies)
+        self.transforms = [Compose(policy) for policy in self.policies]
+
+    def __call__(self, results):
+        transform = np.random.choice(self.transforms)
+        return transform(results)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}(policies={self.policies})'
 
 
 class DataContainer:

@@ -171,6 +171,15 @@ int brcnn_conv2d_nhwc_multi(const void *x, const void *w, const float *scale, co
                             int kh, int kw, int stride, int pad, int relu, int dtype,
                             void *stream);
 
+/* Grouped convolution (ResNeXt bottleneck conv2, mmdet/models/backbones/resnext.py:10-84).
+ * x (N,H,W,Cin) fp32; w_tiles (Cout,KH,KW,window) block-diagonal per 64-channel output tile
+ * (tile t = co/64 reads input channels [t*window, (t+1)*window), window = 64*cg_in/cg_out,
+ * a multiple of 32; Cout % 64 == 0); same fused epilogue as brcnn_conv2d_nhwc. */
+int brcnn_conv2d_nhwc_grouped(const void *x, const void *w_tiles, const float *scale,
+                              const float *shift, const void *residual, void *y, int batch,
+                              int height, int width, int cin, int cout, int kh, int kw, int stride,
+                              int pad, int window, int relu, int dtype, void *stream);
+
 /* Backward of the convolution (autograd of the trainable convs / FCs; the reference gets these
  * from cuDNN/cuBLAS through torch autograd).
  * dgrad: dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout) and w_t (Cin,KH,KW,Cout) =

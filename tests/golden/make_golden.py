@@ -554,7 +554,67 @@ def g15_voc():
     npz('g15_voc', **d)
 
 
+def g16_resnext_autoaug():
+    """the reference's ResNeXt (grouped 3x3 convs; 32x4d, depth 50: group widths 4/8/16/32) on a
+    seeded input, and its AutoAugment / RandomCrop pipeline logic on a synthetic sample"""
+    from mmdet.models import build_backbone
+    from mmdet.datasets.pipelines import Compose
+    d = {}
+    bcfg = dict(type='ResNeXt', depth=50, groups=32, base_width=4, num_stages=4, out_indices=(0, 1, 2, 3),
+                frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=True), style='pytorch')
+    m = build_backbone(cfgdict(copy.deepcopy(bcfg)))
+    m.load_state_dict(util.seeded_state_dict(m, seed=16))
+    m.eval()
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(161))
+    with torch.no_grad():
+        outs = m(x)
+    d['backbone_cfg'] = np.array(json.dumps(bcfg))
+    d['keys'] = np.array(sorted(m.state_dict().keys()))
+    for i, t in enumerate(outs):
+        d[f'c{i}_stat'] = np.array([t.double().mean(), t.double().std(), t.double().abs().max()])
+        d[f'c{i}_slice'] = t[:, :16, :4, :6]
+        d[f'c{i}_sum'] = t.double().sum((2, 3))
+    # AutoAugment with the x101 recipe's two policies (sizes scaled down)
+    pol = [dict(type='RandomFlip', flip_ratio=0.5),
+           dict(type='AutoAugment', policies=[
+               [dict(type='Resize', img_scale=[(96, 200), (112, 200), (128, 200)], multiscale_mode='value',
+                     keep_ratio=True)],
+               [dict(type='Resize', img_scale=[(80, 420), (100, 420), (120, 420)], multiscale_mode='value',
+                     keep_ratio=True),
+                dict(type='RandomCrop', crop_type='absolute_range', crop_size=(64, 100), allow_negative_crop=True),
+                dict(type='Resize', img_scale=[(96, 200), (112, 200), (128, 200)], multiscale_mode='value',
+                     override=True, keep_ratio=True)]]),
+           dict(type='Normalize', mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+           dict(type='Pad', size_divisor=1),
+           dict(type='DefaultFormatBundle'),
+           dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels'])]
+    rng = np.random.RandomState(6)
+    img = rng.randint(0, 256, (90, 140, 3), dtype=np.uint8)
+    boxes = np.array([[10, 12, 60, 50], [0, 0, 140, 90], [100, 60, 139.5, 89.2], [70, 5, 90, 30]], dtype=np.float32)
+    labels = np.array([0, 3, 1, 2], dtype=np.int64)
+    d['img'], d['boxes'], d['labels'] = img, boxes, labels
+    d['pipe_cfg'] = np.array(json.dumps(pol))
+    pipe = Compose(pol)
+    for s_ in range(8):
+        np.random.seed(70 + s_)
+        out = pipe(dict(img=img.copy(), img_shape=img.shape, ori_shape=img.shape, img_fields=['img'], filename='x',
+                        ori_filename='x', gt_bboxes=boxes.copy(), gt_labels=labels.copy(), bbox_fields=['gt_bboxes']))
+        t = out['img'].data
+        d[f'aa{s_}_shape'] = np.array(t.shape)
+        d[f'aa{s_}_sum'] = t.double().sum((1, 2))
+        d[f'aa{s_}_boxes'] = out['gt_bboxes'].data
+        d[f'aa{s_}_labels'] = out['gt_labels'].data
+        m_ = out['img_metas'].data
+        d[f'aa{s_}_meta'] = np.array(json.dumps(dict(img_shape=list(m_['img_shape']), pad_shape=list(m_['pad_shape']),
+                                                     scale_factor=[float(v) for v in m_['scale_factor']],
+                                                     flip=bool(m_['flip']))))
+    npz('g16_resnext_autoaug', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'x101':
+        g16_resnext_autoaug()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'voc':
         g15_voc()
         return

@@ -287,3 +287,25 @@ def test_voc_box_head_structure():
     head = brcnn.build_head(json.loads(str(g['head_cfg'])))
     assert sorted(head.state_dict().keys()) == g['head_keys'].tolist()
     assert not head._simple and head.fc_reg.in_features == 256 * 49 and head.fc_cls.in_features == 1024
+
+
+def test_autoaugment_random_crop_match_reference_golden():
+    g = load('g16_resnext_autoaug')
+    pipe = P.Compose(_cfg(str(g['pipe_cfg'])))
+    seen = set()
+    for s in range(8):
+        np.random.seed(70 + s)
+        out = pipe(dict(img=g['img'].copy(), img_shape=g['img'].shape, ori_shape=g['img'].shape, img_fields=['img'],
+                        filename='x', ori_filename='x', gt_bboxes=g['boxes'].copy(), gt_labels=g['labels'].copy(),
+                        bbox_fields=['gt_bboxes']))
+        t = out['img'].data
+        assert list(t.shape) == g[f'aa{s}_shape'].tolist()
+        assert np.allclose(t.double().sum((1, 2)).numpy(), g[f'aa{s}_sum'], rtol=0, atol=1e-6)
+        assert np.array_equal(out['gt_bboxes'].data.numpy(), g[f'aa{s}_boxes'])
+        assert np.array_equal(out['gt_labels'].data.numpy(), g[f'aa{s}_labels'])
+        meta = json.loads(str(g[f'aa{s}_meta']))
+        m = out['img_metas'].data
+        assert list(m['img_shape']) == meta['img_shape'] and bool(m['flip']) == meta['flip']
+        assert [float(v) for v in m['scale_factor']] == meta['scale_factor']
+        seen.add(len(out['gt_labels'].data))
+    assert len(seen) > 1       # some draws took the crop policy and lost boxes
