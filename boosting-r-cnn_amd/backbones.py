@@ -239,3 +239,265 @@ class ResNeXt(ResNet):
 
     def block_kwargs(self):
         return dict(groups=self.groups, base_width=self.base_width, base_channels=self._base_channels)
+
+
+# --------------------------------------------------------------------------- Res2Net (+ DCNv2)
+class DCNv2(nn.Module):
+    """mmcv.ops.ModulatedDeformConv2dPack (the `dcn=dict(type='DCNv2', deform_groups=1)` of the
+    r2_101 recipes): a 3x3 conv whose taps are displaced by learned offsets and scaled by a
+    learned mask, both predicted by `conv_offset` (zero-initialised).  Parameter names as mmcv's:
+    `weight`, `conv_offset.{weight,bias}`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1,
+                 deform_groups=1, bias=False):
+        super().__init__()
+        assert groups == 1 and deform_groups == 1 and kernel_size == 3 and not bias
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = (3, 3), stride, padding, dilation
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.conv_offset = nn.Conv2d(in_channels, 27, 3, stride=stride, padding=padding, dilation=dilation, bias=True)
+        nn.init.kaiming_uniform_(self.weight, nonlinearity='relu')
+        nn.init.constant_(self.conv_offset.weight, 0)
+        nn.init.constant_(self.conv_offset.bias, 0)
+
+
+def _pad_to(n, mult=32):
+    return (n + mult - 1) // mult * mult
+
+
+class Bottle2neck(nn.Module):
+    """res2net.py:13-162.  The `scales` splits of conv1's output are `width` = 26/52/104/208 channels
+    wide; here every split is laid out padded to a multiple of 32 channels (zero filters / zero
+    BN affine in the pad slots, so the pad channels stay exactly 0 through ReLU, the hierarchical
+    adds and the concat), which keeps all convs on the vector (LDS-DMA) MFMA path; the packed,
+    padded weights are functions of the reference-layout parameters."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style='pytorch', norm_cfg=dict(type='BN'),
+                 scales=4, base_width=26, base_channels=64, stage_type='normal', dcn=None):
+        super().__init__()
+        import math
+        assert scales > 1 and style == 'pytorch'
+        self.inplanes, self.planes, self.stride, self.style = inplanes, planes, stride, style
+        self.conv1_stride, self.conv2_stride = 1, stride
+        width = int(math.floor(planes * (base_width / base_channels)))
+        self.width, self.scales, self.stage_type = width, scales, stage_type
+        self.with_dcn = dcn is not None
+        self.conv1 = nn.Conv2d(inplanes, width * scales, 1, stride=1, bias=False)
+        self.add_module('bn1', build_norm_layer(norm_cfg, width * scales, 1)[1])
+        if stage_type == 'stage' and stride != 1:
+            self.pool = nn.AvgPool2d(kernel_size=3, stride=stride, padding=1)
+        convs, bns = [], []
+        for i in range(scales - 1):
+            if self.with_dcn:
+                convs.append(DCNv2(width, width, 3, stride=stride, padding=1, deform_groups=dcn.get('deform_groups', 1)))
+            else:
+                convs.append(nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False))
+            bns.append(build_norm_layer(norm_cfg, width, i + 1)[1])
+        self.convs, self.bns = nn.ModuleList(convs), nn.ModuleList(bns)
+        self.conv3 = nn.Conv2d(width * scales, planes * self.expansion, 1, bias=False)
+        self.add_module('bn3', build_norm_layer(norm_cfg, planes * self.expansion, 3)[1])
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self._cache = PackedCache()
+        self._c_down = PackedCache()
+
+    # ---- padded, packed tensors (inference: cached; rebuilt when a parameter changes) --------
+    def _packed(self):
+        from .blocks import fold_bn, pack_weight
+        w, s, wp = self.width, self.scales, _pad_to(self.width)
+
+        def builder():
+            d = {}
+            s1, b1 = fold_bn(self.bn1)
+            w1 = self.conv1.weight.detach().float().view(s, w, self.inplanes)
+            d['w1'] = torch.nn.functional.pad(w1, (0, 0, 0, wp - w)).reshape(s * wp, 1, 1, self.inplanes).contiguous()
+            d['s1'] = torch.nn.functional.pad(s1.view(s, w), (0, wp - w)).reshape(-1).contiguous()
+            d['b1'] = torch.nn.functional.pad(b1.view(s, w), (0, wp - w)).reshape(-1).contiguous()
+            for i, (conv, bn) in enumerate(zip(self.convs, self.bns)):
+                si, bi = fold_bn(bn)
+                wi = pack_weight(conv.weight)                                   # (w, 3, 3, w)
+                d[f'cw{i}'] = torch.nn.functional.pad(wi, (0, wp - w, 0, 0, 0, 0, 0, wp - w)).contiguous()
+                d[f'cs{i}'] = torch.nn.functional.pad(si, (0, wp - w)).contiguous()
+                d[f'cb{i}'] = torch.nn.functional.pad(bi, (0, wp - w)).contiguous()
+                if self.with_dcn:
+                    wo = pack_weight(conv.conv_offset.weight)                   # (27, 3, 3, w)
+                    d[f'wo{i}'] = torch.nn.functional.pad(wo, (0, wp - w)).contiguous()
+                    d[f'bo{i}'] = conv.conv_offset.bias.detach().float().contiguous()
+            s3, b3 = fold_bn(self.bn3)
+            w3 = self.conv3.weight.detach().float().view(-1, s, w)
+            d['w3'] = torch.nn.functional.pad(w3, (0, wp - w)).reshape(-1, 1, 1, s * wp).contiguous()
+            d['s3'], d['b3'] = s3, b3
+            return d
+        srcs = [p for p in self.parameters()] + [b for b in self.buffers() if b.dtype.is_floating_point]
+        return self._cache.get(srcs, builder)
+
+    def _conv_i(self, d, i, sp):
+        """convs[i] + bns[i] + ReLU on a (N,h,w,wp) split"""
+        conv = self.convs[i]
+        if not self.with_dcn:
+            return ops.conv2d_nhwc(sp, d[f'cw{i}'], d[f'cs{i}'], d[f'cb{i}'], None, True, self.conv2_stride, 1)
+        om = ops.conv2d_nhwc(sp, d[f'wo{i}'], None, d[f'bo{i}'], None, False, self.conv2_stride, 1)
+        col, (ho, wo) = ops.deform_im2col_nhwc(sp, om, 3, self.conv2_stride, 1, 1)
+        n, wp = sp.shape[0], sp.shape[3]
+        y = ops.conv2d_nhwc(col.view(n * ho * wo, 1, 1, 9 * wp), d[f'cw{i}'].reshape(wp, 1, 1, 9 * wp),
+                            d[f'cs{i}'], d[f'cb{i}'], None, True, 1, 0)
+        return y.view(n, ho, wo, wp)
+
+    def forward_nhwc(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('Res2Net blocks have no HIP backward yet (they train next round); '
+                                      'run under torch.no_grad() or freeze the stage')
+        if x.dtype != torch.float32:
+            raise NotImplementedError('Res2Net runs in fp32 only this round')
+        d = self._packed()
+        wp, s = _pad_to(self.width), self.scales
+        out = ops.conv2d_nhwc(x, d['w1'], d['s1'], d['b1'], None, True, 1, 0)     # (N,h,w,s*wp)
+        spx = [out[..., i * wp:(i + 1) * wp] for i in range(s)]
+        sp = self._conv_i(d, 0, spx[0].contiguous())
+        outs = [sp]
+        for i in range(1, s - 1):
+            sp = spx[i].contiguous() if self.stage_type == 'stage' else sp + spx[i]
+            sp = self._conv_i(d, i, sp)
+            outs.append(sp)
+        if self.stage_type == 'normal' or self.conv2_stride == 1:
+            outs.append(spx[s - 1])
+        else:
+            outs.append(ops.avgpool_nhwc(spx[s - 1].contiguous(), 3, self.conv2_stride, 1, False, True))
+        cat = torch.cat(outs, 3)
+        identity = x
+        if self.downsample is not None:
+            pool, conv, bn = self.downsample[0], self.downsample[1], self.downsample[2]
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            xi = x if k == 1 else ops.avgpool_nhwc(x, k, k, 0, True, False)
+            identity = conv_bn_act_nhwc(xi, conv, bn, self._c_down, False)
+        return ops.conv2d_nhwc(cat, d['w3'], d['s3'], d['b3'], identity, True, 1, 0)
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
+
+
+class Res2Layer(nn.Sequential):
+    """res2net.py:165-233: avg_down shortcut (AvgPool(stride, ceil_mode, no pad count) + 1x1 conv + BN),
+    first block of a stage is of type 'stage'"""
+
+    def __init__(self, block, inplanes, planes, num_blocks, stride=1, style='pytorch', norm_cfg=dict(type='BN'),
+                 scales=4, base_width=26, base_channels=64, dcn=None):
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True, count_include_pad=False),
+                nn.Conv2d(inplanes, planes * block.expansion, 1, stride=1, bias=False),
+                build_norm_layer(norm_cfg, planes * block.expansion)[1])
+        kw = dict(scales=scales, base_width=base_width, base_channels=base_channels, dcn=dcn)
+        layers = [block(inplanes, planes, stride, downsample, style, norm_cfg, stage_type='stage', **kw)]
+        inplanes = planes * block.expansion
+        for _ in range(1, num_blocks):
+            layers.append(block(inplanes, planes, 1, None, style, norm_cfg, **kw))
+        super().__init__(*layers)
+
+    def forward_nhwc(self, x):
+        for blk in self:
+            x = blk.forward_nhwc(x)
+        return x
+
+
+@BACKBONES.register_module()
+class Res2Net(nn.Module):
+    """mmdet/models/backbones/res2net.py:236-327 (always the v1d form: deep 3x3 stem, avg_down),
+    with optional DCNv2 in the stages of `stage_with_dcn` (resnet.py:500-520)"""
+    arch_settings = {50: (Bottle2neck, (3, 4, 6, 3)), 101: (Bottle2neck, (3, 4, 23, 3)),
+                     152: (Bottle2neck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, scales=4, base_width=26, in_channels=3, stem_channels=None, base_channels=64,
+                 num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3),
+                 style='pytorch', deep_stem=True, avg_down=True, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True, pretrained=None, init_cfg=None):
+        super().__init__()
+        assert depth in self.arch_settings and conv_cfg is None and plugins is None
+        assert all(d == 1 for d in dilations) and 1 <= num_stages <= 4 and max(out_indices) < num_stages
+        self.depth, self.scales, self.base_width = depth, scales, base_width
+        self.num_stages, self.out_indices, self.frozen_stages = num_stages, out_indices, frozen_stages
+        self.norm_cfg, self.norm_eval, self.init_cfg = norm_cfg, norm_eval, init_cfg
+        self.zero_init_residual = zero_init_residual
+        stem_channels = stem_channels or base_channels
+        block, stage_blocks = self.arch_settings[depth]
+        h = stem_channels // 2
+        self.stem = nn.Sequential(
+            nn.Conv2d(in_channels, h, 3, stride=2, padding=1, bias=False), build_norm_layer(norm_cfg, h)[1],
+            nn.ReLU(inplace=True),
+            nn.Conv2d(h, h, 3, stride=1, padding=1, bias=False), build_norm_layer(norm_cfg, h)[1],
+            nn.ReLU(inplace=True),
+            nn.Conv2d(h, stem_channels, 3, stride=1, padding=1, bias=False),
+            build_norm_layer(norm_cfg, stem_channels)[1], nn.ReLU(inplace=True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.res_layers, inplanes = [], stem_channels
+        for i, nb in enumerate(stage_blocks[:num_stages]):
+            planes = base_channels * 2 ** i
+            stage_dcn = None
+            if dcn is not None and stage_with_dcn[i]:
+                stage_dcn = dict(dcn)
+                stage_dcn.pop('fallback_on_stride', None)
+                assert stage_dcn.pop('type') == 'DCNv2'
+            layer = Res2Layer(block, inplanes, planes, nb, strides[i], style, norm_cfg, scales, base_width,
+                              base_channels, stage_dcn)
+            inplanes = planes * block.expansion
+            self.add_module(f'layer{i + 1}', layer)
+            self.res_layers.append(f'layer{i + 1}')
+        self.feat_dim = inplanes
+        self._stem_caches = [PackedCache() for _ in range(3)]
+        self._freeze_stages()
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():
+            if isinstance(m, DCNv2):
+                nn.init.constant_(m.conv_offset.weight, 0)
+                nn.init.constant_(m.conv_offset.bias, 0)
+        if self.zero_init_residual and not (isinstance(self.init_cfg, dict) and
+                                            self.init_cfg.get('type') == 'Pretrained'):
+            for m in self.modules():
+                if isinstance(m, Bottle2neck):
+                    nn.init.constant_(m.bn3.weight, 0)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.stem.eval()
+            for p in self.stem.parameters():
+                p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def forward_nhwc(self, x):
+        for j in range(3):
+            x = conv_bn_act_nhwc(x, self.stem[3 * j], self.stem[3 * j + 1], self._stem_caches[j], True)
+        x = ops.maxpool3x3s2_nhwc(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name).forward_nhwc(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def forward(self, x):
+        return tuple(to_nchw_view(o) for o in self.forward_nhwc(to_nhwc(x)))

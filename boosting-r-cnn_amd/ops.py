@@ -712,3 +712,42 @@ def preprocess_u8(src_u8, out, new_w, new_h, flip_direction, mean, std, to_rgb=T
                                        m3, s3, int(bool(to_rgb)), _stream())
     _L.check(st, 'brcnn_preprocess_u8')
     return out
+
+
+# --------------------------------------------------------------------------- Res2Net / DCNv2
+def avgpool_out_size(size, kernel, stride, pad, ceil_mode):
+    if ceil_mode:
+        o = (size + 2 * pad - kernel + stride - 1) // stride + 1
+        if (o - 1) * stride >= size + pad:
+            o -= 1
+        return o
+    return (size + 2 * pad - kernel) // stride + 1
+
+
+def avgpool_nhwc(x, kernel, stride, pad=0, ceil_mode=False, count_include_pad=True):
+    """torch.nn.AvgPool2d on an NHWC fp32 map"""
+    _require_gpu(x)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    n, h, w, c = x.shape
+    ho, wo = avgpool_out_size(h, kernel, stride, pad, ceil_mode), avgpool_out_size(w, kernel, stride, pad, ceil_mode)
+    y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    st = _L.load().brcnn_avgpool_nhwc(_ptr(x), _ptr(y), n, h, w, c, int(kernel), int(stride), int(pad),
+                                      int(bool(ceil_mode)), int(bool(count_include_pad)), _stream())
+    _L.check(st, 'brcnn_avgpool_nhwc')
+    return y
+
+
+def deform_im2col_nhwc(x, offset_mask, kernel=3, stride=1, pad=1, dilation=1, channels_padded=None):
+    """mmcv modulated deformable im2col (deform_groups 1): x (N,H,W,C), offset_mask (N,Ho,Wo,>=27)
+    raw conv_offset output -> columns (N*Ho*Wo, k*k*Cp), K order (tap, c), zero in the pad channels"""
+    _require_gpu(x, offset_mask)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    n, h, w, c = x.shape
+    cp = c if channels_padded is None else channels_padded
+    ho, wo = conv_out_size(h, w, dilation * (kernel - 1) + 1, dilation * (kernel - 1) + 1, stride, pad)
+    assert tuple(offset_mask.shape[:3]) == (n, ho, wo) and offset_mask.is_contiguous()
+    col = torch.empty((n * ho * wo, kernel * kernel * cp), dtype=torch.float32, device=x.device)
+    st = _L.load().brcnn_deform_im2col_nhwc(_ptr(x), _ptr(offset_mask), _ptr(col), n, h, w, c, kernel, kernel,
+                                            int(stride), int(pad), int(dilation), offset_mask.shape[3], cp, _stream())
+    _L.check(st, 'brcnn_deform_im2col_nhwc')
+    return col, (ho, wo)

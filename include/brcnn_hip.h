@@ -239,6 +239,18 @@ int brcnn_bn_act_backward(const void *dout, const void *out, const void *z, cons
                           size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
                           void *stream);
 
+/* Res2Net / DCNv2 rows (the r2_101 recipes): NHWC average pooling with torch.nn.AvgPool2d's
+ * window / divisor rules (res2net.py:52-54, 173-178), and mmcv's modulated deformable im2col
+ * (ModulatedDeformConv2dPack, deform_groups 1): col (N*Ho*Wo, KH*KW*channels_padded) with K
+ * order (tap, c); `offset_mask` is the raw conv_offset output (N,Ho,Wo,>=3*KH*KW) NHWC with
+ * om_stride floats per pixel: [2t] = dy, [2t+1] = dx of tap t, [2*KH*KW + t] = mask logit. */
+int brcnn_avgpool_nhwc(const float *x, float *y, int batch, int height, int width, int channels,
+                       int kernel, int stride, int pad, int ceil_mode, int count_include_pad,
+                       void *stream);
+int brcnn_deform_im2col_nhwc(const float *x, const float *offset_mask, float *col, int batch,
+                             int height, int width, int channels, int kh, int kw, int stride, int pad,
+                             int dilation, int om_stride, int channels_padded, void *stream);
+
 /* FPN top-down path: dst[n,y,x,c] += src[n, y*Hs/Hd, x*Ws/Wd, c]  (nearest,
  * F.interpolate(size=...) at necks/pafpn.py:113-115, fpn.py:178-181) */
 int brcnn_upsample_nearest_add_nhwc(void *dst, const void *src, int batch, int hd, int wd,

@@ -611,7 +611,32 @@ def g16_resnext_autoaug():
     npz('g16_resnext_autoaug', **d)
 
 
+def g17_res2net():
+    """the reference's Res2Net-50 26w x 4s (v1d: deep stem, avg_down shortcuts, hierarchical
+    Bottle2neck; no DCN -- mmcv's deformable op is not importable) on a seeded input"""
+    from mmdet.models import build_backbone
+    d = {}
+    bcfg = dict(type='Res2Net', depth=50, scales=4, base_width=26, num_stages=4, out_indices=(0, 1, 2, 3),
+                frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
+    m = build_backbone(cfgdict(copy.deepcopy(bcfg)))
+    m.load_state_dict(util.seeded_state_dict(m, seed=17))
+    m.eval()
+    x = torch.randn(2, 3, 72, 100, generator=torch.Generator().manual_seed(171))     # odd sizes: ceil_mode pooling
+    with torch.no_grad():
+        outs = m(x)
+    d['backbone_cfg'] = np.array(json.dumps(bcfg))
+    d['keys'] = np.array(sorted(m.state_dict().keys()))
+    for i, t in enumerate(outs):
+        d[f'c{i}_shape'] = np.array(t.shape)
+        d[f'c{i}_slice'] = t[:, :16, :4, :6]
+        d[f'c{i}_sum'] = t.double().sum((2, 3))
+    npz('g17_res2net', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'r2':
+        g17_res2net()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'x101':
         g16_resnext_autoaug()
         return

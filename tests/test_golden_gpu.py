@@ -399,3 +399,102 @@ def test_grouped_conv_and_resnext_golden():
     with torch.no_grad():
         res = det(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
     assert len(res) == 1 and len(res[0]) == 80 and all(r.shape[1] == 5 for r in res[0])
+
+
+def _deform_ref(x, om, w, stride, pad):
+    """modulated deformable 3x3 conv in fp64 torch, straight from the published algorithm
+    (mmcv modulated_deform_conv: taps displaced by (dy, dx), zero outside (-1, H) x (-1, W),
+    bilinear with per-corner validity, times sigmoid(mask))"""
+    n, c, h, wd = x.shape
+    ho, wo = om.shape[2], om.shape[3]
+    x, om, w = x.double(), om.double(), w.double()
+    out = torch.zeros(n, w.shape[0], ho, wo, dtype=torch.float64)
+    ys = (torch.arange(ho) * stride - pad).view(1, ho, 1).double()
+    xs = (torch.arange(wo) * stride - pad).view(1, 1, wo).double()
+    for t in range(9):
+        i, j = t // 3, t % 3
+        hy = ys + i + om[:, 2 * t]
+        wx = xs + j + om[:, 2 * t + 1]
+        mask = torch.sigmoid(om[:, 18 + t])
+        inside = (hy > -1) & (wx > -1) & (hy < h) & (wx < wd)
+        hl, wl = torch.floor(hy), torch.floor(wx)
+        lh, lw = hy - hl, wx - wl
+        val = torch.zeros(n, c, ho, wo, dtype=torch.float64)
+        for (hh, ww, wt) in ((hl, wl, (1 - lh) * (1 - lw)), (hl, wl + 1, (1 - lh) * lw),
+                             (hl + 1, wl, lh * (1 - lw)), (hl + 1, wl + 1, lh * lw)):
+            ok = inside & (hh >= 0) & (hh <= h - 1) & (ww >= 0) & (ww <= wd - 1)
+            hi, wi = hh.clamp(0, h - 1).long(), ww.clamp(0, wd - 1).long()
+            g = x[torch.arange(n).view(n, 1, 1), :, hi, wi].permute(0, 3, 1, 2)      # (n,c,ho,wo)
+            val += g * (wt * ok).unsqueeze(1)
+        val = val * mask.unsqueeze(1)
+        out += torch.einsum('nchw,oc->nohw', val, w[:, :, i, j])
+    return out
+
+
+def test_avgpool_deform_res2net_golden():
+    """Res2Net / DCNv2 rows: AvgPool2d variants against torch, the modulated
+    deformable conv (HIP im2col + MFMA GEMM) against an fp64 restatement of the published
+    algorithm, the Res2Net-50 backbone against the reference's own forward (golden g17), and the
+    r2_101 DCN recipe end to end."""
+    import os
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(12)
+    for (h, w, k, s, p, ceil, cip) in [(36, 50, 3, 2, 1, False, True), (36, 50, 2, 2, 0, True, False),
+                                       (37, 51, 2, 2, 0, True, False), (9, 13, 3, 1, 1, False, True),
+                                       (18, 25, 3, 2, 1, False, True)]:
+        x = torch.randn(2, 32, h, w, generator=gen)
+        ref = F.avg_pool2d(x, k, s, p, ceil_mode=ceil, count_include_pad=cip)
+        y = ops.avgpool_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), k, s, p, ceil, cip).permute(0, 3, 1, 2).cpu()
+        assert y.shape == ref.shape and torch.allclose(y, ref, rtol=1e-6, atol=1e-6), (h, w, k, s)
+    for (c, h, w, stride) in [(32, 14, 19, 1), (64, 15, 22, 2), (128, 9, 11, 1)]:
+        x = torch.randn(2, c, h, w, generator=gen)
+        ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+        om = torch.randn(2, 27, ho, wo, generator=gen) * 2.0
+        om[:, :18] += (torch.rand(2, 18, ho, wo, generator=gen) > 0.9).float() * 30      # some taps far outside
+        wt = torch.randn(c, c, 3, 3, generator=gen) / np.sqrt(9 * c)
+        ref = _deform_ref(x, om, wt, stride, 1)
+        col, (ho2, wo2) = ops.deform_im2col_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                                 om.permute(0, 2, 3, 1).contiguous().to(DEV), 3, stride, 1, 1)
+        assert (ho2, wo2) == (ho, wo)
+        wp = wt.permute(0, 2, 3, 1).reshape(c, 1, 1, 9 * c).contiguous().to(DEV)
+        y = ops.conv2d_nhwc(col.view(2 * ho * wo, 1, 1, 9 * c), wp).view(2, ho, wo, c).permute(0, 3, 1, 2).cpu().double()
+        assert (y - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), (c, stride)
+    g = load('g17_res2net')
+    m = brcnn.build_backbone(json.loads(str(g['backbone_cfg'])))
+    assert sorted(m.state_dict().keys()) == g['keys'].tolist()
+    m.load_state_dict(util.seeded_state_dict(m, seed=17))
+    m = m.to(DEV).eval()
+    x = torch.randn(2, 3, 72, 100, generator=torch.Generator().manual_seed(171)).to(DEV)
+    with torch.no_grad():
+        outs = m(x)
+    for i, t in enumerate(outs):
+        assert list(t.shape) == g[f'c{i}_shape'].tolist()
+        assert _close(t[:, :16, :4, :6], T(g[f'c{i}_slice']))
+        assert _close(t.double().sum((2, 3)), T(g[f'c{i}_sum']), tol=1e-3)
+    # DCN recipe end to end; with the zero-initialised conv_offset a DCN conv is an ordinary conv
+    # with mask 0.5, which the seeded (non-zero) offsets of this test then move away from
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), 'boosting_rcnn_r2_101_dcn_pafpn_mstrain_3x_coco.py'))
+    det = build_detector(cfg.model)
+    blk = det.backbone.layer2[1]
+    assert type(det.backbone).__name__ == 'Res2Net' and blk.with_dcn and not det.backbone.layer1[0].with_dcn
+    det.load_state_dict(util.seeded_state_dict(det, seed=3))
+    det = det.to(DEV).eval()
+    img, metas, _, _ = util.demo_inputs(1, 128, 192, seed=3)
+    with torch.no_grad():
+        res = det(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
+        # one DCN conv of the network against the fp64 restatement on its real input
+        xs = torch.randn(1, 40, 56, 64, generator=torch.Generator().manual_seed(9)).to(DEV)     # NHWC, wp = 64
+        xs[..., 52:] = 0
+        d = blk._packed()
+        y = blk._conv_i(d, 0, xs)
+        conv, bn = blk.convs[0], blk.bns[0]
+        xr = xs[..., :52].permute(0, 3, 1, 2).cpu()
+        omr = F.conv2d(xr, conv.conv_offset.weight.cpu(), conv.conv_offset.bias.cpu(), 1, 1)
+        ref = _deform_ref(xr, omr, conv.weight.detach().cpu(), 1, 1)
+        sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().cpu().double()
+        ref = (ref * sc.view(1, -1, 1, 1) + (bn.bias - bn.running_mean * sc.float().to(DEV)).detach().cpu().double()
+               .view(1, -1, 1, 1)).relu()
+    assert len(res[0]) == 80
+    got = y[..., :52].permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert float(y[..., 52:].abs().max()) == 0.0            # pad channels stay exactly zero
