@@ -28,11 +28,16 @@ __device__ __forceinline__ unsigned short f2bf(float v) {
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
-template <int MT, int NT, bool RES, bool OUTF32>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams p) {
-    constexpr int BM = 64 * MT, BN = 64 * NT;
-    constexpr int AG = BM / 8 / 4;      // 8-row groups of the A tile per wave
-    constexpr int BG = BN / 8 / 4;
+// WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
+// two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
+// 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
+template <int MT, int NT, bool RES, bool OUTF32, int WM>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
+    constexpr int NW = 2 * WM;          // waves per workgroup
+    constexpr int BM = 32 * MT * WM, BN = 64 * NT;
+    constexpr int AG = BM / 8 / NW;     // 8-row groups of the A tile per wave
+    constexpr int BG = BN / 8 / NW;
+    static_assert(AG >= 1 && BG >= 1 && AG * 8 * NW == BM && BG * 8 * NW == BN, "tile / wave split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][32 dwords = 128 B]
     const int nk = p.K / BKE;
@@ -273,32 +278,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_dma_kernel(ConvParams 
     }
 }
 
-template <int MT, int NT, bool RES, bool OUTF32>
+template <int MT, int NT, bool RES, bool OUTF32, int WM = 2>
 int launch(const ConvParams& p, hipStream_t s) {
-    const size_t lds_full = (size_t)2 * (64 * MT + 64 * NT) * 32 * sizeof(float);
-    const size_t lds_epi = (size_t)4 * 32 * (32 * NT + 4) * sizeof(float);
+    const size_t lds_full = (size_t)2 * (32 * MT * WM + 64 * NT) * 32 * sizeof(float);
+    const size_t lds_epi = (size_t)2 * WM * 32 * (32 * NT + 4) * sizeof(float);
     const size_t lds = p.K / BKE > 1 ? lds_full : (lds_full / 2 > lds_epi ? lds_full / 2 : lds_epi);
     static bool attr_done = false;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+        const size_t lds_max = lds_full > lds_epi ? lds_full : lds_epi;
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32>), dim3(p.tiles_m * p.tiles_n),
-                       dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM>), dim3(p.tiles_m * p.tiles_n),
+                       dim3(128 * WM), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int WM = 2>
 int launch2(ConvParams& p, hipStream_t s) {
-    p.tiles_m = (p.M + 64 * MT - 1) / (64 * MT);
+    p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
     p.tiles_n = (p.Cout + 64 * NT - 1) / (64 * NT);
-    if (p.out_f32) return p.residual ? launch<MT, NT, true, true>(p, s) : launch<MT, NT, false, true>(p, s);
-    return p.residual ? launch<MT, NT, true, false>(p, s) : launch<MT, NT, false, false>(p, s);
+    if (p.out_f32) return p.residual ? launch<MT, NT, true, true, WM>(p, s) : launch<MT, NT, false, true, WM>(p, s);
+    return p.residual ? launch<MT, NT, true, false, WM>(p, s) : launch<MT, NT, false, false, WM>(p, s);
 }
 
-int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT
+int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 waves), 42 = 256x128 (8 waves)
 
 }  // namespace
 
@@ -310,14 +316,15 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
         t = (p.Cout <= 64) ? 21 : (t22 >= 1024 ? 22 : (t22 >= 256 ? 21 : 11));
     }
-    if (t == 22 && p.Cout > 64) return launch2<2, 2>(p, s);
-    if (t == 21 || (t == 22 && p.Cout <= 64)) return launch2<2, 1>(p, s);
+    if (t == 42 && p.Cout > 64) return launch2<2, 2, 4>(p, s);
+    if ((t == 22 || t == 42) && p.Cout > 64) return launch2<2, 2>(p, s);
+    if (t == 21 || ((t == 22 || t == 42) && p.Cout <= 64)) return launch2<2, 1>(p, s);
     return launch2<1, 1>(p, s);
 }
 }  // namespace brcnn_conv
 
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
-    if (mtnt != 0 && mtnt != 11 && mtnt != 21 && mtnt != 22) return BRCNN_EINVAL;
+    if (mtnt != 0 && mtnt != 11 && mtnt != 21 && mtnt != 22 && mtnt != 42) return BRCNN_EINVAL;
     g_bf16_tile = mtnt;
     return 0;
 }

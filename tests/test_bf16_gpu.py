@@ -269,3 +269,27 @@ def test_train_step_bf16_close_to_fp32():
         assert torch.isfinite(b).all()
         cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-20)
         assert cos > 0.9, (k, cos.item())
+
+
+def test_bf16_tile_variants_agree():
+    """every bf16 tile shape (64x64, 128x64, 128x128 with 4 waves, 256x128 with 8 waves) computes the
+    same K order per output element -> bit-identical results"""
+    from brcnn import lib
+    g = torch.Generator().manual_seed(5)
+    L = lib.load()
+    for (n, cin, h, w, cout, k, stride, res) in [(2, 128, 37, 41, 256, 3, 1, True), (1, 256, 50, 84, 128, 1, 1, False),
+                                                 (3, 64, 29, 31, 512, 3, 2, True)]:
+        x = torch.randn(n, h, w, cin, generator=g).to(DEV, BF)
+        wt = (torch.randn(cout, k, k, cin, generator=g) / np.sqrt(cin * k * k)).to(DEV, BF)
+        sc, sh = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+        ho, wo = ops.conv_out_size(h, w, k, k, stride, k // 2)
+        r = torch.randn(n, ho, wo, cout, generator=g).to(DEV, BF) if res else None
+        outs = []
+        try:
+            for tile in (11, 21, 22, 42):
+                assert L.brcnn_conv_set_tile_bf16(tile) == 0
+                outs.append(ops.conv2d_nhwc(x, wt, sc, sh, r, True, stride, k // 2))
+        finally:
+            L.brcnn_conv_set_tile_bf16(0)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
