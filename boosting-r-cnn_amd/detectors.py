@@ -186,9 +186,8 @@ class TwoStageDetector(BaseDetector):
 
     def _device_path_ok(self):
         rc, rp = self.test_cfg.rcnn, self.test_cfg.rpn
-        k, c = rp.max_per_img, self.roi_head.bbox_head.num_classes
         return rc.nms.get('type', 'nms') == 'nms' and rp.nms.get('type', 'nms') == 'nms' and \
-            k * c < rc.nms.get('split_thr', 10000)
+            not rc.nms.get('class_agnostic', False)
 
 
 @DETECTORS.register_module()

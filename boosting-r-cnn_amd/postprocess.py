@@ -54,7 +54,8 @@ def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offse
     return dets, ids_kept, num
 
 
-def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_threshold, max_keep, offset=0):
+def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_threshold, max_keep, offset=0,
+                                return_ids=False):
     """mmcv `batched_nms` above `split_thr` for a whole mini-batch, no host sync: NMS per id
     (pyramid level) on the offset boxes, survivors re-sorted by score, first `max_keep`
     (mmcv/ops/nms.py batched_nms, the `for id in torch.unique(idxs)` branch).  Column ranges
@@ -110,4 +111,7 @@ def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_thre
     kmask = torch.arange(K, device=device)[None, :] < n_kept[:, None]
     dets = torch.cat([torch.gather(c_boxes, 1, order[..., None].expand(B, K, 4)),
                       torch.gather(c_scores, 1, order)[..., None]], 2) * kmask[..., None]
+    if return_ids:
+        ids_kept = torch.where(kmask, torch.gather(c_ids, 1, order), torch.full((), -1, dtype=c_ids.dtype, device=device))
+        return dets, ids_kept, n_kept
     return dets, n_kept
