@@ -182,6 +182,189 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// NHWC forward, footprint form (default).  The sampling grid of a bin is a product grid and the
+// bilinear weight of a sample is hy*hx / ly*hx / ..., validity and border clamping are per axis,
+// so   sum_samples sum_corners w * v  ==  sum_{rows} sum_{cols} Wy[row] * Wx[col] * v[row,col]
+// with Wy[row] = sum over the bin's valid y-samples of the weight they put on that row (same for
+// Wx).  A bin then reads every pixel of its footprint ONCE ((rows x cols) <= (gh+1) x (gw+1)
+// loads instead of 4*gh*gw): the kernel is bound by L2->CU bytes, and this halves them on the
+// 7x7-bins-of-1..2-px RoIs the level mapping produces.  Lane l evaluates y-sample l and x-sample l
+// and then holds Wy[row_min + l], Wx[col_min + l]; the accumulation order differs from the
+// reference's sample order, so results agree to fp32 round-off (not bit for bit -- the exact-order
+// kernel above stays selectable with brcnn_roi_align_set_exact).  Grids or footprints wider than
+// 64 (bins larger than ~60 px) take the sample loop.
+// ---------------------------------------------------------------------------------------
+struct AxisSample { int lo, hi; float wlo, whi; bool valid; };
+
+__device__ __forceinline__ AxisSample axis_sample(float v, int size) {
+    AxisSample a;
+    a.valid = !(v < -1.0f || v > (float)size);
+    if (v <= 0) v = 0;
+    int lo = (int)v, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; }
+    else hi = lo + 1;
+    a.lo = lo; a.hi = hi;
+    a.whi = v - (float)lo;
+    a.wlo = 1.f - a.whi;
+    return a;
+}
+
+// per-axis footprint weights: returns (first index, extent); lane l ends up with W[first + l]
+__device__ __forceinline__ void axis_weights(float start, float bin, int pidx, int g, int size, int lane,
+                                             int& first, int& extent, float& W) {
+    const float v = start + pidx * bin + (float)(lane + .5f) * bin / (float)g;
+    AxisSample a = axis_sample(v, size);
+    const bool live = lane < g && a.valid;
+    const unsigned long long m = __ballot(live);
+    if (m == 0ull) { first = 0; extent = 0; W = 0.f; return; }
+    const int f = __ffsll((long long)m) - 1, l = 63 - __clzll((long long)m);
+    first = __shfl(a.lo, f);
+    extent = __shfl(a.hi, l) - first + 1;
+    const int mine = first + lane;
+    float w = 0.f;
+    for (int i = f; i <= l; i++) {           // valid samples are a contiguous run (monotonic coordinate)
+        const int lo = __shfl(a.lo, i), hi = __shfl(a.hi, i);
+        const float wl = __shfl(a.wlo, i), wh = __shfl(a.whi, i);
+        if (lo == mine) w += wl;
+        if (hi == mine) w += wh;
+    }
+    W = w;
+}
+
+// one wave per (roi, ph) ROW of bins: the level mapping (sqrt / log2), the RoI geometry (divisions,
+// ceil) and the y-axis weights are computed once per row instead of once per bin -- with 1..2 px
+// bins the per-bin address / weight arithmetic, not the bytes, is what bounds this kernel
+template <bool MULTI, typename T = float>
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
+    const T* __restrict__ input, LevelTable lv, const float* __restrict__ rois,
+    T* __restrict__ output, int32_t* __restrict__ levels_out, int channels, int height,
+    int width, int n_rois, int ph_n, int pw_n, float spatial_scale, int sampling_ratio,
+    int aligned) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= (long long)n_rois * ph_n) return;
+    const int k = (int)(row / ph_n);
+    const int ph = (int)(row - (long long)k * ph_n);
+    const float* roi = rois + (size_t)k * 5;
+    const T* feat = input;
+    if (MULTI) {
+        int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
+        feat = reinterpret_cast<const T*>(lv.feat[l]);
+        height = lv.height[l];
+        width = lv.width[l];
+        spatial_scale = lv.scale[l];
+        if (levels_out && ph == 0 && lane == 0) levels_out[k] = l;
+    }
+    const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
+    const T* base = feat + (size_t)g.batch * height * width * channels;
+    T* out_row = output + (size_t)row * pw_n * channels;
+    const bool small = g.gh <= 64 && g.gw <= 64;
+    int y0 = 0, ny = 0;
+    float Wy = 0.f;
+    if (small) axis_weights(g.start_h, g.bin_h, ph, g.gh, height, lane, y0, ny, Wy);
+    // x-axis weights of ALL bins of the row at once when a bin has <= 8 samples and <= 8 footprint
+    // columns (bins up to 7 px): lane group q = lane/8 is bin pw = q, slot j = lane%8
+    const int q = lane >> 3, jx = lane & 7;
+    int x0_all = 0, nx_all = 0;
+    float Wx_all = 0.f;
+    bool vecx = small && g.gw <= 8 && pw_n <= 8;
+    if (vecx) {
+        const float v = g.start_w + q * g.bin_w + (float)(jx + .5f) * g.bin_w / (float)g.gw;
+        const AxisSample a = axis_sample(v, width);
+        const bool live = jx < g.gw && q < pw_n && a.valid;
+        const unsigned mg = (unsigned)((__ballot(live) >> (q * 8)) & 0xffull);
+        if (mg) {
+            const int f = __ffs((int)mg) - 1, l = 31 - __clz((int)mg);
+            x0_all = __shfl(a.lo, q * 8 + f);
+            nx_all = __shfl(a.hi, q * 8 + l) - x0_all + 1;
+        }
+        const int mine = x0_all + jx;
+        float w = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int lo = __shfl(a.lo, q * 8 + i), hi = __shfl(a.hi, q * 8 + i);
+            const float wl = __shfl(a.wlo, q * 8 + i), wh = __shfl(a.whi, q * 8 + i);
+            if ((mg >> i) & 1u) {
+                if (lo == mine) w += wl;
+                if (hi == mine) w += wh;
+            }
+        }
+        Wx_all = w;
+        if (__ballot(nx_all > 8) != 0ull) vecx = false;
+    }
+    for (int pw = 0; pw < pw_n; pw++) {
+        T* out = out_row + (size_t)pw * channels;
+        int x0 = 0, nx = 0;
+        float Wx = 0.f;
+        if (vecx) {
+            x0 = __shfl(x0_all, pw * 8);
+            nx = __shfl(nx_all, pw * 8);
+            Wx = __shfl(Wx_all, pw * 8 + (lane & 7));      // lane l < 8 holds the weight of column x0 + l
+        } else if (small) {
+            axis_weights(g.start_w, g.bin_w, pw, g.gw, width, lane, x0, nx, Wx);
+        }
+        if (small && ny <= 64 && nx <= 64) {
+            for (int c0 = lane * 4; c0 < channels; c0 += 256) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                // 2 rows x 4 columns of the footprint per batch: 8 independent 16-byte loads in
+                // flight; positions past the footprint re-read its last pixel with weight 0
+                for (int ry = 0; ry < ny; ry += 2) {
+                    const float wy0 = __shfl(Wy, ry);
+                    const float wy1 = (ry + 1 < ny) ? __shfl(Wy, ry + 1) : 0.f;
+                    const T* r0 = base + (size_t)(y0 + ry) * width * channels + c0;
+                    const T* r1 = base + (size_t)(y0 + min(ry + 1, ny - 1)) * width * channels + c0;
+                    for (int rx = 0; rx < nx; rx += 4) {
+                        float4 v0[4], v1[4];
+                        float wx[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int xx = x0 + min(rx + j, nx - 1);
+                            v0[j] = ld4(r0 + (size_t)xx * channels);
+                            v1[j] = ld4(r1 + (size_t)xx * channels);
+                            wx[j] = (rx + j < nx) ? __shfl(Wx, rx + j) : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float a = wy0 * wx[j], b = wy1 * wx[j];
+                            acc.x += a * v0[j].x; acc.y += a * v0[j].y; acc.z += a * v0[j].z; acc.w += a * v0[j].w;
+                            acc.x += b * v1[j].x; acc.y += b * v1[j].y; acc.z += b * v1[j].z; acc.w += b * v1[j].w;
+                        }
+                    }
+                }
+                acc.x /= g.count; acc.y /= g.count; acc.z /= g.count; acc.w /= g.count;
+                st4(out + c0, acc);
+            }
+            continue;
+        }
+        for (int c0 = lane * 4; c0 < channels; c0 += 256) {      // huge bins: the sample loop
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < g.gh; iy++) {
+                const float y = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.gh;
+                for (int ix = 0; ix < g.gw; ix++) {
+                    const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
+                    const Tap t = bilinear_tap(y, x, height, width);
+                    if (!t.valid) continue;
+                    const float4 v1 = ld4(base + (size_t)t.p1 * channels + c0);
+                    const float4 v2 = ld4(base + (size_t)t.p2 * channels + c0);
+                    const float4 v3 = ld4(base + (size_t)t.p3 * channels + c0);
+                    const float4 v4 = ld4(base + (size_t)t.p4 * channels + c0);
+                    acc.x += t.w1 * v1.x + t.w2 * v2.x + t.w3 * v3.x + t.w4 * v4.x;
+                    acc.y += t.w1 * v1.y + t.w2 * v2.y + t.w3 * v3.y + t.w4 * v4.y;
+                    acc.z += t.w1 * v1.z + t.w2 * v2.z + t.w3 * v3.z + t.w4 * v4.z;
+                    acc.w += t.w1 * v1.w + t.w2 * v2.w + t.w3 * v3.w + t.w4 * v4.w;
+                }
+            }
+            acc.x /= g.count; acc.y /= g.count; acc.z /= g.count; acc.w /= g.count;
+            st4(out + c0, acc);
+        }
+    }
+}
+
+int g_roi_exact = 0;     // 1: exact sample-order kernel (bit-identical to the reference's CPU order)
+
 // NHWC backward (avg): same decomposition, atomicAdd of g*w/count to the four corners.
 template <bool MULTI>
 __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(
@@ -315,9 +498,14 @@ BRCNN_API int brcnn_roi_align_forward(const float* input, const float* rois, flo
         if (pool_mode != 1 || (channels & 3)) return BRCNN_EINVAL;
         LevelTable lv = {};
         const long long bins = (long long)n_rois * pooled_h * pooled_w;
-        hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<false, float>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
-                           s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
-                           n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
+        if (g_roi_exact)
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<false, float>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
+                               s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
+                               n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
+        else
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<false, float>), dim3(brcnn_cdiv((long long)n_rois * pooled_h, 4)), dim3(256), 0,
+                               s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
+                               n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
     } else if (layout == BRCNN_LAYOUT_NCHW) {
         if (pool_mode == 0 && (!argmax_y || !argmax_x)) return BRCNN_EINVAL;
         int grid = brcnn_cdiv(total, 256);
@@ -395,14 +583,27 @@ BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int
     if (n_rois == 0) return 0;
     if (!rois || !output) return BRCNN_EINVAL;
     const long long bins = (long long)n_rois * pooled_h * pooled_w;
-    if (dtype == BRCNN_DT_BF16)
-        hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, bf16_t>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
-                           (hipStream_t)stream, (const bf16_t*)nullptr, lv, rois, (bf16_t*)output, levels_out,
-                           channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
-    else
-    hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, float>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)nullptr, lv, rois, (float*)output, levels_out,
-                       channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    const dim3 grid(brcnn_cdiv(bins, 4)), grid_rows(brcnn_cdiv((long long)n_rois * pooled_h, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == BRCNN_DT_BF16) {
+        if (g_roi_exact)
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)nullptr,
+                               lv, rois, (bf16_t*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
+                               sampling_ratio, 1);
+        else
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, bf16_t>), grid_rows, dim3(256), 0, s,
+                               (const bf16_t*)nullptr, lv, rois, (bf16_t*)output, levels_out, channels, 0, 0, n_rois,
+                               pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    } else {
+        if (g_roi_exact)
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, float>), grid, dim3(256), 0, s, (const float*)nullptr,
+                               lv, rois, (float*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
+                               sampling_ratio, 1);
+        else
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, float>), grid_rows, dim3(256), 0, s,
+                               (const float*)nullptr, lv, rois, (float*)output, levels_out, channels, 0, 0, n_rois,
+                               pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    }
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -426,5 +627,11 @@ BRCNN_API int brcnn_roi_extract_backward(float* const* grad_feats_host, const in
                        (hipStream_t)stream, grad_output, lv, rois, (float*)nullptr, channels, 0, 0,
                        n_rois, pooled_h, pooled_w, 0.f, sampling_ratio, 1);
     BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+
+BRCNN_API int brcnn_roi_align_set_exact(int exact) {
+    g_roi_exact = exact ? 1 : 0;
     return 0;
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     'brcnn_conv2d_nhwc_grouped': (c_int, [c_ptr] * 6 + [c_int] * 12 + [c_ptr]),
     'brcnn_avgpool_nhwc': (c_int, [c_ptr, c_ptr] + [c_int] * 9 + [c_ptr]),
     'brcnn_deform_im2col_nhwc': (c_int, [c_ptr] * 3 + [c_int] * 11 + [c_ptr]),
+    'brcnn_roi_align_set_exact': (c_int, [c_int]),
     'brcnn_rpn_topk': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     'brcnn_preprocess_u8': (c_int, [c_ptr, c_int, c_int, c_ptr] + [c_int] * 5 + [c_ptr, c_ptr, c_int, c_ptr]),
 }

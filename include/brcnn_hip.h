@@ -83,6 +83,10 @@ int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights
                                const float *rois, const float *grad_output, int batch,
                                int channels, int n_rois, int pooled_h, int pooled_w,
                                int sampling_ratio, float finest_scale, void *stream);
+/* NHWC RoIAlign forward variants: 0 (default) = footprint form (every pixel of a bin's footprint
+ * read once; equal to the reference to fp32 round-off), 1 = the reference's sample-order
+ * accumulation (bit-identical to mmcv's CPU kernel; ~1.5x the L2 reads). */
+int brcnn_roi_align_set_exact(int exact);
 
 /* ------------------------------------------------------------------------------
  * NMS.  Replaces mmcv.ops.nms (ext `nms(boxes, scores, iou_threshold, offset)`),

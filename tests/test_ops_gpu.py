@@ -41,9 +41,19 @@ def test_roi_align_nhwc_bit_exact_c256():
     rois = util.rand_rois(256, 2, 42 * 32.0, 25 * 32.0, seed=4)
     ref = orc.roi_align_forward(x, rois, 7, 1 / 32., 0, 'avg', True)
     xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
-    out = ops.roi_align(xg, rois.to(DEV), 7, 1 / 32., 0, 'avg', True)
+    from brcnn import lib
+    try:        # exact-order kernel: bit-identical to the reference's CPU accumulation order
+        lib.load().brcnn_roi_align_set_exact(1)
+        out = ops.roi_align(xg, rois.to(DEV), 7, 1 / 32., 0, 'avg', True)
+    finally:
+        lib.load().brcnn_roi_align_set_exact(0)
     assert out.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(out.cpu().contiguous(), ref)
+    # default footprint-form kernel: same value up to fp32 re-association (a bin sums <= ~40 products)
+    out2 = ops.roi_align(xg, rois.to(DEV), 7, 1 / 32., 0, 'avg', True).cpu().contiguous()
+    assert (out2 - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    f64 = orc.roi_align_f64(x, rois, 7, 1 / 32., 0, True)
+    assert (out2.double() - f64).abs().max().item() <= (ref.double() - f64).abs().max().item() * 2 + 1e-6
 
 
 def test_roi_align_max_mode():
@@ -109,9 +119,24 @@ def test_roi_extract_fused_matches_per_level():
         if inds.numel():
             ref[inds] = orc.roi_align_forward(feats[i], rois[inds], 7, 1. / strides[i], 0, 'avg', True)
     fg = [f.to(DEV).permute(0, 2, 3, 1).contiguous() for f in feats]
-    out, lv = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+    from brcnn import lib
+    try:
+        lib.load().brcnn_roi_align_set_exact(1)
+        out, lv = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+    finally:
+        lib.load().brcnn_roi_align_set_exact(0)
     assert torch.equal(lv.cpu().long(), lvls)
     assert torch.equal(out.permute(0, 3, 1, 2).cpu().contiguous(), ref)
+    # default (footprint form): RoIs from 8 px to 1200 px -> grids up to 22 x 22 samples per bin and
+    # the > 64-sample fallback; equal to fp32 round-off of a sum of up to ~500 products
+    out2, lv2 = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+    assert torch.equal(lv2, lv)
+    err = (out2.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+    assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+    huge = torch.tensor([[0., -500., -300., 2500., 1900.], [1., 10., 10., 1300., 790.]])   # bins > 64 px
+    o1, _ = ops.roi_extract(fg, huge.to(DEV), 7, strides, 56, 0)
+    r1 = orc.roi_align_forward(feats[4], huge, 7, 1. / 128, 0, 'avg', True)
+    assert (o1.permute(0, 3, 1, 2).cpu() - r1).abs().max().item() <= 1e-5
 
 
 # --------------------------------------------------------------------------- NMS
