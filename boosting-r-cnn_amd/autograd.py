@@ -138,6 +138,57 @@ def roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=56
                                     sampling_ratio, *[f.contiguous() for f in feats_nhwc])
 
 
+class GroupedConvFunction(Function):
+    """grouped conv (ResNeXt conv2) on NHWC fp32 maps: forward, data gradient and weight gradient on
+    the block-diagonal 64-channel tiles of the MFMA kernel (`brcnn_conv2d_*_nhwc_grouped`).
+    weight: the reference parameter (Cout, Cin/groups, KH, KW)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, groups, stride, pad):
+        _require_gpu(x, weight)
+        x = x.contiguous()
+        w_tiles, window = ops.pack_grouped_weight(weight, groups)
+        y = ops.conv2d_nhwc_grouped(x, w_tiles, window, None, None, None, False, stride, pad)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (groups, stride, pad, window, tuple(y.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        groups, stride, pad, window, yshape = ctx.cfg
+        n, h, w, cin = x.shape
+        cout, cg_in, kh, kw = weight.shape
+        cg_out = cout // groups
+        dy = dy.float().contiguous()
+        lib = _L.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # per-group transposed + flipped filters, as a grouped weight from dy channels to dx channels
+            wt = weight.detach().float().view(groups, cg_out, cg_in, kh, kw).flip(3, 4).permute(0, 2, 1, 3, 4)
+            wt = wt.reshape(groups * cg_in, cg_out, kh, kw)
+            wt_tiles, win_t = ops.pack_grouped_weight(wt, groups)
+            dx = torch.empty_like(x)
+            st = lib.brcnn_conv2d_dgrad_nhwc_grouped(_ptr(dy), _ptr(wt_tiles), _ptr(dx), n, h, w, yshape[1], yshape[2],
+                                                     cin, cout, kh, kw, stride, pad, win_t, DT_F32, _stream())
+            _L.check(st, 'brcnn_conv2d_dgrad_nhwc_grouped')
+        if ctx.needs_input_grad[1]:
+            dwt = torch.zeros((cout, kh, kw, window), dtype=torch.float32, device=x.device)
+            st = lib.brcnn_conv2d_wgrad_nhwc_grouped(_ptr(x), _ptr(dy), _ptr(dwt), n, h, w, cin, cout, kh, kw,
+                                                     stride, pad, window, DT_F32, _stream())
+            _L.check(st, 'brcnn_conv2d_wgrad_nhwc_grouped')
+            co = torch.arange(cout, device=x.device)
+            start = ((co // cg_out) * cg_in) - (co // 64) * window
+            idx = (start[:, None] + torch.arange(cg_in, device=x.device)[None, :])
+            dw = torch.gather(dwt, 3, idx[:, None, None, :].expand(cout, kh, kw, cg_in)).permute(0, 3, 1, 2)
+        return dx, dw, None, None, None
+
+
+def grouped_conv_autograd(x, weight, groups, stride, pad):
+    return GroupedConvFunction.apply(x, weight, groups, stride, pad)
+
+
 class BnActFunction(Function):
     """out = [relu](z * scale + shift [+ res]) over NHWC rows, one kernel each way
     (`brcnn_bn_act_forward/backward`); scale / shift are the (C,) fp32 eval-BN affine."""

@@ -139,12 +139,21 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
 
 def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):
     """grouped conv (ResNeXt conv2) + folded eval-BN + ReLU in one launch; inference / frozen only"""
-    from .autograd import wants_grad
-    if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None):
-        raise NotImplementedError('grouped convolution has no HIP backward yet (ResNeXt trains next round); '
-                                  'run it under torch.no_grad() or freeze the stage')
+    from .autograd import bn_act_autograd, bn_act_supported, grouped_conv_autograd, wants_grad
     if x.dtype != torch.float32:
         raise NotImplementedError('grouped convolution runs in fp32 only this round')
+    if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None):
+        assert conv.bias is None
+        y = grouped_conv_autograd(x, conv.weight, conv.groups, conv.stride[0], conv.padding[0])
+        if bn is not None:
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+            if bn_act_supported(y):
+                return bn_act_autograd(y, scale, shift, residual, relu)
+            y = y * scale + shift
+        if residual is not None:
+            y = y + residual
+        return y.relu() if relu else y
     srcs = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var]
                                        if bn is not None else [])
 

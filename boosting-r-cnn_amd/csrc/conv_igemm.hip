@@ -610,22 +610,20 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
 // its A operand shifted by tile_n * window channels.  `w_tiles` (Cout, KH, KW, window) holds,
 // for output channel co of tile t = co / 64, the filter taps at window position
 // (co / cg_out) * cg_in - t * window + ci and zeros elsewhere (brcnn.ops.pack_grouped_weight).
-BRCNN_API int brcnn_conv2d_nhwc_grouped(const void* x, const void* w_tiles, const float* scale,
-                                        const float* shift, const void* residual, void* y, int batch,
-                                        int height, int width, int cin, int cout, int kh, int kw,
-                                        int stride, int pad, int window, int relu, int dtype,
-                                        void* stream) {
+static int grouped_launch(const void* x, const void* w_tiles, const float* scale, const float* shift,
+                          const void* residual, void* y, int batch, int height, int width, int cin, int cout,
+                          int kh, int kw, int stride, int pad, int dilate, int Ho, int Wo, int window, int relu,
+                          int dtype, void* stream) {
     if (!x || !w_tiles || !y || batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || kh <= 0 ||
-        kw <= 0 || stride <= 0 || pad < 0 || dtype != BRCNN_DT_F32 || window <= 0 || (window % 32) ||
-        (cout % 64) || (cout / 64) * window != cin || height + pad >= 4096 || width + pad >= 4096)
+        kw <= 0 || stride <= 0 || pad < 0 || dilate < 1 || dtype != BRCNN_DT_F32 || window <= 0 || (window % 32) ||
+        (cout % 64) || (cout / 64) * window != cin || height * dilate + pad >= 4096 || width * dilate + pad >= 4096)
         return BRCNN_EINVAL;
-    const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
-    if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+    if (Ho <= 0 || Wo <= 0 || Ho >= 4096 || Wo >= 4096) return BRCNN_EINVAL;
     ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w_tiles; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
     p.batch = batch; p.Cin = window; p.Cout = cout; p.KH = kh; p.KW = kw;
-    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = 1; p.dilate = 1; p.gstep = window;
+    p.stride = stride; p.pad = pad; p.pitch = cin; p.nseg = 1; p.dilate = dilate; p.gstep = window;
     p.seg_H[0] = height; p.seg_W[0] = width; p.seg_Ho[0] = Ho; p.seg_Wo[0] = Wo;
     p.seg_m0[0] = 0; p.seg_xoff[0] = 0;
     const long long m_total = (long long)batch * Ho * Wo, x_elems = (long long)batch * height * width * cin;
@@ -640,6 +638,28 @@ BRCNN_API int brcnn_conv2d_nhwc_grouped(const void* x, const void* w_tiles, cons
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = cout / 64;
     return p.residual ? launch_dma<1, 1, true>(p, (hipStream_t)stream) : launch_dma<1, 1, false>(p, (hipStream_t)stream);
+}
+
+BRCNN_API int brcnn_conv2d_nhwc_grouped(const void* x, const void* w_tiles, const float* scale,
+                                        const float* shift, const void* residual, void* y, int batch,
+                                        int height, int width, int cin, int cout, int kh, int kw,
+                                        int stride, int pad, int window, int relu, int dtype,
+                                        void* stream) {
+    if (stride <= 0 || kh <= 0 || kw <= 0) return BRCNN_EINVAL;
+    const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
+    return grouped_launch(x, w_tiles, scale, shift, residual, y, batch, height, width, cin, cout, kh, kw, stride,
+                          pad, 1, Ho, Wo, window, relu, dtype, stream);
+}
+
+// data gradient of the grouped conv: the same tiles on the zero-stuffed dy with the per-group
+// flipped / transposed weights (packed as a grouped weight from the dy channels to the dx channels)
+BRCNN_API int brcnn_conv2d_dgrad_nhwc_grouped(const void* dy, const void* w_t_tiles, void* dx, int batch,
+                                              int in_height, int in_width, int out_height, int out_width,
+                                              int cin, int cout, int kh, int kw, int stride, int pad,
+                                              int window, int dtype, void* stream) {
+    if (pad > kh - 1 || pad > kw - 1) return BRCNN_EINVAL;
+    return grouped_launch(dy, w_t_tiles, nullptr, nullptr, nullptr, dx, batch, out_height, out_width, cout, cin,
+                          kh, kw, 1, kh - 1 - pad, stride, in_height, in_width, window, 0, dtype, stream);
 }
 
 BRCNN_API int brcnn_conv2d_nhwc_multi(const void* x, const void* w, const float* scale,

@@ -30,6 +30,8 @@ struct WgradParams {
     int Cin, Cout, KH, KW, stride, pad, M, K;
     int tiles_co, tiles_k, slices, rows_per_slice;
     unsigned dy_bytes, x_bytes;
+    int pitch;      // floats between adjacent input pixels (== Cin unless grouped)
+    int gstep;      // grouped conv: co tile t reads input channels [t*gstep, t*gstep + Cin); 0 = dense
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
     int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
                     const int wo = rem - ho * Wo;
                     const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
                     if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                        offx = ((int)p.seg_xoff[sg] + ((n * H + hi) * W + wi) * p.Cin + ci) * 4;
+                        offx = ((int)p.seg_xoff[sg] + ((n * H + hi) * W + wi) * p.pitch + ci + tco * p.gstep) * 4;
                 }
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)&Ya[buf][(wave * 2 + j) * 4][0], 16, offy, 0, 0, 0);
@@ -181,6 +183,7 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
     WgradParams p = {};
     p.dy = (const float*)dy; p.x = (const float*)x; p.dw = (float*)dw;
     p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.pitch = cin; p.gstep = 0;
     p.nseg = num_segments;
     long long m_total = 0, x_off = 0;
     for (int s = 0; s < num_segments; s++) {
@@ -215,6 +218,49 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
     p.rows_per_slice = rps;
     hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3(tiles * p.slices), dim3(256), 0,
                        (hipStream_t)stream, p);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// weight gradient of the grouped conv: per 64-channel co tile a dense (64 x KH*KW*window) wgrad over
+// the tile's input window; the caller keeps the block-diagonal entries (brcnn.autograd)
+BRCNN_API int brcnn_conv2d_wgrad_nhwc_grouped(const void* x, const void* dy, void* dw_tiles, int batch,
+                                              int height, int width, int cin, int cout, int kh, int kw,
+                                              int stride, int pad, int window, int dtype, void* stream) {
+    if (!x || !dy || !dw_tiles || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
+        pad < 0 || dtype != BRCNN_DT_F32 || window <= 0 || (window & 3) || (cout % 64) ||
+        (cout / 64) * window != cin)
+        return BRCNN_EINVAL;
+    const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+    WgradParams p = {};
+    p.dy = (const float*)dy; p.x = (const float*)x; p.dw = (float*)dw_tiles;
+    p.Cin = window; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.pitch = cin; p.gstep = window; p.nseg = 1;
+    p.seg_H[0] = height; p.seg_W[0] = width; p.seg_Ho[0] = Ho; p.seg_Wo[0] = Wo;
+    p.seg_m0[0] = 0; p.seg_xoff[0] = 0;
+    magic_for((unsigned)(Ho * Wo), &p.seg_mhw[0], &p.seg_shw[0]);
+    magic_for((unsigned)Wo, &p.seg_mw[0], &p.seg_sw[0]);
+    const long long m_total = (long long)batch * Ho * Wo, x_elems = (long long)batch * height * width * cin;
+    for (int s = 1; s <= BRCNN_MAX_LEVELS; s++) p.seg_m0[s] = (int)m_total;
+    if (m_total * cout * 4 >= 0x7fffffffLL || x_elems * 4 >= 0x7fffffffLL) return BRCNN_EINVAL;
+    p.M = (int)m_total;
+    p.K = kh * kw * window;
+    p.dy_bytes = (unsigned)(m_total * cout * 4);
+    p.x_bytes = (unsigned)(x_elems * 4);
+    p.tiles_co = cout / TC;
+    p.tiles_k = (p.K + TC - 1) / TC;
+    const int tiles = p.tiles_co * p.tiles_k;
+    int slices = (8192 + tiles - 1) / tiles;
+    const int max_slices = (p.M + 255) / 256;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    int rps = (p.M + slices - 1) / slices;
+    rps = (rps + TM - 1) / TM * TM;
+    p.slices = (p.M + rps - 1) / rps;
+    p.rows_per_slice = rps;
+    hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3(tiles * p.slices), dim3(256), 0, (hipStream_t)stream, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

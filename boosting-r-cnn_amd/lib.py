@@ -61,6 +61,8 @@ SIGNATURES = {
     'brcnn_avgpool_nhwc': (c_int, [c_ptr, c_ptr] + [c_int] * 9 + [c_ptr]),
     'brcnn_deform_im2col_nhwc': (c_int, [c_ptr] * 3 + [c_int] * 11 + [c_ptr]),
     'brcnn_roi_align_set_exact': (c_int, [c_int]),
+    'brcnn_conv2d_dgrad_nhwc_grouped': (c_int, [c_ptr] * 3 + [c_int] * 13 + [c_ptr]),
+    'brcnn_conv2d_wgrad_nhwc_grouped': (c_int, [c_ptr] * 3 + [c_int] * 11 + [c_ptr]),
     'brcnn_rpn_topk': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     'brcnn_preprocess_u8': (c_int, [c_ptr, c_int, c_int, c_ptr] + [c_int] * 5 + [c_ptr, c_ptr, c_int, c_ptr]),
 }

@@ -183,6 +183,16 @@ int brcnn_conv2d_nhwc_grouped(const void *x, const void *w_tiles, const float *s
                               const float *shift, const void *residual, void *y, int batch,
                               int height, int width, int cin, int cout, int kh, int kw, int stride,
                               int pad, int window, int relu, int dtype, void *stream);
+/* its backward: dgrad with w_t_tiles = the grouped packing of the flipped, (co<->ci)-transposed
+ * per-group filters; wgrad into dw_tiles (Cout,KH,KW,window) (zero-filled by the caller, fp32
+ * atomics), of which the block-diagonal entries are the parameter gradient. */
+int brcnn_conv2d_dgrad_nhwc_grouped(const void *dy, const void *w_t_tiles, void *dx, int batch,
+                                    int in_height, int in_width, int out_height, int out_width, int cin,
+                                    int cout, int kh, int kw, int stride, int pad, int window, int dtype,
+                                    void *stream);
+int brcnn_conv2d_wgrad_nhwc_grouped(const void *x, const void *dy, void *dw_tiles, int batch, int height,
+                                    int width, int cin, int cout, int kh, int kw, int stride, int pad,
+                                    int window, int dtype, void *stream);
 
 /* Backward of the convolution (autograd of the trainable convs / FCs; the reference gets these
  * from cuDNN/cuBLAS through torch autograd).

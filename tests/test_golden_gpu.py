@@ -498,3 +498,21 @@ def test_avgpool_deform_res2net_golden():
     got = y[..., :52].permute(0, 3, 1, 2).cpu().double()
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
     assert float(y[..., 52:].abs().max()) == 0.0            # pad channels stay exactly zero
+
+
+def test_x101_recipe_train_step():
+    """the ResNeXt recipe trains: one step through the grouped-conv forward / dgrad / wgrad kernels"""
+    import os
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), 'boosting_rcnn_x101_pafpn_mstrain_3x_coco.py'))
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=6))
+    m = m.to(DEV).train()
+    img, metas, gts, gls = util.demo_inputs(1, 128, 192, num_classes=80, seed=6)
+    torch.manual_seed(1)
+    losses = m.forward_train(img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    loss, log_vars = m._parse_losses(losses)
+    loss.backward()
+    assert np.isfinite(log_vars['loss'])
+    g2 = m.backbone.layer3[5].conv2.weight.grad
+    assert g2 is not None and g2.shape == (1024, 16, 3, 3) and torch.isfinite(g2).all() and g2.abs().max() > 0
+    assert m.backbone.layer1[0].conv2.weight.grad is None          # frozen stage

@@ -590,3 +590,27 @@ def test_bn_act_fused_forward_backward(dtype):
             assert (r1.grad.double() - r2.grad).abs().max().item() <= tol * mag(r2.grad) * 1.01
         assert (scale.grad.double() - s2.grad).abs().max().item() <= 2e-5 * mag(s2.grad) * (rows ** 0.5)
         assert (shift.grad.double() - h2.grad).abs().max().item() <= 2e-5 * mag(h2.grad) * (rows ** 0.5)
+
+
+def test_grouped_conv_autograd_matches_torch():
+    """forward / dgrad / wgrad of the grouped conv (ResNeXt conv2) against torch's grouped conv in fp64"""
+    import torch.nn.functional as F
+    from brcnn.autograd import grouped_conv_autograd
+    gen = torch.Generator().manual_seed(41)
+    for (n, c, h, w, groups, stride) in [(2, 128, 20, 30, 32, 1), (1, 256, 17, 23, 32, 2), (2, 256, 9, 14, 64, 1),
+                                         (1, 512, 10, 12, 64, 2), (1, 1024, 7, 9, 32, 1)]:
+        x = torch.randn(n, c, h, w, generator=gen)
+        wt = torch.randn(c, c // groups, 3, 3, generator=gen) / np.sqrt(9 * c / groups)
+        xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+        ref = F.conv2d(xr, wr, None, stride, 1, groups=groups)
+        go = torch.randn(ref.shape, generator=gen)
+        ref.backward(go.double())
+        xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+        wg = wt.to(DEV).requires_grad_()
+        y = grouped_conv_autograd(xg, wg, groups, stride, 1)
+        y.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
+        tol = lambda t: 3e-5 * max(1.0, t.abs().max().item())    # noqa: E731
+        assert (y.detach().permute(0, 3, 1, 2).cpu().double() - ref.detach()).abs().max().item() < tol(ref)
+        assert (xg.grad.permute(0, 3, 1, 2).cpu().double() - xr.grad).abs().max().item() < tol(xr.grad)
+        assert wg.grad.shape == wt.shape
+        assert (wg.grad.cpu().double() - wr.grad).abs().max().item() < 2e-4 * max(1.0, wr.grad.abs().max().item())
