@@ -189,6 +189,39 @@ def grouped_conv_autograd(x, weight, groups, stride, pad):
     return GroupedConvFunction.apply(x, weight, groups, stride, pad)
 
 
+class DeformIm2colFunction(Function):
+    """modulated deformable im2col (DCNv2, deform_groups 1) with its backward: x (N,H,W,C),
+    offset_mask (N,Ho,Wo,27) raw conv_offset output -> columns (N*Ho*Wo, 9*C)"""
+
+    @staticmethod
+    def forward(ctx, x, om, stride, pad):
+        _require_gpu(x, om)
+        x, om = x.contiguous(), om.contiguous()
+        assert om.shape[3] == 27
+        col, (ho, wo) = ops.deform_im2col_nhwc(x, om, 3, stride, pad, 1)
+        ctx.save_for_backward(x, om)
+        ctx.cfg = (stride, pad)
+        return col
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcol):
+        x, om = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        n, h, w, c = x.shape
+        dcol = dcol.float().contiguous()
+        dx = torch.zeros_like(x)
+        dom = torch.empty_like(om)
+        st = _L.load().brcnn_deform_col2im_nhwc(_ptr(x), _ptr(om), _ptr(dcol), _ptr(dx), _ptr(dom), n, h, w, c, 3, 3,
+                                                int(stride), int(pad), 1, 27, c, _stream())
+        _L.check(st, 'brcnn_deform_col2im_nhwc')
+        return dx, dom, None, None
+
+
+def deform_im2col_autograd(x, om, stride, pad):
+    return DeformIm2colFunction.apply(x, om, stride, pad)
+
+
 class BnActFunction(Function):
     """out = [relu](z * scale + shift [+ res]) over NHWC rows, one kernel each way
     (`brcnn_bn_act_forward/backward`); scale / shift are the (C,) fp32 eval-BN affine."""

@@ -344,12 +344,70 @@ class Bottle2neck(nn.Module):
                             d[f'cs{i}'], d[f'cb{i}'], None, True, 1, 0)
         return y.view(n, ho, wo, wp)
 
+    # ---- training: the same padded layout built differentiably from the parameters ----------
+    def _affine(self, bn, pad_to=None):
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        return scale, shift
+
+    def _bn_act(self, y, scale, shift, residual, relu):
+        from .autograd import bn_act_autograd, bn_act_supported
+        if bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
+            return bn_act_autograd(y, scale, shift, residual, relu)
+        y = y * scale + shift
+        if residual is not None:
+            y = y + residual
+        return y.relu() if relu else y
+
+    def _forward_train(self, x):
+        import torch.nn.functional as F
+        from .autograd import conv2d_nhwc_autograd, deform_im2col_autograd, linear_autograd
+        w, s, wp = self.width, self.scales, _pad_to(self.width)
+        pw = wp - w
+        s1, b1 = self._affine(self.bn1)
+        w1 = F.pad(self.conv1.weight.view(s, w, self.inplanes), (0, 0, 0, pw)).reshape(s * wp, self.inplanes, 1, 1)
+        out = conv2d_nhwc_autograd(x, w1, None, 1, 0)
+        out = self._bn_act(out, F.pad(s1.view(s, w), (0, pw)).reshape(-1), F.pad(b1.view(s, w), (0, pw)).reshape(-1),
+                           None, True)
+        spx = [out[..., i * wp:(i + 1) * wp] for i in range(s)]
+        outs, sp = [], None
+        for i in range(s - 1):
+            sp = spx[i].contiguous() if (i == 0 or self.stage_type == 'stage') else sp + spx[i]
+            conv, bn = self.convs[i], self.bns[i]
+            si, bi = self._affine(bn)
+            wi = F.pad(conv.weight, (0, 0, 0, 0, 0, pw, 0, pw))                      # (wp, wp, 3, 3)
+            if self.with_dcn:
+                wo = F.pad(conv.conv_offset.weight, (0, 0, 0, 0, 0, pw))             # (27, wp, 3, 3)
+                om = conv2d_nhwc_autograd(sp, wo, conv.conv_offset.bias, self.conv2_stride, 1)
+                col = deform_im2col_autograd(sp, om, self.conv2_stride, 1)
+                n, ho, wo_ = om.shape[0], om.shape[1], om.shape[2]
+                y = linear_autograd(col, wi.permute(0, 2, 3, 1).reshape(wp, 9 * wp), None).view(n, ho, wo_, wp)
+            else:
+                y = conv2d_nhwc_autograd(sp, wi, None, self.conv2_stride, 1)
+            sp = self._bn_act(y, F.pad(si, (0, pw)), F.pad(bi, (0, pw)), None, True)
+            outs.append(sp)
+        if self.stage_type == 'normal' or self.conv2_stride == 1:
+            outs.append(spx[s - 1])
+        else:
+            outs.append(F.avg_pool2d(spx[s - 1].permute(0, 3, 1, 2), 3, self.conv2_stride, 1).permute(0, 2, 3, 1))
+        cat = torch.cat(outs, 3).contiguous()
+        identity = x
+        if self.downsample is not None:
+            pool, conv, bn = self.downsample[0], self.downsample[1], self.downsample[2]
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            xi = x if k == 1 else F.avg_pool2d(x.permute(0, 3, 1, 2), k, k, 0, ceil_mode=True,
+                                               count_include_pad=False).permute(0, 2, 3, 1).contiguous()
+            identity = conv_bn_act_nhwc(xi, conv, bn, self._c_down, False)
+        s3, b3 = self._affine(self.bn3)
+        w3 = F.pad(self.conv3.weight.view(-1, s, w), (0, pw)).reshape(-1, s * wp, 1, 1)
+        y = conv2d_nhwc_autograd(cat, w3, None, 1, 0)
+        return self._bn_act(y, s3, b3, identity.contiguous(), True)
+
     def forward_nhwc(self, x):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('Res2Net blocks have no HIP backward yet (they train next round); '
-                                      'run under torch.no_grad() or freeze the stage')
         if x.dtype != torch.float32:
             raise NotImplementedError('Res2Net runs in fp32 only this round')
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(x)
         d = self._packed()
         wp, s = _pad_to(self.width), self.scales
         out = ops.conv2d_nhwc(x, d['w1'], d['s1'], d['b1'], None, True, 1, 0)     # (N,h,w,s*wp)

@@ -264,6 +264,12 @@ int brcnn_avgpool_nhwc(const float *x, float *y, int batch, int height, int widt
 int brcnn_deform_im2col_nhwc(const float *x, const float *offset_mask, float *col, int batch,
                              int height, int width, int channels, int kh, int kw, int stride, int pad,
                              int dilation, int om_stride, int channels_padded, void *stream);
+/* backward of the above: dx (zero-filled by the caller, fp32 atomics) and d_offset_mask (N,Ho,Wo,
+ * 3*KH*KW; every entry written) from dcol; the mask sigmoid's derivative is included. */
+int brcnn_deform_col2im_nhwc(const float *x, const float *offset_mask, const float *dcol, float *dx,
+                             float *d_offset_mask, int batch, int height, int width, int channels, int kh,
+                             int kw, int stride, int pad, int dilation, int om_stride, int channels_padded,
+                             void *stream);
 
 /* FPN top-down path: dst[n,y,x,c] += src[n, y*Hs/Hd, x*Ws/Wd, c]  (nearest,
  * F.interpolate(size=...) at necks/pafpn.py:113-115, fpn.py:178-181) */

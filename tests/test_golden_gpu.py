@@ -516,3 +516,47 @@ def test_x101_recipe_train_step():
     g2 = m.backbone.layer3[5].conv2.weight.grad
     assert g2 is not None and g2.shape == (1024, 16, 3, 3) and torch.isfinite(g2).all() and g2.abs().max() > 0
     assert m.backbone.layer1[0].conv2.weight.grad is None          # frozen stage
+
+
+def test_deform_conv_backward_and_res2net_train_step():
+    """DCNv2 backward (HIP col2im: dx by atomics, offset / mask gradients by wave reductions) against
+    torch autograd through the fp64 restatement, then one train step of the Res2Net-DCN recipe"""
+    import os
+    from brcnn.autograd import deform_im2col_autograd, linear_autograd
+    gen = torch.Generator().manual_seed(14)
+    for (c, h, w, stride) in [(32, 11, 13, 1), (64, 12, 17, 2)]:
+        x = torch.randn(2, c, h, w, generator=gen)
+        ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+        om = torch.randn(2, 27, ho, wo, generator=gen) * 1.5
+        om[:, :18] += (torch.rand(2, 18, ho, wo, generator=gen) > 0.9).float() * 20
+        wt = torch.randn(c, c, 3, 3, generator=gen) / np.sqrt(9 * c)
+        xr, omr, wr = x.double().requires_grad_(), om.double().requires_grad_(), wt.double().requires_grad_()
+        ref = _deform_ref(xr, omr, wr, stride, 1)
+        go = torch.randn(ref.shape, generator=gen)
+        ref.backward(go.double())
+        xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+        og = om.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+        wg = wt.to(DEV).requires_grad_()
+        col = deform_im2col_autograd(xg, og, stride, 1)
+        y = linear_autograd(col, wg.permute(0, 2, 3, 1).reshape(c, 9 * c), None).view(2, ho, wo, c)
+        y.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
+        rel = lambda a, b: (a - b).abs().max().item() / max(1.0, b.abs().max().item())   # noqa: E731
+        assert rel(y.detach().permute(0, 3, 1, 2).cpu().double(), ref.detach()) < 3e-5
+        assert rel(xg.grad.permute(0, 3, 1, 2).cpu().double(), xr.grad) < 1e-4
+        assert rel(og.grad.permute(0, 3, 1, 2).cpu().double(), omr.grad) < 1e-4
+        assert rel(wg.grad.cpu().double(), wr.grad) < 2e-4
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), 'boosting_rcnn_r2_101_dcn_pafpn_mstrain_3x_coco.py'))
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=8))
+    m = m.to(DEV).train()
+    img, metas, gts, gls = util.demo_inputs(1, 128, 192, num_classes=80, seed=8)
+    torch.manual_seed(2)
+    losses = m.forward_train(img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    loss, log_vars = m._parse_losses(losses)
+    loss.backward()
+    assert np.isfinite(log_vars['loss'])
+    blk = m.backbone.layer3[4]
+    for p in (blk.convs[1].weight, blk.convs[1].conv_offset.weight, blk.convs[1].conv_offset.bias, blk.conv1.weight,
+              blk.conv3.weight, blk.bns[0].weight, m.backbone.layer2[0].downsample[1].weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+    assert m.backbone.layer1[0].conv1.weight.grad is None
