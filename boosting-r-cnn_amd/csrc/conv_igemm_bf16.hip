@@ -31,10 +31,10 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
-template <int MT, int NT, bool RES, bool OUTF32, int WM>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
-    constexpr int NW = 2 * WM;          // waves per workgroup
-    constexpr int BM = 32 * MT * WM, BN = 64 * NT;
+template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2>
+__global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
+    constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
     constexpr int AG = BM / 8 / NW;     // 8-row groups of the A tile per wave
     constexpr int BG = BN / 8 / NW;
     static_assert(AG >= 1 && BG >= 1 && AG * 8 * NW == BM && BG * 8 * NW == BN, "tile / wave split");
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_igemm_bf16_dma
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int li = lane & 31, lh = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -278,30 +278,32 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void conv_igemm_bf16_dma
     }
 }
 
-template <int MT, int NT, bool RES, bool OUTF32, int WM = 2>
+template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2>
 int launch(const ConvParams& p, hipStream_t s) {
-    const size_t lds_full = (size_t)2 * (32 * MT * WM + 64 * NT) * 32 * sizeof(float);
-    const size_t lds_epi = (size_t)2 * WM * 32 * (32 * NT + 4) * sizeof(float);
-    const size_t lds = p.K / BKE > 1 ? lds_full : (lds_full / 2 > lds_epi ? lds_full / 2 : lds_epi);
+    const size_t lds_full = (size_t)2 * (32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
+    const size_t lds_epi = (size_t)WNW * WM * 32 * (32 * NT + 4) * sizeof(float);
+    const size_t lds_k = p.K / BKE > 1 ? lds_full : lds_full / 2;      // operand buffers (one if a single K tile)
+    const size_t lds = lds_k > lds_epi ? lds_k : lds_epi;               // the epilogue slabs reuse the same space
     static bool attr_done = false;
     if (!attr_done) {
         const size_t lds_max = lds_full > lds_epi ? lds_full : lds_epi;
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM>), dim3(p.tiles_m * p.tiles_n),
-                       dim3(128 * WM), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW>), dim3(p.tiles_m * p.tiles_n),
+                       dim3(64 * WM * WNW), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
-template <int MT, int NT, int WM = 2>
+template <int MT, int NT, int WM = 2, int WNW = 2>
 int launch2(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
-    p.tiles_n = (p.Cout + 64 * NT - 1) / (64 * NT);
-    if (p.out_f32) return p.residual ? launch<MT, NT, true, true, WM>(p, s) : launch<MT, NT, false, true, WM>(p, s);
-    return p.residual ? launch<MT, NT, true, false, WM>(p, s) : launch<MT, NT, false, false, WM>(p, s);
+    p.tiles_n = (p.Cout + 32 * NT * WNW - 1) / (32 * NT * WNW);
+    if (p.out_f32)
+        return p.residual ? launch<MT, NT, true, true, WM, WNW>(p, s) : launch<MT, NT, false, true, WM, WNW>(p, s);
+    return p.residual ? launch<MT, NT, true, false, WM, WNW>(p, s) : launch<MT, NT, false, false, WM, WNW>(p, s);
 }
 
 int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 waves), 42 = 256x128 (8 waves)
@@ -312,11 +314,22 @@ namespace brcnn_conv {
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     int t = g_bf16_tile;
     if (t == 0) {
-        // enough 128x128 tiles to give every CU >= 4 workgroups -> the big tile; else smaller
+        // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more
+        // waves share the LDS-DMA issue of a K tile, the better -- 128x128 on 8 waves of 32x64 beats the
+        // same tile on 4 waves of 64x64 by ~10 %, 128x64 on 8 waves wins on the mid-size maps; the
+        // small 4-wave tiles keep the few-tile layers (FC, stage 4) spread over the chip.
         const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-        t = (p.Cout <= 64) ? 21 : (t22 >= 1024 ? 22 : (t22 >= 256 ? 21 : 11));
+        if (p.Cout <= 64) t = 21;
+        else if (t22 < 256) t = 11;
+        else if (p.M >= 65536) t = 82;
+        else if (p.M >= 16384) t = 81;
+        else t = 21;
     }
     if (t == 42 && p.Cout > 64) return launch2<2, 2, 4>(p, s);
+    if (t == 82 && p.Cout > 64) return launch2<1, 2, 4>(p, s);       // 128x128 on 8 waves of 32x64
+    if (t == 164 && p.Cout > 64) return launch2<1, 1, 4, 4>(p, s);   // 128x128 on 16 waves of 32x32
+    if (t == 81 || ((t == 82 || t == 164) && p.Cout <= 64)) return launch2<1, 1, 4, 2>(p, s);   // 128x64 on 8 waves
+
     if ((t == 22 || t == 42) && p.Cout > 64) return launch2<2, 2>(p, s);
     if (t == 21 || ((t == 22 || t == 42) && p.Cout <= 64)) return launch2<2, 1>(p, s);
     return launch2<1, 1>(p, s);
@@ -324,7 +337,8 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 }  // namespace brcnn_conv
 
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
-    if (mtnt != 0 && mtnt != 11 && mtnt != 21 && mtnt != 22 && mtnt != 42) return BRCNN_EINVAL;
+    if (mtnt != 0 && mtnt != 11 && mtnt != 21 && mtnt != 22 && mtnt != 42 && mtnt != 82 && mtnt != 81 && mtnt != 164)
+        return BRCNN_EINVAL;
     g_bf16_tile = mtnt;
     return 0;
 }

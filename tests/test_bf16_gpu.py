@@ -286,7 +286,7 @@ def test_bf16_tile_variants_agree():
         r = torch.randn(n, ho, wo, cout, generator=g).to(DEV, BF) if res else None
         outs = []
         try:
-            for tile in (11, 21, 22, 42):
+            for tile in (11, 21, 22, 42, 82, 81, 164):
                 assert L.brcnn_conv_set_tile_bf16(tile) == 0
                 outs.append(ops.conv2d_nhwc(x, wt, sc, sh, r, True, stride, k // 2))
         finally:
