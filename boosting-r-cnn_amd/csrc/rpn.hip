@@ -93,11 +93,19 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
 // order-preserving key find the k-th key exactly; one more pass collects the k winners as
 // (key << 32 | index) composites -- ties at the threshold are taken in index order -- and a
 // bitonic sort of the <= 4096 composites in LDS puts them in (score desc, index asc) order.
+// A job = one (row of a level) or, for a long level, one PART of its rows (stage 1: the level's
+// top-k is contained in the union of its parts' top-k) or the merge of those parts (stage 2, which
+// maps candidate positions back to anchor indices through `idx_map`).  For equal scores the
+// candidate position order equals the anchor index order (parts are index ranges in order and
+// each part's winners are (score desc, index asc) sorted), so the tie rule survives the split.
+constexpr int TOPK_MAX_JOBS = 24;
 struct TopkLevels {
-    const float* score[BRCNN_MAX_LEVELS];
-    float* out_score[BRCNN_MAX_LEVELS];
-    int64_t* out_idx[BRCNN_MAX_LEVELS];
-    int n[BRCNN_MAX_LEVELS];
+    const float* score[TOPK_MAX_JOBS];
+    float* out_score[TOPK_MAX_JOBS];
+    int64_t* out_idx[TOPK_MAX_JOBS];
+    const int64_t* idx_map[TOPK_MAX_JOBS];
+    long long row_stride[TOPK_MAX_JOBS], out_stride[TOPK_MAX_JOBS], map_stride[TOPK_MAX_JOBS];
+    int n[TOPK_MAX_JOBS], idx_add[TOPK_MAX_JOBS];
 };
 
 // descending key: larger score <=> smaller key; -0.0 == +0.0
@@ -117,11 +125,14 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, in
     const int lvl = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const int n = lv.n[lvl];
     const int kk = min(k, n);
-    const float* __restrict__ sc = lv.score[lvl] + (size_t)b * n;
-    float* __restrict__ os = lv.out_score[lvl] + (size_t)b * kk;
-    int64_t* __restrict__ oi = lv.out_idx[lvl] + (size_t)b * kk;
+    const float* __restrict__ sc = lv.score[lvl] + (size_t)b * lv.row_stride[lvl];
+    float* __restrict__ os = lv.out_score[lvl] + (size_t)b * lv.out_stride[lvl];
+    int64_t* __restrict__ oi = lv.out_idx[lvl] + (size_t)b * lv.out_stride[lvl];
+    const int64_t* __restrict__ imap = lv.idx_map[lvl] ? lv.idx_map[lvl] + (size_t)b * lv.map_stride[lvl] : nullptr;
+    const int iadd = lv.idx_add[lvl];
+    (void)kk;
     if (n <= k) {       // the reference keeps the level unsorted in this case
-        for (int i = tid; i < n; i += 1024) { os[i] = sc[i]; oi[i] = i; }
+        for (int i = tid; i < n; i += 1024) { os[i] = sc[i]; oi[i] = imap ? imap[i] : (int64_t)(i + iadd); }
         return;
     }
     unsigned prefix = 0u, mask = 0u;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, in
     __syncthreads();
     for (int j = tid; j < k; j += 1024) {
         const unsigned idx = (unsigned)(sel[j] & 0xffffffffull);
-        oi[j] = (int64_t)idx;
+        oi[j] = imap ? imap[idx] : (int64_t)idx + iadd;
         os[j] = sc[idx];
     }
 }
@@ -250,25 +261,78 @@ BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
     return 0;
 }
 
+namespace {
+constexpr int TOPK_SPLIT_MIN = 32768;      // levels at least this long are selected in parts
+constexpr int TOPK_PART = 20000;
+inline int topk_parts(int n, int k) {
+    if (n < TOPK_SPLIT_MIN) return 1;
+    int p = (n + TOPK_PART - 1) / TOPK_PART;
+    if (p > 8) p = 8;
+    while (p > 1 && (n + p - 1) / p <= k) p--;           // every part must be longer than k
+    return p;
+}
+}  // namespace
+
+BRCNN_API size_t brcnn_rpn_topk_workspace_bytes(const int* n_host, int num_levels, int batch, int k) {
+    if (!n_host || num_levels <= 0 || batch <= 0 || k <= 0) return 0;
+    size_t b = 0;
+    for (int l = 0; l < num_levels; l++) {
+        const int p = topk_parts(n_host[l], k);
+        if (p > 1) b += (size_t)batch * p * k * (sizeof(float) + sizeof(int64_t));
+    }
+    return b + 256;
+}
+
 BRCNN_API int brcnn_rpn_topk(const float* const* score_levels, const int* n_host, int num_levels,
                              int batch, int k, float* const* out_score, int64_t* const* out_idx,
-                             void* stream) {
+                             void* workspace, size_t workspace_bytes, void* stream) {
     if (num_levels <= 0 || num_levels > BRCNN_MAX_LEVELS || batch < 0 || k <= 0 || k > 4096 ||
         !score_levels || !n_host || !out_score || !out_idx)
         return BRCNN_EINVAL;
     if (batch == 0) return 0;
-    TopkLevels lv = {};
+    if (workspace_bytes < brcnn_rpn_topk_workspace_bytes(n_host, num_levels, batch, k) || !workspace)
+        return BRCNN_EINVAL;
+    TopkLevels s1 = {}, s2 = {};
+    int j1 = 0, j2 = 0;
+    char* ws = (char*)workspace;
     for (int l = 0; l < num_levels; l++) {
-        if (n_host[l] <= 0 || !score_levels[l] || !out_score[l] || !out_idx[l]) return BRCNN_EINVAL;
-        lv.score[l] = score_levels[l];
-        lv.out_score[l] = out_score[l];
-        lv.out_idx[l] = out_idx[l];
-        lv.n[l] = n_host[l];
+        const int n = n_host[l];
+        if (n <= 0 || !score_levels[l] || !out_score[l] || !out_idx[l]) return BRCNN_EINVAL;
+        const int kk = n < k ? n : k;
+        const int parts = topk_parts(n, k);
+        if (parts == 1) {
+            if (j1 >= TOPK_MAX_JOBS) return BRCNN_EINVAL;
+            s1.score[j1] = score_levels[l]; s1.row_stride[j1] = n; s1.n[j1] = n;
+            s1.out_score[j1] = out_score[l]; s1.out_idx[j1] = out_idx[l]; s1.out_stride[j1] = kk;
+            j1++;
+            continue;
+        }
+        float* tmp_s = (float*)ws;
+        ws += (size_t)batch * parts * k * sizeof(float);
+        int64_t* tmp_i = (int64_t*)ws;
+        ws += (size_t)batch * parts * k * sizeof(int64_t);
+        const int len = (n + parts - 1) / parts;
+        for (int q = 0; q < parts; q++) {
+            if (j1 >= TOPK_MAX_JOBS) return BRCNN_EINVAL;
+            const int beg = q * len, cnt = (beg + len <= n ? len : n - beg);
+            s1.score[j1] = score_levels[l] + beg; s1.row_stride[j1] = n; s1.n[j1] = cnt; s1.idx_add[j1] = beg;
+            s1.out_score[j1] = tmp_s + (size_t)q * k; s1.out_idx[j1] = tmp_i + (size_t)q * k;
+            s1.out_stride[j1] = (long long)parts * k;
+            j1++;
+        }
+        s2.score[j2] = tmp_s; s2.row_stride[j2] = (long long)parts * k; s2.n[j2] = parts * k;
+        s2.idx_map[j2] = tmp_i; s2.map_stride[j2] = (long long)parts * k;
+        s2.out_score[j2] = out_score[l]; s2.out_idx[j2] = out_idx[l]; s2.out_stride[j2] = k;
+        j2++;
     }
     int KP = 2;
     while (KP < k) KP <<= 1;
-    hipLaunchKernelGGL(rpn_topk_kernel, dim3(batch, num_levels), dim3(1024), (size_t)KP * 8,
-                       (hipStream_t)stream, lv, k, KP);
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(batch, j1), dim3(1024), (size_t)KP * 8, (hipStream_t)stream, s1, k, KP);
     BRCNN_LAUNCH_CHECK();
+    if (j2 > 0) {
+        hipLaunchKernelGGL(rpn_topk_kernel, dim3(batch, j2), dim3(1024), (size_t)KP * 8, (hipStream_t)stream, s2, k,
+                           KP);
+        BRCNN_LAUNCH_CHECK();
+    }
     return 0;
 }

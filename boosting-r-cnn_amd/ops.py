@@ -660,8 +660,11 @@ def rpn_topk(scores, k):
     out_s = [torch.empty((B, min(k, n)), dtype=torch.float32, device=dev) for n in ns]
     out_i = [torch.empty((B, min(k, n)), dtype=torch.int64, device=dev) for n in ns]
     pa = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
-    st = _L.load().brcnn_rpn_topk(pa(scores), (ctypes.c_int * L)(*ns), L, B, int(k), pa(out_s), pa(out_i),
-                                  _stream())
+    lib = _L.load()
+    n_arr = (ctypes.c_int * L)(*ns)
+    wsb = lib.brcnn_rpn_topk_workspace_bytes(n_arr, L, B, int(k))
+    ws = _ws(wsb, dev)
+    st = lib.brcnn_rpn_topk(pa(scores), n_arr, L, B, int(k), pa(out_s), pa(out_i), _ptr(ws), wsb, _stream())
     _L.check(st, 'brcnn_rpn_topk')
     return list(zip(out_s, out_i))
 

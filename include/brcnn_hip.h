@@ -302,7 +302,8 @@ int brcnn_nhwc_to_nchw(const void *src, float *dst, int batch, int channels, int
  *   nms_pre (atss_rpn_head.py:727-737); exact radix select + an in-LDS sort of the winners.
  *   score_levels / out_score / out_idx are HOST arrays of device pointers, one per level:
  *   score (batch, n_l), out_score / out_idx (batch, min(k, n_l)).  A level with n_l <= k is
- *   passed through in index order, as the reference does.  k <= 4096.
+ *   passed through in index order, as the reference does.  k <= 4096.  Levels of >= 32768 anchors
+ *   are selected in up to 8 parts and merged (two launches; device scratch in `workspace`).
  * -------------------------------------------------------------------------- */
 int brcnn_rpn_score(const float *cls, const float *iou, float *score, int64_t rows,
                     int num_anchors, int cls_stride, int iou_stride, void *stream);
@@ -312,9 +313,10 @@ int brcnn_rpn_decode(const int64_t *topk_inds, const float *bbox_pred, int pred_
                      int stride_h, const float *means4_host, const float *stds4_host,
                      double wh_ratio_clip, float max_h, float max_w, float min_size,
                      float *proposals, uint8_t *valid, void *stream);
+size_t brcnn_rpn_topk_workspace_bytes(const int *n_host, int num_levels, int batch, int k);
 int brcnn_rpn_topk(const float *const *score_levels, const int *n_host, int num_levels,
                    int batch, int k, float *const *out_score, int64_t *const *out_idx,
-                   void *stream);
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------
  * Input front door: the reference's Resize -> RandomFlip -> Normalize -> Pad

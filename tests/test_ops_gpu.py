@@ -388,6 +388,8 @@ def test_rpn_topk_matches_stable_sort():
     levels[1][:, ::7] = 0.0
     levels[1][:, 1::14] = -0.0
     levels[0][0, 5000:9000] = levels[0][0, 4999]                             # a 4000-long run of ties
+    levels[0][1, 18000:20000] = 0.99999                                      # ties across a part boundary (18900)
+    levels[0][2, 37700:37900] = 2.0                                          # the winners straddle two parts
     for k in (1000, 2000, 37):
         got = ops.rpn_topk([l.to(DEV) for l in levels], k)
         for l, (gs, gi) in zip(levels, got):
