@@ -1,0 +1,20 @@
+"""copy the judged summaries of `tools/profile_round.sh <round>` from gpurun_out/<round>/ into profiles/"""
+import os, shutil, subprocess, sys
+r = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src, dst = f'gpurun_out/{r}', 'profiles'
+pairs = [('bench.json', 'bench.json'), ('bench_bf16.json', 'bench_bf16.json'), ('bench_train.json', 'bench_train.json'),
+         ('bench_train_bf16.json', 'bench_train_bf16.json'), ('stats/step_kernel_stats.csv', 'bench_kernel_stats.csv'),
+         ('stats_bf16/step_kernel_stats.csv', 'bench_bf16_kernel_stats.csv'),
+         ('stats_train/step_kernel_stats.csv', 'train_kernel_stats.csv'),
+         ('stats_train_bf16/step_kernel_stats.csv', 'train_bf16_kernel_stats.csv'),
+         ('conv_tiles.txt', 'conv_tiles.txt'), ('conv_tiles_bf16.txt', 'conv_tiles_bf16.txt'),
+         ('layers.txt', 'conv_layers.txt'), ('layers_bf16.txt', 'conv_layers_bf16.txt'),
+         ('op_bench.json', 'op_bench.json'), ('recipes.json', 'recipes.json'), ('pytest_gpu.txt', 'pytest_gpu.txt')]
+for a, b in pairs:
+    p = os.path.join(src, a)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f'{r}_{b}'))
+        print('copied', a)
+    else:
+        print('MISSING', a)
+subprocess.check_call([sys.executable, 'tools/summarize_pmc.py', r])
