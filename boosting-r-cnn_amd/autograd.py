@@ -32,7 +32,19 @@ class ConvNHWCFunction(Function):
         _require_gpu(x_cat, weight, bias)
         # fp32 activations: exact-fp32 MFMA; bf16 activations: bf16 MFMA with fp32 accumulation
         # (weights are cast per step from the fp32 master copy, gradients of weights stay fp32)
-        w_p = weight.detach().float().permute(0, 2, 3, 1).to(x_cat.dtype).contiguous()
+        # one launch writes the forward operand and (when the input needs a gradient) the flipped /
+        # transposed data-gradient operand
+        wsrc = weight.detach()
+        if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
+            wsrc = wsrc.float().contiguous()
+        cout_, cin_, kh_, kw_ = wsrc.shape
+        w_p = torch.empty((cout_, kh_, kw_, cin_), dtype=x_cat.dtype, device=x_cat.device)
+        w_t = torch.empty((cin_, kh_, kw_, cout_), dtype=x_cat.dtype, device=x_cat.device) \
+            if x_cat.requires_grad else None
+        st = _L.load().brcnn_pack_conv_weights(_ptr(wsrc), _ptr(w_p), _ptr(w_t), cout_, cin_, kh_, kw_,
+                                               DT_F32 if x_cat.dtype == torch.float32 else DT_BF16, _stream())
+        _L.check(st, 'brcnn_pack_conv_weights')
+        ctx.w_t = w_t
         x_cat = x_cat.contiguous()
         y, out_sizes = ops.conv2d_nhwc_multi(x_cat, w_p, batch, sizes, None,
                                              bias.detach().float().contiguous() if bias is not None else None,
@@ -55,7 +67,9 @@ class ConvNHWCFunction(Function):
         ohs, ows = _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).to(x_cat.dtype).contiguous()   # (Cin,KH,KW,Cout)
+            w_t = ctx.w_t
+            if w_t is None:
+                w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).to(x_cat.dtype).contiguous()   # (Cin,KH,KW,Cout)
             dx = torch.empty_like(x_cat)
             st = lib.brcnn_conv2d_dgrad_nhwc_multi(_ptr(dy), _ptr(w_t), _ptr(dx), batch, L, hs, ws, ohs,
                                                    ows, cin, cout, kh, kw, stride, pad, dt, _stream())

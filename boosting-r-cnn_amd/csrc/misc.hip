@@ -217,6 +217,31 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// Per-step weight preparation of a trainable conv: the fp32 master parameter (Cout,Cin,KH,KW) is
+// written once as the forward operand (Cout,KH,KW,Cin) and once as the data-gradient operand
+// (Cin,KH,KW,Cout) with flipped taps, in fp32 or bf16 -- one launch instead of the five
+// permute / flip / cast / contiguous kernels of the torch formulation.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, T* __restrict__ fwd,
+                                                               T* __restrict__ dgrad, int Cout, int Cin, int KH,
+                                                               int KW) {
+    const long long total = (long long)Cout * Cin * KH * KW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        // idx enumerates the FORWARD layout (co, a, b, ci): coalesced writes of `fwd`
+        const int ci = (int)(idx % Cin);
+        long long r = idx / Cin;
+        const int b = (int)(r % KW); r /= KW;
+        const int a = (int)(r % KH);
+        const int co = (int)(r / KH);
+        const float v = w[(((size_t)co * Cin + ci) * KH + a) * KW + b];
+        T o;
+        if (sizeof(T) == 2) o = (T)f2bf(v); else *reinterpret_cast<float*>(&o) = v;
+        if (fwd) fwd[idx] = o;
+        if (dgrad) dgrad[(((size_t)ci * KH + (KH - 1 - a)) * KW + (KW - 1 - b)) * Cout + co] = o;
+    }
+}
+
 inline int stream_grid(long long total) {
     long long g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -359,6 +384,23 @@ BRCNN_API int brcnn_nhwc_to_nchw(const void* src, float* dst, int batch, int cha
         return BRCNN_EINVAL;
     hipLaunchKernelGGL(transpose_kernel, dim3((channels + 31) / 32, (hw + 31) / 32, batch),
                        dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, hw, channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+
+BRCNN_API int brcnn_pack_conv_weights(const float* weight, void* fwd, void* dgrad, int cout, int cin, int kh,
+                                      int kw, int dtype, void* stream) {
+    if (!weight || (!fwd && !dgrad) || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const long long total = (long long)cout * cin * kh * kw;
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(pack_conv_weights_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           weight, (float*)fwd, (float*)dgrad, cout, cin, kh, kw);
+    else
+        hipLaunchKernelGGL(pack_conv_weights_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, weight, (bf16_t*)fwd, (bf16_t*)dgrad, cout, cin, kh, kw);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

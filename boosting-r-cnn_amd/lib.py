@@ -64,6 +64,7 @@ SIGNATURES = {
     'brcnn_conv2d_dgrad_nhwc_grouped': (c_int, [c_ptr] * 3 + [c_int] * 13 + [c_ptr]),
     'brcnn_conv2d_wgrad_nhwc_grouped': (c_int, [c_ptr] * 3 + [c_int] * 11 + [c_ptr]),
     'brcnn_deform_col2im_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 11 + [c_ptr]),
+    'brcnn_pack_conv_weights': (c_int, [c_ptr] * 3 + [c_int] * 5 + [c_ptr]),
     'brcnn_rpn_topk_workspace_bytes': (ctypes.c_size_t, [c_ptr, c_int, c_int, c_int]),
     'brcnn_rpn_topk': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     'brcnn_preprocess_u8': (c_int, [c_ptr, c_int, c_int, c_ptr] + [c_int] * 5 + [c_ptr, c_ptr, c_int, c_ptr]),

@@ -210,6 +210,11 @@ int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int b
                                   int num_segments, const int *heights_host,
                                   const int *widths_host, int cin, int cout, int kh, int kw,
                                   int stride, int pad, int dtype, void *stream);
+/* per-step operand preparation of a trainable conv: weight (Cout,Cin,KH,KW) fp32 (the reference's
+ * parameter layout) -> fwd (Cout,KH,KW,Cin) and / or dgrad (Cin,KH,KW,Cout) with flipped taps, in
+ * `dtype`; either output may be NULL. */
+int brcnn_pack_conv_weights(const float *weight, void *fwd, void *dgrad, int cout, int cin, int kh, int kw,
+                            int dtype, void *stream);
 /* tuning hook of the bf16 wgrad kernel: 0 heuristic, 1 = 64x64 output tile, 2 = 128x128 */
 int brcnn_conv_set_tile_wgrad_bf16(int wt);
 
