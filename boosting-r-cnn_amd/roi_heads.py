@@ -199,13 +199,16 @@ class ProbConvFCBBoxHead(nn.Module):
         x = roi_feats.reshape(k, ph * pw * c)
         from .autograd import linear_autograd, wants_grad
         if wants_grad(x, self.fc_cls.weight, self.shared_fcs[0].weight):
+            from .blocks import compute_dtype
+            if compute_dtype() == torch.bfloat16:
+                x = x.to(torch.bfloat16)      # bf16 mode: the FC GEMMs (fwd / dgrad / wgrad) on bf16 MFMA
             for i, fc in enumerate(self.shared_fcs):
                 w = fc.weight
                 if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable view
                     w = w.view(-1, c, ph, pw).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
                 x = linear_autograd(x, w, fc.bias).relu()
             y = linear_autograd(x, torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0),
-                                torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0))
+                                torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)).float()
             nc = self.fc_cls.out_features
             return y[:, :nc], y[:, nc:]
         for i, fc in enumerate(self.shared_fcs):
