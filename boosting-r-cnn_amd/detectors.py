@@ -186,7 +186,9 @@ class TwoStageDetector(BaseDetector):
 
     def _device_path_ok(self):
         rc, rp = self.test_cfg.rcnn, self.test_cfg.rpn
-        return rc.nms.get('type', 'nms') == 'nms' and rp.nms.get('type', 'nms') == 'nms' and \
+        typ = rc.nms.get('type', 'nms')
+        split = rp.max_per_img * self.roi_head.bbox_head.num_classes >= rc.nms.get('split_thr', 10000)
+        return (typ == 'nms' or (typ == 'soft_nms' and split)) and rp.nms.get('type', 'nms') == 'nms' and \
             not rc.nms.get('class_agnostic', False)
 
 

@@ -273,6 +273,30 @@ def soft_nms_segments(boxes, scores, seg_offsets, iou_threshold=0.3, sigma=0.5, 
     return dets, inds, num_keep
 
 
+def soft_nms_ranges(boxes, scores, ranges, iou_threshold=0.3, sigma=0.5, min_score=1e-3, method=1, offset=0):
+    """soft-NMS over arbitrary [begin, end) segments of a flat box list (`ranges` (S,2) int32), no
+    host sync; segment s's picks sit at dets / inds [begin_s : begin_s + num_keep[s]] in pick order"""
+    _require_gpu(boxes, scores, ranges)
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    ranges = ranges.to(torch.int32)
+    n, S = boxes.size(0), ranges.size(0)
+    dets = torch.zeros((max(n, 1), 5), dtype=torch.float32, device=boxes.device)
+    inds = torch.zeros((max(n, 1),), dtype=torch.int64, device=boxes.device)
+    num_keep = torch.zeros((S,), dtype=torch.int32, device=boxes.device)
+    if n == 0:
+        return dets[:0], inds[:0], num_keep
+    lib = _L.load()
+    wsb = lib.brcnn_softnms_workspace_bytes(n, S)
+    ws = _ws(wsb, boxes.device)
+    sb, se = ranges[:, 0].contiguous(), ranges[:, 1].contiguous()
+    st = lib.brcnn_softnms(_ptr(boxes), _ptr(scores), _ptr(sb), _ptr(se), S, n, float(iou_threshold), float(sigma),
+                           float(min_score), int(method), int(offset), _ptr(dets), _ptr(inds), _ptr(num_keep),
+                           _ptr(ws), wsb, _stream())
+    _L.check(st, 'brcnn_softnms')
+    return dets, inds, num_keep
+
+
 def soft_nms(boxes, scores, iou_threshold=0.3, sigma=0.5, min_score=1e-3, method='linear',
              offset=0):
     """mmcv.ops.soft_nms: returns (dets (k,5) with decayed scores, inds (k,)) in pick order.

@@ -55,7 +55,7 @@ def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offse
 
 
 def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_threshold, max_keep, offset=0,
-                                return_ids=False):
+                                return_ids=False, soft=None):
     """mmcv `batched_nms` above `split_thr` for a whole mini-batch, no host sync: NMS per id
     (pyramid level) on the offset boxes, survivors re-sorted by score, first `max_keep`
     (mmcv/ops/nms.py batched_nms, the `for id in torch.unique(idxs)` branch).  Column ranges
@@ -94,8 +94,15 @@ def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_thre
     begins = csum[:, bounds[:-1]]
     base = (torch.arange(B, device=device) * T)[:, None]
     ranges = torch.stack([(begins + base).reshape(-1), (ends + base).reshape(-1)], 1).to(torch.int32)
-    keep, num = ops.nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges, max(level_sizes),
-                               iou_threshold, offset, -1)
+    if soft is not None:
+        # soft-NMS (mmcv batched_nms with type='soft_nms', per-id branch): every (image, id) segment is
+        # decayed independently; the survivors carry their decayed scores
+        method = {'naive': 0, 'linear': 1, 'gaussian': 2}[soft.get('method', 'linear')]
+        sdets, keep, num = ops.soft_nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges, iou_threshold,
+                                               soft.get('sigma', 0.5), soft.get('min_score', 1e-3), method, offset)
+    else:
+        keep, num = ops.nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges, max(level_sizes),
+                                   iou_threshold, offset, -1)
     num = num.view(B, L).long()
     lvl = torch.searchsorted(ends.contiguous(), pos.expand(B, T).contiguous(), right=True).clamp(max=L - 1)
     is_kept_slot = in_range & ((pos - torch.gather(begins, 1, lvl)) < torch.gather(num, 1, lvl))
@@ -103,6 +110,10 @@ def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_thre
     mask = torch.zeros(B * T + 1, dtype=torch.bool, device=device)
     mask.scatter_(0, kept_idx.reshape(-1), is_kept_slot.reshape(-1))
     mask = mask[:B * T].view(B, T)
+    if soft is not None:        # scores_after_nms[kept] = decayed score of the pick
+        after = torch.zeros(B * T + 1, dtype=c_scores.dtype, device=device)
+        after.scatter_(0, kept_idx.reshape(-1), sdets[:B * T, 4] * is_kept_slot.reshape(-1))
+        c_scores = after[:B * T].view(B, T)
     # survivors by descending score (ties: ascending index, the shared tie rule), first K
     key = torch.where(mask, c_scores, c_scores.new_full((), float('-inf')))
     _, order = key.sort(dim=1, descending=True, stable=True)

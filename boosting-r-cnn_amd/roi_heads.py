@@ -557,7 +557,10 @@ class ProbRoIHead(nn.Module):
         B, K, _ = dets.shape
         C = head.num_classes
         device = dets.device
-        assert nms_type == 'nms' and not nms_cfg.get('class_agnostic', False) and not head.reg_class_agnostic
+        assert nms_type in ('nms', 'soft_nms') and not nms_cfg.get('class_agnostic', False) and \
+            not head.reg_class_agnostic
+        split = K * C >= nms_cfg.get('split_thr', 10000)
+        assert nms_type == 'nms' or split, 'soft-NMS below split_thr keeps pick order: per-image path'
         bidx = torch.arange(B, device=device, dtype=dets.dtype).view(B, 1, 1).expand(B, K, 1)
         rois = torch.cat([bidx, dets[..., :4]], -1).view(B * K, 5)
         prior = dets[..., 4].reshape(-1)
@@ -577,14 +580,15 @@ class ProbRoIHead(nn.Module):
         s = scores[..., :C]
         valid = (s > cfg.score_thr) & row_ok[..., None]
         labels = torch.arange(C, device=device).view(1, 1, C).expand(B, K, C)
-        if K * C >= nms_cfg.get('split_thr', 10000):
+        if split:
             # mmcv's per-class branch (80-class COCO heads: 256 x 80 candidates): class-major
-            # slots, one segmented launch over (image, class); same boxes, same order
+            # slots, one segmented (soft-)NMS launch over (image, class); same boxes, same order
             from .postprocess import batched_nms_images_by_level
             cm = lambda t: t.transpose(1, 2).reshape(B, C * K, *t.shape[3:]).contiguous()   # noqa: E731
             return batched_nms_images_by_level(cm(bboxes.view(B, K, C, 4)), cm(s), cm(labels), cm(valid),
-                                               [K] * C, nms_cfg['iou_threshold'], cfg.max_per_img,
-                                               nms_cfg.get('offset', 0), return_ids=True)
+                                               [K] * C, nms_cfg.get('iou_threshold', 0.3), cfg.max_per_img,
+                                               nms_cfg.get('offset', 0), return_ids=True,
+                                               soft=nms_cfg if nms_type == 'soft_nms' else None)
         det, lab, nd = batched_nms_images(bboxes.reshape(B, K * C, 4), s.reshape(B, K * C),
                                           labels.reshape(B, K * C), valid.reshape(B, K * C),
                                           nms_cfg['iou_threshold'], cfg.max_per_img,

@@ -124,6 +124,22 @@ def _nms_ranges(boxes, scores, ranges, max_segment_len, iou_threshold, offset=0,
     return keep, num
 
 
+def _soft_nms_ranges(boxes, scores, ranges, iou_threshold=0.3, sigma=0.5, min_score=1e-3, method=1, offset=0):
+    n = boxes.size(0)
+    dets = torch.zeros((max(n, 1), 5))
+    inds = torch.zeros((max(n, 1),), dtype=torch.int64)
+    num = torch.zeros(ranges.size(0), dtype=torch.int32)
+    name = {0: 'naive', 1: 'linear', 2: 'gaussian'}[int(method)]
+    for s_ in range(ranges.size(0)):
+        b, e = int(ranges[s_, 0]), int(ranges[s_, 1])
+        if e > b:
+            d, k = orc.soft_nms(boxes[b:e], scores[b:e], iou_threshold, sigma, min_score, name, offset)
+            dets[b:b + k.numel()] = d
+            inds[b:b + k.numel()] = k + b
+            num[s_] = k.numel()
+    return dets, inds, num
+
+
 def _rpn_score(cls, iou):
     return (cls.sigmoid() * iou.sigmoid()).sqrt()
 
@@ -204,7 +220,7 @@ _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw
               groupnorm_nhwc_multi=_groupnorm_multi, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
               groupnorm_nhwc=_groupnorm, upsample_nearest_add_nhwc_=_upsample_add_,
               nchw_to_nhwc=_nchw_to_nhwc, nhwc_to_nchw=_nhwc_to_nchw, roi_extract=_roi_extract,
-              nms_ranges=_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode, rpn_topk=_rpn_topk,
+              nms_ranges=_nms_ranges, soft_nms_ranges=_soft_nms_ranges, rpn_score=_rpn_score, rpn_decode=_rpn_decode, rpn_topk=_rpn_topk,
               nms=orc.nms, soft_nms=orc.soft_nms, batched_nms=orc.batched_nms,
               roi_align=orc.roi_align, RoIAlign=orc.RoIAlign, sigmoid_focal_loss=orc.sigmoid_focal_loss)
 

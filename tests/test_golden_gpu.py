@@ -560,3 +560,29 @@ def test_deform_conv_backward_and_res2net_train_step():
               blk.conv3.weight, blk.bns[0].weight, m.backbone.layer2[0].downsample[1].weight):
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
     assert m.backbone.layer1[0].conv1.weight.grad is None
+
+
+@pytest.mark.parametrize('cfg_name', ['boosting_rcnn_r101_pafpn_softnms_coco.py', 'boosting_rcnn_r50_pafpn_1x_coco.py'])
+def test_batched_postprocess_equals_per_image_reference_path(cfg_name):
+    """the device-resident whole-batch second stage (one segmented NMS / soft-NMS launch over (image,
+    class)) against the per-image restatement of the reference's simple_test_bboxes ->
+    multiclass_nms -> mmcv batched_nms loop, on the same features and proposals"""
+    import os
+    cfg = Config.fromfile(os.path.join(os.path.dirname(CFG), cfg_name))
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=5))
+    m = m.to(DEV).eval()
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=3)
+    assert m._device_path_ok()
+    with torch.no_grad():
+        fast = m.simple_test(img.to(DEV), metas, rescale=True)
+        x = m.extract_feat(img.to(DEV))
+        props = m.rpn_head.simple_test_rpn(x, metas)
+        slow = m.roi_head.simple_test(x, props, metas, rescale=True)
+    n = sum(len(c) for r in slow for c in r)
+    assert n > 10 and sum(len(c) for r in fast for c in r) == n
+    for b in range(2):
+        for c in range(80):
+            assert len(fast[b][c]) == len(slow[b][c]), (b, c)
+            if len(slow[b][c]):
+                assert _match_dets(fast[b][c], slow[b][c], 1e-3, 1e-5) == 1.0, (b, c)
