@@ -90,20 +90,25 @@ __global__ __launch_bounds__(TPB) void softnms_kernel(
     }
     __syncthreads();
 
-    for (int i = 0; i < nboxes; i++) {
-        // ---- 1. arg-max over [i, nboxes) -------------------------------------------------
+    // arg-max over [from, nboxes): block-wide, first position on ties
+    auto block_argmax = [&](int from) -> Best {
         Best bst; bst.s = -INFINITY; bst.pos = 0x7fffffff;
-        for (int p = i + tid; p < nboxes; p += TPB) {
+        for (int p = from + tid; p < nboxes; p += TPB) {
             Best c; c.s = sc[p]; c.pos = p;
             bst = better(bst, c);
         }
         bst = wave_best(bst);
+        __syncthreads();
         if ((tid & 63) == 0) sh_b[tid >> 6] = bst;
         __syncthreads();
-        Best m = better(better(sh_b[0], sh_b[1]), better(sh_b[2], sh_b[3]));
+        return better(better(sh_b[0], sh_b[1]), better(sh_b[2], sh_b[3]));
+    };
+    Best m = block_argmax(0);
+    for (int i = 0; i < nboxes; i++) {
+        // ---- 1. the pick: `m` = arg-max over [i, nboxes), known from the previous sweep ------------
         // the reference starts from position i and only moves on a strictly larger score;
         // NaN / -inf corner: nothing compares greater -> position i
-        int max_pos = (m.pos == 0x7fffffff || !(m.s > sc[i])) ? i : m.pos;
+        const int max_pos = (m.pos == 0x7fffffff || !(m.s > sc[i])) ? i : m.pos;
         __syncthreads();
         // ---- 2. swap to the front, emit --------------------------------------------------
         if (tid == 0) {
@@ -121,8 +126,9 @@ __global__ __launch_bounds__(TPB) void softnms_kernel(
         __syncthreads();
         const float ix1 = sh_box[0], iy1 = sh_box[1], ix2 = sh_box[2], iy2 = sh_box[3],
                     iarea = sh_box[4];
-        // ---- 3. decay sweep --------------------------------------------------------------
+        // ---- 3. decay sweep, fused with the arg-max of the next pick ------------------------
         int dead = 0;
+        Best nxt; nxt.s = -INFINITY; nxt.pos = 0x7fffffff;
         for (int p = i + 1 + tid; p < nboxes; p += TPB) {
             const float xx1 = fmaxf(ix1, x1[p]), yy1 = fmaxf(iy1, y1[p]);
             const float xx2 = fminf(ix2, x2[p]), yy2 = fminf(iy2, y2[p]);
@@ -136,8 +142,17 @@ __global__ __launch_bounds__(TPB) void softnms_kernel(
             const float s = sc[p] * weight;
             sc[p] = s;
             dead += (s < min_score) ? 1 : 0;
+            Best c; c.s = s; c.pos = p;
+            nxt = better(nxt, c);
         }
-        const int ndead = block_sum(dead, sh_i);
+        // one reduction for both: dead count and next arg-max
+        nxt = wave_best(nxt);
+        for (int off = 32; off > 0; off >>= 1) dead += __shfl_xor(dead, off);
+        __syncthreads();
+        if ((tid & 63) == 0) { sh_b[tid >> 6] = nxt; sh_i[tid >> 6] = dead; }
+        __syncthreads();
+        m = better(better(sh_b[0], sh_b[1]), better(sh_b[2], sh_b[3]));
+        const int ndead = sh_i[0] + sh_i[1] + sh_i[2] + sh_i[3];
         if (ndead == 0) continue;   // uniform
         // ---- 4. swap-with-last compaction, emulated exactly --------------------------------
         const int tail = nboxes - (i + 1);
@@ -170,6 +185,7 @@ __global__ __launch_bounds__(TPB) void softnms_kernel(
         }
         nboxes = B;
         __syncthreads();
+        m = block_argmax(i + 1);        // the compaction moved boxes: positions of the maximum changed
     }
     if (tid == 0) num_keep[seg] = nboxes;
 }
