@@ -141,7 +141,11 @@ def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):
     """grouped conv (ResNeXt conv2) + folded eval-BN + ReLU in one launch; inference / frozen only"""
     from .autograd import bn_act_autograd, bn_act_supported, grouped_conv_autograd, wants_grad
     if x.dtype != torch.float32:
-        raise NotImplementedError('grouped convolution runs in fp32 only this round')
+        # bf16 mode: the grouped 3x3 itself still runs on the fp32 MFMA tiles (its bf16 tile variant is
+        # next); widen its input and narrow its output, the 1x1 convs around it stay bf16
+        y = _grouped_conv_bn_act_nhwc(x.float(), conv, bn, cache, relu,
+                                      residual.float() if residual is not None else None)
+        return y.to(x.dtype)
     if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None):
         assert conv.bias is None
         y = grouped_conv_autograd(x, conv.weight, conv.groups, conv.stride[0], conv.padding[0])

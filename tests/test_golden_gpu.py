@@ -399,6 +399,18 @@ def test_grouped_conv_and_resnext_golden():
     with torch.no_grad():
         res = det(return_loss=False, rescale=True, img=[img.to(DEV)], img_metas=[metas])
     assert len(res) == 1 and len(res[0]) == 80 and all(r.shape[1] == 5 for r in res[0])
+    # bf16 mode (the recipe's `fp16` key maps to it): 1x1 convs on bf16 MFMA, grouped 3x3 widened to fp32
+    from brcnn import blocks
+    try:
+        with torch.no_grad():
+            f32 = [f.float() for f in det.extract_feat_nhwc(img.to(DEV))]
+            det.set_compute_dtype('bf16')
+            f16 = det.extract_feat_nhwc(img.to(DEV))
+        assert all(f.dtype == torch.bfloat16 for f in f16)
+        for a, b in zip(f16, f32):
+            assert (a.float() - b).abs().max().item() < 0.08 * b.abs().max().item()
+    finally:
+        blocks.set_compute_dtype('f32')
 
 
 def _deform_ref(x, om, w, stride, pad):
