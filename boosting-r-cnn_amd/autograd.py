@@ -162,7 +162,7 @@ class GroupedConvFunction(Function):
         _require_gpu(x, weight)
         x = x.contiguous()
         w_tiles, window = ops.pack_grouped_weight(weight, groups)
-        y = ops.conv2d_nhwc_grouped(x, w_tiles, window, None, None, None, False, stride, pad)
+        y = ops.conv2d_nhwc_grouped(x, w_tiles.to(x.dtype), window, None, None, None, False, stride, pad)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (groups, stride, pad, window, tuple(y.shape))
         return y
@@ -175,7 +175,8 @@ class GroupedConvFunction(Function):
         n, h, w, cin = x.shape
         cout, cg_in, kh, kw = weight.shape
         cg_out = cout // groups
-        dy = dy.float().contiguous()
+        dy = dy.to(x.dtype).contiguous()
+        gdt = DT_F32 if x.dtype == torch.float32 else DT_BF16
         lib = _L.load()
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -183,14 +184,15 @@ class GroupedConvFunction(Function):
             wt = weight.detach().float().view(groups, cg_out, cg_in, kh, kw).flip(3, 4).permute(0, 2, 1, 3, 4)
             wt = wt.reshape(groups * cg_in, cg_out, kh, kw)
             wt_tiles, win_t = ops.pack_grouped_weight(wt, groups)
+            wt_tiles = wt_tiles.to(x.dtype)
             dx = torch.empty_like(x)
             st = lib.brcnn_conv2d_dgrad_nhwc_grouped(_ptr(dy), _ptr(wt_tiles), _ptr(dx), n, h, w, yshape[1], yshape[2],
-                                                     cin, cout, kh, kw, stride, pad, win_t, DT_F32, _stream())
+                                                     cin, cout, kh, kw, stride, pad, win_t, gdt, _stream())
             _L.check(st, 'brcnn_conv2d_dgrad_nhwc_grouped')
         if ctx.needs_input_grad[1]:
             dwt = torch.zeros((cout, kh, kw, window), dtype=torch.float32, device=x.device)
             st = lib.brcnn_conv2d_wgrad_nhwc_grouped(_ptr(x), _ptr(dy), _ptr(dwt), n, h, w, cin, cout, kh, kw,
-                                                     stride, pad, window, DT_F32, _stream())
+                                                     stride, pad, window, gdt, _stream())
             _L.check(st, 'brcnn_conv2d_wgrad_nhwc_grouped')
             co = torch.arange(cout, device=x.device)
             start = ((co // cg_out) * cg_in) - (co // 64) * window

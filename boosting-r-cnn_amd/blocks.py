@@ -140,9 +140,10 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
 def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):
     """grouped conv (ResNeXt conv2) + folded eval-BN + ReLU in one launch; inference / frozen only"""
     from .autograd import bn_act_autograd, bn_act_supported, grouped_conv_autograd, wants_grad
-    if x.dtype != torch.float32:
-        # bf16 mode: the grouped 3x3 itself still runs on the fp32 MFMA tiles (its bf16 tile variant is
-        # next); widen its input and narrow its output, the 1x1 convs around it stay bf16
+    cg_in, cg_out = conv.in_channels // conv.groups, conv.out_channels // conv.groups
+    if x.dtype != torch.float32 and ((64 // cg_out) * cg_in) % 64:
+        # bf16 tiles need a 64-channel input window per 64-channel output tile; other group shapes
+        # widen to the fp32 tiles
         y = _grouped_conv_bn_act_nhwc(x.float(), conv, bn, cache, relu,
                                       residual.float() if residual is not None else None)
         return y.to(x.dtype)
@@ -163,6 +164,7 @@ def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):
 
     def builder():
         w, window = ops.pack_grouped_weight(conv.weight, conv.groups)
+        w = w.to(x.dtype)
         scale = shift = None
         if bn is not None:
             scale, shift = fold_bn(bn)

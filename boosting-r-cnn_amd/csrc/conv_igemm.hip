@@ -615,9 +615,11 @@ static int grouped_launch(const void* x, const void* w_tiles, const float* scale
                           int kh, int kw, int stride, int pad, int dilate, int Ho, int Wo, int window, int relu,
                           int dtype, void* stream) {
     if (!x || !w_tiles || !y || batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || kh <= 0 ||
-        kw <= 0 || stride <= 0 || pad < 0 || dilate < 1 || dtype != BRCNN_DT_F32 || window <= 0 || (window % 32) ||
+        kw <= 0 || stride <= 0 || pad < 0 || dilate < 1 || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) ||
+        window <= 0 || (window % (dtype == BRCNN_DT_F32 ? 32 : 64)) ||
         (cout % 64) || (cout / 64) * window != cin || height * dilate + pad >= 4096 || width * dilate + pad >= 4096)
         return BRCNN_EINVAL;
+    const int esz = dtype == BRCNN_DT_F32 ? 4 : 2;
     if (Ho <= 0 || Wo <= 0 || Ho >= 4096 || Wo >= 4096) return BRCNN_EINVAL;
     ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w_tiles; p.scale = scale; p.shift = shift;
@@ -629,12 +631,13 @@ static int grouped_launch(const void* x, const void* w_tiles, const float* scale
     const long long m_total = (long long)batch * Ho * Wo, x_elems = (long long)batch * height * width * cin;
     for (int sgi = 1; sgi <= BRCNN_MAX_LEVELS; sgi++) p.seg_m0[sgi] = (int)m_total;
     p.K = kh * kw * window;
-    if (x_elems * 4 >= 0x7fffffffLL || (long long)cout * p.K * 4 >= 0x7fffffffLL || m_total > 0x7fffffffLL)
+    if (x_elems * esz >= 0x7fffffffLL || (long long)cout * p.K * esz >= 0x7fffffffLL || m_total > 0x7fffffffLL)
         return BRCNN_EINVAL;
-    p.x_bytes = (unsigned)(x_elems * 4);
-    p.w_bytes = (unsigned)((long long)cout * p.K * 4);
+    p.x_bytes = (unsigned)(x_elems * esz);
+    p.w_bytes = (unsigned)((long long)cout * p.K * esz);
     p.M = (int)m_total;
     p.relu = relu;
+    if (dtype == BRCNN_DT_BF16) return dispatch_conv_bf16(p, (hipStream_t)stream);
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = cout / 64;
     return p.residual ? launch_dma<1, 1, true>(p, (hipStream_t)stream) : launch_dma<1, 1, false>(p, (hipStream_t)stream);

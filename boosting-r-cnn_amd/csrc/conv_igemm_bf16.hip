@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
                 wi = qw;
             }
             ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
-            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j]) * 2 : OOB;
+            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j] + tile_n * p.gstep) * 2 : OOB;
             float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
         }
@@ -312,6 +312,7 @@ int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 wave
 
 namespace brcnn_conv {
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
+    if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
     int t = g_bf16_tile;
     if (t == 0) {
         // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more

@@ -30,6 +30,7 @@ struct WgradHParams {
     int Cin, Cout, KH, KW, stride, pad, M, K;
     int tiles_co, tiles_k, slices, rows_per_slice;
     unsigned dy_bytes, x_bytes;
+    int pitch, gstep;       // pixel pitch of x (== Cin unless grouped); grouped: co tile t reads channels [t*gstep, +Cin)
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
     int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
                 const int wo = rem - ho * Wo;
                 hi0 = ho * p.stride - p.pad;
                 wi0 = wo * p.stride - p.pad;
-                xb = (int)p.seg_xoff[sg] + n * H * W * p.Cin;
+                xb = (int)p.seg_xoff[sg] + n * H * W * p.pitch;
             }
 #pragma unroll
             for (int cb = 0; cb < WT; cb++) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
                     const int kh = tap / p.KW, kw = tap - kh * p.KW;
                     const int hi = hi0 + kh, wi = wi0 + kw;
                     if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                        offx = (xb + (hi * W + wi) * p.Cin + ci) * 2;
+                        offx = (xb + (hi * W + wi) * p.pitch + ci + tco * p.gstep) * 2;
                 }
                 unsigned short* dy_dst = Ya + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
                 unsigned short* x_dst = Xa + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
@@ -241,6 +242,7 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
     WgradHParams p = {};
     p.dy = (const unsigned short*)dy; p.x = (const unsigned short*)x; p.dw = (float*)dw;
     p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.pitch = cin; p.gstep = 0;
     p.nseg = num_segments;
     long long m_total = 0, x_off = 0;
     for (int s = 0; s < num_segments; s++) {
@@ -270,4 +272,31 @@ BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
     if (wt < 0 || wt > 2) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;
+}
+
+
+// grouped variant (ResNeXt conv2): per 64-channel co tile a dense (64 x KH*KW*window) wgrad over the
+// tile's input window; called by brcnn_conv2d_wgrad_nhwc_grouped for dtype == BRCNN_DT_BF16
+int brcnn_wgrad_bf16_grouped_dispatch(const void* x, const void* dy, void* dw_tiles, int batch, int height, int width,
+                                      int cin, int cout, int kh, int kw, int stride, int pad, int window,
+                                      hipStream_t stream) {
+    if ((window & 7) || (cout % 64) || (cout / 64) * window != cin) return BRCNN_EINVAL;
+    const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
+    WgradHParams p = {};
+    p.dy = (const unsigned short*)dy; p.x = (const unsigned short*)x; p.dw = (float*)dw_tiles;
+    p.Cin = window; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
+    p.pitch = cin; p.gstep = window; p.nseg = 1;
+    p.seg_H[0] = height; p.seg_W[0] = width; p.seg_Ho[0] = Ho; p.seg_Wo[0] = Wo;
+    p.seg_m0[0] = 0; p.seg_xoff[0] = 0;
+    magic_for((unsigned)(Ho * Wo), &p.seg_mhw[0], &p.seg_shw[0]);
+    magic_for((unsigned)Wo, &p.seg_mw[0], &p.seg_sw[0]);
+    const long long m_total = (long long)batch * Ho * Wo, x_elems = (long long)batch * height * width * cin;
+    for (int s = 1; s <= BRCNN_MAX_LEVELS; s++) p.seg_m0[s] = (int)m_total;
+    if (m_total * cout * 2 >= 0x7fffffffLL || x_elems * 2 >= 0x7fffffffLL) return BRCNN_EINVAL;
+    p.M = (int)m_total;
+    p.K = kh * kw * window;
+    p.dy_bytes = (unsigned)(m_total * cout * 2);
+    p.x_bytes = (unsigned)(x_elems * 2);
+    return launch<1>(p, stream);          // 64 x 64 output tiles: the co tile is the group window
 }

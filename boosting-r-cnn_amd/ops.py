@@ -490,17 +490,20 @@ def pack_grouped_weight(weight, groups):
 def conv2d_nhwc_grouped(x, w_tiles, window, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
     """grouped conv on the MFMA kernel; `w_tiles`, `window` from pack_grouped_weight"""
     _require_gpu(x, w_tiles, scale, shift, residual)
-    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and w_tiles.is_contiguous()
+    assert x.dim() == 4 and x.is_contiguous() and w_tiles.is_contiguous() and w_tiles.dtype == x.dtype
     n, h, wd, cin = x.shape
     cout, kh, kw, win = w_tiles.shape
     assert win == window
+    dt = _dt(x)
+    if dt == DT_BF16 and window % 64:
+        raise _L.BrcnnHipError(f'bf16 grouped conv needs a window that is a multiple of 64 channels (got {window})')
     ho, wo = conv_out_size(h, wd, kh, kw, stride, pad)
-    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
     if residual is not None:
         assert residual.shape == y.shape and residual.is_contiguous()
     st = _L.load().brcnn_conv2d_nhwc_grouped(_ptr(x), _ptr(w_tiles), _ptr(scale), _ptr(shift), _ptr(residual),
                                              _ptr(y), n, h, wd, cin, cout, kh, kw, int(stride), int(pad),
-                                             int(window), int(bool(relu)), DT_F32, _stream())
+                                             int(window), int(bool(relu)), dt, _stream())
     _L.check(st, 'brcnn_conv2d_nhwc_grouped')
     return y
 

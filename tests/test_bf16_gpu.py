@@ -293,3 +293,27 @@ def test_bf16_tile_variants_agree():
             L.brcnn_conv_set_tile_bf16(0)
         for o in outs[1:]:
             assert torch.equal(o, outs[0])
+
+
+def test_grouped_conv_bf16_forward_backward():
+    """bf16 grouped conv (ResNeXt conv2): forward, dgrad and tiled wgrad against the fp64 gradients of the
+    same bf16-rounded operands"""
+    from brcnn.autograd import grouped_conv_autograd
+    gen = torch.Generator().manual_seed(43)
+    for (n, c, h, w, groups, stride) in [(2, 128, 20, 30, 32, 1), (1, 256, 17, 23, 64, 2), (2, 512, 9, 14, 64, 1),
+                                         (1, 1024, 7, 9, 32, 2)]:
+        x = _bf(torch.randn(n, c, h, w, generator=gen))
+        wt = _bf(torch.randn(c, c // groups, 3, 3, generator=gen) / np.sqrt(9 * c / groups))
+        xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+        ref = F.conv2d(xr, wr, None, stride, 1, groups=groups)
+        go = _bf(torch.randn(ref.shape, generator=gen))
+        ref.backward(go.double())
+        xg = x.permute(0, 2, 3, 1).contiguous().to(DEV, BF).requires_grad_()
+        wg = wt.to(DEV).requires_grad_()
+        y = grouped_conv_autograd(xg, wg, groups, stride, 1)
+        assert y.dtype == BF
+        y.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV, BF))
+        assert _rne_close(y.detach().float().permute(0, 3, 1, 2).cpu().double(), ref.detach())
+        assert xg.grad.dtype == BF and _rne_close(xg.grad.float().permute(0, 3, 1, 2).cpu().double(), xr.grad)
+        assert wg.grad.dtype == torch.float32 and wg.grad.shape == wt.shape
+        assert (wg.grad.cpu().double() - wr.grad).abs().max().item() <= 2e-4 * max(1.0, wr.grad.abs().max().item())
