@@ -189,7 +189,7 @@ class TwoStageDetector(BaseDetector):
         typ = rc.nms.get('type', 'nms')
         split = rp.max_per_img * self.roi_head.bbox_head.num_classes >= rc.nms.get('split_thr', 10000)
         return (typ == 'nms' or (typ == 'soft_nms' and split)) and rp.nms.get('type', 'nms') == 'nms' and \
-            not rc.nms.get('class_agnostic', False)
+            not rc.nms.get('class_agnostic', False) and getattr(self.roi_head, 'device_test_path', True)
 
 
 @DETECTORS.register_module()

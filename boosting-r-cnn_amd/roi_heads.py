@@ -12,6 +12,7 @@ arguments and parameter names (`bbox_head.{shared_fcs.{i},fc_cls,fc_reg}`).  Exe
   * test-time: sqrt(softmax * prior), per-class decode, threshold, class-aware NMS for the
     whole batch stay on the device (postprocess.batched_nms_images).
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -19,7 +20,7 @@ import torch.nn.functional as F
 from . import ops
 from .blocks import PackedCache, to_nhwc
 from .core import bbox2result, bbox2roi, bbox_overlaps, multi_apply, multiclass_nms
-from .losses import accuracy
+from .losses import SmoothL1Loss, accuracy
 from .postprocess import batched_nms_images
 from .registry import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head,
                        build_loss, build_roi_extractor, build_sampler)
@@ -505,8 +506,11 @@ class ProbRoIHead(nn.Module):
         return (cls_score.softmax(1) * prior.reshape(-1, 1)) ** 0.5
 
     def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
-        rois = bbox2roi(proposals)
         prior = torch.cat([boxes[:, -1] for boxes in proposals], dim=0)
+        return self._simple_test_bboxes_with_prior(x, img_metas, proposals, prior, rcnn_test_cfg, rescale)
+
+    def _simple_test_bboxes_with_prior(self, x, img_metas, proposals, prior, rcnn_test_cfg, rescale):
+        rois = bbox2roi(proposals)
         if rois.shape[0] == 0:
             batch_size = len(proposals)
             det_bbox = rois.new_zeros(0, 5)
@@ -594,3 +598,179 @@ class ProbRoIHead(nn.Module):
                                           nms_cfg['iou_threshold'], cfg.max_per_img,
                                           nms_cfg.get('offset', 0))
         return det, lab, nd
+
+
+# ----------------------------------------------------------------------------- variants
+@HEADS.register_module()
+class BoostRoIHead(ProbRoIHead):
+    """prob_roi_head.py:285-468: the variant fed by a first stage that scores every class --
+    proposals are (n, 4 + P) rows [x1,y1,x2,y2,s_0..s_{P-1}].  Training priors are the (n, P+1)
+    matrix [s | bg], bg = 0 for positives and max_p s_p for negatives, gathered at the sample's
+    label; the boosted weights go STRAIGHT into the head loss as label weights (no norm_loss
+    rescaling, default reduction).  Test-time fusion multiplies softmax column c by s_c and the
+    background column by 1."""
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels,
+                      gt_bboxes_ignore=None, gt_masks=None):
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        sampling_results, priors, ious = [], [], []
+        for i in range(num_imgs):
+            assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i],
+                                                      gt_bboxes_ignore[i], gt_labels[i])
+            sampling_result = self.bbox_sampler.sample(assign_result, proposal_list[i],
+                                                       gt_bboxes[i], gt_labels[i],
+                                                       feats=[lvl[i][None] for lvl in x])
+            sampling_results.append(sampling_result)
+            num_gts = assign_result.num_gts
+            pos_inds = sampling_result.pos_inds[num_gts:].clone() - num_gts
+            neg_inds = sampling_result.neg_inds.clone() - num_gts
+            neg_scores = proposal_list[i][neg_inds, 4:]
+            prior = torch.cat((proposal_list[i][pos_inds, 4:], neg_scores), dim=0).clone()
+            prior = torch.cat((prior, prior.new_zeros(prior.shape[0], 1)), dim=1)
+            prior[pos_inds.shape[0]:, -1] = neg_scores.clone().max(-1)[0]
+            gt_weights = prior.new_zeros(num_gts, prior.shape[1])
+            if self.quality:
+                pos_ious = assign_result.max_overlaps[sampling_result.pos_inds]
+                neg_ious = 1 - assign_result.max_overlaps[sampling_result.neg_inds]
+                ious.append(torch.cat([pos_ious, neg_ious], dim=0).detach())
+            priors.append(torch.cat([gt_weights, prior], dim=0).detach())
+        priors = torch.cat(priors, dim=0)
+        ious = torch.cat(ious, dim=0) if self.quality else None
+        losses = dict()
+        if self.boost:
+            bbox_results = self._bbox_forward_train_boost(x, sampling_results, gt_bboxes, gt_labels,
+                                                          img_metas, priors, ious)
+        else:
+            bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels,
+                                                    img_metas)
+        losses.update(bbox_results['loss_bbox'])
+        return losses
+
+    def _bbox_forward_train_boost(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
+                                  priors, ious=None):
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(x, rois)
+        labels, label_weights, bbox, bbox_weights = self.bbox_head.get_targets(
+            sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        priors = torch.gather(priors, 1, labels.reshape(-1, 1)).squeeze()
+        label_weights_new = self.boost_weights(bbox_results['cls_score'], labels, priors, ious)
+        loss_bbox = self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                        labels, label_weights_new, bbox, bbox_weights)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
+
+    def fuse_scores(self, cls_score, prior):
+        """prob_roi_head.py:369-393"""
+        if not self.prob:
+            return cls_score
+        return (cls_score.softmax(1) * prior) ** 0.5
+
+    def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
+        # the parent's flow with the per-class prior matrix [s | 1] in place of the score column
+        prior = torch.cat([boxes[:, 4:] for boxes in proposals], dim=0)
+        prior = torch.cat((prior, prior.new_ones(prior.shape[0], 1)), dim=1)
+        return self._simple_test_bboxes_with_prior(x, img_metas, proposals, prior, rcnn_test_cfg, rescale)
+
+    device_test_path = False    # per-class priors: the per-image test path (simple_test) serves it
+
+
+EPS = 1e-15
+
+
+@HEADS.register_module()
+class DyProbRoIHead(ProbRoIHead):
+    """prob_roi_head.py:473-623: Dynamic R-CNN schedule on the boosting head.  Every iteration
+    records the batch mean of the `iou_topk`-th largest proposal IoU and the `beta_topk`-th
+    smallest mean |dx,dy| regression target; every `update_iter_interval` iterations the
+    assigner's IoU thresholds become max(initial_iou, mean(history)) and the SmoothL1 beta
+    min(initial_beta, median(history)).  The boosted weights are plain label weights here."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        assert isinstance(self.bbox_head.loss_bbox, SmoothL1Loss)
+        self.iou_history = []
+        self.beta_history = []
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels,
+                      gt_bboxes_ignore=None, gt_masks=None):
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        dyn = self.train_cfg.dynamic_rcnn
+        sampling_results, priors, kth = [], [], []
+        for i in range(num_imgs):
+            assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i],
+                                                      gt_bboxes_ignore[i], gt_labels[i])
+            sampling_result = self.bbox_sampler.sample(assign_result, proposal_list[i],
+                                                       gt_bboxes[i], gt_labels[i],
+                                                       feats=[lvl[i][None] for lvl in x])
+            iou_topk = min(dyn.iou_topk, len(assign_result.max_overlaps))
+            kth.append(torch.topk(assign_result.max_overlaps, iou_topk)[0][-1])
+            sampling_results.append(sampling_result)
+            num_gts = assign_result.num_gts
+            pos_inds = sampling_result.pos_inds[num_gts:].clone() - num_gts
+            neg_inds = sampling_result.neg_inds.clone() - num_gts
+            pos_prior = proposal_list[i][pos_inds, -1].clone()
+            neg_prior = 1 - proposal_list[i][neg_inds, -1].clone()
+            priors.append(torch.cat([neg_prior.new_zeros(num_gts), pos_prior, neg_prior], dim=0).detach())
+        priors = torch.cat(priors, dim=0)
+        # one host read for the whole batch (the reference reads one scalar per image)
+        self.iou_history.append(np.mean(torch.stack(kth).tolist()))
+        losses = dict()
+        if self.boost:
+            bbox_results = self._bbox_forward_train_boost(x, sampling_results, gt_bboxes, gt_labels,
+                                                          img_metas, priors)
+        else:
+            bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels,
+                                                    img_metas)
+        losses.update(bbox_results['loss_bbox'])
+        if len(self.iou_history) % dyn.update_iter_interval == 0:
+            self.update_hyperparameters()
+        return losses
+
+    def _record_beta(self, bbox, bbox_weights, num_imgs):
+        pos_inds = bbox_weights[:, 0].nonzero().squeeze(1)
+        cur_target = bbox[pos_inds, :2].abs().mean(dim=1)
+        beta_topk = min(self.train_cfg.dynamic_rcnn.beta_topk * num_imgs, len(pos_inds))
+        self.beta_history.append(torch.kthvalue(cur_target, beta_topk)[0].item())
+
+    def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas):
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(x, rois)
+        bbox_targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels,
+                                                  self.train_cfg)
+        self._record_beta(bbox_targets[2], bbox_targets[3], len(img_metas))
+        loss_bbox = self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                        *bbox_targets)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
+
+    def _bbox_forward_train_boost(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
+                                  priors, ious=None):
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(x, rois)
+        labels, label_weights, bbox, bbox_weights = self.bbox_head.get_targets(
+            sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        self._record_beta(bbox, bbox_weights, len(img_metas))
+        label_weights_new = self.boost_weights(bbox_results['cls_score'], labels, priors)
+        loss_bbox = self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                        labels, label_weights_new, bbox, bbox_weights)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
+
+    def update_hyperparameters(self):
+        dyn = self.train_cfg.dynamic_rcnn
+        new_iou_thr = max(dyn.initial_iou, np.mean(self.iou_history))
+        self.iou_history = []
+        self.bbox_assigner.pos_iou_thr = new_iou_thr
+        self.bbox_assigner.neg_iou_thr = new_iou_thr
+        self.bbox_assigner.min_pos_iou = new_iou_thr
+        if np.median(self.beta_history) < EPS:
+            new_beta = self.bbox_head.loss_bbox.beta
+        else:
+            new_beta = min(dyn.initial_beta, np.median(self.beta_history))
+        self.beta_history = []
+        self.bbox_head.loss_bbox.beta = new_beta
+        return new_iou_thr, new_beta

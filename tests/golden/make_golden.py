@@ -633,7 +633,70 @@ def g17_res2net():
     npz('g17_res2net', **d)
 
 
+def _variant_head_cfg(cfg, typ, num_classes, **over):
+    rc = copy.deepcopy(cfg.model.roi_head.to_dict())
+    rc['type'] = typ
+    rc['bbox_head']['num_classes'] = num_classes
+    rc['train_cfg'] = copy.deepcopy(cfg.model.train_cfg.rcnn.to_dict())
+    rc['test_cfg'] = copy.deepcopy(cfg.model.test_cfg.rcnn.to_dict())
+    rc.update(over)
+    return rc
+
+
+def g18_boost_variants(cfg):
+    """BoostRoIHead / DyProbRoIHead (prob_roi_head.py:285-623) run through the reference on CPU:
+    train losses (seeded sampler), the multi-column test-time fusion, and the Dynamic R-CNN
+    threshold / beta schedule over 4 iterations."""
+    from mmdet.models import build_head
+    d = {}
+    # --- BoostRoIHead, single foreground class (the only case the reference's assigner accepts)
+    for tag, over in (('q', dict(boost=True, quality=True, iou_gamma=0.5, gamma=0.5)),
+                      ('p', dict(boost=True, quality=False, gamma=0.5, alpha=0.75))):
+        rc = _variant_head_cfg(cfg, 'BoostRoIHead', 1, **over)
+        head = build_head(cfgdict(rc))
+        head.load_state_dict(util.seeded_state_dict(head, seed=18))
+        head.train()
+        feats, metas, gts, gls, props = util.variant_inputs(1, 1, 18)
+        torch.manual_seed(5)
+        losses = head.forward_train(feats, metas, props, gts, gls)
+        for k, v in losses.items():
+            d[f'boost_{tag}_{k}'] = v
+    # --- BoostRoIHead test path, 3 classes, proposals carry one score per class
+    rc = _variant_head_cfg(cfg, 'BoostRoIHead', 3, boost=True)
+    head = build_head(cfgdict(rc))
+    head.load_state_dict(util.seeded_state_dict(head, seed=19))
+    head.eval()
+    feats, metas, gts, gls, props = util.variant_inputs(3, 3, 19)
+    with torch.no_grad():
+        det, lab = head.simple_test_bboxes(feats, metas, props, head.test_cfg, rescale=True)
+    for b in range(2):
+        d[f'boost_det{b}'], d[f'boost_lab{b}'] = det[b], lab[b]
+    # --- DyProbRoIHead: 4 iterations, update every 2
+    rc = _variant_head_cfg(cfg, 'DyProbRoIHead', 4, boost=True, gamma=0.5)
+    rc['bbox_head']['loss_bbox'] = dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)
+    rc['train_cfg']['dynamic_rcnn'] = dict(iou_topk=40, beta_topk=6, update_iter_interval=2,
+                                           initial_iou=0.4, initial_beta=1.0)
+    head = build_head(cfgdict(rc))
+    head.load_state_dict(util.seeded_state_dict(head, seed=20))
+    head.train()
+    sched = []
+    for it in range(4):
+        feats, metas, gts, gls, props = util.variant_inputs(4, 1, 30 + it)
+        torch.manual_seed(50 + it)
+        losses = head.forward_train(feats, metas, props, gts, gls)
+        for k, v in losses.items():
+            d[f'dy{it}_{k}'] = v
+        sched.append([head.bbox_assigner.pos_iou_thr, head.bbox_assigner.neg_iou_thr,
+                      head.bbox_assigner.min_pos_iou, head.bbox_head.loss_bbox.beta,
+                      len(head.iou_history), len(head.beta_history)])
+    d['dy_sched'] = np.array(sched, np.float64)
+    npz('g18_boost_variants', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        g18_boost_variants(Config.fromfile(REF_CFG))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'r2':
         g17_res2net()
         return

@@ -598,3 +598,89 @@ def test_batched_postprocess_equals_per_image_reference_path(cfg_name):
             assert len(fast[b][c]) == len(slow[b][c]), (b, c)
             if len(slow[b][c]):
                 assert _match_dets(fast[b][c], slow[b][c], 1e-3, 1e-5) == 1.0, (b, c)
+
+
+# ---- remaining boosting variants: BoostRoIHead / DyProbRoIHead ---------------
+def _variant_head(typ, num_classes, seed, **over):
+    import copy
+    from brcnn.registry import build_head
+    cfg = Config.fromfile(CFG)
+    rc = copy.deepcopy(cfg.model.roi_head)
+    rc['type'] = typ
+    rc['bbox_head']['num_classes'] = num_classes
+    rc['train_cfg'] = copy.deepcopy(cfg.model.train_cfg.rcnn)
+    rc['test_cfg'] = copy.deepcopy(cfg.model.test_cfg.rcnn)
+    dyn = over.pop('dynamic_rcnn', None)
+    if dyn:
+        rc['train_cfg']['dynamic_rcnn'] = dyn
+    lb = over.pop('loss_bbox', None)
+    if lb:
+        rc['bbox_head']['loss_bbox'] = lb
+    rc.update(over)
+    head = build_head(rc)
+    head.load_state_dict(util.seeded_state_dict(head, seed=seed))
+    return head.to(DEV)
+
+
+def _dev_inputs(num_classes, cols, seed):
+    feats, metas, gts, gls, props = util.variant_inputs(num_classes, cols, seed)
+    return ([f.to(DEV) for f in feats], metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls],
+            [p.to(DEV) for p in props])
+
+
+def _loss_close(got, ref):
+    return torch.allclose(got.detach().cpu().float().reshape(-1), T(ref).float().reshape(-1), rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize('tag,over', [('q', dict(boost=True, quality=True, iou_gamma=0.5, gamma=0.5)),
+                                      ('p', dict(boost=True, quality=False, gamma=0.5, alpha=0.75))])
+def test_boost_roi_head_train_golden(tag, over):
+    """BoostRoIHead.forward_train (prob_roi_head.py:290-359,438-468) on the device against the
+    reference's CPU losses: per-class prior matrix gathered at the label, weights passed as label
+    weights (incl. the reference's (n,n) broadcast when `quality` is on)"""
+    g = load('g18_boost_variants')
+    head = _variant_head('BoostRoIHead', 1, 18, **over).train()
+    feats, metas, gts, gls, props = _dev_inputs(1, 1, 18)
+    torch.manual_seed(5)
+    losses = head.forward_train(feats, metas, props, gts, gls)
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        assert _loss_close(losses[k], g[f'boost_{tag}_{k}']), (k, losses[k], g[f'boost_{tag}_{k}'])
+    (losses['loss_cls'] + losses['loss_bbox']).backward()
+    assert all(torch.isfinite(p.grad).all() for p in head.parameters() if p.grad is not None)
+
+
+def test_boost_roi_head_test_golden():
+    """per-class test-time fusion sqrt(softmax * [s_0..s_{C-1}, 1]) (prob_roi_head.py:361-436)"""
+    g = load('g18_boost_variants')
+    head = _variant_head('BoostRoIHead', 3, 19, boost=True).eval()
+    feats, metas, gts, gls, props = _dev_inputs(3, 3, 19)
+    with torch.no_grad():
+        det, lab = head.simple_test_bboxes(feats, metas, props, head.test_cfg, rescale=True)
+    for b in range(2):
+        ref, rl = g[f'boost_det{b}'], g[f'boost_lab{b}']
+        got, gl = det[b].cpu().numpy(), lab[b].cpu().numpy()
+        assert len(ref) > 5 and abs(len(got) - len(ref)) <= max(2, len(ref) // 20)
+        for c in range(3):
+            assert _match_dets(got[gl == c], ref[rl == c], 5e-2, 1e-3) >= 0.9
+            assert _match_dets(ref[rl == c], got[gl == c], 5e-2, 1e-3) >= 0.9
+
+
+def test_dyprob_roi_head_schedule_golden():
+    """DyProbRoIHead (prob_roi_head.py:473-623): losses of 4 iterations and the Dynamic R-CNN
+    IoU-threshold / SmoothL1-beta updates after iterations 2 and 4"""
+    g = load('g18_boost_variants')
+    head = _variant_head('DyProbRoIHead', 4, 20, boost=True, gamma=0.5,
+                         loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0),
+                         dynamic_rcnn=dict(iou_topk=40, beta_topk=6, update_iter_interval=2,
+                                           initial_iou=0.4, initial_beta=1.0)).train()
+    for it in range(4):
+        feats, metas, gts, gls, props = _dev_inputs(4, 1, 30 + it)
+        torch.manual_seed(50 + it)
+        losses = head.forward_train(feats, metas, props, gts, gls)
+        for k in ('loss_cls', 'loss_bbox', 'acc'):
+            assert _loss_close(losses[k], g[f'dy{it}_{k}']), (it, k, losses[k], g[f'dy{it}_{k}'])
+        sched = [head.bbox_assigner.pos_iou_thr, head.bbox_assigner.neg_iou_thr,
+                 head.bbox_assigner.min_pos_iou, head.bbox_head.loss_bbox.beta,
+                 len(head.iou_history), len(head.beta_history)]
+        assert np.allclose(sched, g['dy_sched'][it], rtol=1e-4, atol=1e-6), (it, sched, g['dy_sched'][it])
+    assert g['dy_sched'][1][3] != 1.0 or g['dy_sched'][1][0] != 0.6   # the schedule moved something

@@ -49,3 +49,17 @@ def test_product_ops_restored_after_patch():
     import pytest
     with pytest.raises(RuntimeError):
         ops.rpn_score(torch.zeros(4), torch.zeros(4))
+
+
+def test_boosting_variant_heads_cpu_match_reference_golden(monkeypatch):
+    """BoostRoIHead / DyProbRoIHead host logic (priors, boosted label weights, Dynamic R-CNN
+    schedule) on the CPU oracle pipeline against golden g18; the device run of the same cases is
+    tests/test_golden_gpu.py"""
+    import tests.test_golden_gpu as tg
+    monkeypatch.setattr(tg, 'DEV', 'cpu')
+    torch.set_num_threads(8)
+    with cpu_pipeline.patched():
+        tg.test_boost_roi_head_train_golden('q', dict(boost=True, quality=True, iou_gamma=0.5, gamma=0.5))
+        tg.test_boost_roi_head_train_golden('p', dict(boost=True, quality=False, gamma=0.5, alpha=0.75))
+        tg.test_boost_roi_head_test_golden()
+        tg.test_dyprob_roi_head_schedule_golden()

@@ -114,3 +114,22 @@ def demo_inputs(batch=2, h=128, w=192, num_classes=4, seed=0, num_gt=5):
         gt_bboxes.append(b)
         gt_labels.append(torch.randint(0, num_classes, (num_gt,), generator=g))
     return img, img_metas, gt_bboxes, gt_labels
+
+
+def variant_inputs(num_classes, score_cols, seed):
+    """seeded pyramid, proposals (n, 4 + score_cols) near the GTs, GTs for a 2 x 128 x 192 batch"""
+    g = torch.Generator().manual_seed(seed)
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    feats = [torch.randn(2, 256, h, w, generator=g) for h, w in sizes]
+    _, metas, gts, gls = demo_inputs(2, 128, 192, num_classes=num_classes, seed=seed)
+    props = []
+    for b in range(2):
+        jit = gts[b].repeat(30, 1) + torch.randn(gts[b].shape[0] * 30, 4, generator=g) * 6
+        rnd = rand_boxes(150, img_w=192., img_h=128., seed=seed + b, min_size=4., max_size=120.)
+        boxes = torch.cat([jit, rnd], 0)
+        boxes[:, 0::2] = boxes[:, 0::2].clamp(0, 192)
+        boxes[:, 1::2] = boxes[:, 1::2].clamp(0, 128)
+        boxes = torch.cat([torch.min(boxes[:, :2], boxes[:, 2:]), torch.max(boxes[:, :2], boxes[:, 2:]) + 1], 1)
+        sc = torch.rand(boxes.shape[0], score_cols, generator=g)
+        props.append(torch.cat([boxes, sc], 1))
+    return feats, metas, gts, gls, props

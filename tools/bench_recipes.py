@@ -40,5 +40,6 @@ for f in sorted(os.listdir(d)):
     print(f, json.dumps(out[f]), flush=True)
     del m
     torch.cuda.empty_cache()
-m.set_compute_dtype('f32')
+from brcnn.blocks import set_compute_dtype
+set_compute_dtype('f32')
 json.dump(out, open('gpurun_out/recipes.json' if DTYPE == 'f32' else f'gpurun_out/recipes_{DTYPE}.json', 'w'), indent=1)

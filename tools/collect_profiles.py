@@ -9,7 +9,7 @@ pairs = [('bench.json', 'bench.json'), ('bench_bf16.json', 'bench_bf16.json'), (
          ('stats_train_bf16/step_kernel_stats.csv', 'train_bf16_kernel_stats.csv'),
          ('conv_tiles.txt', 'conv_tiles.txt'), ('conv_tiles_bf16.txt', 'conv_tiles_bf16.txt'),
          ('layers.txt', 'conv_layers.txt'), ('layers_bf16.txt', 'conv_layers_bf16.txt'),
-         ('op_bench.json', 'op_bench.json'), ('recipes.json', 'recipes.json'), ('pytest_gpu.txt', 'pytest_gpu.txt')]
+         ('op_bench.json', 'op_bench.json'), ('recipes.json', 'recipes.json'), ('recipes_bf16.json', 'recipes_bf16.json'), ('pytest_gpu.txt', 'pytest_gpu.txt')]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p):

@@ -24,4 +24,6 @@ BRCNN_DTYPE=bf16 python tools/layers.py > $O/layers_bf16.txt 2>&1
 python tools/op_bench.py > $O/op_bench.json 2>$O/op_bench.err
 python tools/bench_recipes.py > $O/recipes.txt 2>&1
 cp gpurun_out/recipes.json $O/recipes.json
+BRCNN_DTYPE=bf16 python tools/bench_recipes.py > $O/recipes_bf16.txt 2>&1
+cp gpurun_out/recipes_bf16.json $O/recipes_bf16.json
 cat $O/pytest_gpu.txt; cat $O/bench.json; cat $O/bench_bf16.json | cut -c1-250; cat $O/bench_train.json | cut -c1-250; cat $O/bench_train_bf16.json | cut -c1-250
