@@ -6,6 +6,7 @@
 namespace brcnn_conv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // any byte offset >= the buffer extent makes a raw buffer load return zeros: the zero padding

@@ -405,36 +405,57 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     __syncthreads();
 
     // fragment addressing: row R = base + li, logical chunk c = 2*kk + lh, physical c ^ ((R>>1)&7);
-    // all row bases are multiples of 32, so (R>>1)&7 == (li>>1)&7
+    // all row bases are multiples of 32, so (R>>1)&7 == (li>>1)&7.
+    // The fragment reads are INLINE ASM on purpose: a compiler-visible LDS read after a
+    // `buffer_load ... lds` makes the waitcnt pass put `s_waitcnt vmcnt(0)` in front of it (it
+    // cannot tell the two buffers apart), which serialises the prefetch of tile kt+1 with the
+    // MFMAs of tile kt inside every wave.  With opaque reads the only vmcnt wait of an iteration
+    // is the explicit one before the barrier, so the DMA lands under the MFMA block.
     const int sw = (li >> 1) & 7;
+    unsigned chb[BK / 8];
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk++) chb[kk] = (unsigned)(((2 * kk + lh) ^ sw) * 16);
+    const unsigned a_lane = (unsigned)(size_t)(lds_ptr_t)(As + (wm * 32 * MT + li) * 32);
+    const unsigned b_lane = (unsigned)(size_t)(lds_ptr_t)(Bs + (wn * 32 * NT + li) * 32);
+    f32x4 av[2][MT], bv[2][NT];
+    auto frag_read = [&](int slot, unsigned a_addr, unsigned b_addr) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(av[slot][0]) : "v"(a_addr) : "memory");
+        if constexpr (MT == 2)
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(av[slot][1]) : "v"(a_addr) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bv[slot][0]) : "v"(b_addr) : "memory");
+        if constexpr (NT == 2)
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bv[slot][1]) : "v"(b_addr) : "memory");
+    };
+    auto frag_wait = [&](int slot) {
+        if constexpr (MT == 2 && NT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1]), "+v"(bv[slot][0]), "+v"(bv[slot][1]) :: "memory");
+        else if constexpr (MT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1]), "+v"(bv[slot][0]) :: "memory");
+        else if constexpr (NT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]), "+v"(bv[slot][1]) :: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]) :: "memory");
+    };
     int cur = 0;
     for (int kt = 0; kt < nk; kt++) {
         if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
-        const float* as = As + cur * BM * 32 + (wm * 32 * MT + li) * 32;
-        const float* bs = Bs + cur * BN * 32 + (wn * 32 * NT + li) * 32;
+        const unsigned a_cur = a_lane + cur * (BM * 32 * 4);
+        const unsigned b_cur = b_lane + cur * (BN * 32 * 4);
+        frag_read(0, a_cur + chb[0], b_cur + chb[0]);
+        frag_wait(0);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; kk++) {
-            const int ch = ((2 * kk + lh) ^ sw) * 4;
-            float av[MT][4];
-#pragma unroll
-            for (int t = 0; t < MT; t++) {
-                const float4 a = *reinterpret_cast<const float4*>(as + t * 32 * 32 + ch);
-                av[t][0] = a.x; av[t][1] = a.y; av[t][2] = a.z; av[t][3] = a.w;
-            }
-            float bv[NT][4];
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float4 b = *reinterpret_cast<const float4*>(bs + t * 32 * 32 + ch);
-                bv[t][0] = b.x; bv[t][1] = b.y; bv[t][2] = b.z; bv[t][3] = b.w;
-            }
+            const int sl = kk & 1;
+            if (kk + 1 < BK / 8) frag_read(sl ^ 1, a_cur + chb[kk + 1], b_cur + chb[kk + 1]);
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
                 for (int tm = 0; tm < MT; tm++)
 #pragma unroll
                     for (int t = 0; t < NT; t++)
-                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][e], bv[t][e],
+                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl][tm][e], bv[sl][t][e],
                                                                           acc[tm][t], 0, 0, 0);
+            if (kk + 1 < BK / 8) frag_wait(sl ^ 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -156,31 +156,54 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Fragment reads are inline asm: a compiler-visible LDS read after `buffer_load ... lds` gets
+    // an `s_waitcnt vmcnt(0)` put in front of it by the waitcnt pass (it cannot tell the two LDS
+    // buffers apart), which would serialise the prefetch of tile kt+1 with the MFMAs of tile kt
+    // in every wave.  Opaque reads leave the explicit wait before the barrier as the only one.
     const int sw = (li >> 1) & 7;
+    unsigned chb[BKE / 16];
+#pragma unroll
+    for (int kk = 0; kk < BKE / 16; kk++) chb[kk] = (unsigned)(((2 * kk + lh) ^ sw) * 16);
+    const unsigned a_lane = (unsigned)(size_t)(lds_ptr_t)(As + (wm * 32 * MT + li) * 32);
+    const unsigned b_lane = (unsigned)(size_t)(lds_ptr_t)(Bs + (wn * 32 * NT + li) * 32);
+    f32x4 av[2][MT], bv[2][NT];
+    auto frag_read = [&](int slot, unsigned a_addr, unsigned b_addr) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(av[slot][0]) : "v"(a_addr) : "memory");
+        if constexpr (MT == 2)
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(av[slot][1]) : "v"(a_addr) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bv[slot][0]) : "v"(b_addr) : "memory");
+        if constexpr (NT == 2)
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bv[slot][1]) : "v"(b_addr) : "memory");
+    };
+    auto frag_wait = [&](int slot) {
+        if constexpr (MT == 2 && NT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1]), "+v"(bv[slot][0]), "+v"(bv[slot][1]) :: "memory");
+        else if constexpr (MT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1]), "+v"(bv[slot][0]) :: "memory");
+        else if constexpr (NT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]), "+v"(bv[slot][1]) :: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]) :: "memory");
+    };
+    static_assert(MT <= 2 && NT <= 2, "fragment readers cover 1 or 2 MFMA tiles per wave and axis");
     int cur = 0;
     for (int kt = 0; kt < nk; kt++) {
         if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
-        const float* as = As + cur * BM * 32 + (wm * 32 * MT + li) * 32;
-        const float* bs = Bs + cur * BN * 32 + (wn * 32 * NT + li) * 32;
+        const unsigned a_cur = a_lane + cur * (BM * 32 * 4);
+        const unsigned b_cur = b_lane + cur * (BN * 32 * 4);
+        frag_read(0, a_cur + chb[0], b_cur + chb[0]);
+        frag_wait(0);
 #pragma unroll
         for (int kk = 0; kk < BKE / 16; kk++) {
-            const int ch = ((2 * kk + lh) ^ sw) * 4;
-            bf16x8 av[MT], bv[NT];
-#pragma unroll
-            for (int t = 0; t < MT; t++) {
-                const uint4 a = *reinterpret_cast<const uint4*>(as + t * 32 * 32 + ch);
-                av[t] = *reinterpret_cast<const bf16x8*>(&a);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const uint4 b = *reinterpret_cast<const uint4*>(bs + t * 32 * 32 + ch);
-                bv[t] = *reinterpret_cast<const bf16x8*>(&b);
-            }
+            const int sl = kk & 1;
+            if (kk + 1 < BKE / 16) frag_read(sl ^ 1, a_cur + chb[kk + 1], b_cur + chb[kk + 1]);
 #pragma unroll
             for (int tm = 0; tm < MT; tm++)
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[t], av[tm], acc[tm][t], 0, 0, 0);
+                    acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, bv[sl][t]), __builtin_bit_cast(bf16x8, av[sl][tm]), acc[tm][t], 0, 0, 0);
+            if (kk + 1 < BKE / 16) frag_wait(sl ^ 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
