@@ -30,6 +30,7 @@ struct ConvParams {
     unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
     int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
     int out_f32;                     // bf16 compute path: write the result as fp32 (head outputs)
+    int il;                          // tuning: 1 = LDS-DMA pieces interleaved with the MFMA groups (bf16 kernel)
     int gstep;                       // grouped conv: N tile t reads input channels [t*gstep, t*gstep + Cin); 0 = dense
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;

@@ -31,8 +31,8 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
-template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2>
-__global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
+template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2>
+__global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
     constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
     constexpr int AG = BM / 8 / NW;     // 8-row groups of the A tile per wave
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][32 dwords = 128 B]
     const int nk = p.K / BKE;
-    const int nbuf = nk > 1 ? 2 : 1;    // a single K tile needs no second buffer: more workgroups per CU
+    const int nbuf = nk < ST ? nk : ST; // ring of ST K-tile buffers (fewer when the K loop is shorter)
     float* Bs = smem + nbuf * BM * 32;  // [nbuf][BN][32 dwords]
 
     const int tid = threadIdx.x;
@@ -101,15 +101,21 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    auto dma_tile = [&](int kt, int buf) {
-        const int k0 = kt * BKE;
-        const int tap = k0 / p.Cin;
-        const int ci0 = k0 - tap * p.Cin;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-        for (int j = 0; j < AG; j++) {
-            int hi = (a_hw[j] >> 16) - 4096 + kh;
-            int wi = (a_hw[j] & 0xffff) - 4096 + kw;
+    constexpr int PIECES = AG + BG;     // LDS-DMA instructions per wave and K tile
+    struct TileK { int k0, ci0, kh, kw; };
+    auto dma_setup = [&](int kt) {
+        TileK t;
+        t.k0 = kt * BKE;
+        const int tap = t.k0 / p.Cin;
+        t.ci0 = t.k0 - tap * p.Cin;
+        t.kh = tap / p.KW;
+        t.kw = tap - t.kh * p.KW;
+        return t;
+    };
+    auto dma_piece = [&](const TileK& t, int buf, int j) {
+        if (j < AG) {
+            int hi = (a_hw[j] >> 16) - 4096 + t.kh;
+            int wi = (a_hw[j] & 0xffff) - 4096 + t.kw;
             bool ok = a_base[j] >= 0;
             if (p.dilate > 1) {      // zero-stuffed input (data gradient of a strided conv)
                 ok = ok & (hi >= 0) & (wi >= 0);
@@ -119,19 +125,23 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
                 wi = qw;
             }
             ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
-            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j] + tile_n * p.gstep) * 2 : OOB;
+            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + t.ci0 + a_lc[j] + tile_n * p.gstep) * 2 : OOB;
             float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < BG; j++) {
-            const int off = (b_off[j] >= 0) ? (b_off[j] + k0) * 2 : OOB;
-            float* dst = Bs + buf * BN * 32 + (wave * BG + j) * 8 * 32;
+        } else {
+            const int jb = j - AG;
+            const int off = (b_off[jb] >= 0) ? (b_off[jb] + t.k0) * 2 : OOB;
+            float* dst = Bs + buf * BN * 32 + (wave * BG + jb) * 8 * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)dst, 16, off, 0, 0, 0);
         }
     };
+    auto dma_tile = [&](int kt, int buf) {
+        const TileK t = dma_setup(kt);
+#pragma unroll
+        for (int j = 0; j < PIECES; j++) dma_piece(t, buf, j);
+    };
 
-    dma_tile(0, 0);
+    if (ST == 2) dma_tile(0, 0);
 
     // residual rows (bf16, 16 B = 8 channels of one pixel per lane, the read-out mapping of the
     // epilogue), issued before the K loop so that their latency hides behind it
@@ -153,8 +163,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
                     rq[tm][it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.Cout + co);
             }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (ST == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     // Fragment reads are inline asm: a compiler-visible LDS read after `buffer_load ... lds` gets
     // an `s_waitcnt vmcnt(0)` put in front of it by the waitcnt pass (it cannot tell the two LDS
@@ -186,11 +198,19 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]) :: "memory");
     };
     static_assert(MT <= 2 && NT <= 2, "fragment readers cover 1 or 2 MFMA tiles per wave and axis");
-    int cur = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
-        const unsigned a_cur = a_lane + cur * (BM * 32 * 4);
-        const unsigned b_cur = b_lane + cur * (BN * 32 * 4);
+    // `fill_kt` >= 0: the LDS-DMA pieces of that K tile go into ring slot `fill_slot`, spread
+    // between the MFMA groups (p.il) so that their issue time overlaps MFMAs already queued in
+    // the matrix pipe, or all in front of the tile's first fragment read.
+    auto compute_tile = [&](int slot, int fill_kt, int fill_slot) {
+        const bool issue = fill_kt >= 0;
+        const bool spread = issue && p.il;
+        TileK ft = dma_setup(issue ? fill_kt : 0);
+        if (issue && !spread) {
+#pragma unroll
+            for (int j = 0; j < PIECES; j++) dma_piece(ft, fill_slot, j);
+        }
+        const unsigned a_cur = a_lane + slot * (BM * 32 * 4);
+        const unsigned b_cur = b_lane + slot * (BN * 32 * 4);
         frag_read(0, a_cur + chb[0], b_cur + chb[0]);
         frag_wait(0);
 #pragma unroll
@@ -203,11 +223,41 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
                 for (int t = 0; t < NT; t++)
                     acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, bv[sl][t]), __builtin_bit_cast(bf16x8, av[sl][tm]), acc[tm][t], 0, 0, 0);
+            if (spread) {
+#pragma unroll
+                for (int j = 0; j < PIECES; j++)
+                    if (j * (BKE / 16) / PIECES == kk) dma_piece(ft, fill_slot, j);
+            }
             if (kk + 1 < BKE / 16) frag_wait(sl ^ 1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+    };
+    if constexpr (ST == 2) {
+        int cur = 0;
+        for (int kt = 0; kt < nk; kt++) {
+            compute_tile(cur, kt + 1 < nk ? kt + 1 : -1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // ST-deep ring: tiles kt+1 .. kt+ST-2 stay in flight while tile kt is multiplied.  One
+        // counted wait (this wave's pieces of tile kt have landed) and one raw barrier (every
+        // wave's pieces have, and nobody still reads slot kt-1) per K tile; slot kt-1 is refilled
+        // with tile kt+ST-1 after the barrier.
+#pragma unroll
+        for (int t = 0; t < ST - 1; t++)
+            if (t < nk) dma_tile(t, t);
+        int slot = 0;
+        for (int kt = 0; kt < nk; kt++) {
+            if (nk - 1 - kt >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            int fill = slot + ST - 1;
+            if (fill >= ST) fill -= ST;
+            compute_tile(slot, kt + ST - 1 < nk ? kt + ST - 1 : -1, fill);
+            slot = slot + 1 == ST ? 0 : slot + 1;
+        }
+        asm volatile("s_barrier" ::: "memory");      // the epilogue slabs overwrite the ring
     }
 
     // ---- epilogue.  The MFMA ran as D^T = W A^T, so lane l holds pixel m = l&31 and, per
@@ -301,40 +351,44 @@ __global__ __launch_bounds__(64 * WM * WNW, (WM * WNW == 4 || MT == 1) ? 2 : 1) 
     }
 }
 
-template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2>
+template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2>
 int launch(const ConvParams& p, hipStream_t s) {
-    const size_t lds_full = (size_t)2 * (32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
+    const size_t lds_stage = (size_t)(32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
+    const size_t lds_full = ST * lds_stage;
     const size_t lds_epi = (size_t)WNW * WM * 32 * (32 * NT + 4) * sizeof(float);
-    const size_t lds_k = p.K / BKE > 1 ? lds_full : lds_full / 2;      // operand buffers (one if a single K tile)
+    const int nk = p.K / BKE;
+    const size_t lds_k = (nk < ST ? nk : ST) * lds_stage;              // operand ring (shorter for a short K loop)
     const size_t lds = lds_k > lds_epi ? lds_k : lds_epi;               // the epilogue slabs reuse the same space
     static bool attr_done = false;
     if (!attr_done) {
         const size_t lds_max = lds_full > lds_epi ? lds_full : lds_epi;
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW>), dim3(p.tiles_m * p.tiles_n),
+    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST>), dim3(p.tiles_m * p.tiles_n),
                        dim3(64 * WM * WNW), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
-template <int MT, int NT, int WM = 2, int WNW = 2>
+template <int MT, int NT, int WM = 2, int WNW = 2, int ST = 2>
 int launch2(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
     p.tiles_n = (p.Cout + 32 * NT * WNW - 1) / (32 * NT * WNW);
     if (p.out_f32)
-        return p.residual ? launch<MT, NT, true, true, WM, WNW>(p, s) : launch<MT, NT, false, true, WM, WNW>(p, s);
-    return p.residual ? launch<MT, NT, true, false, WM, WNW>(p, s) : launch<MT, NT, false, false, WM, WNW>(p, s);
+        return p.residual ? launch<MT, NT, true, true, WM, WNW, ST>(p, s) : launch<MT, NT, false, true, WM, WNW, ST>(p, s);
+    return p.residual ? launch<MT, NT, true, false, WM, WNW, ST>(p, s) : launch<MT, NT, false, false, WM, WNW, ST>(p, s);
 }
 
+int g_bf16_il = 0;     // tuning hook (set_tile_bf16(-1 / -2)): spread the LDS-DMA pieces between the MFMA groups
 int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 waves), 42 = 256x128 (8 waves)
 
 }  // namespace
 
 namespace brcnn_conv {
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
+    p.il = g_bf16_il;
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
     int t = g_bf16_tile;
     if (t == 0) {
@@ -349,6 +403,12 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         else if (p.M >= 16384) t = 81;
         else t = 21;
     }
+    if (t == 342 && p.Cout > 64) return launch2<2, 2, 4, 2, 3>(p, s);    // 3-stage ring variants
+    if (t == 382 && p.Cout > 64) return launch2<1, 2, 4, 2, 3>(p, s);
+    if (t == 3164 && p.Cout > 64) return launch2<1, 1, 4, 4, 3>(p, s);
+    if (t == 322 && p.Cout > 64) return launch2<2, 2, 2, 2, 3>(p, s);
+    if (t == 482 && p.Cout > 64) return launch2<1, 2, 4, 2, 4>(p, s);
+    if (t == 381 || ((t == 342 || t == 382 || t == 3164 || t == 322 || t == 482) && p.Cout <= 64)) return launch2<1, 1, 4, 2, 3>(p, s);
     if (t == 42 && p.Cout > 64) return launch2<2, 2, 4>(p, s);
     if (t == 82 && p.Cout > 64) return launch2<1, 2, 4>(p, s);       // 128x128 on 8 waves of 32x64
     if (t == 164 && p.Cout > 64) return launch2<1, 1, 4, 4>(p, s);   // 128x128 on 16 waves of 32x32
@@ -361,8 +421,11 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 }  // namespace brcnn_conv
 
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
-    if (mtnt != 0 && mtnt != 11 && mtnt != 21 && mtnt != 22 && mtnt != 42 && mtnt != 82 && mtnt != 81 && mtnt != 164)
-        return BRCNN_EINVAL;
+    if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
+    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381};
+    bool found = false;
+    for (int v : ok) found |= (v == mtnt);
+    if (!found) return BRCNN_EINVAL;
     g_bf16_tile = mtnt;
     return 0;
 }

@@ -163,7 +163,12 @@ int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const fl
  * benchmarking scripts (tools/conv_bench.py). */
 int brcnn_conv_set_tile(int wm, int nt);
 
-/* Tuning hook of the bf16 kernel: 0 heuristic, 11 / 21 / 22 = 64x64 / 128x64 / 128x128 tile. */
+/* Tuning hook of the bf16 kernel: 0 heuristic; 11 / 21 / 22 = 64x64 / 128x64 / 128x128 tile on
+ * 4 waves; 81 / 82 / 164 / 42 = 128x64 / 128x128 (8 waves) / 128x128 (16 waves) / 256x128 (8
+ * waves); 381 / 382 / 3164 / 322 / 342 = the same tiles on a 3-deep LDS ring with counted
+ * vmcnt waits, 482 = 4-deep (measured slower than two double-buffered workgroups per CU:
+ * profiles/r01_notes.md).  -1 / -2: spread the LDS-DMA pieces of the next K tile between the MFMA
+ * groups / issue them in front of the tile (default). */
 int brcnn_conv_set_tile_bf16(int mtnt);
 
 /* The same convolution over `num_segments` feature maps that share one set of weights (the

@@ -22,6 +22,8 @@ shapes = [  # name, N,H,W,Cin,Cout,k,stride,pad,res
  ('s3 3x3 s2 256->256', 8,100,168,256,256,3,2,1,False),
 ]
 tiles = [int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else [11, 21, 22, 0]
+if len(sys.argv) > 2:      # 'il0' / 'il1': LDS-DMA pieces in front of / spread between the MFMA groups
+    L.brcnn_conv_set_tile_bf16(-1 if sys.argv[2] == 'il1' else -2)
 def bench(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
