@@ -127,20 +127,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
     dma_tile(m_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // Operand reads are inline asm (explicit lgkmcnt waits): a compiler-visible LDS read after a
+    // `buffer_load ... lds` gets `s_waitcnt vmcnt(0)` put in front of it, which would serialise
+    // the prefetch of the next 32 rows with this tile's MFMAs in every wave.
+    // one MFMA step consumes reduction rows (2s, 2s+1): lane half lh takes row 2s + lh
+    const unsigned y_lane = (unsigned)(size_t)(lds_ptr_t)&Ya[0][lh][wm * 32 + li];
+    const unsigned x_lane = (unsigned)(size_t)(lds_ptr_t)&Xa[0][lh][wn * 32 + li];
+    static_assert(TM == 32 && TC == 64, "read offsets below are written for 32 x 64 tiles");
+    float ya[2][8], xa[2][8];
+#define BRCNN_RD(H, S) asm volatile("ds_read_b32 %0, %2 offset:" #S "\n\tds_read_b32 %1, %3 offset:" #S \
+                                    : "=v"(ya[H][(S / 512) & 7]), "=v"(xa[H][(S / 512) & 7]) : "v"(ya_addr), "v"(xa_addr) : "memory")
+#define BRCNN_WAIT(H) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[H][0]), "+v"(ya[H][1]), "+v"(ya[H][2]), "+v"(ya[H][3]), \
+                                   "+v"(ya[H][4]), "+v"(ya[H][5]), "+v"(ya[H][6]), "+v"(ya[H][7]), "+v"(xa[H][0]), "+v"(xa[H][1]), \
+                                   "+v"(xa[H][2]), "+v"(xa[H][3]), "+v"(xa[H][4]), "+v"(xa[H][5]), "+v"(xa[H][6]), "+v"(xa[H][7]) :: "memory")
     int cur = 0;
     for (int mt = m_begin; mt < m_end; mt += TM) {
         if (mt + TM < m_end) dma_tile(mt + TM, cur ^ 1);
-        // one MFMA step consumes reduction rows (2s, 2s+1): lane half lh takes row 2s + lh
+        const unsigned ya_addr = y_lane + cur * (TM * TC * 4), xa_addr = x_lane + cur * (TM * TC * 4);
+        BRCNN_RD(0, 0); BRCNN_RD(0, 512); BRCNN_RD(0, 1024); BRCNN_RD(0, 1536);
+        BRCNN_RD(0, 2048); BRCNN_RD(0, 2560); BRCNN_RD(0, 3072); BRCNN_RD(0, 3584);
+        BRCNN_WAIT(0);
+        BRCNN_RD(1, 4096); BRCNN_RD(1, 4608); BRCNN_RD(1, 5120); BRCNN_RD(1, 5632);
+        BRCNN_RD(1, 6144); BRCNN_RD(1, 6656); BRCNN_RD(1, 7168); BRCNN_RD(1, 7680);
 #pragma unroll
-        for (int s = 0; s < TM / 2; s++) {
-            const int row = 2 * s + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ya[cur][row][wm * 32 + li], Xa[cur][row][wn * 32 + li],
-                                                       acc, 0, 0, 0);
-        }
+        for (int s = 0; s < 8; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[0][s], xa[0][s], acc, 0, 0, 0);
+        BRCNN_WAIT(1);
+#pragma unroll
+        for (int s = 0; s < 8; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[1][s], xa[1][s], acc, 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
+#undef BRCNN_RD
+#undef BRCNN_WAIT
 
     // D[row = co][col = k]:  col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int kk = k0 + wn * 32 + li;

@@ -136,23 +136,57 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
     };
     (void)y_col; (void)x_ci; (void)x_kh; (void)x_kw; (void)y_ok; (void)x_ok;
 
-    // transposing read of one 8-element fragment: 32 columns starting at tile-local column
-    // `col0`, reduction rows ks*16 + 8*lh + (0..7)
+    // Transposing read of one 8-element fragment: 32 columns starting at tile-local column
+    // `col0`, reduction rows ks*16 + 8*lh + (0..7), as two `ds_read_b64_tr_b16` (rows +0..3 and
+    // +4..7).  The reads are inline asm with explicit lgkmcnt waits: a compiler-visible LDS read
+    // after `buffer_load ... lds` gets `s_waitcnt vmcnt(0)` put in front of it, which would
+    // serialise the prefetch of the next 64 rows with this tile's MFMAs in every wave.
+    // Per lane the address of (operand, MFMA tile, half) is loop invariant up to the buffer
+    // offset; the ks step is an immediate (16 rows x 128 B).
     const int g = lane >> 4, t = lane & 15;
-    auto frag = [&](const unsigned short* base, int col0, int ks) -> bf16x8 {
+    auto frag_addr = [&](const unsigned short* base, int col0, int q) -> unsigned {
         const int col = col0 + 16 * (g & 1) + 4 * (t & 3);      // tile-local column of this lane's piece
-        const unsigned short* blk = base + (col >> 6) * BLK;
         const int cc = col & 63;
-        s16x4 v[2];
+        const int row = 8 * (g >> 1) + 4 * q + (t >> 2);
+        const int off = (col >> 6) * BLK + row * 64 + (((cc >> 3) ^ ((row >> 1) & 7)) << 3) + (cc & 4);
+        return (unsigned)(size_t)(lds_ptr_t)(base + off);
+    };
+    unsigned ya_addr[WT][2], xa_addr[WT][2];
+#pragma unroll
+    for (int a = 0; a < WT; a++)
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const int row = ks * 16 + 8 * (g >> 1) + 4 * q + (t >> 2);
-            const int off = row * 64 + (((cc >> 3) ^ ((row >> 1) & 7)) << 3) + (cc & 4);
-            v[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(blk + off));
+            ya_addr[a][q] = frag_addr(Ya, (wm * WT + a) * 32, q);
+            xa_addr[a][q] = frag_addr(Xa, (wn * WT + a) * 32, q);
         }
+    s16x4 fy[2][WT][2], fx[2][WT][2];       // [register slot][MFMA tile][half]
+    auto tr_read = [&](s16x4& d, unsigned addr, int ks) {
+        if (ks == 0) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(addr) : "memory");
+        else if (ks == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(d) : "v"(addr) : "memory");
+        else if (ks == 2) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(d) : "v"(addr) : "memory");
+        else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(d) : "v"(addr) : "memory");
+    };
+    static_assert(TM == 64 && (WT == 1 || WT == 2), "fragment readers: 4 ks steps, 1 or 2 MFMA tiles per wave and axis");
+    auto frag_read = [&](int slot, int ks, unsigned boff) {
+#pragma unroll
+        for (int a = 0; a < WT; a++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                tr_read(fy[slot][a][q], ya_addr[a][q] + boff, ks);
+                tr_read(fx[slot][a][q], xa_addr[a][q] + boff, ks);
+            }
+    };
+    auto frag_wait = [&](int slot) {
+        if constexpr (WT == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fy[slot][0][0]), "+v"(fy[slot][0][1]), "+v"(fy[slot][1][0]), "+v"(fy[slot][1][1]),
+                         "+v"(fx[slot][0][0]), "+v"(fx[slot][0][1]), "+v"(fx[slot][1][0]), "+v"(fx[slot][1][1]) :: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fy[slot][0][0]), "+v"(fy[slot][0][1]), "+v"(fx[slot][0][0]), "+v"(fx[slot][0][1]) :: "memory");
+    };
+    auto pack = [&](const s16x4& lo, const s16x4& hi) -> bf16x8 {
         union { s16x4 h[2]; bf16x8 f; } u;
-        u.h[0] = v[0];
-        u.h[1] = v[1];
+        u.h[0] = lo;
+        u.h[1] = hi;
         return u.f;
     };
 
@@ -162,20 +196,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
     int cur = 0;
     for (int mt = m_begin; mt < m_end; mt += TM) {
         if (mt + TM < m_end) dma_tile(mt + TM, cur ^ 1);
-        const unsigned short* ya = Ya + cur * WT * BLK;
-        const unsigned short* xa = Xa + cur * WT * BLK;
+        const unsigned boff = cur * (WT * BLK * 2);
+        frag_read(0, 0, boff);
+        frag_wait(0);
 #pragma unroll
         for (int ks = 0; ks < TM / 16; ks++) {
-            bf16x8 af[WT], bfr[WT];
-#pragma unroll
-            for (int a = 0; a < WT; a++) af[a] = frag(ya, (wm * WT + a) * 32, ks);
-#pragma unroll
-            for (int c = 0; c < WT; c++) bfr[c] = frag(xa, (wn * WT + c) * 32, ks);
+            const int sl = ks & 1;
+            if (ks + 1 < TM / 16) frag_read(sl ^ 1, ks + 1, boff);
 #pragma unroll
             for (int a = 0; a < WT; a++)
 #pragma unroll
                 for (int c = 0; c < WT; c++)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack(fy[sl][a][0], fy[sl][a][1]),
+                                                                        pack(fx[sl][c][0], fx[sl][c][1]), acc[a][c], 0, 0, 0);
+            if (ks + 1 < TM / 16) frag_wait(sl ^ 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
