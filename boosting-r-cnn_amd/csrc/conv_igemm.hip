@@ -383,10 +383,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 
     dma_tile(0, 0);
 
-    // residual prefetch (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // residual tile (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): fetched at
+    // the top of the LAST K tile -- no LDS-DMA is in flight any more, so nothing has to wait for
+    // it before the epilogue, and its latency hides under that tile's MFMAs
     const float* __restrict__ res = p.residual;
     float rv[MT][NT][16];
-    if (RES) {
+    auto load_residual = [&]() {
 #pragma unroll
         for (int tn = 0; tn < NT; tn++) {
             const int co = n0 + wn * 32 * NT + tn * 32 + li;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
                 }
             }
         }
-    }
+    };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -436,9 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
         else
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]) :: "memory");
     };
-    int cur = 0;
-    for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
+    auto compute_tile = [&](int cur) {
         const unsigned a_cur = a_lane + cur * (BM * 32 * 4);
         const unsigned b_cur = b_lane + cur * (BN * 32 * 4);
         frag_read(0, a_cur + chb[0], b_cur + chb[0]);
@@ -457,10 +457,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
                                                                           acc[tm][t], 0, 0, 0);
             if (kk + 1 < BK / 8) frag_wait(sl ^ 1);
         }
+    };
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; kt++) {
+        dma_tile(kt + 1, cur ^ 1);
+        compute_tile(cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
+    // last K tile: no prefetch, no barrier (nothing in LDS is read afterwards)
+    if (RES) load_residual();
+    compute_tile(cur);
 
     float* __restrict__ yout = p.y;
 #pragma unroll
