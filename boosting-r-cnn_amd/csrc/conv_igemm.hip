@@ -351,11 +351,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 
     const int nk = (p.K + BK - 1) / BK;
 
+    // K tiles are staged in order, so the filter tap (kh, kw) and the channel offset of the next
+    // tile are carried as scalar state instead of being re-derived by two integer divisions
+    int d_k0 = 0, d_ci0 = 0, d_kh = 0, d_kw = 0;
     auto dma_tile = [&](int kt, int buf) {
-        const int k0 = kt * BK;
-        const int tap = k0 / p.Cin;
-        const int ci0 = k0 - tap * p.Cin;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        (void)kt;
+        const int k0 = d_k0, ci0 = d_ci0, kh = d_kh, kw = d_kw;
+        d_k0 += BK;
+        d_ci0 += BK;
+        if (d_ci0 >= p.Cin) {
+            d_ci0 = 0;
+            if (++d_kw == p.KW) { d_kw = 0; d_kh++; }
+        }
 #pragma unroll
         for (int j = 0; j < AG; j++) {
             int hi = (a_hw[j] >> 16) - 4096 + kh;
@@ -438,11 +445,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
         else
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]) :: "memory");
     };
-    auto compute_tile = [&](int cur) {
+    auto compute_tile = [&](int cur, bool prefetch) {
         const unsigned a_cur = a_lane + cur * (BM * 32 * 4);
         const unsigned b_cur = b_lane + cur * (BN * 32 * 4);
+        __builtin_amdgcn_s_setprio(1);
         frag_read(0, a_cur + chb[0], b_cur + chb[0]);
+        if (prefetch) dma_tile(0, cur ^ 1);      // issued under the latency of the first fragment read
         frag_wait(0);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; kk++) {
             const int sl = kk & 1;
@@ -460,15 +470,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     };
     int cur = 0;
     for (int kt = 0; kt + 1 < nk; kt++) {
-        dma_tile(kt + 1, cur ^ 1);
-        compute_tile(cur);
+        compute_tile(cur, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
     // last K tile: no prefetch, no barrier (nothing in LDS is read afterwards)
     if (RES) load_residual();
-    compute_tile(cur);
+    compute_tile(cur, false);
 
     float* __restrict__ yout = p.y;
 #pragma unroll

@@ -103,13 +103,18 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && (WM * WNW == 4 || MT == 
 
     constexpr int PIECES = AG + BG;     // LDS-DMA instructions per wave and K tile
     struct TileK { int k0, ci0, kh, kw; };
+    // K tiles are staged in order: the filter tap and channel offset of the next tile are carried
+    // as scalar state instead of being re-derived by two integer divisions per tile
+    TileK d_next = {0, 0, 0, 0};
     auto dma_setup = [&](int kt) {
-        TileK t;
-        t.k0 = kt * BKE;
-        const int tap = t.k0 / p.Cin;
-        t.ci0 = t.k0 - tap * p.Cin;
-        t.kh = tap / p.KW;
-        t.kw = tap - t.kh * p.KW;
+        (void)kt;
+        const TileK t = d_next;
+        d_next.k0 += BKE;
+        d_next.ci0 += BKE;
+        if (d_next.ci0 >= p.Cin) {
+            d_next.ci0 = 0;
+            if (++d_next.kw == p.KW) { d_next.kw = 0; d_next.kh++; }
+        }
         return t;
     };
     auto dma_piece = [&](const TileK& t, int buf, int j) {
@@ -204,15 +209,18 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && (WM * WNW == 4 || MT == 
     auto compute_tile = [&](int slot, int fill_kt, int fill_slot) {
         const bool issue = fill_kt >= 0;
         const bool spread = issue && p.il;
-        TileK ft = dma_setup(issue ? fill_kt : 0);
-        if (issue && !spread) {
+        TileK ft = {0, 0, 0, 0};
+        if (issue) ft = dma_setup(fill_kt);
+        const unsigned a_cur = a_lane + slot * (BM * 32 * 4);
+        const unsigned b_cur = b_lane + slot * (BN * 32 * 4);
+        __builtin_amdgcn_s_setprio(1);       // the prefetch issue wins over other waves' MFMA streams
+        frag_read(0, a_cur + chb[0], b_cur + chb[0]);
+        if (issue && !spread) {              // under the latency of the first fragment read
 #pragma unroll
             for (int j = 0; j < PIECES; j++) dma_piece(ft, fill_slot, j);
         }
-        const unsigned a_cur = a_lane + slot * (BM * 32 * 4);
-        const unsigned b_cur = b_lane + slot * (BN * 32 * 4);
-        frag_read(0, a_cur + chb[0], b_cur + chb[0]);
         frag_wait(0);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < BKE / 16; kk++) {
             const int sl = kk & 1;
