@@ -390,22 +390,39 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 
     dma_tile(0, 0);
 
-    // residual tile (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): fetched at
-    // the top of the LAST K tile -- no LDS-DMA is in flight any more, so nothing has to wait for
-    // it before the epilogue, and its latency hides under that tile's MFMAs
+    // residual tile, fetched at the top of the LAST K tile -- no LDS-DMA is in flight any more, so
+    // nothing has to wait for it before the epilogue, and its latency hides under that tile's
+    // MFMAs.  Channel counts that are multiples of 4 use the row mapping of the vectorised
+    // epilogue (lane -> row it*8 + lane/8, 4 channels at 4*(lane%8): one 16-byte load per 4
+    // values); ragged counts (fused heads) the accumulator (D) layout col = lane&31,
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const float* __restrict__ res = p.residual;
+    const bool vec = (p.Cout & 3) == 0;
+    const int vrow = lane >> 3, vcol = (lane & 7) * 4;
     float rv[MT][NT][16];
     auto load_residual = [&]() {
 #pragma unroll
         for (int tn = 0; tn < NT; tn++) {
-            const int co = n0 + wn * 32 * NT + tn * 32 + li;
 #pragma unroll
             for (int tm = 0; tm < MT; tm++) {
-                const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
+                if (vec) {
+                    const int co = n0 + wn * 32 * NT + tn * 32 + vcol;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    rv[tm][tn][r] = (co < p.Cout && m < p.M) ? res[(size_t)m * p.Cout + co] : 0.f;
+                    for (int it = 0; it < 4; it++) {
+                        const int m = m0 + wm * 32 * MT + tm * 32 + it * 8 + vrow;
+                        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (co < p.Cout && m < p.M) q = *reinterpret_cast<const float4*>(res + (size_t)m * p.Cout + co);
+                        rv[tm][tn][4 * it + 0] = q.x; rv[tm][tn][4 * it + 1] = q.y;
+                        rv[tm][tn][4 * it + 2] = q.z; rv[tm][tn][4 * it + 3] = q.w;
+                    }
+                } else {
+                    const int co = n0 + wn * 32 * NT + tn * 32 + li;
+                    const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        rv[tm][tn][r] = (co < p.Cout && m < p.M) ? res[(size_t)m * p.Cout + co] : 0.f;
+                    }
                 }
             }
         }
@@ -479,7 +496,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     if (RES) load_residual();
     compute_tile(cur, false);
 
+    // ---- epilogue.  Scale / shift in the accumulator layout; for channel counts that are
+    // multiples of 4 each wave then transposes one 32x32 tile at a time through a private 4 KiB
+    // slab of the idle operand buffer (the one the last K tile did not read), so that residual
+    // loads and result stores are 16-byte pieces of NHWC rows: 4 wide stores per tile instead
+    // of 16 scalar ones (the store tail is issue bound).
     float* __restrict__ yout = p.y;
+    float* slab = (wave < 2 ? As + (cur ^ 1) * BM * 32 : Bs + (cur ^ 1) * BN * 32) + (wave & 1) * 1024;
 #pragma unroll
     for (int tn = 0; tn < NT; tn++) {
         const int co = n0 + wn * 32 * NT + tn * 32 + li;
@@ -488,16 +511,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
         const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < MT; tm++) {
-            const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
+            if (vec) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = acc[tm][tn][r];
-                if (p.scale) v = v * sc;
-                v = v + sh;
-                if (RES) v = v + rv[tm][tn][r];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (cok && m < p.M) yout[(size_t)m * p.Cout + co] = v;
+                for (int r = 0; r < 16; r++) {
+                    float v = acc[tm][tn][r];
+                    if (p.scale) v = v * sc;
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = v + sh;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int cv = n0 + wn * 32 * NT + tn * 32 + vcol;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int row = it * 8 + vrow;
+                    const int m = m0 + wm * 32 * MT + tm * 32 + row;
+                    float4 v = *reinterpret_cast<const float4*>(slab + row * 32 + vcol);
+                    if (RES) {
+                        v.x += rv[tm][tn][4 * it + 0]; v.y += rv[tm][tn][4 * it + 1];
+                        v.z += rv[tm][tn][4 * it + 2]; v.w += rv[tm][tn][4 * it + 3];
+                    }
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (cv < p.Cout && m < p.M) *reinterpret_cast<float4*>(yout + (size_t)m * p.Cout + cv) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                const int mb = m0 + wm * 32 * MT + tm * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    float v = acc[tm][tn][r];
+                    if (p.scale) v = v * sc;
+                    v = v + sh;
+                    if (RES) v = v + rv[tm][tn][r];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (cok && m < p.M) yout[(size_t)m * p.Cout + co] = v;
+                }
             }
         }
     }
