@@ -220,6 +220,19 @@ def const_like(values, like):
     return t
 
 
+def const_rows(rows, like):
+    """(R, C) constant tensor (per-image host metadata: image shapes, scale factors) on `like`'s
+    device / dtype, uploaded once per distinct value set -- keeps the device-resident test path
+    free of H2D copies so that it can be captured in a HIP graph"""
+    key = ('rows', tuple(tuple(float(v) for v in r) for r in rows), str(like.device), like.dtype)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 256:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = like.new_tensor([list(map(float, r)) for r in rows])
+    return t
+
+
 # ----------------------------------------------------------------------------- coder
 def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     assert proposals.size() == gt.size()
@@ -277,7 +290,7 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     if clip_border and max_shape is not None:
         if not isinstance(max_shape, torch.Tensor):
             flat = all(not isinstance(v, (list, tuple, np.ndarray)) for v in max_shape)
-            max_shape = const_like(max_shape, x1) if flat else x1.new_tensor(max_shape)
+            max_shape = const_like(max_shape, x1) if flat else const_rows(max_shape, x1)
         max_shape = max_shape[..., :2].type_as(x1)
         if max_shape.ndim == 2:
             assert bboxes.ndim == 3

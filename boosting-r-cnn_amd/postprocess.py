@@ -38,7 +38,7 @@ def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offse
     in_range = torch.arange(T, device=device)[None, :] < cnt[:, None]
     lowest = torch.finfo(c_boxes.dtype).min
     max_coord = torch.where(in_range[..., None], c_boxes, c_boxes.new_full((), lowest)).amax((1, 2))
-    offs = c_ids.to(c_boxes) * (max_coord + torch.tensor(1).to(c_boxes))[:, None]
+    offs = c_ids.to(c_boxes) * (max_coord + 1)[:, None]
     boxes_for_nms = c_boxes + offs[..., None]
     seg_begin = (torch.arange(B, device=device) * T).to(torch.int32)
     ranges = torch.stack([seg_begin, seg_begin + cnt.to(torch.int32)], 1)
@@ -83,7 +83,7 @@ def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_thre
     in_range = pos < cnt[:, None]
     lowest = torch.finfo(c_boxes.dtype).min
     max_coord = torch.where(in_range[..., None], c_boxes, c_boxes.new_full((), lowest)).amax((1, 2))
-    offs = c_ids.to(c_boxes) * (max_coord + torch.tensor(1).to(c_boxes))[:, None]
+    offs = c_ids.to(c_boxes) * (max_coord + 1)[:, None]
     boxes_for_nms = c_boxes + offs[..., None]
     # per-(image, level) survivor counts of the validity filter -> contiguous segments
     bounds = [0]

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .blocks import PackedCache, to_nhwc
-from .core import bbox2result, bbox2roi, bbox_overlaps, multi_apply, multiclass_nms
+from .core import bbox2result, bbox2roi, bbox_overlaps, const_rows, multi_apply, multiclass_nms
 from .losses import SmoothL1Loss, accuracy
 from .postprocess import batched_nms_images
 from .registry import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head,
@@ -572,13 +572,11 @@ class ProbRoIHead(nn.Module):
         cls_score, bbox_pred = head.forward_nhwc(roi_feats)
         scores = self.fuse_scores(cls_score, prior).view(B, K, C + 1)
         # per-image clip border / rescale (image shapes are host metadata)
-        max_shape = torch.tensor([m['img_shape'][:2] for m in img_metas], dtype=dets.dtype,
-                                 device=device)
+        max_shape = const_rows([m['img_shape'][:2] for m in img_metas], dets)
         bboxes = head.bbox_coder.decode(rois[:, 1:].view(B, K, 4), bbox_pred.view(B, K, 4 * C),
                                         max_shape=max_shape)
         if rescale:
-            sf = torch.tensor([list(m['scale_factor']) for m in img_metas], dtype=dets.dtype,
-                              device=device)
+            sf = const_rows([list(m['scale_factor']) for m in img_metas], dets)
             bboxes = (bboxes.view(B, K, C, 4) / sf.view(B, 1, 1, 4)).view(B, K, 4 * C)
         row_ok = torch.arange(K, device=device)[None, :] < num[:, None]
         s = scores[..., :C]
