@@ -32,7 +32,7 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
 template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2>
-__global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
     constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
     constexpr int AG = BM / 8 / NW;     // 8-row groups of the A tile per wave
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && (WM * WNW == 4 || MT == 
     const bool vec_ok = (p.Cout & 7) == 0;
     const int rl = lane / LPR, cl = (lane % LPR) * 8;
     const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(p.residual);
+    static_assert(!RES || MT * (32 / RPI) <= 16, "residual prefetch registers: use the non-residual form for 4x4 register tiles");
     uint4 rq[MT][32 / RPI];
     if (RES) {
 #pragma unroll
@@ -184,25 +185,28 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && (WM * WNW == 4 || MT == 
     const unsigned a_lane = (unsigned)(size_t)(lds_ptr_t)(As + (wm * 32 * MT + li) * 32);
     const unsigned b_lane = (unsigned)(size_t)(lds_ptr_t)(Bs + (wn * 32 * NT + li) * 32);
     f32x4 av[2][MT], bv[2][NT];
+    auto lds_read = [&](f32x4& d, unsigned addr, int t) {      // t-th 32-row MFMA tile: +4096 B
+        if (t == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory");
+        else if (t == 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(d) : "v"(addr) : "memory");
+        else if (t == 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(d) : "v"(addr) : "memory");
+        else asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(d) : "v"(addr) : "memory");
+    };
     auto frag_read = [&](int slot, unsigned a_addr, unsigned b_addr) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(av[slot][0]) : "v"(a_addr) : "memory");
-        if constexpr (MT == 2)
-            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(av[slot][1]) : "v"(a_addr) : "memory");
-        asm volatile("ds_read_b128 %0, %1" : "=v"(bv[slot][0]) : "v"(b_addr) : "memory");
-        if constexpr (NT == 2)
-            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bv[slot][1]) : "v"(b_addr) : "memory");
+#pragma unroll
+        for (int t = 0; t < MT; t++) lds_read(av[slot][t], a_addr, t);
+#pragma unroll
+        for (int t = 0; t < NT; t++) lds_read(bv[slot][t], b_addr, t);
     };
+    // the wait, then one empty asm per fragment register: volatile asms keep their order, so every
+    // use of a fragment is placed after the wait
     auto frag_wait = [&](int slot) {
-        if constexpr (MT == 2 && NT == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1]), "+v"(bv[slot][0]), "+v"(bv[slot][1]) :: "memory");
-        else if constexpr (MT == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1]), "+v"(bv[slot][0]) :: "memory");
-        else if constexpr (NT == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]), "+v"(bv[slot][1]) :: "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[slot][0]), "+v"(bv[slot][0]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < MT; t++) asm volatile("" : "+v"(av[slot][t]));
+#pragma unroll
+        for (int t = 0; t < NT; t++) asm volatile("" : "+v"(bv[slot][t]));
     };
-    static_assert(MT <= 2 && NT <= 2, "fragment readers cover 1 or 2 MFMA tiles per wave and axis");
+    static_assert(MT <= 4 && NT <= 4, "fragment readers cover up to 4 MFMA tiles per wave and axis");
     // `fill_kt` >= 0: the LDS-DMA pieces of that K tile go into ring slot `fill_slot`, spread
     // between the MFMA groups (p.il) so that their issue time overlaps MFMAs already queued in
     // the matrix pipe, or all in front of the tile's first fragment read.
@@ -384,9 +388,13 @@ template <int MT, int NT, int WM = 2, int WNW = 2, int ST = 2>
 int launch2(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
     p.tiles_n = (p.Cout + 32 * NT * WNW - 1) / (32 * NT * WNW);
-    if (p.out_f32)
-        return p.residual ? launch<MT, NT, true, true, WM, WNW, ST>(p, s) : launch<MT, NT, false, true, WM, WNW, ST>(p, s);
-    return p.residual ? launch<MT, NT, true, false, WM, WNW, ST>(p, s) : launch<MT, NT, false, false, WM, WNW, ST>(p, s);
+    if constexpr (MT * NT > 4) {        // large register tiles: bf16 output, no residual operand (callers check)
+        return launch<MT, NT, false, false, WM, WNW, ST>(p, s);
+    } else {
+        if (p.out_f32)
+            return p.residual ? launch<MT, NT, true, true, WM, WNW, ST>(p, s) : launch<MT, NT, false, true, WM, WNW, ST>(p, s);
+        return p.residual ? launch<MT, NT, true, false, WM, WNW, ST>(p, s) : launch<MT, NT, false, false, WM, WNW, ST>(p, s);
+    }
 }
 
 int g_bf16_il = 0;     // tuning hook (set_tile_bf16(-1 / -2)): spread the LDS-DMA pieces between the MFMA groups
