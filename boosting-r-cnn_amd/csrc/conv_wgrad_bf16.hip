@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
             int n = 0, hi0 = 0, wi0 = 0, H = 0, W = 0, xb = 0;
             if (m_ok) {
                 int sg = 0;
+                if (p.nseg > 1) {       // single-map layers keep the geometry in scalar registers
 #pragma unroll
-                for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                    for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
                     if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+                }
                 const int ml = m - p.seg_m0[sg];
                 const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg];
                 H = p.seg_H[sg]; W = p.seg_W[sg];
