@@ -32,6 +32,7 @@ struct WgradParams {
     unsigned dy_bytes, x_bytes;
     int pitch;      // floats between adjacent input pixels (== Cin unless grouped)
     int gstep;      // grouped conv: co tile t reads input channels [t*gstep, t*gstep + Cin); 0 = dense
+    int direct;     // 1x1 / stride 1 / pad 0: input pixel index == output row index, no decode at all
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
     int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
@@ -49,6 +50,7 @@ __device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned magic, unsigned
 // 64 x 64 output tile, 4 waves x one 32x32 MFMA tile; both operand tiles ([32 m][64 cols] fp32,
 // 256-byte rows) are staged by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no
 // ds_write pass), double buffered, one `vmcnt(0)` + barrier per 32 reduction rows.
+template <bool DIRECT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) float Ya[2][TM][TC];   // dY tile  [m][co]
     __shared__ __attribute__((aligned(16))) float Xa[2][TM][TC];   // im2col tile [m][k]
@@ -95,6 +97,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
+    // Row -> input pixel decode.  A lane stages the same two tile rows of every tile, i.e. output
+    // pixels m, m+32, m+64, ...: the decode (two divisions, a segment search) runs once per lane
+    // and map, afterwards (ho, wo) and the offset of the input row advance incrementally -- one
+    // conditional wrap per step when the map is at least 32 wide; narrower maps and the first row
+    // after a map boundary take the full decode again.
+    int s_ho[2], s_wo[2], s_rb[2], s_H[2], s_W[2], s_Ho[2], s_Wo[2], s_end[2] = {0, 0};
+    auto decode = [&](int m, int j) {
+        int sg = 0;
+        if (p.nseg > 1) {       // single-map layers keep the geometry in scalar registers
+#pragma unroll
+            for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+        }
+        const int ml = m - p.seg_m0[sg];
+        const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg], H = p.seg_H[sg], W = p.seg_W[sg];
+        const int n = (int)fastdiv((unsigned)ml, p.seg_mhw[sg], p.seg_shw[sg]);
+        const int rem = ml - n * (Ho * Wo);
+        const int ho = (int)fastdiv((unsigned)rem, p.seg_mw[sg], p.seg_sw[sg]);
+        s_ho[j] = ho;
+        s_wo[j] = rem - ho * Wo;
+        s_H[j] = H; s_W[j] = W; s_Ho[j] = Ho; s_Wo[j] = Wo;
+        s_rb[j] = (int)p.seg_xoff[sg] + (n * H + ho * p.stride) * W * p.pitch;
+        s_end[j] = p.seg_m0[sg + 1];
+    };
     auto dma_tile = [&](int mt, int buf) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -103,22 +129,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
             int offy = OOB, offx = OOB;
             if (m < m_end) {
                 if (co_ok) offy = (m * p.Cout + co) * 4;
-                if (k_ok) {
-                    int sg = 0;
-                    if (p.nseg > 1) {       // single-map layers keep the geometry in scalar registers
-#pragma unroll
-                        for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
-                            if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+                if (k_ok && DIRECT) {
+                    offx = (m * p.pitch + ci + tco * p.gstep) * 4;
+                } else if (k_ok) {
+                    if (m >= s_end[j] || s_Wo[j] < TM) {
+                        decode(m, j);
+                    } else {                    // same map, 32 output pixels further
+                        int wo = s_wo[j] + TM;
+                        if (wo >= s_Wo[j]) {
+                            wo -= s_Wo[j];
+                            int ho = s_ho[j] + 1;
+                            int rb = s_rb[j] + p.stride * s_W[j] * p.pitch;
+                            if (ho == s_Ho[j]) {    // next image of the map
+                                ho = 0;
+                                rb += (s_H[j] - s_Ho[j] * p.stride) * s_W[j] * p.pitch;
+                            }
+                            s_ho[j] = ho;
+                            s_rb[j] = rb;
+                        }
+                        s_wo[j] = wo;
                     }
-                    const int ml = m - p.seg_m0[sg];
-                    const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg], H = p.seg_H[sg], W = p.seg_W[sg];
-                    const int n = (int)fastdiv((unsigned)ml, p.seg_mhw[sg], p.seg_shw[sg]);
-                    const int rem = ml - n * (Ho * Wo);
-                    const int ho = (int)fastdiv((unsigned)rem, p.seg_mw[sg], p.seg_sw[sg]);
-                    const int wo = rem - ho * Wo;
-                    const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-                    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                        offx = ((int)p.seg_xoff[sg] + ((n * H + hi) * W + wi) * p.pitch + ci + tco * p.gstep) * 4;
+                    const int hi = s_ho[j] * p.stride - p.pad + kh, wi = s_wo[j] * p.stride - p.pad + kw;
+                    if ((unsigned)hi < (unsigned)s_H[j] && (unsigned)wi < (unsigned)s_W[j])
+                        offx = (s_rb[j] + ((kh - p.pad) * s_W[j] + wi) * p.pitch + ci + tco * p.gstep) * 4;
                 }
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)&Ya[buf][(wave * 2 + j) * 4][0], 16, offy, 0, 0, 0);
@@ -209,6 +242,7 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
     p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
     p.pitch = cin; p.gstep = 0;
     p.nseg = num_segments;
+    p.direct = (kh == 1 && kw == 1 && stride == 1 && pad == 0);
     long long m_total = 0, x_off = 0;
     for (int s = 0; s < num_segments; s++) {
         const int H = heights_host[s], W = widths_host[s];
@@ -240,8 +274,8 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
     rps = (rps + TM - 1) / TM * TM;
     p.slices = (p.M + rps - 1) / rps;
     p.rows_per_slice = rps;
-    hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3(tiles * p.slices), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    if (p.direct) hipLaunchKernelGGL(conv_wgrad_f32_kernel<true>, dim3(tiles * p.slices), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_f32_kernel<false>, dim3(tiles * p.slices), dim3(256), 0, (hipStream_t)stream, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -265,6 +299,7 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_grouped(const void* x, const void* dy, voi
     p.dy = (const float*)dy; p.x = (const float*)x; p.dw = (float*)dw_tiles;
     p.Cin = window; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
     p.pitch = cin; p.gstep = window; p.nseg = 1;
+    p.direct = (kh == 1 && kw == 1 && stride == 1 && pad == 0);
     p.seg_H[0] = height; p.seg_W[0] = width; p.seg_Ho[0] = Ho; p.seg_Wo[0] = Wo;
     p.seg_m0[0] = 0; p.seg_xoff[0] = 0;
     magic_for((unsigned)(Ho * Wo), &p.seg_mhw[0], &p.seg_shw[0]);
@@ -287,7 +322,8 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_grouped(const void* x, const void* dy, voi
     rps = (rps + TM - 1) / TM * TM;
     p.slices = (p.M + rps - 1) / rps;
     p.rows_per_slice = rps;
-    hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3(tiles * p.slices), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.direct) hipLaunchKernelGGL(conv_wgrad_f32_kernel<true>, dim3(tiles * p.slices), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_f32_kernel<false>, dim3(tiles * p.slices), dim3(256), 0, (hipStream_t)stream, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
