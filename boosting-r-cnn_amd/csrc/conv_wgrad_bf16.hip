@@ -78,8 +78,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
 
     // DMA: one wave instruction fills 8 rows x 128 B of one block; wave w owns row groups 2w, 2w+1
     const int rg_row = lane >> 3, pc = lane & 7;
-    int y_col[WT], x_ci[WT], x_kh[WT], x_kw[WT];
-    bool y_ok[WT], x_ok[WT];
 
     f32x16 acc[WT][WT];
 #pragma unroll
@@ -89,45 +87,83 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
 
+    // A lane stages the same two rows of every tile and, per column block, the same 8 columns:
+    // the column -> (tap, channel) split is loop invariant, and the row -> input pixel decode
+    // (two divisions, a segment search) advances incrementally from tile to tile -- one
+    // conditional wrap per 64-row step on maps at least 64 wide; narrower maps and the first row
+    // after a map boundary take the full decode.
+    int c_yoff[2][WT], c_xoff[2][WT], c_kh[2][WT], c_kw[2][WT];     // -1: column out of range
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = (wave * 2 + j) * 8 + rg_row;
+        const int lc = (pc ^ ((row >> 1) & 7)) * 8;              // logical column of this lane's chunk
+#pragma unroll
+        for (int cb = 0; cb < WT; cb++) {
+            const int co = co0 + cb * 64 + lc;
+            c_yoff[j][cb] = co < p.Cout ? co : -1;
+            const int k = k0 + cb * 64 + lc;
+            c_xoff[j][cb] = -1;
+            c_kh[j][cb] = c_kw[j][cb] = 0;
+            if (k < p.K) {
+                const int tap = k / p.Cin;
+                c_kh[j][cb] = tap / p.KW;
+                c_kw[j][cb] = tap - c_kh[j][cb] * p.KW;
+                c_xoff[j][cb] = k - tap * p.Cin + tco * p.gstep;
+            }
+        }
+    }
+    int s_ho[2], s_wo[2], s_rb[2], s_H[2], s_W[2], s_Ho[2], s_Wo[2], s_end[2] = {0, 0};
+    auto decode = [&](int m, int j) {
+        int sg = 0;
+        if (p.nseg > 1) {       // single-map layers keep the geometry in scalar registers
+#pragma unroll
+            for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+        }
+        const int ml = m - p.seg_m0[sg];
+        const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg], H = p.seg_H[sg], W = p.seg_W[sg];
+        const int n = (int)fastdiv((unsigned)ml, p.seg_mhw[sg], p.seg_shw[sg]);
+        const int rem = ml - n * (Ho * Wo);
+        const int ho = (int)fastdiv((unsigned)rem, p.seg_mw[sg], p.seg_sw[sg]);
+        s_ho[j] = ho;
+        s_wo[j] = rem - ho * Wo;
+        s_H[j] = H; s_W[j] = W; s_Ho[j] = Ho; s_Wo[j] = Wo;
+        s_rb[j] = (int)p.seg_xoff[sg] + (n * H + ho * p.stride) * W * p.pitch;   // input row ho*stride, column 0
+        s_end[j] = p.seg_m0[sg + 1];
+    };
     auto dma_tile = [&](int mt, int buf) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int row = (wave * 2 + j) * 8 + rg_row;
-            const int lc = (pc ^ ((row >> 1) & 7)) * 8;          // logical column of this lane's chunk
-            const int m = mt + row;
+            const int m = mt + (wave * 2 + j) * 8 + rg_row;
             const bool m_ok = m < m_end;
-            int n = 0, hi0 = 0, wi0 = 0, H = 0, W = 0, xb = 0;
             if (m_ok) {
-                int sg = 0;
-                if (p.nseg > 1) {       // single-map layers keep the geometry in scalar registers
-#pragma unroll
-                    for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
-                    if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+                if (m >= s_end[j] || s_Wo[j] < TM) {
+                    decode(m, j);
+                } else {                        // same map, 64 output pixels further
+                    int wo = s_wo[j] + TM;
+                    if (wo >= s_Wo[j]) {
+                        wo -= s_Wo[j];
+                        int ho = s_ho[j] + 1;
+                        int rb = s_rb[j] + p.stride * s_W[j] * p.pitch;
+                        if (ho == s_Ho[j]) {        // next image of the map
+                            ho = 0;
+                            rb += (s_H[j] - s_Ho[j] * p.stride) * s_W[j] * p.pitch;
+                        }
+                        s_ho[j] = ho;
+                        s_rb[j] = rb;
+                    }
+                    s_wo[j] = wo;
                 }
-                const int ml = m - p.seg_m0[sg];
-                const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg];
-                H = p.seg_H[sg]; W = p.seg_W[sg];
-                n = (int)fastdiv((unsigned)ml, p.seg_mhw[sg], p.seg_shw[sg]);
-                const int rem = ml - n * (Ho * Wo);
-                const int ho = (int)fastdiv((unsigned)rem, p.seg_mw[sg], p.seg_sw[sg]);
-                const int wo = rem - ho * Wo;
-                hi0 = ho * p.stride - p.pad;
-                wi0 = wo * p.stride - p.pad;
-                xb = (int)p.seg_xoff[sg] + n * H * W * p.pitch;
             }
+            const int hi0 = s_ho[j] * p.stride - p.pad, wi0 = s_wo[j] * p.stride - p.pad;
 #pragma unroll
             for (int cb = 0; cb < WT; cb++) {
-                const int co = co0 + cb * 64 + lc;
-                const int offy = (m_ok && co < p.Cout) ? (m * p.Cout + co) * 2 : OOB;
-                const int k = k0 + cb * 64 + lc;
+                const int offy = (m_ok && c_yoff[j][cb] >= 0) ? (m * p.Cout + c_yoff[j][cb]) * 2 : OOB;
                 int offx = OOB;
-                if (m_ok && k < p.K) {
-                    const int tap = k / p.Cin;
-                    const int ci = k - tap * p.Cin;
-                    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-                    const int hi = hi0 + kh, wi = wi0 + kw;
-                    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                        offx = (xb + (hi * W + wi) * p.pitch + ci + tco * p.gstep) * 2;
+                if (m_ok && c_xoff[j][cb] >= 0) {
+                    const int hi = hi0 + c_kh[j][cb], wi = wi0 + c_kw[j][cb];
+                    if ((unsigned)hi < (unsigned)s_H[j] && (unsigned)wi < (unsigned)s_W[j])
+                        offx = (s_rb[j] + ((c_kh[j][cb] - p.pad) * s_W[j] + wi) * p.pitch + c_xoff[j][cb]) * 2;
                 }
                 unsigned short* dy_dst = Ya + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
                 unsigned short* x_dst = Xa + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
@@ -136,7 +172,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
             }
         }
     };
-    (void)y_col; (void)x_ci; (void)x_kh; (void)x_kw; (void)y_ok; (void)x_ok;
 
     // Transposing read of one 8-element fragment: 32 columns starting at tile-local column
     // `col0`, reduction rows ks*16 + 8*lh + (0..7), as two `ds_read_b64_tr_b16` (rows +0..3 and
