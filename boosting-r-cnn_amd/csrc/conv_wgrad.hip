@@ -13,6 +13,7 @@
 // "reduction-major" in memory ((M,Cout) and (M,K) rows), which is exactly the MFMA operand
 // order lane -> column: the LDS tiles are stored [m][64 columns] unpadded (conflict-free
 // ds_read_b32 of 32 consecutive columns), one read per operand per MFMA.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -207,6 +208,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(WgradParams p) {
     }
 }
 
+// M slices: about two generations of resident workgroups (measured, tools/_sweep.sh: 2560 slots,
+// >= 256 rows per slice; every extra slice adds a full tile of fp32 atomics into dW, too few leave
+// CUs idle).  BRCNN_WG_SLOTS / BRCNN_WG_MINROWS override for tuning runs.
+int wgrad_slices(int tiles, int M) {
+    static int slots = getenv("BRCNN_WG_SLOTS") ? atoi(getenv("BRCNN_WG_SLOTS")) : 2560;
+    static int minrows = getenv("BRCNN_WG_MINROWS") ? atoi(getenv("BRCNN_WG_MINROWS")) : 256;
+    int slices = slots / tiles;
+    const int max_slices = (M + minrows - 1) / minrows;
+    if (slices > max_slices) slices = max_slices;
+    return slices < 1 ? 1 : slices;
+}
+
 // q = (mulhi(x, magic) + x) >> shift == x / d for every x < 2^32 (Granlund-Montgomery, round-up
 // variant with the implicit 2^32 term)
 void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
@@ -264,10 +277,9 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
     p.x_bytes = (unsigned)(x_off * 4);
     p.tiles_co = (cout + TC - 1) / TC;
     p.tiles_k = (p.K + TC - 1) / TC;
-    // enough slices of M to fill the chip ~8x over, each at least 256 rows deep
     const int tiles = p.tiles_co * p.tiles_k;
-    int slices = (8192 + tiles - 1) / tiles;
-    const int max_slices = (p.M + 255) / 256;
+    int slices = wgrad_slices(tiles, p.M);
+    const int max_slices = p.M;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     int rps = (p.M + slices - 1) / slices;
@@ -314,8 +326,8 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_grouped(const void* x, const void* dy, voi
     p.tiles_co = cout / TC;
     p.tiles_k = (p.K + TC - 1) / TC;
     const int tiles = p.tiles_co * p.tiles_k;
-    int slices = (8192 + tiles - 1) / tiles;
-    const int max_slices = (p.M + 255) / 256;
+    int slices = wgrad_slices(tiles, p.M);
+    const int max_slices = p.M;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     int rps = (p.M + slices - 1) / slices;

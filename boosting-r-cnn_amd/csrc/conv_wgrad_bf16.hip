@@ -11,6 +11,7 @@
 // columns 4(t&3)..+3) and lane t receives column t of the 4 rows.  Two such reads give a lane the
 // 8 reduction elements of its column -- the MFMA A (co) and B (k) fragments -- with no
 // ds_write / shuffle pass.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -281,8 +282,14 @@ int launch(WgradHParams& p, hipStream_t s) {
     p.tiles_co = (p.Cout + T - 1) / T;
     p.tiles_k = (p.K + T - 1) / T;
     const int tiles = p.tiles_co * p.tiles_k;
-    int slices = (4096 + tiles - 1) / tiles;
-    const int max_slices = (p.M + 511) / 512;
+    // M slices: as many as fit ONE generation of resident workgroups (a count just above a
+    // multiple of the slot number costs a whole extra generation; every extra slice adds a full
+    // tile of fp32 atomics into dW), each at least `minrows` reduction rows deep
+    static int slots_env = getenv("BRCNN_WG_SLOTS") ? atoi(getenv("BRCNN_WG_SLOTS")) : 0;
+    static int minrows = getenv("BRCNN_WG_MINROWS") ? atoi(getenv("BRCNN_WG_MINROWS")) : 1024;
+    const int slots = slots_env ? slots_env : (WT == 2 ? 512 : 1024);
+    int slices = slots / tiles;
+    const int max_slices = (p.M + minrows - 1) / minrows;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     int rps = (p.M + slices - 1) / slices;
@@ -335,7 +342,7 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
     p.dy_bytes = (unsigned)(m_total * cout * 2);
     p.x_bytes = (unsigned)(x_off * 2);
     int wt = g_wgrad_bf16_tile;
-    if (wt == 0) wt = (cout >= 128 && p.K >= 128) ? 2 : 1;
+    if (wt == 0) wt = (cout >= 128 && p.K >= 256) ? 2 : 1;
     return wt == 2 ? launch<2>(p, stream) : launch<1>(p, stream);
 }
 

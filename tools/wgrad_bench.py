@@ -4,6 +4,7 @@ import brcnn
 from brcnn import ops, lib
 L = lib.load()
 BF = len(sys.argv) > 1 and sys.argv[1] == 'bf16'
+if len(sys.argv) > 2: L.brcnn_conv_set_tile_wgrad_bf16(int(sys.argv[2]))
 shapes = [('rpn_l0 3x3 256->256', 8,100,168,256,256,3,1,1), ('s3 3x3 256->256', 8,50,84,256,256,3,1,1),
           ('s2 1x1 128->512', 8,100,168,128,512,1,1,0), ('s3 1x1 1024->256', 8,50,84,1024,256,1,1,0),
           ('s4 3x3 512->512', 8,25,42,512,512,3,1,1), ('fc 12544->1024', 4096,1,1,12544,1024,1,1,0),
