@@ -303,7 +303,7 @@ class ATSSRPNHead(AnchorHead):
                 concat_anchor_list, concat_valid_flag_list)
 
     def loss_single(self, anchors, cls_score, bbox_pred, iou_pred, labels, label_weights,
-                    bbox_targets, num_total_samples):
+                    bbox_targets, level_pos_inds=None, num_total_samples=1.0):
         anchors = anchors.reshape(-1, 4)
         cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels).contiguous()
         bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 4)
@@ -311,7 +311,8 @@ class ATSSRPNHead(AnchorHead):
         bbox_targets = bbox_targets.reshape(-1, 4)
         labels = labels.reshape(-1)
         label_weights = label_weights.reshape(-1)
-        pos_inds = ((labels >= 0) & (labels < self.num_classes)).nonzero().squeeze(1)
+        pos_inds = level_pos_inds if level_pos_inds is not None else \
+            ((labels >= 0) & (labels < self.num_classes)).nonzero().squeeze(1)
         if len(pos_inds) > 0:
             pos_bbox_targets = bbox_targets[pos_inds]
             pos_bbox_pred = bbox_pred[pos_inds]
@@ -363,25 +364,57 @@ class ATSSRPNHead(AnchorHead):
         anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
         label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
-        targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
-                                   gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None,
-                                   label_channels=label_channels)
-        if targets is None:
+        def build_targets():
+            targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
+                                       gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None,
+                                       label_channels=label_channels)
+            if targets is None:
+                return None
+            (labels_l, label_weights_l, bbox_targets_l, _, pos_inds, _, anchors_l, _) = targets
+            lv_labels = images_to_levels(labels_l, num_level_anchors)
+            # positives per level, in the flattened (image, anchor) order loss_single uses
+            lv_pos = [((l.reshape(-1) >= 0) & (l.reshape(-1) < self.num_classes)).nonzero().squeeze(1)
+                      for l in lv_labels]
+            return (lv_labels,
+                    images_to_levels(label_weights_l, num_level_anchors),
+                    images_to_levels(anchors_l, num_level_anchors),
+                    images_to_levels(bbox_targets_l, num_level_anchors),
+                    lv_pos, sum(p.numel() for p in pos_inds))
+
+        ev = getattr(self, '_inputs_ready', None)
+        self._inputs_ready = None
+        if ev is not None and device.type == 'cuda':
+            # target assignment on the side stream opened before the backbone was queued
+            # (detectors.forward_train): its host syncs do not wait for the main stream
+            main = torch.cuda.current_stream()
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                built = build_targets()
+            main.wait_stream(side)
+            if built is not None:
+                for lst in built[:5]:
+                    for t in lst:
+                        t.record_stream(main)
+        else:
+            built = build_targets()
+        if built is None:
             return None
-        (labels_list, label_weights_list, bbox_targets_list, _, pos_inds, _, anchor_list, _) = targets
-        labels_list = images_to_levels(labels_list, num_level_anchors)
-        label_weights_list = images_to_levels(label_weights_list, num_level_anchors)
-        anchor_list = images_to_levels(anchor_list, num_level_anchors)
-        bbox_targets_list = images_to_levels(bbox_targets_list, num_level_anchors)
-        num_total_pos = sum(p.numel() for p in pos_inds)
-        num_total_samples = reduce_mean(
-            torch.tensor(num_total_pos, dtype=torch.float, device=device)).item()
-        num_total_samples = max(num_total_samples, 1.0)
+        labels_list, label_weights_list, anchor_list, bbox_targets_list, level_pos, num_total_pos = built
+        if dist.is_available() and dist.is_initialized():
+            # rank mean of the positive count (atss_rpn_head.py:440-444), kept on the device
+            num_total_samples = reduce_mean(
+                torch.tensor(num_total_pos, dtype=torch.float, device=device)).clamp(min=1.0)
+        else:
+            num_total_samples = max(float(num_total_pos), 1.0)
         losses_cls, losses_bbox, losses_iou, bbox_avg_factor = multi_apply(
             self.loss_single, anchor_list, cls_scores, bbox_preds, iou_preds, labels_list,
-            label_weights_list, bbox_targets_list, num_total_samples=num_total_samples)
+            label_weights_list, bbox_targets_list, level_pos, num_total_samples=num_total_samples)
         bbox_avg_factor = sum(bbox_avg_factor)
-        bbox_avg_factor = reduce_mean(bbox_avg_factor).clamp_(min=1).item()
+        # stays a device scalar: reading it back would stall the host behind the whole forward pass
+        bbox_avg_factor = reduce_mean(bbox_avg_factor).clamp(min=1).detach()
         losses_bbox = [x / bbox_avg_factor for x in losses_bbox]
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox, loss_rpn_iou=losses_iou)
 

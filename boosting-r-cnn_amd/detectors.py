@@ -146,6 +146,13 @@ class TwoStageDetector(BaseDetector):
     # ---- train ---------------------------------------------------------------------------
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, proposals=None, **kwargs):
+        if self.with_rpn and img.is_cuda:
+            # the RPN targets depend on anchors and ground truth only: the head computes them on a
+            # side stream that starts HERE, so the host syncs of the assignment (nonzero / unique)
+            # wait for that stream instead of for the whole backbone queued on the main one
+            ev = torch.cuda.Event()
+            ev.record()
+            self.rpn_head._inputs_ready = ev
         x = self.extract_feat(img)
         losses = dict()
         if self.with_rpn:
