@@ -31,6 +31,10 @@ struct ConvParams {
     int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
     int out_f32;                     // bf16 compute path: write the result as fp32 (head outputs)
     int il;                          // tuning: 1 = LDS-DMA pieces interleaved with the MFMA groups (bf16 kernel)
+    // output scatter (data gradient of a stride-2 conv by parity class): output pixel (a, b) of the
+    // launch goes to pixel (2*(a-sc_o)+sc_ph, 2*(b-sc_o)+sc_pw) of a (batch, sc_H, sc_W, Cout) tensor and
+    // is dropped when a-sc_o / b-sc_o fall outside [0, sc_na) / [0, sc_nb); 0 = dense output
+    int scatter, sc_H, sc_W, sc_ph, sc_pw, sc_o, sc_na, sc_nb;
     int gstep;                       // grouped conv: N tile t reads input channels [t*gstep, t*gstep + Cin); 0 = dense
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
@@ -47,6 +51,17 @@ __device__ __forceinline__ static int xcd_remap(int bid, int nwg) {
     return base + loc;
 }
 
+
+// element offset of output row m (-1: row dropped); dense launches: m * Cout
+__device__ __forceinline__ static long long out_row_offset(const ConvParams& p, int m) {
+    if (!p.scatter) return (long long)m * p.Cout;
+    const int Ho = p.seg_Ho[0], Wo = p.seg_Wo[0];
+    const int n = m / (Ho * Wo);
+    const int r = m - n * (Ho * Wo);
+    const int a = r / Wo - p.sc_o, b = r - (r / Wo) * Wo - p.sc_o;
+    if ((unsigned)a >= (unsigned)p.sc_na || (unsigned)b >= (unsigned)p.sc_nb) return -1;
+    return (((long long)n * p.sc_H + 2 * a + p.sc_ph) * p.sc_W + 2 * b + p.sc_pw) * p.Cout;
+}
 
 // bf16 dispatch (conv_igemm_bf16.hip)
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s);

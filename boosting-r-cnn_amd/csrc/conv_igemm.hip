@@ -532,7 +532,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
                     if (p.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    if (cv < p.Cout && m < p.M) *reinterpret_cast<float4*>(yout + (size_t)m * p.Cout + cv) = v;
+                    if (cv < p.Cout && m < p.M) {
+                        const long long ro = out_row_offset(p, m);
+                        if (ro >= 0) *reinterpret_cast<float4*>(yout + ro + cv) = v;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             } else {
@@ -545,7 +548,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
                     v = v + sh;
                     if (RES) v = v + rv[tm][tn][r];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    if (cok && m < p.M) yout[(size_t)m * p.Cout + co] = v;
+                    if (cok && m < p.M) {
+                        const long long ro = out_row_offset(p, m);
+                        if (ro >= 0) yout[ro + co] = v;
+                    }
                 }
             }
         }
@@ -647,7 +653,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
                                  const int* heights_host, const int* widths_host,
                                  const int* out_heights_host, const int* out_widths_host, int cin,
                                  int cout, int kh, int kw, int stride, int pad, int dilate, int relu,
-                                 int dtype, void* stream, int pitch = 0) {
+                                 int dtype, void* stream, int pitch = 0, const int* scatter = nullptr) {
     if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
         pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
         !heights_host || !widths_host)
@@ -686,8 +692,31 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     p.M = (int)m_total;
     p.K = kh * kw * cin;
     p.relu = relu;
+    if (scatter) {      // {out_h, out_w, ph, pw, origin, rows, cols}: single map, LDS-DMA kernels only
+        if (num_segments != 1 || cin % 32 != 0 || residual) return BRCNN_EINVAL;
+        p.scatter = 1;
+        p.sc_H = scatter[0]; p.sc_W = scatter[1]; p.sc_ph = scatter[2]; p.sc_pw = scatter[3];
+        p.sc_o = scatter[4]; p.sc_na = scatter[5]; p.sc_nb = scatter[6];
+    }
     if (bf16) return dispatch_conv_bf16(p, (hipStream_t)stream);
     return dispatch_conv(p, (hipStream_t)stream);
+}
+
+BRCNN_API int brcnn_conv2d_nhwc_scatter2(const void* x, const void* w, void* y, int batch, int height, int width,
+                                         int cin, int cout, int kh, int kw, int pad, int out_height,
+                                         int out_width, int ph, int pw, int origin, int dtype, void* stream) {
+    if (out_height <= 0 || out_width <= 0 || ph < 0 || ph > 1 || pw < 0 || pw > 1 || origin < 0 ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const int Ho = height + 2 * pad - kh + 1, Wo = width + 2 * pad - kw + 1;
+    int na = (out_height - ph + 1) / 2, nb = (out_width - pw + 1) / 2;      // pixels of this parity class
+    if (na > Ho - origin) na = Ho - origin;                                  // rows the launch produces
+    if (nb > Wo - origin) nb = Wo - origin;
+    if (na <= 0 || nb <= 0) return 0;
+    const int sc[7] = {out_height, out_width, ph, pw, origin, na, nb};
+    const int hs[1] = {height}, ws[1] = {width};
+    return conv_setup_and_launch(x, w, nullptr, nullptr, nullptr, y, batch, 1, hs, ws, nullptr, nullptr, cin, cout,
+                                 kh, kw, 1, pad, 1, 0, dtype, stream, 0, sc);
 }
 
 // Grouped convolution (ResNeXt, resnext.py:10-84: conv2 of every bottleneck has `groups` = 32 / 64).

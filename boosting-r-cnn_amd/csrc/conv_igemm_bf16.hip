@@ -322,6 +322,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             if (m >= p.M || co >= p.Cout) continue;
+            const long long ro = out_row_offset(p, m);
+            if (ro < 0) continue;
             if (vec_ok) {
                 if (RES) {
                     const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (OUTF32) {
-                    float4* dst = reinterpret_cast<float4*>(yf + (size_t)m * p.Cout + co);
+                    float4* dst = reinterpret_cast<float4*>(yf + ro + co);
                     dst[0] = make_float4(v[0], v[1], v[2], v[3]);
                     dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
                     o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
                     o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-                    *reinterpret_cast<uint4*>(yh + (size_t)m * p.Cout + co) = o;
+                    *reinterpret_cast<uint4*>(yh + ro + co) = o;
                 }
             } else {       // ragged channel count (fused heads: 54, 21): element-wise tail
 #pragma unroll
@@ -354,8 +356,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     float t = v[e];
                     if (RES) t += bf2f(res[(size_t)m * p.Cout + co + e]);
                     if (p.relu) t = fmaxf(t, 0.f);
-                    if (OUTF32) yf[(size_t)m * p.Cout + co + e] = t;
-                    else yh[(size_t)m * p.Cout + co + e] = f2bf(t);
+                    if (OUTF32) yf[ro + co + e] = t;
+                    else yh[ro + co + e] = f2bf(t);
                 }
             }
         }

@@ -158,6 +158,19 @@ int brcnn_conv2d_nhwc(const void *x, const void *w, const float *scale, const fl
                       int cout, int kh, int kw, int stride, int pad, int relu, int dtype,
                       void *stream);
 
+/* Stride-1 convolution whose output is scattered with stride 2: output pixel (a, b) of the
+ * (height + 2 pad - kh + 1) x (width + 2 pad - kw + 1) result goes to pixel
+ * (2 (a - origin) + ph, 2 (b - origin) + pw) of y (batch, out_height, out_width, cout); pixels that
+ * fall outside y are dropped, pixels of y of other parities are not touched.  It is one parity
+ * class of the data gradient of a stride-2 convolution (x = dy, w = the class's taps as
+ * (Cin_of_the_layer, KH', KW', Cout_of_the_layer)): the four classes of a 3x3 / pad 1 layer have
+ * 1 + 2 + 2 + 4 = 9 taps, against 36 for the full kernel over the zero-stuffed dy that
+ * brcnn_conv2d_dgrad_nhwc_multi runs (the reference gets the same effect from cuDNN's strided
+ * dgrad).  cin % 32 == 0 (fp32) / % 64 (bf16). */
+int brcnn_conv2d_nhwc_scatter2(const void *x, const void *w, void *y, int batch, int height, int width,
+                               int cin, int cout, int kh, int kw, int pad, int out_height,
+                               int out_width, int ph, int pw, int origin, int dtype, void *stream);
+
 /* Tuning hook: force the workgroup tile (wm: 2 -> 128 rows, 4 -> 256 rows; nt: 1 -> 64
  * columns, 2 -> 128 columns; 0 -> built-in heuristic).  Process-wide; used by the
  * benchmarking scripts (tools/conv_bench.py). */

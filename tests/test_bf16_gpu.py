@@ -317,3 +317,26 @@ def test_grouped_conv_bf16_forward_backward():
         assert xg.grad.dtype == BF and _rne_close(xg.grad.float().permute(0, 3, 1, 2).cpu().double(), xr.grad)
         assert wg.grad.dtype == torch.float32 and wg.grad.shape == wt.shape
         assert (wg.grad.cpu().double() - wr.grad).abs().max().item() <= 2e-4 * max(1.0, wr.grad.abs().max().item())
+
+
+def test_scatter2_conv_bf16_equals_strided_copy():
+    """brcnn_conv2d_nhwc_scatter2 (one parity class of a stride-2 data gradient) in bf16: the
+    scattered rows equal the dense bf16 conv written through a strided copy, bit for bit, and
+    pixels of the other parities keep their previous contents"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    n, ho, wo, c_in, c_out, H, W = 2, 9, 11, 128, 64, 17, 22
+    dy = torch.randn(n, ho, wo, c_in, generator=g).bfloat16().to(DEV)
+    for (kh, kw, ph, pw) in [(1, 1, 0, 0), (2, 1, 1, 0), (1, 2, 0, 1), (2, 2, 1, 1)]:
+        wt = (torch.randn(c_out, kh, kw, c_in, generator=g) * 0.05).bfloat16().to(DEV)
+        dense = ops.conv2d_nhwc(dy, wt, None, None, None, False, 1, 1)
+        na, nb = (H - ph + 1) // 2, (W - pw + 1) // 2
+        ref = torch.full((n, H, W, c_out), 7.0, dtype=torch.bfloat16, device=DEV)
+        ref[:, ph::2, pw::2] = dense[:, 1:1 + na, 1:1 + nb]
+        out = torch.full((n, H, W, c_out), 7.0, dtype=torch.bfloat16, device=DEV)
+        st = L.brcnn_conv2d_nhwc_scatter2(dy.data_ptr(), wt.data_ptr(), out.data_ptr(), n, ho, wo, c_in, c_out,
+                                          kh, kw, 1, H, W, ph, pw, 1, 1, None)
+        assert st == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (kh, kw, ph, pw)
