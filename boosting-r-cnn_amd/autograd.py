@@ -90,6 +90,37 @@ class ConvNHWCFunction(Function):
         return dx, dw, db, None, None, None, None
 
 
+class GroupNormNHWCFunction(Function):
+    """GroupNorm(+ReLU) over one or several NHWC segments on the HIP kernels, forward and backward
+    (torch's native group norm wants NCHW: two layout copies per layer and direction)."""
+
+    @staticmethod
+    def forward(ctx, x_cat, gamma, beta, groups, batch, sizes, eps, relu):
+        _require_gpu(x_cat, gamma, beta)
+        x_cat = x_cat.contiguous()
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y, stats = ops.groupnorm_nhwc_multi(x_cat, g32, b32, groups, batch, sizes, eps, relu, return_stats=True)
+        ctx.save_for_backward(x_cat, stats, g32, b32)
+        ctx.cfg = (groups, batch, tuple(sizes), bool(relu), gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x_cat, stats, g32, b32 = ctx.saved_tensors
+        groups, batch, sizes, relu, gdt, bdt = ctx.cfg
+        dx, dg, db = ops.groupnorm_nhwc_multi_backward(dy.to(x_cat.dtype).contiguous(), x_cat, stats, g32, b32,
+                                                       groups, batch, sizes, relu)
+        return dx, dg.to(gdt), db.to(bdt), None, None, None, None, None
+
+
+def groupnorm_nhwc_autograd(x, gamma, beta, groups, eps, relu):
+    """x (N,H,W,C) -> GroupNorm(+ReLU), differentiable"""
+    n, h, w, c = x.shape
+    y = GroupNormNHWCFunction.apply(x.reshape(n * h * w, c), gamma, beta, groups, n, ((h, w),), eps, relu)
+    return y.view(n, h, w, c)
+
+
 def _dgrad_stride2(dy, weight, batch, in_size, out_size, k, pad, dtype):
     """Data gradient of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0) by output parity.
 

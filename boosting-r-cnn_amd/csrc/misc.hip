@@ -174,6 +174,144 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x,
     }
 }
 
+
+// ---- GroupNorm(+ReLU) backward over the same multi-segment NHWC layout ----------------------
+// With xh = (x - mean) * rstd, g = dy (zeroed where the ReLU clipped):
+//     dbeta_c = sum g,  dgamma_c = sum g*xh                     (over images and pixels)
+//     s1 = sum_{c in group, pixels} g*gamma_c,  s2 = sum g*gamma_c*xh     (per segment, image, group)
+//     dx = rstd * (g*gamma_c - s1/D - xh*s2/D),   D = pixels * channels per group
+// pass 1 (same streaming layout as gn_stats_kernel): per workgroup the per-channel sums (A = sum g,
+// B = sum g*xh) of its row chunk; they go to a partial buffer [workgroup][2][C] for the
+// deterministic second stage (dgamma / dbeta), and, weighted by gamma, as two double atomics per
+// group into gsum (s1, s2).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const double* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, double* __restrict__ gsum,
+                                                           float* __restrict__ part, GnSegs sg, int N, int C, int G,
+                                                           int rows_per_block, int relu) {
+    __shared__ float red[4][256][2];
+    const int seg = blockIdx.y / N, n = blockIdx.y - seg * N;
+    const int HW = sg.hw[seg];
+    const int row0 = blockIdx.x * rows_per_block;
+    float* my_part = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+    const int cpg = C / G;
+    if (row0 >= HW) {       // chunk beyond this (smaller) segment: its partial must still be defined
+        for (int c = threadIdx.x; c < 2 * C; c += 256) my_part[c] = 0.f;
+        return;
+    }
+    const int row1 = min(HW, row0 + rows_per_block);
+    const size_t base = (size_t)(sg.row0[seg] + (long long)n * HW) * C;
+    const T* xs = x + base;
+    const T* ds = dy + base;
+    const int c4n = C >> 2;
+    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int q0 = q; q0 < c4n; q0 += 64) {
+        float mean[4], rstd[4], gm[4], bt[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = q0 * 4 + e;
+            const float2 mr = reinterpret_cast<const float2*>(stats + ((size_t)blockIdx.y * G + c / cpg) * 2)[0];
+            mean[e] = mr.x; rstd[e] = mr.y; gm[e] = gamma[c]; bt[e] = beta[c];
+        }
+        float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        for (int r = row0 + rl; r < row1; r += 4) {
+            const float4 xv = ld4(xs + (size_t)r * C + q0 * 4);
+            const float4 dv = ld4(ds + (size_t)r * C + q0 * 4);
+            const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float xh = (xi[e] - mean[e]) * rstd[e];
+                const float g = (relu && xh * gm[e] + bt[e] <= 0.f) ? 0.f : di[e];
+                a[e] += g;
+                b[e] += g * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            red[rl][q0 * 4 + e][0] = a[e];
+            red[rl][q0 * 4 + e][1] = b[e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float A = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
+        const float B = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+        my_part[c] = A;
+        my_part[C + c] = B;
+        red[0][c][0] = A * gamma[c];
+        red[0][c][1] = B * gamma[c];
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; c++) { s1 += red[0][c][0]; s2 += red[0][c][1]; }
+        atomicAdd(&gsum[((size_t)blockIdx.y * G + g) * 2 + 0], s1);
+        atomicAdd(&gsum[((size_t)blockIdx.y * G + g) * 2 + 1], s2);
+    }
+}
+
+// second stage of dgamma / dbeta: column sums of the [num_parts][2][C] partials (1024 threads:
+// 2C columns x row lanes, combined through LDS)
+__global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int num_parts, int C) {
+    __shared__ float red[1024];
+    const int cols = 2 * C;                 // <= 512
+    const int lanes = 1024 / cols;          // >= 2
+    const int col = threadIdx.x % cols, lane = threadIdx.x / cols;
+    float acc = 0.f;
+    if (lane < lanes)
+        for (int r = lane; r < num_parts; r += lanes) acc += part[(size_t)r * cols + col];
+    red[threadIdx.x] = (lane < lanes) ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        float t = 0.f;
+        for (int l = 0; l < lanes; l++) t += red[l * cols + threadIdx.x];
+        if (threadIdx.x < C) dbeta[threadIdx.x] = t;
+        else dgamma[threadIdx.x - C] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          const double* __restrict__ stats,
+                                                          const double* __restrict__ gsum,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ dx,
+                                                          GnSegs sg, int N, int C, int G, int relu) {
+    const int c4n = C >> 2, cpg = C / G;
+    const long long total = sg.row0[sg.nseg] * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long long row = idx / c4n;
+        int seg = 0;
+#pragma unroll
+        for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+            if (t < sg.nseg && row >= sg.row0[t]) seg = t;
+        const int n = (int)((row - sg.row0[seg]) / sg.hw[seg]);
+        const size_t sbase = ((size_t)(seg * N + n)) * G;
+        const float inv_d = 1.f / ((float)sg.hw[seg] * (float)cpg);
+        const float4 xv = ld4(x + (size_t)idx * 4);
+        const float4 dv = ld4(dy + (size_t)idx * 4);
+        const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = c4 * 4 + e;
+            const size_t gi = (sbase + c / cpg) * 2;
+            const float2 mr = reinterpret_cast<const float2*>(stats + gi)[0];
+            const float s1 = (float)gsum[gi], s2 = (float)gsum[gi + 1];
+            const float xh = (xi[e] - mr.x) * mr.y;
+            const float gmm = gamma[c];
+            const float g = (relu && xh * gmm + beta[c] <= 0.f) ? 0.f : di[e];
+            out[e] = mr.y * (g * gmm - (s1 + xh * s2) * inv_d);
+        }
+        st4(dx + (size_t)idx * 4, make_float4(out[0], out[1], out[2], out[3]));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_add_kernel(T* __restrict__ dst,
                                                           const T* __restrict__ src, int N,
@@ -336,6 +474,89 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
                                s, (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y,
                                sg, batch, channels, groups, relu);
     }
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+
+static int gn_setup(GnSegs& sg, long long& rows, int& max_hw, int batch, int num_segments, const int* hw_host) {
+    sg = GnSegs{};
+    sg.nseg = num_segments;
+    rows = 0;
+    max_hw = 0;
+    for (int i = 0; i < num_segments; i++) {
+        if (hw_host[i] <= 0) return BRCNN_EINVAL;
+        sg.hw[i] = hw_host[i];
+        sg.row0[i] = rows;
+        rows += (long long)batch * hw_host[i];
+        if (hw_host[i] > max_hw) max_hw = hw_host[i];
+    }
+    for (int i = num_segments; i <= BRCNN_MAX_LEVELS; i++) sg.row0[i] = rows;
+    return 0;
+}
+
+static void gn_bwd_chunks(int max_hw, int* chunks, int* rpb) {
+    int c = (max_hw + 255) / 256;
+    if (c > 64) c = 64;
+    *rpb = (max_hw + c - 1) / c;
+    *chunks = (max_hw + *rpb - 1) / *rpb;
+}
+
+BRCNN_API size_t brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(int batch, int num_segments, const int* hw_host,
+                                                                    int channels, int groups) {
+    if (batch <= 0 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || groups <= 0)
+        return 0;
+    int max_hw = 0;
+    for (int i = 0; i < num_segments; i++) max_hw = hw_host[i] > max_hw ? hw_host[i] : max_hw;
+    int chunks, rpb;
+    gn_bwd_chunks(max_hw, &chunks, &rpb);
+    return (size_t)batch * num_segments * groups * 2 * sizeof(double) +
+           (size_t)batch * num_segments * chunks * 2 * channels * sizeof(float);
+}
+
+BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x, const void* stats,
+                                                  const float* gamma, const float* beta, void* dx, float* dgamma,
+                                                  float* dbeta, void* workspace, size_t workspace_bytes, int batch,
+                                                  int num_segments, const int* hw_host, int channels, int groups,
+                                                  int relu, int dtype, void* stream) {
+    if (!dy || !x || !stats || !gamma || !beta || !dx || !dgamma || !dbeta || !workspace || batch <= 0 ||
+        num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || channels > 256 ||
+        groups <= 0 || channels % groups || (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    if (workspace_bytes < brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(batch, num_segments, hw_host, channels, groups))
+        return BRCNN_EINVAL;
+    GnSegs sg;
+    long long rows;
+    int max_hw;
+    if (gn_setup(sg, rows, max_hw, batch, num_segments, hw_host)) return BRCNN_EINVAL;
+    int chunks, rpb;
+    gn_bwd_chunks(max_hw, &chunks, &rpb);
+    hipStream_t s = (hipStream_t)stream;
+    double* gsum = (double*)workspace;
+    const size_t gbytes = (size_t)batch * num_segments * groups * 2 * sizeof(double);
+    float* part = (float*)((char*)workspace + gbytes);
+    BRCNN_HIP_CHECK(hipMemsetAsync(gsum, 0, gbytes, s));
+    const long long total = rows * (channels >> 2);
+    const int num_parts = batch * num_segments * chunks;
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+                           (const float*)x, (const float*)dy, (const double*)stats, gamma, beta, gsum, part, sg, batch,
+                           channels, groups, rpb, relu);
+    else
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+                           (const bf16_t*)x, (const bf16_t*)dy, (const double*)stats, gamma, beta, gsum, part, sg,
+                           batch, channels, groups, rpb, relu);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(1), dim3(1024), 0, s, part, dgamma, dbeta, num_parts, channels);
+    BRCNN_LAUNCH_CHECK();
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
+                           (const float*)dy, (const double*)stats, gsum, gamma, beta, (float*)dx, sg, batch, channels,
+                           groups, relu);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x,
+                           (const bf16_t*)dy, (const double*)stats, gsum, gamma, beta, (bf16_t*)dx, sg, batch, channels,
+                           groups, relu);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -48,6 +48,9 @@ SIGNATURES = {
     'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
     'brcnn_groupnorm_nhwc_multi': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_int, c_int, c_f32,
                                                           c_int, c_int, c_ptr]),
+    'brcnn_groupnorm_nhwc_multi_backward_workspace_bytes': (c_size, [c_int, c_int, c_ptr, c_int, c_int]),
+    'brcnn_groupnorm_nhwc_multi_backward': (c_int, [c_ptr] * 9 + [c_size, c_int, c_int, c_ptr] + [c_int] * 4 +
+                                            [c_ptr]),
     'brcnn_upsample_nearest_add_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 7 + [c_ptr]),
     'brcnn_nchw_to_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
     'brcnn_nhwc_to_nchw': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),

@@ -539,9 +539,9 @@ def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=N
     return y, out_sizes
 
 
-def groupnorm_nhwc_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, relu=False):
+def groupnorm_nhwc_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, relu=False, return_stats=False):
     """GroupNorm(+ReLU) with statistics per (segment, image, group) over a concatenation of
-    NHWC segments (rows, C)."""
+    NHWC segments (rows, C).  `return_stats`: also the (mean, rstd) buffer the backward needs."""
     import ctypes
     _require_gpu(x_cat, gamma, beta)
     L = len(sizes)
@@ -553,7 +553,28 @@ def groupnorm_nhwc_multi(x_cat, gamma, beta, groups, batch, sizes, eps=1e-5, rel
                                               batch, L, hw, c, int(groups), float(eps),
                                               int(bool(relu)), _dt(x_cat), _stream())
     _L.check(st, 'brcnn_groupnorm_nhwc_multi')
-    return y
+    return (y, ws) if return_stats else y
+
+
+def groupnorm_nhwc_multi_backward(dy, x_cat, stats, gamma, beta, groups, batch, sizes, relu):
+    """(dx, dgamma, dbeta) of groupnorm_nhwc_multi; `stats` from its return_stats"""
+    import ctypes
+    _require_gpu(dy, x_cat, stats, gamma, beta)
+    assert dy.shape == x_cat.shape and dy.dtype == x_cat.dtype and dy.is_contiguous() and x_cat.is_contiguous()
+    L = len(sizes)
+    c = x_cat.shape[1]
+    hw = (ctypes.c_int * L)(*[h * w for h, w in sizes])
+    lib = _L.load()
+    nbytes = lib.brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(batch, L, hw, c, int(groups))
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x_cat.device)
+    dx = torch.empty_like(x_cat)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x_cat.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x_cat.device)
+    st = lib.brcnn_groupnorm_nhwc_multi_backward(_ptr(dy), _ptr(x_cat), _ptr(stats), _ptr(gamma), _ptr(beta),
+                                                 _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nbytes, batch, L, hw,
+                                                 c, int(groups), int(bool(relu)), _dt(x_cat), _stream())
+    _L.check(st, 'brcnn_groupnorm_nhwc_multi_backward')
+    return dx, dgamma, dbeta
 
 
 def pack_stem_weight(w, dtype=torch.float32):

@@ -261,6 +261,21 @@ int brcnn_groupnorm_nhwc_multi(const void *x, const float *gamma, const float *b
                                int batch, int num_segments, const int *hw_host, int channels,
                                int groups, float eps, int relu, int dtype, void *stream);
 
+/* Backward of brcnn_groupnorm_nhwc_multi (training of the RPN tower: GroupNorm(32) + ReLU of
+ * mmcv's ConvModule, atss_rpn_head.py:150-170; torch's native group-norm backward needs NCHW
+ * and costs two layout copies per layer and direction).  `x` is the forward input, `stats` the
+ * forward's stats_ws (mean / rstd per (segment, image, group) after the forward call), `relu`
+ * the forward's flag (the clipped positions are recomputed from x).  Writes dx (same layout and
+ * dtype as x), dgamma / dbeta (channels, fp32, overwritten).  Deterministic except for the
+ * double-precision group sums (atomics). */
+size_t brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(int batch, int num_segments, const int *hw_host,
+                                                           int channels, int groups);
+int brcnn_groupnorm_nhwc_multi_backward(const void *dy, const void *x, const void *stats, const float *gamma,
+                                        const float *beta, void *dx, float *dgamma, float *dbeta,
+                                        void *workspace, size_t workspace_bytes, int batch, int num_segments,
+                                        const int *hw_host, int channels, int groups, int relu, int dtype,
+                                        void *stream);
+
 /* Element-wise tail of a trainable conv block in training (eval-mode BatchNorm = per-channel
  * affine whose gamma / beta still train, resnet.py:263-302 with norm_eval=True):
  *   forward   out = [relu](z * scale[c] + shift[c] [+ residual])          (rows, C) NHWC rows

@@ -212,7 +212,12 @@ def _bn_act_autograd(z, scale, shift, res=None, relu=True):
     return y.relu() if relu else y
 
 
-_PATCH_AUTOGRAD = dict(bn_act_autograd=_bn_act_autograd, conv2d_nhwc_autograd=_conv2d_nhwc_autograd, linear_autograd=_linear_autograd,
+def _groupnorm_nhwc_autograd(x, gamma, beta, groups, eps, relu):
+    z = F.group_norm(x.permute(0, 3, 1, 2).float(), groups, gamma, beta, eps).permute(0, 2, 3, 1).to(x.dtype)
+    return (z.relu() if relu else z).contiguous()
+
+
+_PATCH_AUTOGRAD = dict(groupnorm_nhwc_autograd=_groupnorm_nhwc_autograd, bn_act_autograd=_bn_act_autograd, conv2d_nhwc_autograd=_conv2d_nhwc_autograd, linear_autograd=_linear_autograd,
                        roi_extract_autograd=_roi_extract_autograd)
 
 _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw,

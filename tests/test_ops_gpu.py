@@ -616,3 +616,46 @@ def test_grouped_conv_autograd_matches_torch():
         assert (xg.grad.permute(0, 3, 1, 2).cpu().double() - xr.grad).abs().max().item() < tol(xr.grad)
         assert wg.grad.shape == wt.shape
         assert (wg.grad.cpu().double() - wr.grad).abs().max().item() < 2e-4 * max(1.0, wr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype,relu', [(torch.float32, True), (torch.float32, False), (torch.bfloat16, True)])
+def test_groupnorm_multi_backward_matches_torch(dtype, relu):
+    """HIP GroupNorm(+ReLU) backward over two NHWC segments against torch's fp64 group_norm
+    autograd per (segment): dx, dgamma, dbeta"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    B, C, G = 2, 256, 32
+    sizes = [(13, 21), (7, 11)]
+    xs = [torch.randn(B, h, w, C, generator=g) * 1.5 + 0.3 for h, w in sizes]
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    gos = [torch.randn(B, h, w, C, generator=g) for h, w in sizes]
+    if dtype == torch.bfloat16:
+        xs = [t.bfloat16().float() for t in xs]
+        gos = [t.bfloat16().float() for t in gos]
+    # reference
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    refs = []
+    for x, go in zip(xs, gos):
+        xr = x.double().permute(0, 3, 1, 2).requires_grad_()
+        y = F.group_norm(xr, G, gr, br, 1e-5)
+        y = y.relu() if relu else y
+        y.backward(go.double().permute(0, 3, 1, 2))
+        refs.append((y.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)))
+    # HIP
+    from brcnn.autograd import GroupNormNHWCFunction
+    x_cat = torch.cat([x.reshape(-1, C) for x in xs]).to(dtype).to(DEV).requires_grad_()
+    gg, bg = gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    y = GroupNormNHWCFunction.apply(x_cat, gg, bg, G, B, tuple(sizes), 1e-5, relu)
+    y.backward(torch.cat([go.reshape(-1, C) for go in gos]).to(dtype).to(DEV))
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    r0 = 0
+    for (h, w), (yr, dxr) in zip(sizes, refs):
+        n = B * h * w
+        yy = y[r0:r0 + n].detach().float().cpu().view(B, h, w, C).double()
+        dx = x_cat.grad[r0:r0 + n].float().cpu().view(B, h, w, C).double()
+        assert (yy - yr).abs().max().item() <= tol * max(yr.abs().max().item(), 1.0)
+        assert (dx - dxr).abs().max().item() <= tol * max(dxr.abs().max().item(), 1.0), (dtype, relu)
+        r0 += n
+    assert (gg.grad.double().cpu() - gr.grad).abs().max().item() <= tol * gr.grad.abs().max().item() + 1e-4
+    assert (bg.grad.double().cpu() - br.grad).abs().max().item() <= tol * br.grad.abs().max().item() + 1e-4
