@@ -184,6 +184,14 @@ def conv2d_nhwc_autograd(x, weight, bias, stride, pad):
     return y if cout == weight.shape[0] else y[..., :cout]
 
 
+def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad):
+    """several NHWC maps that share one set of weights (pyramid levels), concatenated as
+    (rows, Cin) -> (rows_out, Cout): one forward / dgrad / wgrad launch for all of them"""
+    weight, bias, cout = _pad_cout(weight, bias, 32 if x_cat.dtype == torch.float32 else 64)
+    y = ConvNHWCFunction.apply(x_cat, weight, bias, batch, tuple(sizes), stride, pad)
+    return y if cout == weight.shape[0] else y[:, :cout]
+
+
 def linear_autograd(x, weight, bias):
     """x (M,K) @ weight(N,K)^T + bias, differentiable (the 1x1 case with H=W=1)"""
     weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)

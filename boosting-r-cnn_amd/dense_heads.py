@@ -215,8 +215,41 @@ class ATSSRPNHead(AnchorHead):
 
     def forward_nhwc(self, feats):
         """feats: list of (N,h,w,C) -> 3 lists of (N,h,w,A | 4A | A) NHWC head outputs"""
+        from .autograd import wants_grad
+        if feats[0].is_cuda and wants_grad(feats[0], self.rpn_cls.weight) and \
+                all(isinstance(c.norm, nn.GroupNorm) and c.conv.bias is None and c.conv.groups == 1
+                    for c in self.rpn_convs) and self.feat_channels <= 256 and self.feat_channels % 4 == 0:
+            return self._forward_train_fused(feats)
         outs = [self.forward_single_nhwc(f, i) for i, f in enumerate(feats)]
         return tuple(map(list, zip(*outs)))
+
+    def _forward_train_fused(self, feats):
+        """Training forward with all pyramid levels in one launch per layer: the tower and the
+        heads share their weights across levels (atss_rpn_head.py:296-297), so conv forward, data
+        gradient and weight gradient of a layer each run once over the concatenated rows, and
+        GroupNorm keeps its per-(level, image, group) statistics through the segment table."""
+        from .autograd import GroupNormNHWCFunction, conv2d_nhwc_multi_autograd
+        B = feats[0].shape[0]
+        sizes = tuple(tuple(f.shape[1:3]) for f in feats)
+        x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
+        for conv in self.rpn_convs:
+            x = conv2d_nhwc_multi_autograd(x, conv.conv.weight, None, B, sizes, 1, conv.conv.padding[0])
+            x = GroupNormNHWCFunction.apply(x, conv.norm.weight, conv.norm.bias, conv.norm.num_groups, B, sizes,
+                                            conv.norm.eps, conv.with_activation)
+        heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
+        y = conv2d_nhwc_multi_autograd(x, torch.cat([h.weight for h in heads], 0),
+                                       torch.cat([h.bias for h in heads], 0), B, sizes, 1,
+                                       self.rpn_cls.padding[0]).float()
+        a, c = self.num_anchors, self.cls_out_channels
+        cls, reg, iou, r0 = [], [], [], 0
+        for lvl, (h, w) in enumerate(sizes):
+            n = B * h * w
+            t = y[r0:r0 + n].view(B, h, w, y.shape[1])
+            cls.append(t[..., :a * c])
+            reg.append(t[..., a * c:a * c + 4 * a] * self.scales[lvl].scale)
+            iou.append(t[..., a * c + 4 * a:])
+            r0 += n
+        return cls, reg, iou
 
     def forward_fused(self, feats):
         """All pyramid levels in ONE launch per layer (the tower and the heads share their
