@@ -252,24 +252,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// second stage of dgamma / dbeta: column sums of the [num_parts][2][C] partials (1024 threads:
-// 2C columns x row lanes, combined through LDS)
+// second stage of dgamma / dbeta: column sums of the [num_parts][2][C] partials; one workgroup per
+// 32 columns (32 columns x 32 row lanes, combined through LDS)
 __global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int num_parts, int C) {
-    __shared__ float red[1024];
-    const int cols = 2 * C;                 // <= 512
-    const int lanes = 1024 / cols;          // >= 2
-    const int col = threadIdx.x % cols, lane = threadIdx.x / cols;
+    __shared__ float red[32][33];
+    const int cols = 2 * C;
+    const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cl;
     float acc = 0.f;
-    if (lane < lanes)
-        for (int r = lane; r < num_parts; r += lanes) acc += part[(size_t)r * cols + col];
-    red[threadIdx.x] = (lane < lanes) ? acc : 0.f;
+    if (col < cols)
+        for (int r = lane; r < num_parts; r += 32) acc += part[(size_t)r * cols + col];
+    red[lane][cl] = acc;
     __syncthreads();
-    if (threadIdx.x < cols) {
+    if (lane == 0 && col < cols) {
         float t = 0.f;
-        for (int l = 0; l < lanes; l++) t += red[l * cols + threadIdx.x];
-        if (threadIdx.x < C) dbeta[threadIdx.x] = t;
-        else dgamma[threadIdx.x - C] = t;
+#pragma unroll
+        for (int l = 0; l < 32; l++) t += red[l][cl];
+        if (col < C) dbeta[col] = t;
+        else dgamma[col - C] = t;
     }
 }
 
@@ -547,7 +548,8 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
                            (const bf16_t*)x, (const bf16_t*)dy, (const double*)stats, gamma, beta, gsum, part, sg,
                            batch, channels, groups, rpb, relu);
     BRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(1), dim3(1024), 0, s, part, dgamma, dbeta, num_parts, channels);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * channels + 31) / 32), dim3(1024), 0, s, part, dgamma, dbeta,
+                       num_parts, channels);
     BRCNN_LAUNCH_CHECK();
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
