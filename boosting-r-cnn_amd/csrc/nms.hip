@@ -192,6 +192,107 @@ NmsWs carve(void* base, int64_t n, int S, int words) {
     return w;
 }
 
+
+// ---- whole-batch candidate preparation for batched NMS (postprocess.batched_nms_images) ------
+// One workgroup per image slot of T candidates: order-preserving compaction of the valid ones
+// (rejected rows leave zeros behind), the image's largest surviving coordinate, and the
+// class / level separation of mmcv's batched_nms on the same fp32 values:
+//     boxes_for_nms = box + float(id) * (max_coordinate + 1)
+// plus the image's [begin, end) range for the segmented NMS.  Replaces ~30 small torch launches
+// (cumsum, where, 3 scatters, amax, ...) per call.
+__global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          const long long* __restrict__ ids,
+                                                          const unsigned char* __restrict__ valid, float* __restrict__ c_boxes,
+                                                          float* __restrict__ c_scores, long long* __restrict__ c_ids,
+                                                          float* __restrict__ nms_boxes, int* __restrict__ ranges, int T) {
+    __shared__ int wsum[16];
+    __shared__ float wmax[16];
+    __shared__ int s_base;
+    __shared__ float s_max;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row0 = (size_t)b * T;
+    if (tid == 0) s_base = 0;
+    float vmax = -3.402823466e+38f;             // torch.finfo(float32).min, the reference's fill value
+    __syncthreads();
+    // pass 1: positions of the survivors + the largest coordinate among them
+    for (int t0 = 0; t0 < T; t0 += 1024) {
+        const int t = t0 + tid;
+        const int v = (t < T && valid[row0 + t]) ? 1 : 0;
+        // inclusive scan inside the wave, then across the 16 waves
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        int total = 0;
+        for (int w = 0; w < 16; w++) total += wsum[w];
+        const int pos = s_base + woff + incl - 1;
+        if (v) {
+            const float4 bx = *reinterpret_cast<const float4*>(boxes + (row0 + t) * 4);
+            *reinterpret_cast<float4*>(c_boxes + (row0 + pos) * 4) = bx;
+            c_scores[row0 + pos] = scores[row0 + t];
+            c_ids[row0 + pos] = ids[row0 + t];
+            vmax = fmaxf(vmax, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    const int cnt = s_base;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+    if (lane == 0) wmax[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = wmax[0];
+        for (int w = 1; w < 16; w++) m = fmaxf(m, wmax[w]);
+        s_max = m;
+        ranges[2 * b] = b * T;
+        ranges[2 * b + 1] = b * T + cnt;
+    }
+    __syncthreads();
+    const float step = s_max + 1.0f;
+    // pass 2: zero the tail of the slot, offset boxes for the segmented NMS
+    for (int t = tid; t < T; t += 1024) {
+        if (t < cnt) {
+            const float4 bx = *reinterpret_cast<const float4*>(c_boxes + (row0 + t) * 4);
+            const float off = (float)c_ids[row0 + t] * step;
+            *reinterpret_cast<float4*>(nms_boxes + (row0 + t) * 4) = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
+        } else {
+            *reinterpret_cast<float4*>(c_boxes + (row0 + t) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(nms_boxes + (row0 + t) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            c_scores[row0 + t] = 0.f;
+            c_ids[row0 + t] = 0;
+        }
+    }
+}
+
+// survivors of the segmented NMS back into fixed (B, K) slots: dets = [box, score] of keep[b*T + k]
+// for k < min(num[b], K), zero rows / id -1 behind them
+__global__ __launch_bounds__(256) void nms_collect_kernel(const long long* __restrict__ keep, const int* __restrict__ num,
+                                                         const float* __restrict__ c_boxes, const float* __restrict__ c_scores,
+                                                         const long long* __restrict__ c_ids, float* __restrict__ dets,
+                                                         long long* __restrict__ ids_kept, int B, int T, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i - b * K;
+    float* d = dets + (size_t)i * 5;
+    if (k < num[b]) {
+        const long long src = keep[(size_t)b * T + k];
+        const float4 bx = *reinterpret_cast<const float4*>(c_boxes + src * 4);
+        d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = c_scores[src];
+        ids_kept[i] = c_ids[src];
+    } else {
+        d[0] = d[1] = d[2] = d[3] = d[4] = 0.f;
+        ids_kept[i] = -1;
+    }
+}
+
 }  // namespace
 
 BRCNN_API size_t brcnn_nms_workspace_bytes(int64_t n, int num_segments, int64_t max_segment_len) {
@@ -235,6 +336,32 @@ BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* 
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(num_segments), dim3(256), (size_t)(words + 1) * 8, s,
                        (const unsigned long long*)w.mask, (const int32_t*)w.idx_out, seg_begin, seg_end,
                        keep, num_keep, words, max_keep);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_nms_prepare(const float* boxes, const float* scores, const int64_t* ids, const uint8_t* valid,
+                                float* c_boxes, float* c_scores, int64_t* c_ids, float* nms_boxes, int32_t* ranges,
+                                int batch, int slot, void* stream) {
+    if (!boxes || !scores || !ids || !valid || !c_boxes || !c_scores || !c_ids || !nms_boxes || !ranges ||
+        batch <= 0 || slot <= 0 || (long long)batch * slot >= 0x7fffffffLL)
+        return BRCNN_EINVAL;
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, boxes, scores,
+                       (const long long*)ids, valid, c_boxes, c_scores, (long long*)c_ids, nms_boxes, ranges, slot);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_nms_collect(const int64_t* keep, const int32_t* num, const float* c_boxes, const float* c_scores,
+                                const int64_t* c_ids, float* dets, int64_t* ids_kept, int batch, int slot,
+                                int max_keep, void* stream) {
+    if (!keep || !num || !c_boxes || !c_scores || !c_ids || !dets || !ids_kept || batch <= 0 || slot <= 0 ||
+        max_keep <= 0 || max_keep > slot)
+        return BRCNN_EINVAL;
+    const int total = batch * max_keep;
+    hipLaunchKernelGGL(nms_collect_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)keep, num, c_boxes, c_scores, (const long long*)c_ids, dets,
+                       (long long*)ids_kept, batch, slot, max_keep);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

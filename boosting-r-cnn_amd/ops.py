@@ -220,6 +220,35 @@ def nms_ranges(boxes, scores, ranges, max_segment_len, iou_threshold, offset=0, 
     return keep, num_keep
 
 
+def nms_prepare(boxes, scores, ids, valid):
+    """(B,T,4) f32, (B,T) f32, (B,T) int64, (B,T) bool -> compacted c_boxes, c_scores, c_ids, the offset
+    boxes for the segmented NMS and the (B,2) int32 ranges, in one launch (brcnn_nms_prepare)"""
+    _require_gpu(boxes, scores, ids, valid)
+    B, T = scores.shape
+    boxes, scores = boxes.contiguous().float(), scores.contiguous().float()
+    ids = ids.contiguous().long()
+    valid = valid.contiguous().to(torch.uint8) if valid.dtype != torch.bool else valid.contiguous().view(torch.uint8)
+    c_boxes, nms_boxes = torch.empty_like(boxes), torch.empty_like(boxes)
+    c_scores, c_ids = torch.empty_like(scores), torch.empty_like(ids)
+    ranges = torch.empty((B, 2), dtype=torch.int32, device=boxes.device)
+    st = _L.load().brcnn_nms_prepare(_ptr(boxes), _ptr(scores), _ptr(ids), _ptr(valid), _ptr(c_boxes), _ptr(c_scores),
+                                     _ptr(c_ids), _ptr(nms_boxes), _ptr(ranges), B, T, _stream())
+    _L.check(st, 'brcnn_nms_prepare')
+    return c_boxes, c_scores, c_ids, nms_boxes, ranges
+
+
+def nms_collect(keep, num, c_boxes, c_scores, c_ids, K):
+    """first min(num[b], K) survivors of every slot -> dets (B,K,5), ids_kept (B,K) (zeros / -1 padded)"""
+    _require_gpu(keep, num, c_boxes, c_scores, c_ids)
+    B, T = c_scores.shape
+    dets = torch.empty((B, K, 5), dtype=torch.float32, device=c_boxes.device)
+    ids_kept = torch.empty((B, K), dtype=torch.int64, device=c_boxes.device)
+    st = _L.load().brcnn_nms_collect(_ptr(keep), _ptr(num), _ptr(c_boxes), _ptr(c_scores), _ptr(c_ids), _ptr(dets),
+                                     _ptr(ids_kept), B, T, int(K), _stream())
+    _L.check(st, 'brcnn_nms_collect')
+    return dets, ids_kept
+
+
 def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
     """mmcv.ops.nms: returns (dets (k,5), inds (k,) int64), score-descending."""
     assert isinstance(boxes, torch.Tensor) and isinstance(scores, torch.Tensor)

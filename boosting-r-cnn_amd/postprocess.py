@@ -16,7 +16,7 @@ import torch
 from . import ops
 
 
-def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offset=0):
+def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offset=0, fused=None):
     """boxes (B,T,4), scores (B,T), ids (B,T) long, valid (B,T) bool.
     Returns dets (B,K,5) zero padded, ids_kept (B,K) long (-1 padded), num (B,) int32, with
     K = max_keep (or T when max_keep <= 0)."""
@@ -24,6 +24,15 @@ def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offse
     device = scores.device
     K = max_keep if max_keep > 0 else T
     K = min(K, T)
+    if fused is None:
+        fused = boxes.is_cuda and boxes.dtype == torch.float32
+    if fused:
+        # the same steps as below in two launches around the segmented NMS
+        c_boxes, c_scores, c_ids, boxes_for_nms, ranges = ops.nms_prepare(boxes, scores, ids, valid)
+        keep, num = ops.nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges, T,
+                                   iou_threshold, offset, max_keep)
+        dets, ids_kept = ops.nms_collect(keep, num, c_boxes, c_scores, c_ids, K)
+        return dets, ids_kept.to(ids.dtype), num
     cnt = valid.sum(1)
     dest = torch.cumsum(valid, 1) - 1
     dest = torch.where(valid, dest, torch.full_like(dest, T))   # rejected -> overflow column

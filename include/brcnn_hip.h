@@ -88,6 +88,21 @@ int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights
  * accumulation (bit-identical to mmcv's CPU kernel; ~1.5x the L2 reads). */
 int brcnn_roi_align_set_exact(int exact);
 
+/* Whole-batch candidate preparation / collection around brcnn_nms for fixed per-image slots of
+ * `slot` candidates (the device-resident form of mmcv.ops.batched_nms below split_thr, called per
+ * image by atss_rpn_head.py:756 and bbox_nms.py:86): brcnn_nms_prepare compacts the valid rows of
+ * every slot in order (zeros behind them), writes `nms_boxes = box + float(id) * (max + 1)` with
+ * max = the slot's largest surviving coordinate (mmcv's class / level separation, same fp32
+ * operations) and the slot's [begin, end) range; brcnn_nms_collect gathers the first
+ * min(num[b], max_keep) survivors of each slot into dets (batch, max_keep, 5) / ids_kept (zeros / -1
+ * behind them).  ids int64, valid one byte per row. */
+int brcnn_nms_prepare(const float *boxes, const float *scores, const int64_t *ids, const uint8_t *valid,
+                      float *c_boxes, float *c_scores, int64_t *c_ids, float *nms_boxes, int32_t *ranges,
+                      int batch, int slot, void *stream);
+int brcnn_nms_collect(const int64_t *keep, const int32_t *num, const float *c_boxes, const float *c_scores,
+                      const int64_t *c_ids, float *dets, int64_t *ids_kept, int batch, int slot,
+                      int max_keep, void *stream);
+
 /* ------------------------------------------------------------------------------
  * NMS.  Replaces mmcv.ops.nms (ext `nms(boxes, scores, iou_threshold, offset)`),
  * reached through mmcv batched_nms at atss_rpn_head.py:756, rpn_head.py:245 and

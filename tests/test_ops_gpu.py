@@ -659,3 +659,24 @@ def test_groupnorm_multi_backward_matches_torch(dtype, relu):
         r0 += n
     assert (gg.grad.double().cpu() - gr.grad).abs().max().item() <= tol * gr.grad.abs().max().item() + 1e-4
     assert (bg.grad.double().cpu() - br.grad).abs().max().item() <= tol * br.grad.abs().max().item() + 1e-4
+
+
+def test_batched_nms_images_fused_equals_torch_formulation():
+    """brcnn_nms_prepare / brcnn_nms_collect (two launches around the segmented NMS) against the
+    ~30-op torch formulation of the same steps: compaction, max-coordinate offsets, ranges,
+    survivor gather -- bit for bit, incl. an empty image and an all-valid one"""
+    from brcnn.postprocess import batched_nms_images
+    g = torch.Generator().manual_seed(21)
+    B, T = 4, 1500
+    boxes = util.clustered_boxes(B * T, n_clusters=60, seed=21).view(B, T, 4)
+    scores = torch.rand(B, T, generator=g)
+    ids = torch.randint(0, 5, (B, T), generator=g)
+    valid = torch.rand(B, T, generator=g) > 0.3
+    valid[1] = False
+    valid[2] = True
+    args = [t.to(DEV) for t in (boxes, scores, ids, valid)]
+    for max_keep in (100, -1):
+        a = batched_nms_images(*args, 0.7, max_keep, fused=True)
+        b = batched_nms_images(*args, 0.7, max_keep, fused=False)
+        assert torch.equal(a[2], b[2]) and int(a[2][1]) == 0 and int(a[2].sum()) > 50
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), max_keep
