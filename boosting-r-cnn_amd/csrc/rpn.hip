@@ -40,6 +40,46 @@ struct DecodeParams {
     int clip;
 };
 
+// decode of one picked anchor (delta_xywh_bbox_coder.py:145-272 on the grid anchor the flat index
+// denotes): returns the clipped box, *ok = both sides longer than min_size
+__device__ __forceinline__ float4 decode_one(long long idx, int b, const float* __restrict__ bbox_pred,
+                                             const float* __restrict__ base_anchors, int hwA, int width, int A,
+                                             int stride_w, int stride_h, int pred_stride, float pred_scale,
+                                             const DecodeParams& dp, bool* ok) {
+    const int a = (int)(idx % A);
+    const long long cell = idx / A;
+    const int cx = (int)(cell % width), cy = (int)(cell / width);
+    const float sx = (float)(cx * stride_w), sy = (float)(cy * stride_h);
+    const float4 ba = *reinterpret_cast<const float4*>(base_anchors + a * 4);
+    const float x1 = ba.x + sx, y1 = ba.y + sy, x2 = ba.z + sx, y2 = ba.w + sy;
+    const float* dptr = bbox_pred + ((size_t)b * (hwA / A) + cell) * pred_stride + a * 4;
+    float4 d = make_float4(dptr[0], dptr[1], dptr[2], dptr[3]);
+    if (pred_scale != 1.f) {
+        d.x *= pred_scale; d.y *= pred_scale; d.z *= pred_scale; d.w *= pred_scale;
+    }
+    const float dx = d.x * dp.std[0] + dp.mean[0];
+    const float dy = d.y * dp.std[1] + dp.mean[1];
+    float dw = d.z * dp.std[2] + dp.mean[2];
+    float dh = d.w * dp.std[3] + dp.mean[3];
+    const float px = (x1 + x2) * 0.5f, py = (y1 + y2) * 0.5f;
+    const float pw = x2 - x1, ph = y2 - y1;
+    const float dxw = pw * dx, dyh = ph * dy;
+    dw = fminf(fmaxf(dw, -dp.max_ratio), dp.max_ratio);
+    dh = fminf(fmaxf(dh, -dp.max_ratio), dp.max_ratio);
+    const float gw = pw * expf(dw), gh = ph * expf(dh);
+    const float gx = px + dxw, gy = py + dyh;
+    float ox1 = gx - gw * 0.5f, oy1 = gy - gh * 0.5f;
+    float ox2 = gx + gw * 0.5f, oy2 = gy + gh * 0.5f;
+    if (dp.clip) {
+        ox1 = ox1 < 0.f ? 0.f : ox1; ox1 = ox1 > dp.max_w ? dp.max_w : ox1;
+        oy1 = oy1 < 0.f ? 0.f : oy1; oy1 = oy1 > dp.max_h ? dp.max_h : oy1;
+        ox2 = ox2 < 0.f ? 0.f : ox2; ox2 = ox2 > dp.max_w ? dp.max_w : ox2;
+        oy2 = oy2 < 0.f ? 0.f : oy2; oy2 = oy2 > dp.max_h ? dp.max_h : oy2;
+    }
+    *ok = (ox2 - ox1) > dp.min_size && (oy2 - oy1) > dp.min_size;
+    return make_float4(ox1, oy1, ox2, oy2);
+}
+
 // inds: (batch, count) flat anchor indices of one level; bbox_pred: (batch, H*W*A, 4)
 __global__ __launch_bounds__(256) void rpn_decode_kernel(
     const int64_t* __restrict__ inds, const float* __restrict__ bbox_pred,
@@ -49,40 +89,46 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
     const long long total = (long long)batch * count;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(t / count);
-        const long long idx = inds[t];
-        const int a = (int)(idx % A);
-        const long long cell = idx / A;
-        const int cx = (int)(cell % width), cy = (int)(cell / width);
-        const float sx = (float)(cx * stride_w), sy = (float)(cy * stride_h);
-        const float4 ba = *reinterpret_cast<const float4*>(base_anchors + a * 4);
-        const float x1 = ba.x + sx, y1 = ba.y + sy, x2 = ba.z + sx, y2 = ba.w + sy;
-        const float* dptr = bbox_pred + ((size_t)b * (hwA / A) + cell) * dp.pred_stride + a * 4;
-        float4 d = make_float4(dptr[0], dptr[1], dptr[2], dptr[3]);
-        if (dp.pred_scale != 1.f) {
-            d.x *= dp.pred_scale; d.y *= dp.pred_scale; d.z *= dp.pred_scale; d.w *= dp.pred_scale;
-        }
-        const float dx = d.x * dp.std[0] + dp.mean[0];
-        const float dy = d.y * dp.std[1] + dp.mean[1];
-        float dw = d.z * dp.std[2] + dp.mean[2];
-        float dh = d.w * dp.std[3] + dp.mean[3];
-        const float px = (x1 + x2) * 0.5f, py = (y1 + y2) * 0.5f;
-        const float pw = x2 - x1, ph = y2 - y1;
-        const float dxw = pw * dx, dyh = ph * dy;
-        dw = fminf(fmaxf(dw, -dp.max_ratio), dp.max_ratio);
-        dh = fminf(fmaxf(dh, -dp.max_ratio), dp.max_ratio);
-        const float gw = pw * expf(dw), gh = ph * expf(dh);
-        const float gx = px + dxw, gy = py + dyh;
-        float ox1 = gx - gw * 0.5f, oy1 = gy - gh * 0.5f;
-        float ox2 = gx + gw * 0.5f, oy2 = gy + gh * 0.5f;
-        if (dp.clip) {
-            ox1 = ox1 < 0.f ? 0.f : ox1; ox1 = ox1 > dp.max_w ? dp.max_w : ox1;
-            oy1 = oy1 < 0.f ? 0.f : oy1; oy1 = oy1 > dp.max_h ? dp.max_h : oy1;
-            ox2 = ox2 < 0.f ? 0.f : ox2; ox2 = ox2 > dp.max_w ? dp.max_w : ox2;
-            oy2 = oy2 < 0.f ? 0.f : oy2; oy2 = oy2 > dp.max_h ? dp.max_h : oy2;
-        }
-        *reinterpret_cast<float4*>(proposals + (size_t)t * 4) = make_float4(ox1, oy1, ox2, oy2);
-        if (valid) valid[t] = ((ox2 - ox1) > dp.min_size && (oy2 - oy1) > dp.min_size) ? 1 : 0;
+        bool ok;
+        const float4 o = decode_one(inds[t], (int)(t / count), bbox_pred, base_anchors, hwA, width, A, stride_w,
+                                    stride_h, dp.pred_stride, dp.pred_scale, dp, &ok);
+        *reinterpret_cast<float4*>(proposals + (size_t)t * 4) = o;
+        if (valid) valid[t] = ok ? 1 : 0;
+    }
+}
+
+// all pyramid levels of the proposal stage in one launch: the picked anchors of level l occupy
+// columns [col0[l], col0[l+1]) of the (batch, T) candidate slots; also writes the level id column
+struct DecodeLevels {
+    int num;
+    const int64_t* inds[BRCNN_MAX_LEVELS];
+    const float* pred[BRCNN_MAX_LEVELS];
+    const float* base[BRCNN_MAX_LEVELS];
+    int pred_stride[BRCNN_MAX_LEVELS], hwA[BRCNN_MAX_LEVELS], width[BRCNN_MAX_LEVELS];
+    int stride_w[BRCNN_MAX_LEVELS], stride_h[BRCNN_MAX_LEVELS], col0[BRCNN_MAX_LEVELS + 1];
+    float pred_scale[BRCNN_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void rpn_decode_levels_kernel(DecodeLevels lv, int batch, int A, DecodeParams dp,
+                                                               float* __restrict__ proposals,
+                                                               uint8_t* __restrict__ valid, int64_t* __restrict__ ids) {
+    const int T = lv.col0[lv.num];
+    const long long total = (long long)batch * T;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / T), col = (int)(t - (long long)b * T);
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < BRCNN_MAX_LEVELS; i++)
+            if (i < lv.num && col >= lv.col0[i]) l = i;
+        const int count = lv.col0[l + 1] - lv.col0[l];
+        const long long idx = lv.inds[l][(size_t)b * count + (col - lv.col0[l])];
+        bool ok;
+        const float4 o = decode_one(idx, b, lv.pred[l], lv.base[l], lv.hwA[l], lv.width[l], A, lv.stride_w[l],
+                                    lv.stride_h[l], lv.pred_stride[l], lv.pred_scale[l], dp, &ok);
+        *reinterpret_cast<float4*>(proposals + (size_t)t * 4) = o;
+        valid[t] = ok ? 1 : 0;
+        ids[t] = l;
     }
 }
 
@@ -260,6 +306,49 @@ BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
+
+BRCNN_API int brcnn_rpn_decode_levels(const int64_t* const* topk_inds, const float* const* bbox_pred,
+                                      const int* pred_strides, const float* pred_scales,
+                                      const float* const* base_anchors, int batch, int num_levels, const int* counts,
+                                      const int* heights, const int* widths, int num_anchors, const int* strides_w,
+                                      const int* strides_h, const float* means4_host, const float* stds4_host,
+                                      double wh_ratio_clip, float max_h, float max_w, float min_size,
+                                      float* proposals, uint8_t* valid, int64_t* ids, void* stream) {
+    if (batch < 0 || num_levels <= 0 || num_levels > BRCNN_MAX_LEVELS || num_anchors <= 0 || !topk_inds || !bbox_pred ||
+        !pred_strides || !pred_scales || !base_anchors || !counts || !heights || !widths || !strides_w || !strides_h ||
+        !means4_host || !stds4_host || !(wh_ratio_clip > 0.0) || !proposals || !valid || !ids)
+        return BRCNN_EINVAL;
+    DecodeLevels lv = {};
+    lv.num = num_levels;
+    int T = 0;
+    for (int l = 0; l < num_levels; l++) {
+        if (counts[l] <= 0 || heights[l] <= 0 || widths[l] <= 0 || pred_strides[l] < 4 * num_anchors || !topk_inds[l] ||
+            !bbox_pred[l] || !base_anchors[l])
+            return BRCNN_EINVAL;
+        lv.inds[l] = topk_inds[l]; lv.pred[l] = bbox_pred[l]; lv.base[l] = base_anchors[l];
+        lv.pred_stride[l] = pred_strides[l]; lv.pred_scale[l] = pred_scales[l];
+        lv.hwA[l] = heights[l] * widths[l] * num_anchors; lv.width[l] = widths[l];
+        lv.stride_w[l] = strides_w[l]; lv.stride_h[l] = strides_h[l];
+        lv.col0[l] = T;
+        T += counts[l];
+    }
+    for (int l = num_levels; l <= BRCNN_MAX_LEVELS; l++) lv.col0[l] = T;
+    if (batch == 0) return 0;
+    DecodeParams dp;
+    for (int i = 0; i < 4; i++) { dp.mean[i] = means4_host[i]; dp.std[i] = stds4_host[i]; }
+    dp.max_ratio = (float)fabs(log(wh_ratio_clip));
+    dp.clip = (max_h > 0.f && max_w > 0.f) ? 1 : 0;
+    dp.max_h = max_h; dp.max_w = max_w; dp.min_size = min_size;
+    dp.pred_scale = 1.f; dp.pred_stride = 0;
+    const long long total = (long long)batch * T;
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rpn_decode_levels_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, lv, batch, num_anchors,
+                       dp, proposals, valid, ids);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 
 namespace {
 constexpr int TOPK_SPLIT_MIN = 32768;      // levels at least this long are selected in parts

@@ -487,6 +487,18 @@ class ATSSRPNHead(AnchorHead):
                     picked.append((ranked[:, :cfg.nms_pre], rank_inds[:, :cfg.nms_pre].contiguous()))
                 else:
                     picked.append((score, torch.arange(n, device=device).expand(B, n).contiguous()))
+        if len(shapes) == 1 and cfg.min_bbox_size >= 0 and hasattr(ops, 'rpn_decode_levels') and device.type == 'cuda':
+            # one image shape in the batch (the usual case): every level decoded by one launch that
+            # also writes the validity and level-id columns of the (B, T) candidate slots
+            L = len(cls_nhwc)
+            props, valid, ids = ops.rpn_decode_levels(
+                [picked[l][1] for l in range(L)], [reg_nhwc[l] for l in range(L)],
+                [self._base_anchors(l, device) for l in range(L)], [tuple(cls_nhwc[l].shape[1:3]) for l in range(L)],
+                list(self.anchor_generator.strides), self.bbox_coder.means, self.bbox_coder.stds, next(iter(shapes)),
+                cfg.min_bbox_size, pred_scales=None if reg_scales is None else list(reg_scales))
+            sc_l = [picked[l][0] for l in range(L)]
+            scores = torch.cat(sc_l, 1)
+            return self._proposals_from_candidates(props, scores, ids, valid, sc_l, nms_cfg, cfg)
         for lvl in range(len(cls_nhwc)):
             h, w = cls_nhwc[lvl].shape[1:3]
             score, topk_inds = picked[lvl]
@@ -519,6 +531,10 @@ class ATSSRPNHead(AnchorHead):
         props = torch.cat(pr_l, 1)             # (B, T, 4)
         valid = torch.cat(va_l, 1)             # (B, T)  `proposals[valid_mask]` (:750-754)
         ids = torch.cat(id_l, 1)
+        return self._proposals_from_candidates(props, scores, ids, valid, sc_l, nms_cfg, cfg)
+
+    @staticmethod
+    def _proposals_from_candidates(props, scores, ids, valid, sc_l, nms_cfg, cfg):
         if scores.shape[1] >= nms_cfg.get('split_thr', 10000):
             # mmcv batched_nms switches to its per-id (per-level) loop at >= split_thr candidates
             # (the training proposal cfg: 15 150 per image).  Both of its branches keep the same

@@ -59,6 +59,8 @@ SIGNATURES = {
     'brcnn_rpn_score': (c_int, [c_ptr] * 3 + [c_i64, c_int, c_int, c_int, c_ptr]),
     'brcnn_rpn_decode': (c_int, [c_ptr] * 2 + [c_int, c_f32, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr, c_f64, c_f32, c_f32,
                                                              c_f32, c_ptr, c_ptr, c_ptr]),
+    'brcnn_rpn_decode_levels': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
+                                        c_f64, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     'brcnn_conv_set_tile_wgrad_bf16': (c_int, [c_int]),
     'brcnn_bn_act_forward': (c_int, [c_ptr] * 5 + [c_i64, c_int, c_int, c_int, c_ptr]),
     'brcnn_bn_act_backward_workspace_bytes': (ctypes.c_size_t, [c_i64, c_int, c_int]),

@@ -773,6 +773,45 @@ def rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds,
     return props, valid
 
 
+def rpn_decode_levels(topk_inds, bbox_preds, base_anchors, feat_hws, strides, means, stds, max_shape, min_size,
+                      wh_ratio_clip=16 / 1000, pred_scales=None):
+    """rpn_decode for all levels in one launch.  Per-level lists: topk_inds (B,k_l) int64, bbox_preds
+    (B,H_l,W_l,4A) NHWC (possibly channel slices), base_anchors (A,4), feat_hws, strides.
+    Returns proposals (B,T,4), valid (B,T) bool, ids (B,T) int64 (level index), T = sum k_l."""
+    import ctypes
+    L = len(topk_inds)
+    _require_gpu(*topk_inds, *bbox_preds, *base_anchors)
+    b = topk_inds[0].shape[0]
+    a = base_anchors[0].size(0)
+    inds = [t.contiguous() for t in topk_inds]
+    bases = [t.contiguous().float() for t in base_anchors]
+    pstr = []
+    for p_ in bbox_preds:
+        _, a4, ps = _last_dim_strided(p_)
+        assert a4 == 4 * a
+        pstr.append(int(ps))
+    counts = [int(t.shape[1]) for t in inds]
+    T = sum(counts)
+    dev = bbox_preds[0].device
+    props = torch.empty((b, T, 4), dtype=torch.float32, device=dev)
+    valid = torch.empty((b, T), dtype=torch.bool, device=dev)
+    ids = torch.empty((b, T), dtype=torch.int64, device=dev)
+    ptrs = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])     # noqa: E731
+    ints = lambda vs: (ctypes.c_int * L)(*[int(v) for v in vs])               # noqa: E731
+    sw = [s_ if isinstance(s_, int) else s_[0] for s_ in strides]
+    sh = [s_ if isinstance(s_, int) else s_[1] for s_ in strides]
+    scales = (ctypes.c_float * L)(*[float(v) for v in (pred_scales or [1.0] * L)])
+    m4 = (ctypes.c_float * 4)(*[float(v) for v in means])
+    s4 = (ctypes.c_float * 4)(*[float(v) for v in stds])
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    st = _L.load().brcnn_rpn_decode_levels(ptrs(inds), ptrs(bbox_preds), ints(pstr), scales, ptrs(bases), b, L,
+                                           ints(counts), ints([h for h, _ in feat_hws]), ints([w for _, w in feat_hws]),
+                                           a, ints(sw), ints(sh), m4, s4, float(wh_ratio_clip), mh, mw, float(min_size),
+                                           _ptr(props), _ptr(valid), _ptr(ids), _stream())
+    _L.check(st, 'brcnn_rpn_decode_levels')
+    return props, valid, ids
+
+
 # --------------------------------------------------------------------------- input front door
 _FLIP_CODE = {None: 0, 'horizontal': 1, 'vertical': 2, 'diagonal': 3}
 

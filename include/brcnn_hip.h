@@ -366,6 +366,18 @@ int brcnn_rpn_decode(const int64_t *topk_inds, const float *bbox_pred, int pred_
                      int stride_h, const float *means4_host, const float *stds4_host,
                      double wh_ratio_clip, float max_h, float max_w, float min_size,
                      float *proposals, uint8_t *valid, void *stream);
+
+/* brcnn_rpn_decode for all pyramid levels in one launch: level l's picked anchors (topk_inds[l],
+ * (batch, counts[l])) are decoded into columns [sum counts[:l], +counts[l]) of proposals
+ * (batch, T, 4) / valid (batch, T) / ids (batch, T) (ids = the level index: the `level_ids` of
+ * atss_rpn_head.py:738-740 that batched_nms separates by).  Host arrays of device pointers. */
+int brcnn_rpn_decode_levels(const int64_t *const *topk_inds, const float *const *bbox_pred,
+                            const int *pred_strides, const float *pred_scales,
+                            const float *const *base_anchors, int batch, int num_levels, const int *counts,
+                            const int *heights, const int *widths, int num_anchors, const int *strides_w,
+                            const int *strides_h, const float *means4_host, const float *stds4_host,
+                            double wh_ratio_clip, float max_h, float max_w, float min_size,
+                            float *proposals, uint8_t *valid, int64_t *ids, void *stream);
 size_t brcnn_rpn_topk_workspace_bytes(const int *n_host, int num_levels, int batch, int k);
 int brcnn_rpn_topk(const float *const *score_levels, const int *n_host, int num_levels,
                    int batch, int k, float *const *out_score, int64_t *const *out_idx,
