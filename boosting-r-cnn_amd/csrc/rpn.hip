@@ -133,6 +133,57 @@ __global__ __launch_bounds__(256) void rpn_decode_levels_kernel(DecodeLevels lv,
 }
 
 
+// ---- second-stage candidates of a whole batch (prob_roi_head.py:232-240 score fusion,
+// convfc_bbox_head.py:294-330 get_bboxes up to the NMS call): per (image, proposal, class)
+//     score = sqrt(softmax_c * prior),  box = delta2bbox(proposal, deltas[4c:4c+4]) clipped to the
+//     image and divided by its scale factor,  valid = score > thr and the proposal row is real.
+// `probs` are the softmax outputs (all C+1 columns, the background column is not emitted).
+__global__ __launch_bounds__(256) void rcnn_decode_kernel(const float* __restrict__ probs, const float* __restrict__ bbox_pred,
+                                                         const float* __restrict__ props, const int* __restrict__ num,
+                                                         const float* __restrict__ max_shape, const float* __restrict__ scale,
+                                                         int B, int K, int C, float score_thr, DecodeParams dp,
+                                                         float* __restrict__ boxes, float* __restrict__ scores,
+                                                         int64_t* __restrict__ labels, uint8_t* __restrict__ valid) {
+    const long long total = (long long)B * K * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long long bk = t / C;
+        const int b = (int)(bk / K), k = (int)(bk - (long long)b * K);
+        const float* pr = props + bk * 5;            // x1, y1, x2, y2, prior
+        const float s = sqrtf(probs[bk * (C + 1) + c] * pr[4]);
+        const float4 d = *reinterpret_cast<const float4*>(bbox_pred + bk * 4 * C + 4 * c);
+        const float x1 = pr[0], y1 = pr[1], x2 = pr[2], y2 = pr[3];
+        const float dx = d.x * dp.std[0] + dp.mean[0];
+        const float dy = d.y * dp.std[1] + dp.mean[1];
+        float dw = d.z * dp.std[2] + dp.mean[2];
+        float dh = d.w * dp.std[3] + dp.mean[3];
+        const float px = (x1 + x2) * 0.5f, py = (y1 + y2) * 0.5f;
+        const float pw = x2 - x1, ph = y2 - y1;
+        const float dxw = pw * dx, dyh = ph * dy;
+        dw = fminf(fmaxf(dw, -dp.max_ratio), dp.max_ratio);
+        dh = fminf(fmaxf(dh, -dp.max_ratio), dp.max_ratio);
+        const float gw = pw * expf(dw), gh = ph * expf(dh);
+        const float gx = px + dxw, gy = py + dyh;
+        float ox1 = gx - gw * 0.5f, oy1 = gy - gh * 0.5f;
+        float ox2 = gx + gw * 0.5f, oy2 = gy + gh * 0.5f;
+        const float mh = max_shape[2 * b], mw = max_shape[2 * b + 1];
+        ox1 = ox1 < 0.f ? 0.f : ox1; ox1 = ox1 > mw ? mw : ox1;
+        oy1 = oy1 < 0.f ? 0.f : oy1; oy1 = oy1 > mh ? mh : oy1;
+        ox2 = ox2 < 0.f ? 0.f : ox2; ox2 = ox2 > mw ? mw : ox2;
+        oy2 = oy2 < 0.f ? 0.f : oy2; oy2 = oy2 > mh ? mh : oy2;
+        if (scale) {
+            const float* sf = scale + 4 * b;
+            ox1 = ox1 / sf[0]; oy1 = oy1 / sf[1]; ox2 = ox2 / sf[2]; oy2 = oy2 / sf[3];
+        }
+        *reinterpret_cast<float4*>(boxes + t * 4) = make_float4(ox1, oy1, ox2, oy2);
+        scores[t] = s;
+        labels[t] = c;
+        valid[t] = (s > score_thr && k < num[b]) ? 1 : 0;
+    }
+}
+
+
 // ---- per-(image, level) top-k of the proposal scores (atss_rpn_head.py:727-737 sorts the
 // level and keeps nms_pre; the shared tie rule is descending score, ascending index) --------
 // One 1024-thread workgroup per (image, level).  Four 8-bit radix-select passes over the
@@ -303,6 +354,27 @@ BRCNN_API int brcnn_rpn_decode(const int64_t* topk_inds, const float* bbox_pred,
     hipLaunchKernelGGL(rpn_decode_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
                        topk_inds, bbox_pred, base_anchors, batch, count, height * width * num_anchors,
                        width, num_anchors, stride_w, stride_h, dp, proposals, valid);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_rcnn_decode(const float* probs, const float* bbox_pred, const float* proposals, const int32_t* num,
+                                const float* max_shape, const float* scale_factor, int batch, int per_image,
+                                int num_classes, float score_thr, const float* means4_host, const float* stds4_host,
+                                double wh_ratio_clip, float* boxes, float* scores, int64_t* labels, uint8_t* valid,
+                                void* stream) {
+    if (!probs || !bbox_pred || !proposals || !num || !max_shape || !boxes || !scores || !labels || !valid ||
+        batch <= 0 || per_image <= 0 || num_classes <= 0 || !means4_host || !stds4_host || !(wh_ratio_clip > 0.0))
+        return BRCNN_EINVAL;
+    DecodeParams dp = {};
+    for (int i = 0; i < 4; i++) { dp.mean[i] = means4_host[i]; dp.std[i] = stds4_host[i]; }
+    dp.max_ratio = (float)fabs(log(wh_ratio_clip));
+    const long long total = (long long)batch * per_image * num_classes;
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rcnn_decode_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, probs, bbox_pred, proposals,
+                       num, max_shape, scale_factor, batch, per_image, num_classes, score_thr, dp, boxes, scores, labels,
+                       valid);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     'brcnn_rpn_score': (c_int, [c_ptr] * 3 + [c_i64, c_int, c_int, c_int, c_ptr]),
     'brcnn_rpn_decode': (c_int, [c_ptr] * 2 + [c_int, c_f32, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr, c_f64, c_f32, c_f32,
                                                              c_f32, c_ptr, c_ptr, c_ptr]),
+    'brcnn_rcnn_decode': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int, c_f32, c_ptr, c_ptr, c_f64] + [c_ptr] * 5),
     'brcnn_rpn_decode_levels': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                                         c_f64, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     'brcnn_conv_set_tile_wgrad_bf16': (c_int, [c_int]),

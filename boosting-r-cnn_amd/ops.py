@@ -812,6 +812,32 @@ def rpn_decode_levels(topk_inds, bbox_preds, base_anchors, feat_hws, strides, me
     return props, valid, ids
 
 
+def rcnn_decode(probs, bbox_pred, dets, num, max_shape, scale_factor, num_classes, score_thr, means, stds,
+                wh_ratio_clip=16 / 1000):
+    """Fused second-stage candidates (brcnn_rcnn_decode): probs (B*K, C+1), bbox_pred (B*K, 4C), dets (B,K,5)
+    padded proposals with priors, num (B,) int32, max_shape (B,2), scale_factor (B,4) or None.
+    Returns boxes (B,K*C,4), scores (B,K*C), labels (B,K*C) int64, valid (B,K*C) bool."""
+    import ctypes
+    _require_gpu(probs, bbox_pred, dets, num, max_shape, scale_factor)
+    B, K, _ = dets.shape
+    C = int(num_classes)
+    assert probs.shape == (B * K, C + 1) and bbox_pred.shape == (B * K, 4 * C)
+    probs, bbox_pred, dets = probs.contiguous().float(), bbox_pred.contiguous().float(), dets.contiguous().float()
+    dev = dets.device
+    boxes = torch.empty((B, K * C, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, K * C), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, K * C), dtype=torch.int64, device=dev)
+    valid = torch.empty((B, K * C), dtype=torch.bool, device=dev)
+    m4 = (ctypes.c_float * 4)(*[float(v) for v in means])
+    s4 = (ctypes.c_float * 4)(*[float(v) for v in stds])
+    sf = scale_factor.contiguous().float() if scale_factor is not None else None
+    st = _L.load().brcnn_rcnn_decode(_ptr(probs), _ptr(bbox_pred), _ptr(dets), _ptr(num.to(torch.int32).contiguous()),
+                                     _ptr(max_shape.contiguous().float()), _ptr(sf), B, K, C, float(score_thr), m4, s4,
+                                     float(wh_ratio_clip), _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(valid), _stream())
+    _L.check(st, 'brcnn_rcnn_decode')
+    return boxes, scores, labels, valid
+
+
 # --------------------------------------------------------------------------- input front door
 _FLIP_CODE = {None: 0, 'horizontal': 1, 'vertical': 2, 'diagonal': 3}
 

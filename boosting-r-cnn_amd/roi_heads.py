@@ -570,9 +570,19 @@ class ProbRoIHead(nn.Module):
         prior = dets[..., 4].reshape(-1)
         roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, rois)
         cls_score, bbox_pred = head.forward_nhwc(roi_feats)
-        scores = self.fuse_scores(cls_score, prior).view(B, K, C + 1)
         # per-image clip border / rescale (image shapes are host metadata)
         max_shape = const_rows([m['img_shape'][:2] for m in img_metas], dets)
+        coder = head.bbox_coder
+        if not split and self.prob and type(self).fuse_scores is ProbRoIHead.fuse_scores and dets.is_cuda and \
+                cls_score.dtype == torch.float32 and not getattr(coder, 'add_ctr_clamp', False) and \
+                getattr(coder, 'clip_border', True) and hasattr(ops, 'rcnn_decode'):
+            # score fusion, per-class decode, clip, rescale, threshold: one launch after the softmax
+            sf = const_rows([list(m['scale_factor']) for m in img_metas], dets) if rescale else None
+            bb, sc, lb, va = ops.rcnn_decode(cls_score.softmax(1), bbox_pred, dets, num, max_shape, sf, C,
+                                             cfg.score_thr, coder.means, coder.stds)
+            return batched_nms_images(bb, sc, lb, va, nms_cfg['iou_threshold'], cfg.max_per_img,
+                                      nms_cfg.get('offset', 0))
+        scores = self.fuse_scores(cls_score, prior).view(B, K, C + 1)
         bboxes = head.bbox_coder.decode(rois[:, 1:].view(B, K, 4), bbox_pred.view(B, K, 4 * C),
                                         max_shape=max_shape)
         if rescale:

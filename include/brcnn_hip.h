@@ -378,6 +378,19 @@ int brcnn_rpn_decode_levels(const int64_t *const *topk_inds, const float *const 
                             const int *strides_h, const float *means4_host, const float *stds4_host,
                             double wh_ratio_clip, float max_h, float max_w, float min_size,
                             float *proposals, uint8_t *valid, int64_t *ids, void *stream);
+
+/* Second-stage candidates of a whole batch in one launch: the score fusion of
+ * prob_roi_head.py:232-240 and ProbConvFCBBoxHead.get_bboxes (convfc_bbox_head.py:294-330) up to
+ * the NMS call.  probs (batch*per_image, C+1) softmax outputs, bbox_pred (batch*per_image, 4C),
+ * proposals (batch, per_image, 5) [x1,y1,x2,y2,prior] zero padded with num[b] real rows,
+ * max_shape (batch, 2) [h, w], scale_factor (batch, 4) or NULL.  Writes, in (proposal, class)
+ * order, boxes (batch, per_image*C, 4), scores = sqrt(prob * prior), labels = class, valid =
+ * score > score_thr and the row is real. */
+int brcnn_rcnn_decode(const float *probs, const float *bbox_pred, const float *proposals, const int32_t *num,
+                      const float *max_shape, const float *scale_factor, int batch, int per_image,
+                      int num_classes, float score_thr, const float *means4_host, const float *stds4_host,
+                      double wh_ratio_clip, float *boxes, float *scores, int64_t *labels, uint8_t *valid,
+                      void *stream);
 size_t brcnn_rpn_topk_workspace_bytes(const int *n_host, int num_levels, int batch, int k);
 int brcnn_rpn_topk(const float *const *score_levels, const int *n_host, int num_levels,
                    int batch, int k, float *const *out_score, int64_t *const *out_idx,

@@ -680,3 +680,33 @@ def test_batched_nms_images_fused_equals_torch_formulation():
         b = batched_nms_images(*args, 0.7, max_keep, fused=False)
         assert torch.equal(a[2], b[2]) and int(a[2][1]) == 0 and int(a[2].sum()) > 50
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), max_keep
+
+
+def test_rcnn_decode_fused_equals_torch_chain():
+    """brcnn_rcnn_decode (score fusion + per-class delta2bbox + clip + rescale + threshold in one
+    launch) against the torch chain of ProbRoIHead.simple_test_padded on the same inputs"""
+    from brcnn.core import DeltaXYWHBBoxCoder
+    g = torch.Generator().manual_seed(31)
+    B, K, C = 3, 200, 4
+    dets = torch.cat([util.rand_boxes(B * K, seed=31), torch.rand(B * K, 1, generator=g)], 1).view(B, K, 5)
+    num = torch.tensor([200, 57, 0], dtype=torch.int32)
+    cls_score = torch.randn(B * K, C + 1, generator=g) * 2
+    bbox_pred = torch.randn(B * K, 4 * C, generator=g) * 0.5
+    bbox_pred[0, :4] = torch.tensor([0., 0., 60., -60.])        # clamp edges
+    max_shape = torch.tensor([[800., 1333.], [750., 1200.], [640., 640.]])
+    sf = torch.tensor([[1.1, 1.2, 1.1, 1.2], [1., 1., 1., 1.], [0.5, 0.5, 0.5, 0.5]])
+    coder = DeltaXYWHBBoxCoder(target_means=(0., 0., 0., 0.), target_stds=(0.1, 0.1, 0.2, 0.2))
+    d = lambda t: t.to(DEV)   # noqa: E731
+    probs = d(cls_score).softmax(1)
+    bb, sc, lb, va = ops.rcnn_decode(probs, d(bbox_pred), d(dets), d(num), d(max_shape), d(sf), C, 0.05,
+                                     coder.means, coder.stds)
+    # torch chain
+    scores = ((probs * d(dets)[..., 4].reshape(-1, 1)) ** 0.5).view(B, K, C + 1)
+    boxes = coder.decode(d(dets)[..., :4], d(bbox_pred).view(B, K, 4 * C), max_shape=d(max_shape))
+    boxes = (boxes.view(B, K, C, 4) / d(sf).view(B, 1, 1, 4)).reshape(B, K * C, 4)
+    row_ok = torch.arange(K, device=DEV)[None, :] < d(num)[:, None]
+    s = scores[..., :C]
+    valid = ((s > 0.05) & row_ok[..., None]).reshape(B, K * C)
+    assert torch.equal(sc, s.reshape(B, K * C)) and torch.equal(va, valid)
+    assert torch.equal(lb, torch.arange(C, device=DEV).view(1, 1, C).expand(B, K, C).reshape(B, K * C))
+    assert util.ulp_diff(bb.cpu(), boxes.cpu()).max().item() <= 2, util.ulp_diff(bb.cpu(), boxes.cpu()).max()
