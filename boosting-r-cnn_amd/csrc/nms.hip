@@ -15,6 +15,7 @@
 //   4. one wavefront per segment walks the mask 64 rows at a time: the in-chunk dependency
 //      is resolved with wave-uniform scalar ops on the diagonal words (v_readlane), the
 //      rows of the survivors are OR-ed into the LDS-resident `removed` vector.
+#include <cstdlib>
 #include "common.h"
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -293,7 +294,57 @@ __global__ __launch_bounds__(256) void nms_collect_kernel(const long long* __res
     }
 }
 
+
+// ---- segments of at most 8192 candidates: sort + gather in one launch ---------------------
+// One 1024-thread workgroup per segment: (score, position) pairs as 64-bit composites
+// [~order_key(score) | position] sorted ascending by a bitonic network in LDS -- i.e. descending
+// score, ties by ascending position, the order of the stable rocPRIM sort -- then the sorted
+// global indices, the boxes in that order and their areas are written directly (replaces iota +
+// segmented radix sort + gather: 154 -> ~45 us for 8 x 4693 RPN candidates).
+__device__ __forceinline__ unsigned order_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // ascending in f
+}
+
+__global__ __launch_bounds__(1024) void seg_sort_gather_kernel(const float* __restrict__ boxes,
+                                                              const float* __restrict__ scores,
+                                                              const int32_t* __restrict__ seg_begin,
+                                                              const int32_t* __restrict__ seg_end,
+                                                              int32_t* __restrict__ idx_out, float* __restrict__ sboxes,
+                                                              float* __restrict__ sareas, int offset) {
+    extern __shared__ unsigned long long comp[];
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    const int beg = seg_begin[seg], len = seg_end[seg] - beg;
+    if (len <= 0) return;
+    int P = 64;
+    while (P < len) P <<= 1;
+    for (int i = tid; i < P; i += 1024)
+        comp[i] = i < len ? (((unsigned long long)(~order_key(scores[beg + i])) << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // index with bit j clear
+                const int hi = lo | j;
+                const unsigned long long a = comp[lo], b = comp[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) { comp[lo] = b; comp[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < len; i += 1024) {
+        const int src = beg + (int)(comp[i] & 0xffffffffu);
+        idx_out[beg + i] = src;
+        const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)src * 4);
+        *reinterpret_cast<float4*>(sboxes + (size_t)(beg + i) * 4) = b;
+        sareas[beg + i] = (b.z - b.x + offset) * (b.w - b.y + offset);
+    }
+}
+
 }  // namespace
+
+static int g_nms_lds_sort = getenv("BRCNN_NMS_RADIX") ? 0 : 1;     // BRCNN_NMS_RADIX=1: always the rocPRIM sort (A/B)
 
 BRCNN_API size_t brcnn_nms_workspace_bytes(int64_t n, int num_segments, int64_t max_segment_len) {
     if (n <= 0 || num_segments <= 0) return 256;
@@ -320,15 +371,30 @@ BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* 
     NmsWs w = carve(workspace, n, num_segments, words);
     if (w.total > workspace_bytes) return BRCNN_EINVAL;
 
-    hipLaunchKernelGGL(iota_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, w.idx_in, w.idx_out, n);
-    BRCNN_LAUNCH_CHECK();
-    size_t tmp = w.sort_tmp_bytes;
-    BRCNN_HIP_CHECK((rocprim::segmented_radix_sort_pairs_desc(
-        w.sort_tmp, tmp, scores, w.keys_out, (const int32_t*)w.idx_in, w.idx_out, (unsigned)n,
-        (unsigned)num_segments, seg_begin, seg_end, 0, 32, s, false)));
-    hipLaunchKernelGGL(gather_boxes_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, boxes,
-                       (const int32_t*)w.idx_out, w.sboxes, w.sareas, n, offset);
-    BRCNN_LAUNCH_CHECK();
+    if (max_segment_len > 1024 && max_segment_len <= 8192 && g_nms_lds_sort) {   // (shorter segments: rocPRIM's small-segment path is as fast)
+        int P = 64;
+        while (P < max_segment_len) P <<= 1;
+        static bool attr_done = false;
+        if (!attr_done) {
+            BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)seg_sort_gather_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+            attr_done = true;
+        }
+        // rows outside every segment are never read by the mask / reduce kernels
+        hipLaunchKernelGGL(seg_sort_gather_kernel, dim3(num_segments), dim3(1024), (size_t)P * 8, s, boxes, scores,
+                           seg_begin, seg_end, w.idx_out, w.sboxes, w.sareas, offset);
+        BRCNN_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(iota_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, w.idx_in, w.idx_out, n);
+        BRCNN_LAUNCH_CHECK();
+        size_t tmp = w.sort_tmp_bytes;
+        BRCNN_HIP_CHECK((rocprim::segmented_radix_sort_pairs_desc(
+            w.sort_tmp, tmp, scores, w.keys_out, (const int32_t*)w.idx_in, w.idx_out, (unsigned)n,
+            (unsigned)num_segments, seg_begin, seg_end, 0, 32, s, false)));
+        hipLaunchKernelGGL(gather_boxes_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, boxes,
+                           (const int32_t*)w.idx_out, w.sboxes, w.sareas, n, offset);
+        BRCNN_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, num_segments), dim3(64), 0, s,
                        (const float*)w.sboxes, (const float*)w.sareas, seg_begin, seg_end, w.mask, words,
                        iou_threshold, offset);
