@@ -313,6 +313,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+
+// Shader-clock probe: one lane spins for `wall_ticks` ticks of the constant 100 MHz counter and
+// reports how many shader cycles (s_memtime) passed meanwhile: launched on a second stream next
+// to a workload, out[1] / out[0] * 0.1 is the effective shader clock in GHz under that load.
+__global__ void clock_probe_kernel(long long* __restrict__ out, long long wall_ticks) {
+    const long long w0 = wall_clock64(), c0 = clock64();
+    long long w = w0;
+    while (w - w0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w = wall_clock64();
+    }
+    out[0] = w - w0;
+    out[1] = clock64() - c0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_add_kernel(T* __restrict__ dst,
                                                           const T* __restrict__ src, int N,
@@ -559,6 +574,15 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x,
                            (const bf16_t*)dy, (const double*)stats, gsum, gamma, beta, (bf16_t*)dx, sg, batch, channels,
                            groups, relu);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+
+BRCNN_API int brcnn_clock_probe(int64_t* out2, int64_t wall_ticks_100mhz, void* stream) {
+    if (!out2 || wall_ticks_100mhz <= 0) return BRCNN_EINVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)out2,
+                       (long long)wall_ticks_100mhz);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     'brcnn_sigmoid_focal_loss_backward': (c_int, [c_ptr] * 4 + [c_i64, c_i64, c_f32, c_f32, c_ptr]),
     'brcnn_conv2d_nhwc': (c_int, [c_ptr] * 6 + [c_int] * 11 + [c_ptr]),
     'brcnn_conv_set_tile': (c_int, [c_int, c_int]),
+    'brcnn_clock_probe': (c_int, [c_ptr, c_i64, c_ptr]),
     'brcnn_nms_prepare': (c_int, [c_ptr] * 9 + [c_int, c_int, c_ptr]),
     'brcnn_nms_collect': (c_int, [c_ptr] * 7 + [c_int, c_int, c_int, c_ptr]),
     'brcnn_conv2d_nhwc_scatter2': (c_int, [c_ptr] * 3 + [c_int] * 14 + [c_ptr]),

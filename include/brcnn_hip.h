@@ -38,6 +38,13 @@ extern "C" {
 
 /* library / device info -------------------------------------------------------- */
 int brcnn_version(void);
+
+/* Measurement aid: a one-lane kernel that spins for `wall_ticks_100mhz` ticks of the constant
+ * 100 MHz counter and writes {elapsed wall ticks, elapsed shader cycles} to out2 (device, 2 x
+ * int64).  Launched on a second stream beside a workload it gives the effective shader clock
+ * under that load (cycles / ticks * 0.1 GHz) without a profiler attached (tools/clock_under_load.py). */
+int brcnn_clock_probe(int64_t *out2, int64_t wall_ticks_100mhz, void *stream);
+
 /* number of HIP devices visible, or a negative status */
 int brcnn_device_count(void);
 
