@@ -140,16 +140,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x,
                                                       T* __restrict__ y, GnSegs sg, int N, int C,
                                                       int G, int relu) {
     const int cvn = C / (4 * Q), cpg = C / G;
-    const long long total = sg.row0[sg.nseg] * cvn;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int cv = (int)(idx % cvn);
-        const long long row = idx / cvn;
+    // 32-bit index arithmetic (the host checks rows * C < 2^31): the row -> (segment, image) decode
+    // was two 64-bit divisions per thread and iteration
+    const unsigned total = (unsigned)(sg.row0[sg.nseg] * cvn);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned row = idx / (unsigned)cvn;
+        const int cv = (int)(idx - row * (unsigned)cvn);
         int seg = 0;
 #pragma unroll
         for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
-            if (t < sg.nseg && row >= sg.row0[t]) seg = t;
-        const int n = (int)((row - sg.row0[seg]) / sg.hw[seg]);
+            if (t < sg.nseg && row >= (unsigned)sg.row0[t]) seg = t;
+        const int n = (int)((row - (unsigned)sg.row0[seg]) / (unsigned)sg.hw[seg]);
         const size_t sbase = ((size_t)(seg * N + n)) * G;
         float4 v[Q];
 #pragma unroll
@@ -282,16 +283,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                           const float* __restrict__ beta, T* __restrict__ dx,
                                                           GnSegs sg, int N, int C, int G, int relu) {
     const int c4n = C >> 2, cpg = C / G;
-    const long long total = sg.row0[sg.nseg] * c4n;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % c4n);
-        const long long row = idx / c4n;
+    const unsigned total = (unsigned)(sg.row0[sg.nseg] * c4n);      // rows * C < 2^31 checked by the host
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned row = idx / (unsigned)c4n;
+        const int c4 = (int)(idx - row * (unsigned)c4n);
         int seg = 0;
 #pragma unroll
         for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
-            if (t < sg.nseg && row >= sg.row0[t]) seg = t;
-        const int n = (int)((row - sg.row0[seg]) / sg.hw[seg]);
+            if (t < sg.nseg && row >= (unsigned)sg.row0[t]) seg = t;
+        const int n = (int)((row - (unsigned)sg.row0[seg]) / (unsigned)sg.hw[seg]);
         const size_t sbase = ((size_t)(seg * N + n)) * G;
         const float inv_d = 1.f / ((float)sg.hw[seg] * (float)cpg);
         const float4 xv = ld4(x + (size_t)idx * 4);
@@ -453,6 +453,7 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
         if (hw_host[i] > max_hw) max_hw = hw_host[i];
     }
     for (int i = num_segments; i <= BRCNN_MAX_LEVELS; i++) sg.row0[i] = rows;
+    if (rows * channels >= 0x7fffffffLL) return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     BRCNN_HIP_CHECK(hipMemsetAsync(stats_ws, 0,
                                    (size_t)batch * num_segments * groups * 2 * sizeof(double), s));
@@ -545,6 +546,7 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
     long long rows;
     int max_hw;
     if (gn_setup(sg, rows, max_hw, batch, num_segments, hw_host)) return BRCNN_EINVAL;
+    if (rows * channels >= 0x7fffffffLL) return BRCNN_EINVAL;
     int chunks, rpb;
     gn_bwd_chunks(max_hw, &chunks, &rpb);
     hipStream_t s = (hipStream_t)stream;
