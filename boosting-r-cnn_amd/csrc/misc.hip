@@ -28,10 +28,9 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x,
-                                                          T* __restrict__ y, int N, int H,
-                                                          int W, int C, int Ho, int Wo) {
+// one output pixel x 4 channels per thread (fp32: measured 6 % faster than the paired form below)
+__global__ __launch_bounds__(256) void maxpool3x3s2_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                              int H, int W, int C, int Ho, int Wo) {
     const int c4n = C >> 2;
     const long long total = (long long)N * Ho * Wo * c4n;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -54,6 +53,73 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
             }
         }
         st4(y + (size_t)idx * 4, m);
+    }
+}
+
+// 16 bytes of channels (4 fp32 / 8 bf16) of TWO horizontally adjacent output pixels per thread: the
+// pair shares the middle input column, so 15 loads serve 2 outputs (9 each before); 32-bit index
+// arithmetic.  max of bf16 values is exact in fp32, so the bf16 result is bit-identical.
+struct Vec8 { float v[8]; };
+__device__ __forceinline__ void vmax(Vec8& m, const Vec8& x, int n) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) if (e < n) m.v[e] = fmaxf(m.v[e], x.v[e]);
+}
+__device__ __forceinline__ Vec8 ldv(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    Vec8 r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = r.v[5] = r.v[6] = r.v[7] = 0.f;
+    return r;
+}
+__device__ __forceinline__ Vec8 ldv(const bf16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    Vec8 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { r.v[2 * e] = __uint_as_float(w[e] << 16); r.v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    return r;
+}
+__device__ __forceinline__ void stv(float* p, const Vec8& m) { *reinterpret_cast<float4*>(p) = make_float4(m.v[0], m.v[1], m.v[2], m.v[3]); }
+__device__ __forceinline__ void stv(bf16_t* p, const Vec8& m) {
+    uint4 u;
+    u.x = (__float_as_uint(m.v[0]) >> 16) | (__float_as_uint(m.v[1]) & 0xffff0000u);
+    u.y = (__float_as_uint(m.v[2]) >> 16) | (__float_as_uint(m.v[3]) & 0xffff0000u);
+    u.z = (__float_as_uint(m.v[4]) >> 16) | (__float_as_uint(m.v[5]) & 0xffff0000u);
+    u.w = (__float_as_uint(m.v[6]) >> 16) | (__float_as_uint(m.v[7]) & 0xffff0000u);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x,
+                                                          T* __restrict__ y, int N, int H,
+                                                          int W, int C, int Ho, int Wo) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cvn = C / VEC, wp = (Wo + 1) >> 1;
+    const unsigned total = (unsigned)N * Ho * wp * cvn;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int cv = idx % cvn;
+        unsigned r = idx / cvn;
+        const int j = r % wp; r /= wp;
+        const int ho = r % Ho;
+        const int n = r / Ho;
+        Vec8 m0, m1;
+#pragma unroll
+        for (int e = 0; e < 8; e++) m0.v[e] = m1.v[e] = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int hi = ho * 2 - 1 + kh;
+            if (hi < 0 || hi >= H) continue;
+            const T* row = x + ((size_t)n * H + hi) * W * C + cv * VEC;
+#pragma unroll
+            for (int kw = 0; kw < 5; kw++) {
+                const int wi = j * 4 - 1 + kw;
+                if (wi < 0 || wi >= W) continue;
+                const Vec8 v = ldv(row + (size_t)wi * C);
+                if (kw <= 2) vmax(m0, v, VEC);
+                if (kw >= 2) vmax(m1, v, VEC);
+            }
+        }
+        T* out = y + (((size_t)n * Ho + ho) * Wo + 2 * j) * C + cv * VEC;
+        stv(out, m0);
+        if (2 * j + 1 < Wo) stv(out + C, m1);
     }
 }
 
@@ -420,10 +486,13 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int hei
         (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
     const int Ho = (height + 2 - 3) / 2 + 1, Wo = (width + 2 - 3) / 2 + 1;
-    const long long total = (long long)batch * Ho * Wo * (channels >> 2);
+    const int vec = dtype == BRCNN_DT_F32 ? 4 : 8;
+    if (channels % vec) return BRCNN_EINVAL;
+    const long long total = (long long)batch * Ho * ((Wo + 1) / 2) * (channels / vec);
+    if (total >= 0x7fffffffLL) return BRCNN_EINVAL;
     if (dtype == BRCNN_DT_F32)
-        hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(stream_grid(total)), dim3(256), 0,
-                           (hipStream_t)stream, (const float*)x, (float*)y, batch, height, width,
+        hipLaunchKernelGGL(maxpool3x3s2_f32_kernel, dim3(stream_grid((long long)batch * Ho * Wo * (channels >> 2))),
+                           dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, batch, height, width,
                            channels, Ho, Wo);
     else
         hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
