@@ -243,15 +243,37 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, in
             if ((dk & mask) == prefix) atomicAdd(&hist[(dk >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 0;
-            for (; bin < 255; bin++) {
-                if (cum + hist[bin] >= need) break;
-                cum += hist[bin];
+        // the digit whose cumulative count first reaches `need`: a 256-wide scan (a single thread
+        // walking the bins cost ~25 us per launch over the four passes)
+        if (tid < 256) {
+            const int h = hist[tid];
+            int incl = h;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d) incl += o;
             }
-            s_prefix = prefix | ((unsigned)bin << shift);
-            s_need = need - cum;
-            s_ties = hist[bin];
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int h = hist[tid];
+            int incl = h;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d) incl += o;
+            }
+            int woff = 0;
+            for (int w = 0; w < (tid >> 6); w++) woff += wsum[w];
+            incl += woff;
+            const int excl = incl - h;
+            const bool hit = (excl < need && incl >= need) || (tid == 255 && incl < need);
+            if (hit) {
+                s_prefix = prefix | ((unsigned)tid << shift);
+                s_need = need - excl;
+                s_ties = h;
+            }
         }
         __syncthreads();
         prefix = s_prefix;
