@@ -415,7 +415,14 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         // same tile on 4 waves of 64x64 by ~10 %, 128x64 on 8 waves wins on the mid-size maps; the
         // small 4-wave tiles keep the few-tile layers (FC, stage 4) spread over the chip.
         const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-        if (p.Cout <= 64) t = 21;
+        // 256x256 on 16 waves moves half the LDS-DMA bytes per FLOP of the 128x128 tile (980 vs 710
+        // TF/s per full generation), but is one workgroup per CU: only when its tile count fills
+        // whole generations of 256 (the fused RPN tower: 700 tiles)
+        const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
+        const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && t44 >= 512 &&
+                            (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
+        if (fill44) t = 2244;
+        else if (p.Cout <= 64) t = 21;
         else if (t22 < 256) t = 11;
         else if (p.M >= 65536) t = 82;
         else if (p.M >= 16384) t = 81;
@@ -427,6 +434,9 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     if (t == 322 && p.Cout > 64) return launch2<2, 2, 2, 2, 3>(p, s);
     if (t == 482 && p.Cout > 64) return launch2<1, 2, 4, 2, 4>(p, s);
     if (t == 381 || ((t == 342 || t == 382 || t == 3164 || t == 322 || t == 482) && p.Cout <= 64)) return launch2<1, 1, 4, 2, 3>(p, s);
+    if (t == 2244 && p.Cout > 128) return launch2<2, 2, 4, 4>(p, s);   // 256x256 on 16 waves of 64x64
+    if (t == 2144 && p.Cout > 64) return launch2<2, 1, 4, 4>(p, s);    // 256x128 on 16 waves of 64x32
+    if (t == 2244 || t == 2144) t = 82;
     if (t == 42 && p.Cout > 64) return launch2<2, 2, 4>(p, s);
     if (t == 82 && p.Cout > 64) return launch2<1, 2, 4>(p, s);       // 128x128 on 8 waves of 32x64
     if (t == 164 && p.Cout > 64) return launch2<1, 1, 4, 4>(p, s);   // 128x128 on 16 waves of 32x32
@@ -440,7 +450,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
-    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381};
+    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144};
     bool found = false;
     for (int v : ok) found |= (v == mtnt);
     if (!found) return BRCNN_EINVAL;
