@@ -710,3 +710,42 @@ def test_rcnn_decode_fused_equals_torch_chain():
     assert torch.equal(sc, s.reshape(B, K * C)) and torch.equal(va, valid)
     assert torch.equal(lb, torch.arange(C, device=DEV).view(1, 1, C).expand(B, K, C).reshape(B, K * C))
     assert util.ulp_diff(bb.cpu(), boxes.cpu()).max().item() <= 2, util.ulp_diff(bb.cpu(), boxes.cpu()).max()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_multi_level_conv_autograd_matches_torch(dtype):
+    """conv2d_nhwc_multi_autograd: one forward / dgrad / wgrad launch over several pyramid levels
+    that share the weights (the training form of the RPN tower) against torch conv2d per level with
+    the weight gradients summed -- maps wider and narrower than the wgrad tile step (incremental
+    row decode vs full decode), segment boundaries inside a tile"""
+    import torch.nn.functional as F
+    from brcnn.autograd import conv2d_nhwc_multi_autograd
+    g = torch.Generator().manual_seed(41)
+    B, Cin, Cout = 2, 64, 128
+    sizes = [(37, 70), (19, 35), (10, 18), (5, 9)]
+    xs = [torch.randn(B, Cin, h, w, generator=g) for h, w in sizes]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    gos = [torch.randn(B, Cout, h, w, generator=g) for h, w in sizes]
+    if dtype == torch.bfloat16:
+        xs = [t.bfloat16().float() for t in xs]
+        gos = [t.bfloat16().float() for t in gos]
+        wt = wt.bfloat16().float()
+    wr, br = wt.double().requires_grad_(), bias.double().requires_grad_()
+    xr = [t.double().requires_grad_() for t in xs]
+    for x, go in zip(xr, gos):
+        F.conv2d(x, wr, br, 1, 1).backward(go.double())
+    x_cat = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cin) for t in xs]).to(dtype).to(DEV).requires_grad_()
+    wg, bg = wt.to(DEV).requires_grad_(), bias.to(DEV).requires_grad_()
+    y = conv2d_nhwc_multi_autograd(x_cat, wg, bg, B, tuple(sizes), 1, 1)
+    y.backward(torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in gos]).to(dtype).to(DEV))
+    tol = 5e-5 if dtype == torch.float32 else 1.5e-2
+    def rel(a, ref):
+        return (a.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+    r0 = 0
+    for (h, w), x in zip(sizes, xr):
+        n = B * h * w
+        dx = x_cat.grad[r0:r0 + n].float().view(B, h, w, Cin).permute(0, 3, 1, 2)
+        assert rel(dx, x.grad) < tol, (dtype, h, w)
+        r0 += n
+    assert rel(wg.grad, wr.grad) < tol and rel(bg.grad, br.grad) < tol
