@@ -340,3 +340,27 @@ def test_scatter2_conv_bf16_equals_strided_copy():
         assert st == 0
         torch.cuda.synchronize()
         assert torch.equal(out, ref), (kh, kw, ph, pw)
+
+
+def test_bf16_tile_shapes_agree_bit_for_bit():
+    """every workgroup tile shape of the bf16 conv kernel (64x64 ... 256x256, 4 / 8 / 16 waves, the LDS
+    ring variants) accumulates each output over K in the same order: on a layer large enough for all
+    of them (incl. the 256x256 tile the heuristic picks for the fused RPN tower) the results are
+    identical"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 100, 168, 256, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(256, 3, 3, 256, generator=g) * 0.05).bfloat16().to(DEV)
+    sc = (torch.rand(256, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(256, generator=g).to(DEV)
+    try:
+        outs = {}
+        for t in (11, 21, 22, 81, 82, 164, 42, 2244, 2144, 382, 342):
+            assert L.brcnn_conv_set_tile_bf16(t) == 0
+            outs[t] = ops.conv2d_nhwc(x, w, sc, sh, None, True, 1, 1)
+        torch.cuda.synchronize()
+        for t, y in outs.items():
+            assert torch.equal(y, outs[11]), t
+    finally:
+        L.brcnn_conv_set_tile_bf16(0)
