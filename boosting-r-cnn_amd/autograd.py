@@ -28,7 +28,10 @@ class ConvNHWCFunction(Function):
     parameter layout, bias (Cout) or None.  Returns y_cat (rows_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, x_cat, weight, bias, batch, sizes, stride, pad):
+    def forward(ctx, x_cat, weight, bias, batch, sizes, stride, pad, with_skip=False):
+        """`with_skip`: also return an alias of the input (the identity branch of a residual block);
+        its gradient then arrives in THIS backward and is added in the data-gradient kernel's
+        epilogue instead of by a separate autograd add over the whole tensor"""
         _require_gpu(x_cat, weight, bias)
         # fp32 activations: exact-fp32 MFMA; bf16 activations: bf16 MFMA with fp32 accumulation
         # (weights are cast per step from the fp32 master copy, gradients of weights stay fp32)
@@ -51,11 +54,14 @@ class ConvNHWCFunction(Function):
                                              None, False, stride, pad)
         ctx.save_for_backward(x_cat, weight)
         ctx.cfg = (batch, tuple(sizes), tuple(out_sizes), stride, pad, bias is not None)
+        ctx.with_skip = bool(with_skip)
+        if with_skip:
+            return y, x_cat.view_as(x_cat)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x_cat, weight = ctx.saved_tensors
         batch, sizes, out_sizes, stride, pad, has_bias = ctx.cfg
         cout, cin, kh, kw = weight.shape
@@ -71,6 +77,14 @@ class ConvNHWCFunction(Function):
         if ctx.needs_input_grad[0] and stride == 2 and L == 1 and x_cat.dtype == torch.float32 and \
                 (kh, kw, pad) in ((3, 3, 1), (1, 1, 0)) and cout % 32 == 0:
             dx = _dgrad_stride2(dy, weight, batch, sizes[0], out_sizes[0], kh, pad, x_cat.dtype)
+        elif ctx.needs_input_grad[0] and dskip is not None and stride == 1 and L == 1 and kh == kw and \
+                2 * pad == kh - 1 and ctx.w_t is not None and dskip.dtype == x_cat.dtype:
+            # data gradient + the identity branch's gradient in one epilogue (the forward kernel on
+            # the flipped / transposed weights with a residual operand)
+            (h, w_), = sizes
+            dx = ops.conv2d_nhwc(dy.view(batch, h, w_, cout), ctx.w_t, None, None,
+                                 dskip.contiguous().view(batch, h, w_, cin), False, 1, pad).view(batch * h * w_, cin)
+            dskip = None
         elif ctx.needs_input_grad[0]:
             w_t = ctx.w_t
             if w_t is None:
@@ -87,7 +101,9 @@ class ConvNHWCFunction(Function):
             dw = dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
-        return dx, dw, db, None, None, None, None
+        if dskip is not None:
+            dx = dskip if dx is None else dx + dskip
+        return dx, dw, db, None, None, None, None, None
 
 
 class GroupNormNHWCFunction(Function):
@@ -173,15 +189,22 @@ def _pad_cout(weight, bias, mult=32):
     return weight, bias, cout
 
 
-def conv2d_nhwc_autograd(x, weight, bias, stride, pad):
-    """x (N,H,W,Cin) -> (N,Ho,Wo,Cout), differentiable"""
+def conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False):
+    """x (N,H,W,Cin) -> (N,Ho,Wo,Cout), differentiable.  `with_skip`: returns (y, x_alias); gradients
+    reaching x_alias (a residual block's identity branch) are added inside the conv's data-gradient
+    kernel"""
     n, h, w, cin = x.shape
     kh, kw = weight.shape[2], weight.shape[3]
     ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
     weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)
-    y = ConvNHWCFunction.apply(x.reshape(n * h * w, cin), weight, bias, n, ((h, w),), stride, pad)
+    y = ConvNHWCFunction.apply(x.reshape(n * h * w, cin), weight, bias, n, ((h, w),), stride, pad, with_skip)
+    skip = None
+    if with_skip:
+        y, skip = y
+        skip = skip.view(n, h, w, cin)
     y = y.view(n, ho, wo, weight.shape[0])
-    return y if cout == weight.shape[0] else y[..., :cout]
+    y = y if cout == weight.shape[0] else y[..., :cout]
+    return (y, skip) if with_skip else y
 
 
 def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad):

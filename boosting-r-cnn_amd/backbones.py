@@ -38,11 +38,14 @@ class Bottleneck(nn.Module):
         self._c = [PackedCache() for _ in range(4)]
 
     def forward_nhwc(self, x):
-        out = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True)
-        out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True)
-        identity = x
-        if self.downsample is not None:
+        if self.downsample is None:
+            # the identity branch leaves through conv1's autograd node: its gradient is added in
+            # conv1's data-gradient kernel instead of by a separate add over the whole tensor
+            out, identity = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True)
+        else:
+            out = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True)
             identity = conv_bn_act_nhwc(x, self.downsample[0], self.downsample[1], self._c[3], False)
+        out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True)
         # relu(bn3(conv3(out)) + identity) in one epilogue (resnet.py:288-300)
         return conv_bn_act_nhwc(out, self.conv3, self.bn3, self._c[2], True, residual=identity)
 

@@ -97,7 +97,21 @@ def build_norm_layer(cfg, num_features, postfix=''):
     return name + str(postfix), layer
 
 
-def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
+def conv_bn_act_tail(y, bn, relu, residual):
+    """eval-BN affine (+residual, +ReLU) behind a differentiable conv (fused kernel when it applies)"""
+    if bn is not None:
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        from .autograd import bn_act_autograd, bn_act_supported
+        if bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
+            return bn_act_autograd(y, scale, shift, residual, relu)
+        y = y * scale.to(y.dtype) + shift.to(y.dtype)
+    if residual is not None:
+        y = y + residual
+    return y.relu() if relu else y
+
+
+def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False):
     """act(bn(conv(x)) + residual).  Inference / frozen layers: everything folded into one
     kernel launch.  Trainable layers under grad mode: the differentiable conv kernel followed
     by the (cheap, element-wise) eval-BN affine / add / ReLU as torch ops."""
@@ -106,10 +120,18 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
                                   '(the reference runs BN in eval mode: norm_eval=True)')
     from .autograd import conv2d_nhwc_autograd, wants_grad
     if conv.groups > 1:
-        return _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual)
+        out = _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual)
+        return (out, x) if with_skip else out
     if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                   residual if residual is not None and residual.requires_grad else None):
-        y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+        skip = None
+        if with_skip and x.requires_grad:
+            y, skip = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], True)
+        else:
+            y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+            skip = x if with_skip else None
+        if with_skip:
+            return conv_bn_act_tail(y, bn, relu, residual), skip
         if bn is not None:
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale
@@ -134,7 +156,8 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None):
         return w, None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
 
     w, scale, shift = cache.get(srcs, builder)
-    return ops.conv2d_nhwc(x, w, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
+    out = ops.conv2d_nhwc(x, w, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
+    return (out, x) if with_skip else out
 
 
 def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):

@@ -178,9 +178,10 @@ def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds
 
 
 # ---- differentiable CPU restatements of brcnn.autograd (training path of the oracle pipeline) ---
-def _conv2d_nhwc_autograd(x, weight, bias, stride, pad):
+def _conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False):
     y = F.conv2d(x.permute(0, 3, 1, 2), weight, bias, stride, pad)
-    return y.permute(0, 2, 3, 1).contiguous()
+    y = y.permute(0, 2, 3, 1).contiguous()
+    return (y, x) if with_skip else y
 
 
 def _linear_autograd(x, weight, bias):
