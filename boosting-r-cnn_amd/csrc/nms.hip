@@ -194,6 +194,11 @@ NmsWs carve(void* base, int64_t n, int S, int words) {
 }
 
 
+struct LevelBounds {
+    int num;                               // 0: one segment per image
+    int col0[BRCNN_MAX_LEVELS + 1];        // candidate columns [col0[l], col0[l+1]) belong to id / level l
+};
+
 // ---- whole-batch candidate preparation for batched NMS (postprocess.batched_nms_images) ------
 // One workgroup per image slot of T candidates: order-preserving compaction of the valid ones
 // (rejected rows leave zeros behind), the image's largest surviving coordinate, and the
@@ -205,14 +210,17 @@ __global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restri
                                                           const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ valid, float* __restrict__ c_boxes,
                                                           float* __restrict__ c_scores, long long* __restrict__ c_ids,
-                                                          float* __restrict__ nms_boxes, int* __restrict__ ranges, int T) {
+                                                          float* __restrict__ nms_boxes, int* __restrict__ ranges, int T,
+                                                          const LevelBounds lb) {
     __shared__ int wsum[16];
+    __shared__ int s_lcnt[BRCNN_MAX_LEVELS];
     __shared__ float wmax[16];
     __shared__ int s_base;
     __shared__ float s_max;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t row0 = (size_t)b * T;
     if (tid == 0) s_base = 0;
+    if (tid < BRCNN_MAX_LEVELS) s_lcnt[tid] = 0;
     float vmax = -3.402823466e+38f;             // torch.finfo(float32).min, the reference's fill value
     __syncthreads();
     // pass 1: positions of the survivors + the largest coordinate among them
@@ -239,6 +247,13 @@ __global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restri
             c_scores[row0 + pos] = scores[row0 + t];
             c_ids[row0 + pos] = ids[row0 + t];
             vmax = fmaxf(vmax, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+            if (lb.num > 0) {
+                int l = 0;
+#pragma unroll
+                for (int k = 1; k < BRCNN_MAX_LEVELS; k++)
+                    if (k < lb.num && t >= lb.col0[k]) l = k;
+                atomicAdd(&s_lcnt[l], 1);
+            }
         }
         __syncthreads();
         if (tid == 0) s_base += total;
@@ -253,8 +268,18 @@ __global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restri
         float m = wmax[0];
         for (int w = 1; w < 16; w++) m = fmaxf(m, wmax[w]);
         s_max = m;
-        ranges[2 * b] = b * T;
-        ranges[2 * b + 1] = b * T + cnt;
+        if (lb.num > 0) {
+            // the survivors of a level stay contiguous: one [begin, end) per (image, level)
+            int beg = b * T;
+            for (int l = 0; l < lb.num; l++) {
+                ranges[2 * (b * lb.num + l)] = beg;
+                beg += s_lcnt[l];
+                ranges[2 * (b * lb.num + l) + 1] = beg;
+            }
+        } else {
+            ranges[2 * b] = b * T;
+            ranges[2 * b + 1] = b * T + cnt;
+        }
     }
     __syncthreads();
     const float step = s_max + 1.0f;
@@ -342,6 +367,73 @@ __global__ __launch_bounds__(1024) void seg_sort_gather_kernel(const float* __re
     }
 }
 
+// mmcv batched_nms above split_thr (the `for id in torch.unique(idxs)` branch, mmcv/ops/nms.py): after the
+// per-(image, id) NMS the survivors of all ids of an image are re-sorted by score (descending, ties by
+// ascending candidate position) and the first K kept.  One workgroup per image: (score, position)
+// composites of the survivors in LDS, bitonic sort, gather.  `new_scores` (flat rows of 5, column 4) are
+// the decayed scores of soft-NMS picks, aligned with `keep`.
+__global__ __launch_bounds__(1024) void nms_collect_sorted_kernel(const long long* __restrict__ keep,
+                                                                 const int* __restrict__ num, const int* __restrict__ ranges,
+                                                                 const float* __restrict__ c_boxes,
+                                                                 const float* __restrict__ c_scores,
+                                                                 const long long* __restrict__ c_ids,
+                                                                 const float* __restrict__ new_scores,
+                                                                 float* __restrict__ dets, long long* __restrict__ ids_kept,
+                                                                 int* __restrict__ n_kept, int T, int L, int K) {
+    extern __shared__ unsigned long long comp[];
+    __shared__ int s_off[BRCNN_MAX_LEVELS + 1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int o = 0;
+        for (int l = 0; l < L; l++) { s_off[l] = o; o += num[b * L + l]; }
+        s_off[L] = o;
+    }
+    __syncthreads();
+    const int cnt = s_off[L];
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    for (int l = 0; l < L; l++) {
+        const int beg = ranges[2 * (b * L + l)], n_l = s_off[l + 1] - s_off[l];
+        for (int i = tid; i < n_l; i += 1024) {
+            const long long src = keep[beg + i];
+            const float sc = new_scores ? new_scores[(size_t)(beg + i) * 5 + 4] : c_scores[src];
+            comp[s_off[l] + i] = ((unsigned long long)(~order_key(sc)) << 32) | (unsigned)(src - (long long)b * T);
+        }
+    }
+    for (int i = cnt + tid; i < P; i += 1024) comp[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const unsigned long long a = comp[lo], c = comp[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > c) == up) { comp[lo] = c; comp[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int kept = cnt < K ? cnt : K;
+    if (tid == 0) n_kept[b] = kept;
+    for (int k = tid; k < K; k += 1024) {
+        float* d = dets + ((size_t)b * K + k) * 5;
+        if (k < kept) {
+            const unsigned long long c = comp[k];
+            const size_t src = (size_t)b * T + (unsigned)(c & 0xffffffffu);
+            const float4 bx = *reinterpret_cast<const float4*>(c_boxes + src * 4);
+            // the score back from its order key
+            const unsigned key = ~(unsigned)(c >> 32);
+            const unsigned u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+            d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = __uint_as_float(u);
+            if (ids_kept) ids_kept[(size_t)b * K + k] = c_ids[src];
+        } else {
+            d[0] = d[1] = d[2] = d[3] = d[4] = 0.f;
+            if (ids_kept) ids_kept[(size_t)b * K + k] = -1;
+        }
+    }
+}
+
 }  // namespace
 
 static int g_nms_lds_sort = getenv("BRCNN_NMS_RADIX") ? 0 : 1;     // BRCNN_NMS_RADIX=1: always the rocPRIM sort (A/B)
@@ -412,8 +504,56 @@ BRCNN_API int brcnn_nms_prepare(const float* boxes, const float* scores, const i
     if (!boxes || !scores || !ids || !valid || !c_boxes || !c_scores || !c_ids || !nms_boxes || !ranges ||
         batch <= 0 || slot <= 0 || (long long)batch * slot >= 0x7fffffffLL)
         return BRCNN_EINVAL;
+    LevelBounds lb;
+    lb.num = 0;
     hipLaunchKernelGGL(nms_prepare_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, boxes, scores,
-                       (const long long*)ids, valid, c_boxes, c_scores, (long long*)c_ids, nms_boxes, ranges, slot);
+                       (const long long*)ids, valid, c_boxes, c_scores, (long long*)c_ids, nms_boxes, ranges, slot, lb);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_nms_prepare_levels(const float* boxes, const float* scores, const int64_t* ids, const uint8_t* valid,
+                                       float* c_boxes, float* c_scores, int64_t* c_ids, float* nms_boxes,
+                                       int32_t* ranges, int batch, int slot, int num_levels,
+                                       const int* level_sizes_host, void* stream) {
+    if (!boxes || !scores || !ids || !valid || !c_boxes || !c_scores || !c_ids || !nms_boxes || !ranges ||
+        batch <= 0 || slot <= 0 || (long long)batch * slot >= 0x7fffffffLL || num_levels <= 0 ||
+        num_levels > BRCNN_MAX_LEVELS || !level_sizes_host)
+        return BRCNN_EINVAL;
+    LevelBounds lb;
+    lb.num = num_levels;
+    int c = 0;
+    for (int l = 0; l < num_levels; l++) {
+        lb.col0[l] = c;
+        if (level_sizes_host[l] < 0) return BRCNN_EINVAL;
+        c += level_sizes_host[l];
+    }
+    lb.col0[num_levels] = c;
+    if (c != slot) return BRCNN_EINVAL;
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, boxes, scores,
+                       (const long long*)ids, valid, c_boxes, c_scores, (long long*)c_ids, nms_boxes, ranges, slot, lb);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_nms_collect_sorted(const int64_t* keep, const int32_t* num, const int32_t* ranges,
+                                       const float* c_boxes, const float* c_scores, const int64_t* c_ids,
+                                       const float* new_scores5, float* dets, int64_t* ids_kept, int32_t* n_kept,
+                                       int batch, int slot, int num_levels, int max_keep, void* stream) {
+    if (!keep || !num || !ranges || !c_boxes || !c_scores || !c_ids || !dets || !n_kept || batch <= 0 || slot <= 0 ||
+        slot > 16384 || num_levels <= 0 || num_levels > BRCNN_MAX_LEVELS || max_keep <= 0 || max_keep > slot)
+        return BRCNN_EINVAL;
+    int P = 64;
+    while (P < slot) P <<= 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)nms_collect_sorted_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(nms_collect_sorted_kernel, dim3(batch), dim3(1024), (size_t)P * 8, (hipStream_t)stream,
+                       (const long long*)keep, num, ranges, c_boxes, c_scores, (const long long*)c_ids, new_scores5, dets,
+                       (long long*)ids_kept, n_kept, slot, num_levels, max_keep);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

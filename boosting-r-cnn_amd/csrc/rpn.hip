@@ -107,6 +107,8 @@ struct DecodeLevels {
     int pred_stride[BRCNN_MAX_LEVELS], hwA[BRCNN_MAX_LEVELS], width[BRCNN_MAX_LEVELS];
     int stride_w[BRCNN_MAX_LEVELS], stride_h[BRCNN_MAX_LEVELS], col0[BRCNN_MAX_LEVELS + 1];
     float pred_scale[BRCNN_MAX_LEVELS];
+    const float* scale_dev;            // (num) device-resident scales (training: the Scale parameters), or NULL
+    const float* max_shape_dev;        // (batch, 2) [h, w] per-image clip border (img_shape), or NULL = dp.max_h/w
 };
 
 __global__ __launch_bounds__(256) void rpn_decode_levels_kernel(DecodeLevels lv, int batch, int A, DecodeParams dp,
@@ -124,8 +126,11 @@ __global__ __launch_bounds__(256) void rpn_decode_levels_kernel(DecodeLevels lv,
         const int count = lv.col0[l + 1] - lv.col0[l];
         const long long idx = lv.inds[l][(size_t)b * count + (col - lv.col0[l])];
         bool ok;
+        DecodeParams d = dp;
+        if (lv.max_shape_dev) { d.max_h = lv.max_shape_dev[2 * b]; d.max_w = lv.max_shape_dev[2 * b + 1]; }
         const float4 o = decode_one(idx, b, lv.pred[l], lv.base[l], lv.hwA[l], lv.width[l], A, lv.stride_w[l],
-                                    lv.stride_h[l], lv.pred_stride[l], lv.pred_scale[l], dp, &ok);
+                                    lv.stride_h[l], lv.pred_stride[l], lv.scale_dev ? lv.scale_dev[l] : lv.pred_scale[l],
+                                    d, &ok);
         *reinterpret_cast<float4*>(proposals + (size_t)t * 4) = o;
         valid[t] = ok ? 1 : 0;
         ids[t] = l;
@@ -401,26 +406,28 @@ BRCNN_API int brcnn_rcnn_decode(const float* probs, const float* bbox_pred, cons
     return 0;
 }
 
-BRCNN_API int brcnn_rpn_decode_levels(const int64_t* const* topk_inds, const float* const* bbox_pred,
-                                      const int* pred_strides, const float* pred_scales,
-                                      const float* const* base_anchors, int batch, int num_levels, const int* counts,
-                                      const int* heights, const int* widths, int num_anchors, const int* strides_w,
-                                      const int* strides_h, const float* means4_host, const float* stds4_host,
-                                      double wh_ratio_clip, float max_h, float max_w, float min_size,
-                                      float* proposals, uint8_t* valid, int64_t* ids, void* stream) {
+static int decode_levels_impl(const int64_t* const* topk_inds, const float* const* bbox_pred,
+                              const int* pred_strides, const float* pred_scales, const float* pred_scales_dev,
+                              const float* max_shape_dev, const float* const* base_anchors, int batch, int num_levels, const int* counts,
+                              const int* heights, const int* widths, int num_anchors, const int* strides_w,
+                              const int* strides_h, const float* means4_host, const float* stds4_host,
+                              double wh_ratio_clip, float max_h, float max_w, float min_size,
+                              float* proposals, uint8_t* valid, int64_t* ids, void* stream) {
     if (batch < 0 || num_levels <= 0 || num_levels > BRCNN_MAX_LEVELS || num_anchors <= 0 || !topk_inds || !bbox_pred ||
-        !pred_strides || !pred_scales || !base_anchors || !counts || !heights || !widths || !strides_w || !strides_h ||
+        !pred_strides || (!pred_scales && !pred_scales_dev) || !base_anchors || !counts || !heights || !widths || !strides_w || !strides_h ||
         !means4_host || !stds4_host || !(wh_ratio_clip > 0.0) || !proposals || !valid || !ids)
         return BRCNN_EINVAL;
     DecodeLevels lv = {};
     lv.num = num_levels;
+    lv.scale_dev = pred_scales_dev;
+    lv.max_shape_dev = max_shape_dev;
     int T = 0;
     for (int l = 0; l < num_levels; l++) {
         if (counts[l] <= 0 || heights[l] <= 0 || widths[l] <= 0 || pred_strides[l] < 4 * num_anchors || !topk_inds[l] ||
             !bbox_pred[l] || !base_anchors[l])
             return BRCNN_EINVAL;
         lv.inds[l] = topk_inds[l]; lv.pred[l] = bbox_pred[l]; lv.base[l] = base_anchors[l];
-        lv.pred_stride[l] = pred_strides[l]; lv.pred_scale[l] = pred_scales[l];
+        lv.pred_stride[l] = pred_strides[l]; lv.pred_scale[l] = pred_scales ? pred_scales[l] : 1.f;
         lv.hwA[l] = heights[l] * widths[l] * num_anchors; lv.width[l] = widths[l];
         lv.stride_w[l] = strides_w[l]; lv.stride_h[l] = strides_h[l];
         lv.col0[l] = T;
@@ -431,7 +438,7 @@ BRCNN_API int brcnn_rpn_decode_levels(const int64_t* const* topk_inds, const flo
     DecodeParams dp;
     for (int i = 0; i < 4; i++) { dp.mean[i] = means4_host[i]; dp.std[i] = stds4_host[i]; }
     dp.max_ratio = (float)fabs(log(wh_ratio_clip));
-    dp.clip = (max_h > 0.f && max_w > 0.f) ? 1 : 0;
+    dp.clip = ((max_h > 0.f && max_w > 0.f) || max_shape_dev) ? 1 : 0;
     dp.max_h = max_h; dp.max_w = max_w; dp.min_size = min_size;
     dp.pred_scale = 1.f; dp.pred_stride = 0;
     const long long total = (long long)batch * T;
@@ -518,4 +525,32 @@ BRCNN_API int brcnn_rpn_topk(const float* const* score_levels, const int* n_host
         BRCNN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+BRCNN_API int brcnn_rpn_decode_levels(const int64_t* const* topk_inds, const float* const* bbox_pred,
+                                      const int* pred_strides, const float* pred_scales,
+                                      const float* const* base_anchors, int batch, int num_levels, const int* counts,
+                                      const int* heights, const int* widths, int num_anchors, const int* strides_w,
+                                      const int* strides_h, const float* means4_host, const float* stds4_host,
+                                      double wh_ratio_clip, float max_h, float max_w, float min_size,
+                                      float* proposals, uint8_t* valid, int64_t* ids, void* stream) {
+    if (!pred_scales) return BRCNN_EINVAL;
+    return decode_levels_impl(topk_inds, bbox_pred, pred_strides, pred_scales, nullptr, nullptr, base_anchors, batch, num_levels,
+                              counts, heights, widths, num_anchors, strides_w, strides_h, means4_host, stds4_host,
+                              wh_ratio_clip, max_h, max_w, min_size, proposals, valid, ids, stream);
+}
+
+BRCNN_API int brcnn_rpn_decode_levels_dscale(const int64_t* const* topk_inds, const float* const* bbox_pred,
+                                             const int* pred_strides, const float* pred_scales_dev,
+                                             const float* max_shape_dev, const float* const* base_anchors, int batch,
+                                             int num_levels,
+                                             const int* counts, const int* heights, const int* widths, int num_anchors,
+                                             const int* strides_w, const int* strides_h, const float* means4_host,
+                                             const float* stds4_host, double wh_ratio_clip, float max_h, float max_w,
+                                             float min_size, float* proposals, uint8_t* valid, int64_t* ids,
+                                             void* stream) {
+    if (!pred_scales_dev) return BRCNN_EINVAL;
+    return decode_levels_impl(topk_inds, bbox_pred, pred_strides, nullptr, pred_scales_dev, max_shape_dev, base_anchors, batch,
+                              num_levels, counts, heights, widths, num_anchors, strides_w, strides_h, means4_host,
+                              stds4_host, wh_ratio_clip, max_h, max_w, min_size, proposals, valid, ids, stream);
 }

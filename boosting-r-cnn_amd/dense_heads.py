@@ -394,10 +394,22 @@ class ATSSRPNHead(AnchorHead):
         featmap_sizes = [f.size()[-2:] for f in cls_scores]
         assert len(featmap_sizes) == self.anchor_generator.num_levels
         device = cls_scores[0].device
-        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
+        if device.type == 'cuda' and gt_bboxes_ignore is None and self.device_train_ok():
+            # the reference signature on device tensors: repack the per-level NCHW outputs as the fused
+            # (rows, 6A) layout (their Scale is already applied: unit scales) and run the HIP kernels
+            sizes = tuple(tuple(int(v) for v in s_) for s_ in featmap_sizes)
+            rows = [torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in (c_, r_, i_)], 1)
+                    for c_, r_, i_ in zip(cls_scores, bbox_preds, iou_preds)]
+            y = torch.cat(rows, 0).float().contiguous()
+            return self.loss_fused(y, sizes, gt_bboxes, img_metas,
+                                   scales=torch.ones(len(sizes), dtype=torch.float32, device=device))
         label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
-        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        num_level_anchors = [int(h) * int(w) * self.num_anchors for h, w in featmap_sizes]
+
         def build_targets():
+            # anchors and flags depend on shapes only; they are created on the stream the targets are
+            # built on (a cache miss on another stream would race with the reads below)
+            anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
             targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
                                        gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None,
                                        label_channels=label_channels)
@@ -451,6 +463,125 @@ class ATSSRPNHead(AnchorHead):
         losses_bbox = [x / bbox_avg_factor for x in losses_bbox]
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox, loss_rpn_iou=losses_iou)
 
+    # ------------------------------------------------------------------ device-resident train step
+    def device_train_ok(self):
+        """the recipe family the fused target / loss kernels cover (UTDAC, COCO-PAFPN, R101, X101, Res2Net
+        recipes): decoded IoU-log regression + MSE aug, focal classification, sigmoid-BCE IoU branch,
+        MaxIoU assignment without ignore regions"""
+        from .core import MaxIoUAssigner, PseudoSampler
+        from .losses import CrossEntropyLoss, FocalLoss, IoULoss, MSELoss
+        tc = self.train_cfg
+        return bool(
+            tc is not None and self.reg_decoded_bbox and self.use_sigmoid_cls and self.cls_out_channels == 1 and
+            type(self.loss_cls) is FocalLoss and type(self.loss_bbox) is IoULoss and self.loss_bbox.mode == 'log' and
+            self.loss_bbox.reduction == 'mean' and self.loss_cls.reduction == 'mean' and
+            (not self.with_aug_loss or (type(self.aug_loss) is MSELoss and self.aug_loss.reduction == 'mean')) and
+            type(self.loss_centerness) is CrossEntropyLoss and self.loss_centerness.use_sigmoid and
+            self.loss_centerness.class_weight is None and self.loss_centerness.reduction == 'mean' and
+            type(self.assigner) is MaxIoUAssigner and self.assigner.ignore_iof_thr <= 0 and
+            self.assigner.gt_max_assign_all and type(self.sampler) is PseudoSampler and
+            not getattr(self.bbox_coder, 'add_ctr_clamp', False))
+
+    def _tower_fusable(self):
+        return all(isinstance(c.norm, nn.GroupNorm) and c.conv.bias is None and c.conv.groups == 1
+                   for c in self.rpn_convs) and self.feat_channels <= 256 and self.feat_channels % 4 == 0
+
+    def forward_head_fused(self, feats):
+        """training forward of tower + heads over all levels (one launch per layer); returns the fused
+        head output y (rows, Cpad) fp32 [cls A | reg 4A (raw, before Scale) | iou A | zero padding],
+        level-major rows, differentiable"""
+        from .autograd import ConvNHWCFunction, GroupNormNHWCFunction, _pad_cout, conv2d_nhwc_multi_autograd
+        B = feats[0].shape[0]
+        sizes = tuple(tuple(int(v) for v in f.shape[1:3]) for f in feats)
+        x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
+        for conv in self.rpn_convs:
+            x = conv2d_nhwc_multi_autograd(x, conv.conv.weight, None, B, sizes, 1, conv.conv.padding[0])
+            x = GroupNormNHWCFunction.apply(x, conv.norm.weight, conv.norm.bias, conv.norm.num_groups, B, sizes,
+                                            conv.norm.eps, conv.with_activation)
+        heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
+        w, b, _ = _pad_cout(torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0),
+                            32 if x.dtype == torch.float32 else 64)
+        y = ConvNHWCFunction.apply(x, w, b, B, sizes, 1, self.rpn_cls.padding[0])
+        return y.float(), sizes
+
+    def _anchor_table(self, sizes, device):
+        """all levels' grid anchors of ONE image as a cached (n, 4) tensor + the level geometry"""
+        key = (tuple(sizes), str(device))
+        cache = self.__dict__.setdefault('_anchor_tables', {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            anchors = torch.cat(self.anchor_generator.grid_anchors(list(sizes), device), 0).contiguous()
+            starts = [0]
+            for (h, w) in sizes:
+                starts.append(starts[-1] + h * w * self.num_anchors)
+            cache[key] = (anchors, (starts, [w for _, w in sizes], self.num_anchors))
+        return cache[key]
+
+    def assign_targets_device(self, sizes, img_metas, gts, gt_offsets, device):
+        """AnchorHead._get_targets_single's assignment for the whole batch on the device: gt_inds
+        (B, anchors per image) int32 (-1 ignore / outside, 0 negative, k matched to gt k-1)"""
+        import numpy as np
+        from . import train_ops
+        from .core import const_rows
+        anchors, geom = self._anchor_table(sizes, device)
+        B = len(img_metas)
+        valid_hw = None
+        if not all(self.anchor_generator.all_valid(list(sizes), m['pad_shape']) for m in img_metas):
+            rows = []
+            for m in img_metas:
+                h, w = m['pad_shape'][:2]
+                r = []
+                for (fh, fw), st in zip(sizes, self.anchor_generator.strides):
+                    r += [min(int(np.ceil(h / st[1])), fh), min(int(np.ceil(w / st[0])), fw)]
+                rows.append(r)
+            valid_hw = const_rows(rows, anchors).to(torch.int32).view(B, len(sizes), 2).contiguous()
+        border = self.train_cfg.allowed_border
+        img_hw = const_rows([m['img_shape'][:2] for m in img_metas], anchors) if border >= 0 else None
+        a = self.assigner
+        return train_ops.assign_max_iou(anchors, gts, gt_offsets, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou,
+                                        a.match_low_quality, batch=B, geom=geom, valid_hw=valid_hw, img_hw=img_hw,
+                                        allowed_border=border)
+
+    def loss_fused(self, y, sizes, gt_bboxes, img_metas, gt_flat=None, scales=None):
+        """ATSSRPNHead.loss on the fused head output: assignment + every loss term in HIP kernels, no
+        host synchronisation.  Each loss comes back as a one-element list holding the sum over the
+        pyramid levels (the reference returns the per-level terms and sums them in _parse_losses);
+        `self.last_rpn_targets` keeps (gt_inds, per-level losses (3, L), [num_pos, sum iou_target])."""
+        from . import train_ops
+        device = y.device
+        gts, _, offs = gt_flat if gt_flat is not None else train_ops.flatten_gts(gt_bboxes)
+        gt_inds = self.assign_targets_device(sizes, img_metas, gts, offs, device)
+        tc = self.train_cfg
+        meta = train_ops.RPNLossMeta(
+            len(img_metas), sizes, self.anchor_generator.strides,
+            [self._base_anchors(l, device) for l in range(len(sizes))], self.num_anchors, offs, self.loss_cls.gamma,
+            self.loss_cls.alpha, tc.pos_weight, self.gamma, self.bbox_coder.means, self.bbox_coder.stds, 16 / 1000,
+            self.with_aug_loss, self.loss_cls.loss_weight, self.loss_bbox.loss_weight,
+            self.aug_loss.loss_weight if self.with_aug_loss else 0.0, self.loss_centerness.loss_weight)
+        if scales is None:
+            scales = torch.stack([m.scale.reshape(()) for m in self.scales])
+        losses3, per_level, totals = train_ops.rpn_loss(y, scales, gt_inds, gts, meta)
+        self.last_rpn_targets = (gt_inds, per_level, totals)
+        return dict(loss_rpn_cls=[losses3[0]], loss_rpn_bbox=[losses3[1]], loss_rpn_iou=[losses3[2]])
+
+    def proposals_fused(self, y, sizes, img_metas, cfg):
+        """proposal stage straight from the fused head output (no copies: channel-slice views), with
+        the live Scale parameters read on the device; returns padded (dets (B,K,5), num (B,))"""
+        yd = y.detach()
+        B = len(img_metas)
+        a, c = self.num_anchors, self.cls_out_channels
+        cls, reg, iou, r0 = [], [], [], 0
+        for (h, w) in sizes:
+            n = B * h * w
+            t = yd[r0:r0 + n].view(B, h, w, yd.shape[1])
+            cls.append(t[..., :a * c])
+            reg.append(t[..., a * c:a * c + 4 * a])
+            iou.append(t[..., a * c + 4 * a:a * c + 5 * a])
+            r0 += n
+        scales = torch.stack([m.scale.detach().reshape(()) for m in self.scales]).float().contiguous()
+        return self.get_bboxes_padded(cls, reg, iou, img_metas, cfg=cfg, reg_scales=scales)
+
     # ------------------------------------------------------------------ proposals
     def _base_anchors(self, level, device):
         key = (level, str(device))
@@ -487,15 +618,21 @@ class ATSSRPNHead(AnchorHead):
                     picked.append((ranked[:, :cfg.nms_pre], rank_inds[:, :cfg.nms_pre].contiguous()))
                 else:
                     picked.append((score, torch.arange(n, device=device).expand(B, n).contiguous()))
-        if len(shapes) == 1 and cfg.min_bbox_size >= 0 and hasattr(ops, 'rpn_decode_levels') and device.type == 'cuda':
-            # one image shape in the batch (the usual case): every level decoded by one launch that
-            # also writes the validity and level-id columns of the (B, T) candidate slots
+        dev_scales = isinstance(reg_scales, torch.Tensor)
+        if (len(shapes) == 1 or dev_scales) and cfg.min_bbox_size >= 0 and device.type == 'cuda':
+            # every level decoded by one launch that also writes the validity and level-id columns of
+            # the (B, T) candidate slots; device-resident scales (training) also take the per-image
+            # clip border from a device table, so a batch of differently sized images stays one launch
             L = len(cls_nhwc)
+            from .core import const_rows
+            per_image = const_rows([m['img_shape'][:2] for m in img_metas], raw[0]) if dev_scales and len(shapes) > 1 \
+                else None
             props, valid, ids = ops.rpn_decode_levels(
                 [picked[l][1] for l in range(L)], [reg_nhwc[l] for l in range(L)],
                 [self._base_anchors(l, device) for l in range(L)], [tuple(cls_nhwc[l].shape[1:3]) for l in range(L)],
                 list(self.anchor_generator.strides), self.bbox_coder.means, self.bbox_coder.stds, next(iter(shapes)),
-                cfg.min_bbox_size, pred_scales=None if reg_scales is None else list(reg_scales))
+                cfg.min_bbox_size, pred_scales=None if reg_scales is None else (reg_scales if dev_scales else list(reg_scales)),
+                max_shapes=per_image)
             sc_l = [picked[l][0] for l in range(L)]
             scores = torch.cat(sc_l, 1)
             return self._proposals_from_candidates(props, scores, ids, valid, sc_l, nms_cfg, cfg)

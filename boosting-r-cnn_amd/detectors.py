@@ -21,6 +21,58 @@ from .core import bbox2result
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
+class LazyLogVars(OrderedDict):
+    """log_vars of `_parse_losses`: the reference reads every scalar back with `.item()` right after the
+    forward pass (base.py:208), which stalls the host before backward is queued.  Same keys and float
+    values, but the device->host copy is started asynchronously and only waited for on first access."""
+
+    def __init__(self, names, vals):
+        super().__init__()
+        self._names = list(names)
+        self._pending = None
+        if vals.is_cuda:
+            self._host = torch.empty(vals.shape, dtype=vals.dtype).pin_memory()
+            self._host.copy_(vals, non_blocking=True)
+            self._pending = torch.cuda.Event()
+            self._pending.record()
+        else:
+            self._host = vals
+        for k in self._names:
+            OrderedDict.__setitem__(self, k, None)
+
+    def _resolve(self):
+        if self._host is not None:
+            if self._pending is not None:
+                self._pending.synchronize()
+            for k, v in zip(self._names, self._host.tolist()):
+                OrderedDict.__setitem__(self, k, v)
+            self._host = self._pending = None
+
+    def __getitem__(self, k):
+        self._resolve()
+        return OrderedDict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._resolve()
+        return OrderedDict.get(self, k, default)
+
+    def items(self):
+        self._resolve()
+        return OrderedDict.items(self)
+
+    def values(self):
+        self._resolve()
+        return OrderedDict.values(self)
+
+    def __repr__(self):
+        self._resolve()
+        return repr(dict(OrderedDict.items(self)))
+
+    def __reduce__(self):
+        self._resolve()
+        return (OrderedDict, (list(OrderedDict.items(self)),))
+
+
 class BaseDetector(nn.Module):
     def __init__(self, init_cfg=None):
         super().__init__()
@@ -82,9 +134,7 @@ class BaseDetector(nn.Module):
             # one fused collective
             vals = vals.clone()
             dist.all_reduce(vals.div_(dist.get_world_size()))
-        for k, v in zip(names, vals.tolist()):
-            log_vars[k] = v
-        return loss, log_vars
+        return loss, LazyLogVars(names, vals)
 
     def train_step(self, data, optimizer):
         losses = self(**data)
@@ -144,8 +194,36 @@ class TwoStageDetector(BaseDetector):
         return tuple(to_nchw_view(f) for f in self.extract_feat_nhwc(img))
 
     # ---- train ---------------------------------------------------------------------------
+    def _device_train_ok(self, img, gt_bboxes_ignore, proposals):
+        return (img.is_cuda and self.with_rpn and proposals is None and gt_bboxes_ignore is None and
+                getattr(self, 'device_train_path', True) and hasattr(self.rpn_head, 'device_train_ok') and
+                self.rpn_head.device_train_ok() and self.rpn_head._tower_fusable() and
+                hasattr(self.roi_head, 'device_train_ok') and self.roi_head.device_train_ok() and
+                img.shape[0] <= 64)
+
+    def forward_train_device(self, img, img_metas, gt_bboxes, gt_labels):
+        """The train step with targets and losses on the device: RPN tower -> proposals -> second-stage
+        assignment, then -- while the (B,2) sampler counts travel to the host -- the RPN assignment and
+        loss kernels, then sampling, RoI head and the boosting loss.  One host synchronisation."""
+        from . import train_ops
+        feats = self.extract_feat_nhwc(img)
+        rpn = self.rpn_head
+        y, sizes = rpn.forward_head_fused(list(feats))
+        gt_flat = train_ops.flatten_gts(gt_bboxes, gt_labels)
+        proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+        dets, num = rpn.proposals_fused(y, sizes, img_metas, proposal_cfg)
+        roi_losses, rpn_losses = self.roi_head.forward_train_device(
+            feats, img_metas, dets, num, gt_flat,
+            overlap_work=lambda: rpn.loss_fused(y, sizes, gt_bboxes, img_metas, gt_flat=gt_flat))
+        losses = dict()
+        losses.update(rpn_losses)
+        losses.update(roi_losses)
+        return losses
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, proposals=None, **kwargs):
+        if self._device_train_ok(img, gt_bboxes_ignore, proposals):
+            return self.forward_train_device(img, img_metas, gt_bboxes, gt_labels)
         if self.with_rpn and img.is_cuda:
             # the RPN targets depend on anchors and ground truth only: the head computes them on a
             # side stream that starts HERE, so the host syncs of the assignment (nonzero / unique)

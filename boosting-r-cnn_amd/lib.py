@@ -78,6 +78,23 @@ SIGNATURES = {
     'brcnn_rpn_topk_workspace_bytes': (ctypes.c_size_t, [c_ptr, c_int, c_int, c_int]),
     'brcnn_rpn_topk': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     'brcnn_preprocess_u8': (c_int, [c_ptr, c_int, c_int, c_ptr] + [c_int] * 5 + [c_ptr, c_ptr, c_int, c_ptr]),
+    'brcnn_nms_prepare_levels': (c_int, [c_ptr] * 9 + [c_int, c_int, c_int, c_ptr, c_ptr]),
+    'brcnn_nms_collect_sorted': (c_int, [c_ptr] * 10 + [c_int] * 4 + [c_ptr]),
+    'brcnn_rpn_decode_levels_dscale': (c_int, [c_ptr] * 6 + [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
+                                               c_ptr, c_f64, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'brcnn_assign_max_iou': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int,
+                                     c_ptr, c_ptr] + [c_f32] * 5 + [c_int] + [c_ptr] * 5),
+    'brcnn_rcnn_sample': (c_int, [c_ptr, c_ptr, c_int, c_int] + [c_ptr] * 5 + [c_int, c_int, c_int, c_f32, c_ptr, c_ptr,
+                                  c_int, c_int, c_ptr, c_ptr, c_ptr, c_int] + [c_ptr] * 7),
+    'brcnn_rpn_loss_workspace_bytes': (c_size, [c_int, c_int, c_ptr, c_ptr, c_int]),
+    'brcnn_rpn_loss_forward': (c_int, [c_ptr, c_int, c_int, c_int] + [c_ptr] * 5 + [c_int] + [c_ptr] * 6 +
+                               [c_size, c_ptr, c_ptr, c_ptr]),
+    'brcnn_rpn_loss_finalize': (c_int, [c_ptr, c_ptr, c_int] + [c_ptr] * 5),
+    'brcnn_rpn_loss_backward': (c_int, [c_ptr, c_int, c_int, c_int] + [c_ptr] * 5 + [c_int] + [c_ptr] * 8 +
+                                [c_size, c_ptr, c_ptr, c_ptr]),
+    'brcnn_boost_loss_workspace_bytes': (c_size, [c_int]),
+    'brcnn_boost_loss_forward': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr, c_ptr, c_ptr]),
+    'brcnn_boost_loss_backward': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int] + [c_ptr] * 6),
 }
 
 

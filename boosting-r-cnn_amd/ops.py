@@ -220,9 +220,11 @@ def nms_ranges(boxes, scores, ranges, max_segment_len, iou_threshold, offset=0, 
     return keep, num_keep
 
 
-def nms_prepare(boxes, scores, ids, valid):
+def nms_prepare(boxes, scores, ids, valid, level_sizes=None):
     """(B,T,4) f32, (B,T) f32, (B,T) int64, (B,T) bool -> compacted c_boxes, c_scores, c_ids, the offset
-    boxes for the segmented NMS and the (B,2) int32 ranges, in one launch (brcnn_nms_prepare)"""
+    boxes for the segmented NMS and the (B,2) int32 ranges, in one launch (brcnn_nms_prepare).
+    `level_sizes` (host ints, sum == T): the slot's column ranges carry one id each (mmcv batched_nms
+    above split_thr) -> ranges (B*L, 2), one segment per (image, id) (brcnn_nms_prepare_levels)."""
     _require_gpu(boxes, scores, ids, valid)
     B, T = scores.shape
     boxes, scores = boxes.contiguous().float(), scores.contiguous().float()
@@ -230,11 +232,35 @@ def nms_prepare(boxes, scores, ids, valid):
     valid = valid.contiguous().to(torch.uint8) if valid.dtype != torch.bool else valid.contiguous().view(torch.uint8)
     c_boxes, nms_boxes = torch.empty_like(boxes), torch.empty_like(boxes)
     c_scores, c_ids = torch.empty_like(scores), torch.empty_like(ids)
+    if level_sizes is not None:
+        import ctypes
+        L = len(level_sizes)
+        ranges = torch.empty((B * L, 2), dtype=torch.int32, device=boxes.device)
+        st = _L.load().brcnn_nms_prepare_levels(_ptr(boxes), _ptr(scores), _ptr(ids), _ptr(valid), _ptr(c_boxes),
+                                                _ptr(c_scores), _ptr(c_ids), _ptr(nms_boxes), _ptr(ranges), B, T, L,
+                                                (ctypes.c_int * L)(*[int(v) for v in level_sizes]), _stream())
+        _L.check(st, 'brcnn_nms_prepare_levels')
+        return c_boxes, c_scores, c_ids, nms_boxes, ranges
     ranges = torch.empty((B, 2), dtype=torch.int32, device=boxes.device)
     st = _L.load().brcnn_nms_prepare(_ptr(boxes), _ptr(scores), _ptr(ids), _ptr(valid), _ptr(c_boxes), _ptr(c_scores),
                                      _ptr(c_ids), _ptr(nms_boxes), _ptr(ranges), B, T, _stream())
     _L.check(st, 'brcnn_nms_prepare')
     return c_boxes, c_scores, c_ids, nms_boxes, ranges
+
+
+def nms_collect_sorted(keep, num, ranges, c_boxes, c_scores, c_ids, K, L, new_scores5=None):
+    """survivors of the per-(image, id) NMS re-sorted per image by score, first K (mmcv batched_nms above
+    split_thr): dets (B,K,5) zero padded, ids_kept (B,K) (-1 padded), n_kept (B,) int32"""
+    _require_gpu(keep, num, ranges, c_boxes, c_scores, c_ids, new_scores5)
+    B, T = c_scores.shape
+    dets = torch.empty((B, K, 5), dtype=torch.float32, device=c_boxes.device)
+    ids_kept = torch.empty((B, K), dtype=torch.int64, device=c_boxes.device)
+    n_kept = torch.empty((B,), dtype=torch.int32, device=c_boxes.device)
+    st = _L.load().brcnn_nms_collect_sorted(_ptr(keep), _ptr(num), _ptr(ranges.contiguous()), _ptr(c_boxes),
+                                            _ptr(c_scores), _ptr(c_ids), _ptr(new_scores5), _ptr(dets), _ptr(ids_kept),
+                                            _ptr(n_kept), B, T, int(L), int(K), _stream())
+    _L.check(st, 'brcnn_nms_collect_sorted')
+    return dets, ids_kept, n_kept
 
 
 def nms_collect(keep, num, c_boxes, c_scores, c_ids, K):
@@ -774,7 +800,7 @@ def rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds,
 
 
 def rpn_decode_levels(topk_inds, bbox_preds, base_anchors, feat_hws, strides, means, stds, max_shape, min_size,
-                      wh_ratio_clip=16 / 1000, pred_scales=None):
+                      wh_ratio_clip=16 / 1000, pred_scales=None, max_shapes=None):
     """rpn_decode for all levels in one launch.  Per-level lists: topk_inds (B,k_l) int64, bbox_preds
     (B,H_l,W_l,4A) NHWC (possibly channel slices), base_anchors (A,4), feat_hws, strides.
     Returns proposals (B,T,4), valid (B,T) bool, ids (B,T) int64 (level index), T = sum k_l."""
@@ -800,10 +826,23 @@ def rpn_decode_levels(topk_inds, bbox_preds, base_anchors, feat_hws, strides, me
     ints = lambda vs: (ctypes.c_int * L)(*[int(v) for v in vs])               # noqa: E731
     sw = [s_ if isinstance(s_, int) else s_[0] for s_ in strides]
     sh = [s_ if isinstance(s_, int) else s_[1] for s_ in strides]
-    scales = (ctypes.c_float * L)(*[float(v) for v in (pred_scales or [1.0] * L)])
     m4 = (ctypes.c_float * 4)(*[float(v) for v in means])
     s4 = (ctypes.c_float * 4)(*[float(v) for v in stds])
     mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    if isinstance(pred_scales, torch.Tensor):
+        # the live Scale parameters, read on the device (training: no host read-back)
+        _require_gpu(pred_scales)
+        assert pred_scales.numel() == L and pred_scales.dtype == torch.float32 and pred_scales.is_contiguous()
+        if max_shapes is not None:      # (B, 2) [h, w] per-image clip border on the device
+            _require_gpu(max_shapes)
+            assert max_shapes.shape == (b, 2) and max_shapes.dtype == torch.float32 and max_shapes.is_contiguous()
+        st = _L.load().brcnn_rpn_decode_levels_dscale(
+            ptrs(inds), ptrs(bbox_preds), ints(pstr), _ptr(pred_scales), _ptr(max_shapes), ptrs(bases), b, L, ints(counts),
+            ints([h for h, _ in feat_hws]), ints([w for _, w in feat_hws]), a, ints(sw), ints(sh), m4, s4,
+            float(wh_ratio_clip), mh, mw, float(min_size), _ptr(props), _ptr(valid), _ptr(ids), _stream())
+        _L.check(st, 'brcnn_rpn_decode_levels_dscale')
+        return props, valid, ids
+    scales = (ctypes.c_float * L)(*[float(v) for v in (pred_scales or [1.0] * L)])
     st = _L.load().brcnn_rpn_decode_levels(ptrs(inds), ptrs(bbox_preds), ints(pstr), scales, ptrs(bases), b, L,
                                            ints(counts), ints([h for h, _ in feat_hws]), ints([w for _, w in feat_hws]),
                                            a, ints(sw), ints(sh), m4, s4, float(wh_ratio_clip), mh, mw, float(min_size),

@@ -64,7 +64,7 @@ def batched_nms_images(boxes, scores, ids, valid, iou_threshold, max_keep, offse
 
 
 def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_threshold, max_keep, offset=0,
-                                return_ids=False, soft=None):
+                                return_ids=False, soft=None, fused=None):
     """mmcv `batched_nms` above `split_thr` for a whole mini-batch, no host sync: NMS per id
     (pyramid level) on the offset boxes, survivors re-sorted by score, first `max_keep`
     (mmcv/ops/nms.py batched_nms, the `for id in torch.unique(idxs)` branch).  Column ranges
@@ -77,6 +77,25 @@ def batched_nms_images_by_level(boxes, scores, ids, valid, level_sizes, iou_thre
     assert sum(level_sizes) == T
     device = scores.device
     K = min(max_keep, T) if max_keep > 0 else T
+    if fused is None:
+        fused = boxes.is_cuda and boxes.dtype == torch.float32 and T <= 16384 and L <= 8
+    if fused:
+        # compaction + per-(image, id) ranges, the segmented (soft-)NMS, the per-image re-sort: 3 entries
+        c_boxes, c_scores, c_ids, boxes_for_nms, ranges = ops.nms_prepare(boxes, scores, ids, valid,
+                                                                          level_sizes=level_sizes)
+        sdets = None
+        if soft is not None:
+            method = {'naive': 0, 'linear': 1, 'gaussian': 2}[soft.get('method', 'linear')]
+            sdets, keep, num = ops.soft_nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges,
+                                                   iou_threshold, soft.get('sigma', 0.5), soft.get('min_score', 1e-3),
+                                                   method, offset)
+        else:
+            keep, num = ops.nms_ranges(boxes_for_nms.view(-1, 4), c_scores.reshape(-1), ranges, max(level_sizes),
+                                       iou_threshold, offset, -1)
+        dets, ids_kept, n_kept = ops.nms_collect_sorted(keep, num, ranges, c_boxes, c_scores, c_ids, K, L, sdets)
+        if return_ids:
+            return dets, ids_kept.to(ids.dtype), n_kept
+        return dets, n_kept
     cnt = valid.sum(1)
     dest = torch.cumsum(valid, 1) - 1
     dest = torch.where(valid, dest, torch.full_like(dest, T))

@@ -447,6 +447,76 @@ class ProbRoIHead(nn.Module):
         losses.update(bbox_results['loss_bbox'])
         return losses
 
+    # ---- device-resident train step ---------------------------------------------------------
+    def device_train_ok(self):
+        """the configuration the whole-batch assignment / sampling / boosting-loss kernels cover: the
+        shipped ProbRoIHead recipes (boost=True, CrossEntropy + L1, MaxIoU assignment, RandomSampler)"""
+        from .core import MaxIoUAssigner, RandomSampler
+        from .losses import CrossEntropyLoss, L1Loss
+        h = self.bbox_head
+        return bool(
+            type(self) is ProbRoIHead and self.boost and self.train_cfg is not None and
+            type(self.bbox_assigner) is MaxIoUAssigner and self.bbox_assigner.ignore_iof_thr <= 0 and
+            (not self.bbox_assigner.match_low_quality or self.bbox_assigner.gt_max_assign_all) and
+            type(self.bbox_sampler) is RandomSampler and self.bbox_sampler.num <= 2048 and
+            type(h.loss_cls) is CrossEntropyLoss and not h.loss_cls.use_sigmoid and h.loss_cls.class_weight is None and
+            h.loss_cls.ignore_index is None and type(h.loss_bbox) is L1Loss and not h.focal_reg and
+            not h.reg_decoded_bbox and self.train_cfg.pos_weight <= 0 and self.bbox_roi_extractor._fusable())
+
+    def sample_device(self, dets, num, gt_flat, overlap_work=None):
+        """assignment + RandomSampler + targets + priors of the whole batch (prob_roi_head.py:23-69,
+        bbox_head.py:122-253) from the padded proposals `dets` (B,K,5) / `num` (B,).  The one host
+        read of the train step happens here: the (B,2) candidate counts the seeded host `randperm`
+        needs; `overlap_work()` is called while that copy is in flight (the caller queues the RPN
+        loss kernels there, so the device has work while the host waits and draws)."""
+        from . import train_ops
+        gts, gt_labels, offs = gt_flat
+        B, K, _ = dets.shape
+        a, sp = self.bbox_assigner, self.bbox_sampler
+        res = train_ops.assign_max_iou(dets, gts, offs, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou, a.match_low_quality,
+                                       num_boxes=num, want_overlaps=self.quality, want_counts=True)
+        gt_inds, mo, counts = (res[0], res[1], res[2]) if self.quality else (res[0], None, res[1])
+        host = self.__dict__.setdefault('_count_host', {})
+        if host.get('B') != B:
+            host.update(B=B, counts=torch.empty((B, 2), dtype=torch.int32).pin_memory(),
+                        perm=torch.empty((B, int(sp.num * sp.pos_fraction) + sp.num), dtype=torch.int32).pin_memory())
+        host['counts'].copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        extra = overlap_work() if overlap_work is not None else None
+        ev.synchronize()
+        num_pos = int(sp.num * sp.pos_fraction)
+        cnt = []
+        for b, (p_, n_) in enumerate(host['counts'].tolist()):
+            g = offs[b + 1] - offs[b]
+            cnt.append((p_ + (g if sp.add_gt_as_proposals else 0), n_))
+            if min(cnt[-1][0], num_pos) < g:
+                raise RuntimeError(f'image {b}: {g} ground-truth boxes exceed the {num_pos} positive slots of the '
+                                   f'sampler (the reference prior extraction fails on this too)')
+        perm, rows = train_ops.draw_sampler_perms(cnt, sp.num, num_pos, sp.neg_pos_ub)
+        host['perm'].copy_(perm)
+        perm_dev = host['perm'].to(dets.device, non_blocking=True)
+        coder = self.bbox_head.bbox_coder
+        out = train_ops.rcnn_sample(dets, num, gt_inds, mo, gts, gt_labels, offs, perm_dev, rows, sp.num, num_pos,
+                                    sp.neg_pos_ub, self.bbox_head.num_classes, coder.means, coder.stds,
+                                    add_gt_as_proposals=sp.add_gt_as_proposals,
+                                    reg_decoded_bbox=self.bbox_head.reg_decoded_bbox, want_ious=self.quality)
+        out['rows'] = rows
+        return out, extra
+
+    def forward_train_device(self, feats_nhwc, img_metas, dets, num, gt_flat, overlap_work=None):
+        """ProbRoIHead.forward_train on the padded device proposals; returns (losses, overlap_work's result)"""
+        from . import train_ops
+        smp, extra = self.sample_device(dets, num, gt_flat, overlap_work)
+        roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, smp['rois'])
+        cls_score, bbox_pred = self.bbox_head.forward_nhwc(roi_feats)
+        h = self.bbox_head
+        out3 = train_ops.boost_loss(cls_score, bbox_pred, smp['labels'], smp['priors'], smp['bbox_targets'],
+                                    h.num_classes, self.gamma, self.alpha, smp.get('ious'), self.iou_gamma,
+                                    h.loss_cls.loss_weight, h.loss_bbox.loss_weight, self.reg_norm, h.reg_class_agnostic)
+        self.last_samples = smp
+        return dict(loss_cls=out3[0], loss_bbox=out3[1], acc=out3[2].reshape(1)), extra
+
     def _bbox_forward(self, x, rois):
         bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
         cls_score, bbox_pred = self.bbox_head(bbox_feats)

@@ -35,6 +35,7 @@ extern "C" {
 #define BRCNN_DT_BF16_OUT_F32 2  /* bf16 operands, fp32 accumulate, fp32 result  */
 
 #define BRCNN_MAX_LEVELS 8
+#define BRCNN_MAX_IMAGES 64      /* images per call of the whole-batch train-step entries */
 
 /* library / device info -------------------------------------------------------- */
 int brcnn_version(void);
@@ -109,6 +110,23 @@ int brcnn_nms_prepare(const float *boxes, const float *scores, const int64_t *id
 int brcnn_nms_collect(const int64_t *keep, const int32_t *num, const float *c_boxes, const float *c_scores,
                       const int64_t *c_ids, float *dets, int64_t *ids_kept, int batch, int slot,
                       int max_keep, void *stream);
+
+/* The same for mmcv batched_nms at or above split_thr (its per-id branch, mmcv/ops/nms.py; the training
+ * proposal stage has 15 150 candidates per image, atss_rpn_head.py:756, and the 80-class second stage
+ * 256 x 80): candidate columns [sum level_sizes[:l], +level_sizes[l]) of a slot carry id l, so after
+ * the order-preserving compaction every (image, id) is one segment -- ranges is (batch*num_levels, 2).
+ * brcnn_nms_collect_sorted then re-sorts an image's survivors of all ids by score (descending, ties by
+ * ascending candidate position) and keeps the first max_keep: dets (batch, max_keep, 5) zero padded,
+ * ids_kept (batch, max_keep) (-1 padded) or NULL, n_kept (batch).  new_scores5: rows of 5 floats aligned
+ * with `keep` whose column 4 replaces the score (soft-NMS picks), or NULL.  slot <= 16384. */
+int brcnn_nms_prepare_levels(const float *boxes, const float *scores, const int64_t *ids, const uint8_t *valid,
+                             float *c_boxes, float *c_scores, int64_t *c_ids, float *nms_boxes,
+                             int32_t *ranges, int batch, int slot, int num_levels,
+                             const int *level_sizes_host, void *stream);
+int brcnn_nms_collect_sorted(const int64_t *keep, const int32_t *num, const int32_t *ranges,
+                             const float *c_boxes, const float *c_scores, const int64_t *c_ids,
+                             const float *new_scores5, float *dets, int64_t *ids_kept, int32_t *n_kept,
+                             int batch, int slot, int num_levels, int max_keep, void *stream);
 
 /* ------------------------------------------------------------------------------
  * NMS.  Replaces mmcv.ops.nms (ext `nms(boxes, scores, iou_threshold, offset)`),
@@ -385,6 +403,17 @@ int brcnn_rpn_decode_levels(const int64_t *const *topk_inds, const float *const 
                             const int *strides_h, const float *means4_host, const float *stds4_host,
                             double wh_ratio_clip, float max_h, float max_w, float min_size,
                             float *proposals, uint8_t *valid, int64_t *ids, void *stream);
+/* the same with the per-level scales read from DEVICE memory (num_levels floats): the training
+ * proposal stage decodes with the live Scale parameters without reading them back to the host;
+ * max_shape_dev (batch, 2) [h, w] device = per-image clip border (img_shape differs inside a
+ * training batch), or NULL to use max_h / max_w */
+int brcnn_rpn_decode_levels_dscale(const int64_t *const *topk_inds, const float *const *bbox_pred,
+                                   const int *pred_strides, const float *pred_scales_dev,
+                                   const float *max_shape_dev, const float *const *base_anchors, int batch, int num_levels, const int *counts,
+                                   const int *heights, const int *widths, int num_anchors, const int *strides_w,
+                                   const int *strides_h, const float *means4_host, const float *stds4_host,
+                                   double wh_ratio_clip, float max_h, float max_w, float min_size,
+                                   float *proposals, uint8_t *valid, int64_t *ids, void *stream);
 
 /* Second-stage candidates of a whole batch in one launch: the score fusion of
  * prob_roi_head.py:232-240 and ProbConvFCBBoxHead.get_bboxes (convfc_bbox_head.py:294-330) up to
@@ -417,6 +446,107 @@ int brcnn_rpn_topk(const float *const *score_levels, const int *n_host, int num_
 int brcnn_preprocess_u8(const uint8_t *src, int src_h, int src_w, float *dst, int new_h,
                         int new_w, int pad_h, int pad_w, int flip, const float *mean3_host,
                         const float *std3_host, int to_rgb, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * Train step: whole-batch target assignment, RoI sampling and the fused losses.
+ * The reference runs these per image / per level as chains of small torch ops with host
+ * synchronisations (nonzero / unique / .item()); each entry below serves the whole batch.
+ * Ground truth is passed flat: gts (sum G, 4) [+ gt_labels (sum G) int64], image b owning rows
+ * [gt_offsets_host[b], gt_offsets_host[b+1]) (HOST array of batch+1 ints; batch <= BRCNN_MAX_IMAGES).
+ *
+ * brcnn_assign_max_iou -- MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:61-213)
+ *   over BboxOverlaps2D (core/bbox/iou_calculators/iou2d_calculator.py:30-261, mode 'iou').
+ *   boxes: image b's n rows start at boxes + b*box_batch_stride (0: shared anchors), box_row_stride
+ *   floats per row (5 for proposals with a score column); num_boxes (batch) real rows or NULL.
+ *   num_levels > 0 describes RPN anchors (level_start_host[L+1] first anchor of each level,
+ *   level_width_host[L] cells per row, anchors_per_cell): valid_hw (batch, L, 2) device
+ *   [valid_h, valid_w] in cells reproduces AnchorGenerator.valid_flags
+ *   (core/anchor/anchor_generator.py:383-440), img_hw (batch, 2) + allowed_border >= 0
+ *   anchor_inside_flags (core/anchor/utils.py:21-47); either may be NULL.  Boxes that fail take no
+ *   part and come out as -1.  neg_iou_thr as [neg_iou_lo, neg_iou_hi) (a float thr is [0, thr)).
+ *   gt_max_ws (sum G) uint32 scratch for match_low_quality.  Writes gt_inds (batch, n) int32
+ *   (-1 ignore, 0 negative, k matched to gt k-1), max_overlaps (batch, n) or NULL, counts (batch, 2)
+ *   [#positive, #negative] or NULL.  Index-exact with the reference on the host (first maximum on
+ *   ties, later ground truth overriding earlier in the low-quality pass).
+ *
+ * brcnn_rcnn_sample -- RandomSampler.sample (core/bbox/samplers/base_sampler.py:35-102,
+ *   random_sampler.py:32-82), SamplingResult (sampling_result.py:26-55), the prior extraction of
+ *   ProbRoIHead.forward_train (models/roi_heads/prob_roi_head.py:51-64), bbox2roi
+ *   (core/bbox/transforms.py:59-78) and BBoxHead._get_target_single (bbox_heads/bbox_head.py:122-196).
+ *   proposals (batch, per_image, 5) zero padded with num_props[b] real rows; gt_inds / max_overlaps
+ *   from brcnn_assign_max_iou on them.  perm (batch, num_expected_pos + num) int32: image b's first
+ *   num_expected_pos entries are torch.randperm(n_pos)[:num_expected_pos] when n_pos exceeds it, the
+ *   rest randperm(n_neg)[:expected_neg] likewise (drawn on the host: the reference's seeded stream);
+ *   row_offsets_host (batch+1): first output row of each image (host knows the counts).
+ *   list_ws (batch, 2, list_stride) int32 scratch, list_stride >= per_image + max G.
+ *   Writes rois (N,5), labels (N) int64 (background = num_classes), bbox_targets (N,4) (encoded
+ *   with means / stds, or the matched gt box when reg_decoded_bbox), priors (N), ious (N) or NULL
+ *   (`quality`), pos_flags (N) int32 or NULL; rows of an image are [positives | negatives], each
+ *   ascending in candidate index.
+ *
+ * brcnn_rpn_loss_* -- ATSSRPNHead.loss / loss_single (models/dense_heads/atss_rpn_head.py:299-464)
+ *   for reg_decoded_bbox=True, IoULoss(mode 'log') [+ MSELoss aug], FocalLoss, sigmoid-BCE IoU
+ *   branch.  y (rows, ystride) is the fused head output of all levels, level-major rows
+ *   (level l: batch*H_l*W_l rows), channels [cls A | reg 4A | iou A | padding]; scales (L) the
+ *   per-level Scale parameters (device); gt_inds (batch, anchors per image) from
+ *   brcnn_assign_max_iou.  cfg18_host = [focal_gamma, focal_alpha, pos_weight, iou_gamma(self.gamma),
+ *   mean4, std4, max_ratio |ln(wh_ratio_clip)|, with_aug, lw_cls, lw_bbox, lw_aug, lw_iou].
+ *   forward: sums (L, 6) [focal, iou-loss, mse, bce, iou_target, n_pos] and totals (2)
+ *   [n_pos, sum iou_target] of THIS rank; the caller averages totals over ranks (reduce_mean,
+ *   :440-444,458-460) and calls finalize: losses3 = [loss_rpn_cls, loss_rpn_bbox, loss_rpn_iou]
+ *   summed over levels, per_level (3, L), coef2 = the two reciprocal normalisers the backward uses.
+ *   backward: grad3 (3) device = dLoss/dlosses3; writes dy (rows, ystride) and dscales (L).
+ *   Deterministic (fixed-order partial sums, no float atomics).
+ *
+ * brcnn_boost_loss_* -- ProbRoIHead._bbox_forward_train_boost + norm_loss
+ *   (models/roi_heads/prob_roi_head.py:107-154) over ProbConvFCBBoxHead.loss
+ *   (bbox_heads/convfc_bbox_head.py:332-418; CrossEntropyLoss + L1Loss, reduction 'none').
+ *   cfg6_host = [gamma, alpha, iou_gamma, loss_cls weight, loss_bbox weight, reg_norm == 'mean'].
+ *   out3 = [loss_cls, loss_bbox, acc]; backward: dcls (n, C+1), dbbox (n, 4C | 4).
+ * -------------------------------------------------------------------------- */
+int brcnn_assign_max_iou(const float *boxes, int64_t box_batch_stride, int box_row_stride,
+                         const int32_t *num_boxes, int n, int batch, const float *gts,
+                         const int *gt_offsets_host, int num_levels, const int *level_start_host,
+                         const int *level_width_host, int anchors_per_cell, const int32_t *valid_hw,
+                         const float *img_hw, float allowed_border, float pos_iou_thr, float neg_iou_lo,
+                         float neg_iou_hi, float min_pos_iou, int match_low_quality, uint32_t *gt_max_ws,
+                         int32_t *gt_inds, float *max_overlaps, int32_t *counts, void *stream);
+int brcnn_rcnn_sample(const float *proposals, const int32_t *num_props, int per_image, int batch,
+                      const int32_t *gt_inds, const float *max_overlaps, const float *gts,
+                      const int64_t *gt_labels, const int *gt_offsets_host, int add_gt_as_proposals,
+                      int num, int num_expected_pos, float neg_pos_ub, const int32_t *perm,
+                      const int *row_offsets_host, int num_classes, int reg_decoded_bbox,
+                      const float *means4_host, const float *stds4_host, int32_t *list_ws,
+                      int list_stride, float *rois, int64_t *labels, float *bbox_targets, float *priors,
+                      float *ious, int32_t *pos_flags, void *stream);
+size_t brcnn_rpn_loss_workspace_bytes(int batch, int num_levels, const int *heights, const int *widths,
+                                      int anchors_per_cell);
+int brcnn_rpn_loss_forward(const float *y, int ystride, int batch, int num_levels, const int *heights,
+                           const int *widths, const int *strides_w, const int *strides_h,
+                           const float *const *base_anchors, int anchors_per_cell, const float *scales,
+                           const int32_t *gt_inds, const float *gts, const int *gt_offsets_host,
+                           const float *cfg18_host, void *workspace, size_t workspace_bytes, float *sums,
+                           float *totals, void *stream);
+int brcnn_rpn_loss_finalize(const float *sums, const float *totals, int num_levels, const float *cfg18_host,
+                            float *losses3, float *per_level, float *coef2, void *stream);
+int brcnn_rpn_loss_backward(const float *y, int ystride, int batch, int num_levels, const int *heights,
+                            const int *widths, const int *strides_w, const int *strides_h,
+                            const float *const *base_anchors, int anchors_per_cell, const float *scales,
+                            const int32_t *gt_inds, const float *gts, const int *gt_offsets_host,
+                            const float *cfg18_host, const float *grad3, const float *coef2,
+                            void *workspace, size_t workspace_bytes, float *dy, float *dscales,
+                            void *stream);
+size_t brcnn_boost_loss_workspace_bytes(int n);
+int brcnn_boost_loss_forward(const float *cls_score, const float *bbox_pred, const int64_t *labels,
+                             const float *priors, const float *ious, const float *bbox_targets, int n,
+                             int num_classes, int reg_class_agnostic, const float *cfg6_host,
+                             void *workspace, size_t workspace_bytes, float *out3, float *coef2,
+                             void *stream);
+int brcnn_boost_loss_backward(const float *cls_score, const float *bbox_pred, const int64_t *labels,
+                              const float *priors, const float *ious, const float *bbox_targets, int n,
+                              int num_classes, int reg_class_agnostic, const float *cfg6_host,
+                              const float *grad3, const float *coef2, float *dcls, float *dbbox,
+                              void *stream);
 
 #ifdef __cplusplus
 }

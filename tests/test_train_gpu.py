@@ -1,0 +1,381 @@
+"""-m gpu: the whole-batch train-step kernels (target assignment, RoI sampling, fused RPN loss,
+boosting loss, per-level batched NMS) against the golden fixtures produced by the imported
+reference (g4 / g6 / g7 / g10) and against this repository's CPU restatement of the reference
+(`brcnn.core`, itself pinned to the same fixtures by tests/test_host_cpu.py) on seeded random
+inputs.  Bars: assignment / sampling indices and IoUs bit-exact; losses 1e-5 relative; gradients
+1e-4 relative (fp32 round-off of a different summation order)."""
+import numpy as np
+import pytest
+import torch
+
+import brcnn  # noqa: F401
+from brcnn import Config, build_detector, core, ops, train_ops
+from tests import util
+from tests.test_host_cpu import CFG, T, _rpn_head, load
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+RPN_KW = dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0, match_low_quality=True, ignore_iof_thr=-1)
+RCNN_KW = dict(pos_iou_thr=0.6, neg_iou_thr=0.6, min_pos_iou=0.6, match_low_quality=False, ignore_iof_thr=-1)
+
+
+def _assign_dev(boxes, gts_list, kw, **extra):
+    gts, _, offs = train_ops.flatten_gts([g.to(DEV) for g in gts_list])
+    return train_ops.assign_max_iou(boxes, gts, offs, kw['pos_iou_thr'], kw['neg_iou_thr'], kw['min_pos_iou'],
+                                    kw['match_low_quality'], **extra)
+
+
+def test_assign_golden():
+    """the reference's own MaxIoUAssigner outputs (fixture g4), both parameterisations"""
+    g = load('g4_assign_sample')
+    boxes, gts = T(g['boxes']).to(DEV), T(g['gts'])
+    for name, kw in (('rpn', RPN_KW), ('rcnn', RCNN_KW)):
+        gi, mo, cnt = _assign_dev(boxes.contiguous(), [gts], kw, batch=1, want_overlaps=True, want_counts=True)
+        ref = T(g[name + '_gt_inds'])
+        assert torch.equal(gi[0].cpu().long(), ref), name
+        assert torch.equal(mo[0].cpu(), T(g[name + '_max_overlaps'])), name
+        assert cnt.cpu().tolist() == [[int((ref > 0).sum()), int((ref == 0).sum())]]
+
+
+def test_assign_reference_known_answers():
+    """tests/test_utils/test_assigner.py:16-61"""
+    bb = torch.tensor([[0, 0, 10, 10], [10, 10, 20, 20], [5, 5, 15, 15], [32, 32, 38, 42.]], device=DEV)
+    gg = torch.tensor([[0, 0, 10, 9], [0, 10, 10, 19.]])
+    kw = dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.0, match_low_quality=True)
+    assert _assign_dev(bb, [gg], kw, batch=1)[0].tolist() == [1, 0, 2, 0]
+    assert _assign_dev(bb, [torch.empty(0, 4)], kw, batch=1)[0].tolist() == [0, 0, 0, 0]
+
+
+def _anchor_case(seed, sizes, pad_shapes, strides, num_gts, border=-1):
+    """RPN anchors of a small pyramid, per-image padded shapes and ground truth; returns the device
+    result and the CPU restatement (anchor_head.py:199-262 via brcnn.core)"""
+    gen = core.AnchorGenerator(strides=strides, ratios=[0.5, 1.0, 2.0], octave_base_scale=4, scales_per_octave=3)
+    anchors = torch.cat(gen.grid_anchors(sizes, 'cpu'), 0)
+    W, H = sizes[0][1] * strides[0], sizes[0][0] * strides[0]
+    g = torch.Generator().manual_seed(seed)
+    gts = []
+    for n in num_gts:
+        b = util.rand_boxes(n, W, H, seed=seed + n, min_size=8, max_size=min(W, H) * 0.8) if n else torch.empty(0, 4)
+        if n >= 4:
+            b[1] = b[0]                      # duplicate ground truth: equal IoU columns (tie on argmax)
+            b[2, 2:] = b[2, :2]              # zero-area ground truth: gt_max 0 (the min_pos_iou=0 quirk)
+        gts.append(b)
+    starts = [0]
+    for (h, w) in sizes:
+        starts.append(starts[-1] + h * w * 9)
+    geom = (starts, [w for _, w in sizes], 9)
+    valid_hw = torch.tensor([[[min(int(np.ceil(ps[0] / s)), h), min(int(np.ceil(ps[1] / s)), w)]
+                              for (h, w), s in zip(sizes, strides)] for ps in pad_shapes], dtype=torch.int32)
+    img_hw = torch.tensor([[ps[0], ps[1] - 3] for ps in pad_shapes], dtype=torch.float32)
+    gi, mo = _assign_dev(anchors.to(DEV).contiguous(), gts, RPN_KW, batch=len(num_gts), geom=geom,
+                         valid_hw=valid_hw.to(DEV), img_hw=img_hw.to(DEV) if border >= 0 else None,
+                         allowed_border=border, want_overlaps=True)
+    ref_gi, ref_mo = [], []
+    a = core.MaxIoUAssigner(**RPN_KW)
+    for b, ps in enumerate(pad_shapes):
+        flags = torch.cat(gen.valid_flags(sizes, ps, 'cpu'))
+        inside = core.anchor_inside_flags(anchors, flags, (ps[0], ps[1] - 3), border)
+        r = a.assign(anchors[inside], gts[b], None, None)
+        ref_gi.append(core.unmap(r.gt_inds, anchors.shape[0], inside, fill=-1))
+        ref_mo.append(core.unmap(r.max_overlaps, anchors.shape[0], inside, fill=0))
+    return gi.cpu().long(), mo.cpu(), torch.stack(ref_gi), torch.stack(ref_mo)
+
+
+@pytest.mark.parametrize('border', [-1, 0])
+def test_assign_anchors_batch_vs_cpu(border):
+    sizes = [(32, 48), (16, 24), (8, 12), (4, 6), (2, 3)]
+    pads = [(256, 384), (200, 384), (256, 300), (160, 200)]
+    gi, mo, rgi, rmo = _anchor_case(3, sizes, pads, [8, 16, 32, 64, 128], [7, 0, 300, 5], border)
+    assert torch.equal(gi, rgi)
+    assert torch.equal(mo, rmo)
+    assert (gi > 0).any() and (gi == -1).any()
+
+
+def test_assign_full_size_properties():
+    """BASELINE size: 8 images x 201 600 anchors x 20 ground truths -- every ground truth owns at least one
+    anchor (low-quality rule), positives overlap their ground truth by >= the threshold or are its best match"""
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    gen = core.AnchorGenerator(strides=[8, 16, 32, 64, 128], ratios=[0.5, 1.0, 2.0], octave_base_scale=4,
+                               scales_per_octave=3)
+    anchors = torch.cat(gen.grid_anchors(sizes, 'cpu'), 0).to(DEV).contiguous()
+    assert anchors.shape[0] == 201600
+    gts = [util.rand_boxes(20, 1333, 800, seed=40 + b, min_size=16, max_size=600) for b in range(8)]
+    gi, mo = _assign_dev(anchors, gts, RPN_KW, batch=8, want_overlaps=True)
+    gi, mo = gi.cpu().long(), mo.cpu()
+    for b in range(8):
+        assert set(range(1, 21)) <= set(gi[b].unique().tolist())
+        iou = core.bbox_overlaps(gts[b], anchors.cpu())
+        assert torch.equal(mo[b], iou.max(0)[0])
+        pos = gi[b] > 0
+        own = iou[gi[b][pos] - 1, pos.nonzero().squeeze(1)]
+        assert ((own >= 0.5) | (own == iou.max(1)[0][gi[b][pos] - 1])).all()
+        assert ((gi[b] == 0) == ((mo[b] < 0.5) & ~pos)).all()
+
+
+def _cpu_rcnn_chain(props_list, gts, gls, seed, quality=False, num=512):
+    """ProbRoIHead.forward_train's sampling block on the CPU restatement (prob_roi_head.py:23-69)"""
+    cfg = Config.fromfile(CFG)
+    head = brcnn.build_head(cfg.model.roi_head.bbox_head)
+    a = core.MaxIoUAssigner(**RCNN_KW)
+    sp = core.RandomSampler(num=num, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    torch.manual_seed(seed)
+    srs, priors, ious = [], [], []
+    for p, g, l in zip(props_list, gts, gls):
+        r = a.assign(p, g, None, l)
+        s = sp.sample(r, p, g, l)
+        srs.append(s)
+        n = r.num_gts
+        pi, ni = s.pos_inds[n:].clone() - n, s.neg_inds.clone() - n
+        priors.append(torch.cat([p.new_zeros(n), p[pi, -1], 1 - p[ni, -1]]))
+        ious.append(torch.cat([r.max_overlaps[s.pos_inds], 1 - r.max_overlaps[s.neg_inds]]))
+    rois = core.bbox2roi([s.bboxes for s in srs])
+    labels, _, tgt, _ = head.get_targets(srs, gts, gls, cfg.model.train_cfg.rcnn)
+    return rois, labels, tgt, torch.cat(priors), torch.cat(ious), srs
+
+
+def _dev_rcnn_chain(props_list, gts, gls, seed, num=512):
+    B = len(props_list)
+    K = max(p.shape[0] for p in props_list)
+    dets = torch.zeros(B, K, 5)
+    for b, p in enumerate(props_list):
+        dets[b, :p.shape[0]] = p
+    nums = torch.tensor([p.shape[0] for p in props_list], dtype=torch.int32)
+    dets, nums = dets.to(DEV), nums.to(DEV)
+    gflat, lflat, offs = train_ops.flatten_gts([g.to(DEV) for g in gts], [l.to(DEV) for l in gls])
+    gi, mo, cnt = train_ops.assign_max_iou(dets, gflat, offs, 0.6, 0.6, 0.6, False, num_boxes=nums, want_overlaps=True,
+                                           want_counts=True)
+    counts = [(p_ + offs[b + 1] - offs[b], n_) for b, (p_, n_) in enumerate(cnt.cpu().tolist())]
+    torch.manual_seed(seed)
+    perm, rows = train_ops.draw_sampler_perms(counts, num, int(num * 0.25), -1)
+    out = train_ops.rcnn_sample(dets, nums, gi, mo, gflat, lflat, offs, perm.to(DEV), rows, num, int(num * 0.25), -1, 4,
+                                (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2), want_ious=True, want_pos_flags=True)
+    return out, rows
+
+
+def test_rcnn_sample_golden_and_cpu_chain():
+    g = load('g4_assign_sample')
+    props, gts, labels = T(g['props']), T(g['gts']), T(g['labels'])
+    out, rows = _dev_rcnn_chain([props], [gts], [labels], 1234)
+    assert rows == [0, 512]
+    assert torch.equal(out['rois'][:, 1:].cpu(), T(g['s_bboxes']))         # the reference's sampled boxes, in order
+    assert torch.equal(out['labels'][:128].cpu(), labels[T(g['s_pos_assigned'])])
+    rois, lab, tgt, pri, iou, _ = _cpu_rcnn_chain([props], [gts], [labels], 1234)
+    assert torch.equal(out['rois'].cpu(), rois) and torch.equal(out['labels'].cpu(), lab)
+    assert torch.equal(out['priors'].cpu(), pri) and torch.equal(out['ious'].cpu(), iou)
+    assert torch.allclose(out['bbox_targets'].cpu(), tgt, rtol=1e-5, atol=1e-6)
+    assert out['pos_flags'].cpu().tolist() == [1] * 128 + [0] * 384
+
+
+def test_rcnn_sample_ragged_batch_vs_cpu():
+    """images with many / few / no positives, no ground truth, fewer candidates than the sampler wants"""
+    gts, gls, props = [], [], []
+    spec = [(6, 900, 40), (3, 60, 2), (0, 500, 0), (10, 2000, 80), (2, 300, 0)]
+    for b, (ng, nrand, jit) in enumerate(spec):
+        g = util.rand_boxes(ng, 1333, 800, seed=70 + b, min_size=24, max_size=500) if ng else torch.empty(0, 4)
+        gen = torch.Generator().manual_seed(90 + b)
+        near = (g.repeat(jit, 1) + torch.randn(ng * jit, 4, generator=gen) * 4) if ng and jit else torch.empty(0, 4)
+        bx = torch.cat([near, util.rand_boxes(nrand, 1333, 800, seed=80 + b)], 0)
+        bx = torch.cat([torch.min(bx[:, :2], bx[:, 2:]), torch.max(bx[:, :2], bx[:, 2:]) + 1], 1)
+        bx = bx[torch.randperm(bx.shape[0], generator=gen)]
+        props.append(torch.cat([bx, torch.rand(bx.shape[0], 1, generator=gen)], 1))
+        gts.append(g)
+        gls.append(torch.randint(0, 4, (ng,), generator=gen))
+    out, rows = _dev_rcnn_chain(props, gts, gls, 99)
+    rois, lab, tgt, pri, iou, srs = _cpu_rcnn_chain(props, gts, gls, 99)
+    assert rows[-1] == rois.shape[0]
+    assert [rows[b + 1] - rows[b] for b in range(5)] == [len(s.pos_inds) + len(s.neg_inds) for s in srs]
+    assert torch.equal(out['rois'].cpu(), rois) and torch.equal(out['labels'].cpu(), lab)
+    assert torch.equal(out['priors'].cpu(), pri) and torch.equal(out['ious'].cpu(), iou)
+    assert torch.allclose(out['bbox_targets'].cpu(), tgt, rtol=1e-5, atol=1e-6)
+    assert any(len(s.pos_inds) == 128 for s in srs) and any(len(s.pos_inds) < 128 for s in srs)
+
+
+@pytest.mark.parametrize('gamma', [0.5, 2])
+def test_rpn_loss_golden(gamma):
+    """ATSSRPNHead.loss through its reference signature on device tensors == the fused kernels:
+    per-level loss values and the gradients of every head output against the reference's (fixture g6)"""
+    g = load('g6_rpn_loss')
+    head, _ = _rpn_head()
+    head = head.to(DEV)
+    head.gamma = gamma
+    assert head.device_train_ok()
+    cls = [T(g[f'cls{i}']).to(DEV).requires_grad_() for i in range(5)]
+    reg = [T(g[f'reg{i}']).to(DEV).requires_grad_() for i in range(5)]
+    iou = [T(g[f'iou{i}']).to(DEV).requires_grad_() for i in range(5)]
+    _, metas, _, _ = util.demo_inputs(2, 128, 192, seed=6)
+    gts = [T(g['gt0']).to(DEV), T(g['gt1']).to(DEV)]
+    out = head.loss(cls, reg, iou, gts, metas)
+    per_level = head.last_rpn_targets[1].cpu()
+    for r, k in enumerate(('loss_rpn_cls', 'loss_rpn_bbox', 'loss_rpn_iou')):
+        ref = T(g[f'g{gamma}_{k}'])
+        assert torch.allclose(per_level[r], ref, rtol=1e-5, atol=1e-6), (k, per_level[r], ref)
+        assert torch.allclose(out[k][0].cpu(), ref.sum(), rtol=1e-5, atol=1e-6)
+    tot = sum(sum(v) for v in out.values())
+    grads = torch.autograd.grad(tot, cls + reg + iou)
+    for i in range(5):
+        for j, nm in enumerate(('dcls', 'dreg', 'diou')):
+            ref = T(g[f'g{gamma}_{nm}{i}'])
+            got = grads[5 * j + i].cpu()
+            assert torch.allclose(got, ref, rtol=1e-4, atol=1e-7), (nm, i, (got - ref).abs().max())
+
+
+def test_rpn_loss_scale_gradient_and_padding():
+    """the production layout: raw deltas + learnable per-level Scale, 64-channel padded rows; gradient
+    w.r.t. the scales and the raw head output against autograd of the CPU restatement"""
+    g = load('g6_rpn_loss')
+    head, _ = _rpn_head()
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    _, metas, _, _ = util.demo_inputs(2, 128, 192, seed=6)
+    gts = [T(g['gt0']), T(g['gt1'])]
+    sc = torch.tensor([1.3, 0.7, 1.1, 0.9, 1.5])
+    cls = [T(g[f'cls{i}']) for i in range(5)]
+    raw = [T(g[f'reg{i}']).clone().requires_grad_() for i in range(5)]
+    iou = [T(g[f'iou{i}']) for i in range(5)]
+    scp = sc.clone().requires_grad_()
+    out = head.loss(cls, [r * scp[i] for i, r in enumerate(raw)], iou, gts, metas)          # CPU restatement
+    tot = sum(sum(v) for v in out.values())
+    ref_g = torch.autograd.grad(tot, raw + [scp])
+    rows = [torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in (c_, r_, i_)], 1)
+            for c_, r_, i_ in zip(cls, [r.detach() for r in raw], iou)]
+    y = torch.cat(rows, 0)
+    y = torch.cat([y, torch.full((y.shape[0], 10), 7.0)], 1).to(DEV).requires_grad_()      # 54 -> 64 channels
+    head = head.to(DEV)
+    scd = sc.to(DEV).requires_grad_()
+    o2 = head.loss_fused(y, tuple(sizes), [t.to(DEV) for t in gts], metas, scales=scd)
+    t2 = sum(sum(v) for v in o2.values())
+    assert torch.allclose(t2.cpu(), tot.detach(), rtol=1e-5)
+    gy, gs = torch.autograd.grad(t2, [y, scd])
+    assert torch.allclose(gs.cpu(), ref_g[5], rtol=1e-4, atol=1e-7), (gs, ref_g[5])
+    assert (gy[:, 54:] == 0).all()
+    r0 = 0
+    for i, (h, w) in enumerate(sizes):
+        n = 2 * h * w
+        got = gy[r0:r0 + n, 9:45].view(2, h, w, 36).permute(0, 3, 1, 2).cpu()
+        assert torch.allclose(got, ref_g[i], rtol=1e-4, atol=1e-7), i
+        r0 += n
+
+
+@pytest.mark.parametrize('gamma', [0.5, 0.1])
+def test_boost_loss_golden(gamma):
+    """loss values, accuracy and both gradients of the reference's boosting loss (fixture g7)"""
+    g = load('g7_boost_loss')
+    cls = T(g['cls_score']).to(DEV).requires_grad_()
+    bb = T(g['bbox_pred']).to(DEV).requires_grad_()
+    out3 = train_ops.boost_loss(cls, bb, T(g['labels']).to(DEV), T(g['priors']).to(DEV), T(g['bbox_targets']).to(DEV),
+                                4, gamma, loss_cls_weight=2.0, loss_bbox_weight=2.0)
+    gc, gb = torch.autograd.grad(out3[0] + out3[1], [cls, bb])
+    assert torch.allclose(out3[0].cpu(), T(g[f'g{gamma}_loss_cls']), rtol=1e-5)
+    assert torch.allclose(out3[1].cpu(), T(g[f'g{gamma}_loss_bbox']), rtol=1e-5)
+    assert torch.allclose(out3[2].cpu(), T(g[f'g{gamma}_acc'])[0])
+    assert torch.allclose(gc.cpu(), T(g[f'g{gamma}_dcls']), rtol=1e-4, atol=1e-9)
+    assert torch.allclose(gb.cpu(), T(g[f'g{gamma}_dbbox']), rtol=1e-5, atol=1e-9)
+
+
+def test_boost_loss_80_classes_quality_vs_cpu():
+    """COCO head width (81 logits, two lanes rounds), the `quality` and `alpha` factors, reg_norm='mean',
+    a non-unit upstream gradient"""
+    from brcnn.roi_heads import ProbRoIHead
+    gen = torch.Generator().manual_seed(5)
+    n, C = 700, 80
+    cls = torch.randn(n, C + 1, generator=gen) * 2
+    bb = torch.randn(n, 4 * C, generator=gen)
+    labels = torch.randint(0, C + 1, (n,), generator=gen)
+    labels[::3] = C
+    pri, iou = torch.rand(n, generator=gen), torch.rand(n, generator=gen)
+    tgt = torch.randn(n, 4, generator=gen)
+    c1, b1 = cls.clone().requires_grad_(), bb.clone().requires_grad_()
+    L = 2.0 * torch.nn.functional.cross_entropy(c1, labels, reduction='none')
+    p = torch.gather(c1.softmax(1).detach(), 1, labels[:, None]).squeeze(1)
+    w = ((iou - p).abs() ** 0.7 * (1 - pri) ** 0.3) * 1.5
+    loss_cls = ProbRoIHead.norm_loss(L, w, n)
+    pos = labels < C
+    l1 = 2.0 * (b1.view(n, C, 4)[pos, labels[pos]] - tgt[pos]).abs()
+    loss_bbox = l1.mean()
+    rc, rb = torch.autograd.grad(3.0 * loss_cls + 0.5 * loss_bbox, [c1, b1])
+    c2, b2 = cls.to(DEV).requires_grad_(), bb.to(DEV).requires_grad_()
+    out3 = train_ops.boost_loss(c2, b2, labels.to(DEV), pri.to(DEV), tgt.to(DEV), C, 0.3, alpha=1.5, ious=iou.to(DEV),
+                                iou_gamma=0.7, loss_cls_weight=2.0, loss_bbox_weight=2.0, reg_norm='mean')
+    gc, gb = torch.autograd.grad(3.0 * out3[0] + 0.5 * out3[1], [c2, b2])
+    assert torch.allclose(out3[0].cpu(), loss_cls.detach(), rtol=1e-5)
+    assert torch.allclose(out3[1].cpu(), loss_bbox.detach(), rtol=1e-5)
+    acc = (cls.argmax(1) == labels).float().mean() * 100
+    assert torch.allclose(out3[2].cpu(), acc, rtol=1e-6)
+    assert torch.allclose(gc.cpu(), rc, rtol=2e-4, atol=1e-8)
+    assert torch.allclose(gb.cpu(), rb, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('soft', [None, dict(method='linear', sigma=0.5, min_score=1e-3)])
+def test_batched_nms_by_level_fused_equals_torch_chain(soft):
+    """mmcv batched_nms above split_thr for a whole batch: the three-launch device form against the
+    torch-op chain it replaces (itself tested against the per-image reference path)"""
+    from brcnn.postprocess import batched_nms_images_by_level
+    B, sizes = 3, [4000, 4000, 4000, 2457, 693]
+    T_ = sum(sizes)
+    boxes = torch.stack([util.clustered_boxes(T_, 300, seed=b) for b in range(B)]).to(DEV)
+    scores = torch.stack([util.tie_free_scores(T_, seed=10 + b) for b in range(B)]).to(DEV)
+    ids = torch.cat([torch.full((n,), l) for l, n in enumerate(sizes)]).expand(B, T_).contiguous().to(DEV)
+    valid = (torch.rand(B, T_, generator=torch.Generator().manual_seed(3)) > 0.1).to(DEV)
+    valid[2, 4000:8000] = False                      # an empty (image, level) segment
+    if soft is not None:                             # soft-NMS segments are sequential: keep them short
+        sizes = [500] * 8
+        T_ = 4000
+        boxes, scores, valid = boxes[:, :T_].contiguous(), scores[:, :T_].contiguous(), valid[:, :T_].contiguous()
+        ids = torch.cat([torch.full((n,), l) for l, n in enumerate(sizes)]).expand(B, T_).contiguous().to(DEV)
+    a = batched_nms_images_by_level(boxes, scores, ids, valid, sizes, 0.7, 2000, 0, return_ids=True, soft=soft, fused=True)
+    b = batched_nms_images_by_level(boxes, scores, ids, valid, sizes, 0.7, 2000, 0, return_ids=True, soft=soft, fused=False)
+    assert torch.equal(a[2], b[2].to(a[2].dtype))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def _model(cfg_path=CFG, seed=10):
+    cfg = Config.fromfile(cfg_path)
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=seed))
+    return m.to(DEV).train()
+
+
+def test_train_step_device_path_equals_reference_chain():
+    """the device-resident train step (whole-batch kernels) against the per-image / per-level chain of the
+    reference's structure (device_train_path=False) on the same weights, inputs and sampler seed: every
+    loss and every parameter gradient"""
+    m = _model()
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    res = {}
+    for mode in (True, False):
+        m.device_train_path = mode
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(77)
+        losses = m.forward_train(*args)
+        loss, log_vars = m._parse_losses(losses)
+        loss.backward()
+        res[mode] = (dict(log_vars), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert res[True][0].keys() == res[False][0].keys()
+    for k in res[True][0]:
+        assert np.isclose(res[True][0][k], res[False][0][k], rtol=2e-4, atol=1e-6), (k, res[True][0][k], res[False][0][k])
+    assert res[True][1].keys() == res[False][1].keys()
+    for k, ga in res[True][1].items():
+        gb = res[False][1][k]
+        scale = gb.abs().max().item() + 1e-12
+        assert (ga - gb).abs().max().item() <= 2e-3 * scale, (k, (ga - gb).abs().max().item(), scale)
+
+
+def test_train_step_device_path_mixed_shapes_and_empty_gt():
+    """a batch whose images differ in img_shape / pad_shape (validity flags, per-image clip border) and
+    hold 0 ground truths in one image"""
+    m = _model()
+    img, metas, gts, gls = util.demo_inputs(3, 128, 192, seed=12)
+    metas[1] = dict(metas[1], img_shape=(100, 150, 3), pad_shape=(128, 160, 3))
+    gts[1] = torch.tensor([[10., 12., 90., 80.], [60., 20., 140., 95.]])
+    gls[1] = torch.tensor([1, 3])
+    gts[2], gls[2] = torch.empty(0, 4), torch.empty(0, dtype=torch.long)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    vals = {}
+    for mode in (True, False):
+        m.device_train_path = mode
+        torch.manual_seed(5)
+        loss, log_vars = m._parse_losses(m.forward_train(*args))
+        vals[mode] = dict(log_vars)
+    for k in vals[True]:
+        assert np.isclose(vals[True][k], vals[False][k], rtol=2e-4, atol=1e-6), (k, vals[True][k], vals[False][k])
