@@ -384,6 +384,54 @@ class BnActFunction(Function):
         return dz, dscale, dshift, dres, None
 
 
+class BnEvalActFunction(Function):
+    """out = [relu](bn_eval(z) [+ res]) with the eval-mode BatchNorm parameters themselves: the affine
+    scale = gamma / sqrt(var + eps), shift = beta - mean * scale is formed inside the kernels and the
+    backward returns dgamma / dbeta directly (`brcnn_bn_eval_act_forward/backward`)"""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, mean, var, eps, res, relu):
+        _require_gpu(z, gamma, beta, mean, var, res)
+        z = z.contiguous()
+        c = z.shape[-1]
+        rows = z.numel() // c
+        dt = DT_F32 if z.dtype == torch.float32 else DT_BF16
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        m32, v32 = mean.detach().float().contiguous(), var.detach().float().contiguous()
+        r = res.contiguous() if res is not None else None
+        out = torch.empty_like(z)
+        st = _L.load().brcnn_bn_eval_act_forward(_ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), float(eps),
+                                                 _ptr(r), _ptr(out), rows, c, int(relu), dt, _stream())
+        _L.check(st, 'brcnn_bn_eval_act_forward')
+        ctx.save_for_backward(z, g32, m32, v32, out if relu else None)
+        ctx.cfg = (relu, res is not None, dt, rows, c, float(eps), gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        z, g32, m32, v32, out = ctx.saved_tensors
+        relu, has_res, dt, rows, c, eps, gdt, bdt = ctx.cfg
+        dout = dout.to(z.dtype).contiguous()
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[6] else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+        lib = _L.load()
+        nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
+        ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
+        st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(m32), _ptr(v32), eps,
+                                            _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
+                                            int(relu), dt, _stream())
+        _L.check(st, 'brcnn_bn_eval_act_backward')
+        return dz, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres, None
+
+
+def bn_eval_act_autograd(z, bn, res=None, relu=True):
+    """z through the eval-mode BatchNorm module `bn` (+ residual, + ReLU), one kernel each way"""
+    return BnEvalActFunction.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, res, relu)
+
+
 def bn_act_supported(z):
     """channel-vector count a power of two (every BatchNorm width of the ResNet family)"""
     c = z.shape[-1]

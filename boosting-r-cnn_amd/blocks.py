@@ -100,11 +100,11 @@ def build_norm_layer(cfg, num_features, postfix=''):
 def conv_bn_act_tail(y, bn, relu, residual):
     """eval-BN affine (+residual, +ReLU) behind a differentiable conv (fused kernel when it applies)"""
     if bn is not None:
+        from .autograd import bn_act_supported, bn_eval_act_autograd
+        if y.is_cuda and bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
+            return bn_eval_act_autograd(y, bn, residual, relu)
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
-        from .autograd import bn_act_autograd, bn_act_supported
-        if bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
-            return bn_act_autograd(y, scale, shift, residual, relu)
         y = y * scale.to(y.dtype) + shift.to(y.dtype)
     if residual is not None:
         y = y + residual
@@ -133,11 +133,11 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False):
         if with_skip:
             return conv_bn_act_tail(y, bn, relu, residual), skip
         if bn is not None:
+            from .autograd import bn_act_supported, bn_eval_act_autograd
+            if y.is_cuda and bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
+                return bn_eval_act_autograd(y, bn, residual, relu)     # one kernel each way, BN fold included
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale
-            from .autograd import bn_act_autograd, bn_act_supported
-            if bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
-                return bn_act_autograd(y, scale, shift, residual, relu)     # one kernel each way
             # bf16 activations stay bf16 (the affine parameters are rounded once per step)
             y = y * scale.to(y.dtype) + shift.to(y.dtype)
         if residual is not None:
@@ -174,10 +174,11 @@ def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):
         assert conv.bias is None
         y = grouped_conv_autograd(x, conv.weight, conv.groups, conv.stride[0], conv.padding[0])
         if bn is not None:
+            if y.is_cuda and bn_act_supported(y) and (residual is None or residual.dtype == y.dtype):
+                from .autograd import bn_eval_act_autograd
+                return bn_eval_act_autograd(y, bn, residual, relu)
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale
-            if bn_act_supported(y):
-                return bn_act_autograd(y, scale, shift, residual, relu)
             y = y * scale + shift
         if residual is not None:
             y = y + residual

@@ -48,24 +48,48 @@ __device__ __forceinline__ void stv(bf16_t* p, const float v[8]) {
     *reinterpret_cast<uint4*>(p) = u;
 }
 
+// eval-mode BatchNorm statistics (resnet.py:648-657): scale = gamma / sqrt(var + eps),
+// shift = beta - mean * scale, the operation order of the torch expression they replace
+struct BnStats {
+    const float* mean;      // NULL: `scale` / `shift` are the affine itself
+    const float* var;
+    float eps;
+};
+
+__device__ __forceinline__ void bn_affine(const float* gamma, const float* beta, const BnStats& bn, int c, float& sc,
+                                          float& sh) {
+    if (bn.mean) {
+        sc = gamma[c] / sqrtf(bn.var[c] + bn.eps);
+        sh = beta ? beta[c] - bn.mean[c] * sc : 0.f;
+    } else {
+        sc = gamma[c];
+        sh = beta ? beta[c] : 0.f;
+    }
+}
+
+// the launch makes gridDim.x * 256 a multiple of C / V, so a thread meets the same channels in every
+// iteration and holds their scale / shift in registers
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ z,
                                                         const float* __restrict__ scale,
-                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ shift, const BnStats bn,
                                                         const T* __restrict__ res, T* __restrict__ out,
                                                         long long rows, int C, int relu) {
     constexpr int V = Vec<T>::N;
     const int cvn = C / V;
     const long long total = rows * cvn;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(idx % cvn) * V;
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(first % cvn) * V;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) bn_affine(scale, shift, bn, c0 + e, sc[e], sh[e]);
+    for (long long idx = first; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         float v[V], r[V];
         ldv(z + idx * V, v);
         if (res) ldv(res + idx * V, r);
 #pragma unroll
         for (int e = 0; e < V; e++) {
-            float o = v[e] * scale[c0 + e] + shift[c0 + e];
+            float o = v[e] * sc[e] + sh[e];
             if (res) o += r[e];
             if (relu) o = fmaxf(o, 0.f);
             v[e] = o;
@@ -80,7 +104,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ dout,
                                                         const T* __restrict__ out,
                                                         const T* __restrict__ z,
-                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ scale, const BnStats bn,
                                                         T* __restrict__ dz, T* __restrict__ dres,
                                                         float* __restrict__ partial, long long rows,
                                                         int C, int relu, int rows_per_block, int CW) {
@@ -93,7 +117,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ d
     const long long r1 = min(rows, r0 + rows_per_block);
     float ss[V], sh[V], sc[V];
 #pragma unroll
-    for (int e = 0; e < V; e++) { ss[e] = 0.f; sh[e] = 0.f; sc[e] = (cv < cvn) ? scale[cv * V + e] : 0.f; }
+    for (int e = 0; e < V; e++) {
+        ss[e] = 0.f; sh[e] = 0.f; sc[e] = 0.f;
+        float unused;
+        if (cv < cvn) bn_affine(scale, nullptr, bn, cv * V + e, sc[e], unused);
+    }
     if (cv < cvn) {
         for (long long r = r0 + rl; r < r1; r += RL) {
             const long long idx = (r * cvn + cv) * V;
@@ -147,6 +175,31 @@ __global__ __launch_bounds__(1024) void bn_act_reduce_kernel(const float* __rest
     }
 }
 
+// second stage when the affine is an eval-mode BatchNorm: the gradients of gamma / beta themselves,
+//   dbeta = sum dshift,   dgamma = (sum dscale - mean * sum dshift) / sqrt(var + eps)
+__global__ __launch_bounds__(1024) void bn_eval_reduce_kernel(const float* __restrict__ partial, const BnStats bn,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int strips, int C) {
+    __shared__ float red[2][16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f;
+    if (col < C)
+        for (int s = sl; s < strips; s += 16) {
+            a += partial[((size_t)s * 2 + 0) * C + col];
+            b += partial[((size_t)s * 2 + 1) * C + col];
+        }
+    red[0][sl][threadIdx.x & 63] = a;
+    red[1][sl][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (sl == 0 && col < C) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { ta += red[0][k][threadIdx.x]; tb += red[1][k][threadIdx.x]; }
+        dgamma[col] = (ta - bn.mean[col] * tb) / sqrtf(bn.var[col] + bn.eps);
+        dbeta[col] = tb;
+    }
+}
+
 struct BwdPlan { int CW, chunks; long long strips, rpb; };
 inline bool bwd_plan(long long rows, int channels, int V, BwdPlan* pl) {
     const int cvn = channels / V;
@@ -169,28 +222,55 @@ inline int stream_grid(long long total) {
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
-}  // namespace
+// forward grid: gridDim.x * 256 must be a multiple of the channel-vector count (a power of two or a
+// multiple handled by rounding the grid up)
+inline int fwd_grid(long long total, int cvn) {
+    long long g = stream_grid(total);
+    if (g > 4096) g = 4096;
+    long long step = 1;
+    while ((step * 256) % cvn) step++;
+    g = (g + step - 1) / step * step;
+    return (int)g;
+}
 
-BRCNN_API int brcnn_bn_act_forward(const void* z, const float* scale, const float* shift,
-                                   const void* residual, void* out, int64_t rows, int channels,
-                                   int relu, int dtype, void* stream) {
+int forward_impl(const void* z, const float* scale, const float* shift, const BnStats bn, const void* residual,
+                 void* out, int64_t rows, int channels, int relu, int dtype, void* stream) {
     if (!z || !scale || !shift || !out || rows < 0 || channels <= 0 ||
         (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
     const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
     if (channels % V) return BRCNN_EINVAL;
     if (rows == 0) return 0;
-    const long long total = rows * (channels / V);
+    const int cvn = channels / V;
+    const long long total = rows * cvn;
+    const int grid = fwd_grid(total, cvn);
     if (dtype == BRCNN_DT_F32)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)z, scale, shift, (const float*)residual, (float*)out, (long long)rows,
+        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)z, scale, shift, bn, (const float*)residual, (float*)out, (long long)rows,
                            channels, relu);
     else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)z, scale, shift, (const bf16_t*)residual, (bf16_t*)out, (long long)rows,
+        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)z, scale, shift, bn, (const bf16_t*)residual, (bf16_t*)out, (long long)rows,
                            channels, relu);
     BRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+}  // namespace
+
+BRCNN_API int brcnn_bn_act_forward(const void* z, const float* scale, const float* shift,
+                                   const void* residual, void* out, int64_t rows, int channels,
+                                   int relu, int dtype, void* stream) {
+    BnStats bn = {nullptr, nullptr, 0.f};
+    return forward_impl(z, scale, shift, bn, residual, out, rows, channels, relu, dtype, stream);
+}
+
+BRCNN_API int brcnn_bn_eval_act_forward(const void* z, const float* gamma, const float* beta, const float* mean,
+                                        const float* var, float eps, const void* residual, void* out, int64_t rows,
+                                        int channels, int relu, int dtype, void* stream) {
+    if (!mean || !var) return BRCNN_EINVAL;
+    BnStats bn = {mean, var, eps};
+    return forward_impl(z, gamma, beta, bn, residual, out, rows, channels, relu, dtype, stream);
 }
 
 BRCNN_API size_t brcnn_bn_act_backward_workspace_bytes(int64_t rows, int channels, int dtype) {
@@ -200,10 +280,9 @@ BRCNN_API size_t brcnn_bn_act_backward_workspace_bytes(int64_t rows, int channel
     return (size_t)(pl.strips > 0 ? pl.strips : 1) * 2 * channels * sizeof(float);
 }
 
-BRCNN_API int brcnn_bn_act_backward(const void* dout, const void* out, const void* z, const float* scale,
-                                    void* dz, void* dres, float* dscale, float* dshift, void* workspace,
-                                    size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
-                                    void* stream) {
+static int backward_impl(const void* dout, const void* out, const void* z, const float* scale, const BnStats bn,
+                         void* dz, void* dres, float* dscale, float* dshift, void* workspace,
+                         size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype, void* stream) {
     if (!dout || !z || !scale || !dz || !dscale || !dshift || !workspace || rows < 0 || channels <= 0 ||
         (relu && !out) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
         return BRCNN_EINVAL;
@@ -220,15 +299,38 @@ BRCNN_API int brcnn_bn_act_backward(const void* dout, const void* out, const voi
     }
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
-                           (const float*)dout, (const float*)out, (const float*)z, scale, (float*)dz, (float*)dres,
+                           (const float*)dout, (const float*)out, (const float*)z, scale, bn, (float*)dz, (float*)dres,
                            (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     else
         hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
-                           (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)z, scale, (bf16_t*)dz,
+                           (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)z, scale, bn, (bf16_t*)dz,
                            (bf16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     BRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_act_reduce_kernel, dim3((channels + 63) / 64, 2), dim3(1024), 0, s,
-                       (const float*)workspace, dscale, dshift, (int)pl.strips, channels);
+    if (bn.mean)
+        hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s,
+                           (const float*)workspace, bn, dscale, dshift, (int)pl.strips, channels);
+    else
+        hipLaunchKernelGGL(bn_act_reduce_kernel, dim3((channels + 63) / 64, 2), dim3(1024), 0, s,
+                           (const float*)workspace, dscale, dshift, (int)pl.strips, channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+BRCNN_API int brcnn_bn_act_backward(const void* dout, const void* out, const void* z, const float* scale,
+                                    void* dz, void* dres, float* dscale, float* dshift, void* workspace,
+                                    size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
+                                    void* stream) {
+    BnStats bn = {nullptr, nullptr, 0.f};
+    return backward_impl(dout, out, z, scale, bn, dz, dres, dscale, dshift, workspace, workspace_bytes, rows, channels,
+                         relu, dtype, stream);
+}
+
+BRCNN_API int brcnn_bn_eval_act_backward(const void* dout, const void* out, const void* z, const float* gamma,
+                                         const float* mean, const float* var, float eps, void* dz, void* dres,
+                                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                         int64_t rows, int channels, int relu, int dtype, void* stream) {
+    if (!mean || !var) return BRCNN_EINVAL;
+    BnStats bn = {mean, var, eps};
+    return backward_impl(dout, out, z, gamma, bn, dz, dres, dgamma, dbeta, workspace, workspace_bytes, rows, channels,
+                         relu, dtype, stream);
 }

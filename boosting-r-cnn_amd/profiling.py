@@ -83,7 +83,9 @@ def conv_stack_roofline(model, img, metas, iters=3, dtype='f32'):
         'bound': 'mfma', 'kernel': f'conv_igemm_{dtype}*_kernel (all conv/FC launches of one pass)',
         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
         'frac': achieved / peak, 'traffic': traffic,
-        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/*_conv_traffic.json)',
+        'traffic_unit': 'HBM bytes per launch',
+        'traffic_source': 'STORED value: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, '
+                          'committed as profiles/*_conv_traffic.json (not re-measured in this run)',
         'algorithmic_bytes_per_launch': sum(r[3] for r in recs) / max(len(recs), 1),
         'launches': len(recs), 'avg_launch_us': 1000.0 * ms / max(len(recs), 1),
         'algorithmic_gflop_per_pass': flops / 1e9, 'kernel_ms_per_pass': ms,

@@ -331,6 +331,19 @@ int brcnn_bn_act_backward(const void *dout, const void *out, const void *z, cons
                           size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
                           void *stream);
 
+/* The same pair with the eval-mode BatchNorm parameters themselves (norm_eval=True,
+ * backbones/resnet.py:648-657): scale = gamma / sqrt(var + eps), shift = beta - mean * scale are formed
+ * inside the kernels (the reference spends ~5 element-wise torch launches per layer and direction on
+ * them), and the backward returns dgamma = (sum dpre*z - mean * sum dpre) / sqrt(var + eps),
+ * dbeta = sum dpre directly. */
+int brcnn_bn_eval_act_forward(const void *z, const float *gamma, const float *beta, const float *mean,
+                              const float *var, float eps, const void *residual, void *out, int64_t rows,
+                              int channels, int relu, int dtype, void *stream);
+int brcnn_bn_eval_act_backward(const void *dout, const void *out, const void *z, const float *gamma,
+                               const float *mean, const float *var, float eps, void *dz, void *dres,
+                               float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                               int64_t rows, int channels, int relu, int dtype, void *stream);
+
 /* Res2Net / DCNv2 rows (the r2_101 recipes): NHWC average pooling with torch.nn.AvgPool2d's
  * window / divisor rules (res2net.py:52-54, 173-178), and mmcv's modulated deformable im2col
  * (ModulatedDeformConv2dPack, deform_groups 1): col (N*Ho*Wo, KH*KW*channels_padded) with K

@@ -271,12 +271,12 @@ def timed_baseline(cfg, seed=0, batch=1, budget_s=20.0, threads=None):
     bounded sample (a few 1333x800 images) of the same workload."""
     import os
     from brcnn import build_detector
-    from tests import util
+    from brcnn.synth import seeded_state_dict
     threads = threads or available_cpus()
     torch.set_num_threads(threads)
     with patched():
         m = build_detector(cfg.model)
-        m.load_state_dict(util.seeded_state_dict(m, seed=seed))
+        m.load_state_dict(seeded_state_dict(m, seed=seed))
         m.eval()
         g = torch.Generator().manual_seed(seed)
         img = torch.randn(batch, 3, 800, 1344, generator=g)

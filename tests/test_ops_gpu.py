@@ -594,6 +594,47 @@ def test_bn_act_fused_forward_backward(dtype):
         assert (shift.grad.double() - h2.grad).abs().max().item() <= 2e-5 * mag(h2.grad) * (rows ** 0.5)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bn_eval_act_fused_forward_backward(dtype):
+    """the same tail with the eval-mode BatchNorm parameters themselves (scale / shift formed inside the
+    kernels, dgamma / dbeta returned directly) against the torch expression it replaces, in fp64"""
+    from brcnn.autograd import bn_eval_act_autograd
+    g = torch.Generator().manual_seed(32)
+    for (rows, c, has_res, relu) in [(1000, 64, False, True), (777, 256, True, True), (130, 2048, True, True),
+                                     (513, 128, False, False), (20000, 512, True, True)]:
+        bn = torch.nn.BatchNorm2d(c).to(DEV).eval()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g))
+            bn.running_mean.copy_(torch.randn(c, generator=g))
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.3)
+        z = torch.randn(rows, c, generator=g).to(DEV, dtype)
+        res = torch.randn(rows, c, generator=g).to(DEV, dtype) if has_res else None
+        go = torch.randn(rows, c, generator=g).to(DEV, dtype)
+        z1 = z.clone().requires_grad_()
+        r1 = res.clone().requires_grad_() if has_res else None
+        out = bn_eval_act_autograd(z1, bn, r1, relu)
+        out.backward(go)
+        w2, b2 = bn.weight.detach().double().requires_grad_(), bn.bias.detach().double().requires_grad_()
+        z2 = z.double().requires_grad_()
+        r2 = res.double().requires_grad_() if has_res else None
+        scale = w2 / torch.sqrt(bn.running_var.double() + bn.eps)
+        ref = z2 * scale + (b2 - bn.running_mean.double() * scale)
+        if has_res:
+            ref = ref + r2
+        if relu:
+            ref = ref.relu()
+        ref.backward(go.double())
+        tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
+        mag = lambda t: max(1.0, t.abs().max().item())   # noqa: E731
+        assert (out.double() - ref).abs().max().item() <= tol * mag(ref) * 1.01
+        assert (z1.grad.double() - z2.grad).abs().max().item() <= tol * mag(z2.grad) * 1.01
+        if has_res:
+            assert (r1.grad.double() - r2.grad).abs().max().item() <= tol * mag(r2.grad) * 1.01
+        assert (bn.weight.grad.double() - w2.grad).abs().max().item() <= 2e-5 * mag(w2.grad) * (rows ** 0.5)
+        assert (bn.bias.grad.double() - b2.grad).abs().max().item() <= 2e-5 * mag(b2.grad) * (rows ** 0.5)
+
+
 def test_grouped_conv_autograd_matches_torch():
     """forward / dgrad / wgrad of the grouped conv (ResNeXt conv2) against torch's grouped conv in fp64"""
     import torch.nn.functional as F
