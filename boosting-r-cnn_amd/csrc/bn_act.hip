@@ -79,10 +79,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ z
     const int cvn = C / V;
     const long long total = rows * cvn;
     const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c0 = (int)(first % cvn) * V;
+    // the workgroup's distinct channels (all C when C / V <= 256, else a window of 256 vectors) are
+    // derived once, cooperatively, and handed out through LDS
+    __shared__ float s_sc[256 * V], s_sh[256 * V];
+    const int nvec = cvn < 256 ? cvn : 256;
+    const int base = (int)(((long long)blockIdx.x * blockDim.x) % cvn);
+    for (int i = threadIdx.x; i < nvec * V; i += 256) bn_affine(scale, shift, bn, base * V + i, s_sc[i], s_sh[i]);
+    __syncthreads();
+    const int v0 = (int)(threadIdx.x % nvec) * V;
     float sc[V], sh[V];
 #pragma unroll
-    for (int e = 0; e < V; e++) bn_affine(scale, shift, bn, c0 + e, sc[e], sh[e]);
+    for (int e = 0; e < V; e++) { sc[e] = s_sc[v0 + e]; sh[e] = s_sh[v0 + e]; }
     for (long long idx = first; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         float v[V], r[V];
         ldv(z + idx * V, v);
@@ -116,11 +123,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ d
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
     float ss[V], sh[V], sc[V];
+    {   // the CW channel vectors of this workgroup, derived once and shared by its row lanes
+        float* s_sc = &red[0][0][0];
+        for (int i = threadIdx.x; i < CW * V; i += 256) {
+            const int c = blockIdx.y * CW * V + i;
+            float unused, v = 0.f;
+            if (c < C) bn_affine(scale, nullptr, bn, c, v, unused);
+            s_sc[i] = v;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int e = 0; e < V; e++) {
-        ss[e] = 0.f; sh[e] = 0.f; sc[e] = 0.f;
-        float unused;
-        if (cv < cvn) bn_affine(scale, nullptr, bn, cv * V + e, sc[e], unused);
+        for (int e = 0; e < V; e++) { ss[e] = 0.f; sh[e] = 0.f; sc[e] = s_sc[(threadIdx.x % CW) * V + e]; }
+        __syncthreads();
     }
     if (cv < cvn) {
         for (long long r = r0 + rl; r < r1; r += RL) {
@@ -224,9 +238,12 @@ inline int stream_grid(long long total) {
 
 // forward grid: gridDim.x * 256 must be a multiple of the channel-vector count (a power of two or a
 // multiple handled by rounding the grid up)
-inline int fwd_grid(long long total, int cvn) {
+inline int fwd_grid(long long total, int cvn, bool bn_mode) {
     long long g = stream_grid(total);
-    if (g > 4096) g = 4096;
+    // BN form: every thread derives its scale / shift first (correctly rounded sqrt + divide per channel),
+    // so fewer, longer-running threads (4 workgroups per CU) amortise that prologue
+    const long long cap = bn_mode ? 2048 : 4096;
+    if (g > cap) g = cap;
     long long step = 1;
     while ((step * 256) % cvn) step++;
     g = (g + step - 1) / step * step;
@@ -243,7 +260,7 @@ int forward_impl(const void* z, const float* scale, const float* shift, const Bn
     if (rows == 0) return 0;
     const int cvn = channels / V;
     const long long total = rows * cvn;
-    const int grid = fwd_grid(total, cvn);
+    const int grid = fwd_grid(total, cvn, bn.mean != nullptr);
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const float*)z, scale, shift, bn, (const float*)residual, (float*)out, (long long)rows,

@@ -199,7 +199,7 @@ class ATSSRPNHead(AnchorHead):
 
         def builder():
             from .blocks import pack_weight
-            w = pack_weight(conv.weight)
+            w = pack_weight(conv.weight).to(x.dtype)       # bf16 mode: bf16 operands, fp32 result
             b = conv.bias.detach().float()
             if scale is None:
                 return w, None, b.contiguous()
@@ -211,7 +211,8 @@ class ATSSRPNHead(AnchorHead):
             y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, 1, conv.padding[0]).float()
             return y * scale if scale is not None else y
         w, s, b = cache.get(srcs, builder)
-        return ops.conv2d_nhwc(x, w, s, b, None, False, 1, conv.padding[0])
+        # fp32 result in either mode: the proposal stage scores / decodes in fp32
+        return ops.conv2d_nhwc(x, w, s, b, None, False, 1, conv.padding[0], out_f32=True)
 
     def forward_nhwc(self, feats):
         """feats: list of (N,h,w,C) -> 3 lists of (N,h,w,A | 4A | A) NHWC head outputs"""

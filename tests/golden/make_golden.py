@@ -693,7 +693,128 @@ def g18_boost_variants(cfg):
     npz('g18_boost_variants', **d)
 
 
+def g19_coco_pafpn_train():
+    """BASELINE configs[2]: boosting_rcnn_r50_pafpn_mstrain_2x_coco.py (the COCO-PAFPN recipe: 80 classes,
+    RPN gamma 2, IoU / MSE loss weights 2) -- train losses, the total loss' gradient norm and a few
+    parameter gradients of the reference (fp32, CPU) on the demo batch with seeded weights / sampler"""
+    from mmdet.models import build_detector
+    cfg = Config.fromfile('/root/reference/configs/boosting_rcnn/boosting_rcnn_r50_pafpn_mstrain_2x_coco.py')
+    m = build_detector(cfgdict(copy.deepcopy(cfg.model.to_dict())))
+    m.load_state_dict(util.seeded_state_dict(m, seed=19))
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, num_classes=80, seed=19)
+    m.train()
+    torch.manual_seed(79)
+    losses = m.forward_train(img, metas, gts, gls)
+    d = {}
+    for k, v in losses.items():
+        d['loss_' + k] = torch.stack(v) if isinstance(v, list) else v
+    loss, _ = m._parse_losses(losses)
+    loss.backward()
+    sq = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            sq += float(p.grad.double().pow(2).sum())
+    d['grad_norm'] = np.float64(sq ** 0.5)
+    for k in ('roi_head.bbox_head.fc_cls.weight', 'roi_head.bbox_head.fc_reg.bias', 'rpn_head.rpn_cls.weight',
+              'rpn_head.rpn_reg.bias', 'rpn_head.scales.0.scale', 'rpn_head.scales.2.scale',
+              'neck.lateral_convs.2.conv.bias', 'backbone.layer4.2.bn3.weight', 'backbone.layer2.0.bn1.bias'):
+        d['grad_' + k] = dict(m.named_parameters())[k].grad
+    d['grad_backbone.layer4.2.conv3.weight_slice'] = dict(m.named_parameters())['backbone.layer4.2.conv3.weight'].grad[:16, :16]
+    d['grad_rpn_head.rpn_convs.3.conv.weight_slice'] = dict(m.named_parameters())['rpn_head.rpn_convs.3.conv.weight'].grad[:8, :8]
+    npz('g19_coco_pafpn_train', **d)
+
+
+def g20_fullsize(cfg):
+    """BASELINE configs[1] at FULL size (batch 8, 201 600 anchors / image): the reference's proposal stage
+    (top-k anchor indices per level, batched-NMS keep indices, proposals) from seeded head outputs, and its
+    second-stage multiclass NMS (keep indices into the (roi, class) candidates, detections) from seeded
+    box-head outputs on those proposals"""
+    import mmdet.models.dense_heads.atss_rpn_head as M
+    from mmdet.core.post_processing import bbox_nms as BN
+    head = _fake_rpn_head(cfg)
+    B = 8
+    sizes, cls, reg, iou = util.fullsize_head_outputs(20, B)
+    metas = [dict(img_shape=(800, 1333, 3), scale_factor=np.ones(4, np.float32), pad_shape=(800, 1344, 3))
+             for _ in range(B)]
+    captured, kept = [], []
+    orig = M.batched_nms
+
+    def spy(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+        captured.append((boxes.clone(), scores.clone(), idxs.clone()))
+        dets, keep = orig(boxes, scores, idxs, nms_cfg, class_agnostic)
+        kept.append(keep.clone())
+        return dets, keep
+    M.batched_nms = spy
+    try:
+        props = head.get_bboxes(cls, reg, iou, metas, cfg=cfgdict(cfg.model.test_cfg.rpn.to_dict()))
+    finally:
+        M.batched_nms = orig
+    d = {}
+    for b in range(B):
+        d[f'props{b}'] = props[b]
+        d[f'keep{b}'] = kept[b].to(torch.int32)
+        # the anchors the reference picked, per level, in its own order (scores.sort(descending=True)[:nms_pre]);
+        # checked against the scores it handed to batched_nms
+        inds, o = [], 0
+        for l in range(5):
+            s_ = (cls[l][b].permute(1, 2, 0).reshape(-1).sigmoid() * iou[l][b].permute(1, 2, 0).reshape(-1).sigmoid()).sqrt()
+            k = min(1000, s_.numel())
+            rk = s_.sort(descending=True)[1][:k] if s_.numel() > 1000 else torch.arange(s_.numel())
+            inds.append(rk)
+            o += k
+        inds_cat = torch.cat(inds)
+        # candidates with w<=0 or h<=0 after the border clip were dropped before NMS (atss_rpn_head.py:747-754):
+        # the scores handed to batched_nms are the order-preserving subsequence of the picked anchors' scores
+        sc_all = torch.cat([(cls[l][b].permute(1, 2, 0).reshape(-1).sigmoid() *
+                             iou[l][b].permute(1, 2, 0).reshape(-1).sigmoid()).sqrt()[inds[l]] for l in range(5)])
+        cap = captured[b][1]
+        mask, j = torch.zeros(sc_all.numel(), dtype=torch.bool), 0
+        for i in range(sc_all.numel()):
+            if j < cap.numel() and sc_all[i] == cap[j]:
+                mask[i] = True
+                j += 1
+        assert j == cap.numel(), (j, cap.numel())
+        d[f'topk{b}'] = inds_cat.to(torch.int32)
+        d[f'valid{b}'] = mask
+    # second stage on the reference's proposals: seeded box-head outputs -> score fusion, decode, multiclass NMS
+    from mmdet.models.roi_heads.prob_roi_head import ProbRoIHead  # noqa: F401
+    from mmdet.models import build_head
+    rc = copy.deepcopy(cfg.model.roi_head.to_dict())
+    rc.update(train_cfg=None, test_cfg=cfgdict(cfg.model.test_cfg.rcnn.to_dict()))
+    rh = build_head(cfgdict(rc))
+    g = torch.Generator().manual_seed(21)
+    keep2 = []
+    orig2 = BN.batched_nms
+
+    def spy2(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+        dets, keep = orig2(boxes, scores, idxs, nms_cfg, class_agnostic)
+        keep2.append((keep.clone(), boxes.shape[0]))
+        return dets, keep
+    BN.batched_nms = spy2
+    try:
+        for b in range(B):
+            n = props[b].shape[0]
+            cs, bp = util.fullsize_box_head_outputs(g, n)
+            prior = props[b][:, -1]
+            fused = (cs.softmax(1) * prior[:, None]) ** 0.5
+            rois = torch.cat([torch.zeros(n, 1), props[b][:, :4]], 1)
+            det, lab = rh.bbox_head.get_bboxes(rois, fused, bp, (800, 1333, 3), np.ones(4, np.float32), rescale=True,
+                                               cfg=rh.test_cfg)
+            d[f'det{b}'], d[f'lab{b}'] = det, lab.to(torch.int32)
+            d[f'keep2_{b}'] = keep2[-1][0][:100].to(torch.int32)
+            d[f'ncand2_{b}'] = np.int32(keep2[-1][1])
+    finally:
+        BN.batched_nms = orig2
+    npz('g20_fullsize', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'coco':
+        g19_coco_pafpn_train()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+        g20_fullsize(Config.fromfile(REF_CFG))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'variants':
         g18_boost_variants(Config.fromfile(REF_CFG))
         return

@@ -1,0 +1,265 @@
+"""-m gpu: parity at BASELINE.json's full sizes and in the configurations its configs[2] / configs[4] name.
+
+* configs[1] at full size (batch 8 x 201 600 anchors): the proposal stage's top-k anchor indices, validity
+  mask and batched-NMS keep indices, and the second stage's multiclass-NMS keep indices, bit for bit
+  against the reference's own run (fixture g20: expected outputs only; the 39 MB of seeded head outputs
+  are regenerated from the same CPU generator on both sides);
+* configs[2]: boosting_rcnn_r50_pafpn_1x_coco.py (the COCO-PAFPN recipe), FULL train step, fp32 against
+  the reference's losses / gradients (fixture g19) and bf16 against the same within bf16 tolerances;
+* bf16 mode off the whole-batch device path: external proposals, class-agnostic NMS, R101 + soft-NMS.
+"""
+import numpy as np
+import pytest
+import torch
+
+import brcnn  # noqa: F401
+from brcnn import Config, blocks, build_detector, ops
+from brcnn.config import ConfigDict
+from brcnn.postprocess import batched_nms_images
+from tests import util
+from tests.test_host_cpu import CFG, T, load
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+COCO_CFG = CFG.replace('boosting_rcnn_r50_pafpn_1x_utdac.py', 'boosting_rcnn_r50_pafpn_1x_coco.py')
+
+
+def _canon_ties(keys, scores, groups=None):
+    """`keys` reordered ascending inside every run of exactly equal (group, score)"""
+    keys = keys.clone()
+    i, n = 0, keys.numel()
+    while i < n:
+        j = i + 1
+        while j < n and scores[j] == scores[i] and (groups is None or groups[j] == groups[i]):
+            j += 1
+        if j - i > 1:
+            keys[i:j] = keys[i:j].sort()[0]
+        i = j
+    return keys
+
+
+def _canon_rows(d):
+    """(k,5) detections with the rows of every run of exactly equal scores ordered by (x1, y1)"""
+    d = d.clone()
+    i, n = 0, d.shape[0]
+    while i < n:
+        j = i + 1
+        while j < n and d[j, 4] == d[i, 4]:
+            j += 1
+        if j - i > 1:
+            o = sorted(range(i, j), key=lambda r: (float(d[r, 0]), float(d[r, 1])))
+            d[i:j] = d[o].clone()
+        i = j
+    return d
+
+
+def _nhwc(ts):
+    return [t.permute(0, 2, 3, 1).contiguous().to(DEV) for t in ts]
+
+
+def test_fullsize_proposal_indices_and_keep_masks_golden():
+    g = load('g20_fullsize')
+    cfg = Config.fromfile(CFG)
+    c = cfg.model.rpn_head.copy()
+    c.update(train_cfg=cfg.model.train_cfg.rpn, test_cfg=cfg.model.test_cfg.rpn)
+    head = brcnn.build_head(c).to(DEV)
+    B = 8
+    sizes, cls, reg, iou = util.fullsize_head_outputs(20, B)
+    cls, reg, iou = _nhwc(cls), _nhwc(reg), _nhwc(iou)
+    metas = [dict(img_shape=(800, 1333, 3), scale_factor=np.ones(4, np.float32), pad_shape=(800, 1344, 3))
+             for _ in range(B)]
+    # stage by stage through the same operators get_bboxes_padded drives
+    raw = [ops.rpn_score(cls[l], iou[l]).view(B, -1) for l in range(5)]
+    picked = ops.rpn_topk(raw, 1000)
+    idx = torch.cat([p[1] for p in picked], 1).cpu()
+    sc_cpu = torch.cat([p[0] for p in picked], 1).cpu()
+    lvl_of = torch.cat([torch.full((p[1].shape[1],), l) for l, p in enumerate(picked)])
+    ties = 0
+    for b in range(B):
+        # identical anchors in identical order; the reference's sort is unstable, so runs of EXACTLY equal
+        # scores (a handful among 37 544 picks) are compared as sets (both sides ordered by anchor index)
+        ref = T(g[f'topk{b}']).long()
+        assert torch.equal(_canon_ties(idx[b], sc_cpu[b], lvl_of), _canon_ties(ref, sc_cpu[b], lvl_of)), \
+            f'top-k anchor indices, image {b}'
+        ties += int((idx[b] != ref).sum())
+    assert ties <= 16, ties
+    props, valid, ids = ops.rpn_decode_levels(
+        [p[1] for p in picked], reg, [head._base_anchors(l, torch.device(DEV)) for l in range(5)], sizes,
+        list(head.anchor_generator.strides), head.bbox_coder.means, head.bbox_coder.stds, (800, 1333), 0)
+    for b in range(B):
+        assert torch.equal(valid[b].cpu(), T(g[f'valid{b}'])), f'w>0 & h>0 mask, image {b}'
+    scores = torch.cat([p[0] for p in picked], 1)
+    Tn = scores.shape[1]
+    c_boxes, c_scores, c_ids, nms_boxes, ranges = ops.nms_prepare(props, scores, ids, valid)
+    keep, num = ops.nms_ranges(nms_boxes.view(-1, 4), c_scores.reshape(-1), ranges, Tn, 0.7, 0, -1)   # every survivor
+    keep, num = keep.view(B, Tn).cpu(), num.cpu()
+    for b in range(B):
+        # keep indices address the compacted candidate list; through each side's own top-k list they name
+        # (level, anchor) pairs, which must agree (tied picks sit at swapped positions on the two sides)
+        ref = T(g[f'keep{b}']).long()
+        assert int(num[b]) == ref.numel()
+        vb = valid[b].cpu()
+        mine = (lvl_of[vb] * 1000000 + idx[b][vb])[keep[b, :ref.numel()] - b * Tn]
+        theirs = (lvl_of[vb] * 1000000 + T(g[f'topk{b}']).long()[vb])[ref]
+        ksc = sc_cpu[b][vb][keep[b, :ref.numel()] - b * Tn]
+        assert torch.equal(_canon_ties(mine, ksc), _canon_ties(theirs, ksc)), f'NMS keep indices, image {b}'
+    dets, n = head.get_bboxes_padded(cls, reg, iou, metas)
+    for b in range(B):
+        ref = T(g[f'props{b}'])
+        got = dets[b, :int(n[b])].cpu()
+        assert got.shape == ref.shape
+        got, ref = _canon_rows(got), _canon_rows(ref)
+        assert torch.allclose(got[:, 4], ref[:, 4], rtol=0, atol=1e-6), b
+        assert torch.allclose(got[:, :4], ref[:, :4], rtol=0, atol=5e-4), (b, (got[:, :4] - ref[:, :4]).abs().max())
+
+    # second stage on the reference's proposals: score fusion + decode + multiclass NMS
+    gen = torch.Generator().manual_seed(21)
+    K, C = 256, 4
+    P = torch.zeros(B, K, 5)
+    cs_l, bp_l = [], []
+    for b in range(B):
+        p = T(g[f'props{b}'])
+        assert p.shape[0] == K
+        P[b] = p
+        cs, bp = util.fullsize_box_head_outputs(gen, K)
+        cs_l.append(cs)
+        bp_l.append(bp)
+    P = P.to(DEV)
+    nump = torch.full((B,), K, dtype=torch.int32, device=DEV)
+    max_shape = torch.tensor([[800., 1333.]] * B, device=DEV)
+    sf = torch.ones(B, 4, device=DEV)
+    bb, sc, lb, va = ops.rcnn_decode(torch.cat(cs_l).to(DEV).softmax(1), torch.cat(bp_l).to(DEV), P, nump, max_shape, sf,
+                                     C, 0.05, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2))
+    c_boxes, c_scores, c_ids, nms_boxes, ranges = ops.nms_prepare(bb, sc, lb, va)
+    keep, num = ops.nms_ranges(nms_boxes.view(-1, 4), c_scores.reshape(-1), ranges, K * C, 0.7, 0, 100)
+    keep, num = keep.view(B, K * C).cpu(), num.cpu()
+    det, lab, nd = batched_nms_images(bb, sc, lb, va, 0.7, 100, 0)
+    for b in range(B):
+        assert int(va[b].sum()) == int(g[f'ncand2_{b}'])
+        ref = T(g[f'keep2_{b}']).long()
+        k = min(int(num[b]), 100)
+        assert k == ref.numel()
+        assert torch.equal(keep[b, :k] - b * K * C, ref), f'multiclass NMS keep indices, image {b}'
+        assert torch.equal(lab[b, :k].cpu(), T(g[f'lab{b}']).long())
+        rd = T(g[f'det{b}'])
+        assert torch.allclose(det[b, :k, :4].cpu(), rd[:, :4], rtol=0, atol=5e-4)
+        assert torch.allclose(det[b, :k, 4].cpu(), rd[:, 4], rtol=0, atol=1e-6)
+
+
+def _coco_model(dtype):
+    cfg = Config.fromfile(COCO_CFG)
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=19))
+    m = m.to(DEV).train()
+    m.set_compute_dtype(dtype)
+    return m
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_coco_pafpn_full_train_step_golden(dtype):
+    """BASELINE configs[2]: the COCO-PAFPN recipe's full train step (device-resident targets, fused RPN /
+    boosting losses, HIP dgrad / wgrad) against the reference's fp32 CPU run: every loss, the norm of the
+    whole gradient and individual parameter gradients.  fp32: 2e-3; bf16 (the dtype configs[2] names):
+    losses within 3 %, gradient direction cos > 0.98 per checked tensor."""
+    g = load('g19_coco_pafpn_train')
+    try:
+        m = _coco_model(dtype)
+        assert m._device_train_ok(torch.zeros(1, device=DEV), None, None)
+        img, metas, gts, gls = util.demo_inputs(2, 128, 192, num_classes=80, seed=19)
+        torch.manual_seed(79)
+        losses = m.forward_train(img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+        loss, log_vars = m._parse_losses(losses)
+        loss.backward()
+    finally:
+        blocks.set_compute_dtype('f32')
+    rtol = 2e-3 if dtype == 'f32' else 3e-2
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_rpn_iou', 'loss_cls', 'loss_bbox', 'acc'):
+        ref = float(np.asarray(g['loss_' + k]).sum())
+        assert np.isclose(log_vars[k], ref, rtol=rtol, atol=1e-4), (k, log_vars[k], ref)
+    params = dict(m.named_parameters())
+    sq = sum(float(p.grad.double().pow(2).sum()) for p in params.values() if p.grad is not None)
+    assert np.isclose(sq ** 0.5, float(g['grad_norm']), rtol=5e-3 if dtype == 'f32' else 5e-2)
+    for k in list(g.keys()):
+        if not k.startswith('grad_') or k == 'grad_norm':
+            continue
+        name = k[5:]
+        ref = T(g[k])
+        if name.endswith('_slice'):
+            name = name[:-6]
+            got = params[name].grad[:ref.shape[0], :ref.shape[1]].cpu()
+        else:
+            got = params[name].grad.cpu()
+        if dtype == 'f32':
+            assert (got - ref).abs().max().item() <= 3e-3 * (ref.abs().max().item() + 1e-9), (name, got, ref)
+        elif ref.numel() > 1:
+            cos = torch.nn.functional.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0).item()
+            assert cos > 0.98, (name, cos)
+
+
+def test_bf16_reference_signature_paths():
+    """bf16 mode off the whole-batch device path: simple_test with external proposals and with
+    class-agnostic NMS go through the per-level RPN head and the per-image second stage"""
+    cfg = Config.fromfile(CFG)
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, seed=10)
+    try:
+        m = build_detector(cfg.model)
+        m.load_state_dict(util.seeded_state_dict(m, seed=10))
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            ref = m.simple_test(img.to(DEV), metas, rescale=True)
+        m.set_compute_dtype('bf16')
+        with torch.no_grad():
+            x = m.extract_feat(img.to(DEV))
+            cls, reg, iou = m.rpn_head(x)                              # per-level reference signature
+            assert cls[0].dtype == torch.float32 and reg[0].dtype == torch.float32
+            props = m.rpn_head.get_bboxes(cls, reg, iou, metas)
+            res = m.simple_test(img.to(DEV), metas, proposals=props, rescale=True)
+            dev = m.simple_test(img.to(DEV), metas, rescale=True)
+            m.test_cfg.rcnn.nms = ConfigDict(dict(m.test_cfg.rcnn.nms, class_agnostic=True))
+            assert not m._device_path_ok()
+            agn = m.simple_test(img.to(DEV), metas, rescale=True)
+    finally:
+        blocks.set_compute_dtype('f32')
+    n_ref = sum(len(r) for b in ref for r in b)
+    n_res = sum(len(r) for b in res for r in b)
+    assert n_ref > 0 and abs(n_res - n_ref) <= 0.3 * n_ref
+    # the per-image path and the whole-batch path agree in bf16 (same kernels underneath)
+    # (fp32 accumulation order differs between the three per-level head convs and the fused 54-channel one,
+    # so a few borderline candidates may fall on the other side of a threshold)
+    hit = tot = 0
+    for b in range(2):
+        for c in range(4):
+            tot += len(dev[b][c])
+            if len(dev[b][c]) and len(res[b][c]):
+                d = np.abs(dev[b][c][:, None, :] - res[b][c][None, :, :]).max(-1)
+                hit += int((d < 2e-2).any(1).sum())
+    assert tot > 0 and hit >= 0.9 * tot, (hit, tot)
+    assert sum(len(r) for b in agn for r in b) <= n_res
+
+
+def test_r101_softnms_bf16():
+    """BASELINE configs[4] in its reduced-precision mode: R101, 2000 proposals / image, soft-NMS over
+    2000 x 80 candidates -- bf16 run against the fp32 run of the same recipe"""
+    path = CFG.replace('boosting_rcnn_r50_pafpn_1x_utdac.py', 'boosting_rcnn_r101_pafpn_softnms_coco.py')
+    cfg = Config.fromfile(path)
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, num_classes=80, seed=4)
+    out = {}
+    try:
+        for dt in ('f32', 'bf16'):
+            m = build_detector(cfg.model)
+            m.load_state_dict(util.seeded_state_dict(m, seed=4))
+            m = m.to(DEV).eval()
+            m.set_compute_dtype(dt)
+            with torch.no_grad():
+                out[dt] = m.simple_test(img.to(DEV), metas, rescale=True)
+    finally:
+        blocks.set_compute_dtype('f32')
+    for b in range(2):
+        a = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], 1) for c, r in enumerate(out['f32'][b])])
+        d = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], 1) for c, r in enumerate(out['bf16'][b])])
+        assert len(a) > 0 and len(d) > 0
+        # strongest fp32 detections reappear in bf16 (same class, within 3 px, score within 0.05)
+        top = a[np.argsort(-a[:, 4])[:20]]
+        hit = sum(1 for t in top if ((np.abs(d[:, :4] - t[:4]).max(1) < 3) & (d[:, 5] == t[5]) &
+                                     (np.abs(d[:, 4] - t[4]) < 0.05)).any())
+        assert hit >= 14, (b, hit)

@@ -99,3 +99,23 @@ def variant_inputs(num_classes, score_cols, seed):
         sc = torch.rand(boxes.shape[0], score_cols, generator=g)
         props.append(torch.cat([boxes, sc], 1))
     return feats, metas, gts, gls, props
+
+
+def fullsize_head_outputs(seed=20, batch=8):
+    """seeded synthetic RPN head outputs at the BASELINE map sizes (3 x 800 x 1344 input).  Not stored in
+    the fixture g20 (39 MB): the golden generator and the parity test both regenerate them from the same
+    CPU generator"""
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    g = torch.Generator().manual_seed(seed)
+    cls = [torch.randn(batch, 9, h, w, generator=g) * 2 - 1 for h, w in sizes]
+    reg = [torch.randn(batch, 36, h, w, generator=g) * 0.5 for h, w in sizes]
+    iou = [torch.randn(batch, 9, h, w, generator=g) * 2 for h, w in sizes]
+    return sizes, cls, reg, iou
+
+
+def fullsize_box_head_outputs(g, n, num_classes=4):
+    """seeded box-head outputs of one image's `n` proposals (generator `g` is advanced)"""
+    cs = torch.randn(n, num_classes + 1, generator=g) * 2
+    cs[:, num_classes] -= 1.0
+    bp = torch.randn(n, 4 * num_classes, generator=g) * 0.3
+    return cs, bp
