@@ -98,7 +98,9 @@ class ConvNHWCFunction(Function):
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
                                                    cin, cout, kh, kw, stride, pad, dt, _stream())
             _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
-            dw = dwp.permute(0, 3, 1, 2)
+            # (Cout,KH,KW,Cin) -> the parameter's (Cout,Cin,KH,KW): for 1x1 filters the two coincide in
+            # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)
+            dw = dwp.view(cout, cin, 1, 1) if kh == 1 and kw == 1 else dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
         if dskip is not None:

@@ -1,0 +1,62 @@
+"""One rank of the DistributedDataParallel check (launched by tests/test_ddp_gpu.py through
+`python -m torch.distributed.run`, backend nccl = RCCL): the device-resident train step -- custom autograd
+Functions over the HIP kernels, the fused RPN loss with its in-forward all-reduce of the two normalisers,
+the host-synchronised sampler -- under DDP's gradient hooks, against the same step without the wrapper."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import brcnn  # noqa: E402,F401
+from brcnn import Config, build_detector  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'boosting_rcnn', 'boosting_rcnn_r50_pafpn_1x_utdac.py'))
+    dtype = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10 + rank)
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in gts], gt_labels=[l.to(dev) for l in gls])
+    grads = {}
+    for mode in ('plain', 'ddp'):
+        m = build_detector(cfg.model)
+        m.load_state_dict(util.seeded_state_dict(m, seed=10))
+        m = m.to(dev).train()
+        m.set_compute_dtype(dtype)
+        net = m
+        if mode == 'ddp':
+            net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[local], broadcast_buffers=False)
+        torch.manual_seed(77)
+        losses = net(return_loss=True, **data)
+        loss, log_vars = m._parse_losses(losses)
+        loss.backward()
+        grads[mode] = ({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, dict(log_vars))
+    assert grads['plain'][0].keys() == grads['ddp'][0].keys()
+    if world == 1:          # one rank: the wrapper must not change a single value
+        for k, g in grads['plain'][0].items():      # (weight gradients accumulate with fp32 atomics: order varies)
+            tol = (1e-4 if dtype == 'f32' else 2e-2) * (g.abs().max().item() + 1e-12)
+            assert (g - grads['ddp'][0][k]).abs().max().item() <= tol, (k, (g - grads['ddp'][0][k]).abs().max().item(), tol)
+        for k, v in grads['plain'][1].items():
+            assert abs(v - grads['ddp'][1][k]) <= (1e-5 if dtype == 'f32' else 1e-3) * max(1.0, abs(v)), k
+    # every rank ends with identical (averaged) gradients
+    for k, g in sorted(grads['ddp'][0].items())[:8]:
+        t = g.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert torch.equal(t, g), k
+    if rank == 0:
+        print('DDP_OK', len(grads['ddp'][0]), grads['ddp'][1]['loss'], flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
