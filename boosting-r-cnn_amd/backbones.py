@@ -125,10 +125,11 @@ class ResNet(nn.Module):
         """extra constructor arguments of the residual block (ResNeXt: groups / base_width)"""
         return {}
 
-    def init_weights(self):
+    def init_weights(self, pretrained=False):
         """Kaiming (fan_out, relu) for convs, constant 1 for norms, zero for the last BN of each
-        block (resnet.py:392-412).  `init_cfg=Pretrained torchvision://resnet50` needs the
-        network: seeded random init stands in (synthetic weights)."""
+        block (resnet.py:392-412).  `pretrained=True` (the detector's `init_weights()`, i.e. the train
+        driver) then loads `init_cfg=dict(type='Pretrained', checkpoint=...)` from the local model
+        directory (`blocks.load_pretrained`); construction alone never touches the file system."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, a=0, mode='fan_out', nonlinearity='relu')
@@ -140,6 +141,9 @@ class ResNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, Bottleneck):
                     nn.init.constant_(m.bn3.weight, 0)
+        if pretrained:
+            from .blocks import load_pretrained
+            load_pretrained(self, self.init_cfg)
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:
@@ -512,7 +516,7 @@ class Res2Net(nn.Module):
         self._freeze_stages()
         self.init_weights()
 
-    def init_weights(self):
+    def init_weights(self, pretrained=False):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, a=0, mode='fan_out', nonlinearity='relu')
@@ -528,6 +532,9 @@ class Res2Net(nn.Module):
             for m in self.modules():
                 if isinstance(m, Bottle2neck):
                     nn.init.constant_(m.bn3.weight, 0)
+        if pretrained:
+            from .blocks import load_pretrained
+            load_pretrained(self, self.init_cfg)
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:

@@ -79,6 +79,64 @@ def fold_bn(bn):
     return scale.contiguous(), shift.contiguous()
 
 
+def resolve_pretrained(checkpoint):
+    """local file of an `init_cfg=dict(type='Pretrained', checkpoint=...)` entry.  The reference hands
+    `torchvision://resnet50` / `open-mmlab://resnext101_64x4d` ... to mmcv's load_checkpoint, which downloads
+    them; here they resolve against a local model directory: `$BRCNN_PRETRAINED_DIR/<name>.pth` (also
+    `<scheme>/<name>.pth`, `.pt`, or the bare name), or `~/.cache/brcnn/pretrained`.  A plain path is used
+    as it is.  Returns None when nothing is found."""
+    import os
+    if '://' not in checkpoint:
+        return checkpoint if os.path.isfile(checkpoint) else None
+    scheme, name = checkpoint.split('://', 1)
+    roots = [os.environ.get('BRCNN_PRETRAINED_DIR'), os.path.expanduser('~/.cache/brcnn/pretrained')]
+    for root in roots:
+        if not root:
+            continue
+        for rel in (name, os.path.join(scheme, name), name.replace('/', '_')):
+            for ext in ('.pth', '.pt', ''):
+                cand = os.path.join(root, rel + ext)
+                if os.path.isfile(cand):
+                    return cand
+    return None
+
+
+def load_pretrained(module, init_cfg, prefixes=('backbone.', 'module.')):
+    """mmcv PretrainedInit for a backbone: load `init_cfg.checkpoint` (strict=False) into `module`.
+    Returns True when weights were loaded, False when `init_cfg` is not a Pretrained entry.  A Pretrained
+    entry whose file cannot be found raises, unless BRCNN_ALLOW_RANDOM_INIT=1 (tests / benches with
+    synthetic weights): training a recipe from random weights with a frozen random stem silently misses the
+    reference's accuracy, so that must be an explicit choice."""
+    import logging
+    import os
+    if not (isinstance(init_cfg, dict) and init_cfg.get('type') == 'Pretrained'):
+        return False
+    ckpt = init_cfg.get('checkpoint')
+    path = resolve_pretrained(ckpt) if ckpt else None
+    log = logging.getLogger('brcnn')
+    if path is None:
+        msg = (f'pretrained weights {ckpt!r} not found: put the file under $BRCNN_PRETRAINED_DIR (e.g. '
+               f'<dir>/{str(ckpt).split("://")[-1]}.pth) or give a path; set BRCNN_ALLOW_RANDOM_INIT=1 (tools/train.py '
+               f'--allow-random-init) to train from random weights instead')
+        if os.environ.get('BRCNN_ALLOW_RANDOM_INIT') == '1':
+            log.warning('RANDOM INIT: ' + msg)
+            return False
+        raise FileNotFoundError(msg)
+    sd = torch.load(path, map_location='cpu', weights_only=False)
+    sd = sd.get('state_dict', sd) if isinstance(sd, dict) else sd
+    out = {}
+    for k, v in sd.items():
+        for pre in prefixes:
+            if k.startswith(pre):
+                k = k[len(pre):]
+        out[k] = v
+    missing, unexpected = module.load_state_dict(out, strict=False)
+    missing = [k for k in missing if not k.endswith('num_batches_tracked')]
+    log.info(f'loaded pretrained {ckpt} from {path}: {len(out) - len(unexpected)} tensors, missing {missing[:6]}'
+             f'{"..." if len(missing) > 6 else ""}, unexpected {list(unexpected)[:6]}{"..." if len(unexpected) > 6 else ""}')
+    return True
+
+
 def build_norm_layer(cfg, num_features, postfix=''):
     """(name, module) like mmcv.cnn.build_norm_layer: BN -> 'bn', GN -> 'gn'."""
     cfg = dict(cfg)

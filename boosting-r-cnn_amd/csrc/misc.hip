@@ -123,6 +123,59 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
     }
 }
 
+// max-pool 3x3/s2/p1 backward: one input pixel x 4 channels per thread gathers the gradient of the (at most 4)
+// windows that contain it and whose FIRST maximum (row-major scan, torch's argmax rule) it is -- no atomics
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                              const T* __restrict__ dy, T* __restrict__ dx, int N, int H,
+                                                              int W, int C, int Ho, int Wo) {
+    const int cvn = C >> 2;
+    const long long total = (long long)N * H * W * cvn;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % cvn);
+        long long r = idx / cvn;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        const float4 me = ld4(x + (((size_t)n * H + h) * W + w) * C + cv * 4);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        const float mv[4] = {me.x, me.y, me.z, me.w};
+        for (int ho = (h >> 1); ho <= ((h + 1) >> 1); ho++) {
+            if (ho < 0 || ho >= Ho) continue;
+            for (int wo = (w >> 1); wo <= ((w + 1) >> 1); wo++) {
+                if (wo < 0 || wo >= Wo) continue;
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cv * 4;
+                const float4 ym = ld4(y + o), gy = ld4(dy + o);
+                const float yv[4] = {ym.x, ym.y, ym.z, ym.w}, gv[4] = {gy.x, gy.y, gy.z, gy.w};
+                bool mine[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) mine[e] = mv[e] == yv[e];
+                if (!(mine[0] || mine[1] || mine[2] || mine[3])) continue;
+                // an earlier position of the window holding the same maximum takes the gradient instead
+                for (int kh = 0; kh < 3; kh++) {
+                    const int hi = ho * 2 - 1 + kh;
+                    if (hi < 0 || hi >= H) continue;
+                    for (int kw = 0; kw < 3; kw++) {
+                        const int wi = wo * 2 - 1 + kw;
+                        if (wi < 0 || wi >= W) continue;
+                        if (hi > h || (hi == h && wi >= w)) continue;
+                        const float4 v = ld4(x + (((size_t)n * H + hi) * W + wi) * C + cv * 4);
+                        if (v.x == yv[0]) mine[0] = false;
+                        if (v.y == yv[1]) mine[1] = false;
+                        if (v.z == yv[2]) mine[2] = false;
+                        if (v.w == yv[3]) mine[3] = false;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (mine[e]) g[e] += gv[e];
+            }
+        }
+        st4(dx + (((size_t)n * H + h) * W + w) * C + cv * 4, make_float4(g[0], g[1], g[2], g[3]));
+    }
+}
+
 // ---- GroupNorm over one or several back-to-back NHWC segments (pyramid levels) -----------
 struct GnSegs {
     int nseg;
@@ -497,6 +550,25 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int hei
     else
         hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
                            (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, batch, height, width,
+                           channels, Ho, Wo);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_maxpool3x3s2_nhwc_backward(const void* x, const void* y, const void* dy, void* dx, int batch,
+                                               int height, int width, int channels, int dtype, void* stream) {
+    if (!x || !y || !dy || !dx || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const int Ho = (height + 2 - 3) / 2 + 1, Wo = (width + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * height * width * (channels >> 2);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (const float*)y, (const float*)dy, (float*)dx, batch, height, width, channels,
+                           Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, batch, height, width,
                            channels, Ho, Wo);
     BRCNN_LAUNCH_CHECK();
     return 0;

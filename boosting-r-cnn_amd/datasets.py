@@ -540,9 +540,45 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
         sampler = GroupSampler(dataset, samples_per_gpu) if shuffle else None
         batch_size, num_workers = num_gpus * samples_per_gpu, num_gpus * workers_per_gpu
     init_fn = partial(worker_init_fn, num_workers=num_workers, rank=rank, seed=seed) if seed is not None else None
+    from .pipelines import first_device_transform
+    split = first_device_transform(dataset.pipeline) if isinstance(getattr(dataset, 'pipeline', None), Compose) else None
+    if split is not None:
+        # the fused device front door (FusedResizeNormalizePad ...): workers are forked after the parent
+        # has initialised the GPU and must not touch it, so they run the host part of the pipeline only
+        # (file decode, annotations) and hand back raw samples; the device transforms and the collate step
+        # run in the main process (MainProcessTail)
+        tail = Compose(dataset.pipeline.transforms[split:])
+        dataset.pipeline = Compose(dataset.pipeline.transforms[:split])
+        loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+                            collate_fn=identity_collate, pin_memory=False, worker_init_fn=init_fn, **kwargs)
+        return MainProcessTail(loader, tail, partial(collate, samples_per_gpu=samples_per_gpu))
     return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
                       collate_fn=partial(collate, samples_per_gpu=samples_per_gpu), pin_memory=False,
                       worker_init_fn=init_fn, **kwargs)
+
+
+def identity_collate(batch):
+    return batch
+
+
+class MainProcessTail:
+    """A DataLoader whose workers ran only the host part of the pipeline: applies the remaining (device)
+    transforms to every raw sample in the main process, then collates."""
+
+    def __init__(self, loader, tail, collate_fn):
+        self.loader, self.tail, self.collate_fn = loader, tail, collate_fn
+        self.sampler, self.dataset, self.batch_size = loader.sampler, loader.dataset, loader.batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for raw in self.loader:
+            samples = [self.tail(r) for r in raw]
+            if any(s_ is None for s_ in samples):
+                raise RuntimeError('a device transform dropped a sample; only the host part of a pipeline may '
+                                   'reject samples (the dataset re-draws there)')
+            yield self.collate_fn(samples)
 
 
 # --------------------------------------------------------------------------- PASCAL VOC

@@ -92,7 +92,12 @@ class BaseDetector(nn.Module):
         return hasattr(self, 'roi_head') and self.roi_head is not None
 
     def init_weights(self):
-        pass   # submodules initialise themselves at construction (seeded synthetic weights)
+        """mmcv BaseModule.init_weights: every submodule initialises itself at construction; what is left
+        is the backbone's `init_cfg=dict(type='Pretrained', ...)` (configs/boosting_rcnn/*.py:15), loaded from
+        the local model directory -- a missing file raises (see blocks.load_pretrained)"""
+        bb = getattr(self, 'backbone', None)
+        if bb is not None and hasattr(bb, 'init_weights'):
+            bb.init_weights(pretrained=True)
 
     def forward_test(self, imgs, img_metas, **kwargs):
         for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:

@@ -48,6 +48,7 @@ SIGNATURES = {
     'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 6 + [c_ptr]),
     'brcnn_conv_set_tile_bf16': (c_int, [c_int]),
     'brcnn_maxpool3x3s2_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 5 + [c_ptr]),
+    'brcnn_maxpool3x3s2_nhwc_backward': (c_int, [c_ptr] * 4 + [c_int] * 5 + [c_ptr]),
     'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
     'brcnn_groupnorm_nhwc_multi': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_int, c_int, c_f32,
                                                           c_int, c_int, c_ptr]),

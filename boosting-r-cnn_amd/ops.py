@@ -667,8 +667,37 @@ def linear_nhwc(x, w, bias=None, relu=False, out_f32=False):
     return y.reshape(m, w.shape[0])
 
 
+class _MaxPool3x3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        ho, wo = conv_out_size(h, w, 3, 3, 2, 1)
+        y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+        st = _L.load().brcnn_maxpool3x3s2_nhwc(_ptr(x), _ptr(y), n, h, w, c, _dt(x), _stream())
+        _L.check(st, 'brcnn_maxpool3x3s2_nhwc')
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        n, h, w, c = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        st = _L.load().brcnn_maxpool3x3s2_nhwc_backward(_ptr(x), _ptr(y), _ptr(dy), _ptr(dx), n, h, w, c, _dt(x),
+                                                        _stream())
+        _L.check(st, 'brcnn_maxpool3x3s2_nhwc_backward')
+        return dx
+
+
 def maxpool3x3s2_nhwc(x):
+    """ResNet stem max-pool (resnet.py:611) on an NHWC map; differentiable (a trainable stem,
+    frozen_stages < 0, gets its gradient through `brcnn_maxpool3x3s2_nhwc_backward`)"""
     _require_gpu(x)
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _MaxPool3x3s2.apply(x)
     n, h, w, c = x.shape
     ho, wo = conv_out_size(h, w, 3, 3, 2, 1)
     y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)

@@ -717,6 +717,23 @@ class MultiScaleFlipAug:
 
 
 # --------------------------------------------------------------------------- device form
+def first_device_transform(compose):
+    """index of the first transform of a Compose that touches the GPU (itself, or through nested
+    transforms such as MultiScaleFlipAug), or None.  DataLoader workers are forked after the parent has
+    initialised the device and must never run those: `datasets.build_dataloader` keeps them in the main
+    process."""
+    def on_device(t):
+        if getattr(t, 'runs_on_device', False):
+            return True
+        inner = getattr(t, 'transforms', None)
+        inner = getattr(inner, 'transforms', inner)
+        return bool(inner) and any(on_device(u) for u in inner)
+    for i, t in enumerate(compose.transforms):
+        if on_device(t):
+            return i
+    return None
+
+
 @PIPELINES.register_module()
 class FusedResizeNormalizePad:
     """Resize + RandomFlip + Normalize + Pad of one decoded uint8 BGR image as ONE HIP kernel
@@ -729,6 +746,7 @@ class FusedResizeNormalizePad:
                  keep_ratio=True, bbox_clip_border=True, flip_ratio=None, direction='horizontal',
                  size=None, size_divisor=None, pad_val=0, device='cuda'):
         assert pad_val == 0
+        self.runs_on_device = True
         self.resize = Resize(img_scale, multiscale_mode, ratio_range, keep_ratio, bbox_clip_border)
         self.flip = RandomFlip(flip_ratio, direction)
         self.pad = Pad(size, size_divisor, pad_val)
@@ -772,6 +790,7 @@ class FusedResizeNormalizePad:
 class DeviceFormatBundle(DefaultFormatBundle):
     """DefaultFormatBundle for an image that FusedResizeNormalizePad already left on the device
     as a (3,H,W) tensor"""
+    runs_on_device = True
 
     def __call__(self, results):
         img = results.pop('img')

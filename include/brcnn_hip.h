@@ -288,6 +288,10 @@ int brcnn_stem7x7s2_nchw(const float *img, const void *w_packed, const float *sc
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,
                             int channels, int dtype, void *stream);
+/* its backward (a trainable stem: frozen_stages < 0): dx[n,h,w,c] = sum of dy over the windows whose first
+ * maximum (row-major scan, torch's argmax rule) is (h,w); x / y are the forward's input / output */
+int brcnn_maxpool3x3s2_nhwc_backward(const void *x, const void *y, const void *dy, void *dx, int batch,
+                                     int height, int width, int channels, int dtype, void *stream);
 
 /* GroupNorm(+ReLU) over NHWC (RPN tower ConvModule norm, atss_rpn_head.py:118,150-190):
  * y = relu?((x-mean_g)/sqrt(var_g+eps)*gamma[c]+beta[c]); stats per (n, group). */

@@ -43,7 +43,7 @@ def test_train_tool_distributed_launcher(tmp_path):
     cfg.dump(cfg_path)
     work = str(tmp_path / 'work_ddp')
     r = _launch([os.path.join(ROOT, 'tools', 'train.py'), cfg_path, '--work-dir', work, '--seed', '0', '--launcher',
-                 'pytorch'])
+                 'pytorch', '--allow-random-init'])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert os.path.exists(os.path.join(work, 'epoch_1.pth'))
 

@@ -83,6 +83,39 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     assert torch.equal(m2.state_dict()[k], ck['state_dict'][k] + 1)
 
 
+def test_pretrained_backbone_init(tmp_path, monkeypatch):
+    """init_cfg=dict(type='Pretrained', checkpoint='torchvision://resnet50') (the recipes' backbone entry):
+    resolved against $BRCNN_PRETRAINED_DIR, loaded non-strictly (a torchvision file carries fc.*), and a
+    missing file is an error unless random init was asked for"""
+    from brcnn.backbones import ResNet
+    cfg = Config.fromfile(CFG)
+    assert cfg.model.backbone.init_cfg == dict(type='Pretrained', checkpoint='torchvision://resnet50')
+    src = ResNet(depth=50)
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in src.state_dict().items()}
+    sd['fc.weight'], sd['fc.bias'] = torch.zeros(1000, 2048), torch.zeros(1000)       # as in a torchvision file
+    monkeypatch.delenv('BRCNN_ALLOW_RANDOM_INIT', raising=False)
+    monkeypatch.setenv('BRCNN_PRETRAINED_DIR', str(tmp_path / 'nothing_here'))
+    m = build_detector(cfg.model)
+    with pytest.raises(FileNotFoundError, match='BRCNN_PRETRAINED_DIR'):
+        m.init_weights()
+    monkeypatch.setenv('BRCNN_ALLOW_RANDOM_INIT', '1')
+    m.init_weights()                                                                   # explicit opt-in: warns, continues
+    monkeypatch.delenv('BRCNN_ALLOW_RANDOM_INIT')
+    os.makedirs(tmp_path / 'models')
+    torch.save(sd, str(tmp_path / 'models' / 'resnet50.pth'))
+    monkeypatch.setenv('BRCNN_PRETRAINED_DIR', str(tmp_path / 'models'))
+    m.init_weights()
+    got = m.backbone.state_dict()
+    for k in ('conv1.weight', 'layer1.0.bn3.weight', 'layer4.2.conv3.weight', 'bn1.running_var'):
+        assert torch.equal(got[k], sd[k]), k
+    # a plain path and a full-detector checkpoint ('backbone.' prefix, 'state_dict' wrapper) work too
+    torch.save(dict(state_dict={'backbone.' + k: v + 1 for k, v in sd.items() if not k.startswith('fc.')}),
+               str(tmp_path / 'det.pth'))
+    m.backbone.init_cfg = dict(type='Pretrained', checkpoint=str(tmp_path / 'det.pth'))
+    m.init_weights()
+    assert torch.equal(m.backbone.state_dict()['layer2.1.conv2.weight'], sd['layer2.1.conv2.weight'] + 1)
+
+
 def _tiny_cfg(tmp_path, max_epochs):
     from tests.golden.synth import synthetic_coco
     ann_file, prefix = synthetic_coco(str(tmp_path / 'data'), n_img=7)

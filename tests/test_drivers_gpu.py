@@ -81,12 +81,14 @@ def test_train_and_test_tools_end_to_end(tmp_path):
     cfg.dump(cfg_path)
     train, test = _tool('train'), _tool('test')
     work = str(tmp_path / 'work_gpu')
-    runner = train.main([cfg_path, '--work-dir', work, '--seed', '0', '--device-preprocess'])
+    # forked DataLoader workers + the device front door: the workers decode, the main process runs the HIP transform
+    runner = train.main([cfg_path, '--work-dir', work, '--seed', '0', '--device-preprocess', '--allow-random-init',
+                         '--cfg-options', 'data.workers_per_gpu=2'])
     assert runner.epoch == 1 and os.path.exists(os.path.join(work, 'epoch_1.pth'))
     assert all(np.isfinite(v) for row in runner.history for v in row[3].values())
     assert len(runner.eval_history) == 1
     # resume for one more epoch through --cfg-options / --resume-from
-    runner2 = train.main([cfg_path, '--work-dir', work, '--seed', '0', '--no-validate', '--resume-from',
+    runner2 = train.main([cfg_path, '--work-dir', work, '--seed', '0', '--no-validate', '--allow-random-init', '--resume-from',
                           os.path.join(work, 'epoch_1.pth'), '--cfg-options', 'runner.max_epochs=2'])
     assert runner2.epoch == 2 and runner2.iter == 2 * runner.iter
     ckpt = os.path.join(work, 'epoch_2.pth')
@@ -98,7 +100,8 @@ def test_train_and_test_tools_end_to_end(tmp_path):
     res = pickle.load(open(out_pkl, 'rb'))
     assert len(res) == 7 and len(res[0]) == len(CLASSES) and res[0][0].shape[1] == 5
     # the device front door gives the same detections as the host pipeline
-    res_dev = test.main([cfg_path, ckpt, '--out', str(tmp_path / 'res2.pkl'), '--device-preprocess'])
+    res_dev = test.main([cfg_path, ckpt, '--out', str(tmp_path / 'res2.pkl'), '--device-preprocess', '--cfg-options',
+                         'data.workers_per_gpu=2'])
     for a, b in zip(res, res_dev):
         for x, y in zip(a, b):
             assert x.shape == y.shape and np.allclose(x, y, atol=1e-4)

@@ -635,6 +635,28 @@ def test_bn_eval_act_fused_forward_backward(dtype):
         assert (bn.bias.grad.double() - b2.grad).abs().max().item() <= 2e-5 * mag(b2.grad) * (rows ** 0.5)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_maxpool_backward_matches_torch(dtype):
+    """max-pool 3x3/s2/p1 gradient (a trainable stem) against torch's max_pool2d autograd, ties included
+    (bf16 inputs and a plateau repeat values inside windows: the first maximum takes the gradient)"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(8)
+    for (n, h, w, c) in [(2, 17, 23, 64), (1, 64, 96, 8), (3, 5, 4, 128)]:
+        x = torch.randn(n, h, w, c, generator=g)
+        x[:, 2:4, 1:4] = 1.5                                  # a plateau of exact ties
+        x = x.to(DEV, dtype).requires_grad_()
+        y = ops.maxpool3x3s2_nhwc(x)
+        gy = torch.randn(y.shape, generator=g).to(DEV, dtype)
+        y.backward(gy)
+        x2 = x.detach().float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+        y2 = F.max_pool2d(x2, 3, 2, 1)
+        y2.backward(gy.float().permute(0, 3, 1, 2))
+        assert torch.equal(y.float(), y2.permute(0, 2, 3, 1))
+        ref = x2.grad.permute(0, 2, 3, 1)
+        tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
+        assert (x.grad.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_grouped_conv_autograd_matches_torch():
     """forward / dgrad / wgrad of the grouped conv (ResNeXt conv2) against torch's grouped conv in fp64"""
     import torch.nn.functional as F

@@ -35,6 +35,9 @@ def parse_args(argv=None):
     p.add_argument('--cfg-options', nargs='+', action=DictAction,
                    help='override config settings, key=value pairs (xxx=yyy, lists as a,b or "[a,b]")')
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none', help='job launcher')
+    p.add_argument('--allow-random-init', action='store_true',
+                   help="train from random weights when the backbone's pretrained checkpoint "
+                        '(init_cfg, resolved under $BRCNN_PRETRAINED_DIR) is not available')
     p.add_argument('--dist-backend', default=None, help="override dist_params.backend ('gloo' for CPU runs)")
     p.add_argument('--device-preprocess', action='store_true',
                    help='run Resize/Flip/Normalize/Pad as the fused HIP kernel on the uploaded uint8 image')
@@ -80,6 +83,8 @@ def main(argv=None):
         from brcnn.pipelines import fuse_device_pipeline
         cfg.data.train.pipeline = fuse_device_pipeline(cfg.data.train.pipeline)
     model = build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    if args.allow_random_init:
+        os.environ['BRCNN_ALLOW_RANDOM_INIT'] = '1'
     model.init_weights()
     datasets = [build_dataset(cfg.data.train)]
     assert len(cfg.get('workflow', [('train', 1)])) == 1, 'val workflow is not part of the recipes'
