@@ -102,7 +102,7 @@ class ConvNHWCFunction(Function):
             # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)
             dw = dwp.view(cout, cin, 1, 1) if kh == 1 and kw == 1 else dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
+            db = ops.colsum(dy)
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
         return dx, dw, db, None, None, None, None, None

@@ -470,6 +470,98 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(T* __restrict__ dst,
     }
 }
 
+// out = dst + nearest_upsample(src) written to a separate tensor (the differentiable form), and its
+// backward w.r.t. src: every source pixel sums the gradient of the destination pixels that read it
+// (the same floor(dst * scale) mapping, so the candidates around src * Hd / Hs are tested with it)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_out_kernel(const T* __restrict__ dst, const T* __restrict__ src,
+                                                              T* __restrict__ out, int N, int Hd, int Wd, int Hs,
+                                                              int Ws, int C) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * Hd * Wd * c4n;
+    const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        long long r = idx / c4n;
+        const int wd = (int)(r % Wd); r /= Wd;
+        const int hd = (int)(r % Hd);
+        const int n = (int)(r / Hd);
+        const int hs = min((int)floorf(hd * sh), Hs - 1);
+        const int ws = min((int)floorf(wd * sw), Ws - 1);
+        const float4 s = ld4(src + (((size_t)n * Hs + hs) * Ws + ws) * C + c4 * 4);
+        float4 d = ld4(dst + (size_t)idx * 4);
+        d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+        st4(out + (size_t)idx * 4, d);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dsrc, int N,
+                                                              int Hd, int Wd, int Hs, int Ws, int C) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * Hs * Ws * c4n;
+    const float sh = (float)Hs / (float)Hd, sw = (float)Ws / (float)Wd;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        long long r = idx / c4n;
+        const int ws = (int)(r % Ws); r /= Ws;
+        const int hs = (int)(r % Hs);
+        const int n = (int)(r / Hs);
+        const int h0 = max(0, (int)((long long)hs * Hd / Hs) - 1), h1 = min(Hd - 1, (int)((long long)(hs + 1) * Hd / Hs) + 1);
+        const int w0 = max(0, (int)((long long)ws * Wd / Ws) - 1), w1 = min(Wd - 1, (int)((long long)(ws + 1) * Wd / Ws) + 1);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int hd = h0; hd <= h1; hd++) {
+            if (min((int)floorf(hd * sh), Hs - 1) != hs) continue;
+            for (int wd = w0; wd <= w1; wd++) {
+                if (min((int)floorf(wd * sw), Ws - 1) != ws) continue;
+                const float4 g = ld4(dout + (((size_t)n * Hd + hd) * Wd + wd) * C + c4 * 4);
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+            }
+        }
+        st4(dsrc + (size_t)idx * 4, acc);
+    }
+}
+
+// column sums of a (rows, C) tensor (bias gradients): strips of rows per workgroup, then a fixed-order
+// second stage -- deterministic, reads bf16 directly
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                            long long rows, int C, int rows_per_block) {
+    __shared__ float red[256][4];
+    const int c4n = C >> 2;
+    const int CW = c4n < 256 ? c4n : 256;                 // channel vectors per block (power of two or 256)
+    const int cv = blockIdx.y * CW + (threadIdx.x % CW);
+    const int rl = threadIdx.x / CW, RL = 256 / CW;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (long long)rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cv < c4n && rl < RL)
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            const float4 v = ld4(x + (size_t)r * C + cv * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    red[threadIdx.x][0] = acc.x; red[threadIdx.x][1] = acc.y; red[threadIdx.x][2] = acc.z; red[threadIdx.x][3] = acc.w;
+    __syncthreads();
+    if (rl == 0 && cv < c4n) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float a = 0.f;
+            for (int k = 0; k < RL; k++) a += red[k * CW + threadIdx.x][e];
+            partial[(size_t)blockIdx.x * C + cv * 4 + e] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                          int strips, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = 0; s < strips; s++) a += partial[(size_t)s * C + c];
+    out[c] = a;
+}
+
 // (N, R, Cc) -> (N, Cc, R) tiled transpose through LDS: 32x32 tiles, 256 threads
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src,
                                                        float* __restrict__ dst, int R, int Cc) {
@@ -753,6 +845,77 @@ BRCNN_API int brcnn_upsample_nearest_add_nhwc(void* dst, const void* src, int ba
         hipLaunchKernelGGL(upsample_add_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
                            (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, batch, hd, wd, hs, ws,
                            channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_upsample_nearest_add_nhwc_out(const void* dst, const void* src, void* out, int batch, int hd,
+                                                  int wd, int hs, int ws, int channels, int dtype, void* stream) {
+    if (!dst || !src || !out || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 ||
+        (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const long long total = (long long)batch * hd * wd * (channels >> 2);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(upsample_add_out_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dst, (const float*)src, (float*)out, batch, hd, wd, hs, ws, channels);
+    else
+        hipLaunchKernelGGL(upsample_add_out_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dst, (const bf16_t*)src, (bf16_t*)out, batch, hd, wd, hs, ws, channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API int brcnn_upsample_nearest_add_nhwc_backward(const void* dout, void* dsrc, int batch, int hd, int wd, int hs,
+                                                       int ws, int channels, int dtype, void* stream) {
+    if (!dout || !dsrc || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 || (channels & 3) ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const long long total = (long long)batch * hs * ws * (channels >> 2);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(upsample_add_bwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dout, (float*)dsrc, batch, hd, wd, hs, ws, channels);
+    else
+        hipLaunchKernelGGL(upsample_add_bwd_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dout, (bf16_t*)dsrc, batch, hd, wd, hs, ws, channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+BRCNN_API size_t brcnn_colsum_workspace_bytes(int64_t rows, int channels) {
+    if (rows <= 0 || channels <= 0) return 256;
+    long long strips = (rows + 255) / 256;
+    if (strips > 256) strips = 256;
+    return (size_t)strips * channels * sizeof(float) + 256;
+}
+
+BRCNN_API int brcnn_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t rows,
+                           int channels, int dtype, void* stream) {
+    if (!x || !out || !workspace || rows < 0 || channels <= 0 || (channels & 3) ||
+        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        return BRCNN_EINVAL;
+    const int c4n = channels >> 2;
+    if (c4n < 256 && (c4n & (c4n - 1))) return BRCNN_EINVAL;      // channel-vector count: a power of two or >= 256
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        BRCNN_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)channels * sizeof(float), s));
+        return 0;
+    }
+    long long strips = (rows + 255) / 256;
+    if (strips > 256) strips = 256;
+    const int rpb = (int)((rows + strips - 1) / strips);
+    strips = (rows + rpb - 1) / rpb;
+    if (workspace_bytes < (size_t)strips * channels * sizeof(float)) return BRCNN_EINVAL;
+    const int CW = c4n < 256 ? c4n : 256;
+    const dim3 grid((unsigned)strips, (c4n + CW - 1) / CW);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)workspace,
+                           (long long)rows, channels, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (float*)workspace,
+                           (long long)rows, channels, rpb);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, s, (const float*)workspace, out,
+                       (int)strips, channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

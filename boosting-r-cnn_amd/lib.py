@@ -56,6 +56,10 @@ SIGNATURES = {
     'brcnn_groupnorm_nhwc_multi_backward': (c_int, [c_ptr] * 9 + [c_size, c_int, c_int, c_ptr] + [c_int] * 4 +
                                             [c_ptr]),
     'brcnn_upsample_nearest_add_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 7 + [c_ptr]),
+    'brcnn_upsample_nearest_add_nhwc_out': (c_int, [c_ptr] * 3 + [c_int] * 7 + [c_ptr]),
+    'brcnn_upsample_nearest_add_nhwc_backward': (c_int, [c_ptr] * 2 + [c_int] * 7 + [c_ptr]),
+    'brcnn_colsum_workspace_bytes': (c_size, [c_i64, c_int]),
+    'brcnn_colsum': (c_int, [c_ptr] * 3 + [c_size, c_i64, c_int, c_int, c_ptr]),
     'brcnn_nchw_to_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
     'brcnn_nhwc_to_nchw': (c_int, [c_ptr] * 2 + [c_int] * 4 + [c_ptr]),
     'brcnn_rpn_score': (c_int, [c_ptr] * 3 + [c_i64, c_int, c_int, c_int, c_ptr]),

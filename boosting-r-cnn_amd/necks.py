@@ -76,6 +76,9 @@ class FPN(nn.Module):
                     for i, conv in enumerate(self.lateral_convs)]
         for i in range(len(laterals) - 1, 0, -1):
             if laterals[i].requires_grad or laterals[i - 1].requires_grad:
+                if laterals[i].is_cuda and laterals[i].shape[3] % 4 == 0 and laterals[i].dtype == laterals[i - 1].dtype:
+                    laterals[i - 1] = ops.upsample_nearest_add_nhwc(laterals[i - 1], laterals[i])
+                    continue
                 import torch.nn.functional as F
                 up = F.interpolate(laterals[i].permute(0, 3, 1, 2), size=laterals[i - 1].shape[1:3],
                                    mode='nearest').permute(0, 2, 3, 1)

@@ -729,6 +729,59 @@ def upsample_nearest_add_nhwc_(dst, src):
     return dst
 
 
+class _UpsampleAdd(Function):
+    """dst + nearest_upsample(src, size=dst) on NHWC maps with its gradients (FPN top-down step in training)"""
+
+    @staticmethod
+    def forward(ctx, dst, src):
+        _require_gpu(dst, src)
+        dst, src = dst.contiguous(), src.contiguous()
+        n, hd, wd, c = dst.shape
+        _, hs, ws_, _ = src.shape
+        out = torch.empty_like(dst)
+        st = _L.load().brcnn_upsample_nearest_add_nhwc_out(_ptr(dst), _ptr(src), _ptr(out), n, hd, wd, hs, ws_, c,
+                                                            _dt(dst), _stream())
+        _L.check(st, 'brcnn_upsample_nearest_add_nhwc_out')
+        ctx.shapes = (n, hd, wd, hs, ws_, c)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        n, hd, wd, hs, ws_, c = ctx.shapes
+        dout = dout.contiguous()
+        dsrc = None
+        if ctx.needs_input_grad[1]:
+            dsrc = torch.empty((n, hs, ws_, c), dtype=dout.dtype, device=dout.device)
+            st = _L.load().brcnn_upsample_nearest_add_nhwc_backward(_ptr(dout), _ptr(dsrc), n, hd, wd, hs, ws_, c,
+                                                                     _dt(dout), _stream())
+            _L.check(st, 'brcnn_upsample_nearest_add_nhwc_backward')
+        return (dout if ctx.needs_input_grad[0] else None), dsrc
+
+
+def upsample_nearest_add_nhwc(dst, src):
+    """differentiable dst + nearest_upsample(src, size=dst.shape[1:3]) (necks/fpn.py:178-181)"""
+    assert dst.dtype == src.dtype and dst.shape[3] == src.shape[3] and dst.shape[3] % 4 == 0
+    return _UpsampleAdd.apply(dst, src)
+
+
+def colsum(x):
+    """column sums of a (rows, C) fp32 / bf16 tensor as fp32 (C,): bias gradients, deterministic"""
+    _require_gpu(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, c = x.shape
+    c4 = c // 4
+    if c % 4 or (c4 < 256 and c4 & (c4 - 1)):
+        return x.float().sum(0)
+    lib = _L.load()
+    nb = lib.brcnn_colsum_workspace_bytes(rows, c)
+    ws = torch.empty((nb + 3) // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    st = lib.brcnn_colsum(_ptr(x), _ptr(out), _ptr(ws), nb, rows, c, _dt(x), _stream())
+    _L.check(st, 'brcnn_colsum')
+    return out
+
+
 def nchw_to_nhwc(x):
     _require_gpu(x)
     n, c, h, w = x.shape

@@ -370,6 +370,18 @@ int brcnn_deform_col2im_nhwc(const float *x, const float *offset_mask, const flo
  * F.interpolate(size=...) at necks/pafpn.py:113-115, fpn.py:178-181) */
 int brcnn_upsample_nearest_add_nhwc(void *dst, const void *src, int batch, int hd, int wd,
                                     int hs, int ws, int channels, int dtype, void *stream);
+/* differentiable form: out = dst + nearest_upsample(src) into a separate tensor, and the gradient w.r.t.
+ * src (every source pixel sums the gradient of the destination pixels that read it; d/d dst is dout) */
+int brcnn_upsample_nearest_add_nhwc_out(const void *dst, const void *src, void *out, int batch, int hd,
+                                        int wd, int hs, int ws, int channels, int dtype, void *stream);
+int brcnn_upsample_nearest_add_nhwc_backward(const void *dout, void *dsrc, int batch, int hd, int wd, int hs,
+                                             int ws, int channels, int dtype, void *stream);
+
+/* column sums of a (rows, channels) fp32 / bf16 tensor into fp32 (bias gradients of the convs / FCs:
+ * db = sum_rows dy), two fixed-order stages (deterministic); channels / 4 a power of two or >= 256 */
+size_t brcnn_colsum_workspace_bytes(int64_t rows, int channels);
+int brcnn_colsum(const void *x, float *out, void *workspace, size_t workspace_bytes, int64_t rows,
+                 int channels, int dtype, void *stream);
 
 /* layout shuffles between the reference's NCHW boundary and the NHWC interior */
 int brcnn_nchw_to_nhwc(const float *src, void *dst, int batch, int channels, int hw,

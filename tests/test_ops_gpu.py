@@ -657,6 +657,35 @@ def test_maxpool_backward_matches_torch(dtype):
         assert (x.grad.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upsample_add_autograd_and_colsum(dtype):
+    """FPN top-down step (dst + nearest_upsample(src, size=dst)) forward / both gradients against
+    F.interpolate + add, for the non-integer scale factors of the pyramid (13 -> 25, 7 -> 13); bias-gradient
+    column sums against torch"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(12)
+    for (n, hd, wd, hs, ws, c) in [(2, 25, 42, 13, 21, 256), (1, 13, 21, 7, 11, 64), (2, 100, 168, 50, 84, 8)]:
+        dst = torch.randn(n, hd, wd, c, generator=g).to(DEV, dtype).requires_grad_()
+        src = torch.randn(n, hs, ws, c, generator=g).to(DEV, dtype).requires_grad_()
+        out = ops.upsample_nearest_add_nhwc(dst, src)
+        go = torch.randn(out.shape, generator=g).to(DEV, dtype)
+        out.backward(go)
+        d2, s2 = dst.detach().float().requires_grad_(), src.detach().float().requires_grad_()
+        ref = d2 + F.interpolate(s2.permute(0, 3, 1, 2), size=(hd, wd), mode='nearest').permute(0, 2, 3, 1)
+        ref.backward(go.float())
+        tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
+        mag = lambda t: max(1.0, t.abs().max().item())   # noqa: E731
+        assert (out.float() - ref).abs().max().item() <= tol * mag(ref)
+        assert torch.equal(dst.grad, go)
+        assert (src.grad.float() - s2.grad).abs().max().item() <= tol * mag(s2.grad)
+    for rows, c in [(1000, 64), (33000, 256), (7, 1024), (2048, 32), (513, 2048)]:
+        x = torch.randn(rows, c, generator=g).to(DEV, dtype)
+        got = ops.colsum(x)
+        ref = x.double().sum(0)
+        assert got.dtype == torch.float32
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) * rows ** 0.5
+
+
 def test_grouped_conv_autograd_matches_torch():
     """forward / dgrad / wgrad of the grouped conv (ResNeXt conv2) against torch's grouped conv in fp64"""
     import torch.nn.functional as F
