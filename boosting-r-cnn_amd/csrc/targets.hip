@@ -73,6 +73,22 @@ __device__ __forceinline__ float pair_iou(const float4 g, const float ga, const 
     return ov / un;
 }
 
+// the same in two steps: overlap first (most pairs are disjoint and 0 / union == 0 exactly, so the
+// correctly rounded division is only paid where boxes intersect)
+__device__ __forceinline__ float pair_overlap(const float4 g, const float4 b) {
+    const float ltx = fmaxf(g.x, b.x), lty = fmaxf(g.y, b.y);
+    const float rbx = fminf(g.z, b.z), rby = fminf(g.w, b.w);
+    float w = rbx - ltx, h = rby - lty;
+    w = w < 0.f ? 0.f : w;
+    h = h < 0.f ? 0.f : h;
+    return w * h;
+}
+__device__ __forceinline__ float iou_from_overlap(float ov, float ga, float ba) {
+    float un = ga + ba - ov;
+    un = fmaxf(un, 1e-6f);
+    return ov / un;
+}
+
 __device__ __forceinline__ bool box_is_valid(const AssignParams& p, int b, int i, const float4 bx) {
     if (p.num_boxes && i >= p.num_boxes[b]) return false;
     if (p.geom.num_levels > 0 && p.valid_hw) {
@@ -122,23 +138,35 @@ __global__ __launch_bounds__(256) void assign_kernel(const AssignParams p) {
             s_gt[tid] = g;
             s_ga[tid] = (g.z - g.x) * (g.w - g.y);
             if (PASS == 1 && p.low_quality) s_gmax[tid] = p.gt_max[g0 + c0 + tid];
+            if (PASS == 0) s_gmax[tid] = 0u;
         }
         __syncthreads();
         for (int k = 0; k < cn; k++) {
-            const float iou = valid ? pair_iou(s_gt[k], s_ga[k], bx, ba) : -1.f;
+            const float ov = valid ? pair_overlap(s_gt[k], bx) : 0.f;
             if (PASS == 0) {
                 // wave maximum -> one atomic per wave and gt; nothing to do while every lane is at 0
                 // (gt_max starts at 0, the smallest IoU)
-                float m = iou;
+                if (__ballot(ov > 0.f) == 0ull) continue;         // (wave-uniform) no lane overlaps this gt
+                float m = ov > 0.f ? iou_from_overlap(ov, s_ga[k], ba) : 0.f;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-                if (lane == 0 && m > 0.f) atomicMax(p.gt_max + g0 + c0 + k, __float_as_uint(m));
+                if (lane == 0) atomicMax(&s_gmax[k], __float_as_uint(m));        // workgroup maximum in LDS
             } else {
+                const float iou = !valid ? -1.f : (ov > 0.f ? iou_from_overlap(ov, s_ga[k], ba) : 0.f);
                 if (iou > mx) { mx = iou; arg = c0 + k; }      // first maximum, as torch.max(dim=0) on the host
                 if (p.low_quality) {
                     const float gm = __uint_as_float(s_gmax[k]);
                     if (gm >= p.min_pos && iou == gm) lowq = c0 + k + 1;     // later gts override earlier ones
                 }
+            }
+        }
+        if (PASS == 0) {
+            // one global atomic per workgroup and gt, and only when it can still raise the maximum (a few
+            // hundred addresses take every update of the launch: unconditional atomics serialise on them)
+            __syncthreads();
+            if (tid < cn) {
+                const unsigned v = s_gmax[tid];
+                if (v > __atomic_load_n(p.gt_max + g0 + c0 + tid, __ATOMIC_RELAXED)) atomicMax(p.gt_max + g0 + c0 + tid, v);
             }
         }
     }

@@ -60,8 +60,15 @@ def main():
         rg = rois.to(DEV)
         t = timed(lambda: ops.roi_extract(feats, rg, 7, strides, 56, 0))
         by = roialign_bytes(rois, strides, sizes)
+        # the read term is bounded by the whole pyramid read once (22 400 px x 256 ch x 4 B / image)
+        out_b = K * 256 * 49 * 4 + K * 20
+        pyramid = B * sum(h * w for h, w in sizes) * 256 * 4
+        capped = out_b + min(by - out_b, pyramid)
         res[f'roialign_fwd_{per_img}x{B}'] = dict(us=t * 1e6, algorithmic_MB=by / 1e6, GBs=by / t / 1e9,
-                                                  frac_hbm=by / t / 1e9 / HBM)
+                                                  frac_hbm=by / t / 1e9 / HBM, capped_MB=capped / 1e6,
+                                                  capped_GBs=capped / t / 1e9, capped_frac_hbm=capped / t / 1e9 / HBM,
+                                                  note='capped_*: read term limited to the pyramid read once '
+                                                       '(SURVEY 8d); algorithmic_* sums per-RoI footprints')
         fr = [f.clone().requires_grad_() for f in feats]
         go = torch.randn(K, 7, 7, 256, device=DEV)
 
@@ -84,6 +91,48 @@ def main():
         res['nms_' + name] = dict(us=t * 1e6, boxes_per_s=n / t, algorithmic_MB=by / 1e6, GBs=by / t / 1e9,
                                   frac_hbm=by / t / 1e9 / HBM,
                                   note='latency bound: one wavefront per segment resolves the greedy chain')
+    # train-step target / loss kernels at the BASELINE size (8 images, 201 600 anchors, 20 GT each)
+    from brcnn import core, train_ops
+    gen = core.AnchorGenerator(strides=strides, ratios=[0.5, 1.0, 2.0], octave_base_scale=4, scales_per_octave=3)
+    anchors = torch.cat(gen.grid_anchors(sizes, 'cpu'), 0).to(DEV).contiguous()
+    gts_l = [util.rand_boxes(20, 1333, 800, seed=40 + b, min_size=16, max_size=600).to(DEV) for b in range(B)]
+    gts, _, offs = train_ops.flatten_gts(gts_l)
+    t = timed(lambda: train_ops.assign_max_iou(anchors, gts, offs, 0.5, 0.5, 0.0, True, batch=B))
+    by = B * anchors.shape[0] * 4 + anchors.numel() * 4
+    res['assign_rpn_8x201600x20'] = dict(us=t * 1e6, iou_pairs_per_s=2 * B * anchors.shape[0] * 20 / t,
+                                         algorithmic_MB=by / 1e6, GBs=by / t / 1e9,
+                                         note='two passes (per-gt maxima, assignment): IoU-evaluation bound, not HBM')
+    props = torch.stack([torch.cat([util.rand_boxes(2000, 1333, 800, seed=60 + b), torch.rand(2000, 1)], 1)
+                         for b in range(B)]).to(DEV)
+    nump = torch.full((B,), 2000, dtype=torch.int32, device=DEV)
+    t = timed(lambda: train_ops.assign_max_iou(props, gts, offs, 0.6, 0.6, 0.6, False, num_boxes=nump, want_counts=True))
+    res['assign_rcnn_8x2000x20'] = dict(us=t * 1e6, note='launch-latency sized')
+    y = torch.randn(B * sum(h * w for h, w in sizes), 64, device=DEV).requires_grad_()
+    gi = train_ops.assign_max_iou(anchors, gts, offs, 0.5, 0.5, 0.0, True, batch=B)
+    base = [b_.to(DEV) for b_ in gen.base_anchors]
+    meta = train_ops.RPNLossMeta(B, sizes, gen.strides, base, 9, offs, 2.0, 0.25, -1, 2.0, (0., 0., 0., 0.),
+                                 (1., 1., 1., 1.), 16 / 1000, True, 1.0, 2.0, 2.0, 1.0)
+    sc = torch.ones(5, device=DEV, requires_grad=True)
+
+    def rl():
+        l3, _, _ = train_ops.rpn_loss(y, sc, gi, gts, meta)
+        l3.sum().backward()
+    t = timed(rl, 10)
+    by = 2 * y.numel() * 4 + 2 * gi.numel() * 4
+    res['rpn_loss_fwd+bwd_8x22400px'] = dict(us=t * 1e6, algorithmic_MB=by / 1e6, GBs=by / t / 1e9,
+                                             frac_hbm=by / t / 1e9 / HBM,
+                                             note='forward reads the 64-channel head rows once, backward writes them once; '
+                                                  'includes the autograd / launch overhead of 5 small launches')
+    cls = torch.randn(4096, 81, device=DEV).requires_grad_()
+    bb = torch.randn(4096, 320, device=DEV).requires_grad_()
+    lab = torch.randint(0, 81, (4096,), device=DEV)
+    pri, tgt = torch.rand(4096, device=DEV), torch.randn(4096, 4, device=DEV)
+
+    def bl():
+        o = train_ops.boost_loss(cls, bb, lab, pri, tgt, 80, 0.5, loss_cls_weight=2.0, loss_bbox_weight=2.0)
+        (o[0] + o[1]).backward()
+    t = timed(bl, 10)
+    res['boost_loss_fwd+bwd_4096x81'] = dict(us=t * 1e6, note='launch-latency sized (3 launches)')
     # soft-NMS: 80 classes x 8 images, 250 boxes per segment (config #5 scale / 8)
     lens = [250] * 640
     n = sum(lens)
