@@ -137,7 +137,8 @@ def train_bench(args, world, rank, device):
                                                         bucket_cap_mb=64, gradient_as_bucket_view=True)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
     gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)
-    scaler = model.make_loss_scaler() if hasattr(model, 'make_loss_scaler') else None
+    # fp16: the recipes' static loss scaling (fp16 = dict(loss_scale=512.), mmcv Fp16OptimizerHook)
+    scaler = torch.amp.GradScaler('cuda', init_scale=512.) if args.train_dtype == 'f16' else None
     last = {}
 
     def step():
@@ -145,11 +146,15 @@ def train_bench(args, world, rank, device):
         losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
         loss, log_vars = model._parse_losses(losses)
         if scaler is not None:
-            scaler.backward(loss, params)
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(params, max_norm=35, norm_type=2)
+            scaler.step(opt)
+            scaler.update(512.)
         else:
             loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, max_norm=35, norm_type=2)
-        opt.step()
+            torch.nn.utils.clip_grad_norm_(params, max_norm=35, norm_type=2)
+            opt.step()
         last['log_vars'] = log_vars
 
     steps = args.train_steps or args.steps

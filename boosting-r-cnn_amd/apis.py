@@ -219,6 +219,7 @@ class EpochBasedRunner:
         self.ckpt_interval = 1
         self.log_interval = 50
         self.eval_fn, self.eval_interval = None, 1
+        self.loss_scaler, self.loss_scale = None, None      # fp16 recipes: static loss scaling (train_detector)
         self.log_buffer = OrderedDict()
         self.history = []          # (epoch, iter, lr, {name: value}) rows the text logger printed
         self.eval_history = []
@@ -299,12 +300,25 @@ class EpochBasedRunner:
             outputs = self.model.train_step(data, self.optimizer) if not hasattr(self.model, 'module') else \
                 self._ddp_step(data)
             self.optimizer.zero_grad()
-            outputs['loss'].backward()
-            if self.grad_clip is not None:
-                gn = self._clip()
-                if gn is not None:
-                    outputs['log_vars']['grad_norm'] = float(gn)
-            self.optimizer.step()
+            if self.loss_scaler is not None:
+                # Fp16OptimizerHook (mmcv/runner/hooks/optimizer.py, the torch >= 1.6 form): scaled backward,
+                # unscale, clip, a step that is skipped on inf / nan gradients, and -- static mode -- the
+                # scale reset to `loss_scale` every iteration
+                self.loss_scaler.scale(outputs['loss']).backward()
+                self.loss_scaler.unscale_(self.optimizer)
+                if self.grad_clip is not None:
+                    gn = self._clip()
+                    if gn is not None:
+                        outputs['log_vars']['grad_norm'] = float(gn)
+                self.loss_scaler.step(self.optimizer)
+                self.loss_scaler.update(self.loss_scale)
+            else:
+                outputs['loss'].backward()
+                if self.grad_clip is not None:
+                    gn = self._clip()
+                    if gn is not None:
+                        outputs['log_vars']['grad_norm'] = float(gn)
+                self.optimizer.step()
             for k, v in outputs['log_vars'].items():
                 self.log_buffer.setdefault(k, []).append(v)
             self.iter += 1
@@ -403,11 +417,22 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     runner = EpochBasedRunner(model, optimizer, cfg.work_dir, logger, runner_cfg['max_epochs'], meta)
     runner.timestamp = timestamp
     if cfg.get('fp16', None) is not None:
-        # the recipe asks for mmcv's Fp16OptimizerHook (fp16 + loss scaling); the MI355X path's
-        # reduced-precision mode is bf16 MFMA with fp32 master weights, which needs no loss scale
-        logger.info(f'fp16={dict(cfg.fp16)} in the config: training with the bf16 conv stack instead '
-                    '(no loss scaling needed)')
-        (model.module if hasattr(model, 'module') else model).set_compute_dtype('bf16')
+        # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->
+        # mmdet/apis/train.py:115-119, mmcv Fp16OptimizerHook): fp16 MFMA conv stack (fp32 accumulation, fp32
+        # master weights, fp32 heads / losses) with static loss scaling; BRCNN_FP16_AS_BF16=1 keeps the
+        # round-1 behaviour (bf16 conv stack, no scaling needed)
+        module = model.module if hasattr(model, 'module') else model
+        if os.environ.get('BRCNN_FP16_AS_BF16') == '1':
+            logger.info(f'fp16={dict(cfg.fp16)} in the config: BRCNN_FP16_AS_BF16=1 -> bf16 conv stack, no loss scaling')
+            module.set_compute_dtype('bf16')
+        else:
+            scale = cfg.fp16.get('loss_scale', 512.)
+            if isinstance(scale, str) or isinstance(scale, dict):
+                raise NotImplementedError(f'fp16 loss_scale={scale!r}: only the static float form of the recipes is built')
+            module.set_compute_dtype('f16')
+            runner.loss_scale = float(scale)
+            runner.loss_scaler = torch.amp.GradScaler('cuda', init_scale=float(scale), enabled=device.type == 'cuda')
+            logger.info(f'fp16={dict(cfg.fp16)}: fp16 MFMA conv stack, static loss scale {float(scale)}')
     runner.register_training_hooks(cfg.lr_config, cfg.get('optimizer_config', None),
                                    cfg.get('checkpoint_config', None), cfg.get('log_config', None))
     for hook in cfg.get('custom_hooks', None) or []:

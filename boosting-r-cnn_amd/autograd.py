@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 
 from . import lib as _L
 from . import ops
-from .ops import DT_F32, DT_BF16, _ptr, _require_gpu, _stream, conv_out_size
+from .ops import DT_F32, DT_BF16, _dt, _ptr, _require_gpu, _stream, conv_out_size
 
 
 def _ints(vals):
@@ -45,7 +45,7 @@ class ConvNHWCFunction(Function):
         w_t = torch.empty((cin_, kh_, kw_, cout_), dtype=x_cat.dtype, device=x_cat.device) \
             if x_cat.requires_grad else None
         st = _L.load().brcnn_pack_conv_weights(_ptr(wsrc), _ptr(w_p), _ptr(w_t), cout_, cin_, kh_, kw_,
-                                               DT_F32 if x_cat.dtype == torch.float32 else DT_BF16, _stream())
+                                               _dt(x_cat), _stream())
         _L.check(st, 'brcnn_pack_conv_weights')
         ctx.w_t = w_t
         x_cat = x_cat.contiguous()
@@ -66,7 +66,7 @@ class ConvNHWCFunction(Function):
         batch, sizes, out_sizes, stride, pad, has_bias = ctx.cfg
         cout, cin, kh, kw = weight.shape
         dy = dy.to(x_cat.dtype).contiguous()
-        dt = DT_F32 if x_cat.dtype == torch.float32 else DT_BF16
+        dt = _dt(x_cat)
         lib = _L.load()
         L = len(sizes)
         hs, ws = _ints([h for h, _ in sizes]), _ints([w for _, w in sizes])
@@ -153,7 +153,7 @@ def _dgrad_stride2(dy, weight, batch, in_size, out_size, k, pad, dtype):
     cout, cin = weight.shape[0], weight.shape[1]
     w = weight.detach().float()
     lib = _L.load()
-    dt = DT_F32 if dtype == torch.float32 else DT_BF16
+    dt = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: ops.DT_F16}[dtype]
     if k == 1:
         dx = torch.zeros((batch * H * W, cin), dtype=dtype, device=dy.device)
         classes = [(0, 0, w.permute(1, 2, 3, 0), 0, 0)]                       # (ph, pw, taps, pad, origin)
@@ -284,7 +284,7 @@ class GroupedConvFunction(Function):
         cout, cg_in, kh, kw = weight.shape
         cg_out = cout // groups
         dy = dy.to(x.dtype).contiguous()
-        gdt = DT_F32 if x.dtype == torch.float32 else DT_BF16
+        gdt = _dt(x)
         lib = _L.load()
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -356,7 +356,7 @@ class BnActFunction(Function):
         z = z.contiguous()
         c = z.shape[-1]
         rows = z.numel() // c
-        dt = DT_F32 if z.dtype == torch.float32 else DT_BF16
+        dt = _dt(z)
         sc, sh = scale.detach().float().contiguous(), shift.detach().float().contiguous()
         r = res.contiguous() if res is not None else None
         out = torch.empty_like(z)
@@ -397,7 +397,7 @@ class BnEvalActFunction(Function):
         z = z.contiguous()
         c = z.shape[-1]
         rows = z.numel() // c
-        dt = DT_F32 if z.dtype == torch.float32 else DT_BF16
+        dt = _dt(z)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         m32, v32 = mean.detach().float().contiguous(), var.detach().float().contiguous()
         r = res.contiguous() if res is not None else None
@@ -439,7 +439,7 @@ def bn_act_supported(z):
     c = z.shape[-1]
     v = 4 if z.dtype == torch.float32 else 8
     n = c // v
-    return c % v == 0 and n > 0 and (n & (n - 1)) == 0 and z.dtype in (torch.float32, torch.bfloat16)
+    return c % v == 0 and n > 0 and (n & (n - 1)) == 0 and z.dtype in (torch.float32, torch.bfloat16, torch.float16)
 
 
 def bn_act_autograd(z, scale, shift, res=None, relu=True):

@@ -26,8 +26,9 @@ _COMPUTE_DTYPE = torch.float32
 
 def set_compute_dtype(dtype):
     global _COMPUTE_DTYPE
-    dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}.get(dtype, dtype)
-    assert dtype in (torch.float32, torch.bfloat16)
+    dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16,
+             'fp16': torch.float16}.get(dtype, dtype)
+    assert dtype in (torch.float32, torch.bfloat16, torch.float16)
     _COMPUTE_DTYPE = dtype
 
 

@@ -13,10 +13,10 @@
 
 namespace {
 
-typedef unsigned short bf16_t;
 template <typename T> struct Vec;
 template <> struct Vec<float> { static constexpr int N = 4; };
 template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+template <> struct Vec<f16_t> { static constexpr int N = 8; };
 
 __device__ __forceinline__ void ldv(const float* p, float v[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);
@@ -35,6 +35,23 @@ __device__ __forceinline__ unsigned f2bf(float v) {
     unsigned u = __float_as_uint(v);
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
+}
+__device__ __forceinline__ void ldv(const f16_t* p, float v[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        v[2 * e] = brcnn_h2f((unsigned short)(w[e] & 0xffffu));
+        v[2 * e + 1] = brcnn_h2f((unsigned short)(w[e] >> 16));
+    }
+}
+__device__ __forceinline__ void stv(f16_t* p, const float v[8]) {
+    uint4 u;
+    u.x = (unsigned)brcnn_f2h(v[0]) | ((unsigned)brcnn_f2h(v[1]) << 16);
+    u.y = (unsigned)brcnn_f2h(v[2]) | ((unsigned)brcnn_f2h(v[3]) << 16);
+    u.z = (unsigned)brcnn_f2h(v[4]) | ((unsigned)brcnn_f2h(v[5]) << 16);
+    u.w = (unsigned)brcnn_f2h(v[6]) | ((unsigned)brcnn_f2h(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void stv(float* p, const float v[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -253,7 +270,7 @@ inline int fwd_grid(long long total, int cvn, bool bn_mode) {
 int forward_impl(const void* z, const float* scale, const float* shift, const BnStats bn, const void* residual,
                  void* out, int64_t rows, int channels, int relu, int dtype, void* stream) {
     if (!z || !scale || !shift || !out || rows < 0 || channels <= 0 ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
     if (channels % V) return BRCNN_EINVAL;
@@ -265,9 +282,13 @@ int forward_impl(const void* z, const float* scale, const float* shift, const Bn
         hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const float*)z, scale, shift, bn, (const float*)residual, (float*)out, (long long)rows,
                            channels, relu);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)z, scale, shift, bn, (const bf16_t*)residual, (bf16_t*)out, (long long)rows,
+                           channels, relu);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)z, scale, shift, bn, (const f16_t*)residual, (f16_t*)out, (long long)rows,
                            channels, relu);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -301,7 +322,7 @@ static int backward_impl(const void* dout, const void* out, const void* z, const
                          void* dz, void* dres, float* dscale, float* dshift, void* workspace,
                          size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype, void* stream) {
     if (!dout || !z || !scale || !dz || !dscale || !dshift || !workspace || rows < 0 || channels <= 0 ||
-        (relu && !out) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        (relu && !out) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
     if (channels % V) return BRCNN_EINVAL;
@@ -318,10 +339,14 @@ static int backward_impl(const void* dout, const void* out, const void* z, const
         hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
                            (const float*)dout, (const float*)out, (const float*)z, scale, bn, (float*)dz, (float*)dres,
                            (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
                            (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)z, scale, bn, (bf16_t*)dz,
                            (bf16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_kernel<f16_t>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
+                           (const f16_t*)dout, (const f16_t*)out, (const f16_t*)z, scale, bn, (f16_t*)dz,
+                           (f16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     BRCNN_LAUNCH_CHECK();
     if (bn.mean)
         hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s,

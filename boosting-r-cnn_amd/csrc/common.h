@@ -23,3 +23,26 @@ static inline int brcnn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / 
 
 // wave width on gfx950
 #define WAVE 64
+
+// 16-bit element types of the NHWC activations in the reduced-precision modes: bf16 (bit pattern in an
+// unsigned short) and IEEE fp16 (wrapped so that overloads can tell the two apart)
+typedef unsigned short bf16_t;
+struct f16_t { unsigned short v; };
+
+static inline bool brcnn_elem_ok(int dt) { return dt == BRCNN_DT_F32 || dt == BRCNN_DT_BF16 || dt == BRCNN_DT_F16; }
+static inline bool brcnn_is16(int dt) {
+    return dt == BRCNN_DT_BF16 || dt == BRCNN_DT_BF16_OUT_F32 || dt == BRCNN_DT_F16 || dt == BRCNN_DT_F16_OUT_F32;
+}
+static inline bool brcnn_isf16(int dt) { return dt == BRCNN_DT_F16 || dt == BRCNN_DT_F16_OUT_F32; }
+static inline bool brcnn_out_f32(int dt) { return dt == BRCNN_DT_BF16_OUT_F32 || dt == BRCNN_DT_F16_OUT_F32; }
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ float brcnn_h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned short brcnn_f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float brcnn_b2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short brcnn_f2b(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+#endif

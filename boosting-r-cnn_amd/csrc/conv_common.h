@@ -30,6 +30,7 @@ struct ConvParams {
     unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
     int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
     int out_f32;                     // bf16 compute path: write the result as fp32 (head outputs)
+    int f16;                         // 16-bit path: operands are IEEE fp16 instead of bf16
     int il;                          // tuning: 1 = LDS-DMA pieces interleaved with the MFMA groups (bf16 kernel)
     // output scatter (data gradient of a stride-2 conv by parity class): output pixel (a, b) of the
     // launch goes to pixel (2*(a-sc_o)+sc_ph, 2*(b-sc_o)+sc_pw) of a (batch, sc_H, sc_W, Cout) tensor and

@@ -659,11 +659,11 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
         !heights_host || !widths_host)
         return BRCNN_EINVAL;
     const int esize = (dtype == BRCNN_DT_F32) ? 4 : 2;
-    const bool bf16 = (dtype == BRCNN_DT_BF16 || dtype == BRCNN_DT_BF16_OUT_F32);
+    const bool bf16 = brcnn_is16(dtype);          // 16-bit operands (bf16 or fp16), fp32 accumulate
     if (dtype != BRCNN_DT_F32 && !bf16) return BRCNN_EINVAL;
     if (bf16 && cin % 64 != 0) return BRCNN_EINVAL;
     if (dilate > 1 && (cin % 32 != 0 || stride != 1)) return BRCNN_EINVAL;
-    if (bf16 && (cout & 7) && dtype == BRCNN_DT_BF16 && residual) return BRCNN_EINVAL;
+    if (bf16 && (cout & 7) && !brcnn_out_f32(dtype) && residual) return BRCNN_EINVAL;
     ConvParams p = {};
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
@@ -688,7 +688,8 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     if (x_off * esize >= 0x7fffffffLL || (long long)cout * kh * kw * cin * esize >= 0x7fffffffLL) return BRCNN_EINVAL;
     p.x_bytes = (unsigned)(x_off * esize);
     p.w_bytes = (unsigned)((long long)cout * kh * kw * cin * esize);
-    p.out_f32 = (dtype == BRCNN_DT_BF16_OUT_F32);
+    p.out_f32 = brcnn_out_f32(dtype) ? 1 : 0;
+    p.f16 = brcnn_isf16(dtype) ? 1 : 0;
     p.M = (int)m_total;
     p.K = kh * kw * cin;
     p.relu = relu;
@@ -706,7 +707,7 @@ BRCNN_API int brcnn_conv2d_nhwc_scatter2(const void* x, const void* w, void* y, 
                                          int cin, int cout, int kh, int kw, int pad, int out_height,
                                          int out_width, int ph, int pw, int origin, int dtype, void* stream) {
     if (out_height <= 0 || out_width <= 0 || ph < 0 || ph > 1 || pw < 0 || pw > 1 || origin < 0 ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int Ho = height + 2 * pad - kh + 1, Wo = width + 2 * pad - kw + 1;
     int na = (out_height - ph + 1) / 2, nb = (out_width - pw + 1) / 2;      // pixels of this parity class
@@ -731,7 +732,7 @@ static int grouped_launch(const void* x, const void* w_tiles, const float* scale
                           int kh, int kw, int stride, int pad, int dilate, int Ho, int Wo, int window, int relu,
                           int dtype, void* stream) {
     if (!x || !w_tiles || !y || batch <= 0 || height <= 0 || width <= 0 || cin <= 0 || cout <= 0 || kh <= 0 ||
-        kw <= 0 || stride <= 0 || pad < 0 || dilate < 1 || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) ||
+        kw <= 0 || stride <= 0 || pad < 0 || dilate < 1 || !brcnn_elem_ok(dtype) ||
         window <= 0 || (window % (dtype == BRCNN_DT_F32 ? 32 : 64)) ||
         (cout % 64) || (cout / 64) * window != cin || height * dilate + pad >= 4096 || width * dilate + pad >= 4096)
         return BRCNN_EINVAL;
@@ -753,7 +754,8 @@ static int grouped_launch(const void* x, const void* w_tiles, const float* scale
     p.w_bytes = (unsigned)((long long)cout * p.K * esz);
     p.M = (int)m_total;
     p.relu = relu;
-    if (dtype == BRCNN_DT_BF16) return dispatch_conv_bf16(p, (hipStream_t)stream);
+    p.f16 = dtype == BRCNN_DT_F16 ? 1 : 0;
+    if (dtype != BRCNN_DT_F32) return dispatch_conv_bf16(p, (hipStream_t)stream);
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = cout / 64;
     return p.residual ? launch_dma<1, 1, true>(p, (hipStream_t)stream) : launch_dma<1, 1, false>(p, (hipStream_t)stream);
@@ -817,7 +819,7 @@ BRCNN_API int brcnn_conv2d_dgrad_nhwc_multi(const void* dy, const void* w_t, voi
 namespace {
 // EXTRA = zero pixels appended to each row beyond the 3+3 border (so that the last window's
 // full 32-float / 64-bf16 K row stays inside the row); bf16 variant packs 4 x bf16 per pixel.
-template <bool BF16>
+template <int BF16>      // 0 fp32, 1 bf16, 2 fp16
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ img,
                                                        void* __restrict__ out, int N, int H, int W,
                                                        int Wp) {
@@ -834,7 +836,12 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
             const size_t b = ((size_t)n * 3 * H + h) * W + w;
             v.x = img[b]; v.y = img[b + (size_t)H * W]; v.z = img[b + 2 * (size_t)H * W];
         }
-        if (BF16) {
+        if (BF16 == 2) {
+            uint2 u;
+            u.x = (unsigned)brcnn_f2h(v.x) | ((unsigned)brcnn_f2h(v.y) << 16);
+            u.y = (unsigned)brcnn_f2h(v.z);
+            reinterpret_cast<uint2*>(out)[i] = u;
+        } else if (BF16) {
             auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
             uint2 u;
             u.x = bf(v.x) | (bf(v.y) << 16);
@@ -855,17 +862,18 @@ BRCNN_API int brcnn_stem7x7s2_nchw(const float* img, const void* w_packed, const
                                    const float* shift, void* y, void* workspace, int batch,
                                    int height, int width, int cout, int relu, int dtype, void* stream) {
     if (!img || !w_packed || !y || !workspace || batch <= 0 || height < 7 || width < 7 || cout <= 0 ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const bool bf = dtype == BRCNN_DT_BF16;
+    const bool bf = dtype != BRCNN_DT_F32;
     const int kelems = bf ? 64 : 32;                 // K row = 128 bytes of 4-element pixels
     const int Hp = height + 6, Wp = width + 6 + (kelems / 4 - 8);
     const long long total = (long long)batch * Hp * Wp;
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
-    if (bf) hipLaunchKernelGGL(stem_pack_kernel<true>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
-    else hipLaunchKernelGGL(stem_pack_kernel<false>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
+    if (dtype == BRCNN_DT_F16) hipLaunchKernelGGL(stem_pack_kernel<2>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
+    else if (bf) hipLaunchKernelGGL(stem_pack_kernel<1>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
+    else hipLaunchKernelGGL(stem_pack_kernel<0>, dim3((int)g), dim3(256), 0, s, img, workspace, batch, height, width, Wp);
     BRCNN_LAUNCH_CHECK();
     const int Ho = (height + 6 - 7) / 2 + 1, Wo = (width + 6 - 7) / 2 + 1;
     const int hs[1] = {Hp}, ws[1] = {Wp}, ohs[1] = {Ho}, ows[1] = {Wo};

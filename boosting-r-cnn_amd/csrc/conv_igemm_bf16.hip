@@ -18,6 +18,7 @@ namespace {
 using namespace brcnn_conv;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int BKE = 64;     // K tile in elements (128 bytes)
 
@@ -27,11 +28,15 @@ __device__ __forceinline__ unsigned short f2bf(float v) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// ET: element type of the 16-bit operands / result, 0 = bf16, 1 = IEEE fp16 (v_mfma_f32_32x32x16_f16); the
+// staging path moves bytes and is the same for both
+template <int ET> __device__ __forceinline__ float e2f(unsigned short h) { return ET ? brcnn_h2f(h) : bf2f(h); }
+template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { return ET ? brcnn_f2h(v) : f2bf(v); }
 
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
-template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2>
+template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0>
 __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
     constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
@@ -233,8 +238,12 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             for (int tm = 0; tm < MT; tm++)
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, bv[sl][t]), __builtin_bit_cast(bf16x8, av[sl][tm]), acc[tm][t], 0, 0, 0);
+                    if constexpr (ET)
+                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, bv[sl][t]), __builtin_bit_cast(f16x8, av[sl][tm]), acc[tm][t], 0, 0, 0);
+                    else
+                        acc[tm][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, bv[sl][t]), __builtin_bit_cast(bf16x8, av[sl][tm]), acc[tm][t], 0, 0, 0);
             if (spread) {
 #pragma unroll
                 for (int j = 0; j < PIECES; j++)
@@ -329,8 +338,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        v[2 * e] += __uint_as_float(rr[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                        v[2 * e] += e2f<ET>((unsigned short)(rr[e] & 0xffffu));
+                        v[2 * e + 1] += e2f<ET>((unsigned short)(rr[e] >> 16));
                     }
                 }
                 if (p.relu) {
@@ -343,10 +352,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
                     uint4 o;
-                    o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                    o.z = f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-                    o.w = f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    o.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
+                    o.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
+                    o.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
+                    o.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
                     *reinterpret_cast<uint4*>(yh + ro + co) = o;
                 }
             } else {       // ragged channel count (fused heads: 54, 21): element-wise tail
@@ -354,10 +363,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                 for (int e = 0; e < 8; e++) {
                     if (co + e >= p.Cout) break;
                     float t = v[e];
-                    if (RES) t += bf2f(res[(size_t)m * p.Cout + co + e]);
+                    if (RES) t += e2f<ET>(res[(size_t)m * p.Cout + co + e]);
                     if (p.relu) t = fmaxf(t, 0.f);
                     if (OUTF32) yf[ro + co + e] = t;
-                    else yh[ro + co + e] = f2bf(t);
+                    else yh[ro + co + e] = f2e<ET>(t);
                 }
             }
         }
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     }
 }
 
-template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2>
+template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2, int ET = 0>
 int launch(const ConvParams& p, hipStream_t s) {
     const size_t lds_stage = (size_t)(32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
     const size_t lds_full = ST * lds_stage;
@@ -376,26 +385,26 @@ int launch(const ConvParams& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         const size_t lds_max = lds_full > lds_epi ? lds_full : lds_epi;
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST>), dim3(p.tiles_m * p.tiles_n),
+    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET>), dim3(p.tiles_m * p.tiles_n),
                        dim3(64 * WM * WNW), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
-template <int MT, int NT, int WM = 2, int WNW = 2, int ST = 2>
+template <int MT, int NT, int WM = 2, int WNW = 2, int ST = 2, int ET = 0>
 int launch2(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
     p.tiles_n = (p.Cout + 32 * NT * WNW - 1) / (32 * NT * WNW);
     if constexpr (MT * NT > 4) {        // large register tiles: bf16 output, no residual operand (callers check)
-        return launch<MT, NT, false, false, WM, WNW, ST>(p, s);
+        return launch<MT, NT, false, false, WM, WNW, ST, ET>(p, s);
     } else {
         if (p.out_f32)
-            return p.residual ? launch<MT, NT, true, true, WM, WNW, ST>(p, s) : launch<MT, NT, false, true, WM, WNW, ST>(p, s);
-        return p.residual ? launch<MT, NT, true, false, WM, WNW, ST>(p, s) : launch<MT, NT, false, false, WM, WNW, ST>(p, s);
+            return p.residual ? launch<MT, NT, true, true, WM, WNW, ST, ET>(p, s) : launch<MT, NT, false, true, WM, WNW, ST, ET>(p, s);
+        return p.residual ? launch<MT, NT, true, false, WM, WNW, ST, ET>(p, s) : launch<MT, NT, false, false, WM, WNW, ST, ET>(p, s);
     }
 }
 
@@ -405,7 +414,24 @@ int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 wave
 }  // namespace
 
 namespace brcnn_conv {
+// fp16 operands: the production tile shapes only (the tuning-hook variants stay bf16)
+static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
+    p.il = 0;
+    if (p.gstep) return launch2<1, 1, 4, 2, 2, 1>(p, s);
+    const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
+    const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && t44 >= 512 &&
+                        (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
+    if (fill44 && p.Cout > 128) return launch2<2, 2, 4, 4, 2, 1>(p, s);
+    if (p.Cout <= 64) return launch2<2, 1, 2, 2, 2, 1>(p, s);
+    if (t22 < 256) return launch2<1, 1, 2, 2, 2, 1>(p, s);
+    if (p.M >= 65536) return launch2<1, 2, 4, 2, 2, 1>(p, s);
+    if (p.M >= 16384) return launch2<1, 1, 4, 2, 2, 1>(p, s);
+    return launch2<2, 1, 2, 2, 2, 1>(p, s);
+}
+
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
+    if (p.f16) return dispatch_conv_f16(p, s);
     p.il = g_bf16_il;
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
     int t = g_bf16_tile;

@@ -233,10 +233,10 @@ void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
 
 int brcnn_wgrad_bf16_grouped_dispatch(const void* x, const void* dy, void* dw_tiles, int batch, int height, int width,
                                       int cin, int cout, int kh, int kw, int stride, int pad, int window,
-                                      hipStream_t stream);    // conv_wgrad_bf16.hip
+                                      hipStream_t stream, int f16);    // conv_wgrad_bf16.hip
 int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch, int num_segments,
                               const int* heights_host, const int* widths_host, int cin, int cout,
-                              int kh, int kw, int stride, int pad, hipStream_t stream);   // conv_wgrad_bf16.hip
+                              int kh, int kw, int stride, int pad, hipStream_t stream, int f16);   // conv_wgrad_bf16.hip
 
 BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void* dw, int batch,
                                             int num_segments, const int* heights_host,
@@ -244,12 +244,12 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_multi(const void* x, const void* dy, void*
                                             int kw, int stride, int pad, int dtype, void* stream) {
     if (!x || !dy || !dw || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || pad < 0 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
-        !heights_host || !widths_host || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) || (cin & 3) ||
+        !heights_host || !widths_host || !brcnn_elem_ok(dtype) || (cin & 3) ||
         (cout & 3))
         return BRCNN_EINVAL;
-    if (dtype == BRCNN_DT_BF16)
+    if (dtype != BRCNN_DT_F32)
         return brcnn_wgrad_bf16_dispatch(x, dy, dw, batch, num_segments, heights_host, widths_host, cin, cout,
-                                         kh, kw, stride, pad, (hipStream_t)stream);
+                                         kh, kw, stride, pad, (hipStream_t)stream, dtype == BRCNN_DT_F16);
     WgradParams p = {};
     p.dy = (const float*)dy; p.x = (const float*)x; p.dw = (float*)dw;
     p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
@@ -299,12 +299,12 @@ BRCNN_API int brcnn_conv2d_wgrad_nhwc_grouped(const void* x, const void* dy, voi
                                               int height, int width, int cin, int cout, int kh, int kw,
                                               int stride, int pad, int window, int dtype, void* stream) {
     if (!x || !dy || !dw_tiles || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
-        pad < 0 || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) || window <= 0 || (window & 3) || (cout % 64) ||
+        pad < 0 || !brcnn_elem_ok(dtype) || window <= 0 || (window & 3) || (cout % 64) ||
         (cout / 64) * window != cin)
         return BRCNN_EINVAL;
-    if (dtype == BRCNN_DT_BF16)
+    if (dtype != BRCNN_DT_F32)
         return brcnn_wgrad_bf16_grouped_dispatch(x, dy, dw_tiles, batch, height, width, cin, cout, kh, kw, stride, pad,
-                                                 window, (hipStream_t)stream);
+                                                 window, (hipStream_t)stream, dtype == BRCNN_DT_F16);
     const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
     WgradParams p = {};

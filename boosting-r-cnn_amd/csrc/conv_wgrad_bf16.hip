@@ -18,6 +18,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
@@ -46,7 +47,7 @@ __device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned magic, unsigned
 // Output tile (64*WT) x (64*WT); 4 waves 2x2, each WT x WT MFMA tiles.  LDS per operand and
 // buffer: WT column blocks of [64 m][64 columns] bf16 (128-byte rows, physical 16-byte chunk
 // c' of row r holds logical chunk c' ^ ((r>>1)&7)).
-template <int WT>
+template <int WT, int ET = 0>      // ET: 0 = bf16 operands, 1 = IEEE fp16 (v_mfma_f32_32x32x16_f16)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     constexpr int BLK = TM * 64;                     // elements of one [64][64] block
@@ -245,8 +246,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
             for (int a = 0; a < WT; a++)
 #pragma unroll
                 for (int c = 0; c < WT; c++)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack(fy[sl][a][0], fy[sl][a][1]),
-                                                                        pack(fx[sl][c][0], fx[sl][c][1]), acc[a][c], 0, 0, 0);
+                    if constexpr (ET)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, pack(fy[sl][a][0], fy[sl][a][1])),
+                            __builtin_bit_cast(f16x8, pack(fx[sl][c][0], fx[sl][c][1])), acc[a][c], 0, 0, 0);
+                    else
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack(fy[sl][a][0], fy[sl][a][1]),
+                                                                            pack(fx[sl][c][0], fx[sl][c][1]), acc[a][c], 0, 0, 0);
             if (ks + 1 < TM / 16) frag_wait(sl ^ 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,7 +282,7 @@ void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
     *shift = l;
 }
 
-template <int WT>
+template <int WT, int ET = 0>
 int launch(WgradHParams& p, hipStream_t s) {
     const int T = 64 * WT;
     p.tiles_co = (p.Cout + T - 1) / T;
@@ -299,11 +305,11 @@ int launch(WgradHParams& p, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * WT * TM * 64 * sizeof(unsigned short);
     static bool attr_done = false;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<WT>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<WT, ET>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<WT>, dim3(tiles * p.slices), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WT, ET>), dim3(tiles * p.slices), dim3(256), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -315,7 +321,7 @@ int g_wgrad_bf16_tile = 0;      // tuning hook: 0 heuristic, 1 = 64x64, 2 = 128x
 // entry used by brcnn_conv2d_wgrad_nhwc_multi for dtype == BRCNN_DT_BF16
 int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch, int num_segments,
                               const int* heights_host, const int* widths_host, int cin, int cout,
-                              int kh, int kw, int stride, int pad, hipStream_t stream) {
+                              int kh, int kw, int stride, int pad, hipStream_t stream, int f16) {
     if ((cin & 7) || (cout & 7)) return BRCNN_EINVAL;
     WgradHParams p = {};
     p.dy = (const unsigned short*)dy; p.x = (const unsigned short*)x; p.dw = (float*)dw;
@@ -343,6 +349,7 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
     p.x_bytes = (unsigned)(x_off * 2);
     int wt = g_wgrad_bf16_tile;
     if (wt == 0) wt = (cout >= 128 && p.K >= 256) ? 2 : 1;
+    if (f16) return wt == 2 ? launch<2, 1>(p, stream) : launch<1, 1>(p, stream);
     return wt == 2 ? launch<2>(p, stream) : launch<1>(p, stream);
 }
 
@@ -357,7 +364,7 @@ BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
 // tile's input window; called by brcnn_conv2d_wgrad_nhwc_grouped for dtype == BRCNN_DT_BF16
 int brcnn_wgrad_bf16_grouped_dispatch(const void* x, const void* dy, void* dw_tiles, int batch, int height, int width,
                                       int cin, int cout, int kh, int kw, int stride, int pad, int window,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, int f16) {
     if ((window & 7) || (cout % 64) || (cout / 64) * window != cin) return BRCNN_EINVAL;
     const int Ho = (height + 2 * pad - kh) / stride + 1, Wo = (width + 2 * pad - kw) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return BRCNN_EINVAL;
@@ -376,5 +383,6 @@ int brcnn_wgrad_bf16_grouped_dispatch(const void* x, const void* dy, void* dw_ti
     p.K = kh * kw * window;
     p.dy_bytes = (unsigned)(m_total * cout * 2);
     p.x_bytes = (unsigned)(x_elems * 2);
+    if (f16) return launch<1, 1>(p, stream);
     return launch<1>(p, stream);          // 64 x 64 output tiles: the co tile is the group window
 }

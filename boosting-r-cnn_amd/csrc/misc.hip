@@ -8,7 +8,6 @@
 namespace {
 
 // element types of the NHWC activations: fp32 or bf16 (stored as unsigned short)
-typedef unsigned short bf16_t;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
@@ -27,6 +26,21 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     u.y = f2bf(v.z) | (f2bf(v.w) << 16);
     *reinterpret_cast<uint2*>(p) = u;
 }
+__device__ __forceinline__ float4 ld4(const f16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(brcnn_h2f((unsigned short)(u.x & 0xffffu)), brcnn_h2f((unsigned short)(u.x >> 16)),
+                       brcnn_h2f((unsigned short)(u.y & 0xffffu)), brcnn_h2f((unsigned short)(u.y >> 16)));
+}
+__device__ __forceinline__ void st4(f16_t* p, float4 v) {
+    uint2 u;
+    u.x = (unsigned)brcnn_f2h(v.x) | ((unsigned)brcnn_f2h(v.y) << 16);
+    u.y = (unsigned)brcnn_f2h(v.z) | ((unsigned)brcnn_f2h(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+// one element from fp32 (weight packing)
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)f2bf(v); }
+__device__ __forceinline__ void st1(f16_t* p, float v) { p->v = brcnn_f2h(v); }
 
 // one output pixel x 4 channels per thread (fp32: measured 6 % faster than the paired form below)
 __global__ __launch_bounds__(256) void maxpool3x3s2_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
@@ -76,6 +90,25 @@ __device__ __forceinline__ Vec8 ldv(const bf16_t* p) {
 #pragma unroll
     for (int e = 0; e < 4; e++) { r.v[2 * e] = __uint_as_float(w[e] << 16); r.v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
     return r;
+}
+__device__ __forceinline__ Vec8 ldv(const f16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    Vec8 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        r.v[2 * e] = brcnn_h2f((unsigned short)(w[e] & 0xffffu));
+        r.v[2 * e + 1] = brcnn_h2f((unsigned short)(w[e] >> 16));
+    }
+    return r;
+}
+__device__ __forceinline__ void stv(f16_t* p, const Vec8& m) {       // (max of fp16 values: exact, like bf16)
+    uint4 u;
+    u.x = (unsigned)brcnn_f2h(m.v[0]) | ((unsigned)brcnn_f2h(m.v[1]) << 16);
+    u.y = (unsigned)brcnn_f2h(m.v[2]) | ((unsigned)brcnn_f2h(m.v[3]) << 16);
+    u.z = (unsigned)brcnn_f2h(m.v[4]) | ((unsigned)brcnn_f2h(m.v[5]) << 16);
+    u.w = (unsigned)brcnn_f2h(m.v[6]) | ((unsigned)brcnn_f2h(m.v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void stv(float* p, const Vec8& m) { *reinterpret_cast<float4*>(p) = make_float4(m.v[0], m.v[1], m.v[2], m.v[3]); }
 __device__ __forceinline__ void stv(bf16_t* p, const Vec8& m) {
@@ -600,10 +633,8 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
         const int a = (int)(r % KH);
         const int co = (int)(r / KH);
         const float v = w[(((size_t)co * Cin + ci) * KH + a) * KW + b];
-        T o;
-        if (sizeof(T) == 2) o = (T)f2bf(v); else *reinterpret_cast<float*>(&o) = v;
-        if (fwd) fwd[idx] = o;
-        if (dgrad) dgrad[(((size_t)ci * KH + (KH - 1 - a)) * KW + (KW - 1 - b)) * Cout + co] = o;
+        if (fwd) st1(fwd + idx, v);
+        if (dgrad) st1(dgrad + (((size_t)ci * KH + (KH - 1 - a)) * KW + (KW - 1 - b)) * Cout + co, v);
     }
 }
 
@@ -628,7 +659,7 @@ BRCNN_API int brcnn_device_count(void) {
 BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int height, int width,
                                       int channels, int dtype, void* stream) {
     if (!x || !y || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int Ho = (height + 2 - 3) / 2 + 1, Wo = (width + 2 - 3) / 2 + 1;
     const int vec = dtype == BRCNN_DT_F32 ? 4 : 8;
@@ -639,9 +670,13 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int hei
         hipLaunchKernelGGL(maxpool3x3s2_f32_kernel, dim3(stream_grid((long long)batch * Ho * Wo * (channels >> 2))),
                            dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, batch, height, width,
                            channels, Ho, Wo);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
                            (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, batch, height, width,
+                           channels, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, (const f16_t*)x, (f16_t*)y, batch, height, width,
                            channels, Ho, Wo);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -650,7 +685,7 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int hei
 BRCNN_API int brcnn_maxpool3x3s2_nhwc_backward(const void* x, const void* y, const void* dy, void* dx, int batch,
                                                int height, int width, int channels, int dtype, void* stream) {
     if (!x || !y || !dy || !dx || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int Ho = (height + 2 - 3) / 2 + 1, Wo = (width + 2 - 3) / 2 + 1;
     const long long total = (long long)batch * height * width * (channels >> 2);
@@ -658,10 +693,34 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc_backward(const void* x, const void* y, con
         hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, (const float*)y, (const float*)dy, (float*)dx, batch, height, width, channels,
                            Ho, Wo);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, batch, height, width,
                            channels, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)x, (const f16_t*)y, (const f16_t*)dy, (f16_t*)dx, batch, height, width,
+                           channels, Ho, Wo);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int gn_forward_16(const void* x, const float* gamma, const float* beta, void* y, void* stats_ws, const GnSegs& sg,
+                         int batch, int num_segments, int channels, int groups, float eps, int relu, int chunks, int rpb,
+                         long long total, int nstat, hipStream_t s) {
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, batch * num_segments), dim3(256), 0, s, (const T*)x,
+                       (double*)stats_ws, sg, batch, channels, groups, rpb);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, (double*)stats_ws, sg, batch,
+                       channels, groups, eps);
+    BRCNN_LAUNCH_CHECK();
+    if (channels & 7)
+        hipLaunchKernelGGL((gn_apply_kernel<T, 1>), dim3(stream_grid(total)), dim3(256), 0, s, (const T*)x,
+                           (const double*)stats_ws, gamma, beta, (T*)y, sg, batch, channels, groups, relu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<T, 2>), dim3(stream_grid(total / 2)), dim3(256), 0, s, (const T*)x,
+                           (const double*)stats_ws, gamma, beta, (T*)y, sg, batch, channels, groups, relu);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -672,7 +731,7 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
                                          int relu, int dtype, void* stream) {
     if (!x || !y || !gamma || !beta || !stats_ws || batch <= 0 || num_segments <= 0 ||
         num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || channels > 256 || groups <= 0 ||
-        channels % groups || (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        channels % groups || (channels & 3) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     GnSegs sg = {};
     sg.nseg = num_segments;
@@ -700,29 +759,20 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
                            (const float*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
         BRCNN_LAUNCH_CHECK();
-        BRCNN_LAUNCH_CHECK();
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s,
                            (double*)stats_ws, sg, batch, channels, groups, eps);
         BRCNN_LAUNCH_CHECK();
         hipLaunchKernelGGL((gn_apply_kernel<float, 1>), dim3(stream_grid(total)), dim3(256), 0, s,
                            (const float*)x, (const double*)stats_ws, gamma, beta, (float*)y, sg, batch,
                            channels, groups, relu);
+    } else if (dtype == BRCNN_DT_BF16) {
+        if (int st = gn_forward_16<bf16_t>(x, gamma, beta, y, stats_ws, sg, batch, num_segments, channels, groups, eps,
+                                           relu, chunks, rpb, total, nstat, s))
+            return st;
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
-                           (const bf16_t*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
-        BRCNN_LAUNCH_CHECK();
-        BRCNN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s,
-                           (double*)stats_ws, sg, batch, channels, groups, eps);
-        BRCNN_LAUNCH_CHECK();
-        if (channels & 7)
-            hipLaunchKernelGGL((gn_apply_kernel<bf16_t, 1>), dim3(stream_grid(total)), dim3(256), 0, s,
-                               (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y, sg,
-                               batch, channels, groups, relu);
-        else
-            hipLaunchKernelGGL((gn_apply_kernel<bf16_t, 2>), dim3(stream_grid(total / 2)), dim3(256), 0,
-                               s, (const bf16_t*)x, (const double*)stats_ws, gamma, beta, (bf16_t*)y,
-                               sg, batch, channels, groups, relu);
+        if (int st = gn_forward_16<f16_t>(x, gamma, beta, y, stats_ws, sg, batch, num_segments, channels, groups, eps,
+                                          relu, chunks, rpb, total, nstat, s))
+            return st;
     }
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -771,7 +821,7 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
                                                   int relu, int dtype, void* stream) {
     if (!dy || !x || !stats || !gamma || !beta || !dx || !dgamma || !dbeta || !workspace || batch <= 0 ||
         num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || channels > 256 ||
-        groups <= 0 || channels % groups || (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        groups <= 0 || channels % groups || (channels & 3) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     if (workspace_bytes < brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(batch, num_segments, hw_host, channels, groups))
         return BRCNN_EINVAL;
@@ -793,9 +843,13 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
                            (const float*)x, (const float*)dy, (const double*)stats, gamma, beta, gsum, part, sg, batch,
                            channels, groups, rpb, relu);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
                            (const bf16_t*)x, (const bf16_t*)dy, (const double*)stats, gamma, beta, gsum, part, sg,
+                           batch, channels, groups, rpb, relu);
+    else
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<f16_t>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+                           (const f16_t*)x, (const f16_t*)dy, (const double*)stats, gamma, beta, gsum, part, sg,
                            batch, channels, groups, rpb, relu);
     BRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * channels + 31) / 32), dim3(1024), 0, s, part, dgamma, dbeta,
@@ -805,9 +859,13 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
                            (const float*)dy, (const double*)stats, gsum, gamma, beta, (float*)dx, sg, batch, channels,
                            groups, relu);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x,
                            (const bf16_t*)dy, (const double*)stats, gsum, gamma, beta, (bf16_t*)dx, sg, batch, channels,
+                           groups, relu);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0, s, (const f16_t*)x,
+                           (const f16_t*)dy, (const double*)stats, gsum, gamma, beta, (f16_t*)dx, sg, batch, channels,
                            groups, relu);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -834,16 +892,20 @@ BRCNN_API int brcnn_upsample_nearest_add_nhwc(void* dst, const void* src, int ba
                                               int hs, int ws, int channels, int dtype,
                                               void* stream) {
     if (!dst || !src || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 ||
-        (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        (channels & 3) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const long long total = (long long)batch * hd * wd * (channels >> 2);
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(stream_grid(total)), dim3(256), 0,
                            (hipStream_t)stream, (float*)dst, (const float*)src, batch, hd, wd, hs, ws,
                            channels);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(upsample_add_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
                            (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, batch, hd, wd, hs, ws,
+                           channels);
+    else
+        hipLaunchKernelGGL(upsample_add_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, (f16_t*)dst, (const f16_t*)src, batch, hd, wd, hs, ws,
                            channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -852,15 +914,18 @@ BRCNN_API int brcnn_upsample_nearest_add_nhwc(void* dst, const void* src, int ba
 BRCNN_API int brcnn_upsample_nearest_add_nhwc_out(const void* dst, const void* src, void* out, int batch, int hd,
                                                   int wd, int hs, int ws, int channels, int dtype, void* stream) {
     if (!dst || !src || !out || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 ||
-        (channels & 3) || (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        (channels & 3) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const long long total = (long long)batch * hd * wd * (channels >> 2);
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(upsample_add_out_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dst, (const float*)src, (float*)out, batch, hd, wd, hs, ws, channels);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(upsample_add_out_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)dst, (const bf16_t*)src, (bf16_t*)out, batch, hd, wd, hs, ws, channels);
+    else
+        hipLaunchKernelGGL(upsample_add_out_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)dst, (const f16_t*)src, (f16_t*)out, batch, hd, wd, hs, ws, channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -868,15 +933,18 @@ BRCNN_API int brcnn_upsample_nearest_add_nhwc_out(const void* dst, const void* s
 BRCNN_API int brcnn_upsample_nearest_add_nhwc_backward(const void* dout, void* dsrc, int batch, int hd, int wd, int hs,
                                                        int ws, int channels, int dtype, void* stream) {
     if (!dout || !dsrc || batch <= 0 || hd <= 0 || wd <= 0 || hs <= 0 || ws <= 0 || channels <= 0 || (channels & 3) ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const long long total = (long long)batch * hs * ws * (channels >> 2);
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(upsample_add_bwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dout, (float*)dsrc, batch, hd, wd, hs, ws, channels);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(upsample_add_bwd_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)dout, (bf16_t*)dsrc, batch, hd, wd, hs, ws, channels);
+    else
+        hipLaunchKernelGGL(upsample_add_bwd_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)dout, (f16_t*)dsrc, batch, hd, wd, hs, ws, channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -891,7 +959,7 @@ BRCNN_API size_t brcnn_colsum_workspace_bytes(int64_t rows, int channels) {
 BRCNN_API int brcnn_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t rows,
                            int channels, int dtype, void* stream) {
     if (!x || !out || !workspace || rows < 0 || channels <= 0 || (channels & 3) ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int c4n = channels >> 2;
     if (c4n < 256 && (c4n & (c4n - 1))) return BRCNN_EINVAL;      // channel-vector count: a power of two or >= 256
@@ -910,8 +978,11 @@ BRCNN_API int brcnn_colsum(const void* x, float* out, void* workspace, size_t wo
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)workspace,
                            (long long)rows, channels, rpb);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (float*)workspace,
+                           (long long)rows, channels, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, (float*)workspace,
                            (long long)rows, channels, rpb);
     BRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, s, (const float*)workspace, out,
@@ -945,15 +1016,18 @@ BRCNN_API int brcnn_nhwc_to_nchw(const void* src, float* dst, int batch, int cha
 BRCNN_API int brcnn_pack_conv_weights(const float* weight, void* fwd, void* dgrad, int cout, int cin, int kh,
                                       int kw, int dtype, void* stream) {
     if (!weight || (!fwd && !dgrad) || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 ||
-        (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16))
+        !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const long long total = (long long)cout * cin * kh * kw;
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(pack_conv_weights_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                            weight, (float*)fwd, (float*)dgrad, cout, cin, kh, kw);
-    else
+    else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(pack_conv_weights_kernel<bf16_t>, dim3(stream_grid(total)), dim3(256), 0,
                            (hipStream_t)stream, weight, (bf16_t*)fwd, (bf16_t*)dgrad, cout, cin, kh, kw);
+    else
+        hipLaunchKernelGGL(pack_conv_weights_kernel<f16_t>, dim3(stream_grid(total)), dim3(256), 0,
+                           (hipStream_t)stream, weight, (f16_t*)fwd, (f16_t*)dgrad, cout, cin, kh, kw);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -17,7 +17,6 @@
 namespace {
 
 // NHWC element types: fp32 or bf16 (as unsigned short), 4 channels per lane
-typedef unsigned short bf16_t;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
@@ -34,6 +33,18 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
     u.x = f2bf(v.x) | (f2bf(v.y) << 16);
     u.y = f2bf(v.z) | (f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ __forceinline__ float4 ld4(const f16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(brcnn_h2f((unsigned short)(u.x & 0xffffu)), brcnn_h2f((unsigned short)(u.x >> 16)),
+                       brcnn_h2f((unsigned short)(u.y & 0xffffu)), brcnn_h2f((unsigned short)(u.y >> 16)));
+}
+__device__ __forceinline__ void st4(f16_t* p, float4 v) {
+    uint2 u;
+    u.x = (unsigned)brcnn_f2h(v.x) | ((unsigned)brcnn_f2h(v.y) << 16);
+    u.y = (unsigned)brcnn_f2h(v.z) | ((unsigned)brcnn_f2h(v.w) << 16);
     *reinterpret_cast<uint2*>(p) = u;
 }
 
@@ -573,7 +584,7 @@ BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int
                                         int32_t* levels_out, int batch, int channels, int n_rois,
                                         int pooled_h, int pooled_w, int sampling_ratio,
                                         float finest_scale, int dtype, void* stream) {
-    if (dtype != BRCNN_DT_F32 && dtype != BRCNN_DT_BF16) return BRCNN_EINVAL;
+    if (!brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
     if (!feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
         return BRCNN_EINVAL;
     LevelTable lv = {};
@@ -593,6 +604,15 @@ BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int
         else
             hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, bf16_t>), grid_rows, dim3(256), 0, s,
                                (const bf16_t*)nullptr, lv, rois, (bf16_t*)output, levels_out, channels, 0, 0, n_rois,
+                               pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+    } else if (dtype == BRCNN_DT_F16) {
+        if (g_roi_exact)
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, f16_t>), grid, dim3(256), 0, s, (const f16_t*)nullptr,
+                               lv, rois, (f16_t*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
+                               sampling_ratio, 1);
+        else
+            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, f16_t>), grid_rows, dim3(256), 0, s,
+                               (const f16_t*)nullptr, lv, rois, (f16_t*)output, levels_out, channels, 0, 0, n_rois,
                                pooled_h, pooled_w, 0.f, sampling_ratio, 1);
     } else {
         if (g_roi_exact)

@@ -173,8 +173,9 @@ class TwoStageDetector(BaseDetector):
         self._rpn_scale_cache = None    # host copy of rpn_head.scales (freeze_for_inference)
 
     def set_compute_dtype(self, dtype):
-        """'f32' (default: exact-fp32 MFMA, the parity path) or 'bf16' (bf16 MFMA conv stack with
-        fp32 accumulation; heads, proposal stage and NMS stay fp32).  Inference only."""
+        """'f32' (default: exact-fp32 MFMA, the parity path), 'bf16' or 'f16' (16-bit MFMA conv stack with
+        fp32 accumulation; head outputs, proposal stage, losses and NMS stay fp32).  Training in 'f16' wants
+        loss scaling (apis.train_detector wires the recipes' `fp16 = dict(loss_scale=512.)`)."""
         from . import blocks
         blocks.set_compute_dtype(dtype)
         return self

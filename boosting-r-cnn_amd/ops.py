@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 from . import lib as _L
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
-DT_F32, DT_BF16, DT_BF16_OUT_F32 = 0, 1, 2
+DT_F32, DT_BF16, DT_BF16_OUT_F32, DT_F16, DT_F16_OUT_F32 = 0, 1, 2, 3, 4
 
 
 def _dt(t):
@@ -28,7 +28,14 @@ def _dt(t):
         return DT_F32
     if t.dtype == torch.bfloat16:
         return DT_BF16
-    raise _L.BrcnnHipError(f'unsupported activation dtype {t.dtype} (fp32 or bf16)')
+    if t.dtype == torch.float16:
+        return DT_F16
+    raise _L.BrcnnHipError(f'unsupported activation dtype {t.dtype} (fp32, bf16 or fp16)')
+
+
+def _out_f32(dt):
+    """the code that makes a 16-bit conv write an fp32 result"""
+    return {DT_BF16: DT_BF16_OUT_F32, DT_F16: DT_F16_OUT_F32}[dt]
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -512,9 +519,9 @@ def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=
     cout, kh, kw, cin2 = w.shape
     assert cin == cin2, f'conv2d_nhwc: Cin mismatch {cin} vs {cin2}'
     ho, wo = conv_out_size(h, wd, kh, kw, stride, pad)
-    if dt == DT_BF16 and out_f32:
-        dt = DT_BF16_OUT_F32
-    y = torch.empty((n, ho, wo, cout), dtype=torch.float32 if dt != DT_BF16 else torch.bfloat16,
+    if dt != DT_F32 and out_f32:
+        dt = _out_f32(dt)
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype if dt in (DT_BF16, DT_F16) else torch.float32,
                     device=x.device)
     if residual is not None:
         assert residual.shape == y.shape and residual.is_contiguous() and residual.dtype == x.dtype
@@ -550,7 +557,7 @@ def conv2d_nhwc_grouped(x, w_tiles, window, scale=None, shift=None, residual=Non
     cout, kh, kw, win = w_tiles.shape
     assert win == window
     dt = _dt(x)
-    if dt == DT_BF16 and window % 64:
+    if dt != DT_F32 and window % 64:
         raise _L.BrcnnHipError(f'bf16 grouped conv needs a window that is a multiple of 64 channels (got {window})')
     ho, wo = conv_out_size(h, wd, kh, kw, stride, pad)
     y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
@@ -577,9 +584,9 @@ def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=N
     rows = sum(batch * h * ww for h, ww in out_sizes)
     dt = _dt(x_cat)
     assert w.dtype == x_cat.dtype
-    if dt == DT_BF16 and out_f32:
-        dt = DT_BF16_OUT_F32
-    y = torch.empty((rows, cout), dtype=torch.float32 if dt != DT_BF16 else torch.bfloat16,
+    if dt != DT_F32 and out_f32:
+        dt = _out_f32(dt)
+    y = torch.empty((rows, cout), dtype=x_cat.dtype if dt in (DT_BF16, DT_F16) else torch.float32,
                     device=x_cat.device)
     if residual is not None:
         assert residual.shape == y.shape and residual.is_contiguous()

@@ -201,8 +201,8 @@ class ProbConvFCBBoxHead(nn.Module):
         from .autograd import linear_autograd, wants_grad
         if wants_grad(x, self.fc_cls.weight, self.shared_fcs[0].weight):
             from .blocks import compute_dtype
-            if compute_dtype() == torch.bfloat16:
-                x = x.to(torch.bfloat16)      # bf16 mode: the FC GEMMs (fwd / dgrad / wgrad) on bf16 MFMA
+            if compute_dtype() != torch.float32:
+                x = x.to(compute_dtype())     # 16-bit modes: the FC GEMMs (fwd / dgrad / wgrad) on bf16 / fp16 MFMA
             for i, fc in enumerate(self.shared_fcs):
                 w = fc.weight
                 if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable view

@@ -33,6 +33,9 @@ extern "C" {
 #define BRCNN_DT_F32 0
 #define BRCNN_DT_BF16 1          /* bf16 operands, fp32 accumulate, bf16 result */
 #define BRCNN_DT_BF16_OUT_F32 2  /* bf16 operands, fp32 accumulate, fp32 result  */
+#define BRCNN_DT_F16 3           /* IEEE fp16 operands, fp32 accumulate, fp16 result (the recipes' `fp16 =
+                                    dict(loss_scale=512.)`, mmdet/apis/train.py:115-119) */
+#define BRCNN_DT_F16_OUT_F32 4   /* fp16 operands, fp32 accumulate, fp32 result  */
 
 #define BRCNN_MAX_LEVELS 8
 #define BRCNN_MAX_IMAGES 64      /* images per call of the whole-batch train-step entries */

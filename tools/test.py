@@ -33,7 +33,7 @@ def parse_args(argv=None):
                    help='kwargs of dataset.evaluate() / format_results(), key=value')
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
     p.add_argument('--dist-backend', default=None)
-    p.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='arithmetic type of the conv stack')
+    p.add_argument('--dtype', choices=['f32', 'bf16', 'f16'], default='f32', help='arithmetic type of the conv stack')
     p.add_argument('--device-preprocess', action='store_true')
     p.add_argument('--local_rank', type=int, default=0)
     args = p.parse_args(argv)
