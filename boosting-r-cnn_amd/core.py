@@ -334,6 +334,10 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
         assert rows == cols
     if rows * cols == 0:
         return bboxes1.new(batch_shape + ((rows,) if is_aligned else (rows, cols)))
+    if bboxes1.is_cuda and bboxes1.dim() == 2 and bboxes1.dtype == torch.float32 and \
+            not (torch.is_grad_enabled() and (bboxes1.requires_grad or bboxes2.requires_grad)):
+        from .train_ops import bbox_overlaps as _dev       # values only: the HIP table kernel
+        return _dev(bboxes1, bboxes2, mode, is_aligned, eps)
     area1 = (bboxes1[..., 2] - bboxes1[..., 0]) * (bboxes1[..., 3] - bboxes1[..., 1])
     area2 = (bboxes2[..., 2] - bboxes2[..., 0]) * (bboxes2[..., 3] - bboxes2[..., 1])
     if is_aligned:
@@ -411,6 +415,10 @@ class MaxIoUAssigner:
         self.iou_calculator = build_iou_calculator(iou_calculator)
 
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        if bboxes.is_cuda and bboxes.dim() == 2 and bboxes.shape[0] > 0 and self.gt_max_assign_all and \
+                type(self.iou_calculator) is BboxOverlaps2D and \
+                not (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0):
+            return self._assign_device(bboxes, gt_bboxes, gt_labels)
         overlaps = self.iou_calculator(gt_bboxes, bboxes)
         if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None
                 and gt_bboxes_ignore.numel() > 0 and bboxes.numel() > 0):
@@ -420,6 +428,24 @@ class MaxIoUAssigner:
                 ignore_max, _ = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)
             overlaps[:, ignore_max > self.ignore_iof_thr] = -1
         return self.assign_wrt_overlaps(overlaps, gt_labels)
+
+    def _assign_device(self, bboxes, gt_bboxes, gt_labels):
+        """the same assignment for one image on the device kernel (`brcnn_assign_max_iou`, the IoU matrix is
+        never materialised); the whole-batch train step calls the kernel once for all images instead"""
+        from . import train_ops
+        gts = gt_bboxes.reshape(-1, gt_bboxes.shape[-1])[:, :4].float().contiguous()
+        n_gt = gts.shape[0]
+        gi, mo = train_ops.assign_max_iou(bboxes.float().contiguous(), gts, [0, n_gt], self.pos_iou_thr,
+                                          self.neg_iou_thr, self.min_pos_iou, self.match_low_quality, batch=1,
+                                          want_overlaps=True)
+        gt_inds = gi[0].long()
+        labels = None
+        if gt_labels is not None:
+            if n_gt == 0:
+                labels = gt_inds.new_full(gt_inds.shape, -1)
+            else:
+                labels = torch.where(gt_inds > 0, gt_labels[(gt_inds - 1).clamp(min=0)], gt_inds.new_full((), -1))
+        return AssignResult(n_gt, gt_inds, mo[0], labels=labels)
 
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):
         num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)

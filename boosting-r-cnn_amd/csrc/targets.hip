@@ -360,6 +360,37 @@ __global__ __launch_bounds__(1024) void rcnn_sample_kernel(const SampleParams p)
     }
 }
 
+// bbox_overlaps (iou2d_calculator.py:75-261) as a table: out[i, j] (or out[i] when aligned) for modes
+// 0 iou / 1 iof / 2 giou, the reference's operation order
+__global__ __launch_bounds__(256) void bbox_overlaps_kernel(const float* __restrict__ b1, int s1, int n1,
+                                                           const float* __restrict__ b2, int s2, int n2, int mode,
+                                                           int aligned, float eps, float* __restrict__ out) {
+    const long long total = aligned ? n1 : (long long)n1 * n2;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int i = aligned ? (int)idx : (int)(idx / n2), j = aligned ? (int)idx : (int)(idx - (long long)i * n2);
+        const float* p = b1 + (size_t)i * s1;
+        const float* q = b2 + (size_t)j * s2;
+        const float4 a = make_float4(p[0], p[1], p[2], p[3]), b = make_float4(q[0], q[1], q[2], q[3]);
+        const float a1 = (a.z - a.x) * (a.w - a.y), a2 = (b.z - b.x) * (b.w - b.y);
+        float w = fminf(a.z, b.z) - fmaxf(a.x, b.x), h = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+        w = w < 0.f ? 0.f : w;
+        h = h < 0.f ? 0.f : h;
+        const float ov = w * h;
+        float un = mode == 1 ? a1 : a1 + a2 - ov;
+        un = fmaxf(un, eps);
+        float r = ov / un;
+        if (mode == 2) {
+            float ew = fmaxf(a.z, b.z) - fminf(a.x, b.x), eh = fmaxf(a.w, b.w) - fminf(a.y, b.y);
+            ew = ew < 0.f ? 0.f : ew;
+            eh = eh < 0.f ? 0.f : eh;
+            const float ea = fmaxf(ew * eh, eps);
+            r = r - (ea - un) / ea;
+        }
+        out[idx] = r;
+    }
+}
+
 int fill_gt_table(GtTable& t, const int* gt_offsets_host, int batch) {
     if (!gt_offsets_host || batch <= 0 || batch > BRCNN_MAX_IMAGES) return BRCNN_EINVAL;
     for (int b = 0; b <= batch; b++) {
@@ -370,6 +401,21 @@ int fill_gt_table(GtTable& t, const int* gt_offsets_host, int batch) {
 }
 
 }  // namespace
+
+BRCNN_API int brcnn_bbox_overlaps(const float* bboxes1, int stride1, int n1, const float* bboxes2, int stride2, int n2,
+                                  int mode, int is_aligned, float eps, float* out, void* stream) {
+    if (n1 < 0 || n2 < 0 || mode < 0 || mode > 2 || stride1 < 4 || stride2 < 4 || (is_aligned && n1 != n2))
+        return BRCNN_EINVAL;
+    const long long total = is_aligned ? n1 : (long long)n1 * n2;
+    if (total == 0) return 0;
+    if (!bboxes1 || !bboxes2 || !out) return BRCNN_EINVAL;
+    long long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(bbox_overlaps_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, bboxes1, stride1, n1,
+                       bboxes2, stride2, n2, mode, is_aligned ? 1 : 0, eps, out);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
 
 BRCNN_API int brcnn_assign_max_iou(const float* boxes, int64_t box_batch_stride, int box_row_stride,
                                    const int32_t* num_boxes, int n, int batch, const float* gts,

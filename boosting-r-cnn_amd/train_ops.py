@@ -46,6 +46,19 @@ def flatten_gts(gt_bboxes, gt_labels=None):
     return gts, labels, offs
 
 
+def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
+    """bbox_overlaps of two (n, 4|5) device box lists on the HIP kernel (values only, no autograd)"""
+    _require_gpu(bboxes1, bboxes2)
+    b1, b2 = bboxes1.detach().float().contiguous(), bboxes2.detach().float().contiguous()
+    n1, n2 = b1.shape[0], b2.shape[0]
+    out = torch.empty((n1,) if is_aligned else (n1, n2), dtype=torch.float32, device=b1.device)
+    st = _L.load().brcnn_bbox_overlaps(_ptr(b1), b1.shape[1] if n1 else 4, n1, _ptr(b2), b2.shape[1] if n2 else 4, n2,
+                                       {'iou': 0, 'iof': 1, 'giou': 2}[mode], int(bool(is_aligned)), float(eps), _ptr(out),
+                                       _stream())
+    _L.check(st, 'brcnn_bbox_overlaps')
+    return out
+
+
 def _neg_range(neg_iou_thr):
     if isinstance(neg_iou_thr, (tuple, list)):
         assert len(neg_iou_thr) == 2

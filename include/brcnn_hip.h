@@ -536,6 +536,11 @@ int brcnn_preprocess_u8(const uint8_t *src, int src_h, int src_w, float *dst, in
  *   cfg6_host = [gamma, alpha, iou_gamma, loss_cls weight, loss_bbox weight, reg_norm == 'mean'].
  *   out3 = [loss_cls, loss_bbox, acc]; backward: dcls (n, C+1), dbbox (n, 4C | 4).
  * -------------------------------------------------------------------------- */
+/* bbox_overlaps (mmdet/core/bbox/iou_calculators/iou2d_calculator.py:75-261): mode 0 'iou', 1 'iof',
+ * 2 'giou'; out (n1, n2), or (n1) when is_aligned (n1 == n2).  stride = floats per box row (4, or 5 with a
+ * score column, which BboxOverlaps2D.__call__ strips, :30-66).  union / enclosing area clamped at eps. */
+int brcnn_bbox_overlaps(const float *bboxes1, int stride1, int n1, const float *bboxes2, int stride2, int n2,
+                        int mode, int is_aligned, float eps, float *out, void *stream);
 int brcnn_assign_max_iou(const float *boxes, int64_t box_batch_stride, int box_row_stride,
                          const int32_t *num_boxes, int n, int batch, const float *gts,
                          const int *gt_offsets_host, int num_levels, const int *level_start_host,

@@ -347,6 +347,63 @@ def kat():
              legacy=[[1.75, 2.25], [2.75, 3.25]]),
         dict(input=[[1, 2, 5, 6], [3, 4, 7, 8], [9, 10, 13, 14], [11, 12, 15, 16]], roi=[0, 0, 0, 3, 3],
              aligned=[[1.9375, 4.75], [7.5625, 10.375]], legacy=[[3.625, 6.875], [10.125, 13.375]])]
+    # ---- edge vectors: exact-threshold IoU, duplicate boxes, score ties, degenerate
+    # boxes.  All coordinates / areas / IoUs are exactly representable, so float64 brute force is THE answer.
+    # mmcv semantics restated: NMS suppresses on `iou > thr` (strict), soft-NMS decays on `iou >= thr`;
+    # 0/0 of two zero-area boxes is NaN and compares false (nothing suppressed).  Score ties: mmcv's sort is
+    # unstable -- the order below is this repository's tie rule (descending score, ascending index).
+    def nms_bf(bx, sc, thr):
+        bx, sc = np.array(bx, np.float64), np.array(sc, np.float64)
+        order = sorted(range(len(sc)), key=lambda i: (-sc[i], i))
+        keep = []
+        for i in order:
+            ok = True
+            for j in keep:
+                w = max(0., min(bx[i][2], bx[j][2]) - max(bx[i][0], bx[j][0]))
+                h = max(0., min(bx[i][3], bx[j][3]) - max(bx[i][1], bx[j][1]))
+                inter = w * h
+                un = (bx[i][2] - bx[i][0]) * (bx[i][3] - bx[i][1]) + (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]) - inter
+                if un != 0 and inter / un > thr:
+                    ok = False
+            if ok:
+                keep.append(i)
+        return keep
+    half = [[0, 0, 3, 1], [1, 0, 4, 1], [10, 10, 13, 11]]             # IoU(0,1) = 2 / 4 = 0.5 exactly
+    quarter = [[0, 0, 4, 4], [2, 2, 6, 6], [0, 8, 4, 12]]             # IoU(0,1) = 4 / 28 = 1/7; (0,2) disjoint
+    edges = [
+        dict(name='iou == thr is kept (strict >)', boxes=half, scores=[0.9, 0.8, 0.7], thr=0.5),
+        dict(name='just below thr suppresses', boxes=half, scores=[0.9, 0.8, 0.7], thr=0.49),
+        dict(name='duplicate boxes', boxes=[[5, 5, 25, 45], [5, 5, 25, 45], [5, 5, 25, 45], [100, 100, 120, 130]],
+             scores=[0.3, 0.9, 0.5, 0.9], thr=0.7),
+        dict(name='score ties, disjoint', boxes=[[0, 0, 10, 10], [20, 0, 30, 10], [40, 0, 50, 10], [60, 0, 70, 10]],
+             scores=[0.5, 0.5, 0.5, 0.5], thr=0.3),
+        dict(name='score ties, overlapping: lower index wins', boxes=[[0, 0, 10, 10], [1, 0, 11, 10], [2, 0, 12, 10]],
+             scores=[0.75, 0.75, 0.75], thr=0.5),
+        dict(name='zero-area boxes never suppress', boxes=[[5, 5, 5, 5], [5, 5, 5, 5], [0, 0, 10, 10]],
+             scores=[0.9, 0.8, 0.7], thr=0.3),
+        dict(name='one seventh', boxes=quarter, scores=[0.2, 0.6, 0.4], thr=0.125),
+    ]
+    for e in edges:
+        e['keep'] = nms_bf(e['boxes'], e['scores'], e['thr'])
+    d['nms_edges'] = edges
+    # soft-NMS at the exact threshold: linear decay applies at iou >= thr -> 0.8 * (1 - 0.5)
+    d['soft_edges'] = [dict(boxes=half, scores=[0.9, 0.8, 0.7], thr=0.5, method='linear', inds=[0, 2, 1],
+                            scores_out=[0.9, 0.7, 0.4]),
+                       dict(boxes=half, scores=[0.9, 0.8, 0.7], thr=0.5, method='naive', inds=[0, 2], scores_out=[0.9, 0.7])]
+    # ---- hand-derived cv2.resize(INTER_LINEAR, uint8) vectors.  cv2 is not in this image, so
+    # these are NOT outputs of OpenCV: they follow its published rule -- source coordinate (d + 0.5) * scale - 0.5,
+    # clamped to the image, bilinear blend, round half up -- on cases small enough to check on paper
+    # (weights 0.25 / 0.75 / 0.5 are exact in the 11-bit fixed point cv2 uses).  "parity unpinned against cv2".
+    d['resize_hand'] = [
+        dict(src=[[0, 255]], size_wh=[4, 1], out=[[0, 64, 191, 255]],
+             derivation='x = -0.25 (clamped: 0), 0.25 -> 63.75 -> 64, 0.75 -> 191.25 -> 191, 1.25 (clamped: 255)'),
+        dict(src=[[0, 100], [200, 255]], size_wh=[4, 4],
+             out=[[0, 25, 75, 100], [50, 72, 117, 139], [150, 167, 200, 216], [200, 214, 241, 255]],
+             derivation='separable weights (1, .75/.25, .25/.75, 1): e.g. centre (1,1) = .5625*0 + .1875*100 + .1875*200 + '
+                        '.0625*255 = 72.19 -> 72; (1,2) = .1875*0 + .5625*100 + .0625*200 + .1875*255 = 116.56 -> 117'),
+        dict(src=[[0, 16, 32, 48], [64, 80, 96, 112], [128, 144, 160, 176], [192, 208, 224, 240]], size_wh=[2, 2],
+             out=[[40, 72], [168, 200]], derivation='scale 2: source coordinate 0.5 / 2.5 -> mean of each 2x2 block'),
+    ]
     with open(os.path.join(HERE, 'kat_mmcv_ops.json'), 'w') as f:
         json.dump(d, f, indent=1)
     print('kat_mmcv_ops.json', d['nms_keep'], d['soft_linear_inds'], d['soft_linear_scores'])
@@ -809,6 +866,9 @@ def g20_fullsize(cfg):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'kat':
+        kat()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'coco':
         g19_coco_pafpn_train()
         return

@@ -309,3 +309,21 @@ def test_autoaugment_random_crop_match_reference_golden():
         assert [float(v) for v in m['scale_factor']] == meta['scale_factor']
         seen.add(len(out['gt_labels'].data))
     assert len(seen) > 1       # some draws took the crop policy and lost boxes
+
+
+def test_resize_hand_derived_vectors():
+    """cv2.resize(INTER_LINEAR, uint8) cases small enough to check on paper (tests/golden/kat_mmcv_ops.json,
+    `resize_hand`; hand-derived from OpenCV's published rule, NOT cv2 outputs: cv2 is not in the image, so the
+    resize restatement stays "unpinned against cv2" beyond these) through the host restatement and the C oracle"""
+    import json
+    import os
+    from oracle import orc
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_mmcv_ops.json')))
+    assert len(kat['resize_hand']) >= 3
+    for case in kat['resize_hand']:
+        src = np.array(case['src'], dtype=np.uint8)[:, :, None].repeat(3, 2)
+        w, h = case['size_wh']
+        out = P.imresize_u8(src, (w, h))
+        assert out.shape == (h, w, 3) and np.array_equal(out[:, :, 0], np.array(case['out'])), case['derivation']
+        ref = orc.preprocess_u8(src, w, h, h, w, None, [0., 0., 0.], [1., 1., 1.], False)
+        assert np.array_equal(ref.numpy()[0], np.array(case['out'], dtype=np.float32))

@@ -52,6 +52,23 @@ def test_oracle_known_answers():
                               torch.tensor(case['legacy']))
 
 
+def test_oracle_nms_edge_vectors():
+    """exact-threshold IoU (strict `>` for NMS, `>=` for the soft-NMS decay), duplicate boxes, score ties
+    (this repository's rule: descending score, ascending index), zero-area boxes -- float64 brute force on
+    exactly representable numbers (tests/golden/make_golden.py::kat)"""
+    kat = json.load(open(os.path.join(G, 'kat_mmcv_ops.json')))
+    assert len(kat['nms_edges']) >= 7
+    for e in kat['nms_edges']:
+        _, inds = orc.nms(torch.tensor(e['boxes'], dtype=torch.float32), torch.tensor(e['scores']), e['thr'])
+        assert inds.tolist() == e['keep'], e['name']
+    half = kat['nms_edges'][0]
+    assert half['keep'] == [0, 1, 2] and kat['nms_edges'][1]['keep'] == [0, 2]
+    for e in kat['soft_edges']:
+        dets, inds = orc.soft_nms(torch.tensor(e['boxes'], dtype=torch.float32), torch.tensor(e['scores']), e['thr'], 0.5,
+                                  1e-3, e['method'])
+        assert inds.tolist() == e['inds'] and np.allclose(dets[:, 4].numpy(), e['scores_out'], atol=1e-7), e
+
+
 def test_oracle_roi_align_vs_float64_bruteforce():
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 5, 13, 21, generator=g)

@@ -2,6 +2,8 @@
 the CPU oracle (oracle/orc.py) on identical seeded inputs.  Bars: bit-exact for indices and
 for RoIAlign values (same fp32 operation order, no FMA contraction); 1e-5/1e-6 where a
 transcendental (expf/logf/powf) differs between device and host libm."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -655,6 +657,21 @@ def test_maxpool_backward_matches_torch(dtype):
         ref = x2.grad.permute(0, 2, 3, 1)
         tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
         assert (x.grad.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_nms_edge_vectors_on_device():
+    """the float64-derived edge vectors (exact threshold, duplicates, ties, zero area) through the HIP NMS /
+    soft-NMS"""
+    import json
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_mmcv_ops.json')))
+    for e in kat['nms_edges']:
+        _, inds = ops.nms(torch.tensor(e['boxes'], dtype=torch.float32, device=DEV), torch.tensor(e['scores'], device=DEV),
+                          e['thr'])
+        assert inds.tolist() == e['keep'], e['name']
+    for e in kat['soft_edges']:
+        dets, inds = ops.soft_nms(torch.tensor(e['boxes'], dtype=torch.float32, device=DEV),
+                                  torch.tensor(e['scores'], device=DEV), e['thr'], 0.5, 1e-3, e['method'])
+        assert inds.tolist() == e['inds'] and np.allclose(dets[:, 4].cpu().numpy(), e['scores_out'], atol=1e-7), e
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

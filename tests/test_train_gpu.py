@@ -47,6 +47,36 @@ def test_assign_reference_known_answers():
     assert _assign_dev(bb, [torch.empty(0, 4)], kw, batch=1)[0].tolist() == [0, 0, 0, 0]
 
 
+def test_bbox_overlaps_and_assigner_reference_api_on_device():
+    """the reference-signature entry points on device tensors run the HIP kernels: `bbox_overlaps` (all modes,
+    bit-exact vs the reference's own values, fixture g3) and `MaxIoUAssigner.assign` (fixture g4)"""
+    g = load('g3_overlaps')
+    a, b, c = T(g['a']).to(DEV), T(g['b']).to(DEV), T(g['c']).to(DEV)
+    assert torch.equal(core.bbox_overlaps(a, b).cpu(), T(g['iou']))
+    assert torch.equal(core.bbox_overlaps(b, c, is_aligned=True).cpu(), T(g['aligned']))
+    assert torch.equal(core.bbox_overlaps(b, c, mode='giou', is_aligned=True).cpu(), T(g['giou']))
+    assert torch.equal(core.bbox_overlaps(a, b, mode='iof').cpu(), T(g['iof']))
+    b1 = torch.tensor([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42.]], device=DEV)
+    b2 = torch.tensor([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20.]], device=DEV)
+    gi = core.bbox_overlaps(b1, b2, 'giou', is_aligned=True, eps=1e-6)          # tests/test_metrics/test_box_overlap.py:84-100
+    assert np.allclose(gi.cpu().numpy().round(4), [0.5, -0.05, -0.8214], atol=1e-4)
+    g = load('g4_assign_sample')
+    boxes, gts, labels = T(g['boxes']).to(DEV), T(g['gts']).to(DEV), T(g['labels']).to(DEV)
+    for name, kw in (('rpn', RPN_KW), ('rcnn', RCNN_KW)):
+        r = core.MaxIoUAssigner(**kw).assign(boxes, gts, None, labels)
+        assert torch.equal(r.gt_inds.cpu(), T(g[name + '_gt_inds']))
+        assert torch.equal(r.max_overlaps.cpu(), T(g[name + '_max_overlaps']))
+        assert torch.equal(r.labels.cpu(), T(g[name + '_labels']))
+    r = core.MaxIoUAssigner(**RCNN_KW).assign(T(g['props']).to(DEV), gts, None, labels)        # 5-column proposals
+    torch.manual_seed(1234)
+    smp = core.RandomSampler(num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True).sample(
+        r, T(g['props']).to(DEV), gts, labels)
+    assert torch.equal(smp.pos_inds.cpu(), T(g['s_pos_inds'])) and torch.equal(smp.neg_inds.cpu(), T(g['s_neg_inds']))
+    assert torch.equal(smp.bboxes.cpu(), T(g['s_bboxes']))
+    r0 = core.MaxIoUAssigner(**RPN_KW).assign(boxes, torch.empty(0, 4, device=DEV), None, torch.empty(0, dtype=torch.long, device=DEV))
+    assert (r0.gt_inds == 0).all() and (r0.labels == -1).all()
+
+
 def _anchor_case(seed, sizes, pad_shapes, strides, num_gts, border=-1):
     """RPN anchors of a small pyramid, per-image padded shapes and ground truth; returns the device
     result and the CPU restatement (anchor_head.py:199-262 via brcnn.core)"""
