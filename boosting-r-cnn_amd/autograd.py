@@ -225,6 +225,9 @@ def linear_autograd(x, weight, bias):
     return y if cout == weight.shape[0] else y[:, :cout]
 
 
+ROI_BACKWARD_GATHER = True      # False: the scatter form (fp32 atomics), kept for A/B and as the generic fallback
+
+
 class RoIExtractFunction(Function):
     """Fused SingleRoIExtractor on NHWC maps with the RoIAlign feature gradient."""
 
@@ -243,14 +246,26 @@ class RoIExtractFunction(Function):
         output_size, strides, finest_scale, sampling_ratio, shapes = ctx.cfg
         ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
         L = len(shapes)
-        grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
-        ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grads])
         hs, ws = _ints([s[1] for s in shapes]), _ints([s[2] for s in shapes])
         sc = (ctypes.c_float * L)(*[1.0 / s for s in strides])
-        g = grad_out.contiguous()
-        st = _L.load().brcnn_roi_extract_backward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
-                                                  shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
-                                                  float(finest_scale), _stream())
+        g = grad_out.float().contiguous()
+        lib = _L.load()
+        if ROI_BACKWARD_GATHER and ph <= 7 and pw <= 7 and shapes[0][3] % 4 == 0:
+            # gather form: every gradient pixel written once, no zero fill, deterministic
+            grads = [torch.empty(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
+            ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads])
+            nb = lib.brcnn_roi_extract_backward_workspace_bytes(rois.size(0))
+            wsp = torch.empty((nb + 3) // 4, dtype=torch.int32, device=grad_out.device)
+            st = lib.brcnn_roi_extract_backward_gather(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
+                                                       shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
+                                                       float(finest_scale), _ptr(wsp), nb, _stream())
+            _L.check(st, 'brcnn_roi_extract_backward_gather')
+            return (None, None, None, None, None) + tuple(grads)
+        grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
+        ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads])
+        st = lib.brcnn_roi_extract_backward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
+                                            shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
+                                            float(finest_scale), _stream())
         _L.check(st, 'brcnn_roi_extract_backward')
         return (None, None, None, None, None) + tuple(grads)
 

@@ -586,13 +586,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                          int strips, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int strips, int C) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     float a = 0.f;
-    for (int s = 0; s < strips; s++) a += partial[(size_t)s * C + c];
-    out[c] = a;
+    if (col < C)
+        for (int s = sl; s < strips; s += 16) a += partial[(size_t)s * C + col];
+    red[sl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (sl == 0 && col < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][threadIdx.x];
+        out[col] = t;
+    }
 }
 
 // (N, R, Cc) -> (N, Cc, R) tiled transpose through LDS: 32x32 tiles, 256 threads
@@ -951,8 +959,8 @@ BRCNN_API int brcnn_upsample_nearest_add_nhwc_backward(const void* dout, void* d
 
 BRCNN_API size_t brcnn_colsum_workspace_bytes(int64_t rows, int channels) {
     if (rows <= 0 || channels <= 0) return 256;
-    long long strips = (rows + 255) / 256;
-    if (strips > 256) strips = 256;
+    long long strips = (rows + 63) / 64;
+    if (strips > 2048) strips = 2048;
     return (size_t)strips * channels * sizeof(float) + 256;
 }
 
@@ -968,8 +976,8 @@ BRCNN_API int brcnn_colsum(const void* x, float* out, void* workspace, size_t wo
         BRCNN_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)channels * sizeof(float), s));
         return 0;
     }
-    long long strips = (rows + 255) / 256;
-    if (strips > 256) strips = 256;
+    long long strips = (rows + 63) / 64;          // ~2048 workgroups of >= 64 rows: enough to fill the chip
+    if (strips > 2048) strips = 2048;
     const int rpb = (int)((rows + strips - 1) / strips);
     strips = (rows + rpb - 1) / rpb;
     if (workspace_bytes < (size_t)strips * channels * sizeof(float)) return BRCNN_EINVAL;
@@ -985,7 +993,7 @@ BRCNN_API int brcnn_colsum(const void* x, float* out, void* workspace, size_t wo
         hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, (float*)workspace,
                            (long long)rows, channels, rpb);
     BRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, s, (const float*)workspace, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s, (const float*)workspace, out,
                        (int)strips, channels);
     BRCNN_LAUNCH_CHECK();
     return 0;

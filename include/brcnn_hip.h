@@ -94,6 +94,19 @@ int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights
                                const float *rois, const float *grad_output, int batch,
                                int channels, int n_rois, int pooled_h, int pooled_w,
                                int sampling_ratio, float finest_scale, void *stream);
+
+/* The same gradient as a GATHER: every pixel of every grad_feats level is written exactly once (no
+ * pre-zeroing, no atomics, a fixed summation order: deterministic).  One workgroup per 8x8 tile of a
+ * (level, image) map collects the RoIs whose footprint touches the tile and accumulates
+ * dX[h,w] += sum_bins Wy[ph][h] * Wx[pw][w] * dY[roi,ph,pw] / count with the separable bilinear footprint
+ * weights.  workspace: brcnn_roi_extract_backward_workspace_bytes(n_rois).  pooled_h, pooled_w <= 7. */
+size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois);
+int brcnn_roi_extract_backward_gather(float *const *grad_feats_host, const int *heights_host,
+                                      const int *widths_host, const float *scales_host, int num_levels,
+                                      const float *rois, const float *grad_output, int batch, int channels,
+                                      int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
+                                      float finest_scale, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 /* NHWC RoIAlign forward variants: 0 (default) = footprint form (every pixel of a bin's footprint
  * read once; equal to the reference to fp32 round-off), 1 = the reference's sample-order
  * accumulation (bit-identical to mmcv's CPU kernel; ~1.5x the L2 reads). */

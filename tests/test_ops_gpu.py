@@ -545,6 +545,47 @@ def test_linear_and_roi_extract_autograd():
         assert torch.allclose(fg[i].grad.permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=1e-5), i
 
 
+def test_roi_extract_backward_gather_form():
+    """the gather-form RoI feature gradient (no atomics: bit-reproducible run to run) against the C oracle's
+    per-level RoIAlign backward and the scatter form, at C = 256 / 320 (a second channel chunk), with RoIs that hang
+    over the border, sit outside the map, are tiny (many bins on one pixel) or huge"""
+    from brcnn import autograd as ag
+    from brcnn.autograd import roi_extract_autograd
+    g = torch.Generator().manual_seed(14)
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11), (4, 6)]
+    for C, B, K in ((256, 3, 700), (320, 2, 150), (8, 1, 60)):
+        feats = [torch.randn(B, h, w_, C, generator=g) for h, w_ in sizes]
+        rois = util.rand_rois(K, B, 672., 400., seed=5 + C, min_size=4., max_size=900.)
+        extra = torch.tensor([[0, -80., -60., 30., 20.], [0, 650., 380., 720., 460.], [B - 1, -500., -500., -300., -300.],
+                              [0, 100., 100., 101., 101.], [B - 1, 0., 0., 672., 400.], [0, 300., 10., 310., 390.]])
+        rois = torch.cat([rois, extra])
+        go = torch.randn(rois.shape[0], 7, 7, C, generator=g)
+        res = {}
+        for mode in (True, False, True):
+            ag.ROI_BACKWARD_GATHER = mode
+            try:
+                fg = [f.clone().to(DEV).requires_grad_() for f in feats]
+                roi_extract_autograd(fg, rois.to(DEV), 7, strides, 56, 0).backward(go.to(DEV))
+            finally:
+                ag.ROI_BACKWARD_GATHER = True
+            grads = [f.grad.clone() for f in fg]
+            if mode and True in res:
+                assert all(torch.equal(a, b_) for a, b_ in zip(grads, res[True])), 'gather form is deterministic'
+            res[mode] = grads
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        lvls = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=4).long()
+        for i in range(5):
+            mag = max(1.0, res[False][i].abs().max().item())
+            assert (res[True][i] - res[False][i]).abs().max().item() <= 2e-5 * mag, (C, i)
+            if C <= 8:      # the CPU oracle is slow: small case only
+                inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+                ref = orc.roi_align_backward(go[inds].permute(0, 3, 1, 2).contiguous(), rois[inds],
+                                             feats[i].permute(0, 3, 1, 2).shape, 7, 1. / strides[i], 0, True) \
+                    if inds.numel() else torch.zeros_like(feats[i].permute(0, 3, 1, 2))
+                assert torch.allclose(res[True][i].permute(0, 3, 1, 2).cpu(), ref, rtol=1e-4, atol=1e-5), i
+
+
 def test_stem_vector_path_matches_float64():
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(12)

@@ -24,7 +24,8 @@ if __name__ == '__main__':
     calls = sum(r[1] for r in rows)
     print(f'{calls} launches, {tot / 1e6:.2f} ms kernel time; per step ({steps}): {calls / steps:.0f} launches, '
           f'{tot / 1e6 / steps:.2f} ms')
-    own = sum(r[2] for r in rows if 'anonymous namespace' in r[0] and 'at::native' not in r[0])
+    foreign = ('at::native', 'rocclr', 'rocprim', 'hipcub', 'ncclDevKernel', 'rccl')
+    own = sum(r[2] for r in rows if not any(f in r[0] for f in foreign))
     print(f'own kernels: {100.0 * own / tot:.1f} % of kernel time')
     for r in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 40]:
         print(f'{r[1]:7d} {r[2] / 1e6:9.3f} ms {100.0 * r[2] / tot:6.2f}%  {r[0][:130]}')
