@@ -129,8 +129,12 @@ def train_bench(args, world, rank, device):
     model = model.train()
     model.set_compute_dtype(args.train_dtype)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
-                          weight_decay=cfg.optimizer.weight_decay)
+    from brcnn import blocks
+    from brcnn.optim import FusedSGD
+    # the recipes' optimizer (SGD, momentum 0.9, weight decay 1e-4, grad-clip 35) on the fused HIP step
+    opt = FusedSGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
+                   weight_decay=cfg.optimizer.weight_decay)
+    opt.register_conv_weights(model, blocks.compute_dtype())
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], broadcast_buffers=False,
@@ -138,23 +142,15 @@ def train_bench(args, world, rank, device):
     img, metas = synthetic_batch(args.batch, device, seed=rank)
     gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)
     # fp16: the recipes' static loss scaling (fp16 = dict(loss_scale=512.), mmcv Fp16OptimizerHook)
-    scaler = torch.amp.GradScaler('cuda', init_scale=512.) if args.train_dtype == 'f16' else None
+    scale = 512.0 if args.train_dtype == 'f16' else 1.0
     last = {}
 
     def step():
         opt.zero_grad(set_to_none=True)
         losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
         loss, log_vars = model._parse_losses(losses)
-        if scaler is not None:
-            scaler.scale(loss).backward()
-            scaler.unscale_(opt)
-            torch.nn.utils.clip_grad_norm_(params, max_norm=35, norm_type=2)
-            scaler.step(opt)
-            scaler.update(512.)
-        else:
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, max_norm=35, norm_type=2)
-            opt.step()
+        (loss * scale if scale != 1.0 else loss).backward()
+        opt.step(max_norm=35, loss_scale=scale)        # clip + unscale + skip-on-inf + SGD + next step's conv operands
         last['log_vars'] = log_vars
 
     steps = args.train_steps or args.steps

@@ -85,6 +85,10 @@ def build_optimizer(model, cfg):
     typ = cfg.pop('type')
     cls = getattr(torch.optim, typ)
     module = model.module if hasattr(model, 'module') else model
+    if typ == 'SGD' and not cfg.get('nesterov', False) and not cfg.get('dampening', 0) and \
+            all(p.is_cuda for p in module.parameters()) and os.environ.get('BRCNN_TORCH_SGD') != '1':
+        from .optim import FusedSGD       # same param_groups / state_dict layout, one pass on the HIP kernels
+        cls = FusedSGD
     if not paramwise:
         params = [p for p in module.parameters() if p.requires_grad]
         return cls(params, **cfg)
@@ -275,7 +279,7 @@ class EpochBasedRunner:
         rank, world = get_dist_info()
         vals = OrderedDict()
         for k, v in self.log_buffer.items():
-            vals[k] = float(np.mean(v))
+            vals[k] = float(np.mean([float(x) for x in v]))       # (device scalars, e.g. grad_norm, are read here)
         self.log_buffer.clear()
         lr = self.current_lr()[0]
         self.history.append((self.epoch + 1, self.inner_iter + 1, lr, dict(vals)))
@@ -300,7 +304,15 @@ class EpochBasedRunner:
             outputs = self.model.train_step(data, self.optimizer) if not hasattr(self.model, 'module') else \
                 self._ddp_step(data)
             self.optimizer.zero_grad()
-            if self.loss_scaler is not None:
+            from .optim import FusedSGD
+            if isinstance(self.optimizer, FusedSGD) and (self.grad_clip is None or self.grad_clip.get('norm_type', 2) == 2):
+                # clip + (unscale) + SGD + next step's conv operands in one call; the norm stays on the device
+                scale = self.loss_scale or 1.0
+                (outputs['loss'] * scale if scale != 1.0 else outputs['loss']).backward()
+                ctl = self.optimizer.step(max_norm=self.grad_clip['max_norm'] if self.grad_clip else None, loss_scale=scale)
+                if self.grad_clip is not None and ctl is not None:
+                    outputs['log_vars']['grad_norm'] = ctl[0]
+            elif self.loss_scaler is not None:
                 # Fp16OptimizerHook (mmcv/runner/hooks/optimizer.py, the torch >= 1.6 form): scaled backward,
                 # unscale, clip, a step that is skipped on inf / nan gradients, and -- static mode -- the
                 # scale reset to `loss_scale` every iteration
@@ -433,6 +445,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
             runner.loss_scale = float(scale)
             runner.loss_scaler = torch.amp.GradScaler('cuda', init_scale=float(scale), enabled=device.type == 'cuda')
             logger.info(f'fp16={dict(cfg.fp16)}: fp16 MFMA conv stack, static loss scale {float(scale)}')
+    _register_packed(optimizer, model.module if hasattr(model, 'module') else model)
     runner.register_training_hooks(cfg.lr_config, cfg.get('optimizer_config', None),
                                    cfg.get('checkpoint_config', None), cfg.get('log_config', None))
     for hook in cfg.get('custom_hooks', None) or []:
@@ -466,6 +479,14 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
         runner.load_checkpoint(cfg.load_from)
     runner.run(loaders, cfg.get('workflow', [('train', 1)]))
     return runner
+
+
+def _register_packed(optimizer, module):
+    """FusedSGD keeps the conv weights' packed operands of the next step current in the compute dtype"""
+    from . import blocks
+    from .optim import FusedSGD
+    if isinstance(optimizer, FusedSGD):
+        optimizer.register_conv_weights(module, blocks.compute_dtype())
 
 
 def _check_num_classes(model, dataset, logger):

@@ -37,16 +37,21 @@ class ConvNHWCFunction(Function):
         # (weights are cast per step from the fp32 master copy, gradients of weights stay fp32)
         # one launch writes the forward operand and (when the input needs a gradient) the flipped /
         # transposed data-gradient operand
-        wsrc = weight.detach()
-        if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
-            wsrc = wsrc.float().contiguous()
-        cout_, cin_, kh_, kw_ = wsrc.shape
-        w_p = torch.empty((cout_, kh_, kw_, cin_), dtype=x_cat.dtype, device=x_cat.device)
-        w_t = torch.empty((cin_, kh_, kw_, cout_), dtype=x_cat.dtype, device=x_cat.device) \
-            if x_cat.requires_grad else None
-        st = _L.load().brcnn_pack_conv_weights(_ptr(wsrc), _ptr(w_p), _ptr(w_t), cout_, cin_, kh_, kw_,
-                                               _dt(x_cat), _stream())
-        _L.check(st, 'brcnn_pack_conv_weights')
+        pk = getattr(weight, '_brcnn_pack', None)
+        if pk is not None and pk[0] == weight._version and pk[1] == x_cat.dtype and pk[2].device == x_cat.device:
+            # operands the fused optimizer step already wrote for this version of the weight (optim.FusedSGD)
+            w_p, w_t = pk[2], pk[3]
+        else:
+            wsrc = weight.detach()
+            if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
+                wsrc = wsrc.float().contiguous()
+            cout_, cin_, kh_, kw_ = wsrc.shape
+            w_p = torch.empty((cout_, kh_, kw_, cin_), dtype=x_cat.dtype, device=x_cat.device)
+            w_t = torch.empty((cin_, kh_, kw_, cout_), dtype=x_cat.dtype, device=x_cat.device) \
+                if x_cat.requires_grad else None
+            st = _L.load().brcnn_pack_conv_weights(_ptr(wsrc), _ptr(w_p), _ptr(w_t), cout_, cin_, kh_, kw_,
+                                                   _dt(x_cat), _stream())
+            _L.check(st, 'brcnn_pack_conv_weights')
         ctx.w_t = w_t
         x_cat = x_cat.contiguous()
         y, out_sizes = ops.conv2d_nhwc_multi(x_cat, w_p, batch, sizes, None,

@@ -1,0 +1,258 @@
+// Fused optimizer step of the train loop, for gfx950.
+//
+// The reference steps with torch.optim.SGD(lr, momentum 0.9, weight_decay 1e-4) after mmcv's OptimizerHook clipped
+// the global gradient norm to 35 (configs/_base_/schedules/schedule_1x.py:2-3, boosting_rcnn_r50_pafpn_1x_utdac.py:130
+// `optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))`): per step ~40 multi-tensor launches for the
+// norm, the clip and the update, plus -- on this path -- one weight-packing launch per trainable conv at the next
+// forward.  Here the whole step is
+//   sqnorm (two fixed-order stages over a table of gradient tensors)  ->  clip coefficient on the device
+//   update (one pass over every parameter: g * coef [/ loss scale] + wd * w, momentum, w -= lr * buf; skipped
+//           as a whole when the norm is not finite -- the GradScaler rule of the fp16 recipes)
+//   pack   (the conv weights' forward / data-gradient operands of the NEXT step, (Cout,KH,KW,Cin) and flipped
+//           (Cin,KH,KW,Cout) in the compute dtype, through 32 x 32 LDS tiles)
+// with the tensor tables passed by value (the gradient pointers change every step), a few launches in all.
+// HBM-bound streams: update reads w, g, buf and writes w, buf once (16 B + 8 B per parameter).
+#include "common.h"
+
+namespace {
+
+constexpr int TAB = 64;            // tensors per launch (kernel-argument table: 64 x 48 B)
+
+struct SgdEntry {
+    float* w;
+    const float* g;
+    float* buf;
+    int blk0;          // first workgroup of this tensor (each workgroup: 1024 elements)
+    int n;
+    float lr, wd;
+    int has_buf;       // 0: first step of this parameter (buf = d_p, as torch initialises it)
+};
+struct SgdTable {
+    int count, nblocks;
+    SgdEntry e[TAB];
+};
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const SgdTable t, float* __restrict__ partial) {
+    __shared__ float red[4];
+    int lo = 0, hi = t.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.e[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const SgdEntry& e = t.e[lo];
+    const int base = ((int)blockIdx.x - e.blk0) * 1024;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = base + j * 256 + threadIdx.x;
+        if (i < e.n) { const float v = e.g[i]; s += v * v; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = total gradient norm (of the UNSCALED gradients), out[1] = factor the update multiplies g by
+// (inv_scale * min(1, max_norm / (norm + 1e-6)); 0 when the norm is not finite), out[2] = 1 if the step is skipped
+__global__ __launch_bounds__(1024) void sqnorm_final_kernel(const float* __restrict__ partial, int n, float inv_scale,
+                                                           float max_norm, float* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int k = 0; k < 16; k++) tsum += red[k];
+        const float norm = (float)sqrt(tsum) * inv_scale;
+        const bool finite = norm == norm && norm <= 3.402823466e+38f;
+        float coef = inv_scale;
+        if (max_norm > 0.f) {
+            const float c = max_norm / (norm + 1e-6f);           // torch.nn.utils.clip_grad_norm_
+            coef = inv_scale * (c < 1.f ? c : 1.f);
+        }
+        out[0] = norm;
+        out[1] = finite ? coef : 0.f;
+        out[2] = finite ? 0.f : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_update_kernel(const SgdTable t, const float* __restrict__ ctl, float momentum) {
+    const float coef = ctl ? ctl[1] : 1.f;
+    if (ctl && ctl[2] != 0.f) return;                           // non-finite gradients: the whole step is skipped
+    int lo = 0, hi = t.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.e[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const SgdEntry& e = t.e[lo];
+    const int base = ((int)blockIdx.x - e.blk0) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = base + j * 256 + threadIdx.x;
+        if (i < e.n) {
+            const float w = e.w[i];
+            float d = e.g[i] * coef;
+            if (e.wd != 0.f) d = d + e.wd * w;                   // d_p = d_p.add(p, alpha=weight_decay)
+            float b = d;
+            if (momentum != 0.f) {
+                if (e.has_buf) b = momentum * e.buf[i] + d;      // buf.mul_(momentum).add_(d_p)
+                e.buf[i] = b;
+            }
+            e.w[i] = w - e.lr * b;                               // p.add_(buf, alpha=-lr)
+        }
+    }
+}
+
+struct PackEntry {
+    const float* w;    // (Cout, Cin, KH, KW) fp32 master weight
+    void* fwd;         // (Cout, KH, KW, Cin)
+    void* dgrad;       // (Cin, KH, KW, Cout), taps flipped; may be NULL
+    int cout, cin, kh, kw;
+    int blk0;          // first workgroup; workgroups of a tensor = tiles_ci * tiles_co * taps
+};
+struct PackTable {
+    int count, nblocks;
+    PackEntry e[TAB];
+};
+
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = brcnn_f2b(v); }
+__device__ __forceinline__ void st1(f16_t* p, float v) { p->v = brcnn_f2h(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackTable t, const float* __restrict__ ctl) {
+    __shared__ float tile[32][33];
+    if (ctl && ctl[2] != 0.f) return;                           // step skipped: the packed copies are still current
+    int lo = 0, hi = t.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.e[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackEntry& e = t.e[lo];
+    const int taps = e.kh * e.kw;
+    const int tci = (e.cin + 31) >> 5, tco = (e.cout + 31) >> 5;
+    int r = (int)blockIdx.x - e.blk0;
+    const int tap = r % taps; r /= taps;
+    const int ci0 = (r % tci) * 32, co0 = (r / tci) * 32;
+    (void)tco;
+    const int a = tap / e.kw, b = tap - a * e.kw;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {                            // rows = co, columns = ci
+        const int co = co0 + j, ci = ci0 + tx;
+        tile[j][tx] = (co < e.cout && ci < e.cin) ? e.w[((size_t)co * e.cin + ci) * taps + tap] : 0.f;
+    }
+    __syncthreads();
+    T* fwd = reinterpret_cast<T*>(e.fwd);
+    T* dg = reinterpret_cast<T*>(e.dgrad);
+    if (fwd)
+        for (int j = ty; j < 32; j += 8) {
+            const int co = co0 + j, ci = ci0 + tx;
+            if (co < e.cout && ci < e.cin) st1(fwd + ((size_t)co * taps + tap) * e.cin + ci, tile[j][tx]);
+        }
+    if (dg)
+        for (int j = ty; j < 32; j += 8) {                        // rows = ci, columns = co
+            const int ci = ci0 + j, co = co0 + tx;
+            if (co < e.cout && ci < e.cin)
+                st1(dg + (((size_t)ci * e.kh + (e.kh - 1 - a)) * e.kw + (e.kw - 1 - b)) * e.cout + co, tile[tx][j]);
+        }
+}
+
+}  // namespace
+
+BRCNN_API size_t brcnn_sgd_workspace_bytes(int num_tensors, const int64_t* numel_host) {
+    size_t blocks = 0;
+    for (int i = 0; i < num_tensors; i++) blocks += (size_t)((numel_host[i] + 1023) / 1024);
+    return blocks * sizeof(float) + 256;
+}
+
+// params / grads / bufs: HOST arrays of device pointers (fp32, dense); lr / weight_decay per tensor; has_buf per tensor.
+// max_norm <= 0: no clipping (the norm is still computed when ctl3 is given).  ctl3 (device, 3 floats) receives
+// [grad norm, applied factor, skipped]; inv_scale = 1 / loss scale.
+BRCNN_API int brcnn_sgd_step(float* const* params, const float* const* grads, float* const* bufs, const int64_t* numel_host,
+                             const float* lr_host, const float* wd_host, const int* has_buf_host, int num_tensors,
+                             float momentum, float max_norm, float inv_scale, void* workspace, size_t workspace_bytes,
+                             float* ctl3, void* stream) {
+    if (num_tensors <= 0) return 0;
+    if (!params || !grads || !numel_host || !lr_host || !wd_host || !has_buf_host || !workspace || !ctl3 ||
+        (momentum != 0.f && !bufs))
+        return BRCNN_EINVAL;
+    if (workspace_bytes < brcnn_sgd_workspace_bytes(num_tensors, numel_host) - 256) return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    // pass 1: squared norm, tables of TAB tensors
+    int total_blocks = 0;
+    for (int first = 0; first < num_tensors; first += TAB) {
+        SgdTable t;
+        t.count = num_tensors - first < TAB ? num_tensors - first : TAB;
+        int blk = 0;
+        for (int i = 0; i < t.count; i++) {
+            const int k = first + i;
+            if (numel_host[k] <= 0 || numel_host[k] > 0x7fffffffLL || !params[k] || !grads[k]) return BRCNN_EINVAL;
+            t.e[i].w = params[k]; t.e[i].g = grads[k]; t.e[i].buf = bufs ? bufs[k] : nullptr;
+            t.e[i].blk0 = blk; t.e[i].n = (int)numel_host[k]; t.e[i].lr = lr_host[k]; t.e[i].wd = wd_host[k];
+            t.e[i].has_buf = has_buf_host[k];
+            blk += (int)((numel_host[k] + 1023) / 1024);
+        }
+        t.nblocks = blk;
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blk), dim3(256), 0, s, t, partial + total_blocks);
+        BRCNN_LAUNCH_CHECK();
+        total_blocks += blk;
+    }
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, total_blocks, inv_scale,
+                       max_norm, ctl3);
+    BRCNN_LAUNCH_CHECK();
+    for (int first = 0; first < num_tensors; first += TAB) {
+        SgdTable t;
+        t.count = num_tensors - first < TAB ? num_tensors - first : TAB;
+        int blk = 0;
+        for (int i = 0; i < t.count; i++) {
+            const int k = first + i;
+            t.e[i].w = params[k]; t.e[i].g = grads[k]; t.e[i].buf = bufs ? bufs[k] : nullptr;
+            t.e[i].blk0 = blk; t.e[i].n = (int)numel_host[k]; t.e[i].lr = lr_host[k]; t.e[i].wd = wd_host[k];
+            t.e[i].has_buf = has_buf_host[k];
+            blk += (int)((numel_host[k] + 1023) / 1024);
+        }
+        t.nblocks = blk;
+        hipLaunchKernelGGL(sgd_update_kernel, dim3(blk), dim3(256), 0, s, t, (const float*)ctl3, momentum);
+        BRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// forward / data-gradient operands of `num` conv weights in one launch per TAB tensors.  dims_host: 4 ints per tensor
+// (cout, cin, kh, kw); dgrad[i] may be NULL.  ctl3: the optimizer's control block (packing is skipped with the step) or NULL.
+BRCNN_API int brcnn_pack_conv_weights_batch(const float* const* weights, void* const* fwd, void* const* dgrad,
+                                            const int* dims_host, int num, int dtype, const float* ctl3, void* stream) {
+    if (num <= 0) return 0;
+    if (!weights || !fwd || !dgrad || !dims_host || !brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    for (int first = 0; first < num; first += TAB) {
+        PackTable t;
+        t.count = num - first < TAB ? num - first : TAB;
+        long long blk = 0;
+        for (int i = 0; i < t.count; i++) {
+            const int k = first + i;
+            const int* d = dims_host + 4 * k;
+            if (!weights[k] || (!fwd[k] && !dgrad[k]) || d[0] <= 0 || d[1] <= 0 || d[2] <= 0 || d[3] <= 0) return BRCNN_EINVAL;
+            t.e[i].w = weights[k]; t.e[i].fwd = fwd[k]; t.e[i].dgrad = dgrad[k];
+            t.e[i].cout = d[0]; t.e[i].cin = d[1]; t.e[i].kh = d[2]; t.e[i].kw = d[3];
+            t.e[i].blk0 = (int)blk;
+            blk += (long long)((d[0] + 31) / 32) * ((d[1] + 31) / 32) * d[2] * d[3];
+            if (blk > 0x7fffffffLL) return BRCNN_EINVAL;
+        }
+        t.nblocks = (int)blk;
+        if (dtype == BRCNN_DT_F32)
+            hipLaunchKernelGGL(pack_batch_kernel<float>, dim3((unsigned)blk), dim3(256), 0, s, t, ctl3);
+        else if (dtype == BRCNN_DT_BF16)
+            hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3((unsigned)blk), dim3(256), 0, s, t, ctl3);
+        else
+            hipLaunchKernelGGL(pack_batch_kernel<f16_t>, dim3((unsigned)blk), dim3(256), 0, s, t, ctl3);
+        BRCNN_LAUNCH_CHECK();
+    }
+    return 0;
+}

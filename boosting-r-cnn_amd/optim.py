@@ -1,0 +1,130 @@
+"""`FusedSGD`: torch.optim.SGD (momentum, weight decay; dampening 0, no nesterov) + mmcv's OptimizerHook
+gradient clipping + the fp16 recipes' static loss scaling as ONE pass over the parameters on the HIP kernels
+`brcnn_sgd_step` / `brcnn_pack_conv_weights_batch` (csrc/optim.hip).
+
+The reference: `optimizer = dict(type='SGD', lr=.., momentum=0.9, weight_decay=0.0001)`,
+`optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))` (configs/_base_/schedules/schedule_1x.py:2-3,
+configs/boosting_rcnn/boosting_rcnn_r50_pafpn_1x_utdac.py:130) -> torch's multi-tensor kernels, ~40 launches per
+step.  Here: squared norm (fixed-order two stages), clip factor and the skip-on-inf decision on the device, one
+update pass, and -- for the conv weights registered with `register_conv_weights` -- the forward / data-gradient
+operands of the NEXT step written in the compute dtype in the same call, so that the per-layer weight packing
+launches of the next forward disappear.  Same `param_groups` / `state_dict()` layout as torch.optim.SGD
+(`momentum_buffer`), so checkpoints are interchangeable with the reference's.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _L
+from .ops import _dt, _ptr, _stream
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, **kwargs):
+        if dampening != 0 or nesterov:
+            raise NotImplementedError('FusedSGD: dampening / nesterov are not used by the recipes')
+        if kwargs.get('maximize', False):
+            raise NotImplementedError('FusedSGD: maximize')
+        defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False)
+        super().__init__(params, defaults)
+        self._conv = []              # [(param, fwd_buf, dgrad_buf)] of registered conv weights, per compute dtype
+        self._conv_dtype = None
+        self.ctl = None              # device [grad norm, applied factor, skipped]
+        for g in self.param_groups:
+            for p in g['params']:
+                if not p.is_cuda:
+                    raise _L.BrcnnHipError('FusedSGD runs on the HIP device only (move the model first)')
+
+    # ---- conv weight operands of the next step -------------------------------------------------
+    def register_conv_weights(self, module, dtype):
+        """keep the packed forward / data-gradient operands of every trainable, ungrouped nn.Conv2d weight of
+        `module` current in `dtype` (the compute dtype): written by `step()`, consumed by
+        `autograd.ConvNHWCFunction` through `weight._brcnn_pack`"""
+        mult = 32 if dtype == torch.float32 else 64
+        self._conv, self._conv_dtype = [], dtype
+        mine = {id(p) for g in self.param_groups for p in g['params']}
+        for m in module.modules():
+            if isinstance(m, torch.nn.Conv2d) and m.groups == 1 and id(m.weight) in mine and m.weight.requires_grad \
+                    and m.weight.shape[0] % mult == 0 and m.weight.is_contiguous():
+                w = m.weight
+                co, ci, kh, kw = w.shape
+                self._conv.append((w, torch.empty((co, kh, kw, ci), dtype=dtype, device=w.device),
+                                   torch.empty((ci, kh, kw, co), dtype=dtype, device=w.device)))
+        self._pack(None)
+        return len(self._conv)
+
+    def _pack(self, ctl):
+        if not self._conv:
+            return
+        n = len(self._conv)
+        ws = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _ in self._conv])
+        fw = (ctypes.c_void_p * n)(*[f.data_ptr() for _, f, _ in self._conv])
+        dg = (ctypes.c_void_p * n)(*[d.data_ptr() for _, _, d in self._conv])
+        dims = (ctypes.c_int * (4 * n))(*[int(v) for w, _, _ in self._conv for v in w.shape])
+        st = _L.load().brcnn_pack_conv_weights_batch(ws, fw, dg, dims, n, _dt(self._conv[0][1]), _ptr(ctl), _stream())
+        _L.check(st, 'brcnn_pack_conv_weights_batch')
+        for w, f, d in self._conv:
+            w._brcnn_pack = (w._version, self._conv_dtype, f, d)
+
+    # ---- the step ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=None, loss_scale=1.0):
+        """one optimizer step.  `max_norm`: clip the global L2 gradient norm first (None / <= 0: no clipping);
+        `loss_scale`: the gradients carry this factor (fp16 static loss scaling) -- they are unscaled inside the
+        update, and a non-finite norm skips the whole step (what GradScaler.step does).  Returns the device
+        tensor [grad norm, applied factor, skipped]."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        ps, gs, bs, lrs, wds, has = [], [], [], [], [], []
+        momentum = None
+        for group in self.param_groups:
+            if momentum is None:
+                momentum = group['momentum']
+            elif momentum != group['momentum']:
+                raise NotImplementedError('FusedSGD: one momentum for all parameter groups')
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                if not p.is_contiguous() or p.dtype != torch.float32:
+                    raise _L.BrcnnHipError('FusedSGD: fp32 contiguous parameters expected')
+                state = self.state[p]
+                buf = state.get('momentum_buffer')
+                has.append(0 if buf is None else 1)
+                if buf is None and group['momentum'] != 0:
+                    buf = state['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                ps.append(p)
+                gs.append(g)
+                bs.append(buf)
+                lrs.append(group['lr'])
+                wds.append(group['weight_decay'])
+        if not ps:
+            return loss
+        n = len(ps)
+        dev = ps[0].device
+        lib = _L.load()
+        numel = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
+        nb = lib.brcnn_sgd_workspace_bytes(n, numel)
+        ws = torch.empty((nb + 3) // 4, dtype=torch.float32, device=dev)
+        self.ctl = torch.empty(3, dtype=torch.float32, device=dev)
+        pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in ps])
+        gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in gs])
+        bp = (ctypes.c_void_p * n)(*[0 if b is None else b.data_ptr() for b in bs])
+        st = lib.brcnn_sgd_step(pp, gp, bp, numel, (ctypes.c_float * n)(*lrs), (ctypes.c_float * n)(*wds),
+                                (ctypes.c_int * n)(*has), n, float(momentum or 0.0),
+                                float(max_norm) if max_norm else 0.0, 1.0 / float(loss_scale), _ptr(ws), nb, _ptr(self.ctl),
+                                _stream())
+        _L.check(st, 'brcnn_sgd_step')
+        for p in ps:        # the kernels wrote through raw pointers: tell autograd / the packed-operand caches
+            torch.autograd.graph.increment_version(p)
+        self._pack(self.ctl)
+        return self.ctl if loss is None else loss
+
+    @property
+    def last_grad_norm(self):
+        """device scalar: the global gradient norm of the last step (before clipping, after unscaling)"""
+        return None if self.ctl is None else self.ctl[0]

@@ -409,3 +409,59 @@ def test_train_step_device_path_mixed_shapes_and_empty_gt():
         vals[mode] = dict(log_vars)
     for k in vals[True]:
         assert np.isclose(vals[True][k], vals[False][k], rtol=2e-4, atol=1e-6), (k, vals[True][k], vals[False][k])
+
+
+def test_fused_sgd_matches_torch_sgd_with_clipping():
+    """FusedSGD (clip + SGD momentum / weight decay in one pass, per-group lr / decay) against torch.optim.SGD +
+    clip_grad_norm_ over several steps; a non-finite gradient skips the step (the GradScaler rule) and loss-scaled
+    gradients are unscaled inside; the conv operands it writes for the next step equal the per-layer packing"""
+    from brcnn.optim import FusedSGD
+    from brcnn import lib
+    from brcnn.ops import _ptr, _stream
+    torch.manual_seed(3)
+
+    def make():
+        net = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 3, bias=True), torch.nn.BatchNorm2d(128), torch.nn.Conv2d(128, 64, 1),
+                                  torch.nn.Linear(7, 5)).to(DEV)
+        return net
+    a, b = make(), make()
+    b.load_state_dict(a.state_dict())
+    groups = lambda n: [dict(params=[n[0].weight, n[2].weight]), dict(params=[n[0].bias, n[2].bias, n[3].bias], lr=0.04, weight_decay=0.0),  # noqa: E731
+                        dict(params=[n[1].weight, n[1].bias, n[3].weight], weight_decay=0.0)]
+    oa = FusedSGD(groups(a), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD(groups(b), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    assert oa.register_conv_weights(a, torch.bfloat16) == 2
+    pa, pb = list(a.parameters()), list(b.parameters())
+    gen = torch.Generator().manual_seed(5)
+    for it in range(5):
+        scale = 512.0 if it == 3 else 1.0
+        for x, y in zip(pa, pb):
+            g = torch.randn(x.shape, generator=gen).to(DEV) * (30.0 if it % 2 else 0.01)     # clipped / not clipped
+            x.grad, y.grad = g * scale, g.clone()
+        ctl = oa.step(max_norm=35, loss_scale=scale)
+        gn = torch.nn.utils.clip_grad_norm_(pb, max_norm=35, norm_type=2)
+        ob.step()
+        assert torch.allclose(ctl[0], gn, rtol=1e-5) and float(ctl[2]) == 0.0
+        for x, y in zip(pa, pb):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), it
+        for x, y in zip(pa, pb):
+            assert torch.allclose(oa.state[x]['momentum_buffer'], ob.state[y]['momentum_buffer'], rtol=2e-6, atol=1e-7)
+    # packed operands of the (updated) conv weights == the per-layer packing kernel
+    for conv in (a[0], a[2]):
+        w = conv.weight
+        ver, dt, f, d = w._brcnn_pack
+        assert ver == w._version and dt == torch.bfloat16
+        co, ci, kh, kw = w.shape
+        f2 = torch.empty((co, kh, kw, ci), dtype=torch.bfloat16, device=DEV)
+        d2 = torch.empty((ci, kh, kw, co), dtype=torch.bfloat16, device=DEV)
+        st = lib.load().brcnn_pack_conv_weights(_ptr(w.detach()), _ptr(f2), _ptr(d2), co, ci, kh, kw, 1, _stream())
+        assert st == 0 and torch.equal(f, f2) and torch.equal(d, d2)
+        assert torch.equal(f.float(), w.detach().permute(0, 2, 3, 1).to(torch.bfloat16).float())
+    # a non-finite gradient: nothing moves, the packed operands stay valid
+    before = [x.detach().clone() for x in pa]
+    for x in pa:
+        x.grad = torch.ones_like(x)
+    pa[0].grad[0, 0, 0, 0] = float('inf')
+    ctl = oa.step(max_norm=35)
+    assert float(ctl[2]) == 1.0 and all(torch.equal(x, y) for x, y in zip(pa, before))
+    assert set(oa.state_dict()['state'][0].keys()) == {'momentum_buffer'}
