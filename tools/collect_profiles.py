@@ -2,7 +2,14 @@
 import os, shutil, subprocess, sys
 r = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src, dst = f'gpurun_out/{r}', 'profiles'
-pairs = [('bench.json', 'bench.json'), ('bench_bf16.json', 'bench_bf16.json'), ('bench_train.json', 'bench_train.json'),
+pairs = [('bench_f16.json', 'bench_f16.json'), ('bench_bf16_trainf32.json', 'bench_bf16_trainf32.json'),
+         ('bench_under_rocprof.json', 'bench_under_rocprof.json'),
+         ('stats_inf/step_kernel_stats.csv', 'inference_kernel_stats.csv'),
+         ('stats_inf_bf16/step_kernel_stats.csv', 'inference_bf16_kernel_stats.csv'),
+         ('stats_train_f32/step_kernel_stats.csv', 'train_f32_kernel_stats.csv'),
+         ('train_layers_bf16.txt', 'train_layers_bf16.txt'), ('train_layers_f32.txt', 'train_layers_f32.txt'),
+         ('recipes.txt', 'recipes.txt'),
+         ('bench.json', 'bench.json'), ('bench_bf16.json', 'bench_bf16.json'), ('bench_train.json', 'bench_train.json'),
          ('bench_train_bf16.json', 'bench_train_bf16.json'), ('stats/step_kernel_stats.csv', 'bench_kernel_stats.csv'),
          ('stats_bf16/step_kernel_stats.csv', 'bench_bf16_kernel_stats.csv'),
          ('stats_train/step_kernel_stats.csv', 'train_kernel_stats.csv'),
@@ -18,3 +25,5 @@ for a, b in pairs:
     else:
         print('MISSING', a)
 subprocess.check_call([sys.executable, 'tools/summarize_pmc.py', r])
+if os.path.isdir(os.path.join(src, 'op_pmc_fetch')):
+    subprocess.check_call([sys.executable, 'tools/summarize_op_pmc.py', r])
