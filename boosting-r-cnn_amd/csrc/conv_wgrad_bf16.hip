@@ -47,18 +47,29 @@ __device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned magic, unsigned
 // Output tile (64*WT) x (64*WT); 4 waves 2x2, each WT x WT MFMA tiles.  LDS per operand and
 // buffer: WT column blocks of [64 m][64 columns] bf16 (128-byte rows, physical 16-byte chunk
 // c' of row r holds logical chunk c' ^ ((r>>1)&7)).
-template <int WT, int ET = 0>      // ET: 0 = bf16 operands, 1 = IEEE fp16 (v_mfma_f32_32x32x16_f16)
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p) {
+// WG = waves per tile axis: 2 (4 waves, tile 64*WT square, two workgroups per CU) or 4 (16 waves, tile
+// 128*WT square, one workgroup per CU -- per MFMA half the LDS-DMA bytes of the 4-wave tile, which is
+// what bounds the kernel: a 128 x 128 tile needs the full 64 B/clk/CU of the vector-memory path to
+// keep the MFMA pipe busy, a 256 x 256 tile half of it).
+template <int WT, int ET = 0, int WG = 2>      // ET: 0 = bf16 operands, 1 = IEEE fp16 (v_mfma_f32_32x32x16_f16)
+__global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 1) void conv_wgrad_bf16_kernel(WgradHParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     constexpr int BLK = TM * 64;                     // elements of one [64][64] block
-    unsigned short* Ya = smem;                       // [2][WT][64][64]
-    unsigned short* Xa = smem + 2 * WT * BLK;        // [2][WT][64][64]
+    constexpr int CB = WG * WT / 2 > 0 ? WG * WT / 2 : 1;   // 64-column blocks per operand
+    constexpr int NJ = WG == 2 ? 2 : 1;              // 8-row groups of a 64-row tile staged by one wave
+    constexpr int CBW = WG == 2 ? CB : CB / 2;       // column blocks staged by one wave (per operand)
+    constexpr int TILE = 32 * WT * WG;
+    static_assert(WG == 2 || (WG == 4 && WT == 2), "4 waves (2x2) or 16 waves (4x4, 2x2 MFMA tiles each)");
+    unsigned short* Ya = smem;                       // [2][CB][64][64]
+    unsigned short* Xa = smem + 2 * CB * BLK;        // [2][CB][64][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WG, wn = wave % WG;
     const int li = lane & 31, lh = lane >> 5;
+    const int rg0 = WG == 2 ? wave * 2 : (wave & 7);           // first row group this wave stages
+    const int cbw0 = WG == 2 ? 0 : (wave >> 3) * CBW;          // first column block this wave stages
 
     const int nwg = p.tiles_co * p.tiles_k * p.slices;
     int b;
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
     const int slice = b / tiles;
     b -= slice * tiles;
     const int tk = b % p.tiles_k, tco = b / p.tiles_k;
-    const int co0 = tco * 64 * WT, k0 = tk * 64 * WT;
+    const int co0 = tco * TILE, k0 = tk * TILE;
     const int m_begin = slice * p.rows_per_slice;
     const int m_end = min(p.M, m_begin + p.rows_per_slice);
     if (m_begin >= m_end) return;
@@ -94,16 +105,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
     // (two divisions, a segment search) advances incrementally from tile to tile -- one
     // conditional wrap per 64-row step on maps at least 64 wide; narrower maps and the first row
     // after a map boundary take the full decode.
-    int c_yoff[2][WT], c_xoff[2][WT], c_kh[2][WT], c_kw[2][WT];     // -1: column out of range
+    int c_yoff[NJ][CBW], c_xoff[NJ][CBW], c_kh[NJ][CBW], c_kw[NJ][CBW];     // -1: column out of range
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int row = (wave * 2 + j) * 8 + rg_row;
+    for (int j = 0; j < NJ; j++) {
+        const int row = (rg0 + j) * 8 + rg_row;
         const int lc = (pc ^ ((row >> 1) & 7)) * 8;              // logical column of this lane's chunk
 #pragma unroll
-        for (int cb = 0; cb < WT; cb++) {
-            const int co = co0 + cb * 64 + lc;
+        for (int cb = 0; cb < CBW; cb++) {
+            const int co = co0 + (cbw0 + cb) * 64 + lc;
             c_yoff[j][cb] = co < p.Cout ? co : -1;
-            const int k = k0 + cb * 64 + lc;
+            const int k = k0 + (cbw0 + cb) * 64 + lc;
             c_xoff[j][cb] = -1;
             c_kh[j][cb] = c_kw[j][cb] = 0;
             if (k < p.K) {
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
             }
         }
     }
-    int s_ho[2], s_wo[2], s_rb[2], s_H[2], s_W[2], s_Ho[2], s_Wo[2], s_end[2] = {0, 0};
+    int s_ho[NJ], s_wo[NJ], s_rb[NJ], s_H[NJ], s_W[NJ], s_Ho[NJ], s_Wo[NJ], s_end[NJ] = {};
     auto decode = [&](int m, int j) {
         int sg = 0;
         if (p.nseg > 1) {       // single-map layers keep the geometry in scalar registers
@@ -135,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
     };
     auto dma_tile = [&](int mt, int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int m = mt + (wave * 2 + j) * 8 + rg_row;
+        for (int j = 0; j < NJ; j++) {
+            const int m = mt + (rg0 + j) * 8 + rg_row;
             const bool m_ok = m < m_end;
             if (m_ok) {
                 if (m >= s_end[j] || s_Wo[j] < TM) {
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
             }
             const int hi0 = s_ho[j] * p.stride - p.pad, wi0 = s_wo[j] * p.stride - p.pad;
 #pragma unroll
-            for (int cb = 0; cb < WT; cb++) {
+            for (int cb = 0; cb < CBW; cb++) {
                 const int offy = (m_ok && c_yoff[j][cb] >= 0) ? (m * p.Cout + c_yoff[j][cb]) * 2 : OOB;
                 int offx = OOB;
                 if (m_ok && c_xoff[j][cb] >= 0) {
@@ -167,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
                     if ((unsigned)hi < (unsigned)s_H[j] && (unsigned)wi < (unsigned)s_W[j])
                         offx = (s_rb[j] + ((c_kh[j][cb] - p.pad) * s_W[j] + wi) * p.pitch + c_xoff[j][cb]) * 2;
                 }
-                unsigned short* dy_dst = Ya + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
-                unsigned short* x_dst = Xa + (buf * WT + cb) * BLK + (wave * 2 + j) * 8 * 64;
+                unsigned short* dy_dst = Ya + (buf * CB + cbw0 + cb) * BLK + (rg0 + j) * 8 * 64;
+                unsigned short* x_dst = Xa + (buf * CB + cbw0 + cb) * BLK + (rg0 + j) * 8 * 64;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)dy_dst, 16, offy, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)x_dst, 16, offx, 0, 0, 0);
             }
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradHParams p)
     int cur = 0;
     for (int mt = m_begin; mt < m_end; mt += TM) {
         if (mt + TM < m_end) dma_tile(mt + TM, cur ^ 1);
-        const unsigned boff = cur * (WT * BLK * 2);
+        const unsigned boff = cur * (CB * BLK * 2);
         frag_read(0, 0, boff);
         frag_wait(0);
 #pragma unroll
@@ -282,9 +293,10 @@ void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
     *shift = l;
 }
 
-template <int WT, int ET = 0>
+template <int WT, int ET = 0, int WG = 2>
 int launch(WgradHParams& p, hipStream_t s) {
-    const int T = 64 * WT;
+    const int T = 32 * WT * WG;
+    constexpr int CB = WG * WT / 2 > 0 ? WG * WT / 2 : 1;
     p.tiles_co = (p.Cout + T - 1) / T;
     p.tiles_k = (p.K + T - 1) / T;
     const int tiles = p.tiles_co * p.tiles_k;
@@ -293,7 +305,7 @@ int launch(WgradHParams& p, hipStream_t s) {
     // tile of fp32 atomics into dW), each at least `minrows` reduction rows deep
     static int slots_env = getenv("BRCNN_WG_SLOTS") ? atoi(getenv("BRCNN_WG_SLOTS")) : 0;
     static int minrows = getenv("BRCNN_WG_MINROWS") ? atoi(getenv("BRCNN_WG_MINROWS")) : 1024;
-    const int slots = slots_env ? slots_env : (WT == 2 ? 512 : 1024);
+    const int slots = slots_env ? slots_env : (WG == 4 ? 256 : WT == 2 ? 512 : 1024);
     int slices = slots / tiles;
     const int max_slices = (p.M + minrows - 1) / minrows;
     if (slices > max_slices) slices = max_slices;
@@ -302,19 +314,19 @@ int launch(WgradHParams& p, hipStream_t s) {
     rps = (rps + TM - 1) / TM * TM;
     p.slices = (p.M + rps - 1) / rps;
     p.rows_per_slice = rps;
-    const size_t lds = (size_t)2 * 2 * WT * TM * 64 * sizeof(unsigned short);
+    const size_t lds = (size_t)2 * 2 * CB * TM * 64 * sizeof(unsigned short);
     static bool attr_done = false;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<WT, ET>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<WT, ET, WG>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WT, ET>), dim3(tiles * p.slices), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WT, ET, WG>), dim3(tiles * p.slices), dim3(64 * WG * WG), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
 
-int g_wgrad_bf16_tile = 0;      // tuning hook: 0 heuristic, 1 = 64x64, 2 = 128x128
+int g_wgrad_bf16_tile = 0;      // tuning hook: 0 heuristic, 1 = 64x64, 2 = 128x128, 4 = 256x256 (16 waves)
 
 }  // namespace
 
@@ -348,13 +360,23 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
     p.dy_bytes = (unsigned)(m_total * cout * 2);
     p.x_bytes = (unsigned)(x_off * 2);
     int wt = g_wgrad_bf16_tile;
-    if (wt == 0) wt = (cout >= 128 && p.K >= 256) ? 2 : 1;
+    if (wt == 0) {
+        wt = (cout >= 128 && p.K >= 256) ? 2 : 1;
+        // 256 x 256 on 16 waves where the 128 x 128 tile is bound by its LDS-DMA traffic and one generation
+        // of 256 workgroups still has enough reduction rows each: the five-level tower layer (537 -> 912
+        // TFLOP/s), the first FC (384 -> 676).  Every workgroup ends with a full tile of fp32 atomics (their
+        // volume is workgroups x tile area whatever the layer: 67 MB here, 33 MB for the 128 x 128 tile, at
+        // 2-3 TB/s), which is what keeps the medium layers (M = 33 600) on the smaller tile.
+        const long long t256 = (long long)((cout + 255) / 256) * ((p.K + 255) / 256);
+        if (cout >= 256 && p.K >= 1024 && (p.M >= 100000 || t256 >= 128)) wt = 4;
+    }
+    if (wt == 4) return f16 ? launch<2, 1, 4>(p, stream) : launch<2, 0, 4>(p, stream);
     if (f16) return wt == 2 ? launch<2, 1>(p, stream) : launch<1, 1>(p, stream);
     return wt == 2 ? launch<2>(p, stream) : launch<1>(p, stream);
 }
 
 BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
-    if (wt < 0 || wt > 2) return BRCNN_EINVAL;
+    if (wt < 0 || wt == 3 || wt > 4) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;
 }

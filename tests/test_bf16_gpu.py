@@ -208,7 +208,7 @@ def test_conv_autograd_bf16(cfg):
 
 
 def test_wgrad_bf16_tiles_and_multi_level_agree():
-    """64x64 and 128x128 output tiles, one multi-level launch vs per-level launches"""
+    """64x64, 128x128 and 256x256 (16-wave) output tiles, one multi-level launch vs per-level launches"""
     from brcnn import lib
     from brcnn.autograd import ConvNHWCFunction
     g = torch.Generator().manual_seed(6)
@@ -217,7 +217,7 @@ def test_wgrad_bf16_tiles_and_multi_level_agree():
     feats = [torch.randn(B * h * w, C, generator=g).to(DEV, BF) for h, w in sizes]
     wt = (torch.randn(C, C, 3, 3, generator=g) / 48).to(DEV)
     outs = {}
-    for tile in (1, 2):
+    for tile in (1, 2, 4):
         lib.load().brcnn_conv_set_tile_wgrad_bf16(tile)
         w1 = wt.clone().requires_grad_()
         xc = torch.cat(feats, 0).requires_grad_()
@@ -227,7 +227,8 @@ def test_wgrad_bf16_tiles_and_multi_level_agree():
         outs[tile] = (w1.grad.clone(), xc.grad.clone())
     lib.load().brcnn_conv_set_tile_wgrad_bf16(0)
     assert torch.allclose(outs[1][0], outs[2][0], rtol=1e-4, atol=1e-3)      # atomics order differs
-    assert torch.equal(outs[1][1], outs[2][1])
+    assert torch.allclose(outs[4][0], outs[2][0], rtol=1e-4, atol=1e-3)
+    assert torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[4][1], outs[2][1])
     acc, o = torch.zeros_like(wt), 0
     for f, (h, w) in zip(feats, sizes):
         w2 = wt.clone().requires_grad_()
