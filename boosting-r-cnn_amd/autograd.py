@@ -425,14 +425,15 @@ class BnEvalActFunction(Function):
         st = _L.load().brcnn_bn_eval_act_forward(_ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), float(eps),
                                                  _ptr(r), _ptr(out), rows, c, int(relu), dt, _stream())
         _L.check(st, 'brcnn_bn_eval_act_forward')
-        ctx.save_for_backward(z, g32, m32, v32, out if relu else None)
+        # without a residual the backward recomputes the ReLU mask from z and does not read `out`
+        ctx.save_for_backward(z, g32, b32, m32, v32, out if relu and res is not None else None)
         ctx.cfg = (relu, res is not None, dt, rows, c, float(eps), gamma.dtype, beta.dtype)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        z, g32, m32, v32, out = ctx.saved_tensors
+        z, g32, b32, m32, v32, out = ctx.saved_tensors
         relu, has_res, dt, rows, c, eps, gdt, bdt = ctx.cfg
         dout = dout.to(z.dtype).contiguous()
         dz = torch.empty_like(z)
@@ -442,7 +443,7 @@ class BnEvalActFunction(Function):
         lib = _L.load()
         nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
         ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
-        st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(m32), _ptr(v32), eps,
+        st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), eps,
                                             _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
                                             int(relu), dt, _stream())
         _L.check(st, 'brcnn_bn_eval_act_backward')

@@ -6,7 +6,7 @@
 //             dz = dpre * scale[c],  dres = dpre,  dscale[c] = sum_m dpre*z,  dshift[c] = sum_m dpre
 // HBM-bound streams over (rows, C) NHWC tensors, 16 bytes per lane; the per-channel sums are
 // reduced per thread over a strip of rows, across the row lanes of a workgroup through LDS, and
-// leave with one fp32 atomic per channel and workgroup.  The reference reaches the same
+// leave as per-strip partials that a second launch sums in a fixed order (deterministic).  The reference reaches the same
 // arithmetic through ~9 separate torch kernels per block (mul, add, add, relu; threshold_backward,
 // mul, mul, 2 x sum).
 #include "common.h"
@@ -128,48 +128,76 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ dout,
                                                         const T* __restrict__ out,
                                                         const T* __restrict__ z,
-                                                        const float* __restrict__ scale, const BnStats bn,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const BnStats bn,
                                                         T* __restrict__ dz, T* __restrict__ dres,
                                                         float* __restrict__ partial, long long rows,
                                                         int C, int relu, int rows_per_block, int CW) {
+    // `out` NULL with relu: the forward had no residual, the mask is recomputed as z * scale + shift > 0
+    // (the forward's own fp32 expression) and the `out` stream is not read at all
     constexpr int V = Vec<T>::N;
     __shared__ float red[2][256][V];
+    const bool zmask = relu && out == nullptr;
     const int cvn = C / V;
     const int cv = blockIdx.y * CW + (threadIdx.x % CW);
     const int rl = threadIdx.x / CW, RL = 256 / CW;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    float ss[V], sh[V], sc[V];
+    float ss[V], sh[V], sc[V], sf[V];
     {   // the CW channel vectors of this workgroup, derived once and shared by its row lanes
         float* s_sc = &red[0][0][0];
+        float* s_sf = &red[1][0][0];
         for (int i = threadIdx.x; i < CW * V; i += 256) {
             const int c = blockIdx.y * CW * V + i;
-            float unused, v = 0.f;
-            if (c < C) bn_affine(scale, nullptr, bn, c, v, unused);
+            float f = 0.f, v = 0.f;
+            if (c < C) bn_affine(scale, zmask ? shift : nullptr, bn, c, v, f);
             s_sc[i] = v;
+            s_sf[i] = f;
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < V; e++) { ss[e] = 0.f; sh[e] = 0.f; sc[e] = s_sc[(threadIdx.x % CW) * V + e]; }
+        for (int e = 0; e < V; e++) {
+            ss[e] = 0.f; sh[e] = 0.f;
+            sc[e] = s_sc[(threadIdx.x % CW) * V + e];
+            sf[e] = s_sf[(threadIdx.x % CW) * V + e];
+        }
         __syncthreads();
     }
     if (cv < cvn) {
-        for (long long r = r0 + rl; r < r1; r += RL) {
-            const long long idx = (r * cvn + cv) * V;
-            float g[V], o[V], zz[V], gz[V];
-            ldv(dout + idx, g);
-            if (relu) ldv(out + idx, o);
-            ldv(z + idx, zz);
+        // U rows of the strip in flight per lane (with ~512 workgroups the loads of ONE row per lane do not
+        // cover the HBM latency; more workgroups would grow the per-strip partials the second stage reads)
+        constexpr int U = 4;
+        for (long long r = r0 + rl; r < r1; r += (long long)RL * U) {
+            float g[U][V], o[U][V], zz[U][V];
 #pragma unroll
-            for (int e = 0; e < V; e++) {
-                const float d = (!relu || o[e] > 0.f) ? g[e] : 0.f;
-                g[e] = d;
-                ss[e] += d * zz[e];
-                sh[e] += d;
-                gz[e] = d * sc[e];
+            for (int u = 0; u < U; u++) {
+                const long long rr = r + (long long)u * RL;
+                if (rr < r1) {
+                    const long long idx = (rr * cvn + cv) * V;
+                    ldv(dout + idx, g[u]);
+                    if (relu && !zmask) ldv(out + idx, o[u]);
+                    ldv(z + idx, zz[u]);
+                }
             }
-            stv(dz + idx, gz);
-            if (dres) stv(dres + idx, g);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long long rr = r + (long long)u * RL;
+                if (rr < r1) {
+                    const long long idx = (rr * cvn + cv) * V;
+                    float gz[V];
+#pragma unroll
+                    for (int e = 0; e < V; e++) {
+                        const float ov = zmask ? zz[u][e] * sc[e] + sf[e] : o[u][e];
+                        const float d = (!relu || ov > 0.f) ? g[u][e] : 0.f;
+                        g[u][e] = d;
+                        ss[e] += d * zz[u][e];
+                        sh[e] += d;
+                        gz[e] = d * sc[e];
+                    }
+                    stv(dz + idx, gz);
+                    if (dres) stv(dres + idx, g[u]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -208,24 +236,25 @@ __global__ __launch_bounds__(1024) void bn_act_reduce_kernel(const float* __rest
 
 // second stage when the affine is an eval-mode BatchNorm: the gradients of gamma / beta themselves,
 //   dbeta = sum dshift,   dgamma = (sum dscale - mean * sum dshift) / sqrt(var + eps)
+// (16 columns x 64 strip lanes per workgroup: C / 16 workgroups, the launch is latency sized)
 __global__ __launch_bounds__(1024) void bn_eval_reduce_kernel(const float* __restrict__ partial, const BnStats bn,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int strips, int C) {
-    __shared__ float red[2][16][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    __shared__ float red[2][64][16];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
     float a = 0.f, b = 0.f;
     if (col < C)
-        for (int s = sl; s < strips; s += 16) {
+        for (int s = sl; s < strips; s += 64) {
             a += partial[((size_t)s * 2 + 0) * C + col];
             b += partial[((size_t)s * 2 + 1) * C + col];
         }
-    red[0][sl][threadIdx.x & 63] = a;
-    red[1][sl][threadIdx.x & 63] = b;
+    red[0][sl][threadIdx.x & 15] = a;
+    red[1][sl][threadIdx.x & 15] = b;
     __syncthreads();
     if (sl == 0 && col < C) {
         float ta = 0.f, tb = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { ta += red[0][k][threadIdx.x]; tb += red[1][k][threadIdx.x]; }
+        for (int k = 0; k < 64; k++) { ta += red[0][k][threadIdx.x]; tb += red[1][k][threadIdx.x]; }
         dgamma[col] = (ta - bn.mean[col] * tb) / sqrtf(bn.var[col] + bn.eps);
         dbeta[col] = tb;
     }
@@ -234,15 +263,22 @@ __global__ __launch_bounds__(1024) void bn_eval_reduce_kernel(const float* __res
 struct BwdPlan { int CW, chunks; long long strips, rpb; };
 inline bool bwd_plan(long long rows, int channels, int V, BwdPlan* pl) {
     const int cvn = channels / V;
+    // short maps (stage 4: 8 400 rows x 512 / 2048 channels) split the channels too, so that ~1024 workgroups
+    // of >= 32 rows exist; long maps keep whole rows per workgroup and ~512 strips (the second stage reads
+    // strips x 2 x C partials, more strips cost there what they gain here)
+    const bool short_map = rows < 16384;
+    const int cw_max = short_map ? 64 : 256;
+    const int wg_target = short_map ? 1024 : 512;
+    const int min_rows = short_map ? 32 : 64;
     int CW = 1;
-    while (CW < cvn && CW < 256) CW <<= 1;
-    if (cvn < 256 && CW != cvn) return false;      // channel-vector count must be a power of two
+    while (CW < cvn && CW < cw_max) CW <<= 1;
+    if (cvn < cw_max && CW != cvn) return false;      // channel-vector count must be a power of two
     pl->CW = CW;
     pl->chunks = (cvn + CW - 1) / CW;
-    long long strips = 512 / pl->chunks;           // ~512 workgroups, strips of at least 64 rows
+    long long strips = wg_target / pl->chunks;
     if (strips < 1) strips = 1;
     long long rpb = (rows + strips - 1) / strips;
-    if (rpb < 64) rpb = 64;
+    if (rpb < min_rows) rpb = min_rows;
     pl->rpb = rpb;
     pl->strips = rows > 0 ? (rows + rpb - 1) / rpb : 0;
     return true;
@@ -318,11 +354,11 @@ BRCNN_API size_t brcnn_bn_act_backward_workspace_bytes(int64_t rows, int channel
     return (size_t)(pl.strips > 0 ? pl.strips : 1) * 2 * channels * sizeof(float);
 }
 
-static int backward_impl(const void* dout, const void* out, const void* z, const float* scale, const BnStats bn,
-                         void* dz, void* dres, float* dscale, float* dshift, void* workspace,
+static int backward_impl(const void* dout, const void* out, const void* z, const float* scale, const float* shift,
+                         const BnStats bn, void* dz, void* dres, float* dscale, float* dshift, void* workspace,
                          size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype, void* stream) {
     if (!dout || !z || !scale || !dz || !dscale || !dshift || !workspace || rows < 0 || channels <= 0 ||
-        (relu && !out) || !brcnn_elem_ok(dtype))
+        (relu && !out && !shift) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
     const int V = dtype == BRCNN_DT_F32 ? 4 : 8;
     if (channels % V) return BRCNN_EINVAL;
@@ -337,19 +373,19 @@ static int backward_impl(const void* dout, const void* out, const void* z, const
     }
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
-                           (const float*)dout, (const float*)out, (const float*)z, scale, bn, (float*)dz, (float*)dres,
+                           (const float*)dout, (const float*)out, (const float*)z, scale, shift, bn, (float*)dz, (float*)dres,
                            (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
-                           (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)z, scale, bn, (bf16_t*)dz,
+                           (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)z, scale, shift, bn, (bf16_t*)dz,
                            (bf16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     else
         hipLaunchKernelGGL(bn_act_bwd_kernel<f16_t>, dim3((unsigned)pl.strips, pl.chunks), dim3(256), 0, s,
-                           (const f16_t*)dout, (const f16_t*)out, (const f16_t*)z, scale, bn, (f16_t*)dz,
+                           (const f16_t*)dout, (const f16_t*)out, (const f16_t*)z, scale, shift, bn, (f16_t*)dz,
                            (f16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     BRCNN_LAUNCH_CHECK();
     if (bn.mean)
-        hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s,
+        hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 15) / 16), dim3(1024), 0, s,
                            (const float*)workspace, bn, dscale, dshift, (int)pl.strips, channels);
     else
         hipLaunchKernelGGL(bn_act_reduce_kernel, dim3((channels + 63) / 64, 2), dim3(1024), 0, s,
@@ -363,16 +399,17 @@ BRCNN_API int brcnn_bn_act_backward(const void* dout, const void* out, const voi
                                     size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
                                     void* stream) {
     BnStats bn = {nullptr, nullptr, 0.f};
-    return backward_impl(dout, out, z, scale, bn, dz, dres, dscale, dshift, workspace, workspace_bytes, rows, channels,
+    return backward_impl(dout, out, z, scale, nullptr, bn, dz, dres, dscale, dshift, workspace, workspace_bytes, rows, channels,
                          relu, dtype, stream);
 }
 
 BRCNN_API int brcnn_bn_eval_act_backward(const void* dout, const void* out, const void* z, const float* gamma,
-                                         const float* mean, const float* var, float eps, void* dz, void* dres,
+                                         const float* beta, const float* mean, const float* var, float eps, void* dz, void* dres,
                                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                          int64_t rows, int channels, int relu, int dtype, void* stream) {
     if (!mean || !var) return BRCNN_EINVAL;
     BnStats bn = {mean, var, eps};
-    return backward_impl(dout, out, z, gamma, bn, dz, dres, dgamma, dbeta, workspace, workspace_bytes, rows, channels,
+    if (!out && dres) return BRCNN_EINVAL;       // a residual forward needs its output for the mask
+    return backward_impl(dout, out, z, gamma, beta, bn, dz, dres, dgamma, dbeta, workspace, workspace_bytes, rows, channels,
                          relu, dtype, stream);
 }

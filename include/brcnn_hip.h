@@ -359,8 +359,11 @@ int brcnn_bn_act_backward(const void *dout, const void *out, const void *z, cons
 int brcnn_bn_eval_act_forward(const void *z, const float *gamma, const float *beta, const float *mean,
                               const float *var, float eps, const void *residual, void *out, int64_t rows,
                               int channels, int relu, int dtype, void *stream);
+/* `out` (the forward output, read for the ReLU mask) may be NULL when the forward had NO residual and
+ * `beta` is given: the mask is then recomputed as z * scale + shift > 0 and one of the four streams
+ * of the backward pass is not read at all. */
 int brcnn_bn_eval_act_backward(const void *dout, const void *out, const void *z, const float *gamma,
-                               const float *mean, const float *var, float eps, void *dz, void *dres,
+                               const float *beta, const float *mean, const float *var, float eps, void *dz, void *dres,
                                float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
                                int64_t rows, int channels, int relu, int dtype, void *stream);
 
