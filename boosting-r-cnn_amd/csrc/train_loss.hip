@@ -52,6 +52,8 @@ struct RpnLossParams {
     float mean[4], std[4], max_ratio;
     int with_aug;
     float lw_cls, lw_bbox, lw_aug, lw_iou;
+    int cls_mode;              // 0 FocalLoss, 1 VarifocalLoss (iou_weighted), 2 VarifocalLoss (not iou_weighted)
+    int reg_mode;              // 0 decoded boxes: -log(IoU) [+ MSE aug], 1 reg_decoded_bbox=False: CIoU(deltas, encoded targets)
 };
 
 enum { S_FOCAL = 0, S_IOU, S_MSE, S_BCE, S_IOUT, S_NPOS, S_N };
@@ -75,6 +77,76 @@ __device__ __forceinline__ float pow_gamma(float x, float g) {      // tensor **
     if (g == 1.f) return x;
     if (g == 2.f) return x * x;
     return powf(x, g);
+}
+
+// VarifocalLoss element (losses/varifocal_loss.py:10-58): BCE-with-logits(x, t) * (t [or 1] for t > 0,
+// alpha * |sigmoid(x) - t|^gamma for t <= 0); t is detached
+__device__ __forceinline__ float bce_logits(float x, float t) { return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float vfl_fwd(float x, float t, float gamma, float alpha, bool iou_weighted) {
+    if (t > 0.f) return bce_logits(x, t) * (iou_weighted ? t : 1.f);
+    const float s = sigmoidf_(x);
+    return bce_logits(x, t) * (alpha * powf(fabsf(s - t), gamma));
+}
+__device__ __forceinline__ float vfl_bwd(float x, float t, float gamma, float alpha, bool iou_weighted) {
+    const float s = sigmoidf_(x);
+    if (t > 0.f) return (s - t) * (iou_weighted ? t : 1.f);
+    const float u = s - t, au = fabsf(u);
+    const float fw = alpha * powf(au, gamma);
+    const float dfw = au > 0.f ? alpha * gamma * powf(au, gamma - 1.f) * (u > 0.f ? 1.f : -1.f) * s * (1.f - s) : 0.f;
+    return (s - t) * fw + bce_logits(x, t) * dfw;
+}
+
+// Complete-IoU loss of (p, q) as the reference applies it to RAW deltas (reg_decoded_bbox=False with
+// loss_bbox=CIoULoss: atss_rpn_head.py:361-374, losses/iou_loss.py:175-236, eps 1e-6); `grad` (optional)
+// receives d loss / d p with torch's conventions (ties of max / min split evenly, clamp passes at the bound)
+__device__ __forceinline__ float ciou_terms(const float4 p, const float4 q, float eps, float* grad) {
+    const float ltx = fmaxf(p.x, q.x), lty = fmaxf(p.y, q.y), rbx = fminf(p.z, q.z), rby = fminf(p.w, q.w);
+    const float wr = rbx - ltx, hr = rby - lty;
+    const float w = wr < 0.f ? 0.f : wr, h = hr < 0.f ? 0.f : hr;
+    const float ov = w * h;
+    const float bw = p.z - p.x, bh = p.w - p.y;
+    const float ap = bw * bh, ag = (q.z - q.x) * (q.w - q.y);
+    const float un = ap + ag - ov + eps;
+    const float iou = ov / un;
+    const float cwr = fmaxf(p.z, q.z) - fminf(p.x, q.x), chr = fmaxf(p.w, q.w) - fminf(p.y, q.y);
+    const float cw = cwr < 0.f ? 0.f : cwr, ch = chr < 0.f ? 0.f : chr;
+    const float c2 = cw * cw + ch * ch + eps;
+    const float w1 = bw, h1 = bh + eps, w2 = q.z - q.x, h2 = q.w - q.y + eps;
+    const float sx = (q.x + q.z) - (p.x + p.z), sy = (q.y + q.w) - (p.y + p.w);
+    const float rho2 = sx * sx / 4.f + sy * sy / 4.f;
+    const float F = 0.40528473456935116f;            // 4 / pi^2
+    const float r1 = w1 / h1;
+    const float at = atanf(w2 / h2) - atanf(r1);
+    const float v = F * (at * at);
+    const float alpha = iou > 0.5f ? v / (1.f - iou + v) : 0.f;
+    const float ci = iou - (rho2 / c2 + alpha * v);
+    const float loss = 1.f - fminf(fmaxf(ci, -1.f), 1.f);
+    if (grad) {
+        float gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f;
+        const float g_ci = (ci >= -1.f && ci <= 1.f) ? -1.f : 0.f;
+        const float g_rho2 = -g_ci / c2, g_c2 = g_ci * rho2 / (c2 * c2), g_v = -g_ci * alpha;
+        const float g_ov = g_ci / un, g_un = -g_ci * ov / (un * un);
+        const float g_ovt = g_ov - g_un;
+        const float g_w = wr >= 0.f ? g_ovt * h : 0.f, g_h = hr >= 0.f ? g_ovt * w : 0.f;
+        const float kx1 = p.x > q.x ? 1.f : (p.x == q.x ? 0.5f : 0.f), ky1 = p.y > q.y ? 1.f : (p.y == q.y ? 0.5f : 0.f);
+        const float kx2 = p.z < q.z ? 1.f : (p.z == q.z ? 0.5f : 0.f), ky2 = p.w < q.w ? 1.f : (p.w == q.w ? 0.5f : 0.f);
+        gx1 += -g_w * kx1 - g_un * bh;
+        gy1 += -g_h * ky1 - g_un * bw;
+        gx2 += g_w * kx2 + g_un * bh;
+        gy2 += g_h * ky2 + g_un * bw;
+        const float g_cw = cwr >= 0.f ? g_c2 * 2.f * cw : 0.f, g_ch = chr >= 0.f ? g_c2 * 2.f * ch : 0.f;
+        const float mx1 = p.x < q.x ? 1.f : (p.x == q.x ? 0.5f : 0.f), my1 = p.y < q.y ? 1.f : (p.y == q.y ? 0.5f : 0.f);
+        const float mx2 = p.z > q.z ? 1.f : (p.z == q.z ? 0.5f : 0.f), my2 = p.w > q.w ? 1.f : (p.w == q.w ? 0.5f : 0.f);
+        gx1 += -g_cw * mx1; gx2 += g_cw * mx2;
+        gy1 += -g_ch * my1; gy2 += g_ch * my2;
+        const float grx = g_rho2 * (-sx * 0.5f), gry = g_rho2 * (-sy * 0.5f);
+        gx1 += grx; gx2 += grx; gy1 += gry; gy2 += gry;
+        const float g_r1 = -(g_v * F * 2.f * at) / (r1 * r1 + 1.f);
+        const float g_w1 = g_r1 / h1, g_h1 = -g_r1 * w1 / (h1 * h1);
+        gx2 += g_w1; gx1 -= g_w1; gy2 += g_h1; gy1 -= g_h1;
+        grad[0] = gx1; grad[1] = gy1; grad[2] = gx2; grad[3] = gy2;
+    }
+    return loss;
 }
 
 struct PosTerms {
@@ -115,9 +187,18 @@ __device__ __forceinline__ void pos_terms(const RpnLossParams& p, int l, int cel
     t.enc.y = ((ggy - py) / t.ph - p.mean[1]) / p.std[1];
     t.enc.z = (logf(ggw / t.pw) - p.mean[2]) / p.std[2];
     t.enc.w = (logf(ggh / t.ph) - p.mean[3]) / p.std[3];
-    // iou_target = bbox_overlaps(pred, gt, is_aligned=True)
-    const float a1 = (t.box.z - t.box.x) * (t.box.w - t.box.y), a2 = (g.z - g.x) * (g.w - g.y);
-    float w = fminf(t.box.z, g.z) - fmaxf(t.box.x, g.x), h = fminf(t.box.w, g.w) - fmaxf(t.box.y, g.y);
+    float4 q = g;
+    if (p.reg_mode == 1) {
+        // reg_decoded_bbox=False: the target box of iou_target is decode(anchor, encoded target) (:362-367)
+        const float ex = t.enc.x * p.std[0] + p.mean[0], ey = t.enc.y * p.std[1] + p.mean[1];
+        const float ew = fminf(fmaxf(t.enc.z * p.std[2] + p.mean[2], -p.max_ratio), p.max_ratio);
+        const float eh = fminf(fmaxf(t.enc.w * p.std[3] + p.mean[3], -p.max_ratio), p.max_ratio);
+        const float qw = t.pw * expf(ew), qh = t.ph * expf(eh), qx = px + t.pw * ex, qy = py + t.ph * ey;
+        q = make_float4(qx - qw * 0.5f, qy - qh * 0.5f, qx + qw * 0.5f, qy + qh * 0.5f);
+    }
+    // iou_target = bbox_overlaps(pred, target box, is_aligned=True)
+    const float a1 = (t.box.z - t.box.x) * (t.box.w - t.box.y), a2 = (q.z - q.x) * (q.w - q.y);
+    float w = fminf(t.box.z, q.z) - fmaxf(t.box.x, q.x), h = fminf(t.box.w, q.w) - fmaxf(t.box.y, q.y);
     w = w < 0.f ? 0.f : w;
     h = h < 0.f ? 0.f : h;
     const float ov = w * h;
@@ -157,23 +238,32 @@ __global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(const RpnLossParams p
         const int b = (int)(row / p.lv.hw[l]), cell = (int)(row - (long long)b * p.lv.hw[l]);
         const float* yrow = p.y + (size_t)(p.lv.row0[l] + row) * p.ystride;
         const int gi = p.gt_inds[(size_t)b * p.anchors_per_image + p.lv.start[l] + cell * p.A + a];
-        if (gi >= 0) {
-            const bool pos = gi > 0;
-            float f = focal_fwd(yrow[a], pos, p.focal_gamma, p.focal_alpha);
-            if (pos && p.pos_weight > 0.f) f *= p.pos_weight;
-            acc[S_FOCAL] = f;
-            if (pos) {
-                PosTerms t;
-                const float4 g = *reinterpret_cast<const float4*>(p.gts + (size_t)(p.gt.off[b] + gi - 1) * 4);
-                pos_terms(p, l, cell, a, yrow, p.scales[l], g, t);
+        const bool pos = gi > 0;
+        float iou_t = 0.f;
+        if (pos) {
+            PosTerms t;
+            const float4 g = *reinterpret_cast<const float4*>(p.gts + (size_t)(p.gt.off[b] + gi - 1) * 4);
+            pos_terms(p, l, cell, a, yrow, p.scales[l], g, t);
+            iou_t = t.iou;
+            if (p.reg_mode == 1) {
+                acc[S_IOU] = ciou_terms(t.d, t.enc, 1e-6f, nullptr) * t.w;
+            } else {
                 acc[S_IOU] = -logf(fmaxf(t.iou, 1e-6f)) * t.w;
                 const float e0 = t.d.x - t.enc.x, e1 = t.d.y - t.enc.y, e2 = t.d.z - t.enc.z, e3 = t.d.w - t.enc.w;
                 acc[S_MSE] = p.with_aug ? (e0 * e0 * t.w + e1 * e1 * t.w + e2 * e2 * t.w + e3 * e3 * t.w) : 0.f;
-                const float x = yrow[5 * p.A + a];
-                acc[S_BCE] = fmaxf(x, 0.f) - x * t.iou + log1pf(expf(-fabsf(x)));
-                acc[S_IOUT] = t.iou;
-                acc[S_NPOS] = 1.f;
             }
+            const float x = yrow[5 * p.A + a];
+            acc[S_BCE] = bce_logits(x, t.iou);
+            acc[S_IOUT] = t.iou;
+            acc[S_NPOS] = 1.f;
+        }
+        if (p.cls_mode) {
+            // VarifocalLoss is called without label weights (:393-397): anchors outside the image count as negatives
+            acc[S_FOCAL] = vfl_fwd(yrow[a], iou_t, p.focal_gamma, p.focal_alpha, p.cls_mode == 1);
+        } else if (gi >= 0) {
+            float f = focal_fwd(yrow[a], pos, p.focal_gamma, p.focal_alpha);
+            if (pos && p.pos_weight > 0.f) f *= p.pos_weight;
+            acc[S_FOCAL] = f;
         }
     }
 #pragma unroll
@@ -249,19 +339,24 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(const RpnLossParams p
         const float inv_nts = coef[0], inv_baf = coef[1];
         float dcls = 0.f, diou = 0.f;
         float4 dreg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gi >= 0) {
-            const bool pos = gi > 0;
-            float f = focal_bwd(yrow[a], pos, p.focal_gamma, p.focal_alpha);
-            if (pos && p.pos_weight > 0.f) f *= p.pos_weight;
-            dcls = g3[0] * p.lw_cls * inv_nts * f;
-            if (pos) {
-                PosTerms t;
-                const float4 g = *reinterpret_cast<const float4*>(p.gts + (size_t)(p.gt.off[b] + gi - 1) * 4);
-                const float scale = p.scales[l];
-                pos_terms(p, l, cell, a, yrow, scale, g, t);
-                const float x = yrow[5 * p.A + a];
-                diou = g3[2] * p.lw_iou * inv_nts * (sigmoidf_(x) - t.iou);
-                const float gb = g3[1] * inv_baf * (p.with_aug ? 0.5f : 1.f);
+        const bool pos = gi > 0;
+        float iou_t = 0.f;
+        if (pos) {
+            PosTerms t;
+            const float4 g = *reinterpret_cast<const float4*>(p.gts + (size_t)(p.gt.off[b] + gi - 1) * 4);
+            const float scale = p.scales[l];
+            pos_terms(p, l, cell, a, yrow, scale, g, t);
+            iou_t = t.iou;
+            const float x = yrow[5 * p.A + a];
+            diou = g3[2] * p.lw_iou * inv_nts * (sigmoidf_(x) - t.iou);
+            const float gb = g3[1] * inv_baf * (p.with_aug ? 0.5f : 1.f);
+            if (p.reg_mode == 1) {
+                // CIoU(deltas, encoded targets) * w: the deltas ARE the loss's boxes, no decode in the chain
+                float gr[4];
+                ciou_terms(t.d, t.enc, 1e-6f, gr);
+                const float k = gb * p.lw_bbox * t.w;
+                dreg = make_float4(k * gr[0], k * gr[1], k * gr[2], k * gr[3]);
+            } else {
                 // ---- -log(clamp(IoU, 1e-6)) * w through the aligned IoU and the decode
                 float gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f;
                 {
@@ -303,9 +398,16 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(const RpnLossParams p
                     dreg.z += k * (t.d.z - t.enc.z);
                     dreg.w += k * (t.d.w - t.enc.w);
                 }
-                dsc = dreg.x * t.raw.x + dreg.y * t.raw.y + dreg.z * t.raw.z + dreg.w * t.raw.w;
-                dreg.x *= scale; dreg.y *= scale; dreg.z *= scale; dreg.w *= scale;
             }
+            dsc = dreg.x * t.raw.x + dreg.y * t.raw.y + dreg.z * t.raw.z + dreg.w * t.raw.w;
+            dreg.x *= scale; dreg.y *= scale; dreg.z *= scale; dreg.w *= scale;
+        }
+        if (p.cls_mode) {
+            dcls = g3[0] * p.lw_cls * inv_nts * vfl_bwd(yrow[a], iou_t, p.focal_gamma, p.focal_alpha, p.cls_mode == 1);
+        } else if (gi >= 0) {
+            float f = focal_bwd(yrow[a], pos, p.focal_gamma, p.focal_alpha);
+            if (pos && p.pos_weight > 0.f) f *= p.pos_weight;
+            dcls = g3[0] * p.lw_cls * inv_nts * f;
         }
         drow[a] = dcls;
         float* dr = drow + p.A + a * 4;
@@ -354,11 +456,15 @@ int fill_rpn_params(RpnLossParams& p, const float* y, int ystride, int batch, in
     }
     p.lv.row0[num_levels] = row; p.lv.start[num_levels] = start; p.lv.blk0[num_levels] = blk;
     p.anchors_per_image = start;
-    // cfg: [focal_gamma, focal_alpha, pos_weight, iou_gamma, mean4, std4, max_ratio, with_aug, lw_cls, lw_bbox, lw_aug, lw_iou]
+    // cfg (20 floats): [focal_gamma, focal_alpha, pos_weight, iou_gamma, mean4, std4, max_ratio, with_aug, lw_cls, lw_bbox,
+    //                   lw_aug, lw_iou, cls_mode, reg_mode]
     p.focal_gamma = cfg[0]; p.focal_alpha = cfg[1]; p.pos_weight = cfg[2]; p.iou_gamma = cfg[3];
     for (int k = 0; k < 4; k++) { p.mean[k] = cfg[4 + k]; p.std[k] = cfg[8 + k]; }
     p.max_ratio = cfg[12]; p.with_aug = cfg[13] != 0.f;
     p.lw_cls = cfg[14]; p.lw_bbox = cfg[15]; p.lw_aug = cfg[16]; p.lw_iou = cfg[17];
+    p.cls_mode = (int)cfg[18]; p.reg_mode = (int)cfg[19];
+    if (p.cls_mode < 0 || p.cls_mode > 2 || p.reg_mode < 0 || p.reg_mode > 1) return BRCNN_EINVAL;
+    if (p.reg_mode == 1) p.with_aug = 0;       // the aug MSE term only exists on the decoded branch (:329-359)
     return 0;
 }
 
@@ -521,11 +627,11 @@ BRCNN_API int brcnn_rpn_loss_forward(const float* y, int ystride, int batch, int
                                      const int* widths, const int* strides_w, const int* strides_h,
                                      const float* const* base_anchors, int anchors_per_cell, const float* scales,
                                      const int32_t* gt_inds, const float* gts, const int* gt_offsets_host,
-                                     const float* cfg18_host, void* workspace, size_t workspace_bytes, float* sums,
+                                     const float* cfg20_host, void* workspace, size_t workspace_bytes, float* sums,
                                      float* totals, void* stream) {
     RpnLossParams p;
     if (int st = fill_rpn_params(p, y, ystride, batch, num_levels, heights, widths, strides_w, strides_h, base_anchors,
-                                 anchors_per_cell, scales, gt_inds, gts, gt_offsets_host, cfg18_host))
+                                 anchors_per_cell, scales, gt_inds, gts, gt_offsets_host, cfg20_host))
         return st;
     const int blocks = p.lv.blk0[num_levels];
     if (!workspace || !sums || !totals || workspace_bytes < (size_t)blocks * S_N * sizeof(float)) return BRCNN_EINVAL;
@@ -537,13 +643,13 @@ BRCNN_API int brcnn_rpn_loss_forward(const float* y, int ystride, int batch, int
     return 0;
 }
 
-BRCNN_API int brcnn_rpn_loss_finalize(const float* sums, const float* totals, int num_levels, const float* cfg18_host,
+BRCNN_API int brcnn_rpn_loss_finalize(const float* sums, const float* totals, int num_levels, const float* cfg20_host,
                                       float* losses3, float* per_level, float* coef2, void* stream) {
-    if (!sums || !totals || !cfg18_host || !losses3 || !per_level || !coef2 || num_levels <= 0 ||
+    if (!sums || !totals || !cfg20_host || !losses3 || !per_level || !coef2 || num_levels <= 0 ||
         num_levels > BRCNN_MAX_LEVELS)
         return BRCNN_EINVAL;
     hipLaunchKernelGGL(rpn_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, totals, num_levels,
-                       cfg18_host[13] != 0.f ? 1 : 0, cfg18_host[14], cfg18_host[15], cfg18_host[16], cfg18_host[17],
+                       (cfg20_host[13] != 0.f && cfg20_host[19] == 0.f) ? 1 : 0, cfg20_host[14], cfg20_host[15], cfg20_host[16], cfg20_host[17],
                        losses3, per_level, coef2);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -553,12 +659,12 @@ BRCNN_API int brcnn_rpn_loss_backward(const float* y, int ystride, int batch, in
                                       const int* widths, const int* strides_w, const int* strides_h,
                                       const float* const* base_anchors, int anchors_per_cell, const float* scales,
                                       const int32_t* gt_inds, const float* gts, const int* gt_offsets_host,
-                                      const float* cfg18_host, const float* grad3, const float* coef2,
+                                      const float* cfg20_host, const float* grad3, const float* coef2,
                                       void* workspace, size_t workspace_bytes, float* dy, float* dscales,
                                       void* stream) {
     RpnLossParams p;
     if (int st = fill_rpn_params(p, y, ystride, batch, num_levels, heights, widths, strides_w, strides_h, base_anchors,
-                                 anchors_per_cell, scales, gt_inds, gts, gt_offsets_host, cfg18_host))
+                                 anchors_per_cell, scales, gt_inds, gts, gt_offsets_host, cfg20_host))
         return st;
     const int blocks = p.lv.blk0[num_levels];
     if (!workspace || !grad3 || !coef2 || !dy || !dscales || workspace_bytes < (size_t)blocks * sizeof(float))

@@ -465,18 +465,39 @@ class ATSSRPNHead(AnchorHead):
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox, loss_rpn_iou=losses_iou)
 
     # ------------------------------------------------------------------ device-resident train step
+    def _fused_loss_modes(self):
+        """(cls_mode, reg_mode) of `brcnn_rpn_loss_*` for this head's loss configuration, or None when the
+        kernels do not cover it.  Covered: FocalLoss / VarifocalLoss classification; decoded regression with
+        IoULoss('log') [+ MSELoss aug] or raw-delta regression with CIoULoss (reg_decoded_bbox=False)."""
+        from .losses import CIoULoss, FocalLoss, IoULoss, MSELoss, VarifocalLoss
+        if type(self.loss_cls) is FocalLoss:
+            cls_mode = 0
+        elif type(self.loss_cls) is VarifocalLoss and self.loss_cls.use_sigmoid:
+            cls_mode = 1 if self.loss_cls.iou_weighted else 2
+        else:
+            return None
+        if self.loss_cls.reduction != 'mean' or self.loss_bbox.reduction != 'mean':
+            return None
+        if self.reg_decoded_bbox:
+            if not (type(self.loss_bbox) is IoULoss and self.loss_bbox.mode == 'log'):
+                return None
+            if self.with_aug_loss and not (type(self.aug_loss) is MSELoss and self.aug_loss.reduction == 'mean'):
+                return None
+            return cls_mode, 0
+        if type(self.loss_bbox) is CIoULoss and self.loss_bbox.eps == 1e-6:
+            return cls_mode, 1
+        return None
+
     def device_train_ok(self):
-        """the recipe family the fused target / loss kernels cover (UTDAC, COCO-PAFPN, R101, X101, Res2Net
-        recipes): decoded IoU-log regression + MSE aug, focal classification, sigmoid-BCE IoU branch,
-        MaxIoU assignment without ignore regions"""
+        """the loss / target configurations the fused target / loss kernels cover (all nine recipes):
+        focal or varifocal classification, decoded IoU-log regression + MSE aug or CIoU on raw deltas,
+        sigmoid-BCE IoU branch, MaxIoU assignment without ignore regions"""
         from .core import MaxIoUAssigner, PseudoSampler
-        from .losses import CrossEntropyLoss, FocalLoss, IoULoss, MSELoss
+        from .losses import CrossEntropyLoss
         tc = self.train_cfg
         return bool(
-            tc is not None and self.reg_decoded_bbox and self.use_sigmoid_cls and self.cls_out_channels == 1 and
-            type(self.loss_cls) is FocalLoss and type(self.loss_bbox) is IoULoss and self.loss_bbox.mode == 'log' and
-            self.loss_bbox.reduction == 'mean' and self.loss_cls.reduction == 'mean' and
-            (not self.with_aug_loss or (type(self.aug_loss) is MSELoss and self.aug_loss.reduction == 'mean')) and
+            tc is not None and self.use_sigmoid_cls and self.cls_out_channels == 1 and
+            self._fused_loss_modes() is not None and
             type(self.loss_centerness) is CrossEntropyLoss and self.loss_centerness.use_sigmoid and
             self.loss_centerness.class_weight is None and self.loss_centerness.reduction == 'mean' and
             type(self.assigner) is MaxIoUAssigner and self.assigner.ignore_iof_thr <= 0 and
@@ -559,7 +580,8 @@ class ATSSRPNHead(AnchorHead):
             [self._base_anchors(l, device) for l in range(len(sizes))], self.num_anchors, offs, self.loss_cls.gamma,
             self.loss_cls.alpha, tc.pos_weight, self.gamma, self.bbox_coder.means, self.bbox_coder.stds, 16 / 1000,
             self.with_aug_loss, self.loss_cls.loss_weight, self.loss_bbox.loss_weight,
-            self.aug_loss.loss_weight if self.with_aug_loss else 0.0, self.loss_centerness.loss_weight)
+            self.aug_loss.loss_weight if self.with_aug_loss else 0.0, self.loss_centerness.loss_weight,
+            *self._fused_loss_modes())
         if scales is None:
             scales = torch.stack([m.scale.reshape(()) for m in self.scales])
         losses3, per_level, totals = train_ops.rpn_loss(y, scales, gt_inds, gts, meta)

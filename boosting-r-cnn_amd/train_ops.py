@@ -182,7 +182,11 @@ class RPNLossMeta:
     """host-side description of one fused RPN loss call (shapes, anchors, loss configuration)"""
 
     def __init__(self, batch, sizes, strides, base_anchors, num_anchors, gt_offsets, focal_gamma, focal_alpha,
-                 pos_weight, iou_gamma, means, stds, wh_ratio_clip, with_aug, lw_cls, lw_bbox, lw_aug, lw_iou):
+                 pos_weight, iou_gamma, means, stds, wh_ratio_clip, with_aug, lw_cls, lw_bbox, lw_aug, lw_iou,
+                 cls_mode=0, reg_mode=0):
+        """cls_mode: 0 FocalLoss, 1 / 2 VarifocalLoss (iou_weighted / not; focal_gamma / focal_alpha are then
+        the varifocal ones); reg_mode: 0 decoded boxes with IoULoss('log') [+ MSE aug], 1 CIoULoss on the raw
+        deltas (reg_decoded_bbox=False)"""
         self.batch, self.sizes, self.A = int(batch), [tuple(s) for s in sizes], int(num_anchors)
         self.L = len(self.sizes)
         self.hs, self.ws = _ints([h for h, _ in self.sizes]), _ints([w for _, w in self.sizes])
@@ -193,7 +197,8 @@ class RPNLossMeta:
         self.gt_offsets = _ints(gt_offsets)
         self.total_gt = int(gt_offsets[-1])
         self.cfg = _floats([focal_gamma, focal_alpha, pos_weight, iou_gamma] + list(means) + list(stds) +
-                           [abs(math.log(wh_ratio_clip)), 1.0 if with_aug else 0.0, lw_cls, lw_bbox, lw_aug, lw_iou])
+                           [abs(math.log(wh_ratio_clip)), 1.0 if with_aug else 0.0, lw_cls, lw_bbox, lw_aug, lw_iou,
+                            float(cls_mode), float(reg_mode)])
         self.rows = sum(self.batch * h * w for h, w in self.sizes)
         self.anchors_per_image = sum(h * w for h, w in self.sizes) * self.A
 

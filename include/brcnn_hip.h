@@ -533,12 +533,16 @@ int brcnn_preprocess_u8(const uint8_t *src, int src_h, int src_w, float *dst, in
  *   ascending in candidate index.
  *
  * brcnn_rpn_loss_* -- ATSSRPNHead.loss / loss_single (models/dense_heads/atss_rpn_head.py:299-464)
- *   for reg_decoded_bbox=True, IoULoss(mode 'log') [+ MSELoss aug], FocalLoss, sigmoid-BCE IoU
- *   branch.  y (rows, ystride) is the fused head output of all levels, level-major rows
+ *   for every RPN loss configuration of the recipes: reg_decoded_bbox=True with IoULoss(mode 'log')
+ *   [+ MSELoss aug] or reg_decoded_bbox=False with CIoULoss on the raw deltas (:361-374, the FPN
+ *   recipe); FocalLoss or VarifocalLoss (:393-400, the VOC recipe); sigmoid-BCE IoU branch.
+ *   y (rows, ystride) is the fused head output of all levels, level-major rows
  *   (level l: batch*H_l*W_l rows), channels [cls A | reg 4A | iou A | padding]; scales (L) the
  *   per-level Scale parameters (device); gt_inds (batch, anchors per image) from
- *   brcnn_assign_max_iou.  cfg18_host = [focal_gamma, focal_alpha, pos_weight, iou_gamma(self.gamma),
- *   mean4, std4, max_ratio |ln(wh_ratio_clip)|, with_aug, lw_cls, lw_bbox, lw_aug, lw_iou].
+ *   brcnn_assign_max_iou.  cfg20_host = [focal_gamma, focal_alpha, pos_weight, iou_gamma(self.gamma),
+ *   mean4, std4, max_ratio |ln(wh_ratio_clip)|, with_aug, lw_cls, lw_bbox, lw_aug, lw_iou,
+ *   cls_mode (0 FocalLoss, 1 VarifocalLoss iou_weighted, 2 VarifocalLoss not iou_weighted; gamma /
+ *   alpha are then the varifocal ones), reg_mode (0 decoded IoU-log, 1 CIoU on raw deltas)].
  *   forward: sums (L, 6) [focal, iou-loss, mse, bce, iou_target, n_pos] and totals (2)
  *   [n_pos, sum iou_target] of THIS rank; the caller averages totals over ranks (reduce_mean,
  *   :440-444,458-460) and calls finalize: losses3 = [loss_rpn_cls, loss_rpn_bbox, loss_rpn_iou]
@@ -578,15 +582,15 @@ int brcnn_rpn_loss_forward(const float *y, int ystride, int batch, int num_level
                            const int *widths, const int *strides_w, const int *strides_h,
                            const float *const *base_anchors, int anchors_per_cell, const float *scales,
                            const int32_t *gt_inds, const float *gts, const int *gt_offsets_host,
-                           const float *cfg18_host, void *workspace, size_t workspace_bytes, float *sums,
+                           const float *cfg20_host, void *workspace, size_t workspace_bytes, float *sums,
                            float *totals, void *stream);
-int brcnn_rpn_loss_finalize(const float *sums, const float *totals, int num_levels, const float *cfg18_host,
+int brcnn_rpn_loss_finalize(const float *sums, const float *totals, int num_levels, const float *cfg20_host,
                             float *losses3, float *per_level, float *coef2, void *stream);
 int brcnn_rpn_loss_backward(const float *y, int ystride, int batch, int num_levels, const int *heights,
                             const int *widths, const int *strides_w, const int *strides_h,
                             const float *const *base_anchors, int anchors_per_cell, const float *scales,
                             const int32_t *gt_inds, const float *gts, const int *gt_offsets_host,
-                            const float *cfg18_host, const float *grad3, const float *coef2,
+                            const float *cfg20_host, const float *grad3, const float *coef2,
                             void *workspace, size_t workspace_bytes, float *dy, float *dscales,
                             void *stream);
 size_t brcnn_boost_loss_workspace_bytes(int n);

@@ -4,6 +4,8 @@ reference (g4 / g6 / g7 / g10) and against this repository's CPU restatement of 
 (`brcnn.core`, itself pinned to the same fixtures by tests/test_host_cpu.py) on seeded random
 inputs.  Bars: assignment / sampling indices and IoUs bit-exact; losses 1e-5 relative; gradients
 1e-4 relative (fp32 round-off of a different summation order)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -284,6 +286,76 @@ def test_rpn_loss_scale_gradient_and_padding():
         got = gy[r0:r0 + n, 9:45].view(2, h, w, 36).permute(0, 3, 1, 2).cpu()
         assert torch.allclose(got, ref_g[i], rtol=1e-4, atol=1e-7), i
         r0 += n
+
+
+def _variant_head(recipe):
+    from tests.test_host_cpu import ROOT
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'boosting_rcnn', recipe))
+    c = cfg.model.rpn_head.copy()
+    c.update(train_cfg=cfg.model.train_cfg.rpn, test_cfg=cfg.model.test_cfg.rpn)
+    return brcnn.build_head(c)
+
+
+@pytest.mark.parametrize('recipe,modes', [('boosting_rcnn_r50_fpn_1x_coco.py', (0, 1)),        # CIoU on raw deltas
+                                          ('boosting_rcnn_r50_pafpn_1x_voc.py', (1, 0))])      # VarifocalLoss
+def test_rpn_loss_variants_equal_cpu_chain(recipe, modes):
+    """the FPN recipe's reg_decoded_bbox=False + CIoULoss and the VOC recipe's VarifocalLoss on the fused
+    kernels: loss values, gradients w.r.t. the raw head output and the per-level Scale against autograd of
+    the CPU restatement (pinned to the reference by fixtures g11 / g15)"""
+    g = load('g6_rpn_loss')
+    head = _variant_head(recipe)
+    assert head._fused_loss_modes() == modes and head.device_train_ok()
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    _, metas, _, _ = util.demo_inputs(2, 128, 192, seed=6)
+    gts = [T(g['gt0']), T(g['gt1'])]
+    sc = torch.tensor([1.3, 0.7, 1.1, 0.9, 1.5])
+    A = head.num_anchors
+    gen = torch.Generator().manual_seed(21)
+    cls = [(torch.randn(2, A, h, w, generator=gen) - 2).requires_grad_() for h, w in sizes]
+    raw = [(torch.randn(2, 4 * A, h, w, generator=gen) * 0.3).requires_grad_() for h, w in sizes]
+    iou = [torch.randn(2, A, h, w, generator=gen).requires_grad_() for h, w in sizes]
+    scp = sc.clone().requires_grad_()
+    out = head.loss(cls, [r * scp[i] for i, r in enumerate(raw)], iou, gts, metas)          # CPU restatement
+    assert sum(out['loss_rpn_bbox']).item() > 0
+    tot = sum(sum(v) for v in out.values())
+    ref_g = torch.autograd.grad(tot, cls + raw + iou + [scp])
+    rows = [torch.cat([t.detach().permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in (c_, r_, i_)], 1)
+            for c_, r_, i_ in zip(cls, raw, iou)]
+    y = torch.cat(rows, 0)
+    y = torch.cat([y, torch.zeros((y.shape[0], 64 - 6 * A))], 1).to(DEV).requires_grad_()   # 6A -> 64 channels
+    head = head.to(DEV)
+    scd = sc.to(DEV).requires_grad_()
+    o2 = head.loss_fused(y, tuple(sizes), [t.to(DEV) for t in gts], metas, scales=scd)
+    for k in o2:
+        assert torch.allclose(o2[k][0].cpu(), sum(out[k]).detach(), rtol=2e-5, atol=1e-6), (k, o2[k][0], sum(out[k]))
+    t2 = sum(sum(v) for v in o2.values())
+    gy, gs = torch.autograd.grad(t2, [y, scd])
+    assert torch.allclose(gs.cpu(), ref_g[15], rtol=2e-4, atol=1e-7), (gs, ref_g[15])
+    r0 = 0
+    for i, (h, w) in enumerate(sizes):
+        n = 2 * h * w
+        for lo, hi, ref in ((0, A, ref_g[i]), (A, 5 * A, ref_g[5 + i]), (5 * A, 6 * A, ref_g[10 + i])):
+            got = gy[r0:r0 + n, lo:hi].view(2, h, w, hi - lo).permute(0, 3, 1, 2).cpu()
+            tol = 2e-4 * ref.abs().max().item() + 1e-7
+            assert (got - ref).abs().max().item() <= tol, (recipe, i, lo, (got - ref).abs().max().item(), tol)
+        r0 += n
+
+
+def test_rpn_loss_varifocal_reference_golden():
+    """the VOC recipe's RPN loss (VarifocalLoss) on the fused kernels against the reference's own per-level
+    values (fixture g15: rpn.loss of the imported reference on the same seeded head outputs)"""
+    g = load('g15_voc')
+    head = _variant_head('boosting_rcnn_r50_pafpn_1x_voc.py').to(DEV)
+    cls = [T(g[f'rpn_cls{i}']).to(DEV) for i in range(5)]
+    reg = [T(g[f'rpn_reg{i}']).to(DEV) for i in range(5)]
+    iou = [T(g[f'rpn_iou{i}']).to(DEV) for i in range(5)]
+    _, metas, gts, _ = util.demo_inputs(2, 128, 192, seed=15, num_gt=4)
+    out = head.loss(cls, reg, iou, [b.to(DEV) for b in gts], metas)
+    per_level = head.last_rpn_targets[1].cpu()
+    for r, k in enumerate(('loss_rpn_cls', 'loss_rpn_bbox', 'loss_rpn_iou')):
+        ref = T(g['rpn_' + k])
+        assert torch.allclose(per_level[r], ref, rtol=1e-5, atol=1e-6), (k, per_level[r], ref)
+        assert torch.allclose(out[k][0].cpu(), ref.sum(), rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize('gamma', [0.5, 0.1])
