@@ -21,6 +21,69 @@ def _ints(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
 
 
+def _conv_operands(weight, x_cat):
+    """(forward operand (Cout,KH,KW,Cin), data-gradient operand (Cin,KH,KW,Cout) or None) of `weight` in the
+    activation dtype: the ones the fused optimizer step already wrote for this version of the weight
+    (optim.FusedSGD), else one packing launch"""
+    pk = getattr(weight, '_brcnn_pack', None)
+    if pk is not None and pk[0] == weight._version and pk[1] == x_cat.dtype and pk[2].device == x_cat.device:
+        return pk[2], pk[3]
+    wsrc = weight.detach()
+    if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
+        wsrc = wsrc.float().contiguous()
+    cout_, cin_, kh_, kw_ = wsrc.shape
+    w_p = torch.empty((cout_, kh_, kw_, cin_), dtype=x_cat.dtype, device=x_cat.device)
+    w_t = torch.empty((cin_, kh_, kw_, cout_), dtype=x_cat.dtype, device=x_cat.device) \
+        if x_cat.requires_grad else None
+    st = _L.load().brcnn_pack_conv_weights(_ptr(wsrc), _ptr(w_p), _ptr(w_t), cout_, cin_, kh_, kw_,
+                                           _dt(x_cat), _stream())
+    _L.check(st, 'brcnn_pack_conv_weights')
+    return w_p, w_t
+
+
+def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
+    """data / weight gradient of ConvNHWCFunction's forward (dy already in the activation dtype, contiguous);
+    returns (dx, dw, dskip not yet added)"""
+    batch, sizes, out_sizes, stride, pad = cfg
+    cout, cin, kh, kw = weight.shape
+    dt = _dt(x_cat)
+    lib = _L.load()
+    L = len(sizes)
+    hs, ws = _ints([h for h, _ in sizes]), _ints([w for _, w in sizes])
+    ohs, ows = _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes])
+    dx = dw = None
+    # (fp32 only: in bf16 the zero-stuffed MFMA pass is cheaper than four more launches and
+    # their weight slices -- measured 54.1 vs 57.6 ms per train step)
+    if need_dx and stride == 2 and L == 1 and x_cat.dtype == torch.float32 and \
+            (kh, kw, pad) in ((3, 3, 1), (1, 1, 0)) and cout % 32 == 0:
+        dx = _dgrad_stride2(dy, weight, batch, sizes[0], out_sizes[0], kh, pad, x_cat.dtype)
+    elif need_dx and dskip is not None and stride == 1 and L == 1 and kh == kw and \
+            2 * pad == kh - 1 and w_t_saved is not None and dskip.dtype == x_cat.dtype:
+        # data gradient + the identity branch's gradient in one epilogue (the forward kernel on
+        # the flipped / transposed weights with a residual operand)
+        (h, w_), = sizes
+        dx = ops.conv2d_nhwc(dy.view(batch, h, w_, cout), w_t_saved, None, None,
+                             dskip.contiguous().view(batch, h, w_, cin), False, 1, pad).view(batch * h * w_, cin)
+        dskip = None
+    elif need_dx:
+        w_t = w_t_saved
+        if w_t is None:
+            w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).to(x_cat.dtype).contiguous()   # (Cin,KH,KW,Cout)
+        dx = torch.empty_like(x_cat)
+        st = lib.brcnn_conv2d_dgrad_nhwc_multi(_ptr(dy), _ptr(w_t), _ptr(dx), batch, L, hs, ws, ohs,
+                                               ows, cin, cout, kh, kw, stride, pad, dt, _stream())
+        _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
+    if need_dw:
+        dwp = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
+        st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
+                                               cin, cout, kh, kw, stride, pad, dt, _stream())
+        _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
+        # (Cout,KH,KW,Cin) -> the parameter's (Cout,Cin,KH,KW): for 1x1 filters the two coincide in
+        # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)
+        dw = dwp.view(cout, cin, 1, 1) if kh == 1 and kw == 1 else dwp.permute(0, 3, 1, 2)
+    return dx, dw, dskip
+
+
 class ConvNHWCFunction(Function):
     """y = conv(x, w) + b over one or several NHWC segments.
 
@@ -37,21 +100,7 @@ class ConvNHWCFunction(Function):
         # (weights are cast per step from the fp32 master copy, gradients of weights stay fp32)
         # one launch writes the forward operand and (when the input needs a gradient) the flipped /
         # transposed data-gradient operand
-        pk = getattr(weight, '_brcnn_pack', None)
-        if pk is not None and pk[0] == weight._version and pk[1] == x_cat.dtype and pk[2].device == x_cat.device:
-            # operands the fused optimizer step already wrote for this version of the weight (optim.FusedSGD)
-            w_p, w_t = pk[2], pk[3]
-        else:
-            wsrc = weight.detach()
-            if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
-                wsrc = wsrc.float().contiguous()
-            cout_, cin_, kh_, kw_ = wsrc.shape
-            w_p = torch.empty((cout_, kh_, kw_, cin_), dtype=x_cat.dtype, device=x_cat.device)
-            w_t = torch.empty((cin_, kh_, kw_, cout_), dtype=x_cat.dtype, device=x_cat.device) \
-                if x_cat.requires_grad else None
-            st = _L.load().brcnn_pack_conv_weights(_ptr(wsrc), _ptr(w_p), _ptr(w_t), cout_, cin_, kh_, kw_,
-                                                   _dt(x_cat), _stream())
-            _L.check(st, 'brcnn_pack_conv_weights')
+        w_p, w_t = _conv_operands(weight, x_cat)
         ctx.w_t = w_t
         x_cat = x_cat.contiguous()
         y, out_sizes = ops.conv2d_nhwc_multi(x_cat, w_p, batch, sizes, None,
@@ -69,45 +118,10 @@ class ConvNHWCFunction(Function):
     def backward(ctx, dy, dskip=None):
         x_cat, weight = ctx.saved_tensors
         batch, sizes, out_sizes, stride, pad, has_bias = ctx.cfg
-        cout, cin, kh, kw = weight.shape
         dy = dy.to(x_cat.dtype).contiguous()
-        dt = _dt(x_cat)
-        lib = _L.load()
-        L = len(sizes)
-        hs, ws = _ints([h for h, _ in sizes]), _ints([w for _, w in sizes])
-        ohs, ows = _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes])
-        dx = dw = db = None
-        # (fp32 only: in bf16 the zero-stuffed MFMA pass is cheaper than four more launches and
-        # their weight slices -- measured 54.1 vs 57.6 ms per train step)
-        if ctx.needs_input_grad[0] and stride == 2 and L == 1 and x_cat.dtype == torch.float32 and \
-                (kh, kw, pad) in ((3, 3, 1), (1, 1, 0)) and cout % 32 == 0:
-            dx = _dgrad_stride2(dy, weight, batch, sizes[0], out_sizes[0], kh, pad, x_cat.dtype)
-        elif ctx.needs_input_grad[0] and dskip is not None and stride == 1 and L == 1 and kh == kw and \
-                2 * pad == kh - 1 and ctx.w_t is not None and dskip.dtype == x_cat.dtype:
-            # data gradient + the identity branch's gradient in one epilogue (the forward kernel on
-            # the flipped / transposed weights with a residual operand)
-            (h, w_), = sizes
-            dx = ops.conv2d_nhwc(dy.view(batch, h, w_, cout), ctx.w_t, None, None,
-                                 dskip.contiguous().view(batch, h, w_, cin), False, 1, pad).view(batch * h * w_, cin)
-            dskip = None
-        elif ctx.needs_input_grad[0]:
-            w_t = ctx.w_t
-            if w_t is None:
-                w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).to(x_cat.dtype).contiguous()   # (Cin,KH,KW,Cout)
-            dx = torch.empty_like(x_cat)
-            st = lib.brcnn_conv2d_dgrad_nhwc_multi(_ptr(dy), _ptr(w_t), _ptr(dx), batch, L, hs, ws, ohs,
-                                                   ows, cin, cout, kh, kw, stride, pad, dt, _stream())
-            _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
-        if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
-            st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
-                                                   cin, cout, kh, kw, stride, pad, dt, _stream())
-            _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
-            # (Cout,KH,KW,Cin) -> the parameter's (Cout,Cin,KH,KW): for 1x1 filters the two coincide in
-            # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)
-            dw = dwp.view(cout, cin, 1, 1) if kh == 1 and kw == 1 else dwp.permute(0, 3, 1, 2)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy)
+        dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dy, (batch, sizes, out_sizes, stride, pad), dskip,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = ops.colsum(dy) if has_bias and ctx.needs_input_grad[2] else None
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
         return dx, dw, db, None, None, None, None, None
@@ -448,6 +462,91 @@ class BnEvalActFunction(Function):
                                             int(relu), dt, _stream())
         _L.check(st, 'brcnn_bn_eval_act_backward')
         return dz, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres, None
+
+
+class ConvBnEvalActFunction(Function):
+    """out = [relu](bn_eval(conv(x, w)) [+ res]) for a trainable conv + eval-mode BatchNorm in ONE forward
+    launch (`brcnn_conv2d_bn_act_nhwc_multi`: the conv epilogue stores the raw output z and the activation);
+    backward = `brcnn_bn_eval_act_backward` followed by ConvNHWCFunction's data / weight gradient kernels.
+    16-bit activations, single map.  `with_skip` as in ConvNHWCFunction."""
+
+    @staticmethod
+    def forward(ctx, x_cat, weight, gamma, beta, mean, var, eps, res, relu, batch, size, stride, pad, with_skip):
+        _require_gpu(x_cat, weight, gamma, beta, mean, var, res)
+        w_p, w_t = _conv_operands(weight, x_cat)
+        x_cat = x_cat.contiguous()
+        cout, kh, kw, cin = w_p.shape
+        (h, w_) = size
+        ho, wo = conv_out_size(h, w_, kh, kw, stride, pad)
+        rows = batch * ho * wo
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        m32, v32 = mean.detach().float().contiguous(), var.detach().float().contiguous()
+        r = res.contiguous() if res is not None else None
+        z = torch.empty((rows, cout), dtype=x_cat.dtype, device=x_cat.device)
+        out = torch.empty_like(z)
+        assert r is None or (r.shape == out.shape and r.dtype == out.dtype)
+        st = _L.load().brcnn_conv2d_bn_act_nhwc_multi(_ptr(x_cat), _ptr(w_p), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32),
+                                                      float(eps), _ptr(r), _ptr(z), _ptr(out), batch, 1, _ints([h]),
+                                                      _ints([w_]), cin, cout, kh, kw, int(stride), int(pad), int(relu),
+                                                      _dt(x_cat), _stream())
+        _L.check(st, 'brcnn_conv2d_bn_act_nhwc_multi')
+        ctx.w_t = w_t
+        ctx.save_for_backward(x_cat, weight, z, g32, b32, m32, v32, out if relu and res is not None else None)
+        ctx.cfg = (batch, (tuple(size),), ((ho, wo),), stride, pad, bool(relu), res is not None, float(eps),
+                   gamma.dtype, beta.dtype)
+        if with_skip:
+            return out, x_cat.view_as(x_cat)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, dskip=None):
+        x_cat, weight, z, g32, b32, m32, v32, out = ctx.saved_tensors
+        batch, sizes, out_sizes, stride, pad, relu, has_res, eps, gdt, bdt = ctx.cfg
+        rows, c = z.shape
+        dt = _dt(z)
+        dout = dout.to(z.dtype).contiguous()
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[7] else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+        lib = _L.load()
+        nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
+        ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
+        st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), eps,
+                                            _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
+                                            int(relu), dt, _stream())
+        _L.check(st, 'brcnn_bn_eval_act_backward')
+        dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), dskip,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        if dskip is not None:
+            dx = dskip if dx is None else dx + dskip
+        return dx, dw, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres, None, None, None, None, None, None
+
+
+def conv_bn_eval_act_fusable(x, conv, bn, residual):
+    """the one-launch training forward applies: 16-bit NHWC activations, dense conv without bias whose
+    channel counts suit the 16-bit MFMA kernel, eval-mode BatchNorm"""
+    cout, cin = conv.weight.shape[:2]
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and conv.groups == 1 and conv.bias is None and
+            conv.dilation == (1, 1) and cin % 64 == 0 and cout % 64 == 0 and not bn.training and bn.affine and
+            bn.track_running_stats and (residual is None or residual.dtype == x.dtype))
+
+
+def conv_bn_eval_act_autograd(x, conv, bn, residual=None, relu=True, with_skip=False):
+    """x (N,H,W,Cin) -> [relu](bn(conv(x)) [+ residual]) (N,Ho,Wo,Cout), differentiable; `with_skip` as in
+    conv2d_nhwc_autograd"""
+    n, h, w, cin = x.shape
+    cout, _, kh, kw = conv.weight.shape
+    stride, pad = conv.stride[0], conv.padding[0]
+    ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
+    res = residual.reshape(n * ho * wo, cout) if residual is not None else None
+    y = ConvBnEvalActFunction.apply(x.reshape(n * h * w, cin), conv.weight, bn.weight, bn.bias, bn.running_mean,
+                                    bn.running_var, bn.eps, res, relu, n, (h, w), stride, pad, with_skip)
+    if with_skip:
+        y, skip = y
+        return y.view(n, ho, wo, cout), skip.view(n, h, w, cin)
+    return y.view(n, ho, wo, cout)
 
 
 def bn_eval_act_autograd(z, bn, res=None, relu=True):

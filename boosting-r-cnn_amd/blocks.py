@@ -156,6 +156,11 @@ def build_norm_layer(cfg, num_features, postfix=''):
     return name + str(postfix), layer
 
 
+# training forward of conv -> eval-BN -> act as one launch where `autograd.conv_bn_eval_act_fusable` allows
+# (False: conv kernel + bn_act kernel, the fp32 structure)
+FUSE_CONV_BN_TRAIN = True
+
+
 def conv_bn_act_tail(y, bn, relu, residual):
     """eval-BN affine (+residual, +ReLU) behind a differentiable conv (fused kernel when it applies)"""
     if bn is not None:
@@ -184,6 +189,14 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False):
     if wants_grad(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                   residual if residual is not None and residual.requires_grad else None):
         skip = None
+        if bn is not None and FUSE_CONV_BN_TRAIN:
+            from .autograd import conv_bn_eval_act_autograd, conv_bn_eval_act_fusable
+            if conv_bn_eval_act_fusable(x, conv, bn, residual):
+                # conv + eval-BN (+ residual) (+ ReLU) in one forward launch (16-bit compute dtypes)
+                if with_skip and x.requires_grad:
+                    return conv_bn_eval_act_autograd(x, conv, bn, residual, relu, True)
+                out = conv_bn_eval_act_autograd(x, conv, bn, residual, relu)
+                return (out, x) if with_skip else out
         if with_skip and x.requires_grad:
             y, skip = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], True)
         else:

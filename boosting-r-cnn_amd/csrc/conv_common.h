@@ -37,6 +37,13 @@ struct ConvParams {
     // is dropped when a-sc_o / b-sc_o fall outside [0, sc_na) / [0, sc_nb); 0 = dense output
     int scatter, sc_H, sc_W, sc_ph, sc_pw, sc_o, sc_na, sc_nb;
     int gstep;                       // grouped conv: N tile t reads input channels [t*gstep, t*gstep + Cin); 0 = dense
+    // training-mode dual store (16-bit kernel): the raw conv output goes to z_out (what the BatchNorm
+    // backward needs), y = [relu](z * scale + shift [+ residual]); with bn_mean / bn_var set, `scale` /
+    // `shift` are gamma / beta of an eval-mode BatchNorm and the affine is formed in the epilogue
+    void* z_out;
+    const float* bn_mean;
+    const float* bn_var;
+    float bn_eps;
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];

@@ -648,12 +648,15 @@ BRCNN_API int brcnn_conv2d_nhwc(const void* x, const void* w, const float* scale
                                    kw, stride, pad, relu, dtype, stream);
 }
 
+struct TrainTail { void* z_out; const float* mean; const float* var; float eps; };
+
 static int conv_setup_and_launch(const void* x, const void* w, const float* scale, const float* shift,
                                  const void* residual, void* y, int batch, int num_segments,
                                  const int* heights_host, const int* widths_host,
                                  const int* out_heights_host, const int* out_widths_host, int cin,
                                  int cout, int kh, int kw, int stride, int pad, int dilate, int relu,
-                                 int dtype, void* stream, int pitch = 0, const int* scatter = nullptr) {
+                                 int dtype, void* stream, int pitch = 0, const int* scatter = nullptr,
+                                 const TrainTail* tail = nullptr) {
     if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
         pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
         !heights_host || !widths_host)
@@ -699,8 +702,29 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
         p.sc_H = scatter[0]; p.sc_W = scatter[1]; p.sc_ph = scatter[2]; p.sc_pw = scatter[3];
         p.sc_o = scatter[4]; p.sc_na = scatter[5]; p.sc_nb = scatter[6];
     }
+    if (tail) {         // dual store: 16-bit kernels, whole 16-byte channel pieces
+        if (!bf16 || (cout & 7) || brcnn_out_f32(dtype) || scatter || !tail->z_out || !scale || !shift ||
+            (tail->mean != nullptr) != (tail->var != nullptr))
+            return BRCNN_EINVAL;
+        p.z_out = tail->z_out; p.bn_mean = tail->mean; p.bn_var = tail->var; p.bn_eps = tail->eps;
+    }
     if (bf16) return dispatch_conv_bf16(p, (hipStream_t)stream);
     return dispatch_conv(p, (hipStream_t)stream);
+}
+
+// Training forward of conv -> eval-mode BatchNorm (-> + residual) (-> ReLU) in ONE launch: the raw conv
+// output z (which the BatchNorm backward needs for dgamma) and the activation y leave the same epilogue
+// (resnet.py Bottleneck.forward:263-302 with norm_eval=True).  16-bit dtypes only.
+BRCNN_API int brcnn_conv2d_bn_act_nhwc_multi(const void* x, const void* w, const float* gamma, const float* beta,
+                                             const float* mean, const float* var, float eps, const void* residual,
+                                             void* z_out, void* y, int batch, int num_segments,
+                                             const int* heights_host, const int* widths_host, int cin, int cout,
+                                             int kh, int kw, int stride, int pad, int relu, int dtype, void* stream) {
+    if (!brcnn_is16(dtype) || brcnn_out_f32(dtype)) return BRCNN_EINVAL;
+    const TrainTail tail = {z_out, mean, var, eps};
+    return conv_setup_and_launch(x, w, gamma, beta, residual, y, batch, num_segments, heights_host, widths_host,
+                                 nullptr, nullptr, cin, cout, kh, kw, stride, pad, 1, relu, dtype, stream, 0, nullptr,
+                                 &tail);
 }
 
 BRCNN_API int brcnn_conv2d_nhwc_scatter2(const void* x, const void* w, void* y, int batch, int height, int width,

@@ -36,7 +36,7 @@ template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { retur
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
-template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0>
+template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0, bool DUAL = false>
 __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
     constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
@@ -289,6 +289,37 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     // the result written as full 16-byte (bf16) / 32-byte (fp32) pieces of whole NHWC rows.
     constexpr int PITCH = 32 * NT + 4;            // floats
     float* cs = smem + wave * 32 * PITCH;
+    // DUAL (training): the raw tile leaves as z, the affine is applied in the read-out layout where a lane
+    // owns the same 8 channels in every iteration.  The wave's 32*NT channels are derived one per lane
+    // (correctly rounded divide / sqrt: ~100 instructions each) and handed out through the wave's slab.
+    constexpr bool dual = DUAL;
+    const float* __restrict__ acc_scale = dual ? nullptr : p.scale;
+    const float* __restrict__ acc_shift = dual ? nullptr : p.shift;
+    float sc8[8], sh8[8];
+    if constexpr (DUAL) {
+        static_assert(NT <= 2, "one channel per lane");
+        if (lane < 32 * NT) {
+            const int co = cw0 + lane;
+            float a = 1.f, b = 0.f;
+            if (co < p.Cout) {
+                if (p.bn_mean) {       // the operation order of bn_act.hip's bn_affine (the backward recomputes it)
+                    a = p.scale[co] / sqrtf(p.bn_var[co] + p.bn_eps);
+                    b = p.shift[co] - p.bn_mean[co] * a;
+                } else {
+                    a = p.scale ? p.scale[co] : 1.f;
+                    b = p.shift ? p.shift[co] : 0.f;
+                }
+            }
+            cs[lane] = a;
+            cs[64 + lane] = b;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sc8[e] = cs[cl + e]; sh8[e] = cs[64 + cl + e]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
     float4 scv[NT][4], shv[NT][4];
 #pragma unroll
     for (int tn = 0; tn < NT; tn++)
@@ -299,8 +330,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const bool ok = co + e < p.Cout;
-                sc4[e] = (p.scale && ok) ? p.scale[co + e] : 1.f;
-                sh4[e] = (p.shift && ok) ? p.shift[co + e] : 0.f;
+                sc4[e] = (acc_scale && ok) ? acc_scale[co + e] : 1.f;
+                sh4[e] = (acc_shift && ok) ? acc_shift[co + e] : 0.f;
             }
             scv[tn][g] = make_float4(sc4[0], sc4[1], sc4[2], sc4[3]);
             shv[tn][g] = make_float4(sh4[0], sh4[1], sh4[2], sh4[3]);
@@ -334,6 +365,22 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             const long long ro = out_row_offset(p, m);
             if (ro < 0) continue;
             if (vec_ok) {
+                if constexpr (DUAL) {
+                    uint4 zq;
+                    zq.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
+                    zq.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
+                    zq.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
+                    zq.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.z_out) + ro + co) = zq;
+                    // the affine sees the STORED (rounded) z: bit-identical to the conv kernel followed by
+                    // bn_act_fwd_kernel, and the mask the backward recomputes from z is the forward's own
+                    const unsigned zw[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[2 * e] = e2f<ET>((unsigned short)(zw[e] & 0xffffu)) * sc8[2 * e] + sh8[2 * e];
+                        v[2 * e + 1] = e2f<ET>((unsigned short)(zw[e] >> 16)) * sc8[2 * e + 1] + sh8[2 * e + 1];
+                    }
+                }
                 if (RES) {
                     const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
 #pragma unroll
@@ -374,7 +421,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     }
 }
 
-template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2, int ET = 0>
+template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2, int ET = 0, bool DUAL = false>
 int launch(const ConvParams& p, hipStream_t s) {
     const size_t lds_stage = (size_t)(32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
     const size_t lds_full = ST * lds_stage;
@@ -385,11 +432,11 @@ int launch(const ConvParams& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         const size_t lds_max = lds_full > lds_epi ? lds_full : lds_epi;
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, DUAL>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET>), dim3(p.tiles_m * p.tiles_n),
+    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, DUAL>), dim3(p.tiles_m * p.tiles_n),
                        dim3(64 * WM * WNW), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -399,6 +446,15 @@ template <int MT, int NT, int WM = 2, int WNW = 2, int ST = 2, int ET = 0>
 int launch2(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
     p.tiles_n = (p.Cout + 32 * NT * WNW - 1) / (32 * NT * WNW);
+    if (p.z_out) {      // training dual store: the production tiles of the backbone layers only
+        if constexpr (ST == 2 && NT <= 2 && MT * NT <= 2 && ((WM == 4 && WNW == 2) || (WM == 2 && WNW == 2))) {
+            if (p.out_f32) return BRCNN_EINVAL;
+            return p.residual ? launch<MT, NT, true, false, WM, WNW, ST, ET, true>(p, s)
+                              : launch<MT, NT, false, false, WM, WNW, ST, ET, true>(p, s);
+        } else {
+            return BRCNN_EINVAL;
+        }
+    }
     if constexpr (MT * NT > 4) {        // large register tiles: bf16 output, no residual operand (callers check)
         return launch<MT, NT, false, false, WM, WNW, ST, ET>(p, s);
     } else {
@@ -420,7 +476,7 @@ static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     if (p.gstep) return launch2<1, 1, 4, 2, 2, 1>(p, s);
     const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-    const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && t44 >= 512 &&
+    const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && t44 >= 512 &&
                         (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
     if (fill44 && p.Cout > 128) return launch2<2, 2, 4, 4, 2, 1>(p, s);
     if (p.Cout <= 64) return launch2<2, 1, 2, 2, 2, 1>(p, s);
@@ -434,7 +490,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     if (p.f16) return dispatch_conv_f16(p, s);
     p.il = g_bf16_il;
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
-    int t = g_bf16_tile;
+    int t = p.z_out ? 0 : g_bf16_tile;
     if (t == 0) {
         // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more
         // waves share the LDS-DMA issue of a K tile, the better -- 128x128 on 8 waves of 32x64 beats the
@@ -445,7 +501,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         // TF/s per full generation), but is one workgroup per CU: only when its tile count fills
         // whole generations of 256 (the fused RPN tower: 700 tiles)
         const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-        const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && t44 >= 512 &&
+        const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && t44 >= 512 &&
                             (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
         if (fill44) t = 2244;
         else if (p.Cout <= 64) t = 21;

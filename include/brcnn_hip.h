@@ -351,6 +351,17 @@ int brcnn_bn_act_backward(const void *dout, const void *out, const void *z, cons
                           size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype,
                           void *stream);
 
+/* Training forward of conv -> eval-mode BatchNorm [-> + residual] [-> ReLU] in one launch (the trainable
+ * Bottleneck layers, backbones/resnet.py:263-302 with norm_eval=True): z_out receives the raw conv output
+ * (what brcnn_bn_eval_act_backward needs for dgamma and for the recomputed ReLU mask), y the activation;
+ * both (rows, cout) in `dtype`.  mean / var NULL: gamma / beta are a plain per-channel scale / shift.
+ * 16-bit dtypes (BRCNN_DT_BF16 / BRCNN_DT_F16), cout % 8 == 0; geometry as brcnn_conv2d_nhwc_multi. */
+int brcnn_conv2d_bn_act_nhwc_multi(const void *x, const void *w, const float *gamma, const float *beta,
+                                   const float *mean, const float *var, float eps, const void *residual,
+                                   void *z_out, void *y, int batch, int num_segments,
+                                   const int *heights_host, const int *widths_host, int cin, int cout,
+                                   int kh, int kw, int stride, int pad, int relu, int dtype, void *stream);
+
 /* The same pair with the eval-mode BatchNorm parameters themselves (norm_eval=True,
  * backbones/resnet.py:648-657): scale = gamma / sqrt(var + eps), shift = beta - mean * scale are formed
  * inside the kernels (the reference spends ~5 element-wise torch launches per layer and direction on

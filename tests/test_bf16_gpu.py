@@ -207,6 +207,58 @@ def test_conv_autograd_bf16(cfg):
     assert (db - br.grad).abs().max().item() <= 2e-4 * max(1.0, br.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, H, W, Cout, k, stride, residual, relu, with_skip)
+    (2, 64, 20, 28, 64, 3, 1, False, True, False), (2, 128, 14, 18, 256, 1, 1, True, True, False),
+    (1, 64, 17, 23, 128, 3, 2, False, True, False), (2, 256, 9, 11, 64, 1, 1, False, True, True),
+    (1, 128, 12, 10, 128, 1, 2, False, False, False), (8, 256, 50, 84, 1024, 1, 1, True, True, False)])
+def test_conv_bn_act_one_launch_training_forward(cfg, dtype):
+    """conv -> eval-BN [-> + residual] [-> ReLU] with the dual-store epilogue (`brcnn_conv2d_bn_act_nhwc_multi`):
+    bit-identical to the conv kernel followed by the bn_act kernel (the affine is applied to the stored, rounded z)
+    in the forward and in every gradient (input, weight, gamma, beta, residual, the identity alias); the two-kernel
+    path itself is checked against float64 in test_conv_autograd_bf16 / test_bn_eval_act"""
+    from brcnn.autograd import conv_bn_eval_act_autograd, conv_bn_eval_act_fusable
+    N, Cin, H, W, Cout, k, stride, res, relu, with_skip = cfg
+    g = torch.Generator().manual_seed(31)
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride, k // 2, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(Cout).eval().to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(k * k * Cin))
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV, dtype)
+    r = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV, dtype) if res else None
+    go = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV, dtype)
+    gs = torch.randn(N, H, W, Cin, generator=g).to(DEV, dtype) if with_skip else None
+    got = {}
+    for fused in (True, False):
+        blocks.FUSE_CONV_BN_TRAIN = fused
+        try:
+            conv.zero_grad(); bn.zero_grad()
+            xd = x.clone().requires_grad_()
+            rd = r.clone().requires_grad_() if res else None
+            assert conv_bn_eval_act_fusable(xd, conv, bn, rd)
+            out = blocks.conv_bn_act_nhwc(xd, conv, bn, None, relu, rd, with_skip)
+            outs = [out[0], out[1]] if with_skip else [out]
+            torch.autograd.backward(outs, [go, gs] if with_skip else [go])
+            got[fused] = [outs[0].detach(), xd.grad, conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()] + \
+                ([rd.grad] if res else [])
+        finally:
+            blocks.FUSE_CONV_BN_TRAIN = True
+    assert got[True][0].dtype == dtype
+    names = ['out', 'dx', 'dgamma', 'dbeta', 'dres']
+    for i, nm in zip((0, 1, 3, 4, 5), names):
+        if i < len(got[True]):
+            assert torch.equal(got[True][i], got[False][i]), nm
+    # the weight gradient accumulates with fp32 atomics (order varies from launch to launch)
+    dw_a, dw_b = got[True][2], got[False][2]
+    assert (dw_a - dw_b).abs().max().item() <= 1e-5 * max(1.0, dw_b.abs().max().item())
+
+
 def test_wgrad_bf16_tiles_and_multi_level_agree():
     """64x64, 128x128 and 256x256 (16-wave) output tiles, one multi-level launch vs per-level launches"""
     from brcnn import lib
