@@ -21,6 +21,43 @@ def _ints(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
 
 
+import os as _os
+_ARENA_OFF = _os.environ.get('BRCNN_GRAD_ARENA', '1') == '0'
+
+
+class _GradArena:
+    """zero-initialised fp32 storage for the weight-gradient kernels (they accumulate with atomics): ONE fill
+    launch per train step instead of one per layer.  `take` hands out disjoint views of the current chunk; a
+    chunk is sized by what the previous step used (`new_step`, called by optim.FusedSGD.step) and simply
+    replaced when it runs out -- the views keep their chunk alive for as long as a gradient refers to it."""
+
+    MIN_CHUNK = 16 << 20        # floats
+
+    def __init__(self):
+        self.buf, self.off, self.used, self.hint = None, 0, 0, 0
+
+    def take(self, shape, device):
+        if _ARENA_OFF:
+            return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n_al = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            self.buf = torch.zeros(max(n_al, self.hint - self.used, self.MIN_CHUNK), dtype=torch.float32, device=device)
+            self.off = 0
+        v = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        self.used += n_al
+        return v
+
+    def new_step(self):
+        self.hint, self.used, self.buf = max(self.hint, self.used), 0, None
+
+
+grad_arena = _GradArena()
+
+
 def _conv_operands(weight, x_cat):
     """(forward operand (Cout,KH,KW,Cin), data-gradient operand (Cin,KH,KW,Cout) or None) of `weight` in the
     activation dtype: the ones the fused optimizer step already wrote for this version of the weight
@@ -74,7 +111,7 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
                                                ows, cin, cout, kh, kw, stride, pad, dt, _stream())
         _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
     if need_dw:
-        dwp = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
+        dwp = grad_arena.take((cout, kh, kw, cin), dy.device)
         st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
                                                cin, cout, kh, kw, stride, pad, dt, _stream())
         _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')

@@ -122,6 +122,8 @@ class FusedSGD(torch.optim.Optimizer):
         for p in ps:        # the kernels wrote through raw pointers: tell autograd / the packed-operand caches
             torch.autograd.graph.increment_version(p)
         self._pack(self.ctl)
+        from .autograd import grad_arena
+        grad_arena.new_step()       # the next backward's weight-gradient storage: one zero fill
         return self.ctl if loss is None else loss
 
     @property
