@@ -501,6 +501,18 @@ class BnEvalActFunction(Function):
         return dz, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres, None
 
 
+class BnTail:
+    """what the consumer of a conv -> eval-BN -> [ReLU] output needs to run that BatchNorm's backward inside
+    its own data-gradient launch (`brcnn_conv2d_dgrad_bn_backward_nhwc`), and where it leaves the results for
+    the producer's backward.  Only valid when the consumer is the ONLY user of the producer's output (conv2 /
+    conv3 of a Bottleneck): the gradient that then travels along the autograd edge is dz, not d(output)."""
+    __slots__ = ('z', 'g', 'b', 'm', 'v', 'eps', 'relu', 'done', 'dgamma', 'dbeta')
+
+    def __init__(self, z, g, b, m, v, eps, relu):
+        self.z, self.g, self.b, self.m, self.v, self.eps, self.relu = z, g, b, m, v, eps, relu
+        self.done, self.dgamma, self.dbeta = False, None, None
+
+
 class ConvBnEvalActFunction(Function):
     """out = [relu](bn_eval(conv(x, w)) [+ res]) for a trainable conv + eval-mode BatchNorm in ONE forward
     launch (`brcnn_conv2d_bn_act_nhwc_multi`: the conv epilogue stores the raw output z and the activation);
@@ -508,7 +520,11 @@ class ConvBnEvalActFunction(Function):
     16-bit activations, single map.  `with_skip` as in ConvNHWCFunction."""
 
     @staticmethod
-    def forward(ctx, x_cat, weight, gamma, beta, mean, var, eps, res, relu, batch, size, stride, pad, with_skip):
+    def forward(ctx, x_cat, weight, gamma, beta, mean, var, eps, res, relu, batch, size, stride, pad, with_skip,
+                in_tail=None, out_tail=None):
+        """`out_tail` (an empty list): receives this layer's BnTail, for a sole consumer that will run this
+        BatchNorm's backward; `in_tail`: the BnTail of the layer that produced x_cat (this layer is its sole
+        consumer)"""
         _require_gpu(x_cat, weight, gamma, beta, mean, var, res)
         w_p, w_t = _conv_operands(weight, x_cat)
         x_cat = x_cat.contiguous()
@@ -531,6 +547,11 @@ class ConvBnEvalActFunction(Function):
         ctx.save_for_backward(x_cat, weight, z, g32, b32, m32, v32, out if relu and res is not None else None)
         ctx.cfg = (batch, (tuple(size),), ((ho, wo),), stride, pad, bool(relu), res is not None, float(eps),
                    gamma.dtype, beta.dtype)
+        ctx.in_tail = in_tail if (in_tail is not None and w_t is not None and x_cat.requires_grad) else None
+        ctx.tail = None
+        if out_tail is not None and res is None:
+            ctx.tail = BnTail(z, g32, b32, m32, v32, float(eps), bool(relu))
+            out_tail.append(ctx.tail)
         if with_skip:
             return out, x_cat.view_as(x_cat)
         return out
@@ -543,22 +564,52 @@ class ConvBnEvalActFunction(Function):
         rows, c = z.shape
         dt = _dt(z)
         dout = dout.to(z.dtype).contiguous()
-        dz = torch.empty_like(z)
-        dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[7] else None
-        dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
-        dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
         lib = _L.load()
-        nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
-        ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
-        st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), eps,
-                                            _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
-                                            int(relu), dt, _stream())
-        _L.check(st, 'brcnn_bn_eval_act_backward')
-        dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), dskip,
-                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        if dskip is not None:
-            dx = dskip if dx is None else dx + dskip
-        return dx, dw, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres, None, None, None, None, None, None
+        dres = None
+        if ctx.tail is not None and ctx.tail.done:
+            # the sole consumer's data-gradient launch already ran this BatchNorm's backward: `dout` IS dz
+            dz, dgamma, dbeta = dout, ctx.tail.dgamma, ctx.tail.dbeta
+            ctx.tail.done, ctx.tail.dgamma, ctx.tail.dbeta = False, None, None
+        else:
+            dz = torch.empty_like(z)
+            dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[7] else None
+            dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+            nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
+            ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
+            st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32),
+                                                eps, _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
+                                                int(relu), dt, _stream())
+            _L.check(st, 'brcnn_bn_eval_act_backward')
+        t = ctx.in_tail
+        if t is not None and ctx.needs_input_grad[0] and dskip is None:
+            # data gradient + the producer's BatchNorm backward in one launch: dx leaves as the producer's dz
+            cout, cin, kh, kw = weight.shape
+            (h, w_), (ho, wo) = sizes[0], out_sizes[0]
+            dzp = torch.empty_like(x_cat)
+            t.dgamma = torch.empty(cin, dtype=torch.float32, device=z.device)
+            t.dbeta = torch.empty(cin, dtype=torch.float32, device=z.device)
+            nb = lib.brcnn_conv2d_dgrad_bn_backward_workspace_bytes(batch, h, w_, cin)
+            ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
+            st = lib.brcnn_conv2d_dgrad_bn_backward_nhwc(_ptr(dz), _ptr(ctx.w_t), _ptr(t.z), _ptr(t.g), _ptr(t.b), _ptr(t.m),
+                                                         _ptr(t.v), t.eps, int(t.relu), _ptr(dzp), _ptr(t.dgamma),
+                                                         _ptr(t.dbeta), _ptr(ws), nb, batch, h, w_, ho, wo, cin, cout, kh, kw,
+                                                         stride, pad, dt, _stream())
+            _L.check(st, 'brcnn_conv2d_dgrad_bn_backward_nhwc')
+            t.done = True
+            _, dw, _ = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), None, False,
+                                      ctx.needs_input_grad[1])
+            dx = dzp
+        else:
+            dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), dskip,
+                                           ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            if dskip is not None:
+                dx = dskip if dx is None else dx + dskip
+        return (dx, dw, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres) + (None,) * 8
+
+
+# conv2 / conv3 of a Bottleneck run the BatchNorm backward of bn1 / bn2 inside their data-gradient launches
+FUSE_BN_BACKWARD_INTO_DGRAD = _os.environ.get('BRCNN_FUSE_BN_BWD', '1') != '0'
 
 
 def conv_bn_eval_act_fusable(x, conv, bn, residual):
@@ -570,20 +621,29 @@ def conv_bn_eval_act_fusable(x, conv, bn, residual):
             bn.track_running_stats and (residual is None or residual.dtype == x.dtype))
 
 
-def conv_bn_eval_act_autograd(x, conv, bn, residual=None, relu=True, with_skip=False):
+def conv_bn_eval_act_autograd(x, conv, bn, residual=None, relu=True, with_skip=False, sole_consumer=False,
+                              single_use_output=False):
     """x (N,H,W,Cin) -> [relu](bn(conv(x)) [+ residual]) (N,Ho,Wo,Cout), differentiable; `with_skip` as in
-    conv2d_nhwc_autograd"""
+    conv2d_nhwc_autograd.  `single_use_output`: the caller promises that the result feeds exactly one
+    conv_bn_eval_act_autograd(..., sole_consumer=True) call and nothing else -- that call then runs this layer's
+    BatchNorm backward inside its data-gradient launch (the tag travels as `out._brcnn_tail`)."""
     n, h, w, cin = x.shape
     cout, _, kh, kw = conv.weight.shape
     stride, pad = conv.stride[0], conv.padding[0]
     ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
     res = residual.reshape(n * ho * wo, cout) if residual is not None else None
+    in_tail = getattr(x, '_brcnn_tail', None) if sole_consumer and FUSE_BN_BACKWARD_INTO_DGRAD else None
+    out_tail = [] if single_use_output and residual is None and FUSE_BN_BACKWARD_INTO_DGRAD else None
     y = ConvBnEvalActFunction.apply(x.reshape(n * h * w, cin), conv.weight, bn.weight, bn.bias, bn.running_mean,
-                                    bn.running_var, bn.eps, res, relu, n, (h, w), stride, pad, with_skip)
+                                    bn.running_var, bn.eps, res, relu, n, (h, w), stride, pad, with_skip, in_tail, out_tail)
+    skip = None
     if with_skip:
         y, skip = y
-        return y.view(n, ho, wo, cout), skip.view(n, h, w, cin)
-    return y.view(n, ho, wo, cout)
+        skip = skip.view(n, h, w, cin)
+    y = y.view(n, ho, wo, cout)
+    if out_tail:
+        y._brcnn_tail = out_tail[0]
+    return (y, skip) if with_skip else y
 
 
 def bn_eval_act_autograd(z, bn, res=None, relu=True):

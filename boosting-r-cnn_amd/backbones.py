@@ -41,13 +41,15 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             # the identity branch leaves through conv1's autograd node: its gradient is added in
             # conv1's data-gradient kernel instead of by a separate add over the whole tensor
-            out, identity = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True)
+            out, identity = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True,
+                                             single_use_output=True)
         else:
-            out = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True)
+            out = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, single_use_output=True)
             identity = conv_bn_act_nhwc(x, self.downsample[0], self.downsample[1], self._c[3], False)
-        out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True)
+        # out of conv1 / conv2 feeds the next conv only: that conv's data-gradient launch runs bn1's / bn2's backward
+        out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True, sole_consumer=True, single_use_output=True)
         # relu(bn3(conv3(out)) + identity) in one epilogue (resnet.py:288-300)
-        return conv_bn_act_nhwc(out, self.conv3, self.bn3, self._c[2], True, residual=identity)
+        return conv_bn_act_nhwc(out, self.conv3, self.bn3, self._c[2], True, residual=identity, sole_consumer=True)
 
     def forward(self, x):
         return to_nchw_view(self.forward_nhwc(to_nhwc(x)))

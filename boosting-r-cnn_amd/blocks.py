@@ -175,7 +175,8 @@ def conv_bn_act_tail(y, bn, relu, residual):
     return y.relu() if relu else y
 
 
-def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False):
+def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False, sole_consumer=False,
+                     single_use_output=False):
     """act(bn(conv(x)) + residual).  Inference / frozen layers: everything folded into one
     kernel launch.  Trainable layers under grad mode: the differentiable conv kernel followed
     by the (cheap, element-wise) eval-BN affine / add / ReLU as torch ops."""
@@ -193,9 +194,11 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False):
             from .autograd import conv_bn_eval_act_autograd, conv_bn_eval_act_fusable
             if conv_bn_eval_act_fusable(x, conv, bn, residual):
                 # conv + eval-BN (+ residual) (+ ReLU) in one forward launch (16-bit compute dtypes)
+                # `single_use_output` / `sole_consumer` (see conv_bn_eval_act_autograd): a Bottleneck's conv2 / conv3
+                # run the BatchNorm backward of the layer above inside their data-gradient launch
                 if with_skip and x.requires_grad:
-                    return conv_bn_eval_act_autograd(x, conv, bn, residual, relu, True)
-                out = conv_bn_eval_act_autograd(x, conv, bn, residual, relu)
+                    return conv_bn_eval_act_autograd(x, conv, bn, residual, relu, True, sole_consumer, single_use_output)
+                out = conv_bn_eval_act_autograd(x, conv, bn, residual, relu, False, sole_consumer, single_use_output)
                 return (out, x) if with_skip else out
         if with_skip and x.requires_grad:
             y, skip = conv2d_nhwc_autograd(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], True)

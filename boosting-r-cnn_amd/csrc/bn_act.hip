@@ -332,6 +332,17 @@ int forward_impl(const void* z, const float* scale, const float* shift, const Bn
 
 }  // namespace
 
+// second stage over per-tile partials written by another kernel (the data-gradient epilogue of
+// conv_igemm_bf16.hip, MODE 2): partials (strips, 2 [sum d*z | sum d], C)
+int brcnn_bn_eval_reduce_launch(const float* partials, int strips, const float* mean, const float* var, float eps,
+                                float* dgamma, float* dbeta, int channels, hipStream_t s) {
+    BnStats bn = {mean, var, eps};
+    hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 15) / 16), dim3(1024), 0, s, partials, bn, dgamma, dbeta,
+                       strips, channels);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
 BRCNN_API int brcnn_bn_act_forward(const void* z, const float* scale, const float* shift,
                                    const void* residual, void* out, int64_t rows, int channels,
                                    int relu, int dtype, void* stream) {

@@ -41,6 +41,14 @@ struct ConvParams {
     // backward needs), y = [relu](z * scale + shift [+ residual]); with bn_mean / bn_var set, `scale` /
     // `shift` are gamma / beta of an eval-mode BatchNorm and the affine is formed in the epilogue
     void* z_out;
+    // data-gradient launch that also runs the BatchNorm(+ReLU) backward of the layer that PRODUCED this conv's
+    // input (16-bit kernel): tail_z = that layer's raw conv output (same shape as this launch's output),
+    // scale / shift / bn_* its BatchNorm; the epilogue masks the data gradient with z * sc + sh > 0
+    // (tail_relu), stores dz = d * sc as the output and writes per-row-tile sums of d and d * z to
+    // tail_partials (tiles_m, 2, Cout) for dgamma / dbeta
+    const void* tail_z;
+    float* tail_partials;
+    int tail_relu;
     const float* bn_mean;
     const float* bn_var;
     float bn_eps;

@@ -648,7 +648,13 @@ BRCNN_API int brcnn_conv2d_nhwc(const void* x, const void* w, const float* scale
                                    kw, stride, pad, relu, dtype, stream);
 }
 
-struct TrainTail { void* z_out; const float* mean; const float* var; float eps; };
+struct TrainTail {
+    void* z_out; const float* mean; const float* var; float eps;
+    const void* tail_z; float* partials; int tail_relu;        // data gradient + producer's BatchNorm backward
+};
+
+int brcnn_bn_eval_reduce_launch(const float* partials, int strips, const float* mean, const float* var, float eps,
+                                float* dgamma, float* dbeta, int channels, hipStream_t s);     // bn_act.hip
 
 static int conv_setup_and_launch(const void* x, const void* w, const float* scale, const float* shift,
                                  const void* residual, void* y, int batch, int num_segments,
@@ -656,7 +662,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
                                  const int* out_heights_host, const int* out_widths_host, int cin,
                                  int cout, int kh, int kw, int stride, int pad, int dilate, int relu,
                                  int dtype, void* stream, int pitch = 0, const int* scatter = nullptr,
-                                 const TrainTail* tail = nullptr) {
+                                 const TrainTail* tail = nullptr, int* tiles_m_out = nullptr) {
     if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
         pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
         !heights_host || !widths_host)
@@ -703,12 +709,17 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
         p.sc_o = scatter[4]; p.sc_na = scatter[5]; p.sc_nb = scatter[6];
     }
     if (tail) {         // dual store: 16-bit kernels, whole 16-byte channel pieces
-        if (!bf16 || (cout & 7) || brcnn_out_f32(dtype) || scatter || !tail->z_out || !scale || !shift ||
-            (tail->mean != nullptr) != (tail->var != nullptr))
+        if (!bf16 || (cout & 7) || brcnn_out_f32(dtype) || scatter || (!tail->z_out == !tail->tail_z) || !scale ||
+            !shift || (tail->mean != nullptr) != (tail->var != nullptr) || (tail->tail_z && (!tail->partials || residual)))
             return BRCNN_EINVAL;
         p.z_out = tail->z_out; p.bn_mean = tail->mean; p.bn_var = tail->var; p.bn_eps = tail->eps;
+        p.tail_z = tail->tail_z; p.tail_partials = tail->partials; p.tail_relu = tail->tail_relu;
     }
-    if (bf16) return dispatch_conv_bf16(p, (hipStream_t)stream);
+    if (bf16) {
+        const int st = dispatch_conv_bf16(p, (hipStream_t)stream);
+        if (tiles_m_out) *tiles_m_out = p.tiles_m;
+        return st;
+    }
     return dispatch_conv(p, (hipStream_t)stream);
 }
 
@@ -721,10 +732,42 @@ BRCNN_API int brcnn_conv2d_bn_act_nhwc_multi(const void* x, const void* w, const
                                              const int* heights_host, const int* widths_host, int cin, int cout,
                                              int kh, int kw, int stride, int pad, int relu, int dtype, void* stream) {
     if (!brcnn_is16(dtype) || brcnn_out_f32(dtype)) return BRCNN_EINVAL;
-    const TrainTail tail = {z_out, mean, var, eps};
+    const TrainTail tail = {z_out, mean, var, eps, nullptr, nullptr, 0};
     return conv_setup_and_launch(x, w, gamma, beta, residual, y, batch, num_segments, heights_host, widths_host,
                                  nullptr, nullptr, cin, cout, kh, kw, stride, pad, 1, relu, dtype, stream, 0, nullptr,
                                  &tail);
+}
+
+// Data gradient of a conv whose INPUT came out of conv -> eval-BN -> [ReLU] (the next layer up in a Bottleneck),
+// with that BatchNorm's backward folded into the epilogue: dz_prev = (dx masked by the producer's ReLU) * scale
+// leaves instead of dx, dgamma / dbeta of the producer's BatchNorm come from per-row-tile partial sums (fixed
+// order, deterministic).  Saves the write + read of dx and a launch per layer.  Single map, 16-bit dtypes.
+BRCNN_API size_t brcnn_conv2d_dgrad_bn_backward_workspace_bytes(int batch, int in_height, int in_width, int cin) {
+    const long long m = (long long)batch * in_height * in_width;
+    return (size_t)((m + 63) / 64) * 2 * (size_t)cin * sizeof(float);
+}
+
+BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc(const void* dy, const void* w_t, const void* z_prev,
+                                                  const float* gamma, const float* beta, const float* mean,
+                                                  const float* var, float eps, int relu, void* dz_prev,
+                                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                                  int batch, int in_height, int in_width, int out_height, int out_width,
+                                                  int cin, int cout, int kh, int kw, int stride, int pad, int dtype,
+                                                  void* stream) {
+    if (!z_prev || !gamma || !beta || !mean || !var || !dz_prev || !dgamma || !dbeta || !workspace ||
+        !brcnn_is16(dtype) || brcnn_out_f32(dtype) || pad > kh - 1 || pad > kw - 1 || (cin & 63))
+        return BRCNN_EINVAL;
+    if (workspace_bytes < brcnn_conv2d_dgrad_bn_backward_workspace_bytes(batch, in_height, in_width, cin))
+        return BRCNN_EINVAL;
+    const TrainTail tail = {nullptr, mean, var, eps, z_prev, (float*)workspace, relu};
+    const int ih[1] = {in_height}, iw[1] = {in_width}, oh[1] = {out_height}, ow[1] = {out_width};
+    // roles swap as in brcnn_conv2d_dgrad_nhwc_multi: the kernel's "input" is dy, its "output" the input gradient
+    int tiles_m = 0;
+    const int st = conv_setup_and_launch(dy, w_t, gamma, beta, nullptr, dz_prev, batch, 1, oh, ow, ih, iw, cout, cin, kh,
+                                         kw, 1, kh - 1 - pad, stride, 0, dtype, stream, 0, nullptr, &tail, &tiles_m);
+    if (st) return st;
+    return brcnn_bn_eval_reduce_launch((const float*)workspace, tiles_m, mean, var, eps, dgamma, dbeta, cin,
+                                       (hipStream_t)stream);
 }
 
 BRCNN_API int brcnn_conv2d_nhwc_scatter2(const void* x, const void* w, void* y, int batch, int height, int width,

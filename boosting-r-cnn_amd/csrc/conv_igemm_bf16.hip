@@ -36,7 +36,7 @@ template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { retur
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
-template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0, bool DUAL = false>
+template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
     constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
@@ -160,7 +160,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     const int cw0 = n0 + wn * 32 * NT;            // first channel of this wave
     const bool vec_ok = (p.Cout & 7) == 0;
     const int rl = lane / LPR, cl = (lane % LPR) * 8;
-    const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(p.residual);
+    // (MODE 2 launches with RES: the "residual" rows prefetched here are the producer's z tile)
+    const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(MODE == 2 ? p.tail_z : (const void*)p.residual);
     static_assert(!RES || MT * (32 / RPI) <= 16, "residual prefetch registers: use the non-residual form for 4x4 register tiles");
     uint4 rq[MT][32 / RPI];
     if (RES) {
@@ -292,11 +293,15 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     // DUAL (training): the raw tile leaves as z, the affine is applied in the read-out layout where a lane
     // owns the same 8 channels in every iteration.  The wave's 32*NT channels are derived one per lane
     // (correctly rounded divide / sqrt: ~100 instructions each) and handed out through the wave's slab.
-    constexpr bool dual = DUAL;
+    // MODE 2 (data gradient + the BatchNorm backward of the input's producer): the same per-lane channel
+    // vectors; the lane also accumulates sum d and sum d*z of its 8 channels over its rows.
+    constexpr bool DUAL = MODE == 1;
+    constexpr bool dual = MODE != 0;
     const float* __restrict__ acc_scale = dual ? nullptr : p.scale;
     const float* __restrict__ acc_shift = dual ? nullptr : p.shift;
     float sc8[8], sh8[8];
-    if constexpr (DUAL) {
+    float sum_dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sum_d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE != 0) {
         static_assert(NT <= 2, "one channel per lane");
         if (lane < 32 * NT) {
             const int co = cw0 + lane;
@@ -381,7 +386,22 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                         v[2 * e + 1] = e2f<ET>((unsigned short)(zw[e] >> 16)) * sc8[2 * e + 1] + sh8[2 * e + 1];
                     }
                 }
-                if (RES) {
+                if constexpr (MODE == 2) {
+                    // d = the data gradient as the two-kernel path stores it (rounded), masked by the producer's
+                    // ReLU; out = d * scale (bn_act_bwd_kernel's arithmetic)
+                    const unsigned zw[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float zz = e2f<ET>((unsigned short)((e & 1) ? (zw[e >> 1] >> 16) : (zw[e >> 1] & 0xffffu)));
+                        const float g = e2f<ET>(f2e<ET>(v[e]));
+                        const float pre = zz * sc8[e] + sh8[e];
+                        const float d = (!p.tail_relu || pre > 0.f) ? g : 0.f;
+                        sum_dz[e] += d * zz;
+                        sum_d[e] += d;
+                        v[e] = d * sc8[e];
+                    }
+                }
+                if (RES && MODE != 2) {
                     const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -419,9 +439,39 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (MODE == 2) {
+        // lanes that share the channel vector (equal lane % LPR) hold different rows: butterfly over the
+        // row bits, then the WM waves of one channel range add up through their slabs in a fixed order
+#pragma unroll
+        for (int d = LPR; d < 64; d <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                sum_dz[e] += __shfl_xor(sum_dz[e], d, 64);
+                sum_d[e] += __shfl_xor(sum_d[e], d, 64);
+            }
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { cs[lane * 8 + e] = sum_dz[e]; cs[64 + lane * 8 + e] = sum_d[e]; }
+        }
+        __syncthreads();
+        if (wm == 0 && lane < 32 * NT) {
+            const int co = cw0 + lane;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < WM; k++) {
+                const float* o = smem + (k * WNW + wn) * 32 * PITCH;
+                a += o[lane];
+                b += o[64 + lane];
+            }
+            if (co < p.Cout) {
+                p.tail_partials[((size_t)tile_m * 2 + 0) * p.Cout + co] = a;
+                p.tail_partials[((size_t)tile_m * 2 + 1) * p.Cout + co] = b;
+            }
+        }
+    }
 }
 
-template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2, int ET = 0, bool DUAL = false>
+template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2, int ET = 0, int MODE = 0>
 int launch(const ConvParams& p, hipStream_t s) {
     const size_t lds_stage = (size_t)(32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
     const size_t lds_full = ST * lds_stage;
@@ -432,11 +482,11 @@ int launch(const ConvParams& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         const size_t lds_max = lds_full > lds_epi ? lds_full : lds_epi;
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, DUAL>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, MODE>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, DUAL>), dim3(p.tiles_m * p.tiles_n),
+    hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, MODE>), dim3(p.tiles_m * p.tiles_n),
                        dim3(64 * WM * WNW), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -446,11 +496,12 @@ template <int MT, int NT, int WM = 2, int WNW = 2, int ST = 2, int ET = 0>
 int launch2(ConvParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 32 * MT * WM - 1) / (32 * MT * WM);
     p.tiles_n = (p.Cout + 32 * NT * WNW - 1) / (32 * NT * WNW);
-    if (p.z_out) {      // training dual store: the production tiles of the backbone layers only
+    if (p.z_out || p.tail_z) {      // training epilogues: the production tiles of the backbone layers only
         if constexpr (ST == 2 && NT <= 2 && MT * NT <= 2 && ((WM == 4 && WNW == 2) || (WM == 2 && WNW == 2))) {
             if (p.out_f32) return BRCNN_EINVAL;
-            return p.residual ? launch<MT, NT, true, false, WM, WNW, ST, ET, true>(p, s)
-                              : launch<MT, NT, false, false, WM, WNW, ST, ET, true>(p, s);
+            if (p.tail_z) return p.residual ? BRCNN_EINVAL : launch<MT, NT, true, false, WM, WNW, ST, ET, 2>(p, s);
+            return p.residual ? launch<MT, NT, true, false, WM, WNW, ST, ET, 1>(p, s)
+                              : launch<MT, NT, false, false, WM, WNW, ST, ET, 1>(p, s);
         } else {
             return BRCNN_EINVAL;
         }
@@ -476,7 +527,7 @@ static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     if (p.gstep) return launch2<1, 1, 4, 2, 2, 1>(p, s);
     const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-    const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && t44 >= 512 &&
+    const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && !p.tail_z && t44 >= 512 &&
                         (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
     if (fill44 && p.Cout > 128) return launch2<2, 2, 4, 4, 2, 1>(p, s);
     if (p.Cout <= 64) return launch2<2, 1, 2, 2, 2, 1>(p, s);
@@ -490,7 +541,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     if (p.f16) return dispatch_conv_f16(p, s);
     p.il = g_bf16_il;
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
-    int t = p.z_out ? 0 : g_bf16_tile;
+    int t = (p.z_out || p.tail_z) ? 0 : g_bf16_tile;
     if (t == 0) {
         // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more
         // waves share the LDS-DMA issue of a K tile, the better -- 128x128 on 8 waves of 32x64 beats the
@@ -501,7 +552,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         // TF/s per full generation), but is one workgroup per CU: only when its tile count fills
         // whole generations of 256 (the fused RPN tower: 700 tiles)
         const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-        const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && t44 >= 512 &&
+        const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && !p.tail_z && t44 >= 512 &&
                             (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
         if (fill44) t = 2244;
         else if (p.Cout <= 64) t = 21;

@@ -362,6 +362,22 @@ int brcnn_conv2d_bn_act_nhwc_multi(const void *x, const void *w, const float *ga
                                    const int *heights_host, const int *widths_host, int cin, int cout,
                                    int kh, int kw, int stride, int pad, int relu, int dtype, void *stream);
 
+/* Data gradient of a conv whose input came out of conv -> eval-BN -> [ReLU] (conv2 / conv3 of a Bottleneck,
+ * backbones/resnet.py:263-302), with THAT BatchNorm's backward folded into the epilogue: what leaves is
+ * dz_prev = (dx masked by the producer's ReLU, z_prev * scale + shift > 0) * scale -- the gradient of the
+ * producer's raw conv output -- plus dgamma / dbeta of the producer's BatchNorm (per-row-tile partial sums in
+ * `workspace`, summed in a fixed order).  dy (batch, out_h, out_w, cout), w_t (cin, kh, kw, cout) flipped /
+ * transposed as for brcnn_conv2d_dgrad_nhwc_multi, z_prev / dz_prev (batch, in_h, in_w, cin).  16-bit dtypes,
+ * cin % 64 == 0, cout % 64 == 0.  Values equal brcnn_conv2d_dgrad_nhwc_multi followed by
+ * brcnn_bn_eval_act_backward (dz bit for bit; dgamma / dbeta up to the summation order). */
+size_t brcnn_conv2d_dgrad_bn_backward_workspace_bytes(int batch, int in_height, int in_width, int cin);
+int brcnn_conv2d_dgrad_bn_backward_nhwc(const void *dy, const void *w_t, const void *z_prev, const float *gamma,
+                                        const float *beta, const float *mean, const float *var, float eps, int relu,
+                                        void *dz_prev, float *dgamma, float *dbeta, void *workspace,
+                                        size_t workspace_bytes, int batch, int in_height, int in_width,
+                                        int out_height, int out_width, int cin, int cout, int kh, int kw, int stride,
+                                        int pad, int dtype, void *stream);
+
 /* The same pair with the eval-mode BatchNorm parameters themselves (norm_eval=True,
  * backbones/resnet.py:648-657): scale = gamma / sqrt(var + eps), shift = beta - mean * scale are formed
  * inside the kernels (the reference spends ~5 element-wise torch launches per layer and direction on

@@ -259,6 +259,46 @@ def test_conv_bn_act_one_launch_training_forward(cfg, dtype):
     assert (dw_a - dw_b).abs().max().item() <= 1e-5 * max(1.0, dw_b.abs().max().item())
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cfg', [(2, 256, 64, 1, 20, 28, False), (2, 256, 128, 2, 21, 30, True),
+                                 (8, 512, 128, 1, 50, 84, False), (1, 1024, 512, 2, 13, 17, True)])
+def test_bottleneck_bn_backward_inside_data_gradient_launch(cfg, dtype):
+    """a whole Bottleneck with bn1's / bn2's backward folded into conv2's / conv3's data-gradient launches
+    (`brcnn_conv2d_dgrad_bn_backward_nhwc`) against the same block with the separate bn_act backward launches:
+    input gradient bit for bit (dz is the same arithmetic on the same rounded values), dgamma / dbeta up to the
+    summation order, weight gradients up to the order of their atomics"""
+    from brcnn import autograd as A
+    from brcnn.backbones import Bottleneck
+    N, inplanes, planes, stride, H, W, down = cfg
+    torch.manual_seed(41)
+    ds = None
+    if down:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+    blk = Bottleneck(inplanes, planes if down else inplanes // 4, stride if down else 1, ds).to(DEV)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    blk.eval()          # norm_eval=True: BatchNorm uses its running statistics, gamma / beta still train
+    x = torch.randn(N, H, W, inplanes, device=DEV).to(dtype)
+    got = {}
+    for fused in (True, False):
+        A.FUSE_BN_BACKWARD_INTO_DGRAD = fused
+        try:
+            blk.zero_grad()
+            xd = x.clone().requires_grad_()
+            out = blk.forward_nhwc(xd)
+            go = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(dtype)
+            out.backward(go)
+            got[fused] = (out.detach(), xd.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+        finally:
+            A.FUSE_BN_BACKWARD_INTO_DGRAD = True
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    for k, ga in got[True][2].items():
+        gb = got[False][2][k]
+        assert (ga - gb).abs().max().item() <= 2e-5 * max(1.0, gb.abs().max().item()), k
+
+
 def test_wgrad_bf16_tiles_and_multi_level_agree():
     """64x64, 128x128 and 256x256 (16-wave) output tiles, one multi-level launch vs per-level launches"""
     from brcnn import lib
