@@ -360,6 +360,98 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x,
 }
 
 
+// Row-strip forms of the two apply passes for 16-bit tensors: grid (row chunks, N * nseg) like the statistics
+// kernels, 256 threads = 32 lanes of 8 channels (one 16-byte access) x 8 row lanes.  A thread keeps its 8
+// channels' statistics / affine in registers for all of its rows, so the inner loop is load - ~10 flops per
+// element - store: the flat kernels above re-derive (segment, image, group) and re-fetch the statistics per
+// element and are instruction / latency bound on 16-bit data (1.9 TB/s).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x, const double* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y, GnSegs sg,
+                                                           int N, int C, int G, int rows_per_block, int relu) {
+    const int seg = blockIdx.y / N, n = blockIdx.y - seg * N;
+    const int HW = sg.hw[seg];
+    const int row0 = blockIdx.x * rows_per_block;
+    if (row0 >= HW) return;
+    const int row1 = min(HW, row0 + rows_per_block);
+    const size_t base = (size_t)(sg.row0[seg] + (long long)n * HW) * C;
+    const int c8n = C >> 3, cpg = C / G;
+    const int v = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    for (int v0 = v; v0 < c8n; v0 += 32) {
+        float mean[8], rstd[8], gm[8], bt[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int c = v0 * 8 + e;
+            const float2 mr = reinterpret_cast<const float2*>(stats + ((size_t)blockIdx.y * G + c / cpg) * 2)[0];
+            mean[e] = mr.x; rstd[e] = mr.y; gm[e] = gamma[c]; bt[e] = beta[c];
+        }
+        const T* xs = x + base + v0 * 8;
+        T* ys = y + base + v0 * 8;
+#pragma unroll 4
+        for (int r = row0 + rl; r < row1; r += 8) {
+            float4 a, b;
+            ld8(xs + (size_t)r * C, a, b);
+            float in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float o = (in[e] - mean[e]) * rstd[e] * gm[e] + bt[e];
+                in[e] = relu ? fmaxf(o, 0.f) : o;
+            }
+            st8(ys + (size_t)r * C, make_float4(in[0], in[1], in[2], in[3]), make_float4(in[4], in[5], in[6], in[7]));
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const double* __restrict__ stats,
+                                                               const double* __restrict__ gsum,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, T* __restrict__ dx,
+                                                               GnSegs sg, int N, int C, int G, int rows_per_block, int relu) {
+    const int seg = blockIdx.y / N, n = blockIdx.y - seg * N;
+    const int HW = sg.hw[seg];
+    const int row0 = blockIdx.x * rows_per_block;
+    if (row0 >= HW) return;
+    const int row1 = min(HW, row0 + rows_per_block);
+    const size_t base = (size_t)(sg.row0[seg] + (long long)n * HW) * C;
+    const int c8n = C >> 3, cpg = C / G;
+    const float inv_d = 1.f / ((float)HW * (float)cpg);
+    const int v = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    for (int v0 = v; v0 < c8n; v0 += 32) {
+        float mean[8], rstd[8], gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int c = v0 * 8 + e;
+            const size_t gi = ((size_t)blockIdx.y * G + c / cpg) * 2;
+            const float2 mr = reinterpret_cast<const float2*>(stats + gi)[0];
+            mean[e] = mr.x; rstd[e] = mr.y; gm[e] = gamma[c]; bt[e] = beta[c];
+            s1[e] = (float)gsum[gi]; s2[e] = (float)gsum[gi + 1];
+        }
+        const T* xs = x + base + v0 * 8;
+        const T* ds = dy + base + v0 * 8;
+        T* os = dx + base + v0 * 8;
+#pragma unroll 4
+        for (int r = row0 + rl; r < row1; r += 8) {
+            float4 xa, xb, da, db;
+            ld8(xs + (size_t)r * C, xa, xb);
+            ld8(ds + (size_t)r * C, da, db);
+            const float xi[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float di[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+            float out[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xh = (xi[e] - mean[e]) * rstd[e];
+                const float g = (relu && xh * gm[e] + bt[e] <= 0.f) ? 0.f : di[e];
+                out[e] = rstd[e] * (g * gm[e] - (s1[e] + xh * s2[e]) * inv_d);
+            }
+            st8(os + (size_t)r * C, make_float4(out[0], out[1], out[2], out[3]), make_float4(out[4], out[5], out[6], out[7]));
+        }
+    }
+}
+
+
 // ---- GroupNorm(+ReLU) backward over the same multi-segment NHWC layout ----------------------
 // With xh = (x - mean) * rstd, g = dy (zeroed where the ReLU clipped):
 //     dbeta_c = sum g,  dgamma_c = sum g*xh                     (over images and pixels)
@@ -766,6 +858,8 @@ BRCNN_API int brcnn_maxpool3x3s2_nhwc_backward(const void* x, const void* y, con
     return 0;
 }
 
+constexpr int GN_APPLY_ROWS = 128;      // rows of one image per workgroup of the row-strip apply kernels
+
 template <typename T>
 static int gn_forward_16(const void* x, const float* gamma, const float* beta, void* y, void* stats_ws, const GnSegs& sg,
                          int batch, int num_segments, int channels, int groups, float eps, int relu, int chunks, int rpb,
@@ -776,12 +870,16 @@ static int gn_forward_16(const void* x, const float* gamma, const float* beta, v
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, (double*)stats_ws, sg, batch,
                        channels, groups, eps);
     BRCNN_LAUNCH_CHECK();
-    if (channels & 7)
+    if (channels & 7) {
         hipLaunchKernelGGL((gn_apply_kernel<T, 1>), dim3(stream_grid(total)), dim3(256), 0, s, (const T*)x,
                            (const double*)stats_ws, gamma, beta, (T*)y, sg, batch, channels, groups, relu);
-    else
-        hipLaunchKernelGGL((gn_apply_kernel<T, 2>), dim3(stream_grid(total / 2)), dim3(256), 0, s, (const T*)x,
-                           (const double*)stats_ws, gamma, beta, (T*)y, sg, batch, channels, groups, relu);
+    } else {
+        int max_hw = 0;
+        for (int i = 0; i < sg.nseg; i++) max_hw = sg.hw[i] > max_hw ? sg.hw[i] : max_hw;
+        hipLaunchKernelGGL(gn_apply_rows_kernel<T>, dim3((max_hw + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS, batch * num_segments),
+                           dim3(256), 0, s, (const T*)x, (const double*)stats_ws, gamma, beta, (T*)y, sg, batch, channels,
+                           groups, GN_APPLY_ROWS, relu);
+    }
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -823,6 +921,11 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s,
                            (double*)stats_ws, sg, batch, channels, groups, eps);
         BRCNN_LAUNCH_CHECK();
+        if (!(channels & 7))
+            hipLaunchKernelGGL(gn_apply_rows_kernel<float>, dim3((max_hw + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS, batch * num_segments),
+                               dim3(256), 0, s, (const float*)x, (const double*)stats_ws, gamma, beta, (float*)y, sg, batch, channels,
+                               groups, GN_APPLY_ROWS, relu);
+        else
         hipLaunchKernelGGL((gn_apply_kernel<float, 1>), dim3(stream_grid(total)), dim3(256), 0, s,
                            (const float*)x, (const double*)stats_ws, gamma, beta, (float*)y, sg, batch,
                            channels, groups, relu);
@@ -918,11 +1021,25 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
     BRCNN_LAUNCH_CHECK();
     // one channel quad per thread: the two-quad (16-byte) form measured 35 % SLOWER here (295 vs 208 us per
     // backward of the tower tensor in bf16), although it is the faster one in the forward apply kernel
-    if (dtype == BRCNN_DT_F32)
+    if (dtype == BRCNN_DT_F32 && !(channels & 7))
+        hipLaunchKernelGGL(gn_bwd_apply_rows_kernel<float>, dim3((max_hw + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS, batch * num_segments), dim3(256), 0, s, (const float*)x, (const float*)dy,
+                               (const double*)stats, gsum, gamma, beta, (float*)dx, sg, batch, channels, groups,
+                               GN_APPLY_ROWS, relu);
+    else if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<float, 1>), dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x,
                            (const float*)dy, (const double*)stats, gsum, gamma, beta, (float*)dx, sg, batch, channels,
                            groups, relu);
-    else if (dtype == BRCNN_DT_BF16)
+    else if ((channels & 7) == 0) {      // 16-bit, whole 16-byte channel vectors: the row-strip form
+        const dim3 grid((max_hw + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS, batch * num_segments);
+        if (dtype == BRCNN_DT_BF16)
+            hipLaunchKernelGGL(gn_bwd_apply_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
+                               (const double*)stats, gsum, gamma, beta, (bf16_t*)dx, sg, batch, channels, groups,
+                               GN_APPLY_ROWS, relu);
+        else
+            hipLaunchKernelGGL(gn_bwd_apply_rows_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, (const f16_t*)dy,
+                               (const double*)stats, gsum, gamma, beta, (f16_t*)dx, sg, batch, channels, groups,
+                               GN_APPLY_ROWS, relu);
+    } else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, 1>), dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x,
                            (const bf16_t*)dy, (const double*)stats, gsum, gamma, beta, (bf16_t*)dx, sg, batch, channels,
                            groups, relu);
