@@ -52,6 +52,19 @@ def wgrad_shape(a):      # (x,dy,dw,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,dt,s
     return (m, cout, kh * kw * cin)
 
 
+def fused_fwd_shape(a):  # (x,w,gamma,beta,mean,var,eps,res,z,y,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,relu,dt,stream)
+    batch, nl, hs, ws, cin, cout, kh, kw, stride, pad = a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19]
+    m = sum(batch * ((hs[i] + 2 * pad - kh) // stride + 1) * ((ws[i] + 2 * pad - kw) // stride + 1) for i in range(nl))
+    return (m, cout, kh * kw * cin)
+
+
+def fused_dgrad_shape(a):  # (dy,w_t,z,g,b,m,v,eps,relu,dz,dg,db,ws,nb,batch,ih,iw,oh,ow,cin,cout,kh,kw,stride,pad,dt,stream)
+    batch, ih, iw, cin, cout, kh, kw = a[14], a[15], a[16], a[19], a[20], a[21], a[22]
+    return (batch * ih * iw, cin, kh * kw * cout)
+
+
+wrap('brcnn_conv2d_bn_act_nhwc_multi', fused_fwd_shape)
+wrap('brcnn_conv2d_dgrad_bn_backward_nhwc', fused_dgrad_shape)
 wrap('brcnn_conv2d_nhwc_multi', multi_shape)
 wrap('brcnn_conv2d_nhwc', single_shape)
 wrap('brcnn_conv2d_dgrad_nhwc_multi', dgrad_shape)
