@@ -44,8 +44,10 @@ class Bottleneck(nn.Module):
             out, identity = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True,
                                              single_use_output=True)
         else:
-            out = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, single_use_output=True)
-            identity = conv_bn_act_nhwc(x, self.downsample[0], self.downsample[1], self._c[3], False)
+            # the downsample branch reads conv1's input through the same alias: its data gradient is added in
+            # conv1's data-gradient epilogue too (stride-1 conv1, the 'pytorch' style) instead of by an autograd add
+            out, xs = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True, single_use_output=True)
+            identity = conv_bn_act_nhwc(xs, self.downsample[0], self.downsample[1], self._c[3], False)
         # out of conv1 / conv2 feeds the next conv only: that conv's data-gradient launch runs bn1's / bn2's backward
         out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True, sole_consumer=True, single_use_output=True)
         # relu(bn3(conv3(out)) + identity) in one epilogue (resnet.py:288-300)
