@@ -128,9 +128,10 @@ def train_bench(args, world, rank, device):
     model, cfg = build_model('boosting_rcnn_r50_pafpn_1x_coco.py', device)
     model = model.train()
     model.set_compute_dtype(args.train_dtype)
-    params = [p for p in model.parameters() if p.requires_grad]
     from brcnn import blocks
     from brcnn.optim import FusedSGD
+    blocks.conv_weights_channels_last(model)        # the weight-gradient kernels' layout: no per-layer grad copies
+    params = [p for p in model.parameters() if p.requires_grad]
     # the recipes' optimizer (SGD, momentum 0.9, weight decay 1e-4, grad-clip 35) on the fused HIP step
     opt = FusedSGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
                    weight_decay=cfg.optimizer.weight_decay)

@@ -418,6 +418,9 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
                                               len(cfg.get('gpu_ids', [0])), dist=distributed, seed=cfg.get('seed'),
                                               rank=rank, world_size=world), device) for ds in dataset]
     model = model.to(device)
+    if device.type == 'cuda':
+        from .blocks import conv_weights_channels_last
+        conv_weights_channels_last(model)       # before DDP takes the parameters' strides for its bucket views
     if distributed:
         from torch.nn.parallel import DistributedDataParallel
         model = DistributedDataParallel(

@@ -12,6 +12,8 @@ Activations between bricks are (N,H,W,C) contiguous fp32 tensors ("nhwc").  `to_
 gives the zero-copy logical (N,C,H,W) view (== torch.channels_last) used at the public
 module boundaries.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -154,6 +156,23 @@ def build_norm_layer(cfg, num_features, postfix=''):
     for p in layer.parameters():
         p.requires_grad = requires_grad
     return name + str(postfix), layer
+
+
+def conv_weights_channels_last(module):
+    """store the spatial (KH*KW > 1) weights of the trainable dense nn.Conv2d layers of `module` with
+    torch.channels_last strides -- (Cout, KH, KW, Cin) in memory, the layout the weight-gradient kernel writes --
+    so that its result becomes `weight.grad` as it is (autograd's layout contract) instead of through one copy
+    per layer and step.  Values, shapes and state_dict keys are unchanged; call before wrapping the model in
+    DistributedDataParallel (its bucket views take the parameters' strides).  Returns the number converted."""
+    n = 0
+    if os.environ.get('BRCNN_CL_WEIGHTS', '1') == '0':
+        return n
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d) and m.groups == 1 and m.weight.requires_grad and m.weight.shape[2] * m.weight.shape[3] > 1 \
+                and not m.weight.is_contiguous(memory_format=torch.channels_last):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+            n += 1
+    return n
 
 
 # training forward of conv -> eval-BN -> act as one launch where `autograd.conv_bn_eval_act_fusable` allows

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(const SgdTable t, const
 }
 
 struct PackEntry {
-    const float* w;    // (Cout, Cin, KH, KW) fp32 master weight
+    const float* w;    // (Cout, Cin, KH, KW) fp32 master weight; src_cl: stored channels-last, i.e. (Cout, KH, KW, Cin)
+    int src_cl;
     void* fwd;         // (Cout, KH, KW, Cin)
     void* dgrad;       // (Cin, KH, KW, Cout), taps flipped; may be NULL
     int cout, cin, kh, kw;
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackTable t, cons
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8) {                            // rows = co, columns = ci
         const int co = co0 + j, ci = ci0 + tx;
-        tile[j][tx] = (co < e.cout && ci < e.cin) ? e.w[((size_t)co * e.cin + ci) * taps + tap] : 0.f;
+        const size_t src = e.src_cl ? ((size_t)co * taps + tap) * e.cin + ci : ((size_t)co * e.cin + ci) * taps + tap;
+        tile[j][tx] = (co < e.cout && ci < e.cin) ? e.w[src] : 0.f;
     }
     __syncthreads();
     T* fwd = reinterpret_cast<T*>(e.fwd);
@@ -226,8 +228,10 @@ BRCNN_API int brcnn_sgd_step(float* const* params, const float* const* grads, fl
 
 // forward / data-gradient operands of `num` conv weights in one launch per TAB tensors.  dims_host: 4 ints per tensor
 // (cout, cin, kh, kw); dgrad[i] may be NULL.  ctl3: the optimizer's control block (packing is skipped with the step) or NULL.
+// channels_last_host (num ints, or NULL = all 0): tensor i is stored with torch.channels_last strides.
 BRCNN_API int brcnn_pack_conv_weights_batch(const float* const* weights, void* const* fwd, void* const* dgrad,
-                                            const int* dims_host, int num, int dtype, const float* ctl3, void* stream) {
+                                            const int* dims_host, const int* channels_last_host, int num, int dtype,
+                                            const float* ctl3, void* stream) {
     if (num <= 0) return 0;
     if (!weights || !fwd || !dgrad || !dims_host || !brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -240,6 +244,7 @@ BRCNN_API int brcnn_pack_conv_weights_batch(const float* const* weights, void* c
             const int* d = dims_host + 4 * k;
             if (!weights[k] || (!fwd[k] && !dgrad[k]) || d[0] <= 0 || d[1] <= 0 || d[2] <= 0 || d[3] <= 0) return BRCNN_EINVAL;
             t.e[i].w = weights[k]; t.e[i].fwd = fwd[k]; t.e[i].dgrad = dgrad[k];
+            t.e[i].src_cl = channels_last_host ? (channels_last_host[k] != 0) : 0;
             t.e[i].cout = d[0]; t.e[i].cin = d[1]; t.e[i].kh = d[2]; t.e[i].kw = d[3];
             t.e[i].blk0 = (int)blk;
             blk += (long long)((d[0] + 31) / 32) * ((d[1] + 31) / 32) * d[2] * d[3];

@@ -19,6 +19,15 @@ from . import lib as _L
 from .ops import _dt, _ptr, _stream
 
 
+def _dense_layout(t):
+    """'contiguous' / 'channels_last' when `t` covers its storage densely in that order, else None"""
+    if t.is_contiguous():
+        return 'contiguous'
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return 'channels_last'
+    return None
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, **kwargs):
         if dampening != 0 or nesterov:
@@ -39,13 +48,14 @@ class FusedSGD(torch.optim.Optimizer):
     def register_conv_weights(self, module, dtype):
         """keep the packed forward / data-gradient operands of every trainable, ungrouped nn.Conv2d weight of
         `module` current in `dtype` (the compute dtype): written by `step()`, consumed by
-        `autograd.ConvNHWCFunction` through `weight._brcnn_pack`"""
+        `autograd.ConvNHWCFunction` through `weight._brcnn_pack`.  Weights stored channels-last
+        (`blocks.conv_weights_channels_last`) are read in that layout."""
         mult = 32 if dtype == torch.float32 else 64
         self._conv, self._conv_dtype = [], dtype
         mine = {id(p) for g in self.param_groups for p in g['params']}
         for m in module.modules():
             if isinstance(m, torch.nn.Conv2d) and m.groups == 1 and id(m.weight) in mine and m.weight.requires_grad \
-                    and m.weight.shape[0] % mult == 0 and m.weight.is_contiguous():
+                    and m.weight.shape[0] % mult == 0 and _dense_layout(m.weight) is not None:
                 w = m.weight
                 co, ci, kh, kw = w.shape
                 self._conv.append((w, torch.empty((co, kh, kw, ci), dtype=dtype, device=w.device),
@@ -61,7 +71,8 @@ class FusedSGD(torch.optim.Optimizer):
         fw = (ctypes.c_void_p * n)(*[f.data_ptr() for _, f, _ in self._conv])
         dg = (ctypes.c_void_p * n)(*[d.data_ptr() for _, _, d in self._conv])
         dims = (ctypes.c_int * (4 * n))(*[int(v) for w, _, _ in self._conv for v in w.shape])
-        st = _L.load().brcnn_pack_conv_weights_batch(ws, fw, dg, dims, n, _dt(self._conv[0][1]), _ptr(ctl), _stream())
+        cl = (ctypes.c_int * n)(*[int(_dense_layout(w) == 'channels_last') for w, _, _ in self._conv])
+        st = _L.load().brcnn_pack_conv_weights_batch(ws, fw, dg, dims, cl, n, _dt(self._conv[0][1]), _ptr(ctl), _stream())
         _L.check(st, 'brcnn_pack_conv_weights_batch')
         for w, f, d in self._conv:
             w._brcnn_pack = (w._version, self._conv_dtype, f, d)
@@ -87,16 +98,19 @@ class FusedSGD(torch.optim.Optimizer):
             for p in group['params']:
                 if p.grad is None:
                     continue
+                if _dense_layout(p) is None or p.dtype != torch.float32:
+                    raise _L.BrcnnHipError('FusedSGD: fp32 parameters in a dense layout (contiguous or channels-last) expected')
+                # the update is element-wise by memory offset: gradient and momentum buffer in the parameter's layout
                 g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.float().contiguous()
-                if not p.is_contiguous() or p.dtype != torch.float32:
-                    raise _L.BrcnnHipError('FusedSGD: fp32 contiguous parameters expected')
+                if g.dtype != torch.float32 or g.stride() != p.stride():
+                    g = torch.empty_like(p).copy_(g)
                 state = self.state[p]
                 buf = state.get('momentum_buffer')
+                if buf is not None and (buf.stride() != p.stride() or buf.dtype != torch.float32):
+                    buf = state['momentum_buffer'] = torch.empty_like(p).copy_(buf)     # e.g. a loaded checkpoint
                 has.append(0 if buf is None else 1)
                 if buf is None and group['momentum'] != 0:
-                    buf = state['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                    buf = state['momentum_buffer'] = torch.empty_like(p)
                 ps.append(p)
                 gs.append(g)
                 bs.append(buf)

@@ -640,8 +640,10 @@ int brcnn_boost_loss_backward(const float *cls_score, const float *bbox_pred, co
  *   ctl3 = [ ||g||_2 / loss_scale, applied factor, skipped ]; the step is skipped when the norm is not finite
  *   d = g * factor + wd * w;  buf = has_buf ? momentum * buf + d : d;  w -= lr * buf   (dampening 0, no nesterov)
  * brcnn_pack_conv_weights_batch: forward (Cout,KH,KW,Cin) and data-gradient (Cin,KH,KW,Cout, taps flipped)
- * operands of many conv weights in one launch per 64 tensors (dims_host: cout, cin, kh, kw each); with ctl3 the
- * packing follows the step it belongs to (skipped together).
+ * operands of many conv weights in one launch per 64 tensors (dims_host: cout, cin, kh, kw each;
+ * channels_last_host[i] != 0: master weight i is stored with torch.channels_last strides -- the layout the
+ * weight-gradient kernel writes, so that its result IS the parameter's gradient without a layout copy; NULL =
+ * all contiguous); with ctl3 the packing follows the step it belongs to (skipped together).
  * -------------------------------------------------------------------------- */
 size_t brcnn_sgd_workspace_bytes(int num_tensors, const int64_t *numel_host);
 int brcnn_sgd_step(float *const *params, const float *const *grads, float *const *bufs, const int64_t *numel_host,
@@ -649,7 +651,8 @@ int brcnn_sgd_step(float *const *params, const float *const *grads, float *const
                    float momentum, float max_norm, float inv_scale, void *workspace, size_t workspace_bytes,
                    float *ctl3, void *stream);
 int brcnn_pack_conv_weights_batch(const float *const *weights, void *const *fwd, void *const *dgrad,
-                                  const int *dims_host, int num, int dtype, const float *ctl3, void *stream);
+                                  const int *dims_host, const int *channels_last_host, int num, int dtype,
+                                  const float *ctl3, void *stream);
 
 #ifdef __cplusplus
 }

@@ -483,7 +483,8 @@ def test_train_step_device_path_mixed_shapes_and_empty_gt():
         assert np.isclose(vals[True][k], vals[False][k], rtol=2e-4, atol=1e-6), (k, vals[True][k], vals[False][k])
 
 
-def test_fused_sgd_matches_torch_sgd_with_clipping():
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_fused_sgd_matches_torch_sgd_with_clipping(channels_last):
     """FusedSGD (clip + SGD momentum / weight decay in one pass, per-group lr / decay) against torch.optim.SGD +
     clip_grad_norm_ over several steps; a non-finite gradient skips the step (the GradScaler rule) and loss-scaled
     gradients are unscaled inside; the conv operands it writes for the next step equal the per-layer packing"""
@@ -500,6 +501,9 @@ def test_fused_sgd_matches_torch_sgd_with_clipping():
     b.load_state_dict(a.state_dict())
     groups = lambda n: [dict(params=[n[0].weight, n[2].weight]), dict(params=[n[0].bias, n[2].bias, n[3].bias], lr=0.04, weight_decay=0.0),  # noqa: E731
                         dict(params=[n[1].weight, n[1].bias, n[3].weight], weight_decay=0.0)]
+    if channels_last:       # the 3x3 weight stored in the weight-gradient kernel's layout (blocks.conv_weights_channels_last)
+        from brcnn import blocks
+        assert blocks.conv_weights_channels_last(a) == 1 and not a[0].weight.is_contiguous()
     oa = FusedSGD(groups(a), lr=0.02, momentum=0.9, weight_decay=1e-4)
     ob = torch.optim.SGD(groups(b), lr=0.02, momentum=0.9, weight_decay=1e-4)
     assert oa.register_conv_weights(a, torch.bfloat16) == 2
@@ -526,7 +530,7 @@ def test_fused_sgd_matches_torch_sgd_with_clipping():
         co, ci, kh, kw = w.shape
         f2 = torch.empty((co, kh, kw, ci), dtype=torch.bfloat16, device=DEV)
         d2 = torch.empty((ci, kh, kw, co), dtype=torch.bfloat16, device=DEV)
-        st = lib.load().brcnn_pack_conv_weights(_ptr(w.detach()), _ptr(f2), _ptr(d2), co, ci, kh, kw, 1, _stream())
+        st = lib.load().brcnn_pack_conv_weights(_ptr(w.detach().contiguous()), _ptr(f2), _ptr(d2), co, ci, kh, kw, 1, _stream())
         assert st == 0 and torch.equal(f, f2) and torch.equal(d, d2)
         assert torch.equal(f.float(), w.detach().permute(0, 2, 3, 1).to(torch.bfloat16).float())
     # a non-finite gradient: nothing moves, the packed operands stay valid
