@@ -299,6 +299,72 @@ def test_bottleneck_bn_backward_inside_data_gradient_launch(cfg, dtype):
         assert (ga - gb).abs().max().item() <= 2e-5 * max(1.0, gb.abs().max().item()), k
 
 
+@pytest.mark.parametrize('down', [False, True])
+def test_bottleneck_against_plain_torch_float64(down, dtype='f32'):
+    """a Bottleneck in fp32 (identity alias through conv1, downsample branch through the same alias) against the
+    textbook module graph in float64 on the CPU (resnet.py Bottleneck.forward:263-302 with eval-mode BatchNorm):
+    output and every gradient.  (The 16-bit block with its fused BatchNorm launches is checked bit for bit against
+    the same block with separate launches above; against float64 it differs by the ReLU masks that flip when a
+    pre-activation rounds across zero -- ~5 % in the Frobenius norm on random data.)"""
+    from brcnn.backbones import Bottleneck
+    torch.manual_seed(43)
+    inplanes, planes, stride = (128, 64, 2) if down else (256, 64, 1)
+    ds = None
+    if down:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+    blk = Bottleneck(inplanes, planes, stride, ds)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    blk.eval()
+    x = torch.randn(2, inplanes, 18, 22)
+    go = torch.randn(2, planes * 4, 18 // stride, 22 // stride)
+    if dtype == 'bf16':     # operands the 16-bit path represents exactly
+        x, go = x.bfloat16().float(), go.bfloat16().float()
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, torch.nn.Conv2d):
+                    m.weight.copy_(m.weight.bfloat16().float())
+    # float64 reference: plain torch modules
+    import copy
+    ref = copy.deepcopy(blk).double()
+    xr = x.double().requires_grad_()
+
+    def bn(mod, t):
+        return F.batch_norm(t, mod.running_mean, mod.running_var, mod.weight, mod.bias, False, 0.0, mod.eps)
+    o = bn(ref.bn1, ref.conv1(xr)).relu()
+    o = bn(ref.bn2, ref.conv2(o)).relu()
+    o = bn(ref.bn3, ref.conv3(o))
+    idt = bn(ref.downsample[1], ref.downsample[0](xr)) if down else xr
+    out_r = (o + idt).relu()
+    out_r.backward(go.double())
+    # device
+    blk = blk.to(DEV)
+    blocks.set_compute_dtype(dtype)
+    try:
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        if dtype == 'bf16':
+            xd = xd.bfloat16()
+        xd.requires_grad_()
+        out = blk.forward_nhwc(xd)
+        out.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV).to(out.dtype))
+    finally:
+        blocks.set_compute_dtype('f32')
+    def close(a, b):
+        a, b = a.double().cpu(), b.double()
+        if dtype == 'f32':
+            return (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+        # bf16: three layers of activations / gradients rounded to 8 bits, and a ReLU whose pre-activation rounds
+        # across zero passes or blocks a whole gradient element: judged in the Frobenius norm
+        return (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-6
+    assert close(out.detach().float().permute(0, 3, 1, 2), out_r.detach())
+    assert close(xd.grad.float().permute(0, 3, 1, 2), xr.grad)
+    rp = dict(ref.named_parameters())
+    for k, p_ in blk.named_parameters():
+        assert p_.grad is not None and close(p_.grad, rp[k].grad), k
+
+
 def test_wgrad_bf16_tiles_and_multi_level_agree():
     """64x64, 128x128 and 256x256 (16-wave) output tiles, one multi-level launch vs per-level launches"""
     from brcnn import lib
