@@ -506,11 +506,12 @@ class BnTail:
     its own data-gradient launch (`brcnn_conv2d_dgrad_bn_backward_nhwc`), and where it leaves the results for
     the producer's backward.  Only valid when the consumer is the ONLY user of the producer's output (conv2 /
     conv3 of a Bottleneck): the gradient that then travels along the autograd edge is dz, not d(output)."""
-    __slots__ = ('z', 'g', 'b', 'm', 'v', 'eps', 'relu', 'done', 'dgamma', 'dbeta')
+    __slots__ = ('z', 'g', 'b', 'm', 'v', 'eps', 'relu', 'out', 'done', 'dgamma', 'dbeta', 'dres')
 
-    def __init__(self, z, g, b, m, v, eps, relu):
+    def __init__(self, z, g, b, m, v, eps, relu, out=None):
         self.z, self.g, self.b, self.m, self.v, self.eps, self.relu = z, g, b, m, v, eps, relu
-        self.done, self.dgamma, self.dbeta = False, None, None
+        self.out = out          # residual producer (bn3): its output -- the ReLU mask and the consumer's own input
+        self.done, self.dgamma, self.dbeta, self.dres = False, None, None, None
 
 
 class ConvBnEvalActFunction(Function):
@@ -549,8 +550,8 @@ class ConvBnEvalActFunction(Function):
                    gamma.dtype, beta.dtype)
         ctx.in_tail = in_tail if (in_tail is not None and w_t is not None and x_cat.requires_grad) else None
         ctx.tail = None
-        if out_tail is not None and res is None:
-            ctx.tail = BnTail(z, g32, b32, m32, v32, float(eps), bool(relu))
+        if out_tail is not None:
+            ctx.tail = BnTail(z, g32, b32, m32, v32, float(eps), bool(relu), out if res is not None else None)
             out_tail.append(ctx.tail)
         if with_skip:
             return out, x_cat.view_as(x_cat)
@@ -568,8 +569,8 @@ class ConvBnEvalActFunction(Function):
         dres = None
         if ctx.tail is not None and ctx.tail.done:
             # the sole consumer's data-gradient launch already ran this BatchNorm's backward: `dout` IS dz
-            dz, dgamma, dbeta = dout, ctx.tail.dgamma, ctx.tail.dbeta
-            ctx.tail.done, ctx.tail.dgamma, ctx.tail.dbeta = False, None, None
+            dz, dgamma, dbeta, dres = dout, ctx.tail.dgamma, ctx.tail.dbeta, ctx.tail.dres
+            ctx.tail.done, ctx.tail.dgamma, ctx.tail.dbeta, ctx.tail.dres = False, None, None, None
         else:
             dz = torch.empty_like(z)
             dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[7] else None
@@ -582,7 +583,9 @@ class ConvBnEvalActFunction(Function):
                                                 int(relu), dt, _stream())
             _L.check(st, 'brcnn_bn_eval_act_backward')
         t = ctx.in_tail
-        if t is not None and ctx.needs_input_grad[0] and dskip is None:
+        # a residual producer (previous block's bn3) needs this conv's identity alias gradient; a plain one none
+        if t is not None and ctx.needs_input_grad[0] and (dskip is not None) == (t.out is not None) and \
+                (dskip is None or dskip.dtype == x_cat.dtype):
             # data gradient + the producer's BatchNorm backward in one launch: dx leaves as the producer's dz
             cout, cin, kh, kw = weight.shape
             (h, w_), (ho, wo) = sizes[0], out_sizes[0]
@@ -591,8 +594,12 @@ class ConvBnEvalActFunction(Function):
             t.dbeta = torch.empty(cin, dtype=torch.float32, device=z.device)
             nb = lib.brcnn_conv2d_dgrad_bn_backward_workspace_bytes(batch, h, w_, cin)
             ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
+            if dskip is not None:
+                dskip = dskip.contiguous()
+                t.dres = torch.empty_like(x_cat)
             st = lib.brcnn_conv2d_dgrad_bn_backward_nhwc(_ptr(dz), _ptr(ctx.w_t), _ptr(t.z), _ptr(t.g), _ptr(t.b), _ptr(t.m),
-                                                         _ptr(t.v), t.eps, int(t.relu), _ptr(dzp), _ptr(t.dgamma),
+                                                         _ptr(t.v), t.eps, int(t.relu), _ptr(dskip), _ptr(t.out), _ptr(t.dres),
+                                                         _ptr(dzp), _ptr(t.dgamma),
                                                          _ptr(t.dbeta), _ptr(ws), nb, batch, h, w_, ho, wo, cin, cout, kh, kw,
                                                          stride, pad, dt, _stream())
             _L.check(st, 'brcnn_conv2d_dgrad_bn_backward_nhwc')
@@ -610,6 +617,11 @@ class ConvBnEvalActFunction(Function):
 
 # conv2 / conv3 of a Bottleneck run the BatchNorm backward of bn1 / bn2 inside their data-gradient launches
 FUSE_BN_BACKWARD_INTO_DGRAD = _os.environ.get('BRCNN_FUSE_BN_BWD', '1') != '0'
+# ... and, optionally, conv1 of the NEXT block of a stage the backward of bn3 (residual + ReLU) of the block before
+# it.  Off by default: measured 0.2 ms SLOWER per step (23.87 -> 24.07 ms) -- conv1's data gradient is a short-K
+# 1x1 launch that is output-bound already, and three more tile streams through its epilogue cost more than the
+# dedicated streaming kernel they replace (profiles/r02_notes.md).  BRCNN_FUSE_BN3_BWD=1 enables it.
+FUSE_RESIDUAL_BN_BACKWARD = _os.environ.get('BRCNN_FUSE_BN3_BWD', '0') == '1'
 
 
 def conv_bn_eval_act_fusable(x, conv, bn, residual):
@@ -633,7 +645,8 @@ def conv_bn_eval_act_autograd(x, conv, bn, residual=None, relu=True, with_skip=F
     ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
     res = residual.reshape(n * ho * wo, cout) if residual is not None else None
     in_tail = getattr(x, '_brcnn_tail', None) if sole_consumer and FUSE_BN_BACKWARD_INTO_DGRAD else None
-    out_tail = [] if single_use_output and residual is None and FUSE_BN_BACKWARD_INTO_DGRAD else None
+    out_tail = [] if single_use_output and FUSE_BN_BACKWARD_INTO_DGRAD and \
+        (residual is None or FUSE_RESIDUAL_BN_BACKWARD) else None
     y = ConvBnEvalActFunction.apply(x.reshape(n * h * w, cin), conv.weight, bn.weight, bn.bias, bn.running_mean,
                                     bn.running_var, bn.eps, res, relu, n, (h, w), stride, pad, with_skip, in_tail, out_tail)
     skip = None

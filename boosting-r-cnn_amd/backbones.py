@@ -37,12 +37,16 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self._c = [PackedCache() for _ in range(4)]
 
-    def forward_nhwc(self, x):
+    chain_fusion = True        # ResLayer may pass `out_single_use` / `in_from_prev`
+
+    def forward_nhwc(self, x, out_single_use=False, in_from_prev=False):
+        """`out_single_use`: the caller promises that the result feeds only the next block of the stage (whose
+        conv1 then runs bn3's backward inside its data-gradient launch); `in_from_prev`: x is such a result"""
         if self.downsample is None:
             # the identity branch leaves through conv1's autograd node: its gradient is added in
             # conv1's data-gradient kernel instead of by a separate add over the whole tensor
             out, identity = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True,
-                                             single_use_output=True)
+                                             sole_consumer=in_from_prev, single_use_output=True)
         else:
             # the downsample branch reads conv1's input through the same alias: its data gradient is added in
             # conv1's data-gradient epilogue too (stride-1 conv1, the 'pytorch' style) instead of by an autograd add
@@ -51,7 +55,8 @@ class Bottleneck(nn.Module):
         # out of conv1 / conv2 feeds the next conv only: that conv's data-gradient launch runs bn1's / bn2's backward
         out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True, sole_consumer=True, single_use_output=True)
         # relu(bn3(conv3(out)) + identity) in one epilogue (resnet.py:288-300)
-        return conv_bn_act_nhwc(out, self.conv3, self.bn3, self._c[2], True, residual=identity, sole_consumer=True)
+        return conv_bn_act_nhwc(out, self.conv3, self.bn3, self._c[2], True, residual=identity, sole_consumer=True,
+                                single_use_output=out_single_use)
 
     def forward(self, x):
         return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
@@ -74,8 +79,13 @@ class ResLayer(nn.Sequential):
         super().__init__(*layers)
 
     def forward_nhwc(self, x):
-        for blk in self:
-            x = blk.forward_nhwc(x)
+        n = len(self)
+        for i, blk in enumerate(self):
+            if getattr(type(blk), 'chain_fusion', False):
+                # the output of every block but the last feeds only the next block of the stage
+                x = blk.forward_nhwc(x, out_single_use=i + 1 < n, in_from_prev=i > 0)
+            else:
+                x = blk.forward_nhwc(x)
         return x
 
 
@@ -466,8 +476,13 @@ class Res2Layer(nn.Sequential):
         super().__init__(*layers)
 
     def forward_nhwc(self, x):
-        for blk in self:
-            x = blk.forward_nhwc(x)
+        n = len(self)
+        for i, blk in enumerate(self):
+            if getattr(type(blk), 'chain_fusion', False):
+                # the output of every block but the last feeds only the next block of the stage
+                x = blk.forward_nhwc(x, out_single_use=i + 1 < n, in_from_prev=i > 0)
+            else:
+                x = blk.forward_nhwc(x)
         return x
 
 

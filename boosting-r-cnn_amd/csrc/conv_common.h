@@ -49,6 +49,11 @@ struct ConvParams {
     const void* tail_z;
     float* tail_partials;
     int tail_relu;
+    // ... of a RESIDUAL producer (bn3 of the previous Bottleneck): `residual` is the identity branch's gradient
+    // (added first, as in the plain data-gradient launch), tail_mask the producer's output (ReLU mask: > 0),
+    // tail_dres receives the masked gradient itself (the identity gradient of the previous block)
+    const void* tail_mask;
+    void* tail_dres;
     const float* bn_mean;
     const float* bn_var;
     float bn_eps;

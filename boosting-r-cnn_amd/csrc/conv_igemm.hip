@@ -651,6 +651,7 @@ BRCNN_API int brcnn_conv2d_nhwc(const void* x, const void* w, const float* scale
 struct TrainTail {
     void* z_out; const float* mean; const float* var; float eps;
     const void* tail_z; float* partials; int tail_relu;        // data gradient + producer's BatchNorm backward
+    const void* tail_mask; void* dres;                         // ... of a residual producer (see ConvParams)
 };
 
 int brcnn_bn_eval_reduce_launch(const float* partials, int strips, const float* mean, const float* var, float eps,
@@ -710,10 +711,13 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     }
     if (tail) {         // dual store: 16-bit kernels, whole 16-byte channel pieces
         if (!bf16 || (cout & 7) || brcnn_out_f32(dtype) || scatter || (!tail->z_out == !tail->tail_z) || !scale ||
-            !shift || (tail->mean != nullptr) != (tail->var != nullptr) || (tail->tail_z && (!tail->partials || residual)))
+            !shift || (tail->mean != nullptr) != (tail->var != nullptr) ||
+            (tail->tail_z && (!tail->partials || (residual != nullptr) != (tail->tail_mask != nullptr) ||
+                              (tail->tail_mask != nullptr) != (tail->dres != nullptr))))
             return BRCNN_EINVAL;
         p.z_out = tail->z_out; p.bn_mean = tail->mean; p.bn_var = tail->var; p.bn_eps = tail->eps;
         p.tail_z = tail->tail_z; p.tail_partials = tail->partials; p.tail_relu = tail->tail_relu;
+        p.tail_mask = tail->tail_mask; p.tail_dres = tail->dres;
     }
     if (bf16) {
         const int st = dispatch_conv_bf16(p, (hipStream_t)stream);
@@ -732,7 +736,7 @@ BRCNN_API int brcnn_conv2d_bn_act_nhwc_multi(const void* x, const void* w, const
                                              const int* heights_host, const int* widths_host, int cin, int cout,
                                              int kh, int kw, int stride, int pad, int relu, int dtype, void* stream) {
     if (!brcnn_is16(dtype) || brcnn_out_f32(dtype)) return BRCNN_EINVAL;
-    const TrainTail tail = {z_out, mean, var, eps, nullptr, nullptr, 0};
+    const TrainTail tail = {z_out, mean, var, eps, nullptr, nullptr, 0, nullptr, nullptr};
     return conv_setup_and_launch(x, w, gamma, beta, residual, y, batch, num_segments, heights_host, widths_host,
                                  nullptr, nullptr, cin, cout, kh, kw, stride, pad, 1, relu, dtype, stream, 0, nullptr,
                                  &tail);
@@ -749,7 +753,8 @@ BRCNN_API size_t brcnn_conv2d_dgrad_bn_backward_workspace_bytes(int batch, int i
 
 BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc(const void* dy, const void* w_t, const void* z_prev,
                                                   const float* gamma, const float* beta, const float* mean,
-                                                  const float* var, float eps, int relu, void* dz_prev,
+                                                  const float* var, float eps, int relu, const void* dskip,
+                                                  const void* prev_out, void* dres, void* dz_prev,
                                                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                                   int batch, int in_height, int in_width, int out_height, int out_width,
                                                   int cin, int cout, int kh, int kw, int stride, int pad, int dtype,
@@ -757,13 +762,15 @@ BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc(const void* dy, const void* w_
     if (!z_prev || !gamma || !beta || !mean || !var || !dz_prev || !dgamma || !dbeta || !workspace ||
         !brcnn_is16(dtype) || brcnn_out_f32(dtype) || pad > kh - 1 || pad > kw - 1 || (cin & 63))
         return BRCNN_EINVAL;
+    // residual producer (bn3 of the previous block): identity gradient, producer output and dres go together
+    if ((dskip != nullptr) != (prev_out != nullptr) || (dskip != nullptr) != (dres != nullptr)) return BRCNN_EINVAL;
     if (workspace_bytes < brcnn_conv2d_dgrad_bn_backward_workspace_bytes(batch, in_height, in_width, cin))
         return BRCNN_EINVAL;
-    const TrainTail tail = {nullptr, mean, var, eps, z_prev, (float*)workspace, relu};
+    const TrainTail tail = {nullptr, mean, var, eps, z_prev, (float*)workspace, relu, prev_out, dres};
     const int ih[1] = {in_height}, iw[1] = {in_width}, oh[1] = {out_height}, ow[1] = {out_width};
     // roles swap as in brcnn_conv2d_dgrad_nhwc_multi: the kernel's "input" is dy, its "output" the input gradient
     int tiles_m = 0;
-    const int st = conv_setup_and_launch(dy, w_t, gamma, beta, nullptr, dz_prev, batch, 1, oh, ow, ih, iw, cout, cin, kh,
+    const int st = conv_setup_and_launch(dy, w_t, gamma, beta, dskip, dz_prev, batch, 1, oh, ow, ih, iw, cout, cin, kh,
                                          kw, 1, kh - 1 - pad, stride, 0, dtype, stream, 0, nullptr, &tail, &tiles_m);
     if (st) return st;
     return brcnn_bn_eval_reduce_launch((const float*)workspace, tiles_m, mean, var, eps, dgamma, dbeta, cin,

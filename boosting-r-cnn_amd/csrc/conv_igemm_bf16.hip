@@ -164,6 +164,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(MODE == 2 ? p.tail_z : (const void*)p.residual);
     static_assert(!RES || MT * (32 / RPI) <= 16, "residual prefetch registers: use the non-residual form for 4x4 register tiles");
     uint4 rq[MT][32 / RPI];
+    // MODE 3: two more tiles, the producer's z and its output (the ReLU mask); they are requested at the start of
+    // the epilogue (behind the K loop, whose fragment registers they would otherwise compete with: 135 VGPRs and one
+    // workgroup per CU instead of two) and arrive while the affine vectors are derived and the first slab is written
+    uint4 rq2[MODE == 3 ? MT : 1][MODE == 3 ? 32 / RPI : 1], rq3[MODE == 3 ? MT : 1][MODE == 3 ? 32 / RPI : 1];
     if (RES) {
 #pragma unroll
         for (int tm = 0; tm < MT; tm++)
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             for (int it = 0; it < 32 / RPI; it++) {
                 const int m = m0 + wm * 32 * MT + tm * 32 + it * RPI + rl, co = cw0 + cl;
                 rq[tm][it] = make_uint4(0, 0, 0, 0);
-                if (vec_ok && m < p.M && co < p.Cout)
-                    rq[tm][it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.Cout + co);
+                const bool ok = vec_ok && m < p.M && co < p.Cout;
+                if (ok) rq[tm][it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.Cout + co);
             }
     }
     if (ST == 2) {
@@ -290,6 +294,19 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     // the result written as full 16-byte (bf16) / 32-byte (fp32) pieces of whole NHWC rows.
     constexpr int PITCH = 32 * NT + 4;            // floats
     float* cs = smem + wave * 32 * PITCH;
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int m = m0 + wm * 32 * MT + tm * 32 + it * RPI + rl, co = cw0 + cl;
+                rq2[tm][it] = rq3[tm][it] = make_uint4(0, 0, 0, 0);
+                if (vec_ok && m < p.M && co < p.Cout) {
+                    rq2[tm][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.tail_z) + (size_t)m * p.Cout + co);
+                    rq3[tm][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.tail_mask) + (size_t)m * p.Cout + co);
+                }
+            }
+    }
     // DUAL (training): the raw tile leaves as z, the affine is applied in the read-out layout where a lane
     // owns the same 8 channels in every iteration.  The wave's 32*NT channels are derived one per lane
     // (correctly rounded divide / sqrt: ~100 instructions each) and handed out through the wave's slab.
@@ -409,6 +426,31 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                         v[2 * e + 1] += e2f<ET>((unsigned short)(rr[e] >> 16));
                     }
                 }
+                if constexpr (MODE == 3) {
+                    // v = data gradient + identity gradient = d(previous block's output), rounded as the plain launch
+                    // stores it; masked by that output's ReLU it is the identity gradient of the previous block
+                    // (tail_dres) and, times scale, the gradient of its conv3 output z (bn_act_bwd_kernel's arithmetic)
+                    const unsigned zw[4] = {rq2[tm][it].x, rq2[tm][it].y, rq2[tm][it].z, rq2[tm][it].w};
+                    const unsigned ow[4] = {rq3[tm][it].x, rq3[tm][it].y, rq3[tm][it].z, rq3[tm][it].w};
+                    float d8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float zz = e2f<ET>((unsigned short)((e & 1) ? (zw[e >> 1] >> 16) : (zw[e >> 1] & 0xffffu)));
+                        const float oo = e2f<ET>((unsigned short)((e & 1) ? (ow[e >> 1] >> 16) : (ow[e >> 1] & 0xffffu)));
+                        const float g = e2f<ET>(f2e<ET>(v[e]));
+                        const float d = (!p.tail_relu || oo > 0.f) ? g : 0.f;
+                        sum_dz[e] += d * zz;
+                        sum_d[e] += d;
+                        d8[e] = d;
+                        v[e] = d * sc8[e];
+                    }
+                    uint4 dq;
+                    dq.x = f2e<ET>(d8[0]) | ((unsigned)f2e<ET>(d8[1]) << 16);
+                    dq.y = f2e<ET>(d8[2]) | ((unsigned)f2e<ET>(d8[3]) << 16);
+                    dq.z = f2e<ET>(d8[4]) | ((unsigned)f2e<ET>(d8[5]) << 16);
+                    dq.w = f2e<ET>(d8[6]) | ((unsigned)f2e<ET>(d8[7]) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.tail_dres) + ro + co) = dq;
+                }
                 if (p.relu) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
@@ -439,7 +481,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
         // lanes that share the channel vector (equal lane % LPR) hold different rows: butterfly over the
         // row bits, then the WM waves of one channel range add up through their slabs in a fixed order
 #pragma unroll
@@ -499,6 +541,8 @@ int launch2(ConvParams& p, hipStream_t s) {
     if (p.z_out || p.tail_z) {      // training epilogues: the production tiles of the backbone layers only
         if constexpr (ST == 2 && NT <= 2 && MT * NT <= 2 && ((WM == 4 && WNW == 2) || (WM == 2 && WNW == 2))) {
             if (p.out_f32) return BRCNN_EINVAL;
+            if (p.tail_z && p.tail_mask)
+                return (p.residual && p.tail_dres) ? launch<MT, NT, true, false, WM, WNW, ST, ET, 3>(p, s) : BRCNN_EINVAL;
             if (p.tail_z) return p.residual ? BRCNN_EINVAL : launch<MT, NT, true, false, WM, WNW, ST, ET, 2>(p, s);
             return p.residual ? launch<MT, NT, true, false, WM, WNW, ST, ET, 1>(p, s)
                               : launch<MT, NT, false, false, WM, WNW, ST, ET, 1>(p, s);

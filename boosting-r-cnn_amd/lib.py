@@ -79,7 +79,7 @@ SIGNATURES = {
     'brcnn_conv2d_bn_act_nhwc_multi': (c_int, [c_ptr] * 6 + [c_f32] + [c_ptr] * 3 + [c_int, c_int, c_ptr, c_ptr] + [c_int] * 8 +
                                        [c_ptr]),
     'brcnn_conv2d_dgrad_bn_backward_workspace_bytes': (ctypes.c_size_t, [c_int] * 4),
-    'brcnn_conv2d_dgrad_bn_backward_nhwc': (c_int, [c_ptr] * 7 + [c_f32, c_int] + [c_ptr] * 4 + [ctypes.c_size_t] + [c_int] * 12 +
+    'brcnn_conv2d_dgrad_bn_backward_nhwc': (c_int, [c_ptr] * 7 + [c_f32, c_int] + [c_ptr] * 7 + [ctypes.c_size_t] + [c_int] * 12 +
                                             [c_ptr]),
     'brcnn_bn_eval_act_backward': (c_int, [c_ptr] * 7 + [c_f32] + [c_ptr] * 5 + [ctypes.c_size_t, c_i64, c_int, c_int,
                                                                                 c_int, c_ptr]),

@@ -369,10 +369,16 @@ int brcnn_conv2d_bn_act_nhwc_multi(const void *x, const void *w, const float *ga
  * `workspace`, summed in a fixed order).  dy (batch, out_h, out_w, cout), w_t (cin, kh, kw, cout) flipped /
  * transposed as for brcnn_conv2d_dgrad_nhwc_multi, z_prev / dz_prev (batch, in_h, in_w, cin).  16-bit dtypes,
  * cin % 64 == 0, cout % 64 == 0.  Values equal brcnn_conv2d_dgrad_nhwc_multi followed by
- * brcnn_bn_eval_act_backward (dz bit for bit; dgamma / dbeta up to the summation order). */
+ * brcnn_bn_eval_act_backward (dz bit for bit; dgamma / dbeta up to the summation order).
+ * Residual producer (bn3 of the previous Bottleneck, whose output is this conv's input AND the identity of this
+ * block): dskip = the identity branch's gradient (added to the data gradient first, as
+ * brcnn_conv2d_nhwc's residual operand does), prev_out = the producer's output (ReLU mask: > 0 instead of the
+ * recomputed z * scale + shift), dres receives the masked sum -- the previous block's identity gradient.  All
+ * three NULL for a producer without residual. */
 size_t brcnn_conv2d_dgrad_bn_backward_workspace_bytes(int batch, int in_height, int in_width, int cin);
 int brcnn_conv2d_dgrad_bn_backward_nhwc(const void *dy, const void *w_t, const void *z_prev, const float *gamma,
                                         const float *beta, const float *mean, const float *var, float eps, int relu,
+                                        const void *dskip, const void *prev_out, void *dres,
                                         void *dz_prev, float *dgamma, float *dbeta, void *workspace,
                                         size_t workspace_bytes, int batch, int in_height, int in_width,
                                         int out_height, int out_width, int cin, int cout, int kh, int kw, int stride,

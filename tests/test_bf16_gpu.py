@@ -299,6 +299,42 @@ def test_bottleneck_bn_backward_inside_data_gradient_launch(cfg, dtype):
         assert (ga - gb).abs().max().item() <= 2e-5 * max(1.0, gb.abs().max().item()), k
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cfg', [(2, 128, 64, 2, 3, 21, 30), (8, 512, 128, 1, 4, 50, 84), (1, 512, 256, 2, 2, 13, 17)])
+def test_res_layer_residual_bn_backward_inside_next_block(cfg, dtype):
+    """a whole stage (ResLayer): bn3's backward (residual + ReLU) of every block but the last runs inside the NEXT
+    block's conv1 data-gradient launch, bn1 / bn2 inside conv2 / conv3 -- against the same stage with every
+    BatchNorm backward as its own launch: outputs and the input gradient bit for bit, parameter gradients up to the
+    summation / atomics order"""
+    from brcnn import autograd as A
+    from brcnn.backbones import Bottleneck, ResLayer
+    N, inplanes, planes, stride, nblocks, H, W = cfg
+    torch.manual_seed(47)
+    layer = ResLayer(Bottleneck, inplanes, planes, nblocks, stride).to(DEV)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    layer.eval()
+    x = torch.randn(N, H, W, inplanes, device=DEV).to(dtype)
+    got = {}
+    for fused in (True, False):
+        A.FUSE_BN_BACKWARD_INTO_DGRAD = A.FUSE_RESIDUAL_BN_BACKWARD = fused
+        try:
+            layer.zero_grad()
+            xd = x.clone().requires_grad_()
+            out = layer.forward_nhwc(xd)
+            go = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(dtype)
+            out.backward(go)
+            got[fused] = (out.detach(), xd.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
+        finally:
+            A.FUSE_BN_BACKWARD_INTO_DGRAD = A.FUSE_RESIDUAL_BN_BACKWARD = True
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    for k, ga in got[True][2].items():
+        gb = got[False][2][k]
+        assert (ga - gb).abs().max().item() <= 3e-5 * max(1.0, gb.abs().max().item()), k
+
+
 @pytest.mark.parametrize('down', [False, True])
 def test_bottleneck_against_plain_torch_float64(down, dtype='f32'):
     """a Bottleneck in fp32 (identity alias through conv1, downsample branch through the same alias) against the
