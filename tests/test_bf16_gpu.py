@@ -318,6 +318,7 @@ def test_res_layer_residual_bn_backward_inside_next_block(cfg, dtype):
     layer.eval()
     x = torch.randn(N, H, W, inplanes, device=DEV).to(dtype)
     got = {}
+    saved = (A.FUSE_BN_BACKWARD_INTO_DGRAD, A.FUSE_RESIDUAL_BN_BACKWARD)
     for fused in (True, False):
         A.FUSE_BN_BACKWARD_INTO_DGRAD = A.FUSE_RESIDUAL_BN_BACKWARD = fused
         try:
@@ -328,7 +329,7 @@ def test_res_layer_residual_bn_backward_inside_next_block(cfg, dtype):
             out.backward(go)
             got[fused] = (out.detach(), xd.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
         finally:
-            A.FUSE_BN_BACKWARD_INTO_DGRAD = A.FUSE_RESIDUAL_BN_BACKWARD = True
+            A.FUSE_BN_BACKWARD_INTO_DGRAD, A.FUSE_RESIDUAL_BN_BACKWARD = saved
     assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
     for k, ga in got[True][2].items():
         gb = got[False][2][k]
