@@ -733,17 +733,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                            int strips, int C) {
-    __shared__ float red[16][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    // 16 columns x 64 strip lanes per workgroup (C / 16 workgroups: the launch is latency sized)
+    __shared__ float red[64][16];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
     float a = 0.f;
     if (col < C)
-        for (int s = sl; s < strips; s += 16) a += partial[(size_t)s * C + col];
-    red[sl][threadIdx.x & 63] = a;
+        for (int s = sl; s < strips; s += 64) a += partial[(size_t)s * C + col];
+    red[sl][threadIdx.x & 15] = a;
     __syncthreads();
     if (sl == 0 && col < C) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; k++) t += red[k][threadIdx.x];
+        for (int k = 0; k < 64; k++) t += red[k][threadIdx.x];
         out[col] = t;
     }
 }
@@ -1165,7 +1166,7 @@ BRCNN_API int brcnn_colsum(const void* x, float* out, void* workspace, size_t wo
         hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, (float*)workspace,
                            (long long)rows, channels, rpb);
     BRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s, (const float*)workspace, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 15) / 16), dim3(1024), 0, s, (const float*)workspace, out,
                        (int)strips, channels);
     BRCNN_LAUNCH_CHECK();
     return 0;
