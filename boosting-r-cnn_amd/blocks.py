@@ -20,9 +20,10 @@ import torch.nn as nn
 from . import ops
 
 
-# Arithmetic type of the conv stack at inference: torch.float32 (exact-fp32 MFMA, the parity
-# path and the default) or torch.bfloat16 (bf16 MFMA, fp32 accumulate).  Process-wide; set
-# through `TwoStageDetector.set_compute_dtype`.  Training always runs fp32.
+# Arithmetic type of the conv stack: torch.float32 (exact-fp32 MFMA, the parity path and the default),
+# torch.bfloat16 or torch.float16 (16-bit MFMA operands, fp32 accumulation; in training with fp32 master
+# weights, fp32 heads / losses and, for fp16, static loss scaling).  Process-wide; set through
+# `TwoStageDetector.set_compute_dtype`.
 _COMPUTE_DTYPE = torch.float32
 
 
