@@ -58,6 +58,42 @@ class _GradArena:
 grad_arena = _GradArena()
 
 
+# weight-gradient launches on a second HIP stream (see _conv_backward); BRCNN_WGRAD_STREAM=0 keeps one stream
+WGRAD_SIDE_STREAM = _os.environ.get('BRCNN_WGRAD_STREAM', '1') != '0'
+_side_streams = {}
+_join_queued = [False]
+
+
+def _wgrad_side_stream(device):
+    """the second stream of the weight-gradient launches, or None: off, or under DistributedDataParallel (its
+    bucket all-reduce reads a gradient as soon as autograd has accumulated it, on the main stream)"""
+    if not WGRAD_SIDE_STREAM:
+        return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
+def _queue_stream_join(main, side):
+    """main waits for the side stream once, when the running backward pass ends (whoever reads .grad afterwards --
+    optimizer, gradient clipping, GradScaler -- is on the main stream)"""
+    if _join_queued[0]:
+        return
+
+    def join():
+        _join_queued[0] = False
+        main.wait_stream(side)
+    _join_queued[0] = True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+    except RuntimeError:        # not inside a backward pass (a direct call of the Function's backward)
+        join()
+
+
 def _conv_operands(weight, x_cat):
     """(forward operand (Cout,KH,KW,Cin), data-gradient operand (Cin,KH,KW,Cout) or None) of `weight` in the
     activation dtype: the ones the fused optimizer step already wrote for this version of the weight
@@ -112,8 +148,27 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
         _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
     if need_dw:
         dwp = grad_arena.take((cout, kh, kw, cin), dy.device)
-        st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
-                                               cin, cout, kh, kw, stride, pad, dt, _stream())
+        # a second stream only when autograd will take the result as `weight.grad` as it is (a leaf parameter
+        # without a gradient yet, in the layout the kernel writes): anything else -- a slice / cat / permute backward,
+        # an accumulation into an existing .grad -- is a main-stream kernel that would read dW before it is complete
+        takes = weight.is_leaf and weight.grad is None and not weight._backward_hooks and \
+            not getattr(weight, '_post_accumulate_grad_hooks', None) and \
+            (weight.is_contiguous() if kh * kw == 1 else weight.is_contiguous(memory_format=torch.channels_last))
+        side = _wgrad_side_stream(dy.device) if takes else None
+        if side is None:
+            st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
+                                                   cin, cout, kh, kw, stride, pad, dt, _stream())
+        else:
+            # nothing in the backward pass waits for dW: the weight-gradient launch goes to a second HIP stream and
+            # overlaps the data-gradient chain of the layers above (its atomics tail and the other kernel's
+            # LDS-DMA / MFMA phases fill each other's gaps); the streams join at the end of the backward pass
+            main = torch.cuda.current_stream(dy.device)
+            side.wait_event(main.record_event())            # dy, x and the zero fill of dW are complete here
+            st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
+                                                   cin, cout, kh, kw, stride, pad, dt, side.cuda_stream)
+            dy.record_stream(side)                          # the allocator must not recycle them under the launch
+            x_cat.record_stream(side)
+            _queue_stream_join(main, side)
         _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
         # (Cout,KH,KW,Cin) -> the parameter's (Cout,Cin,KH,KW): for 1x1 filters the two coincide in
         # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)

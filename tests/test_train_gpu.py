@@ -463,6 +463,40 @@ def test_train_step_device_path_equals_reference_chain():
         assert (ga - gb).abs().max().item() <= 2e-3 * scale, (k, (ga - gb).abs().max().item(), scale)
 
 
+def test_wgrad_side_stream_gives_the_same_gradients():
+    """weight-gradient launches on the second HIP stream (autograd.WGRAD_SIDE_STREAM): every parameter gradient of a
+    bf16 train step equals the single-stream run up to the order of the fp32 atomics, over several steps that reuse
+    the allocator's blocks (a missing dependency or a recycled buffer shows up as a wrong gradient)"""
+    from brcnn import autograd as A, blocks
+    m = _model()
+    blocks.conv_weights_channels_last(m)
+    m.set_compute_dtype('bf16')
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    saved = A.WGRAD_SIDE_STREAM
+    res = {}
+    try:
+        for mode in (False, True, True, True):
+            A.WGRAD_SIDE_STREAM = mode
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(77)
+            loss, _ = m._parse_losses(m.forward_train(*args))
+            loss.backward()
+            torch.cuda.current_stream().synchronize()       # the join at the end of backward orders the side stream
+            grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+            if not mode:
+                res['ref'] = grads
+            else:
+                assert grads.keys() == res['ref'].keys()
+                for k, ga in grads.items():
+                    gb = res['ref'][k]
+                    scale = gb.abs().max().item() + 1e-12
+                    assert (ga - gb).abs().max().item() <= 1e-4 * scale, (k, (ga - gb).abs().max().item(), scale)
+    finally:
+        A.WGRAD_SIDE_STREAM = saved
+        blocks.set_compute_dtype('f32')
+
+
 def test_train_step_device_path_mixed_shapes_and_empty_gt():
     """a batch whose images differ in img_shape / pad_shape (validity flags, per-image clip border) and
     hold 0 ground truths in one image"""
