@@ -200,6 +200,7 @@ class ConvNHWCFunction(Function):
                                              None, False, stride, pad)
         ctx.save_for_backward(x_cat, weight)
         ctx.cfg = (batch, tuple(sizes), tuple(out_sizes), stride, pad, bias is not None)
+        ctx.bias_ref = bias
         ctx.with_skip = bool(with_skip)
         if with_skip:
             return y, x_cat.view_as(x_cat)
@@ -213,7 +214,24 @@ class ConvNHWCFunction(Function):
         dy = dy.to(x_cat.dtype).contiguous()
         dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dy, (batch, sizes, out_sizes, stride, pad), dskip,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        db = ops.colsum(dy) if has_bias and ctx.needs_input_grad[2] else None
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            b = ctx.bias_ref
+            # the bias gradient's two small launches leave the main chain like the weight gradient (same rule:
+            # only where autograd takes the result as `bias.grad` unchanged)
+            takes = b is not None and b.is_leaf and b.grad is None and not b._backward_hooks and \
+                not getattr(b, '_post_accumulate_grad_hooks', None) and b.dtype == torch.float32
+            side = _wgrad_side_stream(dy.device) if takes else None
+            if side is None:
+                db = ops.colsum(dy)
+            else:
+                main = torch.cuda.current_stream(dy.device)
+                side.wait_event(main.record_event())
+                with torch.cuda.stream(side):
+                    db = ops.colsum(dy)
+                dy.record_stream(side)
+                db.record_stream(main)
+                _queue_stream_join(main, side)
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
         return dx, dw, db, None, None, None, None, None
