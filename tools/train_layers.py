@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from brcnn import lib as L
+from brcnn import autograd as _A
+_A.WGRAD_SIDE_STREAM = False      # per-launch HIP events on ONE stream: keep the weight-gradient launches on it
 
 dt = os.environ.get('BRCNN_DTYPE', 'bf16')
 dev = torch.device('cuda', 0)
