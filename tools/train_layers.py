@@ -60,8 +60,8 @@ def fused_fwd_shape(a):  # (x,w,gamma,beta,mean,var,eps,res,z,y,batch,L,hs,ws,ci
     return (m, cout, kh * kw * cin)
 
 
-def fused_dgrad_shape(a):  # (dy,w_t,z,g,b,m,v,eps,relu,dz,dg,db,ws,nb,batch,ih,iw,oh,ow,cin,cout,kh,kw,stride,pad,dt,stream)
-    batch, ih, iw, cin, cout, kh, kw = a[14], a[15], a[16], a[19], a[20], a[21], a[22]
+def fused_dgrad_shape(a):  # (dy,w_t,z,g,b,m,v,eps,relu,dskip,prev_out,dres,dz,dg,db,ws,nb,batch,ih,iw,oh,ow,cin,cout,kh,kw,...)
+    batch, ih, iw, cin, cout, kh, kw = a[17], a[18], a[19], a[22], a[23], a[24], a[25]
     return (batch * ih * iw, cin, kh * kw * cout)
 
 
