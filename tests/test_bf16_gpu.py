@@ -402,6 +402,42 @@ def test_bottleneck_against_plain_torch_float64(down, dtype='f32'):
         assert p_.grad is not None and close(p_.grad, rp[k].grad), k
 
 
+def test_fused_training_entries_reject_bad_arguments():
+    """error behaviour of the fused training entry points: a status code, never a launch on inconsistent pointers"""
+    import ctypes
+    from brcnn import lib as L
+    from brcnn.ops import DT_BF16, DT_F32, _ptr
+    lib = L.load()
+    n, h, w, ci, co = 1, 8, 8, 64, 64
+    x = torch.zeros(n * h * w, ci, device=DEV, dtype=BF)
+    wt = torch.zeros(co, 1, 1, ci, device=DEV, dtype=BF)
+    v = torch.ones(co, device=DEV)
+    z, y = torch.empty(n * h * w, co, device=DEV, dtype=BF), torch.empty(n * h * w, co, device=DEV, dtype=BF)
+    hs, ws = (ctypes.c_int * 1)(h), (ctypes.c_int * 1)(w)
+    ok = lib.brcnn_conv2d_bn_act_nhwc_multi(_ptr(x), _ptr(wt), _ptr(v), _ptr(v), _ptr(v), _ptr(v), 1e-5, None, _ptr(z), _ptr(y), n, 1,
+                                            hs, ws, ci, co, 1, 1, 1, 0, 1, DT_BF16, None)
+    assert ok == 0
+    # fp32 is not a dual-store dtype; z_out is required; mean without var is inconsistent
+    assert lib.brcnn_conv2d_bn_act_nhwc_multi(_ptr(x), _ptr(wt), _ptr(v), _ptr(v), _ptr(v), _ptr(v), 1e-5, None, _ptr(z), _ptr(y), n, 1,
+                                              hs, ws, ci, co, 1, 1, 1, 0, 1, DT_F32, None) != 0
+    assert lib.brcnn_conv2d_bn_act_nhwc_multi(_ptr(x), _ptr(wt), _ptr(v), _ptr(v), _ptr(v), _ptr(v), 1e-5, None, None, _ptr(y), n, 1,
+                                              hs, ws, ci, co, 1, 1, 1, 0, 1, DT_BF16, None) != 0
+    assert lib.brcnn_conv2d_bn_act_nhwc_multi(_ptr(x), _ptr(wt), _ptr(v), _ptr(v), _ptr(v), None, 1e-5, None, _ptr(z), _ptr(y), n, 1,
+                                              hs, ws, ci, co, 1, 1, 1, 0, 1, DT_BF16, None) != 0
+    # data gradient + BatchNorm backward: workspace too small; residual-producer pointers must come together
+    dg, db = torch.empty(ci, device=DEV), torch.empty(ci, device=DEV)
+    nb = lib.brcnn_conv2d_dgrad_bn_backward_workspace_bytes(n, h, w, ci)
+    wsp = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    args = lambda dskip, prev, dres, nbytes: (_ptr(y), _ptr(wt), _ptr(x), _ptr(v), _ptr(v), _ptr(v), _ptr(v), 1e-5, 1, dskip, prev, dres,   # noqa: E731
+                                              _ptr(torch.empty_like(x)), _ptr(dg), _ptr(db), _ptr(wsp), nbytes, n, h, w, h, w, ci, co,
+                                              1, 1, 1, 0, DT_BF16, None)
+    assert lib.brcnn_conv2d_dgrad_bn_backward_nhwc(*args(None, None, None, nb)) == 0
+    assert lib.brcnn_conv2d_dgrad_bn_backward_nhwc(*args(None, None, None, nb - 4)) != 0
+    assert lib.brcnn_conv2d_dgrad_bn_backward_nhwc(*args(_ptr(x), None, None, nb)) != 0
+    assert lib.brcnn_conv2d_dgrad_bn_backward_nhwc(*args(_ptr(x), _ptr(x), None, nb)) != 0
+    torch.cuda.synchronize()
+
+
 def test_wgrad_bf16_tiles_and_multi_level_agree():
     """64x64, 128x128 and 256x256 (16-wave) output tiles, one multi-level launch vs per-level launches"""
     from brcnn import lib
