@@ -365,31 +365,35 @@ class RoIExtractFunction(Function):
         out, _ = ops.roi_extract(list(feats), rois, output_size, strides, finest_scale, sampling_ratio)
         ctx.save_for_backward(rois)
         ctx.cfg = (output_size, tuple(strides), finest_scale, sampling_ratio,
-                   [tuple(f.shape) for f in feats])
+                   [tuple(f.shape) for f in feats], feats[0].dtype)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
         (rois,) = ctx.saved_tensors
-        output_size, strides, finest_scale, sampling_ratio, shapes = ctx.cfg
+        output_size, strides, finest_scale, sampling_ratio, shapes, fdt = ctx.cfg
         ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
         L = len(shapes)
         hs, ws = _ints([s[1] for s in shapes]), _ints([s[2] for s in shapes])
         sc = (ctypes.c_float * L)(*[1.0 / s for s in strides])
-        g = grad_out.float().contiguous()
         lib = _L.load()
         if ROI_BACKWARD_GATHER and ph <= 7 and pw <= 7 and shapes[0][3] % 4 == 0:
-            # gather form: every gradient pixel written once, no zero fill, deterministic
-            grads = [torch.empty(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
+            # gather form: every gradient pixel written once, no zero fill, deterministic; a 16-bit pyramid gets
+            # its gradient in its own dtype (fp32 accumulation, one rounding at the store)
+            g = grad_out.to(fdt).contiguous()
+            grads = [torch.empty(s, dtype=fdt, device=grad_out.device) for s in shapes]
             ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads])
             nb = lib.brcnn_roi_extract_backward_workspace_bytes(rois.size(0))
             wsp = torch.empty((nb + 3) // 4, dtype=torch.int32, device=grad_out.device)
             st = lib.brcnn_roi_extract_backward_gather(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
                                                        shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
-                                                       float(finest_scale), _ptr(wsp), nb, _stream())
+                                                       float(finest_scale), _ptr(wsp), nb, _dt(g), _stream())
             _L.check(st, 'brcnn_roi_extract_backward_gather')
             return (None, None, None, None, None) + tuple(grads)
+        if fdt != torch.float32:
+            raise _L.BrcnnHipError('RoI extract backward: the atomic scatter form is fp32 only')
+        g = grad_out.float().contiguous()
         grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
         ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads])
         st = lib.brcnn_roi_extract_backward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],

@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict
     recs[k] = r;
 }
 
-__global__ __launch_bounds__(256) void roi_grad_gather_kernel(const float* __restrict__ grad_output, LevelTable lv,
+template <typename T>       // element type of dY and of the gradient maps (fp32, or the 16-bit compute dtype in training)
+__global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restrict__ grad_output, LevelTable lv,
                                                              GatherLevels gl, const float* __restrict__ rois,
                                                              const RoiRec* __restrict__ recs, int n_rois, int channels,
                                                              int ph_n, int pw_n, int sampling_ratio) {
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const float* __res
     const int h1 = min(H - 1, h0 + GT_TILE - 1), w1 = min(W - 1, w0 + GT_TILE - 1);
     const int key = l * gl.batch + b;
     const int wr0 = h0 + 4 * (wave >> 1), wc0 = w0 + 4 * (wave & 1);  // this wave's 4 x 4 pixel quadrant
-    float* gout = lv.gfeat[l] + (size_t)b * H * W * channels;
+    T* gout = reinterpret_cast<T*>(lv.gfeat[l]) + (size_t)b * H * W * channels;
     const float scale = lv.scale[l];
 
     for (int cbase = 0; cbase < channels; cbase += 256) {
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const float* __res
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
-                const float* go = grad_output + (size_t)k * ph_n * pw_n * channels + c;
+                const T* go = grad_output + (size_t)k * ph_n * pw_n * channels + c;
                 for (int ph = 0; ph < ph_n; ph++) {
                     const float wy0 = s_wy[wave][0][ph], wy1 = s_wy[wave][1][ph], wy2 = s_wy[wave][2][ph], wy3 = s_wy[wave][3][ph];
                     if (wy0 == 0.f && wy1 == 0.f && wy2 == 0.f && wy3 == 0.f) continue;
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const float* __res
                         const float wx0 = s_wx[wave][0][pw], wx1 = s_wx[wave][1][pw], wx2 = s_wx[wave][2][pw], wx3 = s_wx[wave][3][pw];
                         if (wx0 == 0.f && wx1 == 0.f && wx2 == 0.f && wx3 == 0.f) continue;
                         float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (c_ok) gv = *reinterpret_cast<const float4*>(go + (size_t)(ph * pw_n + pw) * channels);
+                        if (c_ok) gv = ld4(go + (size_t)(ph * pw_n + pw) * channels);
                         const float wys[4] = {wy0, wy1, wy2, wy3}, wxs[4] = {wx0, wx1, wx2, wx3};
 #pragma unroll
                         for (int r = 0; r < 4; r++)
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const float* __res
 #pragma unroll
             for (int p = 0; p < 16; p++) {
                 const int py = wr0 + (p >> 2), px = wc0 + (p & 3);
-                if (py < H && px < W) *reinterpret_cast<float4*>(gout + ((size_t)py * W + px) * channels + c) = acc[p];
+                if (py < H && px < W) st4(gout + ((size_t)py * W + px) * channels + c, acc[p]);
             }
         }
     }
@@ -831,17 +832,19 @@ BRCNN_API size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois) {
     return (size_t)(n_rois > 0 ? n_rois : 1) * sizeof(RoiRec) + 256;
 }
 
-BRCNN_API int brcnn_roi_extract_backward_gather(float* const* grad_feats_host, const int* heights_host,
+BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, const int* heights_host,
                                                 const int* widths_host, const float* scales_host, int num_levels,
-                                                const float* rois, const float* grad_output, int batch, int channels,
+                                                const float* rois, const void* grad_output, int batch, int channels,
                                                 int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
                                                 float finest_scale, void* workspace, size_t workspace_bytes,
-                                                void* stream) {
+                                                int dtype, void* stream) {
+    if (!brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
     if (!grad_feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0 || pooled_h > 7 ||
         pooled_w > 7 || batch <= 0 || !workspace || workspace_bytes < (size_t)(n_rois > 0 ? n_rois : 1) * sizeof(RoiRec))
         return BRCNN_EINVAL;
     LevelTable lv = {};
-    if (fill_levels(lv, nullptr, grad_feats_host, heights_host, widths_host, scales_host, num_levels, finest_scale))
+    if (fill_levels(lv, nullptr, reinterpret_cast<float* const*>(grad_feats_host), heights_host, widths_host, scales_host,
+                    num_levels, finest_scale))
         return BRCNN_EINVAL;
     if (n_rois > 0 && (!rois || !grad_output)) return BRCNN_EINVAL;
     GatherLevels gl = {};
@@ -863,8 +866,15 @@ BRCNN_API int brcnn_roi_extract_backward_gather(float* const* grad_feats_host, c
                            pooled_h, pooled_w, sampling_ratio, recs);
         BRCNN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(roi_grad_gather_kernel, dim3(blk), dim3(256), 0, s, grad_output, lv, gl, rois, recs, n_rois,
-                       channels, pooled_h, pooled_w, sampling_ratio);
+    if (dtype == BRCNN_DT_F32)
+        hipLaunchKernelGGL(roi_grad_gather_kernel<float>, dim3(blk), dim3(256), 0, s, (const float*)grad_output, lv, gl, rois,
+                           recs, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
+    else if (dtype == BRCNN_DT_BF16)
+        hipLaunchKernelGGL(roi_grad_gather_kernel<bf16_t>, dim3(blk), dim3(256), 0, s, (const bf16_t*)grad_output, lv, gl, rois,
+                           recs, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
+    else
+        hipLaunchKernelGGL(roi_grad_gather_kernel<f16_t>, dim3(blk), dim3(256), 0, s, (const f16_t*)grad_output, lv, gl, rois,
+                           recs, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -26,7 +26,7 @@ SIGNATURES = {
                                    [c_f32, c_ptr]),
     'brcnn_roi_extract_backward_workspace_bytes': (c_size, [c_int]),
     'brcnn_roi_extract_backward_gather': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 + [c_f32, c_ptr, c_size,
-                                                                                                    c_ptr]),
+                                                                                                    c_int, c_ptr]),
     'brcnn_nms_workspace_bytes': (c_size, [c_i64, c_int, c_i64]),
     'brcnn_nms': (c_int, [c_ptr] * 4 + [c_int, c_i64, c_i64, c_f32, c_int, c_int, c_ptr, c_ptr,
                                         c_ptr, c_size, c_ptr]),

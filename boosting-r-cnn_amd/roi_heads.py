@@ -70,9 +70,12 @@ class SingleRoIExtractor(nn.Module):
         l0 = self.roi_layers[0]
         if torch.is_grad_enabled() and any(f.requires_grad for f in feats_nhwc):
             from .autograd import roi_extract_autograd
-            # the R-CNN branch trains in fp32 (bf16 pyramids are widened here; the cast's
-            # backward narrows the feature gradient again)
-            feats_nhwc = [f.float() for f in feats_nhwc]
+            # a 16-bit pyramid is read as it is and its gradient written in the same dtype (the gather backward
+            # accumulates in fp32): no widening / narrowing casts around the extractor
+            from .autograd import ROI_BACKWARD_GATHER
+            ph_pw = l0.output_size if isinstance(l0.output_size, (tuple, list)) else (l0.output_size, l0.output_size)
+            if feats_nhwc[0].dtype != torch.float32 and not (ROI_BACKWARD_GATHER and max(ph_pw) <= 7):
+                feats_nhwc = [f.float() for f in feats_nhwc]
             return roi_extract_autograd(list(feats_nhwc[:self.num_inputs]), rois, l0.output_size,
                                         self.featmap_strides, self.finest_scale, l0.sampling_ratio)
         out, _ = ops.roi_extract(list(feats_nhwc[:self.num_inputs]), rois, l0.output_size,

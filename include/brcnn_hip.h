@@ -99,14 +99,16 @@ int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights
  * pre-zeroing, no atomics, a fixed summation order: deterministic).  One workgroup per 8x8 tile of a
  * (level, image) map collects the RoIs whose footprint touches the tile and accumulates
  * dX[h,w] += sum_bins Wy[ph][h] * Wx[pw][w] * dY[roi,ph,pw] / count with the separable bilinear footprint
- * weights.  workspace: brcnn_roi_extract_backward_workspace_bytes(n_rois).  pooled_h, pooled_w <= 7. */
+ * weights.  workspace: brcnn_roi_extract_backward_workspace_bytes(n_rois).  pooled_h, pooled_w <= 7.
+ * dtype: element type of grad_output AND of the grad_feats maps (BRCNN_DT_F32, or the 16-bit compute dtype of
+ * the pyramid in training: fp32 accumulation, one rounding at the store). */
 size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois);
-int brcnn_roi_extract_backward_gather(float *const *grad_feats_host, const int *heights_host,
+int brcnn_roi_extract_backward_gather(void *const *grad_feats_host, const int *heights_host,
                                       const int *widths_host, const float *scales_host, int num_levels,
-                                      const float *rois, const float *grad_output, int batch, int channels,
+                                      const float *rois, const void *grad_output, int batch, int channels,
                                       int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
                                       float finest_scale, void *workspace, size_t workspace_bytes,
-                                      void *stream);
+                                      int dtype, void *stream);
 /* NHWC RoIAlign forward variants: 0 (default) = footprint form (every pixel of a bin's footprint
  * read once; equal to the reference to fp32 round-off), 1 = the reference's sample-order
  * accumulation (bit-identical to mmcv's CPU kernel; ~1.5x the L2 reads). */

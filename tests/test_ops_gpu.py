@@ -899,3 +899,30 @@ def test_multi_level_conv_autograd_matches_torch(dtype):
         assert rel(dx, x.grad) < tol, (dtype, h, w)
         r0 += n
     assert rel(wg.grad, wr.grad) < tol and rel(bg.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_roi_extract_16bit_training_path(dtype):
+    """the extractor on a 16-bit pyramid in training (no widening casts): features and the pyramid gradient equal the
+    fp32 path on the same (16-bit-representable) values, rounded once to the 16-bit dtype"""
+    from brcnn.autograd import roi_extract_autograd
+    g = torch.Generator().manual_seed(15)
+    strides = [8, 16, 32, 64]
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    B, C, K = 2, 256, 300
+    feats = [torch.randn(B, h, w_, C, generator=g).to(dtype) for h, w_ in sizes]
+    rois = util.rand_rois(K, B, 672., 400., seed=7, min_size=4., max_size=900.)
+    go = torch.randn(K, 7, 7, C, generator=g).to(dtype)
+    res = {}
+    for dt in (torch.float32, dtype):
+        fg = [f.to(DEV, dt).requires_grad_() for f in feats]
+        out = roi_extract_autograd(fg, rois.to(DEV), 7, strides, 56, 0)
+        assert out.dtype == dt
+        out.backward(go.to(DEV, dt))
+        assert all(f.grad.dtype == dt for f in fg)
+        res[dt] = (out.detach().float(), [f.grad.float() for f in fg])
+    assert torch.equal(res[dtype][0], res[torch.float32][0].to(dtype).float())
+    for a, b in zip(res[dtype][1], res[torch.float32][1]):
+        # same fp32 accumulation order in both runs; the 16-bit run rounds once at the store
+        assert torch.equal(a, b.to(dtype).float())
+
