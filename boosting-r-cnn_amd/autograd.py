@@ -70,7 +70,7 @@ def _wgrad_side_stream(device):
     if not WGRAD_SIDE_STREAM:
         return None
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():      # any world size: DDP hooks the gradient accumulators
         return None
     key = (device.type, device.index)
     if key not in _side_streams:
