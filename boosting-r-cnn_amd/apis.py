@@ -309,7 +309,8 @@ class EpochBasedRunner:
                 # clip + (unscale) + SGD + next step's conv operands in one call; the norm stays on the device
                 scale = self.loss_scale or 1.0
                 (outputs['loss'] * scale if scale != 1.0 else outputs['loss']).backward()
-                ctl = self.optimizer.step(max_norm=self.grad_clip['max_norm'] if self.grad_clip else None, loss_scale=scale)
+                ctl = self.optimizer.step(max_norm=self.grad_clip['max_norm'] if self.grad_clip else None, loss_scale=scale,
+                                          skip_nonfinite=self.loss_scale is not None)
                 if self.grad_clip is not None and ctl is not None:
                     outputs['log_vars']['grad_norm'] = ctl[0]
             elif self.loss_scaler is not None:

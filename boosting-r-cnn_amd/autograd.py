@@ -61,7 +61,8 @@ grad_arena = _GradArena()
 # weight-gradient launches on a second HIP stream (see _conv_backward); BRCNN_WGRAD_STREAM=0 keeps one stream
 WGRAD_SIDE_STREAM = _os.environ.get('BRCNN_WGRAD_STREAM', '1') != '0'
 _side_streams = {}
-_join_queued = [False]
+_join_queued = {}        # (device type, index) -> True while a join callback of the running backward pass is queued
+_side_seen = {}          # (device type, index) -> ids of the parameters whose gradient went to the side stream in this pass
 
 
 def _wgrad_side_stream(device):
@@ -70,7 +71,7 @@ def _wgrad_side_stream(device):
     if not WGRAD_SIDE_STREAM:
         return None
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():      # any world size: DDP hooks the gradient accumulators
+    if dist.is_available() and dist.is_initialized() and not _OWN_REDUCER[0]:   # DDP hooks the gradient accumulators
         return None
     key = (device.type, device.index)
     if key not in _side_streams:
@@ -78,16 +79,52 @@ def _wgrad_side_stream(device):
     return _side_streams[key]
 
 
+# parallel.GradReducer reduces the gradients after the end-of-backward join (no accumulator hooks): the side stream
+# stays on under torch.distributed while one is active
+_OWN_REDUCER = [False]
+
+
+def _side_stream_for(param, device):
+    """the side stream for `param`'s gradient launch, or None.  A parameter that feeds several Function nodes of one
+    backward pass (a conv shared across pyramid levels in the per-level fallback) gets the side stream for none but
+    its first use: autograd sums the uses on the main stream as soon as the second one returns, so the second use
+    first makes the main stream wait for the side stream and then runs on the main stream itself."""
+    side = _wgrad_side_stream(device)
+    if side is None:
+        return None
+    key = (device.type, device.index)
+    seen = _side_seen.setdefault(key, set())
+    if id(param) in seen:
+        torch.cuda.current_stream(device).wait_stream(side)
+        return None
+    seen.add(id(param))
+    return side
+
+
+def join_side_streams(device=None):
+    """make the current stream(s) wait for the side stream(s) and forget the per-pass state: the end-of-backward
+    callback, and a backstop for the readers of .grad (optim.FusedSGD.step, the gradient reducer) in case a
+    backward pass raised before its callbacks ran"""
+    for key, side in list(_side_streams.items()):
+        if device is not None and key != (device.type, device.index):
+            continue
+        torch.cuda.current_stream(torch.device(*key)).wait_stream(side)
+        _join_queued[key] = False
+        _side_seen.pop(key, None)
+
+
 def _queue_stream_join(main, side):
     """main waits for the side stream once, when the running backward pass ends (whoever reads .grad afterwards --
     optimizer, gradient clipping, GradScaler -- is on the main stream)"""
-    if _join_queued[0]:
+    key = (main.device.type, main.device.index)
+    if _join_queued.get(key):
         return
 
     def join():
-        _join_queued[0] = False
+        _join_queued[key] = False
+        _side_seen.pop(key, None)
         main.wait_stream(side)
-    _join_queued[0] = True
+    _join_queued[key] = True
     try:
         torch.autograd.Variable._execution_engine.queue_callback(join)
     except RuntimeError:        # not inside a backward pass (a direct call of the Function's backward)
@@ -154,7 +191,7 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
         takes = weight.is_leaf and weight.grad is None and not weight._backward_hooks and \
             not getattr(weight, '_post_accumulate_grad_hooks', None) and \
             (weight.is_contiguous() if kh * kw == 1 else weight.is_contiguous(memory_format=torch.channels_last))
-        side = _wgrad_side_stream(dy.device) if takes else None
+        side = _side_stream_for(weight, dy.device) if takes else None
         if side is None:
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
                                                    cin, cout, kh, kw, stride, pad, dt, _stream())
@@ -221,7 +258,7 @@ class ConvNHWCFunction(Function):
             # only where autograd takes the result as `bias.grad` unchanged)
             takes = b is not None and b.is_leaf and b.grad is None and not b._backward_hooks and \
                 not getattr(b, '_post_accumulate_grad_hooks', None) and b.dtype == torch.float32
-            side = _wgrad_side_stream(dy.device) if takes else None
+            side = _side_stream_for(b, dy.device) if takes else None
             if side is None:
                 db = ops.colsum(dy)
             else:

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const SgdTable t, f
 // out[0] = total gradient norm (of the UNSCALED gradients), out[1] = factor the update multiplies g by
 // (inv_scale * min(1, max_norm / (norm + 1e-6)); 0 when the norm is not finite), out[2] = 1 if the step is skipped
 __global__ __launch_bounds__(1024) void sqnorm_final_kernel(const float* __restrict__ partial, int n, float inv_scale,
-                                                           float max_norm, float* __restrict__ out) {
+                                                           float max_norm, int skip_nonfinite, float* __restrict__ out) {
     __shared__ double red[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
@@ -73,11 +73,14 @@ __global__ __launch_bounds__(1024) void sqnorm_final_kernel(const float* __restr
         float coef = inv_scale;
         if (max_norm > 0.f) {
             const float c = max_norm / (norm + 1e-6f);           // torch.nn.utils.clip_grad_norm_
-            coef = inv_scale * (c < 1.f ? c : 1.f);
+            coef = inv_scale * (c < 1.f ? c : (c != c ? c : 1.f));   // clamp(max=1) keeps a NaN factor, as torch does
         }
         out[0] = norm;
-        out[1] = finite ? coef : 0.f;
-        out[2] = finite ? 0.f : 1.f;
+        // skip_nonfinite (loss-scaled fp16 recipes): GradScaler.step's rule.  Without it the update runs as
+        // clip_grad_norm_ + SGD would: an inf / NaN gradient reaches the weights and the divergence is visible
+        const bool skip = !finite && skip_nonfinite;
+        out[1] = skip ? 0.f : coef;
+        out[2] = skip ? 1.f : 0.f;
     }
 }
 
@@ -174,11 +177,11 @@ BRCNN_API size_t brcnn_sgd_workspace_bytes(int num_tensors, const int64_t* numel
 
 // params / grads / bufs: HOST arrays of device pointers (fp32, dense); lr / weight_decay per tensor; has_buf per tensor.
 // max_norm <= 0: no clipping (the norm is still computed when ctl3 is given).  ctl3 (device, 3 floats) receives
-// [grad norm, applied factor, skipped]; inv_scale = 1 / loss scale.
+// [grad norm, applied factor, skipped]; inv_scale = 1 / loss scale; skip_nonfinite != 0: a non-finite norm skips the step.
 BRCNN_API int brcnn_sgd_step(float* const* params, const float* const* grads, float* const* bufs, const int64_t* numel_host,
                              const float* lr_host, const float* wd_host, const int* has_buf_host, int num_tensors,
-                             float momentum, float max_norm, float inv_scale, void* workspace, size_t workspace_bytes,
-                             float* ctl3, void* stream) {
+                             float momentum, float max_norm, float inv_scale, int skip_nonfinite, void* workspace,
+                             size_t workspace_bytes, float* ctl3, void* stream) {
     if (num_tensors <= 0) return 0;
     if (!params || !grads || !numel_host || !lr_host || !wd_host || !has_buf_host || !workspace || !ctl3 ||
         (momentum != 0.f && !bufs))
@@ -206,7 +209,7 @@ BRCNN_API int brcnn_sgd_step(float* const* params, const float* const* grads, fl
         total_blocks += blk;
     }
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, total_blocks, inv_scale,
-                       max_norm, ctl3);
+                       max_norm, skip_nonfinite, ctl3);
     BRCNN_LAUNCH_CHECK();
     for (int first = 0; first < num_tensors; first += TAB) {
         SgdTable t;

@@ -541,15 +541,20 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
         batch_size, num_workers = num_gpus * samples_per_gpu, num_gpus * workers_per_gpu
     init_fn = partial(worker_init_fn, num_workers=num_workers, rank=rank, seed=seed) if seed is not None else None
     from .pipelines import first_device_transform
-    split = first_device_transform(dataset.pipeline) if isinstance(getattr(dataset, 'pipeline', None), Compose) else None
-    if split is not None:
+    leaves = _pipeline_leaves(dataset)
+    splits = {first_device_transform(d.pipeline) for d in leaves if isinstance(d.pipeline, Compose)}
+    if splits - {None}:
         # the fused device front door (FusedResizeNormalizePad ...): workers are forked after the parent
         # has initialised the GPU and must not touch it, so they run the host part of the pipeline only
         # (file decode, annotations) and hand back raw samples; the device transforms and the collate step
-        # run in the main process (MainProcessTail)
-        tail = Compose(dataset.pipeline.transforms[split:])
-        dataset.pipeline = Compose(dataset.pipeline.transforms[:split])
-        loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+        # run in the main process (MainProcessTail).  The dataset object itself keeps its whole pipeline
+        # (`dataset[i]` and a second loader see it unchanged): the loader reads through HostPartView.
+        if len(splits) != 1 or any(repr(d.pipeline) != repr(leaves[0].pipeline) for d in leaves):
+            raise NotImplementedError('datasets under one wrapper with different pipelines and a device transform')
+        split = splits.pop()
+        tail = Compose(leaves[0].pipeline.transforms[split:])
+        view = HostPartView(dataset, leaves, split)
+        loader = DataLoader(view, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
                             collate_fn=identity_collate, pin_memory=False, worker_init_fn=init_fn, **kwargs)
         return MainProcessTail(loader, tail, partial(collate, samples_per_gpu=samples_per_gpu))
     return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
@@ -561,13 +566,51 @@ def identity_collate(batch):
     return batch
 
 
+def _pipeline_leaves(dataset):
+    """the datasets that own a `pipeline` under `dataset` (itself, or below RepeatDataset / ConcatDataset wrappers)"""
+    if getattr(dataset, 'pipeline', None) is not None:
+        return [dataset]
+    if hasattr(dataset, 'datasets'):
+        return [d for sub_ in dataset.datasets for d in _pipeline_leaves(sub_)]
+    if hasattr(dataset, 'dataset') and not isinstance(dataset.dataset, dict):
+        return _pipeline_leaves(dataset.dataset)
+    return []
+
+
+class HostPartView(Dataset):
+    """`dataset` as the DataLoader workers see it: every sample stops in front of the first device transform.  The
+    underlying datasets are not modified outside `__getitem__` (a worker owns a forked copy; in the main process
+    the swap is undone before returning)."""
+
+    def __init__(self, dataset, leaves, split):
+        self.dataset, self.leaves, self.split = dataset, leaves, split
+        for name in ('flag', 'CLASSES'):
+            if hasattr(dataset, name):
+                setattr(self, name, getattr(dataset, name))
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        full = [d.pipeline for d in self.leaves]
+        for d in self.leaves:
+            d.pipeline = Compose(d.pipeline.transforms[:self.split])
+        try:
+            return self.dataset[idx]
+        finally:
+            for d, p in zip(self.leaves, full):
+                d.pipeline = p
+
+
 class MainProcessTail:
     """A DataLoader whose workers ran only the host part of the pipeline: applies the remaining (device)
     transforms to every raw sample in the main process, then collates."""
 
     def __init__(self, loader, tail, collate_fn):
         self.loader, self.tail, self.collate_fn = loader, tail, collate_fn
-        self.sampler, self.dataset, self.batch_size = loader.sampler, loader.dataset, loader.batch_size
+        ds = loader.dataset
+        self.sampler, self.batch_size = loader.sampler, loader.batch_size
+        self.dataset = ds.dataset if isinstance(ds, HostPartView) else ds
 
     def __len__(self):
         return len(self.loader)

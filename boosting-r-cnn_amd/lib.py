@@ -99,7 +99,7 @@ SIGNATURES = {
     'brcnn_rpn_decode_levels_dscale': (c_int, [c_ptr] * 6 + [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
                                                c_ptr, c_f64, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     'brcnn_sgd_workspace_bytes': (c_size, [c_int, c_ptr]),
-    'brcnn_sgd_step': (c_int, [c_ptr] * 7 + [c_int, c_f32, c_f32, c_f32, c_ptr, c_size, c_ptr, c_ptr]),
+    'brcnn_sgd_step': (c_int, [c_ptr] * 7 + [c_int, c_f32, c_f32, c_f32, c_int, c_ptr, c_size, c_ptr, c_ptr]),
     'brcnn_pack_conv_weights_batch': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_ptr]),
     'brcnn_bbox_overlaps': (c_int, [c_ptr, c_int, c_int, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_ptr]),
     'brcnn_assign_max_iou': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int,

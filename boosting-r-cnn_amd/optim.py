@@ -79,11 +79,13 @@ class FusedSGD(torch.optim.Optimizer):
 
     # ---- the step ------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, closure=None, max_norm=None, loss_scale=1.0):
+    def step(self, closure=None, max_norm=None, loss_scale=1.0, skip_nonfinite=None):
         """one optimizer step.  `max_norm`: clip the global L2 gradient norm first (None / <= 0: no clipping);
         `loss_scale`: the gradients carry this factor (fp16 static loss scaling) -- they are unscaled inside the
-        update, and a non-finite norm skips the whole step (what GradScaler.step does).  Returns the device
-        tensor [grad norm, applied factor, skipped]."""
+        update, and a non-finite norm skips the whole step (what GradScaler.step does).  `skip_nonfinite`: that
+        skip rule; default: only with a loss scale (`loss_scale != 1`) -- an fp32 / bf16 run lets the inf / NaN through
+        to the weights as clip_grad_norm_ + torch.optim.SGD would, so that a divergence is visible.  Returns the
+        device tensor [grad norm, applied factor, skipped]."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -108,9 +110,11 @@ class FusedSGD(torch.optim.Optimizer):
                 buf = state.get('momentum_buffer')
                 if buf is not None and (buf.stride() != p.stride() or buf.dtype != torch.float32):
                     buf = state['momentum_buffer'] = torch.empty_like(p).copy_(buf)     # e.g. a loaded checkpoint
-                has.append(0 if buf is None else 1)
+                # a new buffer starts at zero with has = 1: momentum * 0 + d == d is torch's first-step value, and a step
+                # the device skips (non-finite norm) leaves a defined buffer behind instead of uninitialised memory
                 if buf is None and group['momentum'] != 0:
-                    buf = state['momentum_buffer'] = torch.empty_like(p)
+                    buf = state['momentum_buffer'] = torch.zeros_like(p)
+                has.append(0 if buf is None else 1)
                 ps.append(p)
                 gs.append(g)
                 bs.append(buf)
@@ -120,6 +124,10 @@ class FusedSGD(torch.optim.Optimizer):
             return loss
         n = len(ps)
         dev = ps[0].device
+        # backstop: the gradients written on the weight-gradient side stream are complete before they are read, also
+        # when a backward pass raised before its end-of-pass join ran
+        from . import autograd as _A
+        _A.join_side_streams(dev)
         lib = _L.load()
         numel = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
         nb = lib.brcnn_sgd_workspace_bytes(n, numel)
@@ -130,7 +138,8 @@ class FusedSGD(torch.optim.Optimizer):
         bp = (ctypes.c_void_p * n)(*[0 if b is None else b.data_ptr() for b in bs])
         st = lib.brcnn_sgd_step(pp, gp, bp, numel, (ctypes.c_float * n)(*lrs), (ctypes.c_float * n)(*wds),
                                 (ctypes.c_int * n)(*has), n, float(momentum or 0.0),
-                                float(max_norm) if max_norm else 0.0, 1.0 / float(loss_scale), _ptr(ws), nb, _ptr(self.ctl),
+                                float(max_norm) if max_norm else 0.0, 1.0 / float(loss_scale),
+                                int((loss_scale != 1.0) if skip_nonfinite is None else bool(skip_nonfinite)), _ptr(ws), nb, _ptr(self.ctl),
                                 _stream())
         _L.check(st, 'brcnn_sgd_step')
         for p in ps:        # the kernels wrote through raw pointers: tell autograd / the packed-operand caches

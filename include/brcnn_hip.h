@@ -645,7 +645,8 @@ int brcnn_boost_loss_backward(const float *cls_score, const float *bbox_pred, co
  * norm (torch.optim.SGD + mmcv OptimizerHook grad_clip; configs/_base_/schedules/schedule_1x.py:2-3,
  * configs/boosting_rcnn/boosting_rcnn_r50_pafpn_1x_utdac.py:130), as three stages over tables of tensors
  * passed by value (HOST arrays of device pointers; fp32 dense tensors):
- *   ctl3 = [ ||g||_2 / loss_scale, applied factor, skipped ]; the step is skipped when the norm is not finite
+ *   ctl3 = [ ||g||_2 / loss_scale, applied factor, skipped ]; with skip_nonfinite the step is skipped when the norm
+ *   is not finite (GradScaler.step, the fp16 recipes); without it the update runs as clip_grad_norm_ + SGD would
  *   d = g * factor + wd * w;  buf = has_buf ? momentum * buf + d : d;  w -= lr * buf   (dampening 0, no nesterov)
  * brcnn_pack_conv_weights_batch: forward (Cout,KH,KW,Cin) and data-gradient (Cin,KH,KW,Cout, taps flipped)
  * operands of many conv weights in one launch per 64 tensors (dims_host: cout, cin, kh, kw each;
@@ -656,8 +657,8 @@ int brcnn_boost_loss_backward(const float *cls_score, const float *bbox_pred, co
 size_t brcnn_sgd_workspace_bytes(int num_tensors, const int64_t *numel_host);
 int brcnn_sgd_step(float *const *params, const float *const *grads, float *const *bufs, const int64_t *numel_host,
                    const float *lr_host, const float *wd_host, const int *has_buf_host, int num_tensors,
-                   float momentum, float max_norm, float inv_scale, void *workspace, size_t workspace_bytes,
-                   float *ctl3, void *stream);
+                   float momentum, float max_norm, float inv_scale, int skip_nonfinite, void *workspace,
+                   size_t workspace_bytes, float *ctl3, void *stream);
 int brcnn_pack_conv_weights_batch(const float *const *weights, void *const *fwd, void *const *dgrad,
                                   const int *dims_host, const int *channels_last_host, int num, int dtype,
                                   const float *ctl3, void *stream);

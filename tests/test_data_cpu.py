@@ -225,6 +225,46 @@ def test_collate_and_loader(tmp_path):
     assert data['img_metas'][0][0]['ori_filename'] == '000.npy'
 
 
+def test_loader_keeps_device_transforms_in_the_main_process_without_touching_the_dataset(tmp_path):
+    """a pipeline with a device transform: the workers stop in front of it (HostPartView), the main process applies the
+    rest; the dataset object keeps its whole pipeline (a second loader and `dataset[i]` still work), also under a
+    RepeatDataset wrapper (datasets.build_dataloader)"""
+    import os as _os
+    PIPELINES = P.PIPELINES
+
+    if 'MarkMainProcess' not in PIPELINES.module_dict:
+        @PIPELINES.register_module()
+        class MarkMainProcess:
+            runs_on_device = True      # stands for FusedResizeNormalizePad: must never run in a forked worker
+
+            def __call__(self, results):
+                results['img_info']['ran_in_pid'] = _os.getpid()
+                return results
+
+            def __repr__(self):
+                return 'MarkMainProcess()'
+
+    ann_file, prefix = _synthetic(tmp_path)
+    classes = ('echinus', 'starfish', 'holothurian', 'scallop')
+    train = [dict(type='LoadImageFromFile'), dict(type='LoadAnnotations', with_bbox=True), dict(type='MarkMainProcess'),
+             dict(type='Resize', img_scale=(160, 96), keep_ratio=True), dict(type='RandomFlip', flip_ratio=0.0),
+             dict(type='Normalize', mean=MEAN, std=STD, to_rgb=True), dict(type='Pad', size_divisor=32),
+             dict(type='DefaultFormatBundle'),
+             dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels'], meta_keys=('img_shape', 'pad_shape'))]
+    for wrap in (False, True):
+        ds = D.build_dataset(dict(type='CocoDataset', ann_file=ann_file, img_prefix=prefix, classes=classes, pipeline=train))
+        n_tf = len(ds.pipeline.transforms)
+        whole = D.RepeatDataset(ds, 2) if wrap else ds
+        for rep in range(2):                                   # a second loader over the same object
+            loader = D.build_dataloader(whole, 2, 2, dist=False, seed=0)
+            assert isinstance(loader, D.MainProcessTail) and loader.dataset is whole
+            data = next(iter(loader))
+            assert data['img'].dim() == 4 and data['img'].shape[0] == 2
+            assert len(ds.pipeline.transforms) == n_tf
+        sample = whole[0]                                      # the dataset itself still runs the whole pipeline
+        assert 'img' in sample and 'img_metas' in sample
+
+
 # --------------------------------------------------------------------------- VOC recipe (g15)
 def test_voc_dataset_and_eval_map_match_reference_golden(tmp_path):
     from brcnn.evaluation import eval_map

@@ -497,6 +497,85 @@ def test_wgrad_side_stream_gives_the_same_gradients():
         blocks.set_compute_dtype('f32')
 
 
+def test_wgrad_side_stream_with_a_weight_used_twice():
+    """one conv applied to two inputs in one graph (the per-level RPN fallback shares its ConvModules across pyramid
+    levels): autograd sums the two weight gradients on the main stream as soon as the second arrives, so only the first
+    may use the side stream (autograd.py side-stream rule)"""
+    from brcnn import autograd as A
+    from brcnn.autograd import ConvNHWCFunction
+    torch.manual_seed(11)
+    saved = A.WGRAD_SIDE_STREAM
+    res = {}
+    try:
+        for kh in (1, 3):
+            w0 = (torch.randn(128, 64, kh, kh) / 16).to(DEV)
+            if kh == 3:
+                w0 = w0.contiguous(memory_format=torch.channels_last)
+            b0 = torch.randn(128).to(DEV)
+            xs = [torch.randn(2 * 40 * 56, 64, device=DEV).to(torch.bfloat16), torch.randn(2 * 24 * 32, 64, device=DEV).to(torch.bfloat16)]
+            for mode in (False, True, True, True):
+                A.WGRAD_SIDE_STREAM = mode
+                w = w0.clone().requires_grad_(True)
+                if kh == 3:
+                    w = w0.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+                b = b0.clone().requires_grad_(True)
+                ya = ConvNHWCFunction.apply(xs[0].clone().requires_grad_(True), w, b, 2, [(40, 56)], 1, kh // 2)
+                yb = ConvNHWCFunction.apply(xs[1].clone().requires_grad_(True), w, b, 2, [(24, 32)], 1, kh // 2)
+                (ya.float().pow(2).sum() + yb.float().pow(2).sum() * 3).backward()
+                torch.cuda.current_stream().synchronize()
+                if not mode:
+                    res[kh] = (w.grad.clone(), b.grad.clone())
+                else:
+                    for got, ref in zip((w.grad, b.grad), res[kh]):
+                        scale = ref.abs().max().item()
+                        assert (got - ref).abs().max().item() <= 1e-4 * scale, (kh, (got - ref).abs().max().item(), scale)
+    finally:
+        A.WGRAD_SIDE_STREAM = saved
+
+
+def test_fused_sgd_first_step_skipped_leaves_a_defined_momentum_buffer():
+    """the very first step carries an inf gradient (fp16 static loss scaling overflow): the device skips it, and the
+    next step must behave like torch's first step (optim.py momentum buffer)"""
+    from brcnn.optim import FusedSGD
+    torch.manual_seed(4)
+    a = torch.nn.Linear(33, 17).to(DEV)
+    b = torch.nn.Linear(33, 17).to(DEV)
+    b.load_state_dict(a.state_dict())
+    oa = FusedSGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    before = [p.detach().clone() for p in a.parameters()]
+    for p in a.parameters():
+        p.grad = torch.full_like(p, float('nan'))
+    a.weight.grad[0, 0] = float('inf')
+    ctl = oa.step(max_norm=35, loss_scale=512.)
+    assert float(ctl[2]) == 1.0 and all(torch.equal(x, y) for x, y in zip(a.parameters(), before))
+    for it in range(3):
+        for x, y in zip(a.parameters(), b.parameters()):
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        ctl = oa.step(max_norm=35)
+        torch.nn.utils.clip_grad_norm_(list(b.parameters()), max_norm=35, norm_type=2)
+        ob.step()
+        assert float(ctl[2]) == 0.0
+        for x, y in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), it
+            assert torch.allclose(oa.state[x]['momentum_buffer'], ob.state[y]['momentum_buffer'], rtol=2e-6, atol=1e-7)
+    # without a loss scale nothing is skipped: the inf reaches the weights exactly where clip_grad_norm_ + SGD put it
+    for x, y in zip(a.parameters(), b.parameters()):
+        g = torch.randn_like(x)
+        x.grad, y.grad = g.clone(), g.clone()
+    a.weight.grad[1, 2] = float('inf')
+    b.weight.grad[1, 2] = float('inf')
+    ctl = oa.step(max_norm=35)
+    torch.nn.utils.clip_grad_norm_(list(b.parameters()), max_norm=35, norm_type=2)
+    ob.step()
+    assert float(ctl[2]) == 0.0 and not torch.isfinite(a.weight[1, 2])
+    for x, y in zip(a.parameters(), b.parameters()):
+        assert torch.equal(torch.isfinite(x), torch.isfinite(y))
+        fin = torch.isfinite(y)
+        assert torch.allclose(x[fin], y[fin], rtol=2e-6, atol=1e-7)
+
+
 def test_train_step_device_path_mixed_shapes_and_empty_gt():
     """a batch whose images differ in img_shape / pad_shape (validity flags, per-image clip border) and
     hold 0 ground truths in one image"""
@@ -572,6 +651,6 @@ def test_fused_sgd_matches_torch_sgd_with_clipping(channels_last):
     for x in pa:
         x.grad = torch.ones_like(x)
     pa[0].grad[0, 0, 0, 0] = float('inf')
-    ctl = oa.step(max_norm=35)
+    ctl = oa.step(max_norm=35, skip_nonfinite=True)
     assert float(ctl[2]) == 1.0 and all(torch.equal(x, y) for x, y in zip(pa, before))
     assert set(oa.state_dict()['state'][0].keys()) == {'momentum_buffer'}
