@@ -530,26 +530,51 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// second stage of dgamma / dbeta: column sums of the [num_parts][2][C] partials; one workgroup per
-// 32 columns (32 columns x 32 row lanes, combined through LDS)
-__global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int num_parts, int C) {
-    __shared__ float red[32][33];
+// second stage of dgamma / dbeta: column sums of the [num_parts][2][C] partials.  Grid (32-column blocks,
+// GN_PARAM_SLICES row slices): a workgroup sums its slice of the partial rows (32 columns x 8 row lanes, four rows
+// in flight per lane, combined through LDS) into part2[slice][2C]; gn_bwd_param_final_kernel adds the slices in a
+// fixed order.  (One workgroup per 32 columns over all 2560 partial rows of the five-level tower -- 16 workgroups
+// on a 256-CU part -- took 155 us per layer.)
+constexpr int GN_PARAM_SLICES = 32;
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ part2,
+                                                          int num_parts, int C) {
+    __shared__ float red[8][33];
     const int cols = 2 * C;
     const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cl;
-    float acc = 0.f;
-    if (col < cols)
-        for (int r = lane; r < num_parts; r += 32) acc += part[(size_t)r * cols + col];
-    red[lane][cl] = acc;
+    const int per = (num_parts + GN_PARAM_SLICES - 1) / GN_PARAM_SLICES;
+    const int r0 = blockIdx.y * per, r1 = min(num_parts, r0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < cols) {
+        int r = r0 + lane;
+        for (; r + 24 < r1; r += 32) {
+            a0 += part[(size_t)r * cols + col];
+            a1 += part[(size_t)(r + 8) * cols + col];
+            a2 += part[(size_t)(r + 16) * cols + col];
+            a3 += part[(size_t)(r + 24) * cols + col];
+        }
+        for (; r < r1; r += 8) a0 += part[(size_t)r * cols + col];
+    }
+    red[lane][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (lane == 0 && col < cols) {
         float t = 0.f;
 #pragma unroll
-        for (int l = 0; l < 32; l++) t += red[l][cl];
-        if (col < C) dbeta[col] = t;
-        else dgamma[col - C] = t;
+        for (int l = 0; l < 8; l++) t += red[l][cl];
+        part2[(size_t)blockIdx.y * cols + col] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_param_final_kernel(const float* __restrict__ part2, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int C) {
+    const int cols = 2 * C;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    float t = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < GN_PARAM_SLICES; s++) t += part2[(size_t)s * cols + col];
+    if (col < C) dbeta[col] = t;
+    else dgamma[col - C] = t;
 }
 
 // Q channel quads (16 bytes of a 16-bit tensor with Q = 2) per thread; the group statistics are fetched once per
@@ -976,7 +1001,7 @@ BRCNN_API size_t brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(int batch, 
     int chunks, rpb;
     gn_bwd_chunks(max_hw, &chunks, &rpb);
     return (size_t)batch * num_segments * groups * 2 * sizeof(double) +
-           (size_t)batch * num_segments * chunks * 2 * channels * sizeof(float);
+           ((size_t)batch * num_segments * chunks + GN_PARAM_SLICES) * 2 * channels * sizeof(float);
 }
 
 BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x, const void* stats,
@@ -1017,8 +1042,12 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
                            (const f16_t*)x, (const f16_t*)dy, (const double*)stats, gamma, beta, gsum, part, sg,
                            batch, channels, groups, rpb, relu);
     BRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * channels + 31) / 32), dim3(1024), 0, s, part, dgamma, dbeta,
+    float* part2 = part + (size_t)num_parts * 2 * channels;
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * channels + 31) / 32, GN_PARAM_SLICES), dim3(256), 0, s, part, part2,
                        num_parts, channels);
+    BRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_param_final_kernel, dim3((2 * channels + 255) / 256), dim3(256), 0, s, part2, dgamma, dbeta,
+                       channels);
     BRCNN_LAUNCH_CHECK();
     // one channel quad per thread: the two-quad (16-byte) form measured 35 % SLOWER here (295 vs 208 us per
     // backward of the tower tensor in bf16), although it is the faster one in the forward apply kernel
