@@ -57,6 +57,17 @@ struct ConvParams {
     const float* bn_mean;
     const float* bn_var;
     float bn_eps;
+    // chained stream-K schedule (16-bit kernel): the launch's workgroups take their work item from sk_items[blockIdx.x]
+    // = (tile, first K tile, end K tile, hand-over slot); tile < 0: padding.  The tiles x K-tiles iteration space is
+    // cut into equal ranges, one per resident workgroup slot; a tile that straddles two ranges becomes two items: its K
+    // head (dispatched in the launch's FIRST round; it stores the fp32 accumulators to sk_ws[slot] and sets
+    // sk_flags[slot] = sk_epoch) and its K tail (dispatched in the LAST round; it starts from those accumulators, so the
+    // MFMA chain over K is the unsplit one, bit for bit, and runs the epilogue).  sk_wgs = 0: one whole tile per block.
+    int sk_wgs;
+    const int4* sk_items;
+    float* sk_ws;
+    unsigned* sk_flags;
+    unsigned sk_epoch;
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];

@@ -12,6 +12,9 @@
 // bf16 MFMA issues in 32 cycles, a K tile carries only MT*NT*4 MFMAs per wave, so the larger
 // 128x128 tile (16 MFMAs per wave and barrier) is the default here; the kernel is bound by the
 // L2->LDS stream and the per-tile barrier, not by the matrix pipes.
+#include <algorithm>
+#include <mutex>
+#include <vector>
 #include "conv_common.h"
 
 namespace {
@@ -36,17 +39,20 @@ template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { retur
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
 // 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs.
-template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0, int MODE = 0>
+// SK: chained stream-K schedule (ConvParams::sk_*): the workgroup's item (tile, K range, hand-over slot) comes from
+// the launch's item table.
+template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0, int MODE = 0, bool SK = false>
 __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WNW == 4 || MT == 1)) ? 2 : 1) void conv_igemm_bf16_dma_kernel(ConvParams p) {
     constexpr int NW = WNW * WM;        // waves per workgroup (WM along M x WNW along N)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WNW;
     constexpr int AG = BM / 8 / NW;     // 8-row groups of the A tile per wave
     constexpr int BG = BN / 8 / NW;
     static_assert(AG >= 1 && BG >= 1 && AG * 8 * NW == BM && BG * 8 * NW == BN, "tile / wave split");
+    static_assert(!SK || ST == 2, "stream-K schedule: the two-buffer K loop");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM][32 dwords = 128 B]
     const int nk = p.K / BKE;
-    const int nbuf = nk < ST ? nk : ST; // ring of ST K-tile buffers (fewer when the K loop is shorter)
+    const int nbuf = (SK || nk >= ST) ? ST : nk; // ring of ST K-tile buffers (fewer when the K loop is shorter)
     float* Bs = smem + nbuf * BM * 32;  // [nbuf][BN][32 dwords]
 
     const int tid = threadIdx.x;
@@ -56,7 +62,18 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     const int li = lane & 31, lh = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    int tile, kb = 0, ke = nk, sk_slot = 0;     // this work item: K tiles [kb, ke) of output tile `tile`
+    if constexpr (SK) {
+        const int4 item = p.sk_items[blockIdx.x];       // wave-uniform: scalar loads
+        tile = __builtin_amdgcn_readfirstlane(item.x);
+        kb = __builtin_amdgcn_readfirstlane(item.y);
+        ke = __builtin_amdgcn_readfirstlane(item.z);
+        sk_slot = __builtin_amdgcn_readfirstlane(item.w);
+        if (tile < 0) return;                            // padding entry of the table
+    } else {
+        tile = xcd_remap(blockIdx.x, nwg);
+    }
+    const bool finish = !SK || ke == nk;        // this item ends with the epilogue (else: the partial tile is published)
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -111,6 +128,15 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     // K tiles are staged in order: the filter tap and channel offset of the next tile are carried
     // as scalar state instead of being re-derived by two integer divisions per tile
     TileK d_next = {0, 0, 0, 0};
+    if constexpr (SK) {
+        if (kb > 0) {
+            const int k0 = kb * BKE, tap = k0 / p.Cin;
+            d_next.k0 = k0;
+            d_next.ci0 = k0 - tap * p.Cin;
+            d_next.kh = tap / p.KW;
+            d_next.kw = tap - d_next.kh * p.KW;
+        }
+    }
     auto dma_setup = [&](int kt) {
         (void)kt;
         const TileK t = d_next;
@@ -151,7 +177,32 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         for (int j = 0; j < PIECES; j++) dma_piece(t, buf, j);
     };
 
-    if (ST == 2) dma_tile(0, 0);
+    if (ST == 2) dma_tile(kb, 0);
+    if constexpr (SK) {
+        if (kb > 0) {
+            // the K head of this tile: published by a workgroup of the launch's first round.  One lane polls
+            // (relaxed, with a bound: a lost flag must not hang the device), one agent-scope acquire, then plain loads.
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(p.sk_flags + sk_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
+                       ++spins < (1 << 24))
+                    __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_ws) + (size_t)sk_slot * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x4 v = src[((a * NT + b) * 4 + g) * (NW * 64)];
+                        acc[a][b][4 * g + 0] = v.x; acc[a][b][4 * g + 1] = v.y;
+                        acc[a][b][4 * g + 2] = v.z; acc[a][b][4 * g + 3] = v.w;
+                    }
+        }
+    }
 
     // residual rows (bf16, 16 B = 8 channels of one pixel per lane, the read-out mapping of the
     // epilogue), issued before the K loop so that their latency hides behind it
@@ -175,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             for (int it = 0; it < 32 / RPI; it++) {
                 const int m = m0 + wm * 32 * MT + tm * 32 + it * RPI + rl, co = cw0 + cl;
                 rq[tm][it] = make_uint4(0, 0, 0, 0);
-                const bool ok = vec_ok && m < p.M && co < p.Cout;
+                const bool ok = vec_ok && m < p.M && co < p.Cout && finish;
                 if (ok) rq[tm][it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.Cout + co);
             }
     }
@@ -259,8 +310,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     };
     if constexpr (ST == 2) {
         int cur = 0;
-        for (int kt = 0; kt < nk; kt++) {
-            compute_tile(cur, kt + 1 < nk ? kt + 1 : -1, cur ^ 1);
+        for (int kt = kb; kt < ke; kt++) {
+            compute_tile(cur, kt + 1 < ke ? kt + 1 : -1, cur ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur ^= 1;
@@ -286,6 +337,33 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         asm volatile("s_barrier" ::: "memory");      // the epilogue slabs overwrite the ring
     }
 
+    if constexpr (SK) {
+        if (!finish) {
+            // the K head of a tile that a later workgroup finishes: accumulators in register order (one coalesced
+            // 1 KiB store per wave instruction), then publish: stores drained in every wave, one agent-scope release,
+            // the flag (cdna_hip_programming.md 6 G16; the second wait restates the one behind buffer_wbl2)
+            f32x4* dst = reinterpret_cast<f32x4*>(p.sk_ws) + (size_t)sk_slot * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4 v;
+                        v.x = acc[a][b][4 * g + 0]; v.y = acc[a][b][4 * g + 1];
+                        v.z = acc[a][b][4 * g + 2]; v.w = acc[a][b][4 * g + 3];
+                        dst[((a * NT + b) * 4 + g) * (NW * 64)] = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
     // ---- epilogue.  The MFMA ran as D^T = W A^T, so lane l holds pixel m = l&31 and, per
     // register group g, four consecutive channels co = 8g + 4(l>>5) + (0..3).  Scale/shift are
     // applied in the accumulators; each wave transposes one 32-row slab at a time through its
@@ -513,12 +591,175 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     }
 }
 
+// ---- chained stream-K schedule: host side ---------------------------------------------------------------------
+// Per stream: the hand-over slots (fp32 accumulators of one tile each), their flags and the launch epoch.  Launches
+// on one stream are serialised, so a slot is free again when the next launch starts.
+struct SkStream { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
+struct SkTable { long long tiles; int nk, slots, blocks; int4* items; };
+constexpr size_t SK_WS_BYTES = (size_t)128 << 20;
+constexpr int SK_MAX_SLOTS = 2048;
+std::mutex g_sk_mutex;
+std::vector<SkStream> g_sk_streams;
+std::vector<SkTable> g_sk_tables;
+int g_sk_mode = 1;      // tuning hook (set_tile_bf16(-3 / -4 / -5)): 0 off, 1 heuristic, 2 wherever the tile count allows
+int g_num_cus = 0;
+
+int sk_stream_state(hipStream_t s, SkStream** out) {
+    for (auto& e : g_sk_streams)
+        if (e.stream == s) { *out = &e; return 0; }
+    if (g_sk_streams.capacity() < 64) g_sk_streams.reserve(64);       // pointers handed out stay valid
+    if (g_sk_streams.size() >= 64) return BRCNN_EINVAL;
+    SkStream e = {s, nullptr, nullptr, 0};
+    BRCNN_HIP_CHECK(hipMalloc((void**)&e.ws, SK_WS_BYTES));
+    BRCNN_HIP_CHECK(hipMalloc((void**)&e.flags, SK_MAX_SLOTS * sizeof(unsigned)));
+    BRCNN_HIP_CHECK(hipMemset(e.flags, 0, SK_MAX_SLOTS * sizeof(unsigned)));
+    BRCNN_HIP_CHECK(hipDeviceSynchronize());
+    g_sk_streams.push_back(e);
+    *out = &g_sk_streams.back();
+    return 0;
+}
+
+// The item table of (tiles, nk, slots).  The iteration space tiles x nk is cut into `slots` equal ranges (what a
+// persistent stream-K workgroup would walk, backwards: the K head of its last tile first, whole tiles, the K tail of
+// its first tile last); the items are then laid out for the hardware's in-order dispatch of an ordinary grid (block
+// b goes to XCD b % 8, each XCD starts its blocks in order as slots free up): per XCD, all K heads first, shortest
+// first; the whole tiles; the K tails last, longest first -- so the slot that finished the shortest head picks up the
+// longest tail and every slot ends up with one range's worth of work.  A head and its tail stay on the XCD that owns
+// the tile (xcd_remap's contiguous chunks), so the operand rows and the hand-over stay in one L2.
+int sk_table(long long tiles, int nk, int slots, const SkTable** out) {
+    for (auto& t : g_sk_tables)
+        if (t.tiles == tiles && t.nk == nk && t.slots == slots) { *out = &t; return 0; }
+    struct Item { int tile, kb, ke, slot; };
+    std::vector<Item> heads[8], wholes[8], tails[8];
+    std::vector<int> slot_of((size_t)tiles, -1);
+    const long long iters = tiles * nk, q = iters / slots, r = iters % slots;
+    int nslots = 0;
+    const int cq = slots >> 3, cr = slots & 7;
+    for (int w = 0; w < slots; w++) {
+        // the XCD whose chunk of logical workgroups holds w (xcd_remap)
+        int x = 0;
+        for (int base = 0; x < 8; x++) {
+            const int cnt = cq + (x < cr ? 1 : 0);
+            if (w < base + cnt) break;
+            base += cnt;
+        }
+        const long long sw = q * w + (w < r ? w : r), ew = sw + q + (w < r ? 1 : 0);
+        long long end = ew;
+        while (end > sw) {
+            const long long tile = (end - 1) / nk, t0 = tile * nk;
+            const int kb = (int)((sw > t0 ? sw : t0) - t0), ke = (int)(end - t0);
+            Item it = {(int)tile, kb, ke, 0};
+            if (kb > 0 && ke < nk) return BRCNN_EINVAL;         // three-way split: the caller requires tiles >= slots
+            if (kb > 0 || ke < nk) {
+                if (slot_of[tile] < 0) slot_of[tile] = nslots++;
+                it.slot = slot_of[tile];
+                (kb > 0 ? tails : heads)[x].push_back(it);
+            } else {
+                wholes[x].push_back(it);
+            }
+            end = t0 + kb;
+        }
+    }
+    if (nslots > SK_MAX_SLOTS) return BRCNN_EINVAL;
+    size_t maxlen = 0;
+    std::vector<Item> queue[8];
+    for (int x = 0; x < 8; x++) {
+        std::stable_sort(heads[x].begin(), heads[x].end(), [](const Item& a, const Item& b) { return a.ke - a.kb < b.ke - b.kb; });
+        std::stable_sort(wholes[x].begin(), wholes[x].end(), [](const Item& a, const Item& b) { return a.tile < b.tile; });
+        std::stable_sort(tails[x].begin(), tails[x].end(), [](const Item& a, const Item& b) { return a.ke - a.kb > b.ke - b.kb; });
+        queue[x] = heads[x];
+        queue[x].insert(queue[x].end(), wholes[x].begin(), wholes[x].end());
+        queue[x].insert(queue[x].end(), tails[x].begin(), tails[x].end());
+        if (queue[x].size() > maxlen) maxlen = queue[x].size();
+    }
+    std::vector<int4> host(maxlen * 8);
+    for (size_t loc = 0; loc < maxlen; loc++)
+        for (int x = 0; x < 8; x++) {
+            int4 v = make_int4(-1, 0, 0, 0);
+            if (loc < queue[x].size()) v = make_int4(queue[x][loc].tile, queue[x][loc].kb, queue[x][loc].ke, queue[x][loc].slot);
+            host[loc * 8 + x] = v;
+        }
+    SkTable t = {tiles, nk, slots, (int)(maxlen * 8), nullptr};
+    BRCNN_HIP_CHECK(hipMalloc((void**)&t.items, host.size() * sizeof(int4)));
+    BRCNN_HIP_CHECK(hipMemcpy(t.items, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (g_sk_tables.capacity() < 256) g_sk_tables.reserve(256);
+    if (g_sk_tables.size() >= 256) { (void)hipFree(t.items); return BRCNN_EINVAL; }
+    g_sk_tables.push_back(t);
+    *out = &g_sk_tables.back();
+    return 0;
+}
+
+// the schedule of one launch, or sk_wgs = 0: `slots` = resident workgroups of this kernel on the whole device
+static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s) {
+    p.sk_wgs = 0;
+    if (g_sk_mode == 0 || slots <= 0 || slots > SK_MAX_SLOTS) return 0;
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    const int nk = p.K / BKE;
+    // every slot must own at least one whole tile's worth of iterations: a tile then straddles two ranges at most
+    if (tiles < slots || nk < 2 || tiles * nk >= 0x7fffffffLL) return 0;
+    if ((size_t)(slots + 8) * bm * bn * sizeof(float) > SK_WS_BYTES) return 0;
+    if (g_sk_mode == 1) {
+        // where it pays (tools/conv_bench_bf16.py, profiles/r03_notes.md): the 128 x 128 tile with a last generation of
+        // workgroups that leaves most of the device idle and a K loop of >= 32 tiles -- every slot pays one hand-over
+        // (a tile of fp32 accumulators each way, a second prologue), about a tenth of a tile's time; the smaller tiles
+        // run three to five workgroups per CU, whose last generation speeds up by itself when its neighbours are gone
+        const double gens = (double)tiles / slots;
+        const double eff = gens / (double)(long long)(gens + 0.999999);
+        if (eff >= 0.9 || nk < 32 || bm != 128 || bn != 128) return 0;
+    }
+    std::lock_guard<std::mutex> lock(g_sk_mutex);
+    SkStream* st = nullptr;
+    int rc = sk_stream_state(s, &st);
+    if (rc) return rc;
+    const SkTable* tab = nullptr;
+    rc = sk_table(tiles, nk, slots, &tab);
+    if (rc) return rc == BRCNN_EINVAL ? 0 : rc;
+    if (++st->epoch == 0) st->epoch = 1;
+    p.sk_wgs = tab->blocks;
+    p.sk_items = tab->items;
+    p.sk_ws = st->ws;
+    p.sk_flags = st->flags;
+    p.sk_epoch = st->epoch;
+    return 0;
+}
+
 template <int MT, int NT, bool RES, bool OUTF32, int WM = 2, int WNW = 2, int ST = 2, int ET = 0, int MODE = 0>
-int launch(const ConvParams& p, hipStream_t s) {
+int launch(ConvParams& p, hipStream_t s) {
     const size_t lds_stage = (size_t)(32 * MT * WM + 32 * NT * WNW) * 32 * sizeof(float);
     const size_t lds_full = ST * lds_stage;
     const size_t lds_epi = (size_t)WNW * WM * 32 * (32 * NT + 4) * sizeof(float);
     const int nk = p.K / BKE;
+    if constexpr (ST == 2 && MT * NT <= 4) {
+        // persistent launch of exactly the resident workgroups (the occupancy query can be one high near an SGPR
+        // edge -- MI355X_MICROARCH.md; a surplus workgroup only starts late, lower ranges never wait for higher ones)
+        static int occ = -1;
+        static bool sk_attr = false;
+        const size_t lds_sk = lds_full > lds_epi ? lds_full : lds_epi;
+        if (!sk_attr) {
+            BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, MODE, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sk));
+            int n = 0;
+            BRCNN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &n, (const void*)conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, MODE, true>, 64 * WM * WNW, lds_sk));
+            if (g_num_cus == 0) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                BRCNN_HIP_CHECK(hipGetDevice(&dev));
+                BRCNN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+                g_num_cus = prop.multiProcessorCount;
+            }
+            occ = n;
+            sk_attr = true;
+        }
+        const int rc = sk_plan(p, occ * g_num_cus, 32 * MT * WM, 32 * NT * WNW, s);
+        if (rc) return rc;
+        if (p.sk_wgs > 0) {
+            hipLaunchKernelGGL((conv_igemm_bf16_dma_kernel<MT, NT, RES, OUTF32, WM, WNW, ST, ET, MODE, true>), dim3(p.sk_wgs),
+                               dim3(64 * WM * WNW), lds_sk, s, p);
+            BRCNN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t lds_k = (nk < ST ? nk : ST) * lds_stage;              // operand ring (shorter for a short K loop)
     const size_t lds = lds_k > lds_epi ? lds_k : lds_epi;               // the epilogue slabs reuse the same space
     static bool attr_done = false;
@@ -576,7 +817,9 @@ static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     if (fill44 && p.Cout > 128) return launch2<2, 2, 4, 4, 2, 1>(p, s);
     if (p.Cout <= 64) return launch2<2, 1, 2, 2, 2, 1>(p, s);
     if (t22 < 256) return launch2<1, 1, 2, 2, 2, 1>(p, s);
-    if (p.M >= 65536) return launch2<1, 2, 4, 2, 2, 1>(p, s);
+    const bool sk82 = g_sk_mode == 1 && (p.Cout % 128) == 0 && p.K >= 2048 && t22 >= 512 &&
+                      (double)t22 / (double)(((t22 + 511) / 512) * 512) < 0.9;
+    if (p.M >= 65536 || sk82) return launch2<1, 2, 4, 2, 2, 1>(p, s);
     if (p.M >= 16384) return launch2<1, 1, 4, 2, 2, 1>(p, s);
     return launch2<2, 1, 2, 2, 2, 1>(p, s);
 }
@@ -598,10 +841,14 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
         const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && !p.tail_z && t44 >= 512 &&
                             (double)t44 / (double)(((t44 + 255) / 256) * 256) >= 0.85;
+        // 128x128 under the stream-K schedule where its tile count sits just above a multiple of the 512 slots (the
+        // stage-3 3x3 layers: 526 tiles) and K is long: 69 -> 65 us there, 214 -> 188 us on the 4608-deep layer
+        const bool sk82 = g_sk_mode == 1 && (p.Cout % 128) == 0 && p.K >= 2048 && t22 >= 512 &&
+                          (double)t22 / (double)(((t22 + 511) / 512) * 512) < 0.9;
         if (fill44) t = 2244;
         else if (p.Cout <= 64) t = 21;
         else if (t22 < 256) t = 11;
-        else if (p.M >= 65536) t = 82;
+        else if (p.M >= 65536 || sk82) t = 82;
         else if (p.M >= 16384) t = 81;
         else t = 21;
     }
@@ -627,6 +874,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
+    if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced
     const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144};
     bool found = false;
     for (int v : ok) found |= (v == mtnt);

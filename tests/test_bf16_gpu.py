@@ -596,3 +596,39 @@ def test_bf16_tile_shapes_agree_bit_for_bit():
             assert torch.equal(y, outs[11]), t
     finally:
         L.brcnn_conv_set_tile_bf16(0)
+
+
+@pytest.mark.parametrize('shape', [
+    # batch, H, W, Cin, Cout, k, residual      (8 x 50 x 84 = 33 600 rows: 263 row tiles of 128 -- the stage-3 maps)
+    (8, 50, 84, 256, 256, 3, False),
+    (8, 50, 84, 1024, 256, 1, False),
+    (8, 50, 84, 256, 1024, 1, True),
+    (8, 25, 42, 512, 512, 3, False),
+    (3, 50, 84, 256, 256, 3, True),          # fewer tiles than resident workgroups on most tile shapes: plain launch
+])
+def test_bf16_stream_k_schedule_is_bit_identical(shape):
+    """the chained stream-K schedule (a tile that straddles two workgroup ranges is started by one workgroup and
+    finished by another from the stored fp32 accumulators) keeps the MFMA chain over K: forced on (-5) it equals the
+    one-tile-per-workgroup launch (-3) bit for bit on every production tile shape, with and without residual / ReLU,
+    repeated (the hand-over slots and epoch flags are reused launch after launch)"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    n, h, w_, ci, co, k, res = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, h, w_, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, k, k, ci, generator=g) * 0.05).bfloat16().to(DEV)
+    sc = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(co, generator=g).to(DEV)
+    r = torch.randn(n, h, w_, co, generator=g).bfloat16().to(DEV) if res else None
+    try:
+        for t in (0, 11, 21, 81, 82):
+            assert L.brcnn_conv_set_tile_bf16(t) == 0
+            assert L.brcnn_conv_set_tile_bf16(-3) == 0
+            ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, 1, k // 2)
+            assert L.brcnn_conv_set_tile_bf16(-5) == 0
+            for rep in range(3):
+                out = ops.conv2d_nhwc(x, w, sc, sh, r, True, 1, k // 2)
+                assert torch.equal(out, ref), (t, rep, (out.float() - ref.float()).abs().max().item())
+    finally:
+        L.brcnn_conv_set_tile_bf16(0)
+        L.brcnn_conv_set_tile_bf16(-4)

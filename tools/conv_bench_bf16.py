@@ -20,8 +20,16 @@ shapes = [  # name, N,H,W,Cin,Cout,k,stride,pad,res
  ('s4 1x1 512->2048 +res', 8,25,42,512,2048,1,1,0,True),
  ('s4 1x1 2048->512', 8,25,42,2048,512,1,1,0,False),
  ('s3 3x3 s2 256->256', 8,100,168,256,256,3,2,1,False),
+ ('s2 1x1 512->128', 8,100,168,512,128,1,1,0,False),
+ ('s3 1x1 512->1024 (ds)', 8,50,84,512,1024,1,1,0,False),
+ ('p4 3x3 256->256 M8400', 8,25,42,256,256,3,1,1,False),
+ ('s4 dgrad 3x3 512->512 M33600', 8,50,84,512,512,3,1,1,False),
 ]
-tiles = [int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else [11, 21, 22, 0]
+if os.environ.get('SHAPES'):
+    keep = os.environ['SHAPES'].split(',')
+    shapes = [s_ for s_ in shapes if any(k_ in s_[0] for k_ in keep)]
+# tile ids as brcnn_conv_set_tile_bf16 takes them; suffix 's' = stream-K schedule forced, 'a' = heuristic, none = off
+tiles = sys.argv[1].split(',') if len(sys.argv) > 1 else ['11', '21', '22', '0']
 if len(sys.argv) > 2:      # 'il0' / 'il1': LDS-DMA pieces in front of / spread between the MFMA groups
     L.brcnn_conv_set_tile_bf16(-1 if sys.argv[2] == 'il1' else -2)
 def bench(fn, n=10):
@@ -40,10 +48,13 @@ for name,N,H,W,Ci,Co,k,st,pd,res in shapes:
     fl = 2.0*N*Ho*Wo*Co*k*k*Ci
     by = 2.0*(x.numel() + w.numel() + N*Ho*Wo*Co*(2 if res else 1))
     out = []
-    for t in tiles:
+    for ts in tiles:
+        t = int(ts.rstrip('sa'))
         if L.brcnn_conv_set_tile_bf16(t) != 0:
             continue
+        L.brcnn_conv_set_tile_bf16(-5 if ts.endswith('s') else -4 if ts.endswith('a') else -3)
         ms = bench(lambda: ops.conv2d_nhwc(x,w,sc,sh,r,True,st,pd))
-        out.append(f'{t:3d}: {ms*1000:6.1f} us {fl/ms/1e9:6.1f} TF')
+        out.append(f'{ts:>5s}: {ms*1000:6.1f} us {fl/ms/1e9:6.1f} TF')
     L.brcnn_conv_set_tile_bf16(0)
+    L.brcnn_conv_set_tile_bf16(-4)
     print(f'{name:24s} M={N*Ho*Wo:7d} hbm-floor {by/8e12*1e6:5.1f} us | ' + ' | '.join(out))
