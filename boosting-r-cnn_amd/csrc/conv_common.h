@@ -97,5 +97,7 @@ __device__ __forceinline__ static long long out_row_offset(const ConvParams& p, 
 
 // bf16 dispatch (conv_igemm_bf16.hip)
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s);
+// 256 x 256 tile on the eight-phase two-group schedule (conv_pp_bf16.hip); plain epilogue only
+int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s);
 
 }  // namespace brcnn_conv

@@ -828,7 +828,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     if (p.f16) return dispatch_conv_f16(p, s);
     p.il = g_bf16_il;
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
-    int t = (p.z_out || p.tail_z) ? 0 : g_bf16_tile;
+    int t = ((p.z_out || p.tail_z) && g_bf16_tile != 8844) ? 0 : g_bf16_tile;
     if (t == 0) {
         // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more
         // waves share the LDS-DMA issue of a K tile, the better -- 128x128 on 8 waves of 32x64 beats the
@@ -852,6 +852,8 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         else if (p.M >= 16384) t = 81;
         else t = 21;
     }
+    if (t == 8844 && p.Cout > 128 && p.K >= 128 && p.KH * p.KW <= 32 && !(p.tail_z && p.tail_mask)) return dispatch_conv_pp_bf16(p, s);
+    if (t == 8844) t = 82;
     if (t == 342 && p.Cout > 64) return launch2<2, 2, 4, 2, 3>(p, s);    // 3-stage ring variants
     if (t == 382 && p.Cout > 64) return launch2<1, 2, 4, 2, 3>(p, s);
     if (t == 3164 && p.Cout > 64) return launch2<1, 1, 4, 4, 3>(p, s);
@@ -875,7 +877,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
     if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced
-    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144};
+    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844};
     bool found = false;
     for (int v : ok) found |= (v == mtnt);
     if (!found) return BRCNN_EINVAL;

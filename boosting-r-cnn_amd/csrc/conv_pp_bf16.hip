@@ -1,0 +1,570 @@
+// 16-bit implicit-GEMM convolution on a 256 x 256 x 64 tile with an eight-phase, two-group ("ping-pong") schedule.
+//
+// Same decomposition, operand layout and numerics as conv_igemm_bf16.hip (D[m,co] = sum_k A[m,k] W[co,k], LDS-DMA
+// staging of 128-byte rows with the source-side XOR swizzle, v_mfma_f32_32x32x16 as D^T = W A^T, the K order of the
+// unsplit chain -- so every output is bit-identical to the other tile shapes); what differs is the schedule inside
+// the workgroup.  The two-buffer kernel runs {stage next K tile, read fragments, MFMA, vmcnt(0), barrier} per K tile:
+// every wave is in the same phase, so the matrix pipes idle while fragments are read and the LDS idles during the
+// MFMAs (no unit saturated, phases do not overlap).  Here
+//   * 8 waves = 2 groups (rows 0-127 / 128-255 of the tile) x 4 column strips; a wave owns 128 x 64 outputs
+//     (4 x 2 MFMA tiles, 128 accumulator registers);
+//   * a K tile is four phases, one 64 x 32 quadrant of the wave's outputs each (8 MFMAs = 256 matrix-pipe cycles);
+//     a phase is  {read the quadrant's new fragments, issue ONE half-tile (16 KB) of LDS-DMA}  barrier
+//     {MFMAs}  barrier;  the second group runs one barrier behind the first, so on every SIMD one wave is in its
+//     MFMA block while the other reads fragments and issues DMA (MI355X_MICROARCH.md: matrix beside memory);
+//   * the LDS holds two K tiles as eight 16 KB half-tile slots, each read in exactly one phase of the eight
+//     (slot s in phase s) and re-staged two phases later with the data it needs six phases after that: five
+//     half-tiles (80 KB per CU) are in flight, the only wait is a counted `vmcnt(10)` per phase, never a drain.
+// Hazards (cdna_hip_programming.md 5, "Read a staged buffer one phase AFTER the wait that retires it"): the slot
+// read in phase q was staged in phase q-6 and waited for (by the staging waves, vmcnt(10)) in phase q-1 before that
+// phase's first barrier; it is overwritten in phase q+2, two barriers after the slower group's read was waited for.
+#include <type_traits>
+#include "conv_common.h"
+
+namespace {
+using namespace brcnn_conv;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int BKE = 64;
+constexpr int BM = 256, BN = 256, MT = 4, NT = 2, WNW = 4, NW = 8;
+constexpr int SLOT = 16384;         // bytes of one half-tile slot: 128 rows x 128 B
+
+template <int ET> __device__ __forceinline__ float e2f(unsigned short h) { return ET ? brcnn_h2f(h) : brcnn_b2f(h); }
+template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { return ET ? brcnn_f2h(v) : brcnn_f2b(v); }
+
+template <int N> using ic = std::integral_constant<int, N>;
+
+// DIL: zero-stuffed input (p.dilate > 1, the data gradient of a strided conv): the general address form
+template <bool RES, bool OUTF32, int ET, bool DIL, int MODE = 0>
+__global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nk = p.K / BKE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- staging: per half-tile a wave fills LDS rows [16 wave, 16 wave + 16) with two DMA instructions (8 rows x
+    // 128 B each).  LDS row R of A half h holds tile row (R>>6)*128 + (2h + ((R>>5)&1))*32 + (R&31): the two 32-row
+    // MFMA tiles 2h, 2h+1 of both wave groups; LDS row R of B half h holds output column (R>>5)*64 + h*32 + (R&31).
+    const int rg = lane >> 3, pc = lane & 7;
+    // Per staged A row: the byte offset of its (kh, kw) = (0, 0) tap, the byte stride of an input row, and one validity
+    // bit per filter tap (row inside M, tap inside the map) -- a stage is then one multiply-add, one add and a select
+    // per DMA instruction instead of the unpack / four compares / multiply chain (the load block of a phase has to
+    // fit beside the other group's 256 cycles of MFMAs).  Zero-stuffed inputs (dilate > 1: data gradient of a
+    // strided conv) keep the general form.
+    int a_off[2][2], b_off[2][2], lc[2];
+    int a_ws[DIL ? 1 : 2][2];           // !DIL: byte stride of an input row
+    unsigned a_mask[2][2];
+    int a_hw[DIL ? 2 : 1][2], a_HW[DIL ? 2 : 1][2];         // DIL only: packed (hi0, wi0), (H, W)
+#pragma unroll
+    for (int j = 0; j < 2; j++) lc[j] = (pc ^ ((4 * j + (lane >> 4)) & 7)) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int R = 16 * wave + 8 * j + rg;
+            const int m = m0 + (R >> 6) * 128 + (2 * h + ((R >> 5) & 1)) * 32 + (R & 31);
+            a_off[h][j] = 0;
+            a_mask[h][j] = 0u;
+            if constexpr (DIL) { a_hw[h][j] = 0; a_HW[h][j] = 0; }
+            else a_ws[h][j] = 0;
+            if (m < p.M) {
+                int sg = 0;
+#pragma unroll
+                for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                    if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+                const int ml = m - p.seg_m0[sg];
+                const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg], H = p.seg_H[sg], W = p.seg_W[sg];
+                const int n = ml / (Ho * Wo);
+                const int rem = ml - n * (Ho * Wo);
+                const int ho = rem / Wo, wo = rem - ho * Wo;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                const int base = (int)p.seg_xoff[sg] + n * H * W * p.pitch;
+                if constexpr (DIL) {
+                    a_HW[h][j] = (H << 16) | W;
+                    a_off[h][j] = base;
+                    a_hw[h][j] = ((hi0 + 4096) << 16) | (wi0 + 4096);
+                    a_mask[h][j] = 1u;
+                } else {
+                    a_off[h][j] = (base + (hi0 * W + wi0) * p.pitch + lc[j] + tile_n * p.gstep) * 2;
+                    a_ws[h][j] = W * p.pitch * 2;
+                    unsigned mk = 0u;
+                    for (int kh = 0; kh < p.KH; kh++)
+                        for (int kw = 0; kw < p.KW; kw++)
+                            if ((unsigned)(hi0 + kh) < (unsigned)H && (unsigned)(wi0 + kw) < (unsigned)W) mk |= 1u << (kh * p.KW + kw);
+                    a_mask[h][j] = mk;
+                }
+            }
+            const int co = n0 + (R >> 5) * 64 + h * 32 + (R & 31);
+            b_off[h][j] = (co < p.Cout) ? (co * p.K + lc[j]) * 2 : OOB;
+        }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned st_dst = lds0 + (unsigned)wave * 2048u;        // this wave's rows inside a slot
+
+    int tA_ci0 = 0, tA_kh = 0, tA_kw = 0;      // filter tap / channel offset of the K tile whose A halves are staged next
+    auto advance_tap = [&]() {
+        tA_ci0 += BKE;
+        if (tA_ci0 >= p.Cin) {
+            tA_ci0 = 0;
+            if (++tA_kw == p.KW) { tA_kw = 0; tA_kh++; }
+        }
+    };
+    auto stage_A = [&](int slot, int h, bool valid) {
+        if constexpr (!DIL) {
+            const int tap = tA_kh * p.KW + tA_kw;                   // scalar
+            const int s_off = (tA_kw * p.pitch + tA_ci0) * 2;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const bool ok = valid & (((a_mask[h][j] >> tap) & 1u) != 0u);
+                const int off = ok ? a_off[h][j] + tA_kh * a_ws[h][j] + s_off : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int hi = (a_hw[h][j] >> 16) - 4096 + tA_kh;
+            int wi = (a_hw[h][j] & 0xffff) - 4096 + tA_kw;
+            bool ok = valid & (a_mask[h][j] != 0u) & (hi >= 0) & (wi >= 0);
+            const int qh = hi / p.dilate, qw = wi / p.dilate;
+            ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
+            hi = qh;
+            wi = qw;
+            const int H = a_HW[h][j] >> 16, W = a_HW[h][j] & 0xffff;
+            ok = ok & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+            const int off = ok ? (a_off[h][j] + (hi * W + wi) * p.pitch + tA_ci0 + lc[j] + tile_n * p.gstep) * 2 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+        }
+        }
+    };
+    auto stage_B = [&](int slot, int h, int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            // (an out-of-range row offset plus the K offset stays out of range and below 2^32)
+            const int off = kt < nk ? (int)((unsigned)b_off[h][j] + (unsigned)(kt * (BKE * 2))) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment reads: lane (li, lh) reads row li of a 32-row MFMA tile, chunk (2 kk + lh) ^ ((li >> 1) & 7)
+    const int sw = (li >> 1) & 7;
+    unsigned a_rd[4], b_rd[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const unsigned ch = (unsigned)(((2 * kk + lh) ^ sw) * 16);
+        a_rd[kk] = lds0 + (unsigned)(wm * 64 + li) * 128u + ch;
+        b_rd[kk] = lds0 + (unsigned)(wn * 32 + li) * 128u + ch;
+    }
+    f32x4 Ar[2][4], B0r[4], B1r[4];
+    // slots 4..7 lie beyond the 16-bit offset field: their reads add 64 KiB to the address register
+    auto rd = [&](f32x4& d, unsigned addr, auto off_c) {
+        constexpr int OFF = decltype(off_c)::value;
+        if constexpr (OFF < 65536) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+        } else {
+            const unsigned hi = addr + 65536u;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(hi), "n"(OFF - 65536) : "memory");
+        }
+    };
+    auto read_A = [&](auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            rd(Ar[0][kk], a_rd[kk], ic<S * SLOT>{});
+            rd(Ar[1][kk], a_rd[kk], ic<S * SLOT + 4096>{});
+        }
+    };
+    auto read_B = [&](f32x4 (&Br)[4], auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) rd(Br[kk], b_rd[kk], ic<S * SLOT>{});
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    // quadrant (MFMA tiles tm0, tm0+1) x tn: 8 MFMAs, the two accumulators alternate
+    auto mfma_quad = [&](auto tm0_c, auto tn_c, f32x4 (&Br)[4]) {
+        constexpr int TM0 = decltype(tm0_c)::value, TN = decltype(tn_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if constexpr (ET)
+                    acc[TM0 + t][TN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, Br[kk]), __builtin_bit_cast(f16x8, Ar[t][kk]), acc[TM0 + t][TN], 0, 0, 0);
+                else
+                    acc[TM0 + t][TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, Br[kk]), __builtin_bit_cast(bf16x8, Ar[t][kk]), acc[TM0 + t][TN], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
+    // the fragment registers of this phase are complete: wait, then pin every later use below the wait
+    auto frags_ready = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); };
+
+    // ---- prologue: K tiles 0 (slots 0-3: B0 A0 B1 A1) and 1 (slots 4-7: B1 A0 B0 A1), in read order
+    stage_B(0, 0, 0);
+    stage_A(1, 0, true);
+    stage_B(2, 1, 0);
+    stage_A(3, 1, true);
+    advance_tap();
+    stage_B(4, 1, 1);
+    stage_A(5, 0, 1 < nk);
+    stage_B(6, 0, 1);
+    stage_A(7, 1, 1 < nk);
+    advance_tap();                                   // -> K tile 2
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slots 0, 1 of this wave have landed
+    barrier();
+    read_B(B0r, ic<0>{});                            // "phase 0": B0 of K tile 0
+    if (wm == 1) barrier();                          // the second group runs one barrier behind
+
+    const int iters = (nk + 1) >> 1;
+    for (int it = 0; it < iters; it++) {
+        const int kt = 2 * it;                       // even K tile of this iteration; kt + 1 the odd one
+        const bool odd_ok = kt + 1 < nk;
+        // phase 1: A0 of the even tile (slot 1) x B0; stage slot 7 = A1 of the odd tile kt+1 (already there in the
+        // first iteration: the prologue staged it, and the tap state stands at tile 2)
+        read_A(ic<1>{});
+        // (no DMA is issued there: the prologue's eight stages stand for phases -6 .. 1, so vmcnt(10) still means
+        // "everything up to five stages back has landed")
+        if (it > 0) { stage_A(7, 1, odd_ok); advance_tap(); }
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<0>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 2: x B1 (slot 2); stage slot 0 = B0 of tile kt+2
+        read_B(B1r, ic<2>{});
+        stage_B(0, 0, kt + 2);
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<0>{}, ic<1>{}, B1r);
+        barrier();
+        // phase 3: A1 (slot 3) x B1; stage slot 1 = A0 of tile kt+2
+        read_A(ic<3>{});
+        stage_A(1, 0, kt + 2 < nk);
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<2>{}, ic<1>{}, B1r);
+        barrier();
+        // phase 4: A1 x B0; read B1 of the odd tile (slot 4); stage slot 2 = B1 of tile kt+2
+        read_B(B1r, ic<4>{});
+        stage_B(2, 1, kt + 2);
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<2>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 5: A0 of the odd tile (slot 5) x B1; stage slot 3 = A1 of tile kt+2
+        read_A(ic<5>{});
+        stage_A(3, 1, kt + 2 < nk);
+        advance_tap();
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<0>{}, ic<1>{}, B1r);
+        barrier();
+        // phase 6: x B0 (slot 6); stage slot 4 = B1 of tile kt+3
+        read_B(B0r, ic<6>{});
+        stage_B(4, 1, kt + 3);
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<0>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 7: A1 (slot 7) x B0; stage slot 5 = A0 of tile kt+3
+        read_A(ic<7>{});
+        stage_A(5, 0, kt + 3 < nk);
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<2>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 8: A1 x B1; read B0 of the next even tile (slot 0); stage slot 6 = B0 of tile kt+3
+        read_B(B0r, ic<0>{});
+        stage_B(6, 0, kt + 3);
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<2>{}, ic<1>{}, B1r);
+        barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (wm == 0) barrier();
+    barrier();                                       // every wave is past its last fragment read and DMA: the slabs may land
+
+    // ---- epilogue (conv_igemm_bf16.hip's, the same arithmetic in the same order): lane l holds pixel m = l&31 and, per
+    // register group g, four consecutive channels co = 8g + 4(l>>5) + (0..3); one 32-row slab at a time goes through the
+    // wave's private LDS region so that a lane ends up with 8 consecutive channels of one pixel (16-byte accesses).
+    // MODE 0: scale / shift in the accumulators, residual, ReLU.
+    // MODE 1 (training forward, conv -> eval-BN [-> + residual] [-> ReLU]): the raw tile leaves as z_out, the affine
+    //         (one channel per lane derived from gamma / beta / mean / var, handed out through the slab) is applied to
+    //         the STORED z in the read-out layout.
+    // MODE 2 (data gradient + the BatchNorm backward of the input's producer): tail_z is the producer's raw output;
+    //         d = gradient masked by the producer's ReLU, out = d * scale, per-row-tile sums of d and d * z.
+    constexpr int PITCH = 32 * NT + 4;            // floats
+    float* cs = smem + wave * 32 * PITCH;
+    constexpr int LPR = 4 * NT, RPI = 64 / LPR;
+    const int cw0 = n0 + wn * 32 * NT;
+    const bool vec_ok = (p.Cout & 7) == 0;
+    const int rl = lane / LPR, cl = (lane % LPR) * 8;
+    const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(MODE == 2 ? p.tail_z : (const void*)p.residual);
+    constexpr bool HAS_RQ = RES || MODE == 2;
+    float sc8[8], sh8[8];
+    float sum_dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sum_d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE != 0) {
+        {
+            const int co = cw0 + lane;
+            float a = 1.f, b = 0.f;
+            if (co < p.Cout) {
+                if (p.bn_mean) {       // the operation order of bn_act.hip's bn_affine (the backward recomputes it)
+                    a = p.scale[co] / sqrtf(p.bn_var[co] + p.bn_eps);
+                    b = p.shift[co] - p.bn_mean[co] * a;
+                } else {
+                    a = p.scale ? p.scale[co] : 1.f;
+                    b = p.shift ? p.shift[co] : 0.f;
+                }
+            }
+            cs[lane] = a;
+            cs[64 + lane] = b;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sc8[e] = cs[cl + e]; sh8[e] = cs[64 + cl + e]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    float4 scv[NT][4], shv[NT][4];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = cw0 + tn * 32 + 8 * g + 4 * lh;
+                float sc4[4], sh4[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = co + e < p.Cout;
+                    sc4[e] = (p.scale && ok) ? p.scale[co + e] : 1.f;
+                    sh4[e] = (p.shift && ok) ? p.shift[co + e] : 0.f;
+                }
+                scv[tn][g] = make_float4(sc4[0], sc4[1], sc4[2], sc4[3]);
+                shv[tn][g] = make_float4(sh4[0], sh4[1], sh4[2], sh4[3]);
+            }
+    }
+    unsigned short* __restrict__ yh = reinterpret_cast<unsigned short*>(p.y);
+    float* __restrict__ yf = p.y;
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) {
+        const int mw = m0 + wm * 32 * MT + tm * 32;
+        uint4 rq[32 / RPI];
+        if (HAS_RQ) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int m = mw + it * RPI + rl, co = cw0 + cl;
+                rq[it] = make_uint4(0, 0, 0, 0);
+                if (vec_ok && m < p.M && co < p.Cout) rq[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.Cout + co);
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float4 v;
+                if constexpr (MODE == 0) {
+                    v.x = acc[tm][tn][4 * g + 0] * scv[tn][g].x + shv[tn][g].x;
+                    v.y = acc[tm][tn][4 * g + 1] * scv[tn][g].y + shv[tn][g].y;
+                    v.z = acc[tm][tn][4 * g + 2] * scv[tn][g].z + shv[tn][g].z;
+                    v.w = acc[tm][tn][4 * g + 3] * scv[tn][g].w + shv[tn][g].w;
+                } else {        // (the two-buffer kernel's shared code path: x * 1 + 0, which also turns -0 into +0)
+                    v.x = acc[tm][tn][4 * g + 0] * 1.f + 0.f; v.y = acc[tm][tn][4 * g + 1] * 1.f + 0.f;
+                    v.z = acc[tm][tn][4 * g + 2] * 1.f + 0.f; v.w = acc[tm][tn][4 * g + 3] * 1.f + 0.f;
+                }
+                *reinterpret_cast<float4*>(cs + li * PITCH + tn * 32 + 8 * g + 4 * lh) = v;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the slab is wave-private
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; it++) {
+            const int row = it * RPI + rl;
+            const int m = mw + row, co = cw0 + cl;
+            const float4 lo = *reinterpret_cast<const float4*>(cs + row * PITCH + cl);
+            const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (m >= p.M || co >= p.Cout) continue;
+            const long long ro = out_row_offset(p, m);
+            if (ro < 0) continue;
+            if (vec_ok) {
+                if constexpr (MODE == 1) {
+                    uint4 zq;
+                    zq.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
+                    zq.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
+                    zq.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
+                    zq.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.z_out) + ro + co) = zq;
+                    const unsigned zw[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[2 * e] = e2f<ET>((unsigned short)(zw[e] & 0xffffu)) * sc8[2 * e] + sh8[2 * e];
+                        v[2 * e + 1] = e2f<ET>((unsigned short)(zw[e] >> 16)) * sc8[2 * e + 1] + sh8[2 * e + 1];
+                    }
+                }
+                if constexpr (MODE == 2) {
+                    const unsigned zw[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float zz = e2f<ET>((unsigned short)((e & 1) ? (zw[e >> 1] >> 16) : (zw[e >> 1] & 0xffffu)));
+                        const float g = e2f<ET>(f2e<ET>(v[e]));
+                        const float pre = zz * sc8[e] + sh8[e];
+                        const float d = (!p.tail_relu || pre > 0.f) ? g : 0.f;
+                        sum_dz[e] += d * zz;
+                        sum_d[e] += d;
+                        v[e] = d * sc8[e];
+                    }
+                }
+                if (RES && MODE != 2) {
+                    const unsigned rr[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[2 * e] += e2f<ET>((unsigned short)(rr[e] & 0xffffu));
+                        v[2 * e + 1] += e2f<ET>((unsigned short)(rr[e] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (OUTF32) {
+                    float4* dst = reinterpret_cast<float4*>(yf + ro + co);
+                    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    uint4 o;
+                    o.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
+                    o.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
+                    o.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
+                    o.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(yh + ro + co) = o;
+                }
+            } else {       // ragged channel count: element-wise tail (MODE 0 only: the host checks)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    if (co + e >= p.Cout) break;
+                    float t = v[e];
+                    if (RES) t += e2f<ET>(res[(size_t)m * p.Cout + co + e]);
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (OUTF32) yf[ro + co + e] = t;
+                    else yh[ro + co + e] = f2e<ET>(t);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (MODE == 2) {
+        // lanes that share the channel vector (equal lane % LPR) hold different rows: butterfly over the row bits, then
+        // the two wave groups of one channel strip add up through their slabs in a fixed order
+#pragma unroll
+        for (int d = LPR; d < 64; d <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                sum_dz[e] += __shfl_xor(sum_dz[e], d, 64);
+                sum_d[e] += __shfl_xor(sum_d[e], d, 64);
+            }
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { cs[lane * 8 + e] = sum_dz[e]; cs[64 + lane * 8 + e] = sum_d[e]; }
+        }
+        __syncthreads();
+        if (wm == 0) {
+            const int co = cw0 + lane;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float* o = smem + (k * WNW + wn) * 32 * PITCH;
+                a += o[lane];
+                b += o[64 + lane];
+            }
+            if (co < p.Cout) {
+                p.tail_partials[((size_t)tile_m * 2 + 0) * p.Cout + co] = a;
+                p.tail_partials[((size_t)tile_m * 2 + 1) * p.Cout + co] = b;
+            }
+        }
+    }
+}
+
+template <bool RES, bool OUTF32, int ET, bool DIL, int MODE = 0>
+int launch_pp2(ConvParams& p, hipStream_t s) {
+    constexpr size_t lds = 8 * SLOT;
+    static bool attr_done = false;
+    if (!attr_done) {
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool RES, bool OUTF32, int ET>
+int launch_pp(ConvParams& p, hipStream_t s) {
+    return p.dilate > 1 ? launch_pp2<RES, OUTF32, ET, true>(p, s) : launch_pp2<RES, OUTF32, ET, false>(p, s);
+}
+
+// training epilogues (16-bit result, whole 16-byte channel pieces): MODE 1 dual store, MODE 2 data gradient + the
+// producer's BatchNorm backward (conv_igemm_bf16.hip launch2's rules)
+template <int ET>
+int launch_pp_train(ConvParams& p, hipStream_t s) {
+    if (p.out_f32 || (p.Cout & 7) || (p.tail_z && p.tail_mask)) return BRCNN_EINVAL;
+    if (p.tail_z) {
+        if (p.residual) return BRCNN_EINVAL;
+        return p.dilate > 1 ? launch_pp2<false, false, ET, true, 2>(p, s) : launch_pp2<false, false, ET, false, 2>(p, s);
+    }
+    if (p.dilate > 1) return BRCNN_EINVAL;
+    return p.residual ? launch_pp2<true, false, ET, false, 1>(p, s) : launch_pp2<false, false, ET, false, 1>(p, s);
+}
+
+}  // namespace
+
+namespace brcnn_conv {
+// 256 x 256 tile, eight-phase schedule; plain epilogue (scale / shift, residual, ReLU, bf16 / fp16 or fp32 result)
+// and the training epilogues of the 16-bit backbone layers (dual store; data gradient + BatchNorm backward)
+int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s) {
+    if (p.K < 2 * BKE || (p.K % BKE) || p.KH * p.KW > 32) return BRCNN_EINVAL;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    p.sk_wgs = 0;
+    if (p.z_out || p.tail_z) return p.f16 ? launch_pp_train<1>(p, s) : launch_pp_train<0>(p, s);
+    if (p.f16) {
+        if (p.out_f32) return p.residual ? launch_pp<true, true, 1>(p, s) : launch_pp<false, true, 1>(p, s);
+        return p.residual ? launch_pp<true, false, 1>(p, s) : launch_pp<false, false, 1>(p, s);
+    }
+    if (p.out_f32) return p.residual ? launch_pp<true, true, 0>(p, s) : launch_pp<false, true, 0>(p, s);
+    return p.residual ? launch_pp<true, false, 0>(p, s) : launch_pp<false, false, 0>(p, s);
+}
+}  // namespace brcnn_conv

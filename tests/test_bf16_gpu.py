@@ -588,12 +588,90 @@ def test_bf16_tile_shapes_agree_bit_for_bit():
     sh = torch.randn(256, generator=g).to(DEV)
     try:
         outs = {}
-        for t in (11, 21, 22, 81, 82, 164, 42, 2244, 2144, 382, 342):
+        for t in (11, 21, 22, 81, 82, 164, 42, 2244, 2144, 382, 342, 8844):
             assert L.brcnn_conv_set_tile_bf16(t) == 0
             outs[t] = ops.conv2d_nhwc(x, w, sc, sh, None, True, 1, 1)
         torch.cuda.synchronize()
         for t, y in outs.items():
             assert torch.equal(y, outs[11]), t
+    finally:
+        L.brcnn_conv_set_tile_bf16(0)
+
+
+@pytest.mark.parametrize('cfg', [
+    # N, H, W, Cin, Cout, k, stride, pad, residual, out_f32
+    (2, 50, 84, 256, 256, 3, 1, 1, False, False),      # 36 K tiles
+    (2, 50, 84, 64, 256, 3, 1, 1, True, False),        # 9 K tiles (odd: the last iteration's second half is skipped)
+    (3, 25, 42, 192, 320, 1, 1, 0, False, False),      # 3 K tiles, ragged row / channel tiles
+    (2, 50, 84, 128, 256, 1, 1, 0, True, True),        # 2 K tiles, fp32 result
+    (2, 51, 85, 256, 384, 3, 2, 1, False, False),      # stride 2
+    (1, 13, 21, 256, 54, 3, 1, 1, False, True),        # ragged channel count: routed to the small tiles
+])
+def test_bf16_eight_phase_kernel_is_bit_identical(cfg):
+    """the 256 x 256 eight-phase kernel (conv_pp_bf16.hip) accumulates over K in the order of the two-buffer kernel:
+    identical results, for every K-tile count parity, ragged tiles, strides, residual / fp32 epilogues, several
+    launches in a row (LDS slots and the DMA pipeline start clean each time)"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    n, h, w_, ci, co, k, stride, pad, res, of32 = cfg
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(n, h, w_, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, k, k, ci, generator=g) * 0.05).bfloat16().to(DEV)
+    sc = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(co, generator=g).to(DEV)
+    ho, wo = ops.conv_out_size(h, w_, k, k, stride, pad)
+    r = torch.randn(n, ho, wo, co, generator=g).bfloat16().to(DEV) if res else None
+    try:
+        assert L.brcnn_conv_set_tile_bf16(11) == 0
+        ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad, out_f32=of32)
+        assert L.brcnn_conv_set_tile_bf16(8844) == 0
+        for rep in range(3):
+            out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad, out_f32=of32)
+            assert torch.equal(out, ref), (rep, (out.float() - ref.float()).abs().max().item())
+    finally:
+        L.brcnn_conv_set_tile_bf16(0)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_bf16_eight_phase_kernel_training_epilogues(dtype):
+    """the dual-store forward (MODE 1) and the data gradient + BatchNorm backward (MODE 2, incl. the zero-stuffed
+    stride-2 form) of the eight-phase kernel: the same bit-for-bit checks against the separate bn_act launches as the
+    two-buffer kernel's, with the 256 x 256 tile forced"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    try:
+        assert L.brcnn_conv_set_tile_bf16(8844) == 0
+        for cfg in [(8, 256, 50, 84, 1024, 1, 1, True, True, False), (2, 256, 40, 56, 256, 3, 1, False, True, True),
+                    (2, 128, 30, 44, 512, 3, 2, False, True, False)]:
+            test_conv_bn_act_one_launch_training_forward(cfg, dtype)
+        for cfg in [(2, 1024, 256, 1, 26, 40, False), (1, 1024, 512, 2, 13, 17, True)]:
+            test_bottleneck_bn_backward_inside_data_gradient_launch(cfg, dtype)
+    finally:
+        L.brcnn_conv_set_tile_bf16(0)
+
+
+def test_bf16_eight_phase_kernel_multi_level_and_data_gradient():
+    """five pyramid levels in one launch and the zero-stuffed data gradient of a stride-2 conv on the eight-phase kernel"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(34)
+    sizes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
+    B, C = 2, 256
+    xc = torch.cat([torch.randn(B, h, w, C, generator=g).reshape(-1, C) for h, w in sizes], 0).to(DEV, BF)
+    wt = (torch.randn(C, 3, 3, C, generator=g) / 48).to(DEV, BF)
+    dy = torch.randn(2, 25, 42, 256, generator=g).to(DEV, BF)
+    w2 = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
+    try:
+        outs = {}
+        for t in (11, 8844):
+            assert L.brcnn_conv_set_tile_bf16(t) == 0
+            y, _ = ops.conv2d_nhwc_multi(xc, wt, B, sizes, None, None, None, False, 1, 1)
+            x = torch.randn(2, 50, 84, 256, generator=torch.Generator().manual_seed(35)).to(DEV, BF).requires_grad_(True)
+            from brcnn.autograd import conv2d_nhwc_autograd
+            z = conv2d_nhwc_autograd(x, w2.clone().requires_grad_(True), None, 2, 1)
+            z.backward(dy)
+            outs[t] = (y, x.grad.clone())
+        assert torch.equal(outs[11][0], outs[8844][0]) and torch.equal(outs[11][1], outs[8844][1])
     finally:
         L.brcnn_conv_set_tile_bf16(0)
 

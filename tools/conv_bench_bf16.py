@@ -24,6 +24,10 @@ shapes = [  # name, N,H,W,Cin,Cout,k,stride,pad,res
  ('s3 1x1 512->1024 (ds)', 8,50,84,512,1024,1,1,0,False),
  ('p4 3x3 256->256 M8400', 8,25,42,256,256,3,1,1,False),
  ('s4 dgrad 3x3 512->512 M33600', 8,50,84,512,512,3,1,1,False),
+ ('ideal 3x3 256->256 M131072 (512 tiles of 256x256)', 8,128,128,256,256,3,1,1,False),
+ ('tower-eq 3x3 256->256 M179200', 8,140,160,256,256,3,1,1,False),
+ ('ideal 1x1 1024->1024 M65536', 8,64,128,1024,1024,1,1,0,False),
+ ('ideal 1x1 256->1024 M65536 +res', 8,64,128,256,1024,1,1,0,True),
 ]
 if os.environ.get('SHAPES'):
     keep = os.environ['SHAPES'].split(',')
