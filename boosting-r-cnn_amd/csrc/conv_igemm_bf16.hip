@@ -800,6 +800,18 @@ int launch2(ConvParams& p, hipStream_t s) {
     }
 }
 
+// The 256 x 256 eight-phase kernel (conv_pp_bf16.hip) where it wins (tools/conv_bench_bf16.py, profiles/r03_notes.md):
+// whole 256-channel column tiles, at least half a generation of tiles (one workgroup per CU; on 132 tiles it still
+// beats the small tiles' two full generations: 58 vs 70 us), K >= 512 (on the 1 - 4 K-tile layers the prologue and the
+// partly filled second generation cost more than the schedule returns).  g_pp_mode: 0 never, 1 heuristic.
+int g_pp_mode = 1;
+static bool pp_wins(const ConvParams& p) {
+    if (g_pp_mode == 0 || p.gstep || (p.Cout % 256) || p.K < 512 || (p.K % 64) || p.KH * p.KW > 32 || p.scatter) return false;
+    if (p.tail_z && p.tail_mask) return false;
+    const long long t88 = (long long)((p.M + 255) / 256) * (p.Cout / 256);
+    return t88 >= 128;
+}
+
 int g_bf16_il = 0;     // tuning hook (set_tile_bf16(-1 / -2)): spread the LDS-DMA pieces between the MFMA groups
 int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 waves), 42 = 256x128 (8 waves)
 
@@ -810,6 +822,7 @@ namespace brcnn_conv {
 static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     p.il = 0;
     if (p.gstep) return launch2<1, 1, 4, 2, 2, 1>(p, s);
+    if (pp_wins(p)) return dispatch_conv_pp_bf16(p, s);
     const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
     const bool fill44 = p.Cout >= 256 && p.K >= 1024 && !p.residual && !p.out_f32 && !p.z_out && !p.tail_z && t44 >= 512 &&
@@ -829,6 +842,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     p.il = g_bf16_il;
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
     int t = ((p.z_out || p.tail_z) && g_bf16_tile != 8844) ? 0 : g_bf16_tile;
+    if (t == 0 && pp_wins(p)) return dispatch_conv_pp_bf16(p, s);
     if (t == 0) {
         // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more
         // waves share the LDS-DMA issue of a K tile, the better -- 128x128 on 8 waves of 32x64 beats the
@@ -877,6 +891,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
     if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced
+    if (mtnt == -6 || mtnt == -7) { g_pp_mode = mtnt == -7; return 0; }      // eight-phase kernel: -6 never, -7 heuristic
     const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844};
     bool found = false;
     for (int v : ok) found |= (v == mtnt);

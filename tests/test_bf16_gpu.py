@@ -319,7 +319,7 @@ def test_res_layer_residual_bn_backward_inside_next_block(cfg, dtype):
     x = torch.randn(N, H, W, inplanes, device=DEV).to(dtype)
     got = {}
     saved = (A.FUSE_BN_BACKWARD_INTO_DGRAD, A.FUSE_RESIDUAL_BN_BACKWARD)
-    for fused in (True, False):
+    for fused in (True, False, True, False):
         A.FUSE_BN_BACKWARD_INTO_DGRAD = A.FUSE_RESIDUAL_BN_BACKWARD = fused
         try:
             layer.zero_grad()
@@ -327,13 +327,21 @@ def test_res_layer_residual_bn_backward_inside_next_block(cfg, dtype):
             out = layer.forward_nhwc(xd)
             go = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(dtype)
             out.backward(go)
-            got[fused] = (out.detach(), xd.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
+            cur = (out.detach(), xd.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
         finally:
             A.FUSE_BN_BACKWARD_INTO_DGRAD, A.FUSE_RESIDUAL_BN_BACKWARD = saved
+        if fused in got:        # the BatchNorm gradients are fixed-order sums: a repeat reproduces them bit for bit
+            assert torch.equal(cur[1], got[fused][1]), ('dx differs between two identical passes', fused)
+            for k, g_ in cur[2].items():
+                if g_.dim() == 1:
+                    assert torch.equal(g_, got[fused][2][k]), ('not reproducible', fused, k, (g_ - got[fused][2][k]).abs().max().item())
+        got[fused] = cur
     assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
     for k, ga in got[True][2].items():
         gb = got[False][2][k]
-        assert (ga - gb).abs().max().item() <= 3e-5 * max(1.0, gb.abs().max().item()), k
+        # two different fixed orders of an fp32 sum over up to 33 600 x 8 products of magnitude ~1-10 (the per-tile
+        # partials of the data-gradient epilogue against the row strips of bn_act_bwd): 1e-4 of the largest entry
+        assert (ga - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item()), k
 
 
 @pytest.mark.parametrize('down', [False, True])
