@@ -12,6 +12,8 @@
 // 8 reduction elements of its column -- the MFMA A (co) and B (k) fragments -- with no
 // ds_write / shuffle pass.
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -33,6 +35,11 @@ struct WgradHParams {
     int tiles_co, tiles_k, slices, rows_per_slice;
     unsigned dy_bytes, x_bytes;
     int pitch, gstep;       // pixel pitch of x (== Cin unless grouped); grouped: co tile t reads channels [t*gstep, +Cin)
+    // slices > 1: every workgroup stores its fp32 tile to slab[(slice * tiles + tile)] in register order (plain 16-byte
+    // stores: 3.8 - 4.9 TB/s against 1.1 - 1.3 TB/s for the same volume of fp32 atomics, tools/ubench/atomic_scope.hip)
+    // and wgrad_reduce_kernel adds the slices of a tile in slice order into dw -- a fixed order: the weight gradient is
+    // reproducible bit for bit.  slab == nullptr: atomics straight into dw (one slice, or no workspace).
+    float* slab;
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
     int seg_H[BRCNN_MAX_LEVELS], seg_W[BRCNN_MAX_LEVELS], seg_Ho[BRCNN_MAX_LEVELS], seg_Wo[BRCNN_MAX_LEVELS];
@@ -271,6 +278,22 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 1) void conv_wgrad_bf16
         cur ^= 1;
     }
 
+    if (p.slab) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4* dst = reinterpret_cast<f32x4*>(p.slab) + ((size_t)slice * tiles + b) * (size_t)(TILE * TILE / 4) + wave * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < WT; a++)
+#pragma unroll
+            for (int c = 0; c < WT; c++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    f32x4 v;
+                    v.x = acc[a][c][4 * g4 + 0]; v.y = acc[a][c][4 * g4 + 1];
+                    v.z = acc[a][c][4 * g4 + 2]; v.w = acc[a][c][4 * g4 + 3];
+                    dst[((a * WT + c) * 4 + g4) * (WG * WG * 64)] = v;
+                }
+        return;
+    }
     // D[row = co][col = k]:  col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int c = 0; c < WT; c++) {
@@ -284,6 +307,74 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 1) void conv_wgrad_bf16
                 if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.K + kk, acc[a][c][r]);
             }
     }
+}
+
+// second stage of the sliced weight gradient: workgroup (tile, v) adds register group v = (a, c, g4) of the tile's
+// slabs over `count` slices first, first + stride, ... in that order.  TO_DW: into dw -- the thread layout is the MFMA
+// accumulator's: thread (wave, lane) of the first stage owns rows co = (wm WT + a) 32 + 8 g4 + 4 (lane >> 5) + (0..3),
+// column k = (wn WT + c) 32 + (lane & 31).  !TO_DW (many slices: a first pass over groups of slices, blockIdx.y = group):
+// the sum replaces the group's first slab.
+template <int WT, int WG, bool TO_DW>
+__global__ __launch_bounds__(64 * WG * WG) void wgrad_reduce_kernel(float* __restrict__ slab, float* __restrict__ dw,
+                                                                   int tiles_k, int tiles, int slices, int stride, int group,
+                                                                   int Cout, int K) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int TILE = 32 * WT * WG;
+    const int tile = blockIdx.x / (WT * WT * 4), v = blockIdx.x % (WT * WT * 4);
+    const int tid = threadIdx.x;
+    const int first = blockIdx.y * group * stride;
+    int count = (slices - first + stride - 1) / stride;
+    if (count > group) count = group;
+    const size_t step = (size_t)tiles * (TILE * TILE / 4);
+    f32x4* src = reinterpret_cast<f32x4*>(slab) + (size_t)first * step + (size_t)tile * (TILE * TILE / 4) +
+                 (size_t)v * (WG * WG * 64) + tid;
+    f32x4 s = src[0];
+    int i = 1;
+    for (; i + 3 < count; i += 4) {          // four loads in flight, added in slice order
+        const f32x4 t0 = src[(size_t)i * stride * step], t1 = src[(size_t)(i + 1) * stride * step];
+        const f32x4 t2 = src[(size_t)(i + 2) * stride * step], t3 = src[(size_t)(i + 3) * stride * step];
+        s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+        s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+        s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+        s.x += t3.x; s.y += t3.y; s.z += t3.z; s.w += t3.w;
+    }
+    for (; i < count; i++) {
+        const f32x4 t = src[(size_t)i * stride * step];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if constexpr (!TO_DW) {
+        src[0] = s;
+    } else {
+        const int a = v / (WT * 4), c = (v / 4) % WT, g4 = v & 3;
+        const int wave = tid >> 6, lane = tid & 63;
+        const int wm = wave / WG, wn = wave % WG;
+        const int tk = tile % tiles_k, tco = tile / tiles_k;
+        const int kk = tk * TILE + (wn * WT + c) * 32 + (lane & 31);
+        const int co = tco * TILE + (wm * WT + a) * 32 + 8 * g4 + 4 * (lane >> 5);
+        if (kk >= K) return;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (co + j < Cout) dw[(size_t)(co + j) * K + kk] += sv[j];
+    }
+}
+
+// per-stream slab workspace of the sliced weight gradient (launches on one stream are serialised)
+struct WgradWs { hipStream_t stream; float* buf; };
+constexpr size_t WGRAD_WS_BYTES = (size_t)160 << 20;
+std::mutex g_wgrad_ws_mutex;
+std::vector<WgradWs> g_wgrad_ws;
+int g_wgrad_slabs = 1;       // tuning hook (brcnn_conv_set_tile_wgrad_bf16(10 / 11)): 0 atomics, 1 slabs + second stage
+
+float* wgrad_workspace(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_wgrad_ws_mutex);
+    for (auto& e : g_wgrad_ws)
+        if (e.stream == s) return e.buf;
+    if (g_wgrad_ws.size() >= 64) return nullptr;
+    WgradWs e = {s, nullptr};
+    if (hipMalloc((void**)&e.buf, WGRAD_WS_BYTES) != hipSuccess) return nullptr;
+    g_wgrad_ws.push_back(e);
+    return e.buf;
 }
 
 void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
@@ -321,8 +412,27 @@ int launch(WgradHParams& p, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
+    p.slab = nullptr;
+    if (g_wgrad_slabs && p.slices > 1 && (size_t)tiles * p.slices * T * T * sizeof(float) <= WGRAD_WS_BYTES)
+        p.slab = wgrad_workspace(s);
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WT, ET, WG>), dim3(tiles * p.slices), dim3(64 * WG * WG), lds, s, p);
     BRCNN_LAUNCH_CHECK();
+    if (p.slab) {
+        int stride = 1, count = p.slices;
+        if (p.slices > 24) {         // few output tiles, many slices: groups of ~sqrt(slices) first (more workgroups, shorter chains)
+            int group = 4;
+            while (group * group < p.slices) group++;
+            const int ngroups = (p.slices + group - 1) / group;
+            hipLaunchKernelGGL((wgrad_reduce_kernel<WT, WG, false>), dim3(tiles * WT * WT * 4, ngroups), dim3(64 * WG * WG), 0, s,
+                               p.slab, p.dw, p.tiles_k, tiles, p.slices, 1, group, p.Cout, p.K);
+            BRCNN_LAUNCH_CHECK();
+            stride = group;
+            count = ngroups;
+        }
+        hipLaunchKernelGGL((wgrad_reduce_kernel<WT, WG, true>), dim3(tiles * WT * WT * 4, 1), dim3(64 * WG * WG), 0, s,
+                           p.slab, p.dw, p.tiles_k, tiles, p.slices, stride, count, p.Cout, p.K);
+        BRCNN_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -367,8 +477,10 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
         // TFLOP/s), the first FC (384 -> 676).  Every workgroup ends with a full tile of fp32 atomics (their
         // volume is workgroups x tile area whatever the layer: 67 MB here, 33 MB for the 128 x 128 tile, at
         // 2-3 TB/s), which is what keeps the medium layers (M = 33 600) on the smaller tile.
-        const long long t256 = (long long)((cout + 255) / 256) * ((p.K + 255) / 256);
-        if (cout >= 256 && p.K >= 1024 && (p.M >= 100000 || t256 >= 128)) wt = 4;
+        // (with the slab reduction -- r03 -- the 256 x 256 tile's doubled reduction volume costs plain stores instead of
+        // atomics, and it wins on every layer with >= 256 output channels and K >= 2048: stage-3 3x3 68 -> 60 us,
+        // stage-4 3x3 89 -> 66 us, 3x3 on the 100x168 map 204 -> 159 us; profiles/r03_notes.md)
+        if (cout >= 256 && p.K >= 2048) wt = 4;
     }
     if (wt == 4) return f16 ? launch<2, 1, 4>(p, stream) : launch<2, 0, 4>(p, stream);
     if (f16) return wt == 2 ? launch<2, 1>(p, stream) : launch<1, 1>(p, stream);
@@ -376,6 +488,7 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
 }
 
 BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
+    if (wt == 10 || wt == 11) { g_wgrad_slabs = wt - 10; return 0; }      // reduction over the M slices: atomics / slabs
     if (wt < 0 || wt == 3 || wt > 4) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;

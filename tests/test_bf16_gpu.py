@@ -640,6 +640,42 @@ def test_bf16_eight_phase_kernel_is_bit_identical(cfg):
         L.brcnn_conv_set_tile_bf16(0)
 
 
+def test_bf16_wgrad_slab_reduction_is_reproducible_and_equals_the_atomics_form():
+    """the weight gradient's M slices reduced through per-workgroup slabs + a fixed-order second stage: two launches
+    give the same bits (the fp32-atomics form does not promise that), the values agree with the atomics form to the
+    order of the additions, accumulation into an existing dW is kept, for the three tile shapes and a five-level launch"""
+    import ctypes
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    LV = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    cases = [(2, LV, 256, 256, 3, 1, 1), (8, LV[1:2], 256, 256, 3, 1, 1), (8, LV[1:2], 1024, 256, 1, 1, 0), (3, LV[:1], 128, 128, 3, 2, 1)]
+    try:
+        for (N, lv, ci, co, k, st, pd) in cases:
+            outs = [ops.conv_out_size(H, W, k, k, st, pd) for H, W in lv]
+            M = sum(N * ho * wo for ho, wo in outs)
+            x = torch.randn(sum(N * H * W for H, W in lv), ci, generator=g).to(DEV, BF)
+            dy = torch.randn(M, co, generator=g).to(DEV, BF)
+            hs = (ctypes.c_int * len(lv))(*[h for h, _ in lv]); ws = (ctypes.c_int * len(lv))(*[w for _, w in lv])
+            base = torch.randn(co, k, k, ci, generator=g).to(DEV)
+            for tile in (1, 2, 4):
+                assert L.brcnn_conv_set_tile_wgrad_bf16(tile) == 0
+                res = {}
+                for mode in (11, 11, 10):
+                    assert L.brcnn_conv_set_tile_wgrad_bf16(mode) == 0
+                    dw = base.clone()
+                    assert L.brcnn_conv2d_wgrad_nhwc_multi(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, len(lv), hs, ws, ci, co, k, k,
+                                                           st, pd, 1, None) == 0
+                    torch.cuda.synchronize()
+                    res.setdefault(mode, []).append(dw)
+                assert torch.equal(res[11][0], res[11][1]), (tile, 'slab form not reproducible')
+                scale = (res[10][0] - base).abs().max().item()
+                assert (res[11][0] - res[10][0]).abs().max().item() <= 2e-5 * scale, tile
+    finally:
+        L.brcnn_conv_set_tile_wgrad_bf16(0)
+        L.brcnn_conv_set_tile_wgrad_bf16(11)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_bf16_eight_phase_kernel_training_epilogues(dtype):
     """the dual-store forward (MODE 1) and the data gradient + BatchNorm backward (MODE 2, incl. the zero-stuffed

@@ -6,7 +6,8 @@ import brcnn
 from brcnn import ops, lib
 L = lib.load()
 BF = len(sys.argv) > 1 and sys.argv[1] == 'bf16'
-tiles = [int(v) for v in sys.argv[2:]] or [0]
+# bf16 tile ids; suffix 'a': reduce the M slices with fp32 atomics instead of slabs + second stage
+tiles = sys.argv[2:] or ['0']
 LV = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
 shapes = [('tower 3x3 256->256 x5', 8, LV, 256, 256, 3, 1, 1), ('rpn_l0 3x3 256->256', 8, LV[:1], 256, 256, 3, 1, 1),
           ('s3 3x3 256->256', 8, LV[1:2], 256, 256, 3, 1, 1), ('s2 1x1 128->512', 8, LV[:1], 128, 512, 1, 1, 0),
@@ -36,8 +37,11 @@ for name, N, lv, Ci, Co, k, st, pd in shapes:
     fl = 2.0 * M * Co * k * k * Ci
     ref = None
     line = f'{name:24s} M={M:7d}'
-    for t in tiles:
-        if BF: L.brcnn_conv_set_tile_wgrad_bf16(t)
+    for ts in tiles:
+        t = int(ts.rstrip('a'))
+        if BF:
+            L.brcnn_conv_set_tile_wgrad_bf16(t)
+            L.brcnn_conv_set_tile_wgrad_bf16(10 if ts.endswith('a') else 11)
         dw = torch.zeros(Co, k, k, Ci, device='cuda')
         call = lambda: L.brcnn_conv2d_wgrad_nhwc_multi(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, len(lv), hs, ws, Ci, Co, k, k,
                                                        st, pd, 1 if BF else 0, None)
@@ -47,5 +51,5 @@ for name, N, lv, Ci, Co, k, st, pd in shapes:
         if ref is None: ref = got
         err = float((got - ref).abs().max() / ref.abs().max())
         ms = bench(call)
-        line += f' | t{t}: {ms * 1000:7.1f} us {fl / ms / 1e9:6.1f} TF err {err:.1e}'
+        line += f' | t{ts}: {ms * 1000:7.1f} us {fl / ms / 1e9:6.1f} TF err {err:.1e}'
     print(line)
