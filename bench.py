@@ -156,6 +156,8 @@ def train_bench(args, world, rank, device):
 
     steps = args.train_steps or args.steps
     dt = timed(step, steps, args.warmup, world, device)
+    from brcnn import profiling
+    roof = profiling.train_conv_roofline(step, dtype=args.train_dtype) if rank == 0 else None
     return {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN train step',
         'value': world * args.batch * steps / dt, 'unit': 'images/sec', 'ms_per_step': 1000.0 * dt / steps,
@@ -165,6 +167,7 @@ def train_bench(args, world, rank, device):
                                'device-resident targets / losses' + (', DDP over RCCL' if world > 1 else ''),
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         'loss': float(last['log_vars']['loss']),
+        'roofline': roof,
     }
 
 

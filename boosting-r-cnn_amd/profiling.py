@@ -100,3 +100,115 @@ def per_layer_table(model, img, metas):
     torch.cuda.synchronize()
     return [(r[4], r[0].elapsed_time(r[1]), r[2] / (r[0].elapsed_time(r[1]) * 1e-3) / 1e12,
              r[3] / (r[0].elapsed_time(r[1]) * 1e-3) / 1e9) for r in recs]
+
+
+# ---------------------------------------------------------------------------- train step: conv launches
+def _out_rows(batch, hs, ws, nl, kh, kw, stride, pad):
+    return sum(batch * ((hs[i] + 2 * pad - kh) // stride + 1) * ((ws[i] + 2 * pad - kw) // stride + 1) for i in range(nl))
+
+
+# C-ABI entry -> (kind, shape function of its argument tuple -> (M, N, K) of the implicit GEMM)
+_TRAIN_ENTRIES = {
+    # (x,w,gamma,beta,mean,var,eps,res,z,y,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,relu,dt,stream)
+    'brcnn_conv2d_bn_act_nhwc_multi': ('forward', lambda a: (_out_rows(a[10], a[12], a[13], a[11], a[16], a[17], a[18], a[19]),
+                                                           a[15], a[16] * a[17] * a[14])),
+    # (dy,w_t,z,g,b,m,v,eps,relu,dskip,prev_out,dres,dz,dg,db,ws,nb,batch,ih,iw,oh,ow,cin,cout,kh,kw,...)
+    'brcnn_conv2d_dgrad_bn_backward_nhwc': ('dgrad', lambda a: (a[17] * a[18] * a[19], a[22], a[24] * a[25] * a[23])),
+    # (x,w,scale,shift,res,y,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,relu,dt,stream)
+    'brcnn_conv2d_nhwc_multi': ('forward', lambda a: (_out_rows(a[6], a[8], a[9], a[7], a[12], a[13], a[14], a[15]), a[11],
+                                                    a[12] * a[13] * a[10])),
+    # (x,w,scale,shift,res,y,n,h,w,cin,cout,kh,kw,stride,pad,relu,dt,stream)
+    'brcnn_conv2d_nhwc': ('forward', lambda a: (a[6] * ((a[7] + 2 * a[14] - a[11]) // a[13] + 1) * ((a[8] + 2 * a[14] - a[12]) // a[13] + 1),
+                                              a[10], a[11] * a[12] * a[9])),
+    # (dy,wt,dx,batch,L,hs,ws,ohs,ows,cin,cout,kh,kw,stride,pad,dt,stream): output rows = input pixels
+    'brcnn_conv2d_dgrad_nhwc_multi': ('dgrad', lambda a: (sum(a[3] * a[5][i] * a[6][i] for i in range(a[4])), a[9],
+                                                        a[11] * a[12] * a[10])),
+    # (x,dy,dw,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,dt,stream)
+    'brcnn_conv2d_wgrad_nhwc_multi': ('wgrad', lambda a: (_out_rows(a[3], a[5], a[6], a[4], a[9], a[10], a[11], a[12]), a[8],
+                                                        a[9] * a[10] * a[7])),
+}
+
+
+@contextlib.contextmanager
+def record_train_conv_launches(records):
+    """every conv / FC launch of the train step (forward incl. the fused conv+BN form, data gradient incl. the fused
+    BatchNorm backward, weight gradient) bracketed by HIP events on the stream it is launched on; the weight-gradient
+    side stream is switched off meanwhile so that one stream carries, and one event pair times, each launch.
+    `records` receives (entry, kind, (M, N, K), start event, end event).  (`brcnn_conv2d_nhwc` calls reach the device
+    through `brcnn_conv2d_nhwc_multi` inside the library, not through this table: no double counting.)"""
+    from . import autograd as _A
+    from . import lib as _L
+    lib = _L.load()
+    saved_side = _A.WGRAD_SIDE_STREAM
+    _A.WGRAD_SIDE_STREAM = False
+    originals = {}
+
+    def wrap(name, kind, shape_fn):
+        orig = getattr(lib, name)
+        originals[name] = orig
+
+        def f(*a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a)
+            e.record()
+            records.append((name, kind, shape_fn(a), s, e))
+            return r
+        setattr(lib, name, f)
+    for name, (kind, fn) in _TRAIN_ENTRIES.items():
+        wrap(name, kind, fn)
+    try:
+        yield
+    finally:
+        for name, orig in originals.items():
+            setattr(lib, name, orig)
+        _A.WGRAD_SIDE_STREAM = saved_side
+
+
+def train_conv_roofline(step, dtype='bf16', iters=2):
+    """the `roofline` object of the train half of the bench line: algorithmic FLOPs (2 M N K per launch: forward, data
+    gradient, weight gradient of every trainable conv / FC; the frozen stem and stage 1 run forward only and have no
+    gradient launches) over the HIP-event time of those launches in one step, against the dense MFMA peak of the
+    compute dtype"""
+    best = None
+    for _ in range(iters):
+        recs = []
+        with record_train_conv_launches(recs):
+            step()
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for *_, s, e in recs)
+        if best is None or ms < best[0]:
+            best = (ms, recs)
+    ms, recs = best
+    by_kind = {}
+    for _, kind, (m, n, k), s, e in recs:
+        a = by_kind.setdefault(kind, [0.0, 0.0, 0])
+        a[0] += 2.0 * m * n * k
+        a[1] += s.elapsed_time(e)
+        a[2] += 1
+    flops = sum(a[0] for a in by_kind.values())
+    achieved = flops / (ms * 1e-3) / 1e12
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    traffic, src = None, None
+    try:
+        import json
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        cands = sorted(f for f in os.listdir(os.path.join(root, 'profiles')) if f.endswith(f'_conv_traffic_train_{dtype}.json'))
+        t = json.load(open(os.path.join(root, 'profiles', cands[-1])))
+        traffic = t['hbm_bytes_per_launch']
+        src = f'STORED value: profiles/{cands[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same train step; not re-measured in this run)'
+    except Exception:
+        pass
+    return {
+        'bound': 'mfma', 'kernel': f'conv_pp_bf16 / conv_igemm_bf16_dma / conv_wgrad_bf16 (every conv / FC launch of one train step, {dtype})'
+        if dtype != 'f32' else 'conv_igemm_f32* / conv_wgrad_f32 (every conv / FC launch of one train step)',
+        'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
+        'launches': len(recs), 'avg_launch_us': 1000.0 * ms / max(len(recs), 1),
+        'algorithmic_tflop_per_step': flops / 1e12, 'kernel_ms_per_step': ms,
+        'by_kind': {k: {'tflop': a[0] / 1e12, 'ms': a[1], 'launches': a[2], 'tflops': a[0] / (a[1] * 1e-3) / 1e12 if a[1] else 0.0}
+                    for k, a in by_kind.items()},
+        'note': 'timed with the weight-gradient side stream off (one stream, one HIP-event pair per launch); '
+                'ms_per_step of the bench is measured with it on',
+    }

@@ -16,7 +16,7 @@ pairs = [('bench_f16.json', 'bench_f16.json'), ('bench_bf16_trainf32.json', 'ben
          ('stats_train_bf16/step_kernel_stats.csv', 'train_bf16_kernel_stats.csv'),
          ('conv_tiles.txt', 'conv_tiles.txt'), ('conv_tiles_bf16.txt', 'conv_tiles_bf16.txt'),
          ('layers.txt', 'conv_layers.txt'), ('layers_bf16.txt', 'conv_layers_bf16.txt'),
-         ('op_bench.json', 'op_bench.json'), ('recipes.json', 'recipes.json'), ('recipes_bf16.json', 'recipes_bf16.json'), ('pytest_gpu.txt', 'pytest_gpu.txt')]
+         ('op_bench.json', 'op_bench.json'), ('conv_pmc_layers_bf16.txt', 'conv_pmc_layers_bf16.txt'), ('recipes.json', 'recipes.json'), ('recipes_bf16.json', 'recipes_bf16.json'), ('pytest_gpu.txt', 'pytest_gpu.txt')]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p):
@@ -25,5 +25,7 @@ for a, b in pairs:
     else:
         print('MISSING', a)
 subprocess.check_call([sys.executable, 'tools/summarize_pmc.py', r])
+if os.path.isdir(os.path.join(src, 'pmc_train_fetch')):
+    subprocess.check_call([sys.executable, 'tools/summarize_train_pmc.py', r, 'bf16'])
 if os.path.isdir(os.path.join(src, 'op_pmc_fetch')):
     subprocess.check_call([sys.executable, 'tools/summarize_op_pmc.py', r])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh r02'): tests, bench, rocprof kernel stats of the same
 # bench commands, PMC passes (separate runs, --kernel-trace only: no tracing domains mixed in).
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -20,6 +20,12 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o step -- pyth
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o step -- python3 tools/prof_step.py > /dev/null 2> $O/pmc_write.err
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -f csv -d $O/pmc_sq -o step -- python3 tools/prof_step.py > /dev/null 2> $O/pmc_sq.err
 BRCNN_DTYPE=bf16 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -f csv -d $O/pmc_sq_bf16 -o step -- python3 tools/prof_step.py > /dev/null 2> $O/pmc_sq_bf16.err
+# bf16 train step: HBM traffic and MFMA utilisation of the conv / weight-gradient kernels
+BRCNN_DTYPE=bf16 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_train_fetch -o step -- python3 tools/prof_train.py > /dev/null 2> $O/pmc_train_fetch.err
+BRCNN_DTYPE=bf16 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_train_write -o step -- python3 tools/prof_train.py > /dev/null 2> $O/pmc_train_write.err
+BRCNN_DTYPE=bf16 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -f csv -d $O/pmc_train_sq -o step -- python3 tools/prof_train.py > /dev/null 2> $O/pmc_train_sq.err
+# per-layer PMC of the 3x3 layers of stages 2 / 3 / 4 and the tower (heuristic tile)
+( CONV_SHAPE=8,100,168,128,128,3 bash tools/pmc_conv_one.sh $R/pmc_l_s2 0; CONV_SHAPE=8,50,84,256,256,3 bash tools/pmc_conv_one.sh $R/pmc_l_s3 0; CONV_SHAPE=8,25,42,512,512,3 bash tools/pmc_conv_one.sh $R/pmc_l_s4 0; CONV_SHAPE=8,140,160,256,256,3 bash tools/pmc_conv_one.sh $R/pmc_l_tower 0 ) > $O/conv_pmc_layers_bf16.txt 2>&1
 python tools/op_bench.py > $O/op_bench.json 2> $O/op_bench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/op_pmc_fetch -o step -- python3 tools/op_bench.py > /dev/null 2> $O/op_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/op_pmc_write -o step -- python3 tools/op_bench.py > /dev/null 2> $O/op_pmc_write.err
