@@ -9,7 +9,7 @@
 * `train`: the other half of the metric ("inference+train"), timed in the same run: the full train step
   of boosting_rcnn_r50_pafpn_1x_coco.py (BASELINE configs[2]/[3]: bf16 MFMA conv stack, fp32 master
   weights; forward_train with device-resident targets and losses, backward through the HIP dgrad /
-  wgrad kernels, gradient all-reduce by DistributedDataParallel over RCCL when N > 1, grad-clip, SGD);
+  wgrad kernels, in-place all-reduce of the gradient arena over RCCL when N > 1 (brcnn/distributed.py), grad-clip, SGD);
 * `roofline` (dominant kernel: the MFMA implicit-GEMM conv, HIP-event timed) and `cpu_baseline` (the
   oracle pipeline on the host cores, rank 0 at N=1 only).
 
@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument('--mode', choices=['both', 'inference', 'train'], default='both',
                     help="'both' (default): inference headline + the train step in the same JSON line")
     ap.add_argument('--train-steps', type=int, default=None, help='timed train steps (default: --steps)')
+    ap.add_argument('--force-reducer', action='store_true',
+                    help='N = 1 only: initialise a world-size-1 RCCL group and run the train step through the gradient '
+                         'reducer of the N > 1 path (its overhead against the plain step)')
     return ap.parse_args()
 
 
@@ -136,10 +139,16 @@ def train_bench(args, world, rank, device):
     opt = FusedSGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
                    weight_decay=cfg.optimizer.weight_decay)
     opt.register_conv_weights(model, blocks.compute_dtype())
-    net = model
-    if world > 1:
+    net, reducer = model, None
+    if world > 1 and os.environ.get('BRCNN_DDP', 'own') == 'torch':     # the reference's wrapper (apis/train.py:75-83)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], broadcast_buffers=False,
                                                         bucket_cap_mb=64, gradient_as_bucket_view=True)
+    elif world > 1 or args.force_reducer:
+        # in-place all-reduce of the weight-gradient arena, slice by slice behind the backward pass; no accumulator
+        # hooks, so the second-stream weight gradients and "dW is weight.grad" stay on (brcnn/distributed.py)
+        from brcnn.distributed import GradReducer
+        reducer = GradReducer(params, slice_mb=64)
+        reducer.broadcast_parameters(model)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
     gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)
     # fp16: the recipes' static loss scaling (fp16 = dict(loss_scale=512.), mmcv Fp16OptimizerHook)
@@ -151,6 +160,8 @@ def train_bench(args, world, rank, device):
         losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
         loss, log_vars = model._parse_losses(losses)
         (loss * scale if scale != 1.0 else loss).backward()
+        if reducer is not None:
+            reducer.reduce()
         opt.step(max_norm=35, loss_scale=scale)        # clip + unscale + skip-on-inf + SGD + next step's conv operands
         last['log_vars'] = log_vars
 
@@ -164,7 +175,9 @@ def train_bench(args, world, rank, device):
         'steps': steps, 'warmup': args.warmup, 'dtype': args.train_dtype, 'n_gpus': world,
         'config': {'workload': f'boosting_rcnn_r50_pafpn_1x_coco.py full train step, batch {args.batch} x 3x800x1344 '
                                f'per GPU, 20 GT/img, 512 RoIs/img, SGD+clip, {args.train_dtype} conv stack, '
-                               'device-resident targets / losses' + (', DDP over RCCL' if world > 1 else ''),
+                               'device-resident targets / losses' +
+                               (', gradient arena all-reduced in place over RCCL' if reducer is not None else
+                                ', DDP over RCCL' if world > 1 else ''),
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         'loss': float(last['log_vars']['loss']),
         'roofline': roof,
@@ -218,8 +231,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     line, cfg = None, None
@@ -238,7 +256,7 @@ def main():
             from oracle import cpu_pipeline
             line['cpu_baseline'] = cpu_pipeline.timed_baseline(cfg, seed=0)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         dist.barrier()
         dist.destroy_process_group()
 

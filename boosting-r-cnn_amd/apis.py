@@ -224,6 +224,7 @@ class EpochBasedRunner:
         self.log_interval = 50
         self.eval_fn, self.eval_interval = None, 1
         self.loss_scaler, self.loss_scale = None, None      # fp16 recipes: static loss scaling (train_detector)
+        self.reducer = None                                  # distributed.GradReducer (data parallel without DDP)
         self.log_buffer = OrderedDict()
         self.history = []          # (epoch, iter, lr, {name: value}) rows the text logger printed
         self.eval_history = []
@@ -309,6 +310,8 @@ class EpochBasedRunner:
                 # clip + (unscale) + SGD + next step's conv operands in one call; the norm stays on the device
                 scale = self.loss_scale or 1.0
                 (outputs['loss'] * scale if scale != 1.0 else outputs['loss']).backward()
+                if self.reducer is not None:
+                    self.reducer.reduce()
                 ctl = self.optimizer.step(max_norm=self.grad_clip['max_norm'] if self.grad_clip else None, loss_scale=scale,
                                           skip_nonfinite=self.loss_scale is not None)
                 if self.grad_clip is not None and ctl is not None:
@@ -318,6 +321,8 @@ class EpochBasedRunner:
                 # unscale, clip, a step that is skipped on inf / nan gradients, and -- static mode -- the
                 # scale reset to `loss_scale` every iteration
                 self.loss_scaler.scale(outputs['loss']).backward()
+                if self.reducer is not None:
+                    self.reducer.reduce()
                 self.loss_scaler.unscale_(self.optimizer)
                 if self.grad_clip is not None:
                     gn = self._clip()
@@ -327,6 +332,8 @@ class EpochBasedRunner:
                 self.loss_scaler.update(self.loss_scale)
             else:
                 outputs['loss'].backward()
+                if self.reducer is not None:
+                    self.reducer.reduce()
                 if self.grad_clip is not None:
                     gn = self._clip()
                     if gn is not None:
@@ -422,16 +429,23 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     if device.type == 'cuda':
         from .blocks import conv_weights_channels_last
         conv_weights_channels_last(model)       # before DDP takes the parameters' strides for its bucket views
-    if distributed:
-        from torch.nn.parallel import DistributedDataParallel
+    reducer = None
+    if distributed and (cfg.get('ddp', 'own') == 'torch' or device.type != 'cuda'):
+        from torch.nn.parallel import DistributedDataParallel       # the reference's wrapper (apis/train.py:75-83)
         model = DistributedDataParallel(
             model, device_ids=[device.index] if device.type == 'cuda' else None, broadcast_buffers=False,
             find_unused_parameters=cfg.get('find_unused_parameters', False))
+    elif distributed:
+        # default on the HIP device: the weight-gradient arena all-reduced in place (distributed.GradReducer)
+        from .distributed import GradReducer
+        reducer = GradReducer([p for p in model.parameters() if p.requires_grad])
+        reducer.broadcast_parameters(model)
     optimizer = build_optimizer(model, cfg.optimizer)
     runner_cfg = cfg.get('runner', None) or dict(type='EpochBasedRunner', max_epochs=cfg.total_epochs)
     assert runner_cfg['type'] == 'EpochBasedRunner'
     runner = EpochBasedRunner(model, optimizer, cfg.work_dir, logger, runner_cfg['max_epochs'], meta)
     runner.timestamp = timestamp
+    runner.reducer = reducer
     if cfg.get('fp16', None) is not None:
         # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->
         # mmdet/apis/train.py:115-119, mmcv Fp16OptimizerHook): fp16 MFMA conv stack (fp32 accumulation, fp32

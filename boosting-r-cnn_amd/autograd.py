@@ -35,6 +35,8 @@ class _GradArena:
 
     def __init__(self):
         self.buf, self.off, self.used, self.hint = None, 0, 0, 0
+        self.listener = None        # distributed.GradReducer: all-reduces the arena in place, slice by slice
+        self._chunks = []           # [(chunk, elements handed out)] of the running step (listener only)
 
     def take(self, shape, device):
         if _ARENA_OFF:
@@ -46,13 +48,30 @@ class _GradArena:
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.buf = torch.zeros(max(n_al, self.hint - self.used, self.MIN_CHUNK), dtype=torch.float32, device=device)
             self.off = 0
+            if self.listener is not None:
+                self._chunks.append([self.buf, 0])
+                self.listener.chunk_opened(self.buf)
         v = self.buf[self.off:self.off + n].view(shape)
         self.off += n_al
         self.used += n_al
+        if self.listener is not None:
+            self._chunks[-1][1] = self.off
         return v
+
+    def launched(self, stream):
+        """the kernel that writes the view handed out last has been issued on `stream`"""
+        if self.listener is not None and self.buf is not None:
+            self.listener.writers_launched(self.buf, self.off, stream)
+
+    def used_of(self, buf):
+        for b, n in self._chunks:
+            if b is buf:
+                return n
+        return 0
 
     def new_step(self):
         self.hint, self.used, self.buf = max(self.hint, self.used), 0, None
+        self._chunks = []
 
 
 grad_arena = _GradArena()
@@ -207,6 +226,8 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
             x_cat.record_stream(side)
             _queue_stream_join(main, side)
         _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
+        if grad_arena.listener is not None and dy.is_cuda:
+            grad_arena.launched(side if side is not None else torch.cuda.current_stream(dy.device))
         # (Cout,KH,KW,Cin) -> the parameter's (Cout,Cin,KH,KW): for 1x1 filters the two coincide in
         # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)
         dw = dwp.view(cout, cin, 1, 1) if kh == 1 and kw == 1 else dwp.permute(0, 3, 1, 2)

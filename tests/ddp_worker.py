@@ -27,26 +27,43 @@ def main():
     img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10 + rank)
     data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in gts], gt_labels=[l.to(dev) for l in gls])
     grads = {}
-    for mode in ('plain', 'ddp'):
+    from brcnn import autograd as A
+    from brcnn.distributed import GradReducer
+    for mode in ('plain', 'ddp', 'own'):
         m = build_detector(cfg.model)
         m.load_state_dict(util.seeded_state_dict(m, seed=10))
         m = m.to(dev).train()
         m.set_compute_dtype(dtype)
-        net = m
+        net, red = m, None
         if mode == 'ddp':
             net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[local], broadcast_buffers=False)
-        torch.manual_seed(77)
-        losses = net(return_loss=True, **data)
-        loss, log_vars = m._parse_losses(losses)
-        loss.backward()
+        if mode == 'own':       # the N > 1 path of bench.py / train_detector: arena all-reduced in place, no hooks
+            red = GradReducer([p for p in m.parameters() if p.requires_grad], slice_mb=8)
+            red.broadcast_parameters(m)
+        for rep in range(2 if mode == 'own' else 1):     # twice: the second pass runs on a fresh arena chunk
+            m.zero_grad(set_to_none=True)
+            A.grad_arena.new_step()
+            torch.manual_seed(77)
+            losses = net(return_loss=True, **data)
+            loss, log_vars = m._parse_losses(losses)
+            loss.backward()
+            if red is not None:
+                assert A._wgrad_side_stream(dev) is not None or not A.WGRAD_SIDE_STREAM     # the second stream stays on
+                red.reduce()
+        torch.cuda.synchronize()
         grads[mode] = ({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, dict(log_vars))
-    assert grads['plain'][0].keys() == grads['ddp'][0].keys()
+        if red is not None:
+            red.close()
+    assert grads['plain'][0].keys() == grads['ddp'][0].keys() == grads['own'][0].keys()
     if world == 1:          # one rank: the wrapper must not change a single value
         for k, g in grads['plain'][0].items():      # (weight gradients accumulate with fp32 atomics: order varies)
             tol = (1e-4 if dtype == 'f32' else 2e-2) * (g.abs().max().item() + 1e-12)
             assert (g - grads['ddp'][0][k]).abs().max().item() <= tol, (k, (g - grads['ddp'][0][k]).abs().max().item(), tol)
         for k, v in grads['plain'][1].items():
             assert abs(v - grads['ddp'][1][k]) <= (1e-5 if dtype == 'f32' else 1e-3) * max(1.0, abs(v)), k
+        for k, g in grads['plain'][0].items():
+            tol = (1e-4 if dtype == 'f32' else 2e-2) * (g.abs().max().item() + 1e-12)
+            assert (g - grads['own'][0][k]).abs().max().item() <= tol, ('own', k, (g - grads['own'][0][k]).abs().max().item(), tol)
     # every rank ends with identical (averaged) gradients
     for k, g in sorted(grads['ddp'][0].items())[:8]:
         t = g.clone()

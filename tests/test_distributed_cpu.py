@@ -128,3 +128,61 @@ def test_two_rank_ddp_train_and_test_drivers(tmp_path):
     mp.spawn(_train_worker, args=(world, port, str(tmp_path), ret), nprocs=world, join=True)
     assert len(ret) == 2 and ret[0][0] == ret[1][0] >= 1
     assert ret[0][1] == pytest.approx(ret[1][1], rel=1e-5)        # the logged loss is the all-reduced mean
+
+
+def _reducer_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn import autograd as A
+        from brcnn.distributed import GradReducer
+        torch.manual_seed(5)                      # the same "model" on every rank
+        shapes = [(64, 3, 3, 32), (128, 1, 1, 64), (300,), (17,), (256, 3, 3, 256), (1,), (40, 1, 1, 8)]
+        params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        red = GradReducer(params, slice_mb=0.25)            # 65 536-element slices: the arena spans several
+        # rank-dependent start values so that a missing broadcast shows
+        with torch.no_grad():
+            for p in params:
+                p.add_(float(rank))
+        mod = torch.nn.ParameterList(params)
+        red.broadcast_parameters(mod)
+        for p in params:
+            t = p.detach().clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert torch.equal(t, p.detach())
+        for step in range(3):
+            g = torch.Generator().manual_seed(1000 * step + rank)
+            local = [torch.randn(*s, generator=g) for s in shapes]
+            for p, gl in zip(params, local):
+                if p.dim() == 4:                  # conv weights: the weight-gradient kernel's result IS .grad (arena view)
+                    v = A.grad_arena.take(p.shape, p.device)
+                    v.copy_(gl)
+                    A.grad_arena.launched(None)
+                    p.grad = v
+                else:                             # BatchNorm / bias / Scale gradients: ordinary tensors
+                    p.grad = gl.clone()
+            red.reduce()
+            for i, p in enumerate(params):
+                allg = [torch.zeros_like(local[i]) for _ in range(world)]
+                dist.all_gather(allg, local[i])
+                want = sum(allg) / world
+                assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), (step, i)
+            A.grad_arena.new_step()               # what optim.FusedSGD.step does
+        red.close()
+        assert A.grad_arena.listener is None and not A._OWN_REDUCER[0]
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_grad_reducer_averages_arena_and_small_gradients():
+    """distributed.GradReducer on two gloo ranks: the weight-gradient arena is all-reduced in place (several slices
+    per chunk, a fresh chunk per step), the gradients outside it as one flattened bucket, parameters are broadcast
+    from rank 0 -- every gradient ends as the mean over the ranks, on every step"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reducer_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == 2
