@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP streams share the hardware queues round-robin (4 by default): with RCCL's own streams next to the main stream,
+# the weight-gradient stream and the reducer's communication stream, two of them would land on one queue and
+# serialise.  Read by the HIP runtime when it initialises, i.e. before the first device call below.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
 def parse_args():
@@ -147,7 +151,8 @@ def train_bench(args, world, rank, device):
         # in-place all-reduce of the weight-gradient arena, slice by slice behind the backward pass; no accumulator
         # hooks, so the second-stream weight gradients and "dW is weight.grad" stay on (brcnn/distributed.py)
         from brcnn.distributed import GradReducer
-        reducer = GradReducer(params, slice_mb=64)
+        reducer = GradReducer(params, slice_mb=float(os.environ.get('BRCNN_REDUCER_SLICE_MB', '64')),
+                              overlap=os.environ.get('BRCNN_REDUCER_OVERLAP', '1') != '0')
         reducer.broadcast_parameters(model)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
     gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)

@@ -6,6 +6,12 @@ The directory name `boosting-r-cnn_amd` is not a Python identifier; import it as
 """
 __version__ = '0.1.0'
 
+import os as _os
+# more hardware queues than HIP's default four, so that the weight-gradient stream, the gradient reducer's
+# communication stream and RCCL's own streams do not share one with the main stream (effective when this package is
+# imported before the first device call; bench.py and the tools set it themselves)
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from .registry import Registry, build_from_cfg  # noqa: F401
 from .config import Config, ConfigDict  # noqa: F401
 

@@ -7,6 +7,7 @@
 import argparse
 import copy
 import os
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # before the HIP runtime starts (see brcnn/__init__.py)
 import os.path as osp
 import sys
 import time
