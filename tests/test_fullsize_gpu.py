@@ -146,6 +146,81 @@ def test_fullsize_proposal_indices_and_keep_masks_golden():
         assert torch.allclose(det[b, :k, 4].cpu(), rd[:, 4], rtol=0, atol=1e-6)
 
 
+def test_coco_pafpn_train_step_at_full_size():
+    """BASELINE configs[2] at its real size (batch 8 x 3 x 800 x 1344, 20 GT / image, 80 classes, bf16 conv stack):
+    the device-resident train step yields finite losses, exactly one finite gradient per trainable parameter (none for
+    the frozen stem / stage 1), and the same losses as the per-image reference chain (MaxIoUAssigner / sampler /
+    loss modules called image by image, level by level) on the same weights, inputs and sampler seed"""
+    import bench
+    try:
+        m = _coco_model('bf16')
+        dev = torch.device(DEV)
+        img, metas = bench.synthetic_batch(8, dev, seed=3)
+        gtb, gtl = bench.synthetic_gt(8, dev, 80, seed=3)
+        vals = {}
+        for mode in (True, False):
+            m.device_train_path = mode
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            losses = m.forward_train(img, metas, gtb, gtl)
+            loss, log_vars = m._parse_losses(losses)
+            vals[mode] = {k: float(v) for k, v in log_vars.items()}
+            if mode:
+                loss.backward()
+                torch.cuda.synchronize()
+                assert all(np.isfinite(v) for v in vals[True].values()), vals[True]
+                frozen = {id(p) for p in list(m.backbone.conv1.parameters()) + list(m.backbone.bn1.parameters()) +
+                          list(m.backbone.layer1.parameters())}
+                for name, p in m.named_parameters():
+                    if p.requires_grad and id(p) not in frozen:
+                        assert p.grad is not None and p.grad.shape == p.shape, name
+                        assert bool(torch.isfinite(p.grad).all()), name
+                        assert float(p.grad.abs().max()) > 0 or 'scales' in name, name
+                    else:
+                        assert p.grad is None, name
+        assert vals[True].keys() == vals[False].keys()
+        for k in vals[True]:
+            assert np.isclose(vals[True][k], vals[False][k], rtol=2e-3, atol=1e-5), (k, vals[True][k], vals[False][k])
+    finally:
+        blocks.set_compute_dtype('f32')
+
+
+def test_fullsize_second_stage_soft_nms_golden():
+    """BASELINE configs[4]'s soft-NMS stress at FULL size against the reference's own `multiclass_nms` (golden g21):
+    8 images x 2000 proposals x 80 classes, score_thr 1e-4, soft_nms (linear, iou 0.7, min_score 0), 200 per image.
+    Candidate scores / boxes are formed on the host with the reference's arithmetic (score fusion, delta2bbox --
+    pinned by g2 / g8); the device runs the whole-batch segmented soft-NMS, the collection and the per-image re-sort
+    (`batched_nms_images_by_level(soft=...)`, the path `ProbRoIHead.simple_test_padded` takes).  Pick order, labels
+    and decayed scores: bit for bit."""
+    from brcnn.core import delta2bbox
+    from brcnn.postprocess import batched_nms_images_by_level
+    g = load('g21_fullsize_softnms')
+    B, K, C = 8, 2000, 80
+    bbs, scs = [], []
+    for b in range(B):
+        boxes, prior, cs, bp = util.fullsize_softnms_inputs(b)
+        fused = (cs.softmax(1) * prior[:, None]) ** 0.5
+        dec = delta2bbox(boxes, bp, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2), max_shape=(800, 1333, 3))
+        dec = (dec.view(K, C, 4) / torch.ones(4)).view(K, C, 4)
+        bbs.append(dec)
+        scs.append(fused[:, :C])
+    bb = torch.stack(bbs).to(DEV)                 # (B, K, C, 4)
+    sc = torch.stack(scs).to(DEV)                 # (B, K, C)
+    valid = sc > 1e-4
+    labels = torch.arange(C, device=DEV).view(1, 1, C).expand(B, K, C)
+    cm = lambda t: t.transpose(1, 2).reshape(B, C * K, *t.shape[3:]).contiguous()   # noqa: E731  class-major slots
+    soft = dict(iou_threshold=0.7, min_score=0.0)
+    det, lab, nd = batched_nms_images_by_level(cm(bb), cm(sc), cm(labels), cm(valid), [K] * C, 0.7, 200, 0,
+                                               return_ids=True, soft=soft)
+    det, lab, nd = det.cpu(), lab.cpu(), nd.cpu()
+    for b in range(B):
+        rd, rl = T(g[f'det{b}']), T(g[f'lab{b}']).long()
+        assert int(nd[b]) == rd.shape[0] == 200
+        assert torch.equal(lab[b, :200].long(), rl), f'pick order / labels, image {b}'
+        assert torch.equal(det[b, :200, 4], rd[:, 4]), f'decayed scores, image {b}'
+        assert torch.equal(det[b, :200, :4], rd[:, :4]), f'boxes, image {b}'
+
+
 def _coco_model(dtype):
     cfg = Config.fromfile(COCO_CFG)
     m = build_detector(cfg.model)
@@ -235,6 +310,42 @@ def test_bf16_reference_signature_paths():
                 hit += int((d < 2e-2).any(1).sum())
     assert tot > 0 and hit >= 0.9 * tot, (hit, tot)
     assert sum(len(r) for b in agn for r in b) <= n_res
+
+
+def test_r101_softnms_f16():
+    """BASELINE configs[4] in the dtype it names (fp16; boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 `fp16 =
+    dict(loss_scale=512.)` on the R101 / 2000 proposals / soft-NMS recipe): the fp16 device run against the CPU oracle
+    pipeline (fp32: PyTorch-CPU convs + C oracle RoIAlign / soft-NMS) on the same seeded weights.  fp16 keeps 11
+    significand bits through ~100 layers: the strongest detections reappear within 2 px / 0.03 score."""
+    from oracle import cpu_pipeline
+    path = CFG.replace('boosting_rcnn_r50_pafpn_1x_utdac.py', 'boosting_rcnn_r101_pafpn_softnms_coco.py')
+    cfg = Config.fromfile(path)
+    img, metas, _, _ = util.demo_inputs(2, 128, 192, num_classes=80, seed=4)
+    with cpu_pipeline.patched():
+        m = build_detector(cfg.model)
+        sd = util.seeded_state_dict(m, seed=4)
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            ref = m(return_loss=False, rescale=True, img=[img], img_metas=[[dict(x) for x in metas]])
+    try:
+        m = build_detector(cfg.model)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        m.set_compute_dtype('f16')
+        assert m._device_path_ok()
+        with torch.no_grad():
+            got = m.simple_test(img.to(DEV), metas, rescale=True)
+    finally:
+        blocks.set_compute_dtype('f32')
+    for b in range(2):
+        a = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], 1) for c, r in enumerate(ref[b])])
+        d = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], 1) for c, r in enumerate(got[b])])
+        assert len(a) > 0 and len(d) > 0
+        top = a[np.argsort(-a[:, 4])[:30]]
+        hit = sum(1 for t in top if ((np.abs(d[:, :4] - t[:4]).max(1) < 2) & (d[:, 5] == t[5]) &
+                                     (np.abs(d[:, 4] - t[4]) < 0.03)).any())
+        assert hit >= 27, (b, hit)
 
 
 def test_r101_softnms_bf16():

@@ -19,7 +19,7 @@ def _match(got, ref, box_tol=1e-2, score_tol=1e-3):
         return False
     d = np.abs(ref[:, None, :4] - got[None, :, :4]).max(-1)
     s = np.abs(ref[:, None, 4] - got[None, :, 4])
-    return ((d < box_tol) & (s < score_tol)).any(1).mean() >= 0.9
+    return ((d < box_tol) & (s < score_tol)).any(1).mean() >= 0.99
 
 
 def test_forward_test_two_images_cpu_matches_reference_golden():

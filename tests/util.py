@@ -113,6 +113,21 @@ def fullsize_head_outputs(seed=20, batch=8):
     return sizes, cls, reg, iou
 
 
+def fullsize_softnms_inputs(b, n=2000, num_classes=80):
+    """image `b` of the soft-NMS stress (BASELINE configs[4]: 2000 proposals x 80 classes, score_thr 1e-4): seeded
+    proposals (log-uniform sizes 16..400 px, tie-free first-stage scores) and box-head outputs; regenerated on both
+    sides like `fullsize_head_outputs`"""
+    g = torch.Generator().manual_seed(2100 + b)
+    cx, cy = torch.rand(n, generator=g) * 1333, torch.rand(n, generator=g) * 800
+    w = torch.exp(torch.rand(n, generator=g) * 3.2189 + 2.7726)          # 16 .. 400
+    h = w * torch.exp((torch.rand(n, generator=g) - 0.5) * 1.386)        # aspect 0.5 .. 2
+    boxes = torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
+                         (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], 1)
+    prior = (torch.randperm(n, generator=g).float() + 1) / (n + 1)
+    cs, bp = fullsize_box_head_outputs(g, n, num_classes)
+    return boxes, prior, cs, bp
+
+
 def fullsize_box_head_outputs(g, n, num_classes=4):
     """seeded box-head outputs of one image's `n` proposals (generator `g` is advanced)"""
     cs = torch.randn(n, num_classes + 1, generator=g) * 2
