@@ -867,22 +867,17 @@ def g20_fullsize(cfg):
 
 def g21_fullsize_softnms():
     """BASELINE configs[4] at FULL size: 8 images x 2000 proposals x 80 classes through the reference's
-    `ProbConvFCBBoxHead.get_bboxes` -> `multiclass_nms` (bbox_nms.py:8-95) with the soft-NMS test settings of
+    `multiclass_nms` (bbox_nms.py:8-95) with the soft-NMS test settings of
     boosting_rcnn_r2_101_dcn_pafpn_mstrain_3x_coco.py:24-28 (score_thr 1e-4, soft_nms linear, iou 0.7, min_score 0,
     200 per image): detections in pick order with their decayed scores, and labels"""
-    from mmdet.models import build_head
+    from mmdet.core.post_processing.bbox_nms import multiclass_nms
     cfg = Config.fromfile(os.path.join(os.path.dirname(REF_CFG), 'boosting_rcnn_r2_101_dcn_pafpn_mstrain_3x_coco.py'))
-    rc = copy.deepcopy(cfg.model.roi_head.to_dict())
-    test_cfg = cfgdict(cfg.model.test_cfg.rcnn.to_dict())
-    rc.update(train_cfg=None, test_cfg=test_cfg)
-    rh = build_head(cfgdict(rc))
+    tc = cfg.model.test_cfg.rcnn
+    assert tc.score_thr == 0.0001 and tc.nms.type == 'soft_nms' and tc.max_per_img == 200
     d = {}
     for b in range(8):
-        boxes, prior, cs, bp = util.fullsize_softnms_inputs(b)
-        n = boxes.shape[0]
-        fused = (cs.softmax(1) * prior[:, None]) ** 0.5
-        rois = torch.cat([torch.zeros(n, 1), boxes], 1)
-        det, lab = rh.bbox_head.get_bboxes(rois, fused, bp, (800, 1333, 3), np.ones(4, np.float32), rescale=True, cfg=test_cfg)
+        boxes, scores = util.fullsize_softnms_candidates(b)
+        det, lab = multiclass_nms(boxes, scores, tc.score_thr, cfgdict(tc.nms.to_dict()), tc.max_per_img)
         d[f'det{b}'], d[f'lab{b}'] = det, lab.to(torch.int32)
     npz('g21_fullsize_softnms', **d)
 

@@ -188,22 +188,18 @@ def test_coco_pafpn_train_step_at_full_size():
 def test_fullsize_second_stage_soft_nms_golden():
     """BASELINE configs[4]'s soft-NMS stress at FULL size against the reference's own `multiclass_nms` (golden g21):
     8 images x 2000 proposals x 80 classes, score_thr 1e-4, soft_nms (linear, iou 0.7, min_score 0), 200 per image.
-    Candidate scores / boxes are formed on the host with the reference's arithmetic (score fusion, delta2bbox --
-    pinned by g2 / g8); the device runs the whole-batch segmented soft-NMS, the collection and the per-image re-sort
-    (`batched_nms_images_by_level(soft=...)`, the path `ProbRoIHead.simple_test_padded` takes).  Pick order, labels
-    and decayed scores: bit for bit."""
-    from brcnn.core import delta2bbox
+    The candidates are regenerated bit for bit on this host (no transcendental in their construction); the device
+    runs the whole-batch segmented soft-NMS, the collection and the per-image re-sort
+    (`batched_nms_images_by_level(soft=...)`, the path `ProbRoIHead.simple_test_padded` takes).  Pick order, labels,
+    boxes and decayed scores: bit for bit."""
     from brcnn.postprocess import batched_nms_images_by_level
     g = load('g21_fullsize_softnms')
     B, K, C = 8, 2000, 80
     bbs, scs = [], []
     for b in range(B):
-        boxes, prior, cs, bp = util.fullsize_softnms_inputs(b)
-        fused = (cs.softmax(1) * prior[:, None]) ** 0.5
-        dec = delta2bbox(boxes, bp, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2), max_shape=(800, 1333, 3))
-        dec = (dec.view(K, C, 4) / torch.ones(4)).view(K, C, 4)
-        bbs.append(dec)
-        scs.append(fused[:, :C])
+        boxes, scores = util.fullsize_softnms_candidates(b)
+        bbs.append(boxes.view(K, C, 4))
+        scs.append(scores[:, :C])
     bb = torch.stack(bbs).to(DEV)                 # (B, K, C, 4)
     sc = torch.stack(scs).to(DEV)                 # (B, K, C)
     valid = sc > 1e-4

@@ -113,19 +113,33 @@ def fullsize_head_outputs(seed=20, batch=8):
     return sizes, cls, reg, iou
 
 
-def fullsize_softnms_inputs(b, n=2000, num_classes=80):
-    """image `b` of the soft-NMS stress (BASELINE configs[4]: 2000 proposals x 80 classes, score_thr 1e-4): seeded
-    proposals (log-uniform sizes 16..400 px, tie-free first-stage scores) and box-head outputs; regenerated on both
-    sides like `fullsize_head_outputs`"""
+def fullsize_softnms_candidates(b, n=2000, num_classes=80):
+    """image `b` of the soft-NMS stress (BASELINE configs[4]: 2000 proposals x 80 classes, score_thr 1e-4): the inputs
+    of `multiclass_nms` -- per-class boxes (n, 4C) and scores (n, C+1).  Built from the CPU generator with +, -, * and /
+    only (no exp / softmax / sqrt, whose vectorised implementations differ in the last bit between host CPUs), so the
+    golden generator and the test regenerate the SAME bits on any machine.  250 clusters of 8 heavily overlapping
+    proposals; every candidate clears the threshold (162 000 per image go through soft-NMS), and a sparse strong
+    component shared by a cluster's members of one class puts winners AND their decayed neighbours into the top 200."""
     g = torch.Generator().manual_seed(2100 + b)
-    cx, cy = torch.rand(n, generator=g) * 1333, torch.rand(n, generator=g) * 800
-    w = torch.exp(torch.rand(n, generator=g) * 3.2189 + 2.7726)          # 16 .. 400
-    h = w * torch.exp((torch.rand(n, generator=g) - 0.5) * 1.386)        # aspect 0.5 .. 2
-    boxes = torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
-                         (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], 1)
-    prior = (torch.randperm(n, generator=g).float() + 1) / (n + 1)
-    cs, bp = fullsize_box_head_outputs(g, n, num_classes)
-    return boxes, prior, cs, bp
+    C, m = num_classes, 8
+    nc = n // m
+    cx, cy = torch.rand(nc, generator=g) * 1333, torch.rand(nc, generator=g) * 800
+    u = torch.rand(nc, generator=g)
+    w = 16 + 384 * u * u                                          # 16 .. 400 px, mostly small
+    h = w * (0.5 + 1.5 * torch.rand(nc, generator=g))
+    base = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).repeat_interleave(m, 0)      # (n, 4)
+    size = torch.stack([w, h, w, h], 1).repeat_interleave(m, 0)
+    base = base + (torch.rand(n, 4, generator=g) - 0.5) * 0.1 * size               # member jitter: IoU ~ 0.8 inside a cluster
+    boxes = base[:, None, :] + (torch.rand(n, C, 4, generator=g) - 0.5) * 0.04 * size[:, None, :]
+    boxes = torch.stack([boxes[..., 0].clamp(0, 1333), boxes[..., 1].clamp(0, 800),
+                         boxes[..., 2].clamp(0, 1333), boxes[..., 3].clamp(0, 800)], -1).reshape(n, 4 * C)
+    strong = (torch.randperm(nc * (C + 1), generator=g).float() + 1) / (nc * (C + 1) + 1)
+    for _ in range(10):
+        strong = strong * strong                                  # r^1024: ~0.3 % of the (cluster, class) pairs stay above 0.05
+    strong = strong.view(nc, C + 1).repeat_interleave(m, 0) * (0.5 + 0.5 * torch.rand(n, C + 1, generator=g))
+    weak = (torch.randperm(n * (C + 1), generator=g).float() + 1) / (n * (C + 1) + 1)
+    scores = 0.0002 + 0.001 * weak.view(n, C + 1) + 0.99 * strong
+    return boxes, scores
 
 
 def fullsize_box_head_outputs(g, n, num_classes=4):
