@@ -6,7 +6,9 @@ pycocotools/cocoeval.py, bbox branch, is restated): per (image, category) IoU ma
 crowd handling, greedy matching by descending score at 10 IoU thresholds x 4 area ranges,
 precision envelopes sampled at 101 recall points, the 12 summary statistics.
 PARITY UNPINNED against pycocotools itself (not installed); pinned by known-answer cases
-(tests/test_eval_cpu.py) derived by hand from the algorithm.
+(tests/test_eval_cpu.py) derived by hand from the algorithm: IoU thresholds, the 101-point envelope,
+crowd regions absorbing detections, `ignore` following `iscrowd`, maxDets truncation, area ranges
+inclusive at exactly 32^2 and 96^2.
 """
 from collections import defaultdict
 

@@ -401,9 +401,12 @@ ORC_API int orc_roi_align_forward_range(const float *input, const float *rois, f
 /* resizeGeneric_, HResizeLinear<uchar,int,short>, VResizeLinear<uchar,int,   */
 /* short,FixedPtCast<int,uchar,22>> with INTER_RESIZE_COEF_BITS = 11),        */
 /* mmcv.imnormalize (fp32 subtract / multiply by fp32(1/std)).                */
-/* PARITY UNPINNED for the resize: no cv2 and no reference golden vector of   */
-/* it here; restated from the published algorithm, cross-checked against the  */
-/* independent numpy restatement in the package (tests/test_pipeline_data_cpu)*/
+/* PARITY UNPINNED AGAINST cv2 for the resize: no cv2 and no reference golden */
+/* vector of it here; restated from the published algorithm, cross-checked    */
+/* against the independent numpy restatement in the package and pinned only   */
+/* by paper cases (tests/golden/kat_mmcv_ops.json resize_hand /               */
+/* preprocess_hand: integer and non-integer scale factors, 1-pixel sources,   */
+/* round-half-up, flips, BGR->RGB with RGB-ordered mean / std, padding).      */
 /* ------------------------------------------------------------------------- */
 static void orc_axis_coeff(int d, double scale, int src, int *s, int *c0, int *c1)
 {

@@ -359,7 +359,7 @@ def test_resize_hand_derived_vectors():
     import os
     from oracle import orc
     kat = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_mmcv_ops.json')))
-    assert len(kat['resize_hand']) >= 3
+    assert len(kat['resize_hand']) >= 7
     for case in kat['resize_hand']:
         src = np.array(case['src'], dtype=np.uint8)[:, :, None].repeat(3, 2)
         w, h = case['size_wh']
@@ -367,3 +367,26 @@ def test_resize_hand_derived_vectors():
         assert out.shape == (h, w, 3) and np.array_equal(out[:, :, 0], np.array(case['out'])), case['derivation']
         ref = orc.preprocess_u8(src, w, h, h, w, None, [0., 0., 0.], [1., 1., 1.], False)
         assert np.array_equal(ref.numpy()[0], np.array(case['out'], dtype=np.float32))
+
+
+def test_preprocess_hand_derived_vectors():
+    """Resize -> RandomFlip -> Normalize (to_rgb) -> Pad cases derived on paper (kat_mmcv_ops.json `preprocess_hand`):
+    flip directions, the BGR -> RGB swap with mean / std in RGB order, zero padding -- through the host chain
+    (pipelines.imresize_u8 / imflip / imnormalize / impad) and the C oracle of the fused device front door"""
+    import json
+    import os
+    from oracle import orc
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_mmcv_ops.json')))
+    assert len(kat['preprocess_hand']) >= 3
+    for case in kat['preprocess_hand']:
+        src = np.array(case['src_bgr'], dtype=np.uint8)
+        (w, h), (ph, pw) = case['new_wh'], case['pad_hw']
+        want = np.array(case['out_chw'], dtype=np.float32)
+        img = P.imresize_u8(src, (w, h))
+        if case['flip']:
+            img = P.imflip(img, case['flip'])
+        img = P.imnormalize(img, np.array(case['mean'], np.float32), np.array(case['std'], np.float32), case['to_rgb'])
+        img = P.impad(img, shape=(ph, pw))
+        assert np.array_equal(img.transpose(2, 0, 1), want), case['derivation']
+        ref = orc.preprocess_u8(src, w, h, ph, pw, case['flip'], case['mean'], case['std'], case['to_rgb'])
+        assert np.array_equal(ref.numpy(), want), case['derivation']

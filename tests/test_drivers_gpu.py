@@ -107,3 +107,26 @@ def test_train_and_test_tools_end_to_end(tmp_path):
             assert x.shape == y.shape and np.allclose(x, y, atol=1e-4)
     test.main([cfg_path, ckpt, '--format-only', '--eval-options', f'jsonfile_prefix={tmp_path}/fmt'])
     assert os.path.exists(str(tmp_path / 'fmt.bbox.json'))
+
+
+def test_preprocess_kernel_on_hand_derived_vectors():
+    """the fused front-door kernel on the paper cases of kat_mmcv_ops.json (`resize_hand`: OpenCV's 8-bit
+    INTER_LINEAR rule incl. non-integer down-scaling, 1-pixel sources, round-half-up; `preprocess_hand`: flips,
+    BGR -> RGB, mean / std in RGB order, zero padding)"""
+    import json
+    import os
+    import numpy as np
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_mmcv_ops.json')))
+    for case in kat['resize_hand']:
+        src = np.array(case['src'], dtype=np.uint8)[:, :, None].repeat(3, 2)
+        w, h = case['size_wh']
+        out = torch.empty((3, h, w), device=DEV)
+        ops.preprocess_u8(torch.from_numpy(np.ascontiguousarray(src)).to(DEV), out, w, h, None, [0., 0., 0.], [1., 1., 1.], False)
+        assert np.array_equal(out[0].cpu().numpy(), np.array(case['out'], dtype=np.float32)), case['derivation']
+    for case in kat['preprocess_hand']:
+        src = np.array(case['src_bgr'], dtype=np.uint8)
+        (w, h), (ph, pw) = case['new_wh'], case['pad_hw']
+        out = torch.empty((3, ph, pw), device=DEV)
+        ops.preprocess_u8(torch.from_numpy(np.ascontiguousarray(src)).to(DEV), out, w, h, case['flip'], case['mean'], case['std'],
+                          case['to_rgb'])
+        assert np.array_equal(out.cpu().numpy(), np.array(case['out_chw'], dtype=np.float32)), case['derivation']

@@ -113,3 +113,60 @@ def test_dataset_evaluate_roundtrip(tmp_path):
     assert (tmp_path / 'res.bbox.json').exists()
     empty = [[np.zeros((0, 5), np.float32)] * 4 for _ in range(len(ds))]
     assert ds.evaluate(empty) == {}
+
+
+def test_area_range_edges_are_inclusive_on_both_sides():
+    """COCOeval ignores a ground truth for an area range when `area < lo or area > hi`: a box of exactly 32^2 counts
+    as small AND medium, one of exactly 96^2 as medium AND large (hand-derived from the published rule)"""
+    gt = _gt([1], [(1, 1, (10, 10, 32, 32))])
+    ev = _run(gt, [(1, 1, (10, 10, 32, 32), .9)])
+    assert ev.stats[3] == pytest.approx(1.0) and ev.stats[4] == pytest.approx(1.0) and ev.stats[5] == -1
+    gt = _gt([1], [(1, 1, (10, 10, 96, 96))])
+    ev = _run(gt, [(1, 1, (10, 10, 96, 96), .9)])
+    assert ev.stats[3] == -1 and ev.stats[4] == pytest.approx(1.0) and ev.stats[5] == pytest.approx(1.0)
+    # one pixel more on either side leaves the range
+    gt = _gt([1], [(1, 1, (10, 10, 32, 32.03125))])        # area 1025 > 32^2
+    ev = _run(gt, [(1, 1, (10, 10, 32, 32.03125), .9)])
+    assert ev.stats[3] == -1 and ev.stats[4] == pytest.approx(1.0)
+    # an unmatched detection outside the range is ignored there, inside it is a false positive:
+    # small gt found + one large false positive ranked first -> AP_small stays 1, AP_all drops to 1/2
+    gt = _gt([1], [(1, 1, (10, 10, 20, 20))])
+    ev = _run(gt, [(1, 1, (200, 200, 150, 150), .95), (1, 1, (10, 10, 20, 20), .9)])
+    assert ev.stats[3] == pytest.approx(1.0) and ev.stats[0] == pytest.approx(0.5)
+
+
+def test_maxdets_truncation_and_the_precision_envelope():
+    """detections ranked FP(.9), TP(.8), TP(.7) on two ground truths: precision 1/2 at recall 1/2 and 2/3 at recall 1;
+    the envelope lifts every recall level to 2/3.  With maxDets = 1 only the false positive survives, with 2 one hit."""
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50)), (1, 1, (200, 200, 50, 50))])
+    dets = [(1, 1, (400, 400, 40, 40), .9), (1, 1, (10, 10, 50, 50), .8), (1, 1, (200, 200, 50, 50), .7)]
+    ev = _run(gt, dets, max_dets=(1, 2, 100))
+    assert ev.stats[0] == pytest.approx(2 / 3)
+    assert ev.stats[6] == 0.0 and ev.stats[7] == pytest.approx(0.5) and ev.stats[8] == pytest.approx(1.0)
+    # order of the input list does not matter, only the scores
+    ev2 = _run(gt, dets[::-1], max_dets=(1, 2, 100))
+    assert ev2.stats[0] == pytest.approx(2 / 3) and ev2.stats[6] == 0.0
+
+
+def test_crowd_absorbs_any_number_of_detections_and_ignore_follows_iscrowd():
+    """a crowd region matches every detection that overlaps it enough (intersection over the detection's area), all of
+    them ignored; a plain ground truth is matched once.  pycocotools overwrites an annotation's `ignore` field with
+    `iscrowd` for bbox evaluation: `ignore: 1` alone does not hide a ground truth."""
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50)), (1, 1, (200, 200, 200, 200), 1)])
+    ev = _run(gt, [(1, 1, (210, 210, 30, 30), .95), (1, 1, (250, 250, 30, 30), .9), (1, 1, (300, 300, 30, 30), .85),
+                   (1, 1, (10, 10, 50, 50), .5)])
+    assert ev.stats[0] == pytest.approx(1.0) and ev.stats[8] == pytest.approx(1.0)
+    # a second detection of the plain ground truth is a false positive (matched once): ranked below, it does not matter;
+    # ranked above the true one with a worse IoU it halves the precision at the strict thresholds only
+    ev = _run(gt, [(1, 1, (10, 10, 50, 50), .9), (1, 1, (12, 10, 50, 50), .8)])
+    assert ev.stats[0] == pytest.approx(1.0)
+    # only crowd ground truth: nothing to find -> -1
+    gt = _gt([1], [(1, 1, (200, 200, 200, 200), 1)])
+    ev = _run(gt, [(1, 1, (210, 210, 30, 30), .95)])
+    assert ev.stats[0] == -1
+    # `ignore` without iscrowd
+    c = _gt([1], [(1, 1, (10, 10, 50, 50))])
+    c.dataset['annotations'][0]['ignore'] = 1
+    c.createIndex()
+    ev = _run(c, [(1, 1, (300, 300, 50, 50), .9)])
+    assert ev.stats[0] == 0.0 and ev.stats[8] == 0.0          # the ground truth still counts (and is missed)
