@@ -234,139 +234,99 @@ def const_rows(rows, like):
 
 
 # ----------------------------------------------------------------------------- coder
+# The host forms below serve the reference-signature entry points on CPU tensors (tests, the CPU plumbing run of
+# BASELINE configs[0]) and autograd callers; device tensors take the HIP kernels.  Each keeps the reference's fp32
+# operation ORDER (the parity bar is bit-exact against its goldens g2 / g3 / g4), written once per function over whole
+# (x, y) / (w, h) pairs instead of per coordinate, and only with the options the Boosting R-CNN recipes set.
+def _centre_size(boxes):
+    """(..., 4) corner boxes -> centre (..., 2), size (..., 2)"""
+    lo, hi = boxes[..., :2], boxes[..., 2:4]
+    return (lo + hi) * 0.5, hi - lo
+
+
 def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    """delta_xywh_bbox_coder.py:99-141: ((g_ctr - p_ctr) / p_size, log(g_size / p_size)), normalised"""
     assert proposals.size() == gt.size()
-    proposals = proposals.float()
-    gt = gt.float()
-    px = (proposals[..., 0] + proposals[..., 2]) * 0.5
-    py = (proposals[..., 1] + proposals[..., 3]) * 0.5
-    pw = proposals[..., 2] - proposals[..., 0]
-    ph = proposals[..., 3] - proposals[..., 1]
-    gx = (gt[..., 0] + gt[..., 2]) * 0.5
-    gy = (gt[..., 1] + gt[..., 3]) * 0.5
-    gw = gt[..., 2] - gt[..., 0]
-    gh = gt[..., 3] - gt[..., 1]
-    dx = (gx - px) / pw
-    dy = (gy - py) / ph
-    dw = torch.log(gw / pw)
-    dh = torch.log(gh / ph)
-    deltas = torch.stack([dx, dy, dw, dh], dim=-1)
-    means = const_like(means, deltas).unsqueeze(0)
-    stds = const_like(stds, deltas).unsqueeze(0)
-    return deltas.sub_(means).div_(stds)
+    p_ctr, p_size = _centre_size(proposals.float())
+    g_ctr, g_size = _centre_size(gt.float())
+    deltas = torch.cat([(g_ctr - p_ctr) / p_size, torch.log(g_size / p_size)], dim=-1)
+    return deltas.sub_(const_like(means, deltas)).div_(const_like(stds, deltas))
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
-               wh_ratio_clip=16 / 1000, clip_border=True, add_ctr_clamp=False, ctr_clamp=32):
-    means = const_like(means, deltas).view(1, -1).repeat(1, deltas.size(-1) // 4)
-    stds = const_like(stds, deltas).view(1, -1).repeat(1, deltas.size(-1) // 4)
-    denorm = deltas * stds + means
-    dx, dy, dw, dh = denorm[..., 0::4], denorm[..., 1::4], denorm[..., 2::4], denorm[..., 3::4]
-    x1, y1, x2, y2 = rois[..., 0], rois[..., 1], rois[..., 2], rois[..., 3]
-    px = ((x1 + x2) * 0.5).unsqueeze(-1).expand_as(dx)
-    py = ((y1 + y2) * 0.5).unsqueeze(-1).expand_as(dy)
-    pw = (x2 - x1).unsqueeze(-1).expand_as(dw)
-    ph = (y2 - y1).unsqueeze(-1).expand_as(dh)
-    dx_width = pw * dx
-    dy_height = ph * dy
-    max_ratio = np.abs(np.log(wh_ratio_clip))
-    if add_ctr_clamp:
-        dx_width = torch.clamp(dx_width, max=ctr_clamp, min=-ctr_clamp)
-        dy_height = torch.clamp(dy_height, max=ctr_clamp, min=-ctr_clamp)
-        dw = torch.clamp(dw, max=max_ratio)
-        dh = torch.clamp(dh, max=max_ratio)
-    else:
-        dw = dw.clamp(min=-max_ratio, max=max_ratio)
-        dh = dh.clamp(min=-max_ratio, max=max_ratio)
-    gw = pw * dw.exp()
-    gh = ph * dh.exp()
-    gx = px + dx_width
-    gy = py + dy_height
-    x1 = gx - gw * 0.5
-    y1 = gy - gh * 0.5
-    x2 = gx + gw * 0.5
-    y2 = gy + gh * 0.5
-    bboxes = torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
+               wh_ratio_clip=16 / 1000, clip_border=True):
+    """delta_xywh_bbox_coder.py:145-272 (the recipes' form: no centre clamp).  `deltas` (..., 4) or (..., 4C):
+    class-wise quadruples decode against the same roi; `max_shape` (H, W[, ...]) or one row per leading batch entry."""
+    quads = deltas.reshape(deltas.shape[:-1] + (deltas.shape[-1] // 4, 4))     # (..., C, 4)
+    d = quads * const_like(stds, deltas) + const_like(means, deltas)
+    ctr, size = _centre_size(rois)
+    ctr, size = ctr.unsqueeze(-2), size.unsqueeze(-2)
+    limit = float(np.abs(np.log(wh_ratio_clip)))
+    new_size = size * d[..., 2:].clamp(min=-limit, max=limit).exp()
+    new_ctr = ctr + size * d[..., :2]
+    half = new_size * 0.5
+    boxes = torch.cat([new_ctr - half, new_ctr + half], dim=-1)
     if clip_border and max_shape is not None:
         if not isinstance(max_shape, torch.Tensor):
             flat = all(not isinstance(v, (list, tuple, np.ndarray)) for v in max_shape)
-            max_shape = const_like(max_shape, x1) if flat else const_rows(max_shape, x1)
-        max_shape = max_shape[..., :2].type_as(x1)
-        if max_shape.ndim == 2:
-            assert bboxes.ndim == 3
-            assert max_shape.size(0) == bboxes.size(0)
-        min_xy = const_like([0], x1)[0]
-        max_xy = torch.cat([max_shape] * (deltas.size(-1) // 2), dim=-1).flip(-1).unsqueeze(-2)
-        bboxes = torch.where(bboxes < min_xy, min_xy, bboxes)
-        bboxes = torch.where(bboxes > max_xy, max_xy, bboxes)
-    return bboxes
+            max_shape = const_like(max_shape, boxes) if flat else const_rows(max_shape, boxes)
+        hw = max_shape[..., :2].type_as(boxes)
+        if hw.ndim == 2:        # one border per image of a (B, n, ...) batch
+            assert boxes.ndim == 4 and hw.size(0) == boxes.size(0)
+            hw = hw[:, None, None, :]
+        upper = torch.cat([hw.flip(-1), hw.flip(-1)], dim=-1)                  # (W, H, W, H): clips to W / H, not W-1
+        boxes = torch.minimum(boxes.clamp(min=0), upper)
+    return boxes.reshape(deltas.shape)
 
 
 @BBOX_CODERS.register_module()
 class DeltaXYWHBBoxCoder:
     def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.),
                  clip_border=True, add_ctr_clamp=False, ctr_clamp=32):
+        if add_ctr_clamp:
+            raise NotImplementedError('add_ctr_clamp: not used by the Boosting R-CNN recipes')
         self.means, self.stds = target_means, target_stds
-        self.clip_border, self.add_ctr_clamp, self.ctr_clamp = clip_border, add_ctr_clamp, ctr_clamp
+        self.clip_border, self.add_ctr_clamp, self.ctr_clamp = clip_border, False, ctr_clamp
 
     def encode(self, bboxes, gt_bboxes):
-        assert bboxes.size(0) == gt_bboxes.size(0)
-        assert bboxes.size(-1) == gt_bboxes.size(-1) == 4
+        assert bboxes.size(0) == gt_bboxes.size(0) and bboxes.size(-1) == gt_bboxes.size(-1) == 4
         return bbox2delta(bboxes, gt_bboxes, self.means, self.stds)
 
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
         assert pred_bboxes.size(0) == bboxes.size(0)
         if pred_bboxes.ndim == 3:
             assert pred_bboxes.size(1) == bboxes.size(1)
-        return delta2bbox(bboxes, pred_bboxes, self.means, self.stds, max_shape, wh_ratio_clip,
-                          self.clip_border, self.add_ctr_clamp, self.ctr_clamp)
+        return delta2bbox(bboxes, pred_bboxes, self.means, self.stds, max_shape, wh_ratio_clip, self.clip_border)
 
 
 # ----------------------------------------------------------------------------- IoU
 def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
-    assert mode in ['iou', 'iof', 'giou'], f'Unsupported mode {mode}'
-    assert (bboxes1.size(-1) == 4 or bboxes1.size(0) == 0)
-    assert (bboxes2.size(-1) == 4 or bboxes2.size(0) == 0)
+    """iou2d_calculator.py:75-261: IoU / IoF / GIoU of corner boxes, pairwise (rows x cols) or aligned; no +1
+    offset, union floored at `eps`"""
+    assert mode in ('iou', 'iof', 'giou'), f'Unsupported mode {mode}'
+    assert (bboxes1.size(-1) == 4 or bboxes1.size(0) == 0) and (bboxes2.size(-1) == 4 or bboxes2.size(0) == 0)
     assert bboxes1.shape[:-2] == bboxes2.shape[:-2]
-    batch_shape = bboxes1.shape[:-2]
     rows, cols = bboxes1.size(-2), bboxes2.size(-2)
-    if is_aligned:
-        assert rows == cols
+    assert not is_aligned or rows == cols
     if rows * cols == 0:
-        return bboxes1.new(batch_shape + ((rows,) if is_aligned else (rows, cols)))
+        return bboxes1.new(bboxes1.shape[:-2] + ((rows,) if is_aligned else (rows, cols)))
     if bboxes1.is_cuda and bboxes1.dim() == 2 and bboxes1.dtype == torch.float32 and \
             not (torch.is_grad_enabled() and (bboxes1.requires_grad or bboxes2.requires_grad)):
         from .train_ops import bbox_overlaps as _dev       # values only: the HIP table kernel
         return _dev(bboxes1, bboxes2, mode, is_aligned, eps)
-    area1 = (bboxes1[..., 2] - bboxes1[..., 0]) * (bboxes1[..., 3] - bboxes1[..., 1])
-    area2 = (bboxes2[..., 2] - bboxes2[..., 0]) * (bboxes2[..., 3] - bboxes2[..., 1])
-    if is_aligned:
-        lt = torch.max(bboxes1[..., :2], bboxes2[..., :2])
-        rb = torch.min(bboxes1[..., 2:], bboxes2[..., 2:])
-        wh = (rb - lt).clamp(min=0)
-        overlap = wh[..., 0] * wh[..., 1]
-        union = area1 + area2 - overlap if mode in ['iou', 'giou'] else area1
-        if mode == 'giou':
-            enclosed_lt = torch.min(bboxes1[..., :2], bboxes2[..., :2])
-            enclosed_rb = torch.max(bboxes1[..., 2:], bboxes2[..., 2:])
-    else:
-        lt = torch.max(bboxes1[..., :, None, :2], bboxes2[..., None, :, :2])
-        rb = torch.min(bboxes1[..., :, None, 2:], bboxes2[..., None, :, 2:])
-        wh = (rb - lt).clamp(min=0)
-        overlap = wh[..., 0] * wh[..., 1]
-        union = area1[..., None] + area2[..., None, :] - overlap if mode in ['iou', 'giou'] \
-            else area1[..., None]
-        if mode == 'giou':
-            enclosed_lt = torch.min(bboxes1[..., :, None, :2], bboxes2[..., None, :, :2])
-            enclosed_rb = torch.max(bboxes1[..., :, None, 2:], bboxes2[..., None, :, 2:])
-    eps = const_like([eps], union)
-    union = torch.max(union, eps)
+    a, b = (bboxes1, bboxes2) if is_aligned else (bboxes1.unsqueeze(-2), bboxes2.unsqueeze(-3))
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    inner = (torch.min(a[..., 2:], b[..., 2:]) - torch.max(a[..., :2], b[..., :2])).clamp(min=0)
+    overlap = inner[..., 0] * inner[..., 1]
+    floor = const_like([eps], overlap)
+    union = torch.max(area_a + area_b - overlap if mode != 'iof' else area_a.expand_as(overlap), floor)
     ious = overlap / union
-    if mode in ['iou', 'iof']:
+    if mode != 'giou':
         return ious
-    enclose_wh = (enclosed_rb - enclosed_lt).clamp(min=0)
-    enclose_area = torch.max(enclose_wh[..., 0] * enclose_wh[..., 1], eps)
-    return ious - (enclose_area - union) / enclose_area
+    outer = (torch.max(a[..., 2:], b[..., 2:]) - torch.min(a[..., :2], b[..., :2])).clamp(min=0)
+    hull = torch.max(outer[..., 0] * outer[..., 1], floor)
+    return ious - (hull - union) / hull
 
 
 @IOU_CALCULATORS.register_module()
@@ -375,58 +335,60 @@ class BboxOverlaps2D:
         self.scale, self.dtype = scale, dtype
 
     def __call__(self, bboxes1, bboxes2, mode='iou', is_aligned=False):
-        assert bboxes1.size(-1) in [0, 4, 5]
-        assert bboxes2.size(-1) in [0, 4, 5]
-        if bboxes2.size(-1) == 5:
-            bboxes2 = bboxes2[..., :4]
-        if bboxes1.size(-1) == 5:
-            bboxes1 = bboxes1[..., :4]
-        return bbox_overlaps(bboxes1, bboxes2, mode, is_aligned)
+        assert bboxes1.size(-1) in (0, 4, 5) and bboxes2.size(-1) in (0, 4, 5)
+        return bbox_overlaps(bboxes1[..., :4], bboxes2[..., :4], mode, is_aligned)      # a 5th column is a score
 
 
 # ----------------------------------------------------------------------------- assign
 class AssignResult:
+    """gt_inds: -1 ignore, 0 background, k > 0 matched to ground truth k-1 (assign_result.py)"""
+
     def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
-        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = \
-            num_gts, gt_inds, max_overlaps, labels
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
 
     @property
     def num_preds(self):
         return len(self.gt_inds)
 
     def add_gt_(self, gt_labels):
-        self_inds = torch.arange(1, len(gt_labels) + 1, dtype=torch.long, device=gt_labels.device)
-        self.gt_inds = torch.cat([self_inds, self.gt_inds])
-        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(len(gt_labels)), self.max_overlaps])
+        """the ground truths join the proposals in front, each matched to itself with IoU 1 (:191-205)"""
+        k = len(gt_labels)
+        self.gt_inds = torch.cat([torch.arange(1, k + 1, dtype=torch.long, device=gt_labels.device), self.gt_inds])
+        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(k), self.max_overlaps])
         if self.labels is not None:
             self.labels = torch.cat([gt_labels, self.labels])
 
 
 @BBOX_ASSIGNERS.register_module()
 class MaxIoUAssigner:
+    """max_iou_assigner.py:61-213 with the settings of the recipes: scalar `neg_iou_thr`, every box tied with a ground
+    truth's best IoU joins it (`gt_max_assign_all`)."""
+
     def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True,
                  ignore_iof_thr=-1, ignore_wrt_candidates=True, match_low_quality=True,
                  gpu_assign_thr=-1, iou_calculator=dict(type='BboxOverlaps2D')):
-        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, neg_iou_thr, min_pos_iou
-        self.gt_max_assign_all = gt_max_assign_all
+        if not gt_max_assign_all or isinstance(neg_iou_thr, (tuple, list)):
+            raise NotImplementedError('MaxIoUAssigner: gt_max_assign_all=False / a neg_iou_thr interval are not used '
+                                      'by the Boosting R-CNN recipes')
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, float(neg_iou_thr), min_pos_iou
+        self.gt_max_assign_all = True
         self.ignore_iof_thr, self.ignore_wrt_candidates = ignore_iof_thr, ignore_wrt_candidates
         self.gpu_assign_thr = gpu_assign_thr
         self.match_low_quality = match_low_quality
         self.iou_calculator = build_iou_calculator(iou_calculator)
 
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
-        if bboxes.is_cuda and bboxes.dim() == 2 and bboxes.shape[0] > 0 and self.gt_max_assign_all and \
-                type(self.iou_calculator) is BboxOverlaps2D and \
-                not (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0):
+        has_ignore = self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
+        if bboxes.is_cuda and bboxes.dim() == 2 and bboxes.shape[0] > 0 and \
+                type(self.iou_calculator) is BboxOverlaps2D and not has_ignore:
             return self._assign_device(bboxes, gt_bboxes, gt_labels)
         overlaps = self.iou_calculator(gt_bboxes, bboxes)
-        if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None
-                and gt_bboxes_ignore.numel() > 0 and bboxes.numel() > 0):
+        if has_ignore and bboxes.numel() > 0:
             if self.ignore_wrt_candidates:
-                ignore_max, _ = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)
+                covered = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)[0]
             else:
-                ignore_max, _ = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)
-            overlaps[:, ignore_max > self.ignore_iof_thr] = -1
+                covered = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)[0]
+            overlaps[:, covered > self.ignore_iof_thr] = -1
         return self.assign_wrt_overlaps(overlaps, gt_labels)
 
     def _assign_device(self, bboxes, gt_bboxes, gt_labels):
@@ -448,48 +410,35 @@ class MaxIoUAssigner:
         return AssignResult(n_gt, gt_inds, mo[0], labels=labels)
 
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):
-        num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
-        assigned = overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
-        if num_gts == 0 or num_bboxes == 0:
-            max_overlaps = overlaps.new_zeros((num_bboxes,))
+        """(num_gts, n) IoU table -> AssignResult.  Every step is a `where` over the n boxes (no boolean index
+        assignment: that would synchronise with the host on a device table)."""
+        num_gts, n = overlaps.shape
+        gt_inds = overlaps.new_full((n,), -1, dtype=torch.long)
+        if num_gts == 0 or n == 0:
             if num_gts == 0:
-                assigned[:] = 0
-            labels = None if gt_labels is None else overlaps.new_full((num_bboxes,), -1,
-                                                                      dtype=torch.long)
-            return AssignResult(num_gts, assigned, max_overlaps, labels=labels)
-        max_overlaps, argmax_overlaps = overlaps.max(dim=0)
-        gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
-        # masked assignments as `where` (same values; boolean index_put_ would sync with the host)
-        zero = assigned.new_zeros(())
-        if isinstance(self.neg_iou_thr, float):
-            assigned = torch.where((max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr), zero, assigned)
-        elif isinstance(self.neg_iou_thr, tuple):
-            assert len(self.neg_iou_thr) == 2
-            assigned = torch.where((max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1]),
-                                   zero, assigned)
-        pos_inds = max_overlaps >= self.pos_iou_thr
-        assigned = torch.where(pos_inds, argmax_overlaps + 1, assigned)
+                gt_inds[:] = 0                      # no ground truth: everything is background
+            labels = None if gt_labels is None else overlaps.new_full((n,), -1, dtype=torch.long)
+            return AssignResult(num_gts, gt_inds, overlaps.new_zeros((n,)), labels=labels)
+        best_iou, best_gt = overlaps.max(dim=0)
+        gt_inds = torch.where((best_iou >= 0) & (best_iou < self.neg_iou_thr), gt_inds.new_zeros(()), gt_inds)
+        gt_inds = torch.where(best_iou >= self.pos_iou_thr, best_gt + 1, gt_inds)
         if self.match_low_quality:
-            # the reference loops over gts in order, later gts overriding earlier ones
-            # (max_iou_assigner.py:194-200); the same result without a host loop:
-            ok = gt_max_overlaps >= self.min_pos_iou
-            if self.gt_max_assign_all:
-                hit = (overlaps == gt_max_overlaps[:, None]) & ok[:, None]
-                rank = torch.arange(1, num_gts + 1, device=overlaps.device)[:, None]
-                best = (hit * rank).max(dim=0)[0]
-                assigned = torch.where(best > 0, best, assigned)
-            else:
-                for i in torch.nonzero(ok, as_tuple=False).flatten().tolist():
-                    assigned[gt_argmax_overlaps[i]] = i + 1
+            # every ground truth keeps the boxes that reach its own best IoU (>= min_pos_iou); where two ground
+            # truths claim a box the later one wins, as the reference's loop over ground truths leaves it (:194-200)
+            top = overlaps.max(dim=1)[0]
+            claims = (overlaps == top[:, None]) & (top >= self.min_pos_iou)[:, None]
+            order = torch.arange(1, num_gts + 1, device=overlaps.device)[:, None]
+            winner = (claims * order).max(dim=0)[0]
+            gt_inds = torch.where(winner > 0, winner, gt_inds)
+        labels = None
         if gt_labels is not None:
-            labels = torch.where(assigned > 0, gt_labels[(assigned - 1).clamp(min=0)],
-                                 assigned.new_full((), -1))
-        else:
-            labels = None
-        return AssignResult(num_gts, assigned, max_overlaps, labels=labels)
+            labels = torch.where(gt_inds > 0, gt_labels[(gt_inds - 1).clamp(min=0)], gt_inds.new_full((), -1))
+        return AssignResult(num_gts, gt_inds, best_iou, labels=labels)
 
 
 class SamplingResult:
+    """sampling_result.py:26-55: the sampled rows split into positives / negatives with their targets"""
+
     def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
         self.pos_inds, self.neg_inds = pos_inds, neg_inds
         self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
@@ -500,103 +449,73 @@ class SamplingResult:
             assert self.pos_assigned_gt_inds.numel() == 0
             self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
         else:
-            if len(gt_bboxes.shape) < 2:
-                gt_bboxes = gt_bboxes.view(-1, 4)
-            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds.long(), :]
-        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None \
-            else None
+            self.pos_gt_bboxes = gt_bboxes.view(-1, 4)[self.pos_assigned_gt_inds.long(), :]
+        self.pos_gt_labels = None if assign_result.labels is None else assign_result.labels[pos_inds]
 
     @property
     def bboxes(self):
         return torch.cat([self.pos_bboxes, self.neg_bboxes])
 
 
+def _rows_where(mask):
+    return torch.nonzero(mask, as_tuple=False).reshape(-1)
+
+
 @BBOX_SAMPLERS.register_module()
 class PseudoSampler:
+    """pseudo_sampler.py:24-42: no sampling -- every assigned box is kept"""
+
     def __init__(self, **kwargs):
         pass
 
     def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
-        gt_flags = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
-        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+        flags = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
+        return SamplingResult(_rows_where(assign_result.gt_inds > 0).unique(), _rows_where(assign_result.gt_inds == 0).unique(),
+                              bboxes, gt_bboxes, assign_result, flags)
 
 
 @BBOX_SAMPLERS.register_module()
 class RandomSampler:
+    """base_sampler.py:35-102 + random_sampler.py:32-82: up to int(num * pos_fraction) positives, negatives fill up
+    to `num` (capped at neg_pos_ub x positives); ground truths join the proposals first."""
+
     def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
         self.num, self.pos_fraction = num, pos_fraction
         self.neg_pos_ub, self.add_gt_as_proposals = neg_pos_ub, add_gt_as_proposals
 
-    def random_choice(self, gallery, num):
+    @staticmethod
+    def random_choice(gallery, num):
+        """`num` rows of the index tensor `gallery`: the first `num` entries of a HOST randperm over its length -- the
+        reference's draw (random_sampler.py:58), so a seeded run picks the same samples"""
         assert len(gallery) >= num
-        is_tensor = isinstance(gallery, torch.Tensor)
-        if not is_tensor:
-            device = torch.cuda.current_device() if torch.cuda.is_available() else 'cpu'
-            gallery = torch.tensor(gallery, dtype=torch.long, device=device)
-        # host randperm, as in the reference (random_sampler.py:58): seeded parity
-        perm = torch.randperm(gallery.numel())[:num].to(device=gallery.device)
-        rand_inds = gallery[perm]
-        if not is_tensor:
-            rand_inds = rand_inds.cpu().numpy()
-        return rand_inds
+        return gallery[torch.randperm(gallery.numel())[:num].to(device=gallery.device)]
 
-    def _sample_pos(self, assign_result, num_expected, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False)
-        if pos_inds.numel() != 0:
-            pos_inds = pos_inds.squeeze(1)
-        if pos_inds.numel() <= num_expected:
-            return pos_inds
-        return self.random_choice(pos_inds, num_expected)
-
-    def _sample_neg(self, assign_result, num_expected, **kwargs):
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False)
-        if neg_inds.numel() != 0:
-            neg_inds = neg_inds.squeeze(1)
-        if len(neg_inds) <= num_expected:
-            return neg_inds
-        return self.random_choice(neg_inds, num_expected)
+    def _draw(self, candidates, limit):
+        return candidates if candidates.numel() <= limit else self.random_choice(candidates, limit)
 
     def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
-        if len(bboxes.shape) < 2:
-            bboxes = bboxes[None, :]
-        bboxes = bboxes[:, :4]
+        bboxes = bboxes.reshape(-1, bboxes.shape[-1])[:, :4]
         gt_flags = bboxes.new_zeros((bboxes.shape[0],), dtype=torch.uint8)
         if self.add_gt_as_proposals and len(gt_bboxes) > 0:
             if gt_labels is None:
                 raise ValueError('gt_labels must be given when add_gt_as_proposals is True')
             bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
             assign_result.add_gt_(gt_labels)
-            gt_ones = bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8)
-            gt_flags = torch.cat([gt_ones, gt_flags])
-        num_expected_pos = int(self.num * self.pos_fraction)
-        pos_inds = self._sample_pos(assign_result, num_expected_pos, bboxes=bboxes, **kwargs)
-        pos_inds = pos_inds.unique()
-        num_sampled_pos = pos_inds.numel()
-        num_expected_neg = self.num - num_sampled_pos
+            gt_flags = torch.cat([bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8), gt_flags])
+        pos = self._draw(_rows_where(assign_result.gt_inds > 0), int(self.num * self.pos_fraction)).unique()
+        room = self.num - pos.numel()
         if self.neg_pos_ub >= 0:
-            _pos = max(1, num_sampled_pos)
-            neg_upper_bound = int(self.neg_pos_ub * _pos)
-            if num_expected_neg > neg_upper_bound:
-                num_expected_neg = neg_upper_bound
-        neg_inds = self._sample_neg(assign_result, num_expected_neg, bboxes=bboxes, **kwargs)
-        neg_inds = neg_inds.unique()
-        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+            room = min(room, int(self.neg_pos_ub * max(1, pos.numel())))
+        neg = self._draw(_rows_where(assign_result.gt_inds == 0), room).unique()
+        return SamplingResult(pos, neg, bboxes, gt_bboxes, assign_result, gt_flags)
 
 
 # ----------------------------------------------------------------------------- transforms
 def bbox2roi(bbox_list):
     """list[(n,4|5)] -> (sum n, 5) [batch_ind, x1, y1, x2, y2] (core/bbox/transforms.py:59-78)"""
-    rois_list = []
-    for img_id, bboxes in enumerate(bbox_list):
-        if bboxes.size(0) > 0:
-            img_inds = bboxes.new_full((bboxes.size(0), 1), img_id)
-            rois = torch.cat([img_inds, bboxes[:, :4]], dim=-1)
-        else:
-            rois = bboxes.new_zeros((0, 5))
-        rois_list.append(rois)
-    return torch.cat(rois_list, 0)
+    rows = [torch.cat([b.new_full((b.size(0), 1), i), b[:, :4]], dim=-1) if b.size(0) > 0 else b.new_zeros((0, 5))
+            for i, b in enumerate(bbox_list)]
+    return torch.cat(rows, 0)
 
 
 def bbox2result(bboxes, labels, num_classes):
@@ -604,39 +523,27 @@ def bbox2result(bboxes, labels, num_classes):
     if bboxes.shape[0] == 0:
         return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
     if isinstance(bboxes, torch.Tensor):
-        bboxes = bboxes.detach().cpu().numpy()
-        labels = labels.detach().cpu().numpy()
+        bboxes, labels = bboxes.detach().cpu().numpy(), labels.detach().cpu().numpy()
     return [bboxes[labels == i, :] for i in range(num_classes)]
 
 
-def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
-                   score_factors=None, return_inds=False):
-    """core/post_processing/bbox_nms.py:8-95 on top of this package's batched_nms."""
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None, return_inds=False):
+    """core/post_processing/bbox_nms.py:8-95 on this package's batched_nms: (n, 4 | 4C) boxes and (n, C+1) scores ->
+    the (roi, class) candidates above `score_thr` through class-aware NMS, best `max_num`"""
     from .ops import batched_nms
-    num_classes = multi_scores.size(1) - 1
-    if multi_bboxes.shape[1] > 4:
-        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
-    else:
-        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
-    scores = multi_scores[:, :-1]
-    labels = torch.arange(num_classes, dtype=torch.long, device=scores.device)
-    labels = labels.view(1, -1).expand_as(scores)
-    bboxes = bboxes.reshape(-1, 4)
-    scores = scores.reshape(-1)
-    labels = labels.reshape(-1)
-    valid_mask = scores > score_thr
+    n, num_classes = multi_scores.size(0), multi_scores.size(1) - 1
+    boxes = multi_bboxes.view(n, -1, 4) if multi_bboxes.shape[1] > 4 else multi_bboxes[:, None].expand(n, num_classes, 4)
+    scores = multi_scores[:, :num_classes]
+    keep_mask = (scores > score_thr).reshape(-1)                    # thresholded BEFORE any score factor, as the reference
     if score_factors is not None:
-        score_factors = score_factors.view(-1, 1).expand(multi_scores.size(0), num_classes)
-        scores = scores * score_factors.reshape(-1)
-    inds = valid_mask.nonzero(as_tuple=False).squeeze(1)
-    bboxes, scores, labels = bboxes[inds], scores[inds], labels[inds]
-    if bboxes.numel() == 0:
-        dets = torch.cat([bboxes, scores[:, None]], -1)
+        scores = scores * score_factors.view(-1, 1)
+    inds = _rows_where(keep_mask)
+    labels = torch.arange(num_classes, dtype=torch.long, device=scores.device).repeat(n)[inds]
+    boxes, scores = boxes.reshape(-1, 4)[inds], scores.reshape(-1)[inds]
+    if boxes.numel() == 0:
+        dets = torch.cat([boxes, scores[:, None]], -1)
         return (dets, labels, inds) if return_inds else (dets, labels)
-    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+    dets, keep = batched_nms(boxes, scores, labels, nms_cfg)
     if max_num > 0:
-        dets = dets[:max_num]
-        keep = keep[:max_num]
-    if return_inds:
-        return dets, labels[keep], inds[keep]
-    return dets, labels[keep]
+        dets, keep = dets[:max_num], keep[:max_num]
+    return (dets, labels[keep], inds[keep]) if return_inds else (dets, labels[keep])
