@@ -689,8 +689,9 @@ int sk_table(long long tiles, int nk, int slots, const SkTable** out) {
     return 0;
 }
 
-// the schedule of one launch, or sk_wgs = 0: `slots` = resident workgroups of this kernel on the whole device
-static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s) {
+// the schedule of one launch, or sk_wgs = 0: `slots` = resident workgroups of this kernel on the whole device;
+// `min_nk`: shortest K loop (in K tiles) the heuristic cuts for this tile shape (0: the 128 x 128 rule below)
+static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int min_nk = 0) {
     p.sk_wgs = 0;
     if (g_sk_mode == 0 || slots <= 0 || slots > SK_MAX_SLOTS) return 0;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
@@ -705,7 +706,11 @@ static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s) {
         // run three to five workgroups per CU, whose last generation speeds up by itself when its neighbours are gone
         const double gens = (double)tiles / slots;
         const double eff = gens / (double)(long long)(gens + 0.999999);
-        if (eff >= 0.9 || nk < 32 || bm != 128 || bn != 128) return 0;
+        if (min_nk > 0) {
+            if (eff >= 0.9 || nk < min_nk) return 0;
+        } else if (eff >= 0.9 || nk < 32 || bm != 128 || bn != 128) {
+            return 0;
+        }
     }
     std::lock_guard<std::mutex> lock(g_sk_mutex);
     SkStream* st = nullptr;
@@ -818,6 +823,8 @@ int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 wave
 }  // namespace
 
 namespace brcnn_conv {
+int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s) { return sk_plan(p, slots, bm, bn, s, 16); }
+
 // fp16 operands: the production tile shapes only (the tuning-hook variants stay bf16)
 static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     p.il = 0;

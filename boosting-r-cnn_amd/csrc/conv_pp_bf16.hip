@@ -37,7 +37,9 @@ template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { retur
 template <int N> using ic = std::integral_constant<int, N>;
 
 // DIL: zero-stuffed input (p.dilate > 1, the data gradient of a strided conv): the general address form
-template <bool RES, bool OUTF32, int ET, bool DIL, int MODE = 0>
+// SK: chained stream-K schedule (ConvParams::sk_*, conv_igemm_bf16.hip): the workgroup's item (tile, K tiles [kb, ke),
+// hand-over slot) comes from the launch's table; a K head stores its accumulators, a K tail starts from them.
+template <bool RES, bool OUTF32, int ET, bool DIL, int MODE = 0, bool SK = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nk = p.K / BKE;
@@ -48,7 +50,18 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    int tile, kb = 0, ke = nk, sk_slot = 0;
+    if constexpr (SK) {
+        const int4 item = p.sk_items[blockIdx.x];
+        tile = __builtin_amdgcn_readfirstlane(item.x);
+        kb = __builtin_amdgcn_readfirstlane(item.y);
+        ke = __builtin_amdgcn_readfirstlane(item.z);
+        sk_slot = __builtin_amdgcn_readfirstlane(item.w);
+        if (tile < 0) return;
+    } else {
+        tile = xcd_remap(blockIdx.x, nwg);
+    }
+    const bool finish = !SK || ke == nk;
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -114,6 +127,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
     const unsigned st_dst = lds0 + (unsigned)wave * 2048u;        // this wave's rows inside a slot
 
     int tA_ci0 = 0, tA_kh = 0, tA_kw = 0;      // filter tap / channel offset of the K tile whose A halves are staged next
+    if constexpr (SK) {
+        if (kb > 0) {
+            const int k0 = kb * BKE, tap = k0 / p.Cin;
+            tA_ci0 = k0 - tap * p.Cin;
+            tA_kh = tap / p.KW;
+            tA_kw = tap - tA_kh * p.KW;
+        }
+    }
     auto advance_tap = [&]() {
         tA_ci0 += BKE;
         if (tA_ci0 >= p.Cin) {
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             // (an out-of-range row offset plus the K offset stays out of range and below 2^32)
-            const int off = kt < nk ? (int)((unsigned)b_off[h][j] + (unsigned)(kt * (BKE * 2))) : OOB;
+            const int off = kt < ke ? (int)((unsigned)b_off[h][j] + (unsigned)(kt * (BKE * 2))) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -225,25 +246,52 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
     auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); };
 
     // ---- prologue: K tiles 0 (slots 0-3: B0 A0 B1 A1) and 1 (slots 4-7: B1 A0 B0 A1), in read order
-    stage_B(0, 0, 0);
+    stage_B(0, 0, kb);
     stage_A(1, 0, true);
-    stage_B(2, 1, 0);
+    stage_B(2, 1, kb);
     stage_A(3, 1, true);
     advance_tap();
-    stage_B(4, 1, 1);
-    stage_A(5, 0, 1 < nk);
-    stage_B(6, 0, 1);
-    stage_A(7, 1, 1 < nk);
-    advance_tap();                                   // -> K tile 2
+    stage_B(4, 1, kb + 1);
+    stage_A(5, 0, kb + 1 < ke);
+    stage_B(6, 0, kb + 1);
+    stage_A(7, 1, kb + 1 < ke);
+    advance_tap();                                   // -> K tile kb + 2
+    if constexpr (SK) {
+        if (kb > 0) {
+            // the K head of this tile, published by a workgroup of the launch's first round: one lane polls (bounded),
+            // one agent-scope acquire, then plain loads into the accumulators (the DMA above stays in flight: these
+            // are ordinary loads the compiler counts itself, issued after it)
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(p.sk_flags + sk_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
+                       ++spins < (1 << 24))
+                    __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_ws) + (size_t)sk_slot * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x4 v = src[((a * NT + b) * 4 + g) * (NW * 64)];
+                        acc[a][b][4 * g + 0] = v.x; acc[a][b][4 * g + 1] = v.y;
+                        acc[a][b][4 * g + 2] = v.z; acc[a][b][4 * g + 3] = v.w;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // accumulators and all eight stages landed
+        }
+    }
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slots 0, 1 of this wave have landed
     barrier();
     read_B(B0r, ic<0>{});                            // "phase 0": B0 of K tile 0
     if (wm == 1) barrier();                          // the second group runs one barrier behind
 
-    const int iters = (nk + 1) >> 1;
+    const int iters = (ke - kb + 1) >> 1;
     for (int it = 0; it < iters; it++) {
-        const int kt = 2 * it;                       // even K tile of this iteration; kt + 1 the odd one
-        const bool odd_ok = kt + 1 < nk;
+        const int kt = kb + 2 * it;                  // even K tile of this iteration; kt + 1 the odd one
+        const bool odd_ok = kt + 1 < ke;
         // phase 1: A0 of the even tile (slot 1) x B0; stage slot 7 = A1 of the odd tile kt+1 (already there in the
         // first iteration: the prologue staged it, and the tap state stands at tile 2)
         read_A(ic<1>{});
@@ -265,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
         barrier();
         // phase 3: A1 (slot 3) x B1; stage slot 1 = A0 of tile kt+2
         read_A(ic<3>{});
-        stage_A(1, 0, kt + 2 < nk);
+        stage_A(1, 0, kt + 2 < ke);
         dma_wait();
         barrier();
         frags_ready();
@@ -281,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
         barrier();
         // phase 5: A0 of the odd tile (slot 5) x B1; stage slot 3 = A1 of tile kt+2
         read_A(ic<5>{});
-        stage_A(3, 1, kt + 2 < nk);
+        stage_A(3, 1, kt + 2 < ke);
         advance_tap();
         dma_wait();
         barrier();
@@ -298,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
         barrier();
         // phase 7: A1 (slot 7) x B0; stage slot 5 = A0 of tile kt+3
         read_A(ic<7>{});
-        stage_A(5, 0, kt + 3 < nk);
+        stage_A(5, 0, kt + 3 < ke);
         dma_wait();
         barrier();
         frags_ready();
@@ -316,6 +364,30 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (wm == 0) barrier();
     barrier();                                       // every wave is past its last fragment read and DMA: the slabs may land
+    if constexpr (SK) {
+        if (!finish) {
+            f32x4* dst = reinterpret_cast<f32x4*>(p.sk_ws) + (size_t)sk_slot * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4 v;
+                        v.x = acc[a][b][4 * g + 0]; v.y = acc[a][b][4 * g + 1];
+                        v.z = acc[a][b][4 * g + 2]; v.w = acc[a][b][4 * g + 3];
+                        dst[((a * NT + b) * 4 + g) * (NW * 64)] = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
 
     // ---- epilogue (conv_igemm_bf16.hip's, the same arithmetic in the same order): lane l holds pixel m = l&31 and, per
     // register group g, four consecutive channels co = 8g + 4(l>>5) + (0..3); one 32-row slab at a time goes through the
@@ -521,12 +593,27 @@ template <bool RES, bool OUTF32, int ET, bool DIL, int MODE = 0>
 int launch_pp2(ConvParams& p, hipStream_t s) {
     constexpr size_t lds = 8 * SLOT;
     static bool attr_done = false;
+    static int num_cus = 0;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE>,
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE, false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        BRCNN_HIP_CHECK(hipGetDevice(&dev));
+        BRCNN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+    // one workgroup per CU (128 KiB of LDS): chained stream-K where the tile count leaves much of the last generation idle
+    const int rc = sk_plan_pp(p, num_cus, BM, BN, s);
+    if (rc) return rc;
+    if (p.sk_wgs > 0) {
+        hipLaunchKernelGGL((conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE, true>), dim3(p.sk_wgs), dim3(512), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_pp_bf16_kernel<RES, OUTF32, ET, DIL, MODE, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+    }
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -558,7 +645,6 @@ int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s) {
     if (p.K < 2 * BKE || (p.K % BKE) || p.KH * p.KW > 32) return BRCNN_EINVAL;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
-    p.sk_wgs = 0;
     if (p.z_out || p.tail_z) return p.f16 ? launch_pp_train<1>(p, s) : launch_pp_train<0>(p, s);
     if (p.f16) {
         if (p.out_f32) return p.residual ? launch_pp<true, true, 1>(p, s) : launch_pp<false, true, 1>(p, s);

@@ -727,6 +727,7 @@ def test_bf16_eight_phase_kernel_multi_level_and_data_gradient():
     (8, 50, 84, 256, 1024, 1, True),
     (8, 25, 42, 512, 512, 3, False),
     (3, 50, 84, 256, 256, 3, True),          # fewer tiles than resident workgroups on most tile shapes: plain launch
+    (8, 100, 168, 256, 256, 3, False),       # 525 tiles of 256 x 256: the eight-phase kernel's stream-K case
 ])
 def test_bf16_stream_k_schedule_is_bit_identical(shape):
     """the chained stream-K schedule (a tile that straddles two workgroup ranges is started by one workgroup and
@@ -743,7 +744,7 @@ def test_bf16_stream_k_schedule_is_bit_identical(shape):
     sh = torch.randn(co, generator=g).to(DEV)
     r = torch.randn(n, h, w_, co, generator=g).bfloat16().to(DEV) if res else None
     try:
-        for t in (0, 11, 21, 81, 82):
+        for t in (0, 11, 21, 81, 82, 8844):
             assert L.brcnn_conv_set_tile_bf16(t) == 0
             assert L.brcnn_conv_set_tile_bf16(-3) == 0
             ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, 1, k // 2)
