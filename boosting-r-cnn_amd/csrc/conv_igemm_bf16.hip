@@ -691,11 +691,11 @@ int sk_table(long long tiles, int nk, int slots, const SkTable** out) {
 
 // the schedule of one launch, or sk_wgs = 0: `slots` = resident workgroups of this kernel on the whole device;
 // `min_nk`: shortest K loop (in K tiles) the heuristic cuts for this tile shape (0: the 128 x 128 rule below)
-static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int min_nk = 0) {
+static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int min_nk = 0, int bke = BKE, double max_eff = 0.9) {
     p.sk_wgs = 0;
     if (g_sk_mode == 0 || slots <= 0 || slots > SK_MAX_SLOTS) return 0;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
-    const int nk = p.K / BKE;
+    const int nk = p.K / bke;
     // every slot must own at least one whole tile's worth of iterations: a tile then straddles two ranges at most
     if (tiles < slots || nk < 2 || tiles * nk >= 0x7fffffffLL) return 0;
     if ((size_t)(slots + 8) * bm * bn * sizeof(float) > SK_WS_BYTES) return 0;
@@ -707,7 +707,7 @@ static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int 
         const double gens = (double)tiles / slots;
         const double eff = gens / (double)(long long)(gens + 0.999999);
         if (min_nk > 0) {
-            if (eff >= 0.9 || nk < min_nk) return 0;
+            if (eff >= max_eff || nk < min_nk) return 0;
         } else if (eff >= 0.9 || nk < 32 || bm != 128 || bn != 128) {
             return 0;
         }
@@ -824,6 +824,8 @@ int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 wave
 
 namespace brcnn_conv {
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s) { return sk_plan(p, slots, bm, bn, s, 16); }
+// fp32 (K tiles of 32 values, 16x the MFMA time per tile): a hand-over is cheap against a tile, any idle CU is not
+int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s) { return sk_plan(p, slots, bm, bn, s, 8, 32, 0.97); }
 
 // fp16 operands: the production tile shapes only (the tuning-hook variants stay bf16)
 static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {

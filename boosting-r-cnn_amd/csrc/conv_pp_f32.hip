@@ -1,0 +1,465 @@
+// fp32 implicit-GEMM convolution (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) on a 256 x 256 x 32 tile with the
+// eight-phase, two-group schedule of conv_pp_bf16.hip (see there for the schedule, the eight half-tile LDS slots, the
+// counted vmcnt and the hazard rules: all identical -- a 128-byte LDS row holds 32 floats instead of 64 bf16).
+//
+// What differs from the 16-bit kernel: a phase's quadrant (two 32-row tiles x one 32-column tile x 32 K values) is
+// 32 MFMAs of 64 matrix-pipe cycles each (2048 cycles against 256), so the load block of the other group disappears
+// behind it entirely; the operands are not swapped (D rows = pixels, D columns = channels, the fp32 two-buffer kernel's
+// layout), and every accumulator sees the K values in that kernel's order (chunk pair kk, element e: k = 8 kk + e and
+// 8 kk + 4 + e per MFMA) -- so the result is bit-identical to conv_igemm_f32_dma_kernel's and the fp32 parity path
+// (BASELINE configs[1]) is unchanged.  Plain epilogue (scale / shift, residual, ReLU); chained stream-K items.
+#include <type_traits>
+#include "conv_common.h"
+
+namespace {
+using namespace brcnn_conv;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int BKE = 32;         // K tile in elements (128 bytes of fp32)
+constexpr int BM = 256, BN = 256, MT = 4, NT = 2, WNW = 4, NW = 8;
+constexpr int SLOT = 16384;         // bytes of one half-tile slot: 128 rows x 128 B
+
+
+template <int N> using ic = std::integral_constant<int, N>;
+
+// DIL: zero-stuffed input (p.dilate > 1, the data gradient of a strided conv): the general address form
+// SK: chained stream-K schedule (ConvParams::sk_*, conv_igemm_bf16.hip): the workgroup's item (tile, K tiles [kb, ke),
+// hand-over slot) comes from the launch's table; a K head stores its accumulators, a K tail starts from them.
+template <bool RES, bool DIL, bool SK>
+__global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nk = p.K / BKE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int tile, kb = 0, ke = nk, sk_slot = 0;
+    if constexpr (SK) {
+        const int4 item = p.sk_items[blockIdx.x];
+        tile = __builtin_amdgcn_readfirstlane(item.x);
+        kb = __builtin_amdgcn_readfirstlane(item.y);
+        ke = __builtin_amdgcn_readfirstlane(item.z);
+        sk_slot = __builtin_amdgcn_readfirstlane(item.w);
+        if (tile < 0) return;
+    } else {
+        tile = xcd_remap(blockIdx.x, nwg);
+    }
+    const bool finish = !SK || ke == nk;
+    const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- staging: per half-tile a wave fills LDS rows [16 wave, 16 wave + 16) with two DMA instructions (8 rows x
+    // 128 B each).  LDS row R of A half h holds tile row (R>>6)*128 + (2h + ((R>>5)&1))*32 + (R&31): the two 32-row
+    // MFMA tiles 2h, 2h+1 of both wave groups; LDS row R of B half h holds output column (R>>5)*64 + h*32 + (R&31).
+    const int rg = lane >> 3, pc = lane & 7;
+    // Per staged A row: the byte offset of its (kh, kw) = (0, 0) tap, the byte stride of an input row, and one validity
+    // bit per filter tap (row inside M, tap inside the map) -- a stage is then one multiply-add, one add and a select
+    // per DMA instruction instead of the unpack / four compares / multiply chain (the load block of a phase has to
+    // fit beside the other group's 256 cycles of MFMAs).  Zero-stuffed inputs (dilate > 1: data gradient of a
+    // strided conv) keep the general form.
+    int a_off[2][2], b_off[2][2], lc[2];
+    int a_ws[DIL ? 1 : 2][2];           // !DIL: byte stride of an input row
+    unsigned a_mask[2][2];
+    int a_hw[DIL ? 2 : 1][2], a_HW[DIL ? 2 : 1][2];         // DIL only: packed (hi0, wi0), (H, W)
+#pragma unroll
+    for (int j = 0; j < 2; j++) lc[j] = (pc ^ ((4 * j + (lane >> 4)) & 7)) * 4;     // floats
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int R = 16 * wave + 8 * j + rg;
+            const int m = m0 + (R >> 6) * 128 + (2 * h + ((R >> 5) & 1)) * 32 + (R & 31);
+            a_off[h][j] = 0;
+            a_mask[h][j] = 0u;
+            if constexpr (DIL) { a_hw[h][j] = 0; a_HW[h][j] = 0; }
+            else a_ws[h][j] = 0;
+            if (m < p.M) {
+                int sg = 0;
+#pragma unroll
+                for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
+                    if (t < p.nseg && m >= p.seg_m0[t]) sg = t;
+                const int ml = m - p.seg_m0[sg];
+                const int Ho = p.seg_Ho[sg], Wo = p.seg_Wo[sg], H = p.seg_H[sg], W = p.seg_W[sg];
+                const int n = ml / (Ho * Wo);
+                const int rem = ml - n * (Ho * Wo);
+                const int ho = rem / Wo, wo = rem - ho * Wo;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                const int base = (int)p.seg_xoff[sg] + n * H * W * p.pitch;
+                if constexpr (DIL) {
+                    a_HW[h][j] = (H << 16) | W;
+                    a_off[h][j] = base;
+                    a_hw[h][j] = ((hi0 + 4096) << 16) | (wi0 + 4096);
+                    a_mask[h][j] = 1u;
+                } else {
+                    a_off[h][j] = (base + (hi0 * W + wi0) * p.pitch + lc[j] + tile_n * p.gstep) * 4;
+                    a_ws[h][j] = W * p.pitch * 4;
+                    unsigned mk = 0u;
+                    for (int kh = 0; kh < p.KH; kh++)
+                        for (int kw = 0; kw < p.KW; kw++)
+                            if ((unsigned)(hi0 + kh) < (unsigned)H && (unsigned)(wi0 + kw) < (unsigned)W) mk |= 1u << (kh * p.KW + kw);
+                    a_mask[h][j] = mk;
+                }
+            }
+            const int co = n0 + (R >> 5) * 64 + h * 32 + (R & 31);
+            b_off[h][j] = (co < p.Cout) ? (co * p.K + lc[j]) * 4 : OOB;
+        }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned st_dst = lds0 + (unsigned)wave * 2048u;        // this wave's rows inside a slot
+
+    int tA_ci0 = 0, tA_kh = 0, tA_kw = 0;      // filter tap / channel offset of the K tile whose A halves are staged next
+    if constexpr (SK) {
+        if (kb > 0) {
+            const int k0 = kb * BKE, tap = k0 / p.Cin;
+            tA_ci0 = k0 - tap * p.Cin;
+            tA_kh = tap / p.KW;
+            tA_kw = tap - tA_kh * p.KW;
+        }
+    }
+    auto advance_tap = [&]() {
+        tA_ci0 += BKE;
+        if (tA_ci0 >= p.Cin) {
+            tA_ci0 = 0;
+            if (++tA_kw == p.KW) { tA_kw = 0; tA_kh++; }
+        }
+    };
+    auto stage_A = [&](int slot, int h, bool valid) {
+        if constexpr (!DIL) {
+            const int tap = tA_kh * p.KW + tA_kw;                   // scalar
+            const int s_off = (tA_kw * p.pitch + tA_ci0) * 4;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const bool ok = valid & (((a_mask[h][j] >> tap) & 1u) != 0u);
+                const int off = ok ? a_off[h][j] + tA_kh * a_ws[h][j] + s_off : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int hi = (a_hw[h][j] >> 16) - 4096 + tA_kh;
+            int wi = (a_hw[h][j] & 0xffff) - 4096 + tA_kw;
+            bool ok = valid & (a_mask[h][j] != 0u) & (hi >= 0) & (wi >= 0);
+            const int qh = hi / p.dilate, qw = wi / p.dilate;
+            ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
+            hi = qh;
+            wi = qw;
+            const int H = a_HW[h][j] >> 16, W = a_HW[h][j] & 0xffff;
+            ok = ok & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
+            const int off = ok ? (a_off[h][j] + (hi * W + wi) * p.pitch + tA_ci0 + lc[j] + tile_n * p.gstep) * 4 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+        }
+        }
+    };
+    auto stage_B = [&](int slot, int h, int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            // (an out-of-range row offset plus the K offset stays out of range and below 2^32)
+            const int off = kt < ke ? (int)((unsigned)b_off[h][j] + (unsigned)(kt * (BKE * 4))) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment reads: lane (li, lh) reads row li of a 32-row MFMA tile, chunk (2 kk + lh) ^ ((li >> 1) & 7)
+    const int sw = (li >> 1) & 7;
+    unsigned a_rd[4], b_rd[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const unsigned ch = (unsigned)(((2 * kk + lh) ^ sw) * 16);
+        a_rd[kk] = lds0 + (unsigned)(wm * 64 + li) * 128u + ch;
+        b_rd[kk] = lds0 + (unsigned)(wn * 32 + li) * 128u + ch;
+    }
+    f32x4 Ar[2][4], B0r[4], B1r[4];
+    // slots 4..7 lie beyond the 16-bit offset field: their reads add 64 KiB to the address register
+    auto rd = [&](f32x4& d, unsigned addr, auto off_c) {
+        constexpr int OFF = decltype(off_c)::value;
+        if constexpr (OFF < 65536) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+        } else {
+            const unsigned hi = addr + 65536u;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(hi), "n"(OFF - 65536) : "memory");
+        }
+    };
+    auto read_A = [&](auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            rd(Ar[0][kk], a_rd[kk], ic<S * SLOT>{});
+            rd(Ar[1][kk], a_rd[kk], ic<S * SLOT + 4096>{});
+        }
+    };
+    auto read_B = [&](f32x4 (&Br)[4], auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) rd(Br[kk], b_rd[kk], ic<S * SLOT>{});
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int b = 0; b < NT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    // quadrant (MFMA tiles tm0, tm0+1) x tn: 32 MFMAs; per accumulator the (kk, e) order of conv_igemm_f32_dma_kernel
+    auto mfma_quad = [&](auto tm0_c, auto tn_c, f32x4 (&Br)[4]) {
+        constexpr int TM0 = decltype(tm0_c)::value, TN = decltype(tn_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                    acc[TM0 + t][TN] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar[t][kk][e], Br[kk][e], acc[TM0 + t][TN], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
+    // the fragment registers of this phase are complete: wait, then pin every later use below the wait
+    auto frags_ready = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); };
+
+    // ---- prologue: K tiles 0 (slots 0-3: B0 A0 B1 A1) and 1 (slots 4-7: B1 A0 B0 A1), in read order
+    stage_B(0, 0, kb);
+    stage_A(1, 0, true);
+    stage_B(2, 1, kb);
+    stage_A(3, 1, true);
+    advance_tap();
+    stage_B(4, 1, kb + 1);
+    stage_A(5, 0, kb + 1 < ke);
+    stage_B(6, 0, kb + 1);
+    stage_A(7, 1, kb + 1 < ke);
+    advance_tap();                                   // -> K tile kb + 2
+    if constexpr (SK) {
+        if (kb > 0) {
+            // the K head of this tile, published by a workgroup of the launch's first round: one lane polls (bounded),
+            // one agent-scope acquire, then plain loads into the accumulators (the DMA above stays in flight: these
+            // are ordinary loads the compiler counts itself, issued after it)
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(p.sk_flags + sk_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
+                       ++spins < (1 << 24))
+                    __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_ws) + (size_t)sk_slot * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x4 v = src[((a * NT + b) * 4 + g) * (NW * 64)];
+                        acc[a][b][4 * g + 0] = v.x; acc[a][b][4 * g + 1] = v.y;
+                        acc[a][b][4 * g + 2] = v.z; acc[a][b][4 * g + 3] = v.w;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // accumulators and all eight stages landed
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slots 0, 1 of this wave have landed
+    barrier();
+    read_B(B0r, ic<0>{});                            // "phase 0": B0 of K tile 0
+    if (wm == 1) barrier();                          // the second group runs one barrier behind
+
+    const int iters = (ke - kb + 1) >> 1;
+    for (int it = 0; it < iters; it++) {
+        const int kt = kb + 2 * it;                  // even K tile of this iteration; kt + 1 the odd one
+        const bool odd_ok = kt + 1 < ke;
+        // phase 1: A0 of the even tile (slot 1) x B0; stage slot 7 = A1 of the odd tile kt+1 (already there in the
+        // first iteration: the prologue staged it, and the tap state stands at tile 2)
+        read_A(ic<1>{});
+        // (no DMA is issued there: the prologue's eight stages stand for phases -6 .. 1, so vmcnt(10) still means
+        // "everything up to five stages back has landed")
+        if (it > 0) { stage_A(7, 1, odd_ok); advance_tap(); }
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<0>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 2: x B1 (slot 2); stage slot 0 = B0 of tile kt+2
+        read_B(B1r, ic<2>{});
+        stage_B(0, 0, kt + 2);
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<0>{}, ic<1>{}, B1r);
+        barrier();
+        // phase 3: A1 (slot 3) x B1; stage slot 1 = A0 of tile kt+2
+        read_A(ic<3>{});
+        stage_A(1, 0, kt + 2 < ke);
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<2>{}, ic<1>{}, B1r);
+        barrier();
+        // phase 4: A1 x B0; read B1 of the odd tile (slot 4); stage slot 2 = B1 of tile kt+2
+        read_B(B1r, ic<4>{});
+        stage_B(2, 1, kt + 2);
+        dma_wait();
+        barrier();
+        frags_ready();
+        mfma_quad(ic<2>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 5: A0 of the odd tile (slot 5) x B1; stage slot 3 = A1 of tile kt+2
+        read_A(ic<5>{});
+        stage_A(3, 1, kt + 2 < ke);
+        advance_tap();
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<0>{}, ic<1>{}, B1r);
+        barrier();
+        // phase 6: x B0 (slot 6); stage slot 4 = B1 of tile kt+3
+        read_B(B0r, ic<6>{});
+        stage_B(4, 1, kt + 3);
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<0>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 7: A1 (slot 7) x B0; stage slot 5 = A0 of tile kt+3
+        read_A(ic<7>{});
+        stage_A(5, 0, kt + 3 < ke);
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<2>{}, ic<0>{}, B0r);
+        barrier();
+        // phase 8: A1 x B1; read B0 of the next even tile (slot 0); stage slot 6 = B0 of tile kt+3
+        read_B(B0r, ic<0>{});
+        stage_B(6, 0, kt + 3);
+        dma_wait();
+        barrier();
+        frags_ready();
+        if (odd_ok) mfma_quad(ic<2>{}, ic<1>{}, B1r);
+        barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (wm == 0) barrier();
+    barrier();                                       // every wave is past its last fragment read and DMA: the slabs may land
+    if constexpr (SK) {
+        if (!finish) {
+            f32x4* dst = reinterpret_cast<f32x4*>(p.sk_ws) + (size_t)sk_slot * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < MT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4 v;
+                        v.x = acc[a][b][4 * g + 0]; v.y = acc[a][b][4 * g + 1];
+                        v.z = acc[a][b][4 * g + 2]; v.w = acc[a][b][4 * g + 3];
+                        dst[((a * NT + b) * 4 + g) * (NW * 64)] = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
+
+    // ---- epilogue (conv_igemm_f32_dma_kernel's arithmetic): scale / shift in the accumulator layout (column = lane & 31 =
+    // channel, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = pixels); each wave transposes one 32 x 32 tile at a time
+    // through a private 4 KiB slab so that residual loads and result stores are 16-byte pieces of NHWC rows
+    float* slab = smem + wave * 1024;
+    const int vrow = lane >> 3, vcol = (lane & 7) * 4;
+    const float* __restrict__ res = p.residual;
+    float* __restrict__ yout = p.y;
+#pragma unroll
+    for (int tn = 0; tn < NT; tn++) {
+        const int co = n0 + wn * 32 * NT + tn * 32 + li;
+        const bool cok = co < p.Cout;
+        const float sc = (p.scale && cok) ? p.scale[co] : 1.f;
+        const float sh = (p.shift && cok) ? p.shift[co] : 0.f;
+        const int cv = n0 + wn * 32 * NT + tn * 32 + vcol;
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) {
+            float4 rv[4];
+            if (RES) {
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int m = m0 + wm * 32 * MT + tm * 32 + it * 8 + vrow;
+                    rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cv < p.Cout && m < p.M) rv[it] = *reinterpret_cast<const float4*>(res + (size_t)m * p.Cout + cv);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = acc[tm][tn][r];
+                if (p.scale) v = v * sc;
+                slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = v + sh;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int row = it * 8 + vrow;
+                const int m = m0 + wm * 32 * MT + tm * 32 + row;
+                float4 v = *reinterpret_cast<const float4*>(slab + row * 32 + vcol);
+                if (RES) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (cv < p.Cout && m < p.M) {
+                    const long long ro = out_row_offset(p, m);
+                    if (ro >= 0) *reinterpret_cast<float4*>(yout + ro + cv) = v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <bool RES, bool DIL>
+int launch_pp_f32(ConvParams& p, hipStream_t s) {
+    constexpr size_t lds = 8 * SLOT;
+    static bool attr_done = false;
+    static int num_cus = 0;
+    if (!attr_done) {
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        BRCNN_HIP_CHECK(hipGetDevice(&dev));
+        BRCNN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount;
+        attr_done = true;
+    }
+    // one workgroup per CU; a tile is ~0.2 ms of MFMA work per 1000 K values, so a partly filled last generation is
+    // expensive: chained stream-K whenever the tile count allows it
+    const int rc = sk_plan_pp_f32(p, num_cus, BM, BN, s);
+    if (rc) return rc;
+    if (p.sk_wgs > 0)
+        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, true>), dim3(p.sk_wgs), dim3(512), lds, s, p);
+    else
+        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+    BRCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+namespace brcnn_conv {
+// 256 x 256 tile, eight-phase schedule, exact-fp32 MFMA; plain epilogue
+int dispatch_conv_pp_f32(ConvParams& p, hipStream_t s) {
+    if (p.K < 2 * BKE || (p.K % BKE) || (p.Cin % BKE) || p.KH * p.KW > 32 || (p.Cout & 3) || p.z_out || p.tail_z) return BRCNN_EINVAL;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    if (p.dilate > 1) return p.residual ? BRCNN_EINVAL : launch_pp_f32<false, true>(p, s);      // (no caller pairs the two)
+    return p.residual ? launch_pp_f32<true, false>(p, s) : launch_pp_f32<false, false>(p, s);
+}
+}  // namespace brcnn_conv

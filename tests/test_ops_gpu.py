@@ -926,3 +926,64 @@ def test_roi_extract_16bit_training_path(dtype):
         # same fp32 accumulation order in both runs; the 16-bit run rounds once at the store
         assert torch.equal(a, b.to(dtype).float())
 
+
+
+@pytest.mark.parametrize('cfg', [
+    # N, H, W, Cin, Cout, k, stride, pad, residual
+    (2, 50, 84, 256, 256, 3, 1, 1, False),        # 72 K tiles of 32
+    (2, 50, 84, 96, 256, 3, 1, 1, True),          # 27 K tiles (odd), residual
+    (3, 25, 42, 160, 512, 1, 1, 0, False),        # 5 K tiles, ragged row tiles
+    (2, 51, 85, 64, 256, 3, 2, 1, False),         # stride 2
+    (8, 50, 84, 256, 1024, 1, 1, 0, True),        # 528 tiles: the chained stream-K schedule in the heuristic
+])
+def test_f32_eight_phase_kernel_is_bit_identical(cfg):
+    """the fp32 256 x 256 eight-phase kernel (conv_pp_f32.hip) keeps the two-buffer kernel's K order per accumulator:
+    identical results (plain and stream-K launches, K-tile count parities, strides, residual), launch after launch"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    n, h, w_, ci, co, k, stride, pad, res = cfg
+    g = torch.Generator().manual_seed(35)
+    x = torch.randn(n, h, w_, ci, generator=g).to(DEV)
+    w = (torch.randn(co, k, k, ci, generator=g) * 0.05).to(DEV)
+    sc = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(co, generator=g).to(DEV)
+    ho, wo = ops.conv_out_size(h, w_, k, k, stride, pad)
+    r = torch.randn(n, ho, wo, co, generator=g).to(DEV) if res else None
+    try:
+        assert L.brcnn_conv_set_tile(-2, 0) == 0
+        ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
+        assert L.brcnn_conv_set_tile(-2, 2) == 0
+        for sk in (-3, -5, -4):
+            assert L.brcnn_conv_set_tile_bf16(sk) == 0
+            for rep in range(2):
+                out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
+                assert torch.equal(out, ref), (sk, rep, (out - ref).abs().max().item())
+    finally:
+        L.brcnn_conv_set_tile(-2, 1)
+        L.brcnn_conv_set_tile_bf16(-4)
+
+
+def test_f32_eight_phase_kernel_data_gradient():
+    """the zero-stuffed data gradient of a stride-2 conv (DIL form) and the five-level launch on the fp32 eight-phase kernel"""
+    from brcnn import lib as _lib
+    from brcnn.autograd import conv2d_nhwc_autograd
+    L = _lib.load()
+    g = torch.Generator().manual_seed(36)
+    sizes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
+    B, C = 2, 256
+    xc = torch.cat([torch.randn(B, h, w, C, generator=g).reshape(-1, C) for h, w in sizes], 0).to(DEV)
+    wt = (torch.randn(C, 3, 3, C, generator=g) / 48).to(DEV)
+    dy = torch.randn(2, 25, 42, 256, generator=g).to(DEV)
+    w2 = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
+    try:
+        outs = {}
+        for mode in (0, 2):
+            assert L.brcnn_conv_set_tile(-2, mode) == 0
+            y, _ = ops.conv2d_nhwc_multi(xc, wt, B, sizes, None, None, None, False, 1, 1)
+            x = torch.randn(2, 50, 84, 256, generator=torch.Generator().manual_seed(37)).to(DEV).requires_grad_(True)
+            z = conv2d_nhwc_autograd(x, w2.clone().requires_grad_(True), None, 2, 1)
+            z.backward(dy)
+            outs[mode] = (y, x.grad.clone())
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    finally:
+        L.brcnn_conv_set_tile(-2, 1)
