@@ -596,7 +596,7 @@ int launch_res(const ConvParams& p, hipStream_t s) {
 int g_use_dma = 1;                      // LDS-DMA staged kernel for the FAST path
 int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 = heuristic
 
-int g_pp_f32_mode = 1;      // tuning hook (brcnn_conv_set_tile(-2, 0 / 1 / 2)): eight-phase fp32 kernel never / heuristic / forced
+int g_pp_f32_mode = 1;      // tuning hook (brcnn_conv_set_tile(-2, 0 / 1 / 2 / 128 / 256)): eight-phase fp32 kernel never / heuristic / forced (tile rows by the heuristic / 128 / 256)
 
 int dispatch_conv(ConvParams& p, hipStream_t s) {
     const bool fast = (p.Cin % 32 == 0);
@@ -605,8 +605,10 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
     // chained stream-K schedule evens out the last generation)
     if (fast && g_pp_f32_mode && g_force_wm == 0 && g_force_nt == 0 && !p.gstep && (p.Cout % 256) == 0 && p.K >= 256 &&
         p.KH * p.KW <= 32 && !(p.dilate > 1 && p.residual)) {
-        const long long t88 = (long long)((p.M + 255) / 256) * (p.Cout / 256);
-        if (g_pp_f32_mode == 2 || t88 >= 208) return dispatch_conv_pp_f32(p, s);
+        // (128-row tiles where 256-row ones would leave CUs idle: the stage-3 / stage-4 maps)
+        const long long t48 = (long long)((p.M + 127) / 128) * (p.Cout / 256);
+        p.pp_rows = g_pp_f32_mode >= 128 ? g_pp_f32_mode : 0;
+        if (g_pp_f32_mode >= 2 || t48 >= 208) return dispatch_conv_pp_f32(p, s);
     }
     // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the SMALLEST tile,
     // 64x64 (4 waves x one 32x32 MFMA tile, 32 KiB LDS -> up to 5 resident workgroups / CU,
@@ -643,7 +645,7 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
     if (wm == -1) { g_use_dma = nt; return 0; }   // (-1, 0/1/2): register-staged / heuristic / always LDS-DMA
-    if (wm == -2) { if (nt < 0 || nt > 2) return BRCNN_EINVAL; g_pp_f32_mode = nt; return 0; }
+    if (wm == -2) { if (nt != 0 && nt != 1 && nt != 2 && nt != 128 && nt != 256) return BRCNN_EINVAL; g_pp_f32_mode = nt; return 0; }
     if ((wm != 0 && wm != 1 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
     g_force_wm = wm;
     g_force_nt = nt;

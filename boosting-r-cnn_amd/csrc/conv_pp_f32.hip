@@ -16,7 +16,7 @@ using namespace brcnn_conv;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int BKE = 32;         // K tile in elements (128 bytes of fp32)
-constexpr int BM = 256, BN = 256, MT = 4, NT = 2, WNW = 4, NW = 8;
+constexpr int BN = 256, NT = 2, WNW = 4, NW = 8;
 constexpr int SLOT = 16384;         // bytes of one half-tile slot: 128 rows x 128 B
 
 
@@ -25,8 +25,14 @@ template <int N> using ic = std::integral_constant<int, N>;
 // DIL: zero-stuffed input (p.dilate > 1, the data gradient of a strided conv): the general address form
 // SK: chained stream-K schedule (ConvParams::sk_*, conv_igemm_bf16.hip): the workgroup's item (tile, K tiles [kb, ke),
 // hand-over slot) comes from the launch's table; a K head stores its accumulators, a K tail starts from them.
-template <bool RES, bool DIL, bool SK>
+// MT: 32-row MFMA tiles per wave along M -- 4: 256 x 256 tile, 2: 128 x 256 (the layers whose 256-row tiles would not
+// cover the device; an fp32 phase is still 16 MFMAs = 1024 matrix-pipe cycles)
+template <bool RES, bool DIL, bool SK, int MT>
 __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
+    constexpr int BM = 64 * MT;
+    constexpr int HT = MT / 2;                      // MFMA tiles of one A half per wave
+    constexpr int AHW = 32 * HT;                    // rows one wave group owns in an A half-slot
+    static_assert(MT == 4 || MT == 2, "256- or 128-row tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nk = p.K / BKE;
     const int tid = threadIdx.x;
@@ -63,18 +69,28 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     // per DMA instruction instead of the unpack / four compares / multiply chain (the load block of a phase has to
     // fit beside the other group's 256 cycles of MFMAs).  Zero-stuffed inputs (dilate > 1: data gradient of a
     // strided conv) keep the general form.
-    int a_off[2][2], b_off[2][2], lc[2];
-    int a_ws[DIL ? 1 : 2][2];           // !DIL: byte stride of an input row
-    unsigned a_mask[2][2];
-    int a_hw[DIL ? 2 : 1][2], a_HW[DIL ? 2 : 1][2];         // DIL only: packed (hi0, wi0), (H, W)
+    int a_off[2][HT], b_off[2][2], lc[2], lca[HT];
+    int a_ws[DIL ? 1 : 2][HT];          // !DIL: byte stride of an input row
+    unsigned a_mask[2][HT];
+    int a_hw[DIL ? 2 : 1][HT], a_HW[DIL ? 2 : 1][HT];       // DIL only: packed (hi0, wi0), (H, W)
 #pragma unroll
     for (int j = 0; j < 2; j++) lc[j] = (pc ^ ((4 * j + (lane >> 4)) & 7)) * 4;     // floats
+#pragma unroll
+    for (int j = 0; j < HT; j++) lca[j] = (pc ^ ((4 * ((wave * HT + j) & 1) + (lane >> 4)) & 7)) * 4;
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int R = 16 * wave + 8 * j + rg;
-            const int m = m0 + (R >> 6) * 128 + (2 * h + ((R >> 5) & 1)) * 32 + (R & 31);
+            const int co = n0 + (R >> 5) * 64 + h * 32 + (R & 31);
+            b_off[h][j] = (co < p.Cout) ? (co * p.K + lc[j]) * 4 : OOB;
+        }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j = 0; j < HT; j++) {
+            const int R = 8 * (wave * HT + j) + rg;          // row of the A half-slot (2 * AHW rows)
+            const int m = m0 + (R / AHW) * (32 * MT) + (h * HT + (R % AHW) / 32) * 32 + (R & 31);
             a_off[h][j] = 0;
             a_mask[h][j] = 0u;
             if constexpr (DIL) { a_hw[h][j] = 0; a_HW[h][j] = 0; }
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
                     a_hw[h][j] = ((hi0 + 4096) << 16) | (wi0 + 4096);
                     a_mask[h][j] = 1u;
                 } else {
-                    a_off[h][j] = (base + (hi0 * W + wi0) * p.pitch + lc[j] + tile_n * p.gstep) * 4;
+                    a_off[h][j] = (base + (hi0 * W + wi0) * p.pitch + lca[j] + tile_n * p.gstep) * 4;
                     a_ws[h][j] = W * p.pitch * 4;
                     unsigned mk = 0u;
                     for (int kh = 0; kh < p.KH; kh++)
@@ -106,11 +122,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
                     a_mask[h][j] = mk;
                 }
             }
-            const int co = n0 + (R >> 5) * 64 + h * 32 + (R & 31);
-            b_off[h][j] = (co < p.Cout) ? (co * p.K + lc[j]) * 4 : OOB;
         }
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
-    const unsigned st_dst = lds0 + (unsigned)wave * 2048u;        // this wave's rows inside a slot
+    const unsigned st_dst = lds0 + (unsigned)wave * 2048u;        // this wave's rows inside a B slot (two pieces)
+    const unsigned sta_dst = lds0 + (unsigned)wave * (HT * 1024u);  // ... inside an A slot (HT pieces)
 
     int tA_ci0 = 0, tA_kh = 0, tA_kw = 0;      // filter tap / channel offset of the K tile whose A halves are staged next
     if constexpr (SK) {
@@ -133,14 +148,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
             const int tap = tA_kh * p.KW + tA_kw;                   // scalar
             const int s_off = (tA_kw * p.pitch + tA_ci0) * 4;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < HT; j++) {
                 const bool ok = valid & (((a_mask[h][j] >> tap) & 1u) != 0u);
                 const int off = ok ? a_off[h][j] + tA_kh * a_ws[h][j] + s_off : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(sta_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
             }
         } else {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < HT; j++) {
             int hi = (a_hw[h][j] >> 16) - 4096 + tA_kh;
             int wi = (a_hw[h][j] & 0xffff) - 4096 + tA_kw;
             bool ok = valid & (a_mask[h][j] != 0u) & (hi >= 0) & (wi >= 0);
@@ -150,8 +165,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
             wi = qw;
             const int H = a_HW[h][j] >> 16, W = a_HW[h][j] & 0xffff;
             ok = ok & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
-            const int off = ok ? (a_off[h][j] + (hi * W + wi) * p.pitch + tA_ci0 + lc[j] + tile_n * p.gstep) * 4 : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(st_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
+            const int off = ok ? (a_off[h][j] + (hi * W + wi) * p.pitch + tA_ci0 + lca[j] + tile_n * p.gstep) * 4 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(sta_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
         }
         }
     };
@@ -170,10 +185,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
         const unsigned ch = (unsigned)(((2 * kk + lh) ^ sw) * 16);
-        a_rd[kk] = lds0 + (unsigned)(wm * 64 + li) * 128u + ch;
+        a_rd[kk] = lds0 + (unsigned)(wm * AHW + li) * 128u + ch;
         b_rd[kk] = lds0 + (unsigned)(wn * 32 + li) * 128u + ch;
     }
-    f32x4 Ar[2][4], B0r[4], B1r[4];
+    f32x4 Ar[HT][4], B0r[4], B1r[4];
     // slots 4..7 lie beyond the 16-bit offset field: their reads add 64 KiB to the address register
     auto rd = [&](f32x4& d, unsigned addr, auto off_c) {
         constexpr int OFF = decltype(off_c)::value;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             rd(Ar[0][kk], a_rd[kk], ic<S * SLOT>{});
-            rd(Ar[1][kk], a_rd[kk], ic<S * SLOT + 4096>{});
+            if constexpr (HT == 2) rd(Ar[1][kk], a_rd[kk], ic<S * SLOT + 4096>{});
         }
     };
     auto read_B = [&](f32x4 (&Br)[4], auto slot_c) {
@@ -206,16 +221,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    // quadrant (MFMA tiles tm0, tm0+1) x tn: 32 MFMAs; per accumulator the (kk, e) order of conv_igemm_f32_dma_kernel
-    auto mfma_quad = [&](auto tm0_c, auto tn_c, f32x4 (&Br)[4]) {
-        constexpr int TM0 = decltype(tm0_c)::value, TN = decltype(tn_c)::value;
+    // quadrant (A half `ah`: MFMA tiles ah HT .. ah HT + HT - 1) x tn: 16 HT MFMAs; per accumulator the (kk, e) order of
+    // conv_igemm_f32_dma_kernel
+    auto mfma_quad = [&](auto ah_c, auto tn_c, f32x4 (&Br)[4]) {
+        constexpr int TM0 = (decltype(ah_c)::value / 2) * HT, TN = decltype(tn_c)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int t = 0; t < 2; t++)
+                for (int t = 0; t < HT; t++)
                     acc[TM0 + t][TN] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar[t][kk][e], Br[kk][e], acc[TM0 + t][TN], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -225,7 +241,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); };
+    // five stages stay in flight; they alternate A (HT instructions) and B (2): the smaller of the two window sums
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HT == 2 ? 10 : 7) : "memory"); };
 
     // ---- prologue: K tiles 0 (slots 0-3: B0 A0 B1 A1) and 1 (slots 4-7: B1 A0 B0 A1), in read order
     stage_B(0, 0, kb);
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // accumulators and all eight stages landed
         }
     }
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slots 0, 1 of this wave have landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * HT + 6) : "memory");      // slots 0, 1 of this wave have landed
     barrier();
     read_B(B0r, ic<0>{});                            // "phase 0": B0 of K tile 0
     if (wm == 1) barrier();                          // the second group runs one barrier behind
@@ -424,14 +441,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     }
 }
 
-template <bool RES, bool DIL>
+template <bool RES, bool DIL, int MT>
 int launch_pp_f32(ConvParams& p, hipStream_t s) {
+    constexpr int BM = 64 * MT;
     constexpr size_t lds = 8 * SLOT;
     static bool attr_done = false;
     static int num_cus = 0;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, true, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         BRCNN_HIP_CHECK(hipGetDevice(&dev));
@@ -444,9 +462,9 @@ int launch_pp_f32(ConvParams& p, hipStream_t s) {
     const int rc = sk_plan_pp_f32(p, num_cus, BM, BN, s);
     if (rc) return rc;
     if (p.sk_wgs > 0)
-        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, true>), dim3(p.sk_wgs), dim3(512), lds, s, p);
+        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, true, MT>), dim3(p.sk_wgs), dim3(512), lds, s, p);
     else
-        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, false, MT>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -457,9 +475,17 @@ namespace brcnn_conv {
 // 256 x 256 tile, eight-phase schedule, exact-fp32 MFMA; plain epilogue
 int dispatch_conv_pp_f32(ConvParams& p, hipStream_t s) {
     if (p.K < 2 * BKE || (p.K % BKE) || (p.Cin % BKE) || p.KH * p.KW > 32 || (p.Cout & 3) || p.z_out || p.tail_z) return BRCNN_EINVAL;
-    p.tiles_m = (p.M + BM - 1) / BM;
+    // 256-row tiles where they cover the device, else 128-row tiles
     p.tiles_n = (p.Cout + BN - 1) / BN;
-    if (p.dilate > 1) return p.residual ? BRCNN_EINVAL : launch_pp_f32<false, true>(p, s);      // (no caller pairs the two)
-    return p.residual ? launch_pp_f32<true, false>(p, s) : launch_pp_f32<false, false>(p, s);
+    const long long t256 = (long long)((p.M + 255) / 256) * p.tiles_n;
+    const bool big = t256 >= 208 || p.pp_rows == 256;
+    if (p.pp_rows == 128 ? false : big) {
+        p.tiles_m = (p.M + 255) / 256;
+        if (p.dilate > 1) return p.residual ? BRCNN_EINVAL : launch_pp_f32<false, true, 4>(p, s);      // (no caller pairs the two)
+        return p.residual ? launch_pp_f32<true, false, 4>(p, s) : launch_pp_f32<false, false, 4>(p, s);
+    }
+    p.tiles_m = (p.M + 127) / 128;
+    if (p.dilate > 1) return p.residual ? BRCNN_EINVAL : launch_pp_f32<false, true, 2>(p, s);
+    return p.residual ? launch_pp_f32<true, false, 2>(p, s) : launch_pp_f32<false, false, 2>(p, s);
 }
 }  // namespace brcnn_conv

@@ -231,7 +231,10 @@ int brcnn_conv2d_nhwc_scatter2(const void *x, const void *w, void *y, int batch,
 
 /* Tuning hook: force the workgroup tile (wm: 2 -> 128 rows, 4 -> 256 rows; nt: 1 -> 64
  * columns, 2 -> 128 columns; 0 -> built-in heuristic).  Process-wide; used by the
- * benchmarking scripts (tools/conv_bench.py). */
+ * benchmarking scripts (tools/conv_bench.py).  (-1, 0/1/2): register-staged / heuristic / LDS-DMA
+ * staging.  (-2, 0 / 1 / 2 / 128 / 256): the eight-phase fp32 kernel (csrc/conv_pp_f32.hip: 256- or
+ * 128-row x 256-column tiles, two wave groups alternating MFMA and load blocks, chained stream-K) never /
+ * by the heuristic / forced, forced with 128- / 256-row tiles.  Every choice gives the same bits. */
 int brcnn_conv_set_tile(int wm, int nt);
 
 /* Tuning hook of the bf16 kernel: 0 heuristic; 11 / 21 / 22 = 64x64 / 128x64 / 128x128 tile on
@@ -239,7 +242,10 @@ int brcnn_conv_set_tile(int wm, int nt);
  * waves); 381 / 382 / 3164 / 322 / 342 = the same tiles on a 3-deep LDS ring with counted
  * vmcnt waits, 482 = 4-deep (measured slower than two double-buffered workgroups per CU:
  * profiles/r01_notes.md).  -1 / -2: spread the LDS-DMA pieces of the next K tile between the MFMA
- * groups / issue them in front of the tile (default). */
+ * groups / issue them in front of the tile (default).  8844: the 256x256 eight-phase kernel
+ * (csrc/conv_pp_bf16.hip).  -3 / -4 / -5: chained stream-K schedule (a tile cut between two workgroups
+ * continues from the stored fp32 accumulators; bit-identical) off / by the heuristic / wherever the
+ * tile count allows it.  -6 / -7: eight-phase kernel never / by the heuristic. */
 int brcnn_conv_set_tile_bf16(int mtnt);
 
 /* The same convolution over `num_segments` feature maps that share one set of weights (the
@@ -291,7 +297,9 @@ int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int b
  * `dtype`; either output may be NULL. */
 int brcnn_pack_conv_weights(const float *weight, void *fwd, void *dgrad, int cout, int cin, int kh, int kw,
                             int dtype, void *stream);
-/* tuning hook of the bf16 wgrad kernel: 0 heuristic, 1 = 64x64 output tile, 2 = 128x128 */
+/* tuning hook of the bf16 wgrad kernel: 0 heuristic, 1 = 64x64 output tile, 2 = 128x128, 4 = 256x256 (16 waves);
+ * 10 / 11: the M slices of a tile are reduced with fp32 atomics / through per-workgroup slabs and a fixed-order
+ * second stage (default: reproducible bit for bit, faster) */
 int brcnn_conv_set_tile_wgrad_bf16(int wt);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel NCHW image + folded BN +

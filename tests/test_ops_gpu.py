@@ -952,12 +952,13 @@ def test_f32_eight_phase_kernel_is_bit_identical(cfg):
     try:
         assert L.brcnn_conv_set_tile(-2, 0) == 0
         ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
-        assert L.brcnn_conv_set_tile(-2, 2) == 0
-        for sk in (-3, -5, -4):
-            assert L.brcnn_conv_set_tile_bf16(sk) == 0
-            for rep in range(2):
-                out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
-                assert torch.equal(out, ref), (sk, rep, (out - ref).abs().max().item())
+        for rows in (256, 128):                  # both tile heights forced
+            assert L.brcnn_conv_set_tile(-2, rows) == 0
+            for sk in (-3, -5, -4):
+                assert L.brcnn_conv_set_tile_bf16(sk) == 0
+                for rep in range(2):
+                    out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
+                    assert torch.equal(out, ref), (rows, sk, rep, (out - ref).abs().max().item())
     finally:
         L.brcnn_conv_set_tile(-2, 1)
         L.brcnn_conv_set_tile_bf16(-4)
@@ -977,13 +978,14 @@ def test_f32_eight_phase_kernel_data_gradient():
     w2 = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
     try:
         outs = {}
-        for mode in (0, 2):
+        for mode in (0, 256, 128):
             assert L.brcnn_conv_set_tile(-2, mode) == 0
             y, _ = ops.conv2d_nhwc_multi(xc, wt, B, sizes, None, None, None, False, 1, 1)
             x = torch.randn(2, 50, 84, 256, generator=torch.Generator().manual_seed(37)).to(DEV).requires_grad_(True)
             z = conv2d_nhwc_autograd(x, w2.clone().requires_grad_(True), None, 2, 1)
             z.backward(dy)
             outs[mode] = (y, x.grad.clone())
-        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+        for mode in (256, 128):
+            assert torch.equal(outs[0][0], outs[mode][0]) and torch.equal(outs[0][1], outs[mode][1]), mode
     finally:
         L.brcnn_conv_set_tile(-2, 1)
