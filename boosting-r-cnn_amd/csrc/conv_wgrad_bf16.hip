@@ -365,6 +365,7 @@ constexpr size_t WGRAD_WS_BYTES = (size_t)160 << 20;
 std::mutex g_wgrad_ws_mutex;
 std::vector<WgradWs> g_wgrad_ws;
 int g_wgrad_slabs = 1;       // tuning hook (brcnn_conv_set_tile_wgrad_bf16(10 / 11)): 0 atomics, 1 slabs + second stage
+int g_wgrad_two_pass = 24;   // ... (100 + n): more than n slices per tile -> the second stage runs as two passes
 
 float* wgrad_workspace(hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_wgrad_ws_mutex);
@@ -419,7 +420,7 @@ int launch(WgradHParams& p, hipStream_t s) {
     BRCNN_LAUNCH_CHECK();
     if (p.slab) {
         int stride = 1, count = p.slices;
-        if (p.slices > 24) {         // few output tiles, many slices: groups of ~sqrt(slices) first (more workgroups, shorter chains)
+        if (p.slices > g_wgrad_two_pass) {   // few output tiles, many slices: groups of ~sqrt(slices) first (more workgroups, shorter chains)
             int group = 4;
             while (group * group < p.slices) group++;
             const int ngroups = (p.slices + group - 1) / group;
@@ -489,6 +490,7 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
 
 BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
     if (wt == 10 || wt == 11) { g_wgrad_slabs = wt - 10; return 0; }      // reduction over the M slices: atomics / slabs
+    if (wt >= 100 && wt < 1100) { g_wgrad_two_pass = wt - 100; return 0; }
     if (wt < 0 || wt == 3 || wt > 4) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;
