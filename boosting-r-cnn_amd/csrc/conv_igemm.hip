@@ -608,7 +608,9 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
         // (128-row tiles where 256-row ones would leave CUs idle: the stage-3 / stage-4 maps)
         const long long t48 = (long long)((p.M + 127) / 128) * (p.Cout / 256);
         p.pp_rows = g_pp_f32_mode >= 128 ? g_pp_f32_mode : 0;
-        if (g_pp_f32_mode >= 2 || t48 >= 208) return dispatch_conv_pp_f32(p, s);
+        // (a K = 256 layer with a residual stream is eight K tiles deep and output-bound: measured 6 % behind the
+        // 64 x 64 kernel, tools/conv_bench.py "s3 1x1 256->1024 +res")
+        if (g_pp_f32_mode >= 2 || (t48 >= 208 && (p.K >= 512 || !p.residual))) return dispatch_conv_pp_f32(p, s);
     }
     // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the SMALLEST tile,
     // 64x64 (4 waves x one 32x32 MFMA tile, 32 KiB LDS -> up to 5 resident workgroups / CU,

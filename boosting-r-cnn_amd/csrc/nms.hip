@@ -100,21 +100,55 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
     if (tid == 0) sh_count = 0;
     __syncthreads();
     int count = 0;
+    // the diagonal word of the NEXT chunk does not depend on `removed`: fetched one chunk ahead
+    // (handed from `diag_next` to `diag_cur` through a register move AFTER its wait, so that the use inside the chain
+    // is not a pending load for the compiler's wait-count pass -- it would drain the row prefetch there otherwise)
+    unsigned long long diag_next = 0ull, diag_cur = 0ull;
+    if (wave == 0 && lane < len) diag_next = mask[(size_t)(beg + lane) * words];
+    {
+        unsigned nlo, nhi;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                     : "=v"(nlo), "=v"(nhi)
+                     : "v"((unsigned)diag_next), "v"((unsigned)(diag_next >> 32)));
+        diag_cur = ((unsigned long long)nhi << 32) | nlo;
+    }
     for (int c = 0; c < nchunk; c++) {
+        // rows of this chunk x the next 64 columns, ALL 64 rows (wave = which 16 rows, lane = column), issued before
+        // the sequential resolution of the diagonal so that their latency hides under it; the survivors' words are
+        // picked out of the registers afterwards
+        const unsigned long long* mchunk = mask + (size_t)(beg + c * 64) * words;
+        const int w0 = c + 1 + lane;
+        unsigned long long pre[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int r = wave * 16 + j;
+            pre[j] = (w0 < nchunk && c * 64 + r < len) ? mchunk[(size_t)r * words + w0] : 0ull;
+        }
         if (wave == 0) {
             const int row = c * 64 + lane;
-            const unsigned long long diag = (row < len) ? mask[(size_t)(beg + row) * words + c] : 0ull;
-            unsigned long long cur = remv[c];
+            const unsigned long long diag = diag_cur;
+            if (c + 1 < nchunk && row + 64 < len) diag_next = mask[(size_t)(beg + row + 64) * words + c + 1];
+            else diag_next = 0ull;
+            // the greedy chain of the chunk on the scalar unit: `cur` (removed bits) and `kept` live in SGPRs, one
+            // iteration per SURVIVOR (find-first-set over the not-yet-removed rows), the survivor's diagonal word
+            // comes out of lane b of `diag`
+            const unsigned long long cur_v = remv[c];
+            // (the builtin returns int: cast before widening)
+            unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cur_v >> 32)) << 32) |
+                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)cur_v);
             const int nb = min(64, len - c * 64);
+            const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
             unsigned long long kept = 0ull;
             const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
-            for (int b = 0; b < nb; b++) {
-                if (!((cur >> b) & 1ull)) {
-                    kept |= 1ull << b;
-                    const unsigned dlo = __builtin_amdgcn_readlane(lo, b);
-                    const unsigned dhi = __builtin_amdgcn_readlane(hi, b);
-                    cur |= ((unsigned long long)dhi << 32) | dlo;
-                }
+            unsigned long long rem = ~cur & valid;
+            while (rem) {
+                const int b = __builtin_ctzll(rem);
+                kept |= 1ull << b;
+                const unsigned dlo = __builtin_amdgcn_readlane(lo, b);
+                const unsigned dhi = __builtin_amdgcn_readlane(hi, b);
+                cur |= ((unsigned long long)dhi << 32) | dlo;
+                // rows above b that are still alive (b itself leaves the candidate set)
+                rem = ~cur & valid & ~((2ull << b) - 1ull);
             }
             const bool mine = (kept >> lane) & 1ull;
             const int rank = __popcll(kept & ((1ull << lane) - 1ull));
@@ -128,12 +162,18 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
         __syncthreads();
         count = sh_count;
         if (max_keep > 0 && count >= max_keep) { count = max_keep; break; }
-        // every thread owns mask columns w = c+1+tid (+256k): the survivors' words of a column
-        // are independent loads, issued 16 deep (a spent bit set re-reads the last row: OR is
-        // idempotent), OR-ed in registers and folded into `removed` without atomics
         const unsigned long long k2 = *kept_sh;
-        const unsigned long long* mchunk = mask + (size_t)(beg + c * 64) * words;
-        for (int w = c + 1 + tid; w < nchunk; w += 256) {
+        {
+            unsigned long long acc = 0ull;
+            const unsigned kw = (unsigned)(k2 >> (wave * 16)) & 0xffffu;
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc |= ((kw >> j) & 1u) ? pre[j] : 0ull;
+            if (acc) atomicOr(&remv[w0], acc);
+        }
+        // columns beyond the prefetched 64 (segments of more than 4096 + 64 c candidates): a thread owns a column,
+        // the survivors' words are independent loads issued 16 deep (a spent bit set re-reads the last row: OR is
+        // idempotent)
+        for (int w = c + 65 + tid; w < nchunk; w += 256) {
             unsigned long long acc = 0ull, k = k2;
             int b = 0;
             while (k) {
@@ -146,7 +186,15 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const unsigned long lon
 #pragma unroll
                 for (int j = 0; j < 16; j++) acc |= v[j];
             }
-            remv[w] |= acc;
+            if (acc) atomicOr(&remv[w], acc);
+        }
+        // the prefetched diagonal word has landed by now: settle the load counter here, not in front of the chain
+        {
+            unsigned nlo, nhi;
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                         : "=v"(nlo), "=v"(nhi)
+                         : "v"((unsigned)diag_next), "v"((unsigned)(diag_next >> 32)));
+            diag_cur = ((unsigned long long)nhi << 32) | nlo;
         }
         __syncthreads();
     }
