@@ -160,6 +160,12 @@ def train_bench(args, world, rank, device):
     scale = 512.0 if args.train_dtype == 'f16' else 1.0
     last = {}
 
+    # the RPN branch's backward pass inside the forward pass, beside the proposal stage (detectors.py): gradients are
+    # cleared before the forward pass below, the backward seed is the static loss scale; off under DDP
+    if os.environ.get('BRCNN_EARLY_RPN_BWD', '1') != '0' and net is model:
+        model.early_rpn_backward = True
+        model.early_backward_scale = scale
+
     def step():
         opt.zero_grad(set_to_none=True)
         losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)

@@ -225,6 +225,7 @@ class EpochBasedRunner:
         self.eval_fn, self.eval_interval = None, 1
         self.loss_scaler, self.loss_scale = None, None      # fp16 recipes: static loss scaling (train_detector)
         self.reducer = None                                  # distributed.GradReducer (data parallel without DDP)
+        self.early_rpn_backward = True                       # see _early_rpn_backward (cfg.early_rpn_backward)
         self.log_buffer = OrderedDict()
         self.history = []          # (epoch, iter, lr, {name: value}) rows the text logger printed
         self.eval_history = []
@@ -293,6 +294,21 @@ class EpochBasedRunner:
         self.logger.info(f'Epoch [{self.epoch + 1}][{self.inner_iter + 1}/{len(data_loader)}]\tlr: {lr:.3e}, '
                          f'eta: {eta}, time: {t_iter:.3f}{mem}, {items}')
 
+    def _early_rpn_backward(self):
+        """switch the detector's early RPN backward pass on where this loop can honour its contract: the fused
+        optimizer path (zero_grad before the forward pass, the backward seed = the static loss scale), no
+        DistributedDataParallel wrapper (its reducer brackets ONE backward pass); `early_rpn_backward = False` in the
+        config or BRCNN_EARLY_RPN_BWD=0 keeps the plain order"""
+        from .optim import FusedSGD
+        m = self.model
+        on = (hasattr(type(m), 'early_rpn_backward') and not hasattr(m, 'module') and isinstance(self.optimizer, FusedSGD)
+              and (self.grad_clip is None or self.grad_clip.get('norm_type', 2) == 2)
+              and self.early_rpn_backward and os.environ.get('BRCNN_EARLY_RPN_BWD', '1') != '0')
+        if hasattr(type(m), 'early_rpn_backward'):
+            m.early_rpn_backward = bool(on)
+            m.early_backward_scale = float(self.loss_scale or 1.0)
+        return on
+
     def train(self, data_loader):
         self.model.train()
         sampler = getattr(data_loader, 'sampler', None)
@@ -302,9 +318,14 @@ class EpochBasedRunner:
         for i, data in enumerate(data_loader):
             self.inner_iter = i
             self.lr_updater.apply(self.optimizer, self.epoch, self.iter)
+            early = self._early_rpn_backward()
+            if early:
+                # the RPN branch is back-propagated inside the forward pass (detectors.py): gradients are cleared first
+                self.optimizer.zero_grad()
             outputs = self.model.train_step(data, self.optimizer) if not hasattr(self.model, 'module') else \
                 self._ddp_step(data)
-            self.optimizer.zero_grad()
+            if not early:
+                self.optimizer.zero_grad()
             from .optim import FusedSGD
             if isinstance(self.optimizer, FusedSGD) and (self.grad_clip is None or self.grad_clip.get('norm_type', 2) == 2):
                 # clip + (unscale) + SGD + next step's conv operands in one call; the norm stays on the device
@@ -446,6 +467,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     runner = EpochBasedRunner(model, optimizer, cfg.work_dir, logger, runner_cfg['max_epochs'], meta)
     runner.timestamp = timestamp
     runner.reducer = reducer
+    runner.early_rpn_backward = bool(cfg.get('early_rpn_backward', True))
     if cfg.get('fp16', None) is not None:
         # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->
         # mmdet/apis/train.py:115-119, mmcv Fp16OptimizerHook): fp16 MFMA conv stack (fp32 accumulation, fp32

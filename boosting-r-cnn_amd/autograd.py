@@ -21,6 +21,7 @@ def _ints(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
 
 
+import contextlib
 import os as _os
 _ARENA_OFF = _os.environ.get('BRCNN_GRAD_ARENA', '1') == '0'
 
@@ -132,11 +133,27 @@ def join_side_streams(device=None):
         _side_seen.pop(key, None)
 
 
+_DEFER_JOIN = [False]
+
+
+@contextlib.contextmanager
+def deferred_side_stream_join():
+    """backward passes inside this context do not queue the end-of-pass join: for a partial backward pass in the
+    middle of a step (detectors.py, early_rpn_backward) whose results nobody reads before the step's final backward
+    pass has joined the side stream (or the readers' backstop join has: FusedSGD.step, GradReducer.reduce)"""
+    prev = _DEFER_JOIN[0]
+    _DEFER_JOIN[0] = True
+    try:
+        yield
+    finally:
+        _DEFER_JOIN[0] = prev
+
+
 def _queue_stream_join(main, side):
     """main waits for the side stream once, when the running backward pass ends (whoever reads .grad afterwards --
     optimizer, gradient clipping, GradScaler -- is on the main stream)"""
     key = (main.device.type, main.device.index)
-    if _join_queued.get(key):
+    if _join_queued.get(key) or _DEFER_JOIN[0]:
         return
 
     def join():
@@ -819,3 +836,36 @@ def wants_grad(x, *params):
     if x is not None and x.requires_grad:
         return True
     return any(p is not None and p.requires_grad for p in params)
+
+
+class _InjectGradients(Function):
+    """identity on the pyramid levels whose backward adds a stored gradient per level: the gradient the RPN branch
+    produced in its own, earlier backward pass (detectors.py, early_rpn_backward) joins the second stage's here --
+    the sum autograd forms itself when both branches hang off the same tensors in one backward pass"""
+
+    @staticmethod
+    def forward(ctx, holder, *feats):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return tuple(f.view_as(f) for f in feats)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        out = []
+        for g, extra in zip(grads, ctx.holder):
+            if extra is None:
+                out.append(g)
+            elif g is None:
+                out.append(extra)
+            else:
+                out.append(g + extra.to(g.dtype))
+        ctx.holder = None
+        return (None,) + tuple(out)
+
+
+def inject_gradients(feats, extra):
+    """`feats` with `extra[i]` (or None) added to the gradient of level i on the way back"""
+    if not extra or all(e is None for e in extra):
+        return tuple(feats)
+    return _InjectGradients.apply(list(extra), *feats)

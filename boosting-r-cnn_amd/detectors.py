@@ -214,6 +214,8 @@ class TwoStageDetector(BaseDetector):
         from . import train_ops
         feats = self.extract_feat_nhwc(img)
         rpn = self.rpn_head
+        if self._early_rpn_backward_ok(feats):
+            return self._forward_train_device_early(feats, img_metas, gt_bboxes, gt_labels)
         y, sizes = rpn.forward_head_fused(list(feats))
         gt_flat = train_ops.flatten_gts(gt_bboxes, gt_labels)
         proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
@@ -221,6 +223,79 @@ class TwoStageDetector(BaseDetector):
         roi_losses, rpn_losses = self.roi_head.forward_train_device(
             feats, img_metas, dets, num, gt_flat,
             overlap_work=lambda: rpn.loss_fused(y, sizes, gt_bboxes, img_metas, gt_flat=gt_flat))
+        losses = dict()
+        losses.update(rpn_losses)
+        losses.update(roi_losses)
+        return losses
+
+    # ---- the RPN branch's backward pass inside the forward pass ------------------------------------
+    # The proposal stage (top-k, decode, NMS, second-stage assignment) is a chain of latency-bound launches that
+    # leaves most of the device idle for about a millisecond, and nothing else of the forward pass is independent of
+    # it.  The backward pass of the RPN branch is: it needs the RPN losses only.  With `early_rpn_backward` set, the
+    # proposal stage runs on a second stream while the main stream computes the RPN losses and back-propagates them
+    # through the heads and the tower (parameter gradients are stored, the gradient w.r.t. the pyramid is kept and
+    # added where the second stage's gradient arrives in the caller's backward()).  OPT-IN, because it changes what
+    # the caller may do between forward and backward: gradients of the RPN parameters exist when forward_train
+    # returns, so `optimizer.zero_grad()` has to come BEFORE the forward pass (mmcv's OptimizerHook calls it after:
+    # apis.Runner and bench.py order it accordingly when they switch this on), the seed of backward() has to be
+    # announced (`early_backward_scale`, the static loss scale of the fp16 recipes; 1 otherwise), and a forward
+    # pass whose losses are never back-propagated still leaves gradients behind.
+    early_rpn_backward = False
+    early_backward_scale = 1.0
+
+    def _early_rpn_backward_ok(self, feats):
+        return bool(self.early_rpn_backward) and torch.is_grad_enabled() and feats[0].is_cuda and \
+            any(p.requires_grad for p in self.rpn_head.parameters())
+
+    def _forward_train_device_early(self, feats, img_metas, gt_bboxes, gt_labels):
+        from . import autograd as _A, train_ops
+        rpn = self.rpn_head
+        dev = feats[0].device
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.get('_proposal_stream')
+        if side is None or side.device != dev:
+            side = self.__dict__['_proposal_stream'] = torch.cuda.Stream(dev)
+        cut = [f.detach().requires_grad_(f.requires_grad) for f in feats]
+        y, sizes = rpn.forward_head_fused(cut)
+        gt_flat = train_ops.flatten_gts(gt_bboxes, gt_labels)
+        proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            dets, num = rpn.proposals_fused(y, sizes, img_metas, proposal_cfg)
+        y.record_stream(side)
+        rpn_grads = []
+
+        def rpn_branch():
+            losses = rpn.loss_fused(y, sizes, gt_bboxes, img_metas, gt_flat=gt_flat)
+            total = None
+            for k, v in losses.items():
+                if 'loss' in k:
+                    t = v.mean() if isinstance(v, torch.Tensor) else sum(e.mean() for e in v)
+                    total = t if total is None else total + t
+            if total is not None and total.requires_grad:
+                params = [p for p in rpn.parameters() if p.requires_grad]
+                leaves = [c for c in cut if c.requires_grad]
+                scale = float(self.early_backward_scale)
+                with _A.deferred_side_stream_join():
+                    grads = torch.autograd.grad(total * scale if scale != 1.0 else total, leaves + params,
+                                                allow_unused=True)
+                it = iter(grads[:len(leaves)])
+                rpn_grads.extend(next(it) if c.requires_grad else None for c in cut)
+                late = [(p, g) for p, g in zip(params, grads[len(leaves):]) if g is not None and p.grad is not None]
+                if late:        # gradients left over from an earlier pass: accumulate as autograd would
+                    _A.join_side_streams(dev)
+                for p, g in zip(params, grads[len(leaves):]):
+                    if g is None:
+                        continue
+                    if p.grad is None:
+                        p.grad = g if g.dtype == p.dtype else g.to(p.dtype)
+                    else:
+                        p.grad = p.grad + g
+            return {k: ([e.detach() for e in v] if isinstance(v, list) else v.detach()) for k, v in losses.items()}
+
+        roi_losses, rpn_losses = self.roi_head.forward_train_device(
+            lambda: _A.inject_gradients(feats, rpn_grads), img_metas, dets, num, gt_flat, overlap_work=rpn_branch,
+            proposal_stream=side)
         losses = dict()
         losses.update(rpn_losses)
         losses.update(roi_losses)

@@ -466,7 +466,7 @@ class ProbRoIHead(nn.Module):
             h.loss_cls.ignore_index is None and type(h.loss_bbox) is L1Loss and not h.focal_reg and
             not h.reg_decoded_bbox and self.train_cfg.pos_weight <= 0 and self.bbox_roi_extractor._fusable())
 
-    def sample_device(self, dets, num, gt_flat, overlap_work=None):
+    def sample_device(self, dets, num, gt_flat, overlap_work=None, proposal_stream=None):
         """assignment + RandomSampler + targets + priors of the whole batch (prob_roi_head.py:23-69,
         bbox_head.py:122-253) from the padded proposals `dets` (B,K,5) / `num` (B,).  The one host
         read of the train step happens here: the (B,2) candidate counts the seeded host `randperm`
@@ -476,18 +476,29 @@ class ProbRoIHead(nn.Module):
         gts, gt_labels, offs = gt_flat
         B, K, _ = dets.shape
         a, sp = self.bbox_assigner, self.bbox_sampler
-        res = train_ops.assign_max_iou(dets, gts, offs, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou, a.match_low_quality,
-                                       num_boxes=num, want_overlaps=self.quality, want_counts=True)
-        gt_inds, mo, counts = (res[0], res[1], res[2]) if self.quality else (res[0], None, res[1])
         host = self.__dict__.setdefault('_count_host', {})
         if host.get('B') != B:
             host.update(B=B, counts=torch.empty((B, 2), dtype=torch.int32).pin_memory(),
                         perm=torch.empty((B, int(sp.num * sp.pos_fraction) + sp.num), dtype=torch.int32).pin_memory())
-        host['counts'].copy_(counts, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # `proposal_stream`: the stream the proposals were produced on (detectors.py, early_rpn_backward): assignment
+        # and the count copy stay on it, `overlap_work` is queued on the current stream meanwhile, which joins it below
+        import contextlib
+        with (torch.cuda.stream(proposal_stream) if proposal_stream is not None else contextlib.nullcontext()):
+            res = train_ops.assign_max_iou(dets, gts, offs, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou,
+                                           a.match_low_quality, num_boxes=num, want_overlaps=self.quality,
+                                           want_counts=True)
+            gt_inds, mo, counts = (res[0], res[1], res[2]) if self.quality else (res[0], None, res[1])
+            host['counts'].copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         extra = overlap_work() if overlap_work is not None else None
         ev.synchronize()
+        if proposal_stream is not None:
+            cur = torch.cuda.current_stream(dets.device)
+            cur.wait_stream(proposal_stream)
+            for t in (dets, num, gt_inds, mo):
+                if t is not None:
+                    t.record_stream(cur)
         num_pos = int(sp.num * sp.pos_fraction)
         cnt = []
         for b, (p_, n_) in enumerate(host['counts'].tolist()):
@@ -507,10 +518,13 @@ class ProbRoIHead(nn.Module):
         out['rows'] = rows
         return out, extra
 
-    def forward_train_device(self, feats_nhwc, img_metas, dets, num, gt_flat, overlap_work=None):
-        """ProbRoIHead.forward_train on the padded device proposals; returns (losses, overlap_work's result)"""
+    def forward_train_device(self, feats_nhwc, img_metas, dets, num, gt_flat, overlap_work=None, proposal_stream=None):
+        """ProbRoIHead.forward_train on the padded device proposals; returns (losses, overlap_work's result).
+        `feats_nhwc` may be a callable that yields the pyramid once `overlap_work` has run."""
         from . import train_ops
-        smp, extra = self.sample_device(dets, num, gt_flat, overlap_work)
+        smp, extra = self.sample_device(dets, num, gt_flat, overlap_work, proposal_stream)
+        if callable(feats_nhwc):
+            feats_nhwc = feats_nhwc()
         roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, smp['rois'])
         cls_score, bbox_pred = self.bbox_head.forward_nhwc(roi_feats)
         h = self.bbox_head

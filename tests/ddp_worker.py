@@ -41,6 +41,9 @@ def main():
             red = GradReducer([p for p in m.parameters() if p.requires_grad], slice_mb=8)
             red.broadcast_parameters(m)
         for rep in range(2 if mode == 'own' else 1):     # twice: the second pass runs on a fresh arena chunk
+            # ... and with the RPN branch back-propagated inside the forward pass (detectors.py): its weight gradients
+            # reach the arena, and the reducer, before the second stage's
+            m.early_rpn_backward = mode == 'own' and rep == 1
             m.zero_grad(set_to_none=True)
             A.grad_arena.new_step()
             torch.manual_seed(77)

@@ -497,6 +497,46 @@ def test_wgrad_side_stream_gives_the_same_gradients():
         blocks.set_compute_dtype('f32')
 
 
+@pytest.mark.parametrize('dtype,scale', [('f32', 1.0), ('bf16', 1.0), ('f16', 512.0)])
+def test_early_rpn_backward_gives_the_same_step(dtype, scale):
+    """`early_rpn_backward`: the RPN branch back-propagated inside the forward pass (proposal stage on a second
+    stream) + the second stage's backward() afterwards = the one backward pass over both branches: same losses, and
+    every parameter gradient equal up to the order of the weight-gradient atomics (the two pyramid-gradient terms are
+    added in the other order: a + b == b + a), over
+    several steps that reuse the allocator's blocks across the two streams"""
+    from brcnn import blocks
+    m = _model()
+    blocks.conv_weights_channels_last(m)
+    m.set_compute_dtype(dtype)
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    res = {}
+    try:
+        for mode in (False, True, True, True):
+            m.early_rpn_backward, m.early_backward_scale = mode, scale
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(77)
+            loss, log_vars = m._parse_losses(m.forward_train(*args))
+            if mode:        # the RPN parameters have their gradients already
+                assert m.rpn_head.rpn_convs[0].conv.weight.grad is not None
+            (loss * scale).backward()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+            if not mode:
+                res['ref'] = (dict(log_vars), grads)
+            else:
+                assert dict(log_vars) == res['ref'][0]
+                assert grads.keys() == res['ref'][1].keys()
+                for k, ga in grads.items():
+                    gb = res['ref'][1][k]
+                    # (equal up to the order of the fp32 atomics of the fp32 weight-gradient kernel)
+                    scl = gb.abs().max().item() + 1e-12
+                    assert (ga - gb).abs().max().item() <= 1e-4 * scl, (k, (ga - gb).abs().max().item(), scl)
+    finally:
+        m.early_rpn_backward, m.early_backward_scale = False, 1.0
+        blocks.set_compute_dtype('f32')
+
+
 def test_wgrad_side_stream_with_a_weight_used_twice():
     """one conv applied to two inputs in one graph (the per-level RPN fallback shares its ConvModules across pyramid
     levels): autograd sums the two weight gradients on the main stream as soon as the second arrives, so only the first
