@@ -12,6 +12,8 @@ arguments and parameter names (`bbox_head.{shared_fcs.{i},fc_cls,fc_reg}`).  Exe
   * test-time: sqrt(softmax * prior), per-class decode, threshold, class-aware NMS for the
     whole batch stay on the device (postprocess.batched_nms_images).
 """
+import os as _os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -24,6 +26,9 @@ from .losses import SmoothL1Loss, accuracy
 from .postprocess import batched_nms_images
 from .registry import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head,
                        build_loss, build_roi_extractor, build_sampler)
+
+# BRCNN_TIME_SYNC=1: [seconds the host blocked on the sampler counts, calls] (tools/host_slack.py)
+SYNC_WAIT = [0.0, 0] if _os.environ.get('BRCNN_TIME_SYNC') == '1' else None
 
 
 def _pair(x):
@@ -492,7 +497,14 @@ class ProbRoIHead(nn.Module):
             ev = torch.cuda.Event()
             ev.record()
         extra = overlap_work() if overlap_work is not None else None
-        ev.synchronize()
+        if SYNC_WAIT is not None:       # BRCNN_TIME_SYNC=1: how long the host waits here = its slack over the device
+            import time
+            t0 = time.perf_counter()
+            ev.synchronize()
+            SYNC_WAIT[0] += time.perf_counter() - t0
+            SYNC_WAIT[1] += 1
+        else:
+            ev.synchronize()
         if proposal_stream is not None:
             cur = torch.cuda.current_stream(dets.device)
             cur.wait_stream(proposal_stream)
