@@ -252,10 +252,17 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
     const T* __restrict__ input, LevelTable lv, const float* __restrict__ rois,
     T* __restrict__ output, int32_t* __restrict__ levels_out, int channels, int height,
     int width, int n_rois, int ph_n, int pw_n, float spatial_scale, int sampling_ratio,
-    int aligned) {
+    int aligned, int stream_c) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long row = (long long)blockIdx.x * 4 + wave;
+    // XCD x (= blockIdx % 8, the dispatcher's round robin) takes a CONTIGUOUS eighth of the bin rows: RoIs arrive
+    // image by image, so the maps an XCD's L2 has to hold are one image's (batch 8) instead of the whole batch's
+    int bid = blockIdx.x;
+    if (stream_c & 2) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const long long row = (long long)bid * 4 + wave;
     if (row >= (long long)n_rois * ph_n) return;
     const int k = (int)(row / ph_n);
     const int ph = (int)(row - (long long)k * ph_n);
@@ -305,6 +312,80 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
         }
         Wx_all = w;
         if (__ballot(nx_all > 8) != 0ull) vecx = false;
+    }
+    // ---- column streaming (the common case: every bin of the row has <= 8 footprint columns, the row <= 4 footprint
+    // rows): the footprint of the WHOLE bin row is one dense patch of ny x (X1 - X0) pixels; each pixel is loaded once
+    // (adjacent bins share their border columns: with 1..2 px bins that is a third of the per-bin loads, and the
+    // fixed 2 x 4 batches of the per-bin loop padded a 3 x 3 footprint to 16 loads), CB columns x ny rows in flight
+    // per batch.  Rows are reduced first (column sum = sum_r Wy[r] v[r][x]), then the column sum goes into the bins
+    // whose footprint holds column x with that bin's x weight -- all of it wave-uniform control flow.
+    if (vecx && ny <= 4 && pw_n <= 8 && (stream_c & 1)) {
+        ny = __builtin_amdgcn_readfirstlane(ny);
+        constexpr int CB = 2;
+        int bx0[8], bnx[8];
+        int X0 = 0x7fffffff, X1 = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bx0[b] = __builtin_amdgcn_readlane(x0_all, b * 8);
+            bnx[b] = b < pw_n ? __builtin_amdgcn_readlane(nx_all, b * 8) : 0;
+            if (bnx[b] > 0) { X0 = min(X0, bx0[b]); X1 = max(X1, bx0[b] + bnx[b]); }
+        }
+        float wy[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) wy[r] = r < ny ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Wy), r)) : 0.f;
+        for (int c0 = lane * 4; c0 < channels; c0 += 256) {
+            float4 acc[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ny > 0) {
+                // (wave-uniform pixel address + the lane's channel offset: scalar base, one shared offset register)
+                const int y0u = __builtin_amdgcn_readfirstlane(y0), wu = __builtin_amdgcn_readfirstlane(width);
+                const unsigned long long bq = (unsigned long long)base;
+                const T* bu = (const T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)bq));
+                const T* r0 = bu + (size_t)y0u * wu * channels;
+                const size_t rstride = (size_t)wu * channels;
+                const unsigned lane_off = (unsigned)c0;
+                for (int cx = X0; cx < X1; cx += CB) {
+                    float4 v[4][CB];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int j = 0; j < CB; j++)
+                            if (r < ny && cx + j < X1) v[r][j] = ld4(r0 + r * rstride + (size_t)(cx + j) * channels + lane_off);
+#pragma unroll
+                    for (int j = 0; j < CB; j++) {
+                        if (cx + j >= X1) break;
+                        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (r < ny) {
+                                cs.x += wy[r] * v[r][j].x; cs.y += wy[r] * v[r][j].y;
+                                cs.z += wy[r] * v[r][j].z; cs.w += wy[r] * v[r][j].w;
+                            }
+#pragma unroll
+                        for (int b = 0; b < 8; b++) {
+                            const int jj = cx + j - bx0[b];
+                            if (jj >= 0 && jj < bnx[b]) {
+                                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Wx_all), b * 8 + jj));
+                                acc[b].x += w * cs.x; acc[b].y += w * cs.y; acc[b].z += w * cs.z; acc[b].w += w * cs.w;
+                            }
+                        }
+                    }
+                }
+            }
+            // (x * (1 / count) instead of x / count: 28 IEEE divisions per bin row were a tenth of the wave's instructions;
+            // one more rounding, inside the footprint form's stated round-off)
+            const float inv = 1.f / g.count;
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (b < pw_n) {
+                    float4 o = acc[b];
+                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                    st4(out_row + (size_t)b * channels + c0, o);
+                }
+        }
+        return;
     }
     for (int pw = 0; pw < pw_n; pw++) {
         T* out = out_row + (size_t)pw * channels;
@@ -375,6 +456,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
 }
 
 int g_roi_exact = 0;     // 1: exact sample-order kernel (bit-identical to the reference's CPU order)
+int g_roi_stream_c = 3;  // footprint kernel: bit 0 column streaming over the bin row's patch (else the per-bin loop), bit 1 XCD-contiguous rows
 
 // NHWC backward (avg): same decomposition, atomicAdd of g*w/count to the four corners.
 template <bool MULTI>
@@ -516,7 +598,7 @@ BRCNN_API int brcnn_roi_align_forward(const float* input, const float* rois, flo
         else
             hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<false, float>), dim3(brcnn_cdiv((long long)n_rois * pooled_h, 4)), dim3(256), 0,
                                s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
-                               n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
+                               n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, g_roi_stream_c);
     } else if (layout == BRCNN_LAYOUT_NCHW) {
         if (pool_mode == 0 && (!argmax_y || !argmax_x)) return BRCNN_EINVAL;
         int grid = brcnn_cdiv(total, 256);
@@ -604,7 +686,7 @@ BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int
         else
             hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, bf16_t>), grid_rows, dim3(256), 0, s,
                                (const bf16_t*)nullptr, lv, rois, (bf16_t*)output, levels_out, channels, 0, 0, n_rois,
-                               pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+                               pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c);
     } else if (dtype == BRCNN_DT_F16) {
         if (g_roi_exact)
             hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, f16_t>), grid, dim3(256), 0, s, (const f16_t*)nullptr,
@@ -613,7 +695,7 @@ BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int
         else
             hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, f16_t>), grid_rows, dim3(256), 0, s,
                                (const f16_t*)nullptr, lv, rois, (f16_t*)output, levels_out, channels, 0, 0, n_rois,
-                               pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+                               pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c);
     } else {
         if (g_roi_exact)
             hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, float>), grid, dim3(256), 0, s, (const float*)nullptr,
@@ -622,7 +704,7 @@ BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int
         else
             hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, float>), grid_rows, dim3(256), 0, s,
                                (const float*)nullptr, lv, rois, (float*)output, levels_out, channels, 0, 0, n_rois,
-                               pooled_h, pooled_w, 0.f, sampling_ratio, 1);
+                               pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c);
     }
     BRCNN_LAUNCH_CHECK();
     return 0;
@@ -880,6 +962,9 @@ BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, co
 }
 
 BRCNN_API int brcnn_roi_align_set_exact(int exact) {
-    g_roi_exact = exact ? 1 : 0;
+    // 0: footprint kernel (column streaming, XCD-contiguous bin rows), 1: exact sample order, 2: footprint kernel with
+    // the per-bin loop and round-robin rows (the r02 form), 3: column streaming with round-robin rows
+    g_roi_exact = exact == 1 ? 1 : 0;
+    g_roi_stream_c = exact == 2 ? 0 : exact == 3 ? 1 : 3;
     return 0;
 }

@@ -109,9 +109,11 @@ int brcnn_roi_extract_backward_gather(void *const *grad_feats_host, const int *h
                                       int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
                                       float finest_scale, void *workspace, size_t workspace_bytes,
                                       int dtype, void *stream);
-/* NHWC RoIAlign forward variants: 0 (default) = footprint form (every pixel of a bin's footprint
- * read once; equal to the reference to fp32 round-off), 1 = the reference's sample-order
- * accumulation (bit-identical to mmcv's CPU kernel; ~1.5x the L2 reads). */
+/* NHWC RoIAlign forward variants: 0 (default) = footprint form, column streaming (one wavefront per row of bins
+ * reads every pixel of the ROW's footprint once, rows reduced first, then spread over the bins with their x weights;
+ * bin rows dealt to the XCDs in contiguous eighths; equal to the reference to fp32 round-off), 1 = the reference's
+ * sample-order accumulation (bit-identical to mmcv's CPU kernel; ~1.5x the L2 reads), 2 = the footprint form of
+ * rounds 1-2 (per-bin loop, round-robin rows), 3 = column streaming with round-robin rows (tuning / A-B hooks). */
 int brcnn_roi_align_set_exact(int exact);
 
 /* Whole-batch candidate preparation / collection around brcnn_nms for fixed per-image slots of

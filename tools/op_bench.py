@@ -57,6 +57,8 @@ def main():
         K = per_img * B
         # log-uniform scale 16-800 px, aspect 0.5-2, uniform centres
         rois = util.rand_rois(K, B, 1333., 800., seed=per_img, min_size=16., max_size=800.)
+        # image by image, as bbox2roi / the padded proposal tensor deliver them (score order inside an image = random here)
+        rois = rois[torch.argsort(rois[:, 0], stable=True)].contiguous()
         rg = rois.to(DEV)
         t = timed(lambda: ops.roi_extract(feats, rg, 7, strides, 56, 0))
         by = roialign_bytes(rois, strides, sizes)

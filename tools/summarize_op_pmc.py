@@ -8,16 +8,30 @@ KEYS = ('roi_align_fwd', 'roi_align_bwd', 'roi_grad', 'nms_mask', 'nms_reduce', 
         'rpn_loss_fwd', 'rpn_loss_bwd', 'rcnn_sample', 'boost_loss', 'focal_kernel', 'preprocess')
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
+grids = set()
 for name in ('fetch', 'write'):
     for f in glob.glob(f'gpurun_out/{rnd}/op_pmc_{name}/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             k = next((k_ for k_ in KEYS if k_ in r['Kernel_Name']), None)
             if k is None:
                 continue
+            if k == 'roi_align_fwd':        # one entry per RoI count: the launches differ in their grid size
+                g = int(r['Grid_Size'])
+                grids.add(g)
+                tot[('roi', g)][r['Counter_Name']] += float(r['Counter_Value'])
+                if name == 'fetch':
+                    cnt[('roi', g)] += 1
             tot[k][r['Counter_Name']] += float(r['Counter_Value'])
             if name == 'fetch':
                 cnt[k] += 1
 out = {}
+# RoI counts of tools/op_bench.py in ascending order <-> grid sizes in ascending order
+names = {g: f'roi_align_fwd_{n}x8' for g, n in zip(sorted(grids), (256, 512, 2000))} if len(grids) == 3 else {}
+for k in list(tot):
+    if isinstance(k, tuple):
+        g = k[1]
+        tot[names.get(g, f'roi_align_fwd_grid{g}')] = tot.pop(k)
+        cnt[names.get(g, f'roi_align_fwd_grid{g}')] = cnt.pop(k)
 for k, v in tot.items():
     n = max(cnt[k], 1)
     fetch_b, write_b = 2.0 * v.get('FETCH_SIZE', 0.0) * 1024, v.get('WRITE_SIZE', 0.0) * 1024
