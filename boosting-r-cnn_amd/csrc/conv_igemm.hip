@@ -112,11 +112,14 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_igemm_f32_kernel(ConvParams 
     const int nk = (p.K + BK - 1) / BK;
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+        int k0 = kt * BK;
         if (FAST) {
-            const int tap = k0 / p.Cin;
-            const int ci = k0 - tap * p.Cin + c4 * 4;
+            // (chunk-major K order of the LDS-DMA kernels: K tile kt = channel chunk kt / T, tap kt % T)
+            const int T = p.KH * p.KW;
+            const int cc = kt / T, tap = kt - cc * T;
+            const int ci = cc * BK + c4 * 4;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            k0 = tap * p.Cin + cc * BK;
 #pragma unroll
             for (int j = 0; j < AJ; j++) {
                 int hi = (a_hw[j] >> 16) - 4096 + kh;
@@ -356,12 +359,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     int d_k0 = 0, d_ci0 = 0, d_kh = 0, d_kw = 0;
     auto dma_tile = [&](int kt, int buf) {
         (void)kt;
-        const int k0 = d_k0, ci0 = d_ci0, kh = d_kh, kw = d_kw;
-        d_k0 += BK;
-        d_ci0 += BK;
-        if (d_ci0 >= p.Cin) {
-            d_ci0 = 0;
-            if (++d_kw == p.KW) { d_kw = 0; d_kh++; }
+        // (channel chunk by channel chunk, the filter taps inside a chunk: see conv_pp_f32.hip; every fp32 kernel
+        // visits K in this order, so their results stay bit-identical to each other)
+        const int ci0 = d_ci0, kh = d_kh, kw = d_kw;
+        const int k0 = (kh * p.KW + kw) * p.Cin + ci0;
+        (void)d_k0;
+        if (++d_kw == p.KW) {
+            d_kw = 0;
+            if (++d_kh == p.KH) { d_kh = 0; d_ci0 += BK; }
         }
 #pragma unroll
         for (int j = 0; j < AG; j++) {

@@ -127,25 +127,28 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     struct TileK { int k0, ci0, kh, kw; };
     // K tiles are staged in order: the filter tap and channel offset of the next tile are carried
     // as scalar state instead of being re-derived by two integer divisions per tile
+    // Order: channel chunk by channel chunk, the filter taps INSIDE a chunk (K tile kt = chunk kt / (KH KW), tap
+    // kt % (KH KW)) -- the taps of a 3x3 filter then read shifted windows of the same 128-byte pieces of the same
+    // pixels back to back and hit in L2 (conv_pp_f32.hip has the measurement); every 16-bit kernel uses this order,
+    // so their results stay bit-identical to each other.  k0 = the tile's column in the [Cout][kh][kw][ci] weights.
     TileK d_next = {0, 0, 0, 0};
     if constexpr (SK) {
         if (kb > 0) {
-            const int k0 = kb * BKE, tap = k0 / p.Cin;
-            d_next.k0 = k0;
-            d_next.ci0 = k0 - tap * p.Cin;
+            const int T = p.KH * p.KW, cc = kb / T, tap = kb - cc * T;
+            d_next.ci0 = cc * BKE;
             d_next.kh = tap / p.KW;
             d_next.kw = tap - d_next.kh * p.KW;
+            d_next.k0 = tap * p.Cin + d_next.ci0;
         }
     }
     auto dma_setup = [&](int kt) {
         (void)kt;
         const TileK t = d_next;
-        d_next.k0 += BKE;
-        d_next.ci0 += BKE;
-        if (d_next.ci0 >= p.Cin) {
-            d_next.ci0 = 0;
-            if (++d_next.kw == p.KW) { d_next.kw = 0; d_next.kh++; }
+        if (++d_next.kw == p.KW) {
+            d_next.kw = 0;
+            if (++d_next.kh == p.KH) { d_next.kh = 0; d_next.ci0 += BKE; }
         }
+        d_next.k0 = (d_next.kh * p.KW + d_next.kw) * p.Cin + d_next.ci0;
         return t;
     };
     auto dma_piece = [&](const TileK& t, int buf, int j) {

@@ -8,7 +8,8 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for name in ('fetch', 'write'):
     for r in csv.DictReader(open(f'gpurun_out/{rnd}/pmc_{name}/step_counter_collection.csv')):
-        k = 'conv_igemm_f32_kernel' if 'conv_igemm' in r['Kernel_Name'] else r['Kernel_Name'].split('(')[0][-40:]
+        # every conv / FC launch of the pass: the 64 x 64 two-buffer kernel and (r03) the eight-phase conv_pp_f32 kernel
+        k = 'conv_igemm_f32_kernel' if ('conv_igemm' in r['Kernel_Name'] or 'conv_pp_' in r['Kernel_Name']) else r['Kernel_Name'].split('(')[0][-40:]
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         if name == 'fetch':
             cnt[k] += 1
@@ -28,18 +29,24 @@ print(json.dumps(top['conv_igemm_f32_kernel'], indent=1))
 # ---- MFMA utilisation of the conv kernels from the SQ pass (if present) ---------------------
 try:
     agg = collections.defaultdict(float)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     n_conv = 0
     for r in csv.DictReader(open(f'gpurun_out/{rnd}/pmc_sq/step_counter_collection.csv')):
-        if 'conv_igemm' in r['Kernel_Name']:
-            agg[r['Counter_Name']] += float(r['Counter_Value'])
+        for key in ('conv_igemm', 'conv_pp_'):
+            if key in r['Kernel_Name']:
+                agg[r['Counter_Name']] += float(r['Counter_Value'])
+                per[key][r['Counter_Name']] += float(r['Counter_Value'])
     # SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs share the MFMA cycles
     clk_cycles = agg['SQ_BUSY_CYCLES'] / 32.0
     util = agg['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * clk_cycles)
     sq = dict(mfma_busy_cycles=agg['SQ_VALU_MFMA_BUSY_CYCLES'], sq_busy_cycles_per_se=clk_cycles,
               mfma_util=util, wait_any_frac=agg['SQ_WAIT_ANY'] / agg['SQ_WAVE_CYCLES'],
               wait_inst_any_frac=agg['SQ_WAIT_INST_ANY'] / agg['SQ_WAVE_CYCLES'],
-              note='all conv_igemm launches of 4 inference passes; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / '
-                   '(1024 SIMDs x SQ_BUSY_CYCLES/32)')
+              by_kernel={k.rstrip('_'): dict(mfma_util=v['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * v['SQ_BUSY_CYCLES'] / 32.0),
+                                             wait_any_frac=v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES'])
+                         for k, v in per.items() if v.get('SQ_BUSY_CYCLES')},
+              note='all conv launches (conv_igemm_f32*, conv_pp_f32) of 4 inference passes; MfmaUtil = '
+                   'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES/32)')
     json.dump(sq, open(f'profiles/{rnd}_conv_mfma_util.json', 'w'), indent=1)
     print('mfma_util', util)
 except FileNotFoundError:
