@@ -38,10 +38,13 @@ for name, N, lv, Ci, Co, k, st, pd in shapes:
     ref = None
     line = f'{name:24s} M={M:7d}'
     for ts in tiles:
-        t = int(ts.rstrip('a'))
+        # tile id, optional 'a' (atomics) and 'pNN' (NN percent of a generation of workgroups per launch)
+        base, _, pct = ts.partition('p')
+        t = int(base.rstrip('a'))
         if BF:
             L.brcnn_conv_set_tile_wgrad_bf16(t)
-            L.brcnn_conv_set_tile_wgrad_bf16(10 if ts.endswith('a') else 11)
+            L.brcnn_conv_set_tile_wgrad_bf16(10 if base.endswith('a') else 11)
+            L.brcnn_conv_set_tile_wgrad_bf16(2000 + int(pct or 75))
         dw = torch.zeros(Co, k, k, Ci, device='cuda')
         call = lambda: L.brcnn_conv2d_wgrad_nhwc_multi(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, len(lv), hs, ws, Ci, Co, k, k,
                                                        st, pd, 1 if BF else 0, None)
