@@ -366,6 +366,7 @@ std::mutex g_wgrad_ws_mutex;
 std::vector<WgradWs> g_wgrad_ws;
 int g_wgrad_slabs = 1;       // tuning hook (brcnn_conv_set_tile_wgrad_bf16(10 / 11)): 0 atomics, 1 slabs + second stage
 int g_wgrad_slot_pct = 75;   // ... (2000 + n): n percent of a generation of workgroups per launch (75: the launches share the device with the main stream; same-box A/B 19.92 -> 19.75 ms per step, 50 % level, 35 % +0.9 ms)
+int g_wgrad_slot_pct_big = 75;   // ... (3000 + n): the same for launches of more than 2^17 reduction rows on the 256 x 256 tile
 int g_wgrad_two_pass = 24;   // ... (100 + n): more than n slices per tile -> the second stage runs as two passes
 
 float* wgrad_workspace(hipStream_t s) {
@@ -400,7 +401,8 @@ int launch(WgradHParams& p, hipStream_t s) {
     static int minrows = getenv("BRCNN_WG_MINROWS") ? atoi(getenv("BRCNN_WG_MINROWS")) : 1024;
     // (g_wgrad_slot_pct: the weight-gradient launches share the device with the main stream's kernels -- a fraction of
     // a generation leaves them CUs and shrinks the slab traffic)
-    const int slots = slots_env ? slots_env : (WG == 4 ? 256 : WT == 2 ? 512 : 1024) * g_wgrad_slot_pct / 100;
+    const int slots = slots_env ? slots_env : (WG == 4 ? 256 : WT == 2 ? 512 : 1024) *
+                                                  ((WG == 4 && p.M >= (1 << 17)) ? g_wgrad_slot_pct_big : g_wgrad_slot_pct) / 100;
     int slices = slots / tiles;
     const int max_slices = (p.M + minrows - 1) / minrows;
     if (slices > max_slices) slices = max_slices;
@@ -475,7 +477,7 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
     p.x_bytes = (unsigned)(x_off * 2);
     int wt = g_wgrad_bf16_tile;
     if (wt == 0) {
-        wt = (cout >= 128 && p.K >= 256) ? 2 : 1;
+        wt = (cout >= 128 && p.K >= 128) ? 2 : 1;      // (K = 128, stage-2 conv3: 128 x 128 tile 42 us, 64 x 64 51 us)
         // 256 x 256 on 16 waves where the 128 x 128 tile is bound by its LDS-DMA traffic and one generation
         // of 256 workgroups still has enough reduction rows each: the five-level tower layer (537 -> 912
         // TFLOP/s), the first FC (384 -> 676).  Every workgroup ends with a full tile of fp32 atomics (their
@@ -495,6 +497,7 @@ BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
     if (wt == 10 || wt == 11) { g_wgrad_slabs = wt - 10; return 0; }      // reduction over the M slices: atomics / slabs
     if (wt >= 100 && wt < 1100) { g_wgrad_two_pass = wt - 100; return 0; }
     if (wt >= 2010 && wt <= 2400) { g_wgrad_slot_pct = wt - 2000; return 0; }
+    if (wt >= 3010 && wt <= 3400) { g_wgrad_slot_pct_big = wt - 3000; return 0; }
     if (wt < 0 || wt == 3 || wt > 4) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;
