@@ -379,7 +379,8 @@ __device__ __forceinline__ unsigned order_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // ascending in f
 }
 
-__global__ __launch_bounds__(1024) void seg_sort_gather_kernel(const float* __restrict__ boxes,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void seg_sort_gather_kernel(const float* __restrict__ boxes,
                                                               const float* __restrict__ scores,
                                                               const int32_t* __restrict__ seg_begin,
                                                               const int32_t* __restrict__ seg_end,
@@ -391,12 +392,12 @@ __global__ __launch_bounds__(1024) void seg_sort_gather_kernel(const float* __re
     if (len <= 0) return;
     int P = 64;
     while (P < len) P <<= 1;
-    for (int i = tid; i < P; i += 1024)
+    for (int i = tid; i < P; i += THREADS)
         comp[i] = i < len ? (((unsigned long long)(~order_key(scores[beg + i])) << 32) | (unsigned)i) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (P >> 1); t += 1024) {
+            for (int t = tid; t < (P >> 1); t += THREADS) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // index with bit j clear
                 const int hi = lo | j;
                 const unsigned long long a = comp[lo], b = comp[hi];
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(1024) void seg_sort_gather_kernel(const float* __re
             __syncthreads();
         }
     }
-    for (int i = tid; i < len; i += 1024) {
+    for (int i = tid; i < len; i += THREADS) {
         const int src = beg + (int)(comp[i] & 0xffffffffu);
         idx_out[beg + i] = src;
         const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)src * 4);
@@ -511,18 +512,24 @@ BRCNN_API int brcnn_nms(const float* boxes, const float* scores, const int32_t* 
     NmsWs w = carve(workspace, n, num_segments, words);
     if (w.total > workspace_bytes) return BRCNN_EINVAL;
 
-    if (max_segment_len > 1024 && max_segment_len <= 8192 && g_nms_lds_sort) {   // (shorter segments: rocPRIM's small-segment path is as fast)
+    // own sort for every segment length the pipeline produces (<= 16384 candidates: the composites of a segment fit
+    // the 160 KB of LDS); rocPRIM's segmented radix sort stays as the fallback for longer segments only
+    if (max_segment_len <= 16384 && g_nms_lds_sort) {
         int P = 64;
         while (P < max_segment_len) P <<= 1;
         static bool attr_done = false;
         if (!attr_done) {
-            BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)seg_sort_gather_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+            BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)seg_sort_gather_kernel<1024>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
             attr_done = true;
         }
         // rows outside every segment are never read by the mask / reduce kernels
-        hipLaunchKernelGGL(seg_sort_gather_kernel, dim3(num_segments), dim3(1024), (size_t)P * 8, s, boxes, scores,
-                           seg_begin, seg_end, w.idx_out, w.sboxes, w.sareas, offset);
+        if (max_segment_len <= 512)        // short segments (per-class second-stage sets): four wavefronts each
+            hipLaunchKernelGGL(seg_sort_gather_kernel<256>, dim3(num_segments), dim3(256), (size_t)P * 8, s, boxes, scores,
+                               seg_begin, seg_end, w.idx_out, w.sboxes, w.sareas, offset);
+        else
+            hipLaunchKernelGGL(seg_sort_gather_kernel<1024>, dim3(num_segments), dim3(1024), (size_t)P * 8, s, boxes, scores,
+                               seg_begin, seg_end, w.idx_out, w.sboxes, w.sareas, offset);
         BRCNN_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(iota_kernel, dim3(brcnn_cdiv(n, 256)), dim3(256), 0, s, w.idx_in, w.idx_out, n);
