@@ -755,7 +755,8 @@ struct GatherLevels {
 };
 
 __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict__ rois, int n_rois, LevelTable lv, int batch,
-                                                        int ph_n, int pw_n, int sampling_ratio, RoiRec* __restrict__ recs) {
+                                                        int ph_n, int pw_n, int sampling_ratio, RoiRec* __restrict__ recs,
+                                                        int* __restrict__ ranges) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_rois) return;
     const float* roi = rois + (size_t)k * 5;
@@ -776,6 +777,12 @@ __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict
         r.y01 = (y0 << 16) | max(y1, 0);
         r.x01 = (x0 << 16) | max(x1, 0);
         if (y1 < y0 || x1 < x0) r.key = -1;
+        // the image's RoI index range: RoIs arrive image by image (bbox2roi), so a tile of image b scans
+        // [first, last) instead of every record; any other order only widens the range
+        if (r.key >= 0 && ranges) {
+            atomicMin(&ranges[g.batch], k);
+            atomicMax(&ranges[1024 + g.batch], k + 1);
+        }
     }
     recs[k] = r;
 }
@@ -783,8 +790,8 @@ __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict
 template <typename T>       // element type of dY and of the gradient maps (fp32, or the 16-bit compute dtype in training)
 __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restrict__ grad_output, LevelTable lv,
                                                              GatherLevels gl, const float* __restrict__ rois,
-                                                             const RoiRec* __restrict__ recs, int n_rois, int channels,
-                                                             int ph_n, int pw_n, int sampling_ratio) {
+                                                             const RoiRec* __restrict__ recs, const int* __restrict__ ranges,
+                                                             int n_rois, int channels, int ph_n, int pw_n, int sampling_ratio) {
     constexpr int MAXHIT = 512;
     __shared__ int s_hits[MAXHIT];
     __shared__ int s_wcnt[4];
@@ -815,15 +822,17 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
         float4 acc[16];
 #pragma unroll
         for (int p = 0; p < 16; p++) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int base = 0; base < n_rois; ) {
+        // (the records of this image only: same hits in the same order as a scan over all records)
+        const int r_lo = ranges ? max(ranges[b], 0) : 0, r_hi = ranges ? min(ranges[1024 + b], n_rois) : n_rois;
+        for (int base = r_lo; base < r_hi; ) {
             // ---- collect up to MAXHIT RoIs (in index order) that touch this tile
             if (tid == 0) s_nhit = 0;
             __syncthreads();
             int scanned = base;
-            while (scanned < n_rois) {
+            while (scanned < r_hi) {
                 const int k = scanned + tid;
                 bool hit = false;
-                if (k < n_rois) {
+                if (k < r_hi) {
                     const RoiRec r = recs[k];
                     if (r.key == key) {
                         const int y0 = r.y01 >> 16, y1 = r.y01 & 0xffff, x0 = r.x01 >> 16, x1 = r.x01 & 0xffff;
@@ -875,25 +884,43 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 const T* go = grad_output + (size_t)k * ph_n * pw_n * channels + c;
-                for (int ph = 0; ph < ph_n; ph++) {
+                // the bins whose x weights touch this quadrant (a contiguous run: the bins are monotonic in x); wave-uniform
+                unsigned pwm = 0u;
+#pragma unroll
+                for (int pw = 0; pw < 7; pw++)
+                    if (pw < pw_n && (s_wx[wave][0][pw] != 0.f || s_wx[wave][1][pw] != 0.f || s_wx[wave][2][pw] != 0.f ||
+                                      s_wx[wave][3][pw] != 0.f))
+                        pwm |= 1u << pw;
+                pwm = (unsigned)__builtin_amdgcn_readfirstlane((int)pwm);
+                for (int ph = 0; ph < ph_n && pwm; ph++) {
                     const float wy0 = s_wy[wave][0][ph], wy1 = s_wy[wave][1][ph], wy2 = s_wy[wave][2][ph], wy3 = s_wy[wave][3][ph];
                     if (wy0 == 0.f && wy1 == 0.f && wy2 == 0.f && wy3 == 0.f) continue;
-                    for (int pw = 0; pw < pw_n; pw++) {
-                        const float wx0 = s_wx[wave][0][pw], wx1 = s_wx[wave][1][pw], wx2 = s_wx[wave][2][pw], wx3 = s_wx[wave][3][pw];
-                        if (wx0 == 0.f && wx1 == 0.f && wx2 == 0.f && wx3 == 0.f) continue;
-                        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (c_ok) gv = ld4(go + (size_t)(ph * pw_n + pw) * channels);
-                        const float wys[4] = {wy0, wy1, wy2, wy3}, wxs[4] = {wx0, wx1, wx2, wx3};
+                    const float wys[4] = {wy0, wy1, wy2, wy3};
+                    // the dY rows of up to four bins of this bin row are loaded together (one latency per batch instead
+                    // of one per bin), then accumulated in bin order -- the summation order is unchanged
+                    for (int pw0 = __ffs((int)pwm) - 1; pw0 < pw_n && (pwm >> pw0); pw0 += 4) {
+                        float4 gv[4];
 #pragma unroll
-                        for (int r = 0; r < 4; r++)
+                        for (int j = 0; j < 4; j++) {
+                            gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (((pwm >> (pw0 + j)) & 1u) && c_ok) gv[j] = ld4(go + (size_t)(ph * pw_n + pw0 + j) * channels);
+                        }
 #pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const float w = wys[r] * wxs[q];
-                                acc[r * 4 + q].x += w * gv.x;
-                                acc[r * 4 + q].y += w * gv.y;
-                                acc[r * 4 + q].z += w * gv.z;
-                                acc[r * 4 + q].w += w * gv.w;
-                            }
+                        for (int j = 0; j < 4; j++) {
+                            if (!((pwm >> (pw0 + j)) & 1u)) continue;
+                            const int pw = pw0 + j;
+                            const float wxs[4] = {s_wx[wave][0][pw], s_wx[wave][1][pw], s_wx[wave][2][pw], s_wx[wave][3][pw]};
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const float w = wys[r] * wxs[q];
+                                    acc[r * 4 + q].x += w * gv[j].x;
+                                    acc[r * 4 + q].y += w * gv[j].y;
+                                    acc[r * 4 + q].z += w * gv[j].z;
+                                    acc[r * 4 + q].w += w * gv[j].w;
+                                }
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -911,7 +938,8 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
 }
 
 BRCNN_API size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois) {
-    return (size_t)(n_rois > 0 ? n_rois : 1) * sizeof(RoiRec) + 256;
+    // records + per-image [first, last) RoI index ranges (2 x BRCNN_GATHER_MAX_BATCH ints)
+    return (size_t)(n_rois > 0 ? n_rois : 1) * sizeof(RoiRec) + 256 + 2 * 1024 * sizeof(int);
 }
 
 BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, const int* heights_host,
@@ -943,20 +971,27 @@ BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, co
     for (int l = num_levels; l <= BRCNN_MAX_LEVELS; l++) gl.blk0[l] = blk;
     hipStream_t s = (hipStream_t)stream;
     RoiRec* recs = (RoiRec*)workspace;
+    int* ranges = nullptr;
+    const size_t rec_bytes = ((size_t)(n_rois > 0 ? n_rois : 1) * sizeof(RoiRec) + 255) & ~(size_t)255;
+    if (batch <= 1024 && workspace_bytes >= rec_bytes + 2 * 1024 * sizeof(int)) {
+        ranges = (int*)((char*)workspace + rec_bytes);
+        BRCNN_HIP_CHECK(hipMemsetAsync(ranges, 0x7f, 1024 * sizeof(int), s));          // first = large
+        BRCNN_HIP_CHECK(hipMemsetAsync(ranges + 1024, 0, 1024 * sizeof(int), s));      // last = 0
+    }
     if (n_rois > 0) {
         hipLaunchKernelGGL(roi_record_kernel, dim3(brcnn_cdiv(n_rois, 256)), dim3(256), 0, s, rois, n_rois, lv, batch,
-                           pooled_h, pooled_w, sampling_ratio, recs);
+                           pooled_h, pooled_w, sampling_ratio, recs, ranges);
         BRCNN_LAUNCH_CHECK();
     }
     if (dtype == BRCNN_DT_F32)
         hipLaunchKernelGGL(roi_grad_gather_kernel<float>, dim3(blk), dim3(256), 0, s, (const float*)grad_output, lv, gl, rois,
-                           recs, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
+                           recs, ranges, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
     else if (dtype == BRCNN_DT_BF16)
         hipLaunchKernelGGL(roi_grad_gather_kernel<bf16_t>, dim3(blk), dim3(256), 0, s, (const bf16_t*)grad_output, lv, gl, rois,
-                           recs, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
+                           recs, ranges, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
     else
         hipLaunchKernelGGL(roi_grad_gather_kernel<f16_t>, dim3(blk), dim3(256), 0, s, (const f16_t*)grad_output, lv, gl, rois,
-                           recs, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
+                           recs, ranges, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
