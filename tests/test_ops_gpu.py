@@ -135,6 +135,19 @@ def test_roi_extract_fused_matches_per_level():
     assert torch.equal(lv2, lv)
     err = (out2.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
     assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+    # the other selectable forms of the footprint kernel (2: per-bin loop, round-robin rows; 3: column streaming,
+    # round-robin rows): same bound; the XCD-contiguous row order of the default changes no value
+    try:
+        for mode in (2, 3):
+            lib.load().brcnn_roi_align_set_exact(mode)
+            o_m, lv_m = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+            assert torch.equal(lv_m, lv)
+            err_m = (o_m.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+            assert err_m <= 1e-5 * max(1.0, ref.abs().max().item()), (mode, err_m)
+            if mode == 3:
+                assert torch.equal(o_m, out2)
+    finally:
+        lib.load().brcnn_roi_align_set_exact(0)
     huge = torch.tensor([[0., -500., -300., 2500., 1900.], [1., 10., 10., 1300., 790.]])   # bins > 64 px
     o1, _ = ops.roi_extract(fg, huge.to(DEV), 7, strides, 56, 0)
     r1 = orc.roi_align_forward(feats[4], huge, 7, 1. / 128, 0, 'avg', True)
