@@ -468,7 +468,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                            const float* __restrict__ beta, double* __restrict__ gsum,
                                                            float* __restrict__ part, GnSegs sg, int N, int C, int G,
                                                            int rows_per_block, int relu) {
-    __shared__ float red[4][256][2];
+    // V channels per lane: 16-byte loads for both element widths (8 x 16-bit / 4 x fp32); LPR lanes cover 256 channels
+    // of a row, RL rows are in flight per pass over the block's row strip
+    constexpr int V = sizeof(T) == 2 ? 8 : 4, LPR = 256 / V, RL = 256 / LPR;
+    __shared__ float red[RL][256][2];
     const int seg = blockIdx.y / N, n = blockIdx.y - seg * N;
     const int HW = sg.hw[seg];
     const int row0 = blockIdx.x * rows_per_block;
@@ -482,24 +485,36 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const size_t base = (size_t)(sg.row0[seg] + (long long)n * HW) * C;
     const T* xs = x + base;
     const T* ds = dy + base;
-    const int c4n = C >> 2;
-    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    for (int q0 = q; q0 < c4n; q0 += 64) {
-        float mean[4], rstd[4], gm[4], bt[4];
+    const int cvn = C / V;
+    const int q = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    for (int q0 = q; q0 < cvn; q0 += LPR) {
+        float mean[V], rstd[V], gm[V], bt[V];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int c = q0 * 4 + e;
+        for (int e = 0; e < V; e++) {
+            const int c = q0 * V + e;
             const float2 mr = reinterpret_cast<const float2*>(stats + ((size_t)blockIdx.y * G + c / cpg) * 2)[0];
             mean[e] = mr.x; rstd[e] = mr.y; gm[e] = gamma[c]; bt[e] = beta[c];
         }
-        float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-#pragma unroll 8
-        for (int r = row0 + rl; r < row1; r += 4) {
-            const float4 xv = ld4(xs + (size_t)r * C + q0 * 4);
-            const float4 dv = ld4(ds + (size_t)r * C + q0 * 4);
-            const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+        float a[V], b[V];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < V; e++) a[e] = b[e] = 0.f;
+#pragma unroll 4
+        for (int r = row0 + rl; r < row1; r += RL) {
+            float xi[V], di[V];
+            if constexpr (V == 8) {
+                float4 x0, x1, d0, d1;
+                ld8(xs + (size_t)r * C + q0 * 8, x0, x1);
+                ld8(ds + (size_t)r * C + q0 * 8, d0, d1);
+                xi[0] = x0.x; xi[1] = x0.y; xi[2] = x0.z; xi[3] = x0.w; xi[4] = x1.x; xi[5] = x1.y; xi[6] = x1.z; xi[7] = x1.w;
+                di[0] = d0.x; di[1] = d0.y; di[2] = d0.z; di[3] = d0.w; di[4] = d1.x; di[5] = d1.y; di[6] = d1.z; di[7] = d1.w;
+            } else {
+                const float4 xv = ld4(xs + (size_t)r * C + q0 * 4);
+                const float4 dv = ld4(ds + (size_t)r * C + q0 * 4);
+                xi[0] = xv.x; xi[1] = xv.y; xi[2] = xv.z; xi[3] = xv.w;
+                di[0] = dv.x; di[1] = dv.y; di[2] = dv.z; di[3] = dv.w;
+            }
+#pragma unroll
+            for (int e = 0; e < V; e++) {
                 const float xh = (xi[e] - mean[e]) * rstd[e];
                 const float g = (relu && xh * gm[e] + bt[e] <= 0.f) ? 0.f : di[e];
                 a[e] += g;
@@ -507,15 +522,16 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            red[rl][q0 * 4 + e][0] = a[e];
-            red[rl][q0 * 4 + e][1] = b[e];
+        for (int e = 0; e < V; e++) {
+            red[rl][q0 * V + e][0] = a[e];
+            red[rl][q0 * V + e][1] = b[e];
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        const float A = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
-        const float B = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+        float A = 0.f, B = 0.f;
+#pragma unroll
+        for (int w = 0; w < RL; w++) { A += red[w][c][0]; B += red[w][c][1]; }
         my_part[c] = A;
         my_part[C + c] = B;
         red[0][c][0] = A * gamma[c];
@@ -1011,7 +1027,8 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi_backward(const void* dy, const void* x,
                                                   int relu, int dtype, void* stream) {
     if (!dy || !x || !stats || !gamma || !beta || !dx || !dgamma || !dbeta || !workspace || batch <= 0 ||
         num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS || !hw_host || channels <= 0 || channels > 256 ||
-        groups <= 0 || channels % groups || (channels & 3) || !brcnn_elem_ok(dtype))
+        groups <= 0 || channels % groups || (channels & 3) || !brcnn_elem_ok(dtype) ||
+        (dtype != BRCNN_DT_F32 && (channels & 7)))          // 16-bit rows are read 8 channels (16 bytes) per lane
         return BRCNN_EINVAL;
     if (workspace_bytes < brcnn_groupnorm_nhwc_multi_backward_workspace_bytes(batch, num_segments, hw_host, channels, groups))
         return BRCNN_EINVAL;
