@@ -104,6 +104,7 @@ int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s);
 // fills p.sk_*; p.sk_wgs = 0 when the plain one-tile-per-workgroup launch is the better one
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
 int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
+bool sk_par_enabled();       // split-K of few-tile launches is on (conv_igemm_bf16.hip, sk_table_par)
 // the same schedule on the exact-fp32 MFMA (conv_pp_f32.hip); plain epilogue
 int dispatch_conv_pp_f32(ConvParams& p, hipStream_t s);
 

@@ -615,7 +615,11 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
         p.pp_rows = g_pp_f32_mode >= 128 ? g_pp_f32_mode : 0;
         // (a K = 256 layer with a residual stream is eight K tiles deep and output-bound: measured 6 % behind the
         // 64 x 64 kernel, tools/conv_bench.py "s3 1x1 256->1024 +res")
-        if (g_pp_f32_mode >= 2 || (t48 >= 208 && (p.K >= 512 || !p.residual))) return dispatch_conv_pp_f32(p, s);
+        // ... and the few-tile layers of the 25 x 42 maps (66-132 such tiles on 256 CUs) with a K loop of >= 64 tiles: split-K
+        // pieces summed at the end fill the device (stage-4 3x3: 444 -> 380 us, 2048 -> 512 1x1: 185 -> 171 us; reproducible,
+        // equal to the unsplit sum to fp32 round-off -- the one place where the kernel choice changes the association)
+        const bool few = sk_par_enabled() && t48 >= 64 && t48 < 208 && p.K / 32 >= 64 && p.dilate <= 1;
+        if (g_pp_f32_mode >= 2 || ((t48 >= 208 || few) && (p.K >= 512 || !p.residual))) return dispatch_conv_pp_f32(p, s);
     }
     // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the SMALLEST tile,
     // 64x64 (4 waves x one 32x32 MFMA tile, 32 KiB LDS -> up to 5 resident workgroups / CU,

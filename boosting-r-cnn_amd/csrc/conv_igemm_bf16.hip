@@ -598,7 +598,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
 // Per stream: the hand-over slots (fp32 accumulators of one tile each), their flags and the launch epoch.  Launches
 // on one stream are serialised, so a slot is free again when the next launch starts.
 struct SkStream { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
-struct SkTable { long long tiles; int nk, slots, blocks; int4* items; };
+struct SkTable { long long tiles; int nk, slots, blocks; int4* items; int par; };
 constexpr size_t SK_WS_BYTES = (size_t)128 << 20;
 constexpr int SK_MAX_SLOTS = 2048;
 std::mutex g_sk_mutex;
@@ -631,7 +631,7 @@ int sk_stream_state(hipStream_t s, SkStream** out) {
 // the tile (xcd_remap's contiguous chunks), so the operand rows and the hand-over stay in one L2.
 int sk_table(long long tiles, int nk, int slots, const SkTable** out) {
     for (auto& t : g_sk_tables)
-        if (t.tiles == tiles && t.nk == nk && t.slots == slots) { *out = &t; return 0; }
+        if (t.tiles == tiles && t.nk == nk && t.slots == slots && !t.par) { *out = &t; return 0; }
     struct Item { int tile, kb, ke, slot; };
     std::vector<Item> heads[8], wholes[8], tails[8];
     std::vector<int> slot_of((size_t)tiles, -1);
@@ -682,7 +682,7 @@ int sk_table(long long tiles, int nk, int slots, const SkTable** out) {
             if (loc < queue[x].size()) v = make_int4(queue[x][loc].tile, queue[x][loc].kb, queue[x][loc].ke, queue[x][loc].slot);
             host[loc * 8 + x] = v;
         }
-    SkTable t = {tiles, nk, slots, (int)(maxlen * 8), nullptr};
+    SkTable t = {tiles, nk, slots, (int)(maxlen * 8), nullptr, 0};
     BRCNN_HIP_CHECK(hipMalloc((void**)&t.items, host.size() * sizeof(int4)));
     BRCNN_HIP_CHECK(hipMemcpy(t.items, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice));
     if (g_sk_tables.capacity() < 256) g_sk_tables.reserve(256);
@@ -692,6 +692,73 @@ int sk_table(long long tiles, int nk, int slots, const SkTable** out) {
     return 0;
 }
 
+// Split-K table for launches with FEWER tiles than resident workgroups (the 8 x 25 x 42 maps of stage 4 / P4-P6 at
+// batch 8: 66-132 tiles of the eight-phase kernels on 256 CUs).  The chained hand-over cannot help there -- a tile's
+// K loop stays one serial chain --, so the pieces of a tile run side by side from zero and are summed at the end:
+// tiles x nk is cut into `slots` equal ranges (boundaries one K tile away from a tile edge snap onto it); a range
+// holds the END of one tile and / or the START or a MIDDLE of the next.  Every piece but the one holding the tile's
+// last K tile stores its accumulators to ws[range]; that last piece (w = range | n_prev << 16 | 1 << 30) adds the
+// n_prev ranges before its own, in K order.  Deterministic, but not the unsplit chain's bits: the launchers take this
+// table only where the heuristic (or the forcing hook) says so, and `brcnn_conv_set_tile_bf16(-8)` switches it off.
+// Layout: all storing pieces first (longest first), then the finishing ones (longest first); block b goes to XCD
+// b % 8 and every XCD starts its blocks in order, so no finishing piece can occupy a CU before every storing piece of
+// its XCD has been started.
+int sk_table_par(long long tiles, int nk, int slots, const SkTable** out) {
+    for (auto& t : g_sk_tables)
+        if (t.tiles == tiles && t.nk == nk && t.slots == slots && t.par) { *out = &t; return 0; }
+    struct Item { int tile, kb, ke, w; };
+    std::vector<Item> storing, finishing;
+    const long long iters = tiles * nk;
+    std::vector<long long> bound((size_t)slots + 1);
+    for (int r = 0; r <= slots; r++) {
+        long long b = iters * r / slots;
+        const long long rem = b % nk;
+        if (rem == 1) b -= 1;
+        else if (rem == nk - 1) b += 1;
+        bound[r] = b;
+    }
+    std::vector<int> first_range((size_t)tiles, -1);
+    for (int r = 0; r < slots; r++) {
+        long long sw = bound[r];
+        const long long ew = bound[r + 1];
+        while (sw < ew) {
+            const long long tile = sw / nk, t0 = tile * nk;
+            const long long pe = (ew < t0 + nk) ? ew : t0 + nk;
+            const int kb = (int)(sw - t0), ke = (int)(pe - t0);
+            if (first_range[tile] < 0) first_range[tile] = r;
+            if (ke == nk) {
+                const int n_prev = r - first_range[tile];
+                if (n_prev > 255) return BRCNN_EINVAL;
+                finishing.push_back({(int)tile, kb, ke, r | (n_prev << 16) | (1 << 30)});
+            } else {
+                storing.push_back({(int)tile, kb, ke, r | (1 << 30)});
+            }
+            sw = pe;
+        }
+    }
+    auto longer = [](const Item& a, const Item& b) { return a.ke - a.kb > b.ke - b.kb; };
+    std::stable_sort(storing.begin(), storing.end(), longer);
+    std::stable_sort(finishing.begin(), finishing.end(), longer);
+    std::vector<int4> host;
+    for (auto& it : storing) host.push_back(make_int4(it.tile, it.kb, it.ke, it.w));
+    while (host.size() % 8) host.push_back(make_int4(-1, 0, 0, 0));       // the finishing pieces start on a fresh round of XCDs
+    for (auto& it : finishing) host.push_back(make_int4(it.tile, it.kb, it.ke, it.w));
+    SkTable t = {tiles, nk, slots, (int)host.size(), nullptr, 1};
+    BRCNN_HIP_CHECK(hipMalloc((void**)&t.items, host.size() * sizeof(int4)));
+    BRCNN_HIP_CHECK(hipMemcpy(t.items, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice));
+    if (g_sk_tables.capacity() < 256) g_sk_tables.reserve(256);
+    if (g_sk_tables.size() >= 256) { (void)hipFree(t.items); return BRCNN_EINVAL; }
+    g_sk_tables.push_back(t);
+    *out = &g_sk_tables.back();
+    return 0;
+}
+
+// OFF by default: it is the one schedule whose result is not the unsplit chain's bits, so with it the value of a conv
+// would depend on the tile count -- i.e. on the batch size (the batched and the per-image paths stop agreeing bit for
+// bit, tests/test_golden_gpu.py) -- for +0.7 % on the fp32 inference pass (25.20 -> 25.02 ms; stage-4 3x3 402 -> 369 us,
+// first FC 476 -> 413 us, 2048 -> 512 1x1 184 -> 166 us); bf16 gains nothing (tools/splitk_try.py).
+int g_sk_par = 0;       // tuning hook (set_tile_bf16(-8 / -9 / -10)): split-K of few-tile launches off / heuristic / forced
+
 // the schedule of one launch, or sk_wgs = 0: `slots` = resident workgroups of this kernel on the whole device;
 // `min_nk`: shortest K loop (in K tiles) the heuristic cuts for this tile shape (0: the 128 x 128 rule below)
 static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int min_nk = 0, int bke = BKE, double max_eff = 0.9) {
@@ -699,9 +766,30 @@ static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int 
     if (g_sk_mode == 0 || slots <= 0 || slots > SK_MAX_SLOTS) return 0;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
     const int nk = p.K / bke;
-    // every slot must own at least one whole tile's worth of iterations: a tile then straddles two ranges at most
-    if (tiles < slots || nk < 2 || tiles * nk >= 0x7fffffffLL) return 0;
+    if (nk < 2 || tiles * nk >= 0x7fffffffLL) return 0;
     if ((size_t)(slots + 8) * bm * bn * sizeof(float) > SK_WS_BYTES) return 0;
+    if (tiles < slots) {
+        // fewer tiles than resident workgroups: split-K with a sum at the end (eight-phase kernels only: min_nk > 0),
+        // where at least a fifth of the device would idle and every piece keeps >= min_nk / 2 K tiles
+        if (min_nk <= 0 || g_sk_par == 0) return 0;
+        if (g_sk_par == 1 && (tiles * 5 > (long long)slots * 4 || tiles * nk / slots < min_nk / 2 || tiles * nk / slots < 4)) return 0;
+        if (tiles * nk / slots < 2) return 0;
+        std::lock_guard<std::mutex> lock(g_sk_mutex);
+        SkStream* st = nullptr;
+        int rc = sk_stream_state(s, &st);
+        if (rc) return rc;
+        const SkTable* tab = nullptr;
+        rc = sk_table_par(tiles, nk, slots, &tab);
+        if (rc) return rc == BRCNN_EINVAL ? 0 : rc;
+        if (++st->epoch == 0) st->epoch = 1;
+        p.sk_wgs = tab->blocks;
+        p.sk_items = tab->items;
+        p.sk_ws = st->ws;
+        p.sk_flags = st->flags;
+        p.sk_epoch = st->epoch;
+        return 0;
+    }
+    // every slot must own at least one whole tile's worth of iterations: a tile then straddles two ranges at most
     if (g_sk_mode == 1) {
         // where it pays (tools/conv_bench_bf16.py, profiles/r03_notes.md): the 128 x 128 tile with a last generation of
         // workgroups that leaves most of the device idle and a K loop of >= 32 tiles -- every slot pays one hand-over
@@ -827,6 +915,7 @@ int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 wave
 
 namespace brcnn_conv {
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s) { return sk_plan(p, slots, bm, bn, s, 16); }
+bool sk_par_enabled() { return g_sk_par != 0 && g_sk_mode != 0; }
 // fp32 (K tiles of 32 values, 16x the MFMA time per tile): a hand-over is cheap against a tile, any idle CU is not
 int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s) { return sk_plan(p, slots, bm, bn, s, 8, 32, 0.97); }
 
@@ -903,6 +992,7 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
     if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced
+    if (mtnt <= -8 && mtnt >= -10) { g_sk_par = -8 - mtnt; return 0; }       // split-K of few-tile launches: -8 off, -9 heuristic, -10 forced
     if (mtnt == -6 || mtnt == -7) { g_pp_mode = mtnt == -7; return 0; }      // eight-phase kernel: -6 never, -7 heuristic
     const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844};
     bool found = false;

@@ -42,13 +42,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    int tile, kb = 0, ke = nk, sk_slot = 0;
+    int tile, kb = 0, ke = nk, sk_slot = 0, sk_nprev = 0;
+    bool sk_par = false;        // split-K pieces summed at the end (table bit 30) instead of the chained hand-over
     if constexpr (SK) {
         const int4 item = p.sk_items[blockIdx.x];
         tile = __builtin_amdgcn_readfirstlane(item.x);
         kb = __builtin_amdgcn_readfirstlane(item.y);
         ke = __builtin_amdgcn_readfirstlane(item.z);
-        sk_slot = __builtin_amdgcn_readfirstlane(item.w);
+        const int sk_w = __builtin_amdgcn_readfirstlane(item.w);
+        sk_slot = sk_w & 0xffff;
+        sk_nprev = (sk_w >> 16) & 0xff;
+        sk_par = ((sk_w >> 30) & 1) != 0;
         if (tile < 0) return;
     } else {
         tile = xcd_remap(blockIdx.x, nwg);
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     stage_A(7, 1, kb + 1 < ke);
     advance_tap();                                   // -> K tile kb + 2
     if constexpr (SK) {
-        if (kb > 0) {
+        if (kb > 0 && !sk_par) {
             // the K head of this tile, published by a workgroup of the launch's first round: one lane polls (bounded),
             // one agent-scope acquire, then plain loads into the accumulators (the DMA above stays in flight: these
             // are ordinary loads the compiler counts itself, issued after it)
@@ -394,6 +398,33 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
                 __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
+        }
+        if (sk_par && sk_nprev > 0) {
+            // split-K (launches with fewer tiles than CUs): the pieces of a tile ran side by side from zero; the piece
+            // that holds the tile's last K tile adds the partial sums of the others -- the slots before its own, in K
+            // order: a fixed association, so the result is reproducible (not the unsplit chain's bits)
+            for (int j = sk_nprev; j >= 1; j--) {
+                const int sl = sk_slot - j;
+                if (tid == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
+                           ++spins < (1 << 24))
+                        __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_ws) + (size_t)sl * (BM * BN / 4) + wave * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < MT; a++)
+#pragma unroll
+                    for (int b = 0; b < NT; b++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const f32x4 v = src[((a * NT + b) * 4 + g) * (NW * 64)];
+                            acc[a][b][4 * g + 0] += v.x; acc[a][b][4 * g + 1] += v.y;
+                            acc[a][b][4 * g + 2] += v.z; acc[a][b][4 * g + 3] += v.w;
+                        }
+            }
         }
     }
 

@@ -1002,3 +1002,30 @@ def test_f32_eight_phase_kernel_data_gradient():
             assert torch.equal(outs[0][0], outs[mode][0]) and torch.equal(outs[0][1], outs[mode][1]), mode
     finally:
         L.brcnn_conv_set_tile(-2, 1)
+
+
+def test_f32_split_k_option_is_reproducible_and_within_round_off():
+    """the optional split-K of few-tile launches (brcnn_conv_set_tile_bf16(-9); off by default because its result is
+    not the unsplit chain's bits): pieces of a tile summed at the end in a fixed order -- the same bits run to run,
+    the unsplit result to fp32 round-off, and untouched launches (enough tiles) keep their bits"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(8, 25, 42, 512, generator=g).to(DEV)
+    w = (torch.randn(512, 3, 3, 512, generator=g) / 68).to(DEV)
+    xb = torch.randn(8, 50, 84, 256, generator=g).to(DEV)
+    wb = (torch.randn(256, 3, 3, 256, generator=g) / 48).to(DEV)
+    sc = (torch.rand(512, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(512, generator=g).to(DEV)
+    try:
+        ref = ops.conv2d_nhwc(x, w, sc, sh, None, True, 1, 1)
+        refb = ops.conv2d_nhwc(xb, wb, None, None, None, False, 1, 1)
+        assert L.brcnn_conv_set_tile_bf16(-9) == 0
+        a = ops.conv2d_nhwc(x, w, sc, sh, None, True, 1, 1)
+        b = ops.conv2d_nhwc(x, w, sc, sh, None, True, 1, 1)
+        assert torch.equal(a, b)
+        assert not torch.equal(a, ref)          # the layer IS split (66 x 2 tiles of 128 x 256 on 256 CUs)
+        assert (a - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        assert torch.equal(ops.conv2d_nhwc(xb, wb, None, None, None, False, 1, 1), refb)
+    finally:
+        L.brcnn_conv_set_tile_bf16(-8)
