@@ -152,7 +152,7 @@ def train_bench(args, world, rank, device):
         # hooks, so the second-stream weight gradients and "dW is weight.grad" stay on (brcnn/distributed.py)
         from brcnn.distributed import GradReducer
         reducer = GradReducer(params, slice_mb=float(os.environ.get('BRCNN_REDUCER_SLICE_MB', '64')),
-                              overlap=os.environ.get('BRCNN_REDUCER_OVERLAP', '1') != '0')
+                              overlap=os.environ.get('BRCNN_REDUCER_OVERLAP', '0') == '1')
         reducer.broadcast_parameters(model)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
     gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)

@@ -8,11 +8,14 @@ same on every rank.  `GradReducer` therefore all-reduces slices of that arena in
 accumulator hooks, so the N = 1 optimisations stay on under torch.distributed (weight-gradient launches on the
 second stream, dW handed to `.grad` unchanged):
 
-* as the backward pass fills the arena, every finished slice of `slice_mb` MiB is all-reduced on a communication
-  stream behind an event of the stream that launched its last writer -- the collective overlaps the rest of the
-  backward pass;
-* at the end (`reduce()`): the remainder of the arena, and the few hundred small gradients that do not live in it
-  (BatchNorm / GroupNorm affine, biases, Scale) as one flattened bucket;
+* at the end of the backward pass (`reduce()`): the arena in ONE all-reduce, and the few hundred small gradients that
+  do not live in it (BatchNorm / GroupNorm affine, biases, Scale) as one flattened bucket;
+* `overlap=True` (off by default): as the backward pass fills the arena, every finished slice of `slice_mb` MiB is
+  all-reduced on a communication stream behind an event of the stream that launched its last writer.  Measured at
+  world size 1 on MI355X (profiles/r03_notes.md): with three streams already busy (main, weight gradients, proposals)
+  a fourth stream that WAITS on a weight-gradient event costs the step 1.4-4 ms (19.7 -> 21.6-24 ms, depending on
+  which pooled stream it is; the wait alone, without any RCCL call, 3.3 ms) -- more than the ~1.3 ms of ring
+  all-reduce it could hide at 8 GPUs.  The single all-reduce after the backward pass costs 0.45 ms at world size 1;
 * the average is RCCL's `ReduceOp.AVG` (sum, then one multiply, on backends without it).
 
 One process per GPU; the image batch is sharded by the sampler, weights are replicated (`broadcast_parameters`).
@@ -24,7 +27,7 @@ from . import autograd as _A
 
 
 class GradReducer:
-    def __init__(self, params, process_group=None, slice_mb=64, overlap=True):
+    def __init__(self, params, process_group=None, slice_mb=64, overlap=False):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('GradReducer needs an initialised torch.distributed process group')
         self.params = [p for p in params if p.requires_grad]

@@ -38,7 +38,7 @@ def main():
         if mode == 'ddp':
             net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[local], broadcast_buffers=False)
         if mode == 'own':       # the N > 1 path of bench.py / train_detector: arena all-reduced in place, no hooks
-            red = GradReducer([p for p in m.parameters() if p.requires_grad], slice_mb=8)
+            red = GradReducer([p for p in m.parameters() if p.requires_grad], slice_mb=8, overlap=True)   # (the sliced form; the default reduces once at the end)
             red.broadcast_parameters(m)
         for rep in range(2 if mode == 'own' else 1):     # twice: the second pass runs on a fresh arena chunk
             # ... and with the RPN branch back-propagated inside the forward pass (detectors.py): its weight gradients
