@@ -139,8 +139,12 @@ def train_bench(args, world, rank, device):
     from brcnn.optim import FusedSGD
     blocks.conv_weights_channels_last(model)        # the weight-gradient kernels' layout: no per-layer grad copies
     params = [p for p in model.parameters() if p.requires_grad]
-    # the recipes' optimizer (SGD, momentum 0.9, weight decay 1e-4, grad-clip 35) on the fused HIP step
-    opt = FusedSGD(params, lr=cfg.optimizer.lr * 1e-3, momentum=cfg.optimizer.momentum,
+    # the recipes' optimizer (SGD, momentum 0.9, weight decay 1e-4, grad-clip 35) on the fused HIP step, at the
+    # learning rate the recipe's schedule gives its FIRST iterations: lr x warmup_ratio (linear warm-up over 500
+    # iterations from ratio 0.001, configs/_base_/schedules/schedule_1x.py:5-10) -- randomly initialised weights
+    # (no checkpoint can be fetched) diverge within the timed steps at the post-warm-up rate
+    warm = float(cfg.get('lr_config', {}).get('warmup_ratio', 1e-3))
+    opt = FusedSGD(params, lr=cfg.optimizer.lr * warm, momentum=cfg.optimizer.momentum,
                    weight_decay=cfg.optimizer.weight_decay)
     opt.register_conv_weights(model, blocks.compute_dtype())
     net, reducer = model, None
@@ -152,13 +156,18 @@ def train_bench(args, world, rank, device):
         # hooks, so the second-stream weight gradients and "dW is weight.grad" stay on (brcnn/distributed.py)
         from brcnn.distributed import GradReducer
         reducer = GradReducer(params, slice_mb=float(os.environ.get('BRCNN_REDUCER_SLICE_MB', '64')),
-                              overlap=os.environ.get('BRCNN_REDUCER_OVERLAP', '0') == '1')
+                              overlap=os.environ.get('BRCNN_REDUCER_OVERLAP', '0') == '1',
+                              compress=os.environ.get('BRCNN_REDUCER_COMPRESS') or None)    # 'bf16': half the xGMI bytes
         reducer.broadcast_parameters(model)
     img, metas = synthetic_batch(args.batch, device, seed=rank)
     gtb, gtl = synthetic_gt(args.batch, device, 80, seed=rank)
     # fp16: the recipes' static loss scaling (fp16 = dict(loss_scale=512.), mmcv Fp16OptimizerHook)
     scale = 512.0 if args.train_dtype == 'f16' else 1.0
     last = {}
+    # the RandomSampler draws torch.randperm on the host (random_sampler.py:58): seeded, so that the loss of the last
+    # timed step reproduces from box to box
+    torch.manual_seed(1234 + rank)
+    reduce_ev = []
 
     # the RPN branch's backward pass inside the forward pass, beside the proposal stage (detectors.py): gradients are
     # cleared before the forward pass below, the backward seed is the static loss scale; off under DDP
@@ -172,14 +181,29 @@ def train_bench(args, world, rank, device):
         loss, log_vars = model._parse_losses(losses)
         (loss * scale if scale != 1.0 else loss).backward()
         if reducer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             reducer.reduce()
+            e1.record()
+            reduce_ev.append((e0, e1))
         opt.step(max_norm=35, loss_scale=scale)        # clip + unscale + skip-on-inf + SGD + next step's conv operands
         last['log_vars'] = log_vars
 
     steps = args.train_steps or args.steps
     dt = timed(step, steps, args.warmup, world, device)
+    from brcnn import lib as _lib
+    _lib.handover_status()          # a lost stream-K hand-over inside the timed steps is an error, not a number
+    # HIP-event time of GradReducer.reduce() on the main stream over the timed steps: join of the weight-gradient
+    # stream + the all-reduce of the arena and of the small-gradient bucket (what the N > 1 runs add to the step)
+    reduce_ms = None
+    if reduce_ev:
+        tail = reduce_ev[-steps:]
+        reduce_ms = sum(a.elapsed_time(b) for a, b in tail) / len(tail)
+    grad_bytes = sum(p.numel() for p in params) * 4
     from brcnn import profiling
-    roof = profiling.train_conv_roofline(step, dtype=args.train_dtype) if rank == 0 else None
+    # every rank runs the roofline pass: step() contains collectives (gradient all-reduce, the fused RPN normaliser,
+    # the log scalars), so a rank-0-only pass would pair them with nothing and hang at N > 1
+    roof = profiling.train_conv_roofline(step, dtype=args.train_dtype)
     return {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN train step',
         'value': world * args.batch * steps / dt, 'unit': 'images/sec', 'ms_per_step': 1000.0 * dt / steps,
@@ -191,6 +215,9 @@ def train_bench(args, world, rank, device):
                                 ', DDP over RCCL' if world > 1 else ''),
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         'loss': float(last['log_vars']['loss']),
+        'lr': cfg.optimizer.lr * warm,
+        'grad_bytes': grad_bytes, 'reduce_ms': reduce_ms,
+        'grad_allreduce': None if reducer is None else reducer.describe(),
         'roofline': roof,
     }
 
@@ -204,25 +231,48 @@ def inference_bench(args, world, rank, device):
     last = {}
 
     def step():
+        # benchmark.py:113-114: `model(return_loss=False, rescale=True, **data)` -- forward_test, the device-resident
+        # pass, ONE device->host copy of the padded results, bbox2result to per-class numpy arrays
         with torch.no_grad():
-            det, lab, nd = model.simple_test_device(img, metas, rescale=True)
-        # results leave the device every step, as in benchmark.py (model(return_loss=False) hands back numpy)
-        last['out'] = (det.cpu(), lab.cpu(), nd.cpu())
+            last['out'] = model(return_loss=False, rescale=True, img=[img], img_metas=[metas])
 
     dt = timed(step, args.steps, args.warmup, world, device)
+    from brcnn import lib as _lib
+    _lib.handover_status()          # a lost stream-K hand-over inside the timed steps is an error, not a number
     from brcnn import profiling
     roof = profiling.conv_stack_roofline(model, img, metas, iters=3, dtype=args.dtype)
+
+    def device_pass():
+        with torch.no_grad():
+            det, lab, nd = model.simple_test_device(img, metas, rescale=True)
+        return det.cpu(), lab.cpu(), nd.cpu()
+    stages = profiling.stage_breakdown(device_pass, cuda=True)
+    # batch-1 latency (benchmark.py runs samples_per_gpu=1; the only published neighbours, BASELINE.md, are batch 1):
+    # synchronised passes over one image, mean of `steps`
+    img1, metas1 = img[:1].contiguous(), metas[:1]
+    with torch.no_grad():
+        for _ in range(max(2, args.warmup)):
+            model(return_loss=False, rescale=True, img=[img1], img_metas=[metas1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(return_loss=False, rescale=True, img=[img1], img_metas=[metas1])
+        torch.cuda.synchronize()
+        lat1 = (time.perf_counter() - t0) / args.steps * 1000.0
     line = {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN inference',
         'value': world * args.batch * args.steps / dt, 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': 'boosting_rcnn_r50_pafpn_1x_utdac.py inference (simple_test, rescale), '
+        'config': {'workload': 'boosting_rcnn_r50_pafpn_1x_utdac.py inference (model(return_loss=False, rescale=True): '
+                               'device pass + result copy + bbox2result), '
                                f'batch {args.batch} x 3x800x1344 per GPU, {args.dtype} MFMA conv stack, '
                                '1000 pre-NMS / 256 proposals per image, seeded synthetic weights',
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         'roofline': roof,
-        'detections_last_step': int(last['out'][2].sum()),
+        'stages_ms': stages,
+        'latency_bs1_ms': lat1, 'fps_bs1': 1000.0 / lat1,
+        'detections_last_step': int(sum(len(c) for im in last['out'] for c in im)),
     }
     return line, cfg, model
 
@@ -240,6 +290,12 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hook (tests/test_ddp_gpu.py): every rank on cuda:0 and collectives over gloo, to run the N > 1 control flow
+    # on a one-GPU box (RCCL refuses two ranks per device).  Not a measurement configuration.
+    one_device = os.environ.get('BRCNN_DIST_ONE_DEVICE', '0') == '1'
+    backend = os.environ.get('BRCNN_DIST_BACKEND', 'nccl')
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1 or args.force_reducer:
@@ -249,7 +305,10 @@ def main():
             with socket.socket() as s_:
                 s_.bind(('127.0.0.1', 0))
                 os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     line, cfg = None, None
     if args.mode in ('both', 'inference'):

@@ -366,7 +366,10 @@ class EpochBasedRunner:
             n_since += 1
             if (i + 1) % self.log_interval == 0 or i + 1 == len(data_loader):
                 now = time.time()
-                self._log(data_loader, (now - t_last) / max(n_since, 1))
+                self._log(data_loader, (now - t_last) / max(n_since, 1))        # reads the log scalars: a sync point
+                if torch.cuda.is_available():
+                    from . import lib as _lib
+                    _lib.handover_status()      # a lost stream-K hand-over since the last log line raises here
                 t_last, n_since = now, 0
         self.epoch += 1
 
@@ -459,7 +462,10 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     elif distributed:
         # default on the HIP device: the weight-gradient arena all-reduced in place (distributed.GradReducer)
         from .distributed import GradReducer
-        reducer = GradReducer([p for p in model.parameters() if p.requires_grad])
+        # `grad_allreduce_dtype = 'bf16'` in the config: the weight-gradient arena crosses xGMI as bf16 (fp32 master
+        # weights and optimizer step unchanged)
+        reducer = GradReducer([p for p in model.parameters() if p.requires_grad],
+                              compress=cfg.get('grad_allreduce_dtype', None) or os.environ.get('BRCNN_REDUCER_COMPRESS') or None)
         reducer.broadcast_parameters(model)
     optimizer = build_optimizer(model, cfg.optimizer)
     runner_cfg = cfg.get('runner', None) or dict(type='EpochBasedRunner', max_epochs=cfg.total_epochs)

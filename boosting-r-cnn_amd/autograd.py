@@ -115,6 +115,8 @@ def _side_stream_for(param, device):
     key = (device.type, device.index)
     seen = _side_seen.setdefault(key, set())
     if id(param) in seen:
+        if grad_arena.listener is not None and hasattr(grad_arena.listener, 'shared_parameter'):
+            grad_arena.listener.shared_parameter(param)
         torch.cuda.current_stream(device).wait_stream(side)
         return None
     seen.add(id(param))
@@ -238,7 +240,7 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
             main = torch.cuda.current_stream(dy.device)
             side.wait_event(main.record_event())            # dy, x and the zero fill of dW are complete here
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
-                                                   cin, cout, kh, kw, stride, pad, dt, side.cuda_stream)
+                                                   cin, cout, kh, kw, stride, pad, dt, _L.stream_handle(side))
             dy.record_stream(side)                          # the allocator must not recycle them under the launch
             x_cat.record_stream(side)
             _queue_stream_join(main, side)

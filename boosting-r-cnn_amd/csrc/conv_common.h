@@ -69,6 +69,11 @@ struct ConvParams {
     float* sk_ws;
     unsigned* sk_flags;
     unsigned sk_epoch;
+    // a K tail polls its head's flag at most sk_spin_limit times (~0.3 us each); on a time-out it writes the host-mapped
+    // word sk_err (launch epoch | 1 << 31) before it falls through, and the host turns that into BRCNN_EHANDOVER
+    unsigned* sk_err;
+    int sk_spin_limit;
+    int sk_drop_publish;             // test hook (brcnn_conv_set_tile_bf16(-11)): heads do not publish
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];
@@ -104,6 +109,7 @@ int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s);
 // fills p.sk_*; p.sk_wgs = 0 when the plain one-tile-per-workgroup launch is the better one
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
 int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
+float* conv_ws_wgrad_slabs(hipStream_t s);     // the weight-gradient slab part of the stream's conv workspace (160 MiB)
 bool sk_par_enabled();       // split-K of few-tile launches is on (conv_igemm_bf16.hip, sk_table_par)
 // the same schedule on the exact-fp32 MFMA (conv_pp_f32.hip); plain epilogue
 int dispatch_conv_pp_f32(ConvParams& p, hipStream_t s);

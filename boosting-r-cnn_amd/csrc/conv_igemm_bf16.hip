@@ -188,8 +188,12 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             if (tid == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(p.sk_flags + sk_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
-                       ++spins < (1 << 24))
+                       ++spins < p.sk_spin_limit)
                     __builtin_amdgcn_s_sleep(4);
+                // a hand-over that never arrives must not end as a silent wrong result: the host-mapped error word
+                // makes the next launch on any stream (and brcnn_conv_handover_status) return BRCNN_EHANDOVER
+                if (spins >= p.sk_spin_limit)
+                    __hip_atomic_store(p.sk_err, p.sk_epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
@@ -362,7 +366,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!p.sk_drop_publish)       // (test hook: a lost hand-over)
+                    __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
@@ -597,30 +602,116 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
 // ---- chained stream-K schedule: host side ---------------------------------------------------------------------
 // Per stream: the hand-over slots (fp32 accumulators of one tile each), their flags and the launch epoch.  Launches
 // on one stream are serialised, so a slot is free again when the next launch starts.
-struct SkStream { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
+struct SkStream { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; float* slabs; char* base; int owned; };
 struct SkTable { long long tiles; int nk, slots, blocks; int4* items; int par; };
 constexpr size_t SK_WS_BYTES = (size_t)128 << 20;
 constexpr int SK_MAX_SLOTS = 2048;
+constexpr size_t SK_FLAG_BYTES = (size_t)64 << 10;          // SK_MAX_SLOTS words, padded
+constexpr size_t WGRAD_SLAB_BYTES = (size_t)160 << 20;      // == WGRAD_WS_BYTES of conv_wgrad_bf16.hip
+constexpr size_t CONV_WS_BYTES = SK_WS_BYTES + SK_FLAG_BYTES + WGRAD_SLAB_BYTES;
 std::mutex g_sk_mutex;
 std::vector<SkStream> g_sk_streams;
 std::vector<SkTable> g_sk_tables;
+// hand-over time-outs: ONE host-mapped word every K tail can write (system scope) and every launch wrapper reads
+unsigned* g_sk_err_host = nullptr;
+unsigned* g_sk_err_dev = nullptr;
+int g_sk_spin_limit = 1 << 24;       // ~5 s of polling; test hook -11 / -12: 256 polls and heads that do not publish / back
+int g_sk_drop_publish = 0;
 int g_sk_mode = 1;      // tuning hook (set_tile_bf16(-3 / -4 / -5)): 0 off, 1 heuristic, 2 wherever the tile count allows
 int g_num_cus = 0;
 
+static int sk_error_word() {
+    if (g_sk_err_host) return 0;
+    BRCNN_HIP_CHECK(hipHostMalloc((void**)&g_sk_err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *g_sk_err_host = 0;
+    BRCNN_HIP_CHECK(hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0));
+    return 0;
+}
+
+// 0, or BRCNN_EHANDOVER once per reported time-out (the word is cleared: the caller has been told)
+static int sk_take_error() {
+    if (!g_sk_err_host) return 0;
+    const unsigned v = __atomic_exchange_n(g_sk_err_host, 0u, __ATOMIC_RELAXED);
+    return v ? BRCNN_EHANDOVER : 0;
+}
+
+// The scratch of one stream's conv launches: [stream-K accumulator slots | their flags | weight-gradient slabs].
+// The CALLER provides it (brcnn_conv_set_workspace: SURVEY 8b "caller owns all buffers"); a stream without one gets a
+// library allocation on first use (fallback for plain C callers that never registered; released by
+// brcnn_conv_set_workspace(stream, NULL, 0)).  g_sk_mutex held by the caller.
+static void sk_carve(SkStream& e, char* base) {
+    e.base = base;
+    e.ws = reinterpret_cast<float*>(base);
+    e.flags = reinterpret_cast<unsigned*>(base + SK_WS_BYTES);
+    e.slabs = reinterpret_cast<float*>(base + SK_WS_BYTES + SK_FLAG_BYTES);
+}
+
 int sk_stream_state(hipStream_t s, SkStream** out) {
+    if (int rc = sk_error_word()) return rc;
     for (auto& e : g_sk_streams)
         if (e.stream == s) { *out = &e; return 0; }
     if (g_sk_streams.capacity() < 64) g_sk_streams.reserve(64);       // pointers handed out stay valid
     if (g_sk_streams.size() >= 64) return BRCNN_EINVAL;
-    SkStream e = {s, nullptr, nullptr, 0};
-    BRCNN_HIP_CHECK(hipMalloc((void**)&e.ws, SK_WS_BYTES));
-    BRCNN_HIP_CHECK(hipMalloc((void**)&e.flags, SK_MAX_SLOTS * sizeof(unsigned)));
-    BRCNN_HIP_CHECK(hipMemset(e.flags, 0, SK_MAX_SLOTS * sizeof(unsigned)));
-    BRCNN_HIP_CHECK(hipDeviceSynchronize());
+    SkStream e = {s, nullptr, nullptr, 0, nullptr, nullptr, 1};
+    char* base = nullptr;
+    BRCNN_HIP_CHECK(hipMalloc((void**)&base, CONV_WS_BYTES));
+    sk_carve(e, base);
+    BRCNN_HIP_CHECK(hipMemsetAsync(e.flags, 0, SK_FLAG_BYTES, s));    // ordered before the stream's first stream-K launch
     g_sk_streams.push_back(e);
     *out = &g_sk_streams.back();
     return 0;
 }
+
+}  // namespace
+
+namespace brcnn_conv {
+float* conv_ws_wgrad_slabs(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_sk_mutex);
+    SkStream* st = nullptr;
+    if (sk_stream_state(s, &st)) return nullptr;
+    return st->slabs;
+}
+}  // namespace brcnn_conv
+
+BRCNN_API size_t brcnn_conv_workspace_bytes(void) { return CONV_WS_BYTES; }
+
+BRCNN_API int brcnn_conv_set_workspace(void* stream, void* workspace, size_t bytes) {
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_sk_mutex);
+    if (int rc = sk_error_word()) return rc;
+    if (workspace != nullptr && (bytes < CONV_WS_BYTES || ((uintptr_t)workspace & 255))) return BRCNN_EINVAL;
+    SkStream* e = nullptr;
+    for (auto& c : g_sk_streams)
+        if (c.stream == s) e = &c;
+    if (workspace == nullptr) {             // release: the stream falls back to a library allocation on its next use
+        if (e) {
+            if (e->owned && e->base) {
+                BRCNN_HIP_CHECK(hipStreamSynchronize(s));
+                BRCNN_HIP_CHECK(hipFree(e->base));
+            }
+            const unsigned epoch = e->epoch;
+            *e = g_sk_streams.back();
+            g_sk_streams.pop_back();
+            (void)epoch;
+        }
+        return 0;
+    }
+    if (e == nullptr) {
+        if (g_sk_streams.capacity() < 64) g_sk_streams.reserve(64);
+        if (g_sk_streams.size() >= 64) return BRCNN_EINVAL;
+        g_sk_streams.push_back({s, nullptr, nullptr, 0, nullptr, nullptr, 0});
+        e = &g_sk_streams.back();
+    } else if (e->owned && e->base) {
+        BRCNN_HIP_CHECK(hipStreamSynchronize(s));
+        BRCNN_HIP_CHECK(hipFree(e->base));
+    }
+    e->owned = 0;
+    sk_carve(*e, (char*)workspace);
+    BRCNN_HIP_CHECK(hipMemsetAsync(e->flags, 0, SK_FLAG_BYTES, s));
+    return 0;
+}
+
+namespace {
 
 // The item table of (tiles, nk, slots).  The iteration space tiles x nk is cut into `slots` equal ranges (what a
 // persistent stream-K workgroup would walk, backwards: the K head of its last tile first, whole tiles, the K tail of
@@ -756,13 +847,14 @@ int sk_table_par(long long tiles, int nk, int slots, const SkTable** out) {
 // OFF by default: it is the one schedule whose result is not the unsplit chain's bits, so with it the value of a conv
 // would depend on the tile count -- i.e. on the batch size (the batched and the per-image paths stop agreeing bit for
 // bit, tests/test_golden_gpu.py) -- for +0.7 % on the fp32 inference pass (25.20 -> 25.02 ms; stage-4 3x3 402 -> 369 us,
-// first FC 476 -> 413 us, 2048 -> 512 1x1 184 -> 166 us); bf16 gains nothing (tools/splitk_try.py).
+// first FC 476 -> 413 us, 2048 -> 512 1x1 184 -> 166 us); bf16 gains nothing (tools/experiments/splitk_try.py).
 int g_sk_par = 0;       // tuning hook (set_tile_bf16(-8 / -9 / -10)): split-K of few-tile launches off / heuristic / forced
 
 // the schedule of one launch, or sk_wgs = 0: `slots` = resident workgroups of this kernel on the whole device;
 // `min_nk`: shortest K loop (in K tiles) the heuristic cuts for this tile shape (0: the 128 x 128 rule below)
 static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int min_nk = 0, int bke = BKE, double max_eff = 0.9) {
     p.sk_wgs = 0;
+    if (int e = sk_take_error()) return e;          // a K tail of an EARLIER launch gave up waiting for its head
     if (g_sk_mode == 0 || slots <= 0 || slots > SK_MAX_SLOTS) return 0;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
     const int nk = p.K / bke;
@@ -787,6 +879,9 @@ static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int 
         p.sk_ws = st->ws;
         p.sk_flags = st->flags;
         p.sk_epoch = st->epoch;
+        p.sk_err = g_sk_err_dev;
+        p.sk_spin_limit = g_sk_spin_limit;
+        p.sk_drop_publish = g_sk_drop_publish;
         return 0;
     }
     // every slot must own at least one whole tile's worth of iterations: a tile then straddles two ranges at most
@@ -816,6 +911,9 @@ static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int 
     p.sk_ws = st->ws;
     p.sk_flags = st->flags;
     p.sk_epoch = st->epoch;
+    p.sk_err = g_sk_err_dev;
+    p.sk_spin_limit = g_sk_spin_limit;
+    p.sk_drop_publish = g_sk_drop_publish;
     return 0;
 }
 
@@ -989,11 +1087,19 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
 }
 }  // namespace brcnn_conv
 
+BRCNN_API int brcnn_conv_handover_status(void) {
+    std::lock_guard<std::mutex> lock(g_sk_mutex);
+    return sk_take_error();
+}
+
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
     if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced
     if (mtnt <= -8 && mtnt >= -10) { g_sk_par = -8 - mtnt; return 0; }       // split-K of few-tile launches: -8 off, -9 heuristic, -10 forced
     if (mtnt == -6 || mtnt == -7) { g_pp_mode = mtnt == -7; return 0; }      // eight-phase kernel: -6 never, -7 heuristic
+    // test hook: -11 = the K heads of the following stream-K launches do not publish and the tails give up after 256
+    // polls (a lost hand-over, to exercise BRCNN_EHANDOVER); -12 = back to normal
+    if (mtnt == -11 || mtnt == -12) { g_sk_drop_publish = mtnt == -11; g_sk_spin_limit = mtnt == -11 ? 256 : 1 << 24; return 0; }
     const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844};
     bool found = false;
     for (int v : ok) found |= (v == mtnt);

@@ -276,8 +276,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
             if (tid == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(p.sk_flags + sk_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
-                       ++spins < (1 << 24))
+                       ++spins < p.sk_spin_limit)
                     __builtin_amdgcn_s_sleep(4);
+                // a hand-over that never arrives must not end as a silent wrong result: the host-mapped error word
+                // makes the next launch on any stream (and brcnn_conv_handover_status) return BRCNN_EHANDOVER
+                if (spins >= p.sk_spin_limit)
+                    __hip_atomic_store(p.sk_err, p.sk_epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
@@ -395,7 +399,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!p.sk_drop_publish)       // (test hook: a lost hand-over)
+                    __hip_atomic_store(p.sk_flags + sk_slot, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
@@ -408,8 +413,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
                 if (tid == 0) {
                     int spins = 0;
                     while (__hip_atomic_load(p.sk_flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch &&
-                           ++spins < (1 << 24))
+                           ++spins < p.sk_spin_limit)
                         __builtin_amdgcn_s_sleep(4);
+                    // a hand-over that never arrives must not end as a silent wrong result: the host-mapped error word
+                    // makes the next launch on any stream (and brcnn_conv_handover_status) return BRCNN_EHANDOVER
+                    if (spins >= p.sk_spin_limit)
+                        __hip_atomic_store(p.sk_err, p.sk_epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();

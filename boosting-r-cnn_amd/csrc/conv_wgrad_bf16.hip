@@ -15,6 +15,7 @@
 #include <mutex>
 #include <vector>
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -36,7 +37,7 @@ struct WgradHParams {
     unsigned dy_bytes, x_bytes;
     int pitch, gstep;       // pixel pitch of x (== Cin unless grouped); grouped: co tile t reads channels [t*gstep, +Cin)
     // slices > 1: every workgroup stores its fp32 tile to slab[(slice * tiles + tile)] in register order (plain 16-byte
-    // stores: 3.8 - 4.9 TB/s against 1.1 - 1.3 TB/s for the same volume of fp32 atomics, tools/ubench/atomic_scope.hip)
+    // stores: 3.8 - 4.9 TB/s against 1.1 - 1.3 TB/s for the same volume of fp32 atomics, tools/experiments/ubench/atomic_scope.hip)
     // and wgrad_reduce_kernel adds the slices of a tile in slice order into dw -- a fixed order: the weight gradient is
     // reproducible bit for bit.  slab == nullptr: atomics straight into dw (one slice, or no workspace).
     float* slab;
@@ -359,26 +360,13 @@ __global__ __launch_bounds__(64 * WG * WG) void wgrad_reduce_kernel(float* __res
     }
 }
 
-// per-stream slab workspace of the sliced weight gradient (launches on one stream are serialised)
-struct WgradWs { hipStream_t stream; float* buf; };
+// slab workspace of the sliced weight gradient: part of the stream's conv workspace (caller-provided through
+// brcnn_conv_set_workspace, conv_igemm_bf16.hip; launches on one stream are serialised)
 constexpr size_t WGRAD_WS_BYTES = (size_t)160 << 20;
-std::mutex g_wgrad_ws_mutex;
-std::vector<WgradWs> g_wgrad_ws;
 int g_wgrad_slabs = 1;       // tuning hook (brcnn_conv_set_tile_wgrad_bf16(10 / 11)): 0 atomics, 1 slabs + second stage
 int g_wgrad_slot_pct = 75;   // ... (2000 + n): n percent of a generation of workgroups per launch (75: the launches share the device with the main stream; same-box A/B 19.92 -> 19.75 ms per step, 50 % level, 35 % +0.9 ms)
 int g_wgrad_slot_pct_big = 75;   // ... (3000 + n): the same for launches of more than 2^17 reduction rows on the 256 x 256 tile
 int g_wgrad_two_pass = 24;   // ... (100 + n): more than n slices per tile -> the second stage runs as two passes
-
-float* wgrad_workspace(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_wgrad_ws_mutex);
-    for (auto& e : g_wgrad_ws)
-        if (e.stream == s) return e.buf;
-    if (g_wgrad_ws.size() >= 64) return nullptr;
-    WgradWs e = {s, nullptr};
-    if (hipMalloc((void**)&e.buf, WGRAD_WS_BYTES) != hipSuccess) return nullptr;
-    g_wgrad_ws.push_back(e);
-    return e.buf;
-}
 
 void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
     unsigned l = 0;
@@ -420,7 +408,7 @@ int launch(WgradHParams& p, hipStream_t s) {
     }
     p.slab = nullptr;
     if (g_wgrad_slabs && p.slices > 1 && (size_t)tiles * p.slices * T * T * sizeof(float) <= WGRAD_WS_BYTES)
-        p.slab = wgrad_workspace(s);
+        p.slab = brcnn_conv::conv_ws_wgrad_slabs(s);
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WT, ET, WG>), dim3(tiles * p.slices), dim3(64 * WG * WG), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     if (p.slab) {

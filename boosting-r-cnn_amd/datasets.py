@@ -336,90 +336,80 @@ class CocoDataset(CustomDataset):
 
 
 # --------------------------------------------------------------------------- samplers
+def _aspect_groups(flag, quantum):
+    """the members of every non-empty aspect-ratio group (`dataset.flag`: 0 tall / 1 wide) with the number of slots
+    the group fills once padded to a multiple of `quantum` (a batch, or a batch on every rank)"""
+    flag = np.asarray(flag).astype(np.int64)
+    out = []
+    for g in range(int(flag.max()) + 1 if flag.size else 0):
+        members = np.flatnonzero(flag == g)
+        if members.size:
+            out.append((members, -(-members.size // quantum) * quantum))
+    return out
+
+
 class GroupSampler(Sampler):
-    """samplers/group_sampler.py:11-53"""
+    """Single-process training order (samplers/group_sampler.py:11-53): every batch of `samples_per_gpu` holds images of
+    ONE aspect-ratio group; groups are padded to whole batches by re-drawing members; batches are visited in random
+    order.  The index stream is the reference's for the same `np.random` state (golden g13): per group one in-place
+    shuffle and one `choice` for the padding (drawn even when it is empty), then ONE permutation of the batch rows."""
 
     def __init__(self, dataset, samples_per_gpu=1):
         assert hasattr(dataset, 'flag')
         self.dataset = dataset
-        self.samples_per_gpu = samples_per_gpu
-        self.flag = dataset.flag.astype(np.int64)
-        self.group_sizes = np.bincount(self.flag)
-        self.num_samples = 0
-        for size in self.group_sizes:
-            self.num_samples += int(np.ceil(size / self.samples_per_gpu)) * self.samples_per_gpu
+        self.samples_per_gpu = int(samples_per_gpu)
+        self.flag = np.asarray(dataset.flag).astype(np.int64)
+        self.num_samples = sum(slots for _, slots in _aspect_groups(self.flag, self.samples_per_gpu))
 
     def __iter__(self):
-        indices = []
-        for i, size in enumerate(self.group_sizes):
-            if size == 0:
-                continue
-            indice = np.where(self.flag == i)[0]
-            assert len(indice) == size
-            np.random.shuffle(indice)
-            num_extra = int(np.ceil(size / self.samples_per_gpu)) * self.samples_per_gpu - len(indice)
-            indice = np.concatenate([indice, np.random.choice(indice, num_extra)])
-            indices.append(indice)
-        indices = np.concatenate(indices)
-        spg = self.samples_per_gpu
-        indices = [indices[i * spg:(i + 1) * spg] for i in np.random.permutation(range(len(indices) // spg))]
-        indices = np.concatenate(indices).astype(np.int64).tolist()
-        assert len(indices) == self.num_samples
-        return iter(indices)
+        rows = []
+        for members, slots in _aspect_groups(self.flag, self.samples_per_gpu):
+            np.random.shuffle(members)
+            pad = np.random.choice(members, slots - members.size)
+            rows.append(np.concatenate([members, pad]).reshape(-1, self.samples_per_gpu))
+        rows = np.concatenate(rows) if rows else np.zeros((0, self.samples_per_gpu), np.int64)
+        order = np.random.permutation(range(len(rows)))
+        return iter(rows[order].reshape(-1).astype(np.int64).tolist())
 
     def __len__(self):
         return self.num_samples
 
 
 class DistributedGroupSampler(Sampler):
-    """samplers/group_sampler.py:56-148: aspect-ratio groups, every rank gets whole
-    same-group batches, deterministic in (seed, epoch)"""
+    """Data-parallel training order (samplers/group_sampler.py:56-148): the same grouping, padded so that every rank
+    receives the same number of whole batches; the order is a function of (seed + epoch) alone -- every rank builds the
+    full list from its own `torch.Generator` and keeps its contiguous share.  Index stream = the reference's (golden
+    g13): per group one `randperm`, padding by cycling through that permutation, then ONE `randperm` of the batch rows."""
 
     def __init__(self, dataset, samples_per_gpu=1, num_replicas=None, rank=None, seed=0):
         if num_replicas is None or rank is None:
             import torch.distributed as dist
-            ws, rk = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
-            num_replicas = ws if num_replicas is None else num_replicas
-            rank = rk if rank is None else rank
+            live = dist.is_available() and dist.is_initialized()
+            num_replicas = (dist.get_world_size() if live else 1) if num_replicas is None else num_replicas
+            rank = (dist.get_rank() if live else 0) if rank is None else rank
+        assert hasattr(dataset, 'flag')
         self.dataset = dataset
-        self.samples_per_gpu = samples_per_gpu
-        self.num_replicas = num_replicas
-        self.rank = rank
+        self.samples_per_gpu = int(samples_per_gpu)
+        self.num_replicas, self.rank = int(num_replicas), int(rank)
+        self.seed = 0 if seed is None else seed
         self.epoch = 0
-        self.seed = seed if seed is not None else 0
-        assert hasattr(self.dataset, 'flag')
-        self.flag = self.dataset.flag
-        self.group_sizes = np.bincount(self.flag)
-        self.num_samples = 0
-        for size in self.group_sizes:
-            self.num_samples += int(math.ceil(size * 1.0 / self.samples_per_gpu / self.num_replicas)) * \
-                self.samples_per_gpu
-        self.total_size = self.num_samples * self.num_replicas
+        self.flag = dataset.flag
+        groups = _aspect_groups(self.flag, self.samples_per_gpu * self.num_replicas)
+        self.total_size = sum(slots for _, slots in groups)
+        self.num_samples = self.total_size // self.num_replicas
 
     def __iter__(self):
-        g = torch.Generator()
-        g.manual_seed(self.epoch + self.seed)
-        indices = []
-        for i, size in enumerate(self.group_sizes):
-            if size > 0:
-                indice = np.where(self.flag == i)[0]
-                assert len(indice) == size
-                indice = indice[list(torch.randperm(int(size), generator=g).numpy())].tolist()
-                extra = int(math.ceil(size * 1.0 / self.samples_per_gpu / self.num_replicas)) * \
-                    self.samples_per_gpu * self.num_replicas - len(indice)
-                tmp = indice.copy()
-                for _ in range(extra // size):
-                    indice.extend(tmp)
-                indice.extend(tmp[:extra % size])
-                indices.extend(indice)
-        assert len(indices) == self.total_size
-        spg = self.samples_per_gpu
-        indices = [indices[j] for i in list(torch.randperm(len(indices) // spg, generator=g))
-                   for j in range(i * spg, (i + 1) * spg)]
-        offset = self.num_samples * self.rank
-        indices = indices[offset:offset + self.num_samples]
-        assert len(indices) == self.num_samples
-        return iter(indices)
+        gen = torch.Generator()
+        gen.manual_seed(self.epoch + self.seed)
+        rows = []
+        for members, slots in _aspect_groups(self.flag, self.samples_per_gpu * self.num_replicas):
+            shuffled = members[torch.randperm(members.size, generator=gen).numpy()]
+            rows.append(np.resize(shuffled, slots).reshape(-1, self.samples_per_gpu))      # cyclic padding
+        rows = np.concatenate(rows) if rows else np.zeros((0, self.samples_per_gpu), np.int64)
+        order = torch.randperm(len(rows), generator=gen).numpy()
+        per_rank = len(rows) // self.num_replicas
+        mine = rows[order][self.rank * per_rank:(self.rank + 1) * per_rank]
+        return iter(mine.reshape(-1).astype(np.int64).tolist())
 
     def __len__(self):
         return self.num_samples

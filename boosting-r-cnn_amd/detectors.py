@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .blocks import to_nchw_view, to_nhwc
 from .core import bbox2result
+from .profiling import stage_mark
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -192,8 +193,10 @@ class TwoStageDetector(BaseDetector):
             x = self.backbone.forward_from_nchw(img)
         else:
             x = self.backbone.forward_nhwc(to_nhwc(img))
+        stage_mark('backbone')
         if self.with_neck:
             x = self.neck.forward_nhwc(x)
+            stage_mark('neck')
         return x
 
     def extract_feat(self, img):
@@ -334,10 +337,14 @@ class TwoStageDetector(BaseDetector):
         feats = self.extract_feat_nhwc(img)
         rpn = self.rpn_head
         cls, reg, iou = rpn.split_fused(rpn.forward_fused(list(feats)))
+        stage_mark('rpn_tower')
         scales = [float(s) for s in torch.stack([m.scale.detach() for m in rpn.scales]).tolist()] \
             if self._rpn_scale_cache is None else self._rpn_scale_cache
         dets, num = rpn.get_bboxes_padded(cls, reg, iou, img_metas, reg_scales=scales)
-        return self.roi_head.simple_test_padded(feats, dets, num, img_metas, rescale=rescale)
+        stage_mark('rpn_postprocess')
+        out = self.roi_head.simple_test_padded(feats, dets, num, img_metas, rescale=rescale)
+        stage_mark('rcnn_decode_nms')
+        return out
 
     def simple_test(self, img, img_metas, proposals=None, rescale=False):
         assert self.with_roi_head, 'Bbox head must be implemented.'

@@ -16,7 +16,18 @@ second stream, dW handed to `.grad` unchanged):
   a fourth stream that WAITS on a weight-gradient event costs the step 1.4-4 ms (19.7 -> 21.6-24 ms, depending on
   which pooled stream it is; the wait alone, without any RCCL call, 3.3 ms) -- more than the ~1.3 ms of ring
   all-reduce it could hide at 8 GPUs.  The single all-reduce after the backward pass costs 0.45 ms at world size 1;
-* the average is RCCL's `ReduceOp.AVG` (sum, then one multiply, on backends without it).
+* the average is RCCL's `ReduceOp.AVG` (sum, then one multiply, on backends without it);
+* the small gradients travel through a PERSISTENT flat fp32 bucket: one multi-tensor copy in, one all-reduce, and the
+  parameters' `.grad` become views of the bucket (no per-step `cat`, no copy back);
+* `compress='bf16'` (off by default): the arena is cast to a persistent bf16 buffer, all-reduced as bf16 (half the
+  xGMI bytes: 2 x 7/8 x 92 MB instead of 184 MB per GPU and step) and cast back into the fp32 arena; the master
+  weights and the optimizer step stay fp32 (tests/test_distributed_cpu.py pins the update against an independent
+  computation from the bf16-rounded local gradients);
+* every rank must post the same collectives: the layout (chunk sizes in use, small-bucket length and count) is
+  compared across the ranks through a fixed-size 2-word collective -- read at once on the first step, whenever this
+  rank's layout changes, on CPU tensors and with `strict=True`; read one step later otherwise (no host
+  synchronisation in the steady state) -- and a mismatch raises
+  instead of hanging or averaging unrelated gradients (DistributedDataParallel's reducer raises in the same case).
 
 One process per GPU; the image batch is sharded by the sampler, weights are replicated (`broadcast_parameters`).
 """
@@ -27,19 +38,31 @@ from . import autograd as _A
 
 
 class GradReducer:
-    def __init__(self, params, process_group=None, slice_mb=64, overlap=False):
+    def __init__(self, params, process_group=None, slice_mb=64, overlap=False, compress=None, strict=False):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('GradReducer needs an initialised torch.distributed process group')
+        if compress not in (None, 'bf16'):
+            raise ValueError(f"GradReducer: compress={compress!r} (None or 'bf16')")
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
         self.slice_elems = max(1, int(slice_mb * (1 << 20) // 4))
         self.overlap = bool(overlap)
+        self.compress = compress
+        self.strict = bool(strict)   # compare the layouts with a host synchronisation on EVERY step (~0.1 ms on the GPU)
+        if self.overlap and self.compress:
+            raise ValueError('GradReducer: compress needs overlap=False (the slices are all-reduced in place)')
         self._avg = dist.get_backend(process_group) == 'nccl'
         self._works = []
         self._comm = {}
         # chunk -> [elements already handed to a collective, elements whose writers have all been launched]
         self._progress = []
+        self._bucket = None          # persistent flat fp32 storage of the gradients outside the arena
+        self._cbuf = None            # persistent bf16 staging of the arena (compress='bf16')
+        self._layout = None          # the layout signature the ranks last agreed on
+        self._lazy = None            # (host tensor, event, signature) of the previous step's non-blocking comparison
+        self.last_bytes = 0          # bytes this rank handed to all-reduce in the last reduce() (payload, one direction)
         _A._OWN_REDUCER[0] = True
         _A.grad_arena.listener = self
 
@@ -47,6 +70,12 @@ class GradReducer:
         if _A.grad_arena.listener is self:
             _A.grad_arena.listener = None
         _A._OWN_REDUCER[0] = False
+
+    def describe(self):
+        """what bench.py prints beside `reduce_ms`"""
+        return {'arena': 'in place' if not self.compress else f'{self.compress} staging buffer',
+                'overlap': self.overlap, 'bytes_last_step': int(self.last_bytes), 'world': self.world,
+                'op': 'AVG' if self._avg else 'SUM + scale'}
 
     # ---- parameters -----------------------------------------------------------------------------
     def broadcast_parameters(self, module, src=0):
@@ -58,6 +87,15 @@ class GradReducer:
     # ---- arena listener (called by autograd._GradArena / _conv_backward) ---------------------------
     def chunk_opened(self, buf):
         self._progress.append([buf, 0, 0])
+
+    def shared_parameter(self, param):
+        """a parameter reached a second weight-gradient launch in one backward pass (autograd._side_stream_for):
+        autograd will ADD that result into the first one's arena slice, which the overlapped form may already have
+        handed to the communication stream"""
+        if self.overlap:
+            raise RuntimeError('GradReducer(overlap=True): a parameter is used twice in one backward pass (its second '
+                               'gradient is accumulated into an arena slice that may already be in flight); use '
+                               'overlap=False for this model')
 
     def writers_launched(self, buf, upto, stream):
         """every weight-gradient launch writing arena elements [0, upto) of `buf` has been issued, the last one on
@@ -79,6 +117,7 @@ class GradReducer:
 
     def _all_reduce(self, t, async_op):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self.last_bytes += t.numel() * t.element_size()
         return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
     def _issue(self, buf, lo, hi, stream):
@@ -96,6 +135,49 @@ class GradReducer:
         with torch.cuda.stream(comm):
             self._works.append(self._all_reduce(view, True))
 
+    # ---- the ranks agree on what they are about to all-reduce ------------------------------------------
+    @staticmethod
+    def _signature(values):
+        h = 1469598103934665603
+        for v in values:
+            h = ((h ^ (int(v) & 0xffffffffffff)) * 1099511628211) & 0x3fffffffffffffff
+        return h
+
+    def _agree(self, sig, values, device, blocking):
+        """all-reduce (MAX) of [sig, -sig]: equal on every rank iff max(sig) == -max(-sig).  Fixed size, so it pairs
+        across ranks whatever their layouts are."""
+        t = torch.tensor([sig, -sig], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if blocking:
+            hi, neg_lo = t.tolist()
+            if hi != -neg_lo:
+                raise RuntimeError(f'GradReducer: rank {self.rank} is about to all-reduce a gradient layout that differs '
+                                   f'from another rank\'s (arena chunks in use / small-gradient bucket: {values}); every '
+                                   'rank must run the same backward graph (no rank-dependent fallback paths, no unused '
+                                   'parameters on some ranks only)')
+            self._layout = sig
+            return
+        if t.is_cuda:
+            host = torch.empty(2, dtype=torch.int64).pin_memory()
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lazy = (host, ev, values)
+        else:
+            self._lazy = (t, None, values)
+
+    def _check_lazy(self):
+        if self._lazy is None:
+            return
+        host, ev, values = self._lazy
+        self._lazy = None
+        if ev is not None:
+            ev.synchronize()            # one step old: completed long ago
+        hi, neg_lo = host.tolist()
+        if hi != -neg_lo:
+            raise RuntimeError(f'GradReducer: the previous step all-reduced different gradient layouts on different ranks '
+                               f'(this rank {self.rank}: {values}); the averaged gradients of that step are invalid')
+
     # ---- end of the backward pass -----------------------------------------------------------------
     @torch.no_grad()
     def reduce(self):
@@ -103,13 +185,14 @@ class GradReducer:
         cuda = any(pr[0].is_cuda for pr in self._progress) or any(p.is_cuda for p in self.params)
         if cuda:
             _A.join_side_streams()              # the last weight-gradient launches, on whatever stream they ran
-        arena_ptrs = []
+        self.last_bytes = 0
+        self._check_lazy()
+        arena_ptrs, pending = [], []
         for buf, done, _ in self._progress:
             used = _A.grad_arena.used_of(buf)
             arena_ptrs.append((buf.untyped_storage().data_ptr(), buf.numel() * 4))
-            if used > done:
-                self._works.append(self._all_reduce(buf[done:used], True))
-        # the gradients outside the arena: one flattened bucket
+            pending.append((buf, done, used))
+        # the gradients outside the arena (BatchNorm / GroupNorm affine, biases, Scale, FC weights of odd shapes)
         small = []
         for p in self.params:
             g = p.grad
@@ -118,23 +201,57 @@ class GradReducer:
             ptr = g.untyped_storage().data_ptr()
             if any(a <= ptr < a + n for a, n in arena_ptrs):
                 continue
-            small.append(g)
+            small.append((p, g))
+        n_small = sum(g.numel() for _, g in small)
+        values = [used for _, _, used in pending] + [n_small, len(small)]
+        sig = self._signature(values)
+        device = (pending[0][0] if pending else small[0][1] if small else self.params[0]).device
+        self._agree(sig, values, device, blocking=sig != self._layout or self.strict or device.type != 'cuda')
+        # ---- arena
+        if self.compress == 'bf16':
+            total = sum(used - done for _, done, used in pending)
+            if total:
+                if self._cbuf is None or self._cbuf.numel() < total or self._cbuf.device != device:
+                    self._cbuf = torch.empty(total, dtype=torch.bfloat16, device=device)
+                off = 0
+                for buf, done, used in pending:
+                    if used > done:
+                        self._cbuf[off:off + used - done].copy_(buf[done:used])     # fp32 -> bf16, round to nearest even
+                        off += used - done
+                self._works.append(self._all_reduce(self._cbuf[:total], True))
+        else:
+            for buf, done, used in pending:
+                if used > done:
+                    self._works.append(self._all_reduce(buf[done:used], True))
+        # ---- small gradients: persistent flat bucket, `.grad` becomes a view of it
         if small:
-            flat = torch.cat([g.reshape(-1).float() for g in small])
+            if self._bucket is None or self._bucket.numel() < n_small or self._bucket.device != device:
+                self._bucket = torch.empty(n_small, dtype=torch.float32, device=device)
+            flat = self._bucket[:n_small]
+            views, off = [], 0
+            for _, g in small:
+                n = g.numel()
+                views.append(flat[off:off + n].view(g.shape))
+                off += n
+            # gradients that already ARE the bucket's views (a second reduce without a new backward) stay put
+            todo = [(v, g) for v, (_, g) in zip(views, small) if v.data_ptr() != g.data_ptr() or g.dtype != torch.float32]
+            if todo:
+                torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])   # multi-tensor copy (casts if needed)
             self._all_reduce(flat, False)
             if not self._avg:
                 flat.mul_(1.0 / self.world)
-            views, off = [], 0
-            for g in small:
-                n = g.numel()
-                views.append(flat[off:off + n].view_as(g))
-                off += n
-            torch._foreach_copy_(small, views)      # multi-tensor copy: a handful of launches for ~300 tensors
+            for v, (p, g) in zip(views, small):
+                p.grad = v if g.dtype == torch.float32 else v.to(g.dtype)
         for w in self._works:
             w.wait()                            # the current stream waits for the collective (no host block on RCCL)
+        if self.compress == 'bf16':
+            off = 0
+            for buf, done, used in pending:
+                if used > done:
+                    buf[done:used].copy_(self._cbuf[off:off + used - done])         # bf16 -> fp32 (exact)
+                    off += used - done
         if not self._avg:
-            for buf, _, _ in self._progress:
-                used = _A.grad_arena.used_of(buf)
+            for buf, _, used in pending:
                 if used:
                     buf[:used].mul_(1.0 / self.world)
         self._works = []

@@ -50,6 +50,9 @@ SIGNATURES = {
     'brcnn_stem_workspace_bytes': (c_size, [c_int, c_int, c_int]),
     'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 6 + [c_ptr]),
     'brcnn_conv_set_tile_bf16': (c_int, [c_int]),
+    'brcnn_conv_workspace_bytes': (c_size, []),
+    'brcnn_conv_set_workspace': (c_int, [c_ptr, c_ptr, c_size]),
+    'brcnn_conv_handover_status': (c_int, []),
     'brcnn_maxpool3x3s2_nhwc': (c_int, [c_ptr] * 2 + [c_int] * 5 + [c_ptr]),
     'brcnn_maxpool3x3s2_nhwc_backward': (c_int, [c_ptr] * 4 + [c_int] * 5 + [c_ptr]),
     'brcnn_groupnorm_nhwc': (c_int, [c_ptr] * 5 + [c_int] * 4 + [c_f32, c_int, c_int, c_ptr]),
@@ -150,4 +153,34 @@ def check(status, what):
             raise BrcnnHipError(f'{what}: invalid argument (status -22)')
         if status <= -1000:
             raise BrcnnHipError(f'{what}: HIP error {-status - 1000}')
+        if status == -62:
+            raise BrcnnHipError(f'{what}: an earlier convolution launch lost a stream-K hand-over between two workgroups '
+                                '(BRCNN_EHANDOVER): the results computed since the last check are invalid')
         raise BrcnnHipError(f'{what}: status {status}')
+
+
+# ---- caller-owned conv scratch (include/brcnn_hip.h: brcnn_conv_set_workspace) ------------------------------------
+_workspaces = {}        # hipStream_t handle -> the torch tensor registered as that stream's conv workspace
+
+
+def stream_handle(stream=None):
+    """the hipStream_t of `stream` (default: torch's current stream) for a C-ABI call; on first sight of a stream its
+    convolution scratch (stream-K hand-over slots, weight-gradient slabs) is allocated HERE, by the caller, and
+    registered -- the library allocates nothing for the streams this module drives"""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    h = stream.cuda_stream
+    if h not in _workspaces:
+        lib = load()
+        nb = int(lib.brcnn_conv_workspace_bytes())
+        with torch.cuda.stream(stream):
+            ws = torch.empty(nb, dtype=torch.uint8, device=stream.device)
+        check(lib.brcnn_conv_set_workspace(h, ws.data_ptr(), nb), 'brcnn_conv_set_workspace')
+        _workspaces[h] = ws
+    return h
+
+
+def handover_status():
+    """raise if a stream-K hand-over timed out since the last call (cheap: reads one host word)"""
+    check(load().brcnn_conv_handover_status(), 'brcnn_conv_handover_status')

@@ -47,7 +47,7 @@ def _require_gpu(*tensors):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _L.stream_handle()
 
 
 def _ptr(t):

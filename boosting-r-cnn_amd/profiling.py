@@ -7,6 +7,7 @@ algorithmic FLOPs of each launch (2 * M * K * Cout) are summed -- achieved = sum
 sum(kernel time), the figure bench.py reports against the fp32 MFMA peak.
 """
 import contextlib
+import time
 
 import torch
 
@@ -15,6 +16,71 @@ from . import ops
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 v_mfma_f32_32x32x16_bf16 (16x the f32 rate)
 HBM_PEAK_GBS = 8000.0
+
+
+# ---------------------------------------------------------------------------- per-stage breakdown
+# tools/analysis_tools/benchmark.py:98-131 times whole iterations only; SURVEY 8d asks for the split backbone / neck /
+# RPN tower / RPN post-process / RoIAlign / FC head / NMS beside it.  The detector calls `stage_mark(name)` when a
+# stage has been QUEUED; with a recorder attached a mark is one event on the current stream (or a host clock reading
+# for CPU tensors), without one it is a global load and a compare.
+_STAGE_REC = [None]
+STAGES = ('backbone', 'neck', 'rpn_tower', 'rpn_postprocess', 'roi_align', 'fc_head', 'rcnn_decode_nms')
+
+
+def stage_mark(name):
+    rec = _STAGE_REC[0]
+    if rec is not None:
+        rec.mark(name)
+
+
+class StageRecorder:
+    """`with StageRecorder(cuda=True) as r: model.simple_test_device(...)`; `r.ms()` -> {stage: milliseconds}"""
+
+    def __init__(self, cuda):
+        self.cuda = bool(cuda)
+        self.marks = []
+
+    def _now(self):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return time.perf_counter()
+
+    def mark(self, name):
+        self.marks.append((name, self._now()))
+
+    def __enter__(self):
+        self.marks = [(None, self._now())]
+        self._prev = _STAGE_REC[0]
+        _STAGE_REC[0] = self
+        return self
+
+    def __exit__(self, *exc):
+        _STAGE_REC[0] = self._prev
+        return False
+
+    def ms(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+        out = {}
+        for (_, a), (name, b) in zip(self.marks, self.marks[1:]):
+            dt = a.elapsed_time(b) if self.cuda else (b - a) * 1000.0
+            out[name] = out.get(name, 0.0) + dt
+        return out
+
+
+def stage_breakdown(run, cuda, iters=3):
+    """per-stage milliseconds of `run()` (one pass), the minimum-total of `iters` passes"""
+    best = None
+    for _ in range(iters):
+        with StageRecorder(cuda) as r:
+            run()
+            r.mark('copy_out')
+        ms = r.ms()
+        if best is None or sum(ms.values()) < sum(best.values()):
+            best = ms
+    return {k: round(v, 4) for k, v in best.items()}
 
 
 @contextlib.contextmanager
@@ -80,7 +146,10 @@ def conv_stack_roofline(model, img, metas, iters=3, dtype='f32'):
         pass
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     return {
-        'bound': 'mfma', 'kernel': f'conv_igemm_{dtype}*_kernel (all conv/FC launches of one pass)',
+        'bound': 'mfma',
+        'kernel': ('conv_pp_f32_kernel (eight-phase 256x256 / 128x256 tiles) + conv_igemm_f32_dma_kernel (64x64 tiles)'
+                   if dtype == 'f32' else 'conv_pp_bf16_kernel + conv_igemm_bf16_dma_kernel') +
+                  ': every conv / FC launch of one pass',
         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
         'frac': achieved / peak, 'traffic': traffic,
         'traffic_unit': 'HBM bytes per launch',

@@ -24,10 +24,11 @@ from .blocks import PackedCache, to_nhwc
 from .core import bbox2result, bbox2roi, bbox_overlaps, const_rows, multi_apply, multiclass_nms
 from .losses import SmoothL1Loss, accuracy
 from .postprocess import batched_nms_images
+from .profiling import stage_mark
 from .registry import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head,
                        build_loss, build_roi_extractor, build_sampler)
 
-# BRCNN_TIME_SYNC=1: [seconds the host blocked on the sampler counts, calls] (tools/host_slack.py)
+# BRCNN_TIME_SYNC=1: [seconds the host blocked on the sampler counts, calls] (tools/experiments/host_slack.py)
 SYNC_WAIT = [0.0, 0] if _os.environ.get('BRCNN_TIME_SYNC') == '1' else None
 
 
@@ -668,7 +669,9 @@ class ProbRoIHead(nn.Module):
         rois = torch.cat([bidx, dets[..., :4]], -1).view(B * K, 5)
         prior = dets[..., 4].reshape(-1)
         roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, rois)
+        stage_mark('roi_align')
         cls_score, bbox_pred = head.forward_nhwc(roi_feats)
+        stage_mark('fc_head')
         # per-image clip border / rescale (image shapes are host metadata)
         max_shape = const_rows([m['img_shape'][:2] for m in img_metas], dets)
         coder = head.bbox_coder

@@ -9,8 +9,13 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
  *     work is enqueued on it, nothing synchronises unless stated;
  *   - return value: 0 on success, -22 (EINVAL) for a rejected argument,
- *     -(1000 + hipError_t) when a HIP call failed.  No exceptions cross the ABI;
- *   - thread-safe for calls on distinct streams with distinct workspaces.
+ *     -(1000 + hipError_t) when a HIP call failed, -62 (BRCNN_EHANDOVER) when an
+ *     EARLIER conv launch reported a lost stream-K hand-over (its results are
+ *     invalid; see brcnn_conv_handover_status).  No exceptions cross the ABI;
+ *   - thread-safe for calls on distinct streams with distinct workspaces
+ *     (brcnn_conv_set_workspace); the `brcnn_*_set_*` tuning hooks are
+ *     process-wide test / benchmarking switches: set them from one thread while
+ *     no other thread is inside the library.
  *
  * Each entry cites the reference interface it replaces.  The reference tree has
  * no native code: those interfaces are the `mmcv.ops` Python functions
@@ -231,6 +236,21 @@ int brcnn_conv2d_nhwc_scatter2(const void *x, const void *w, void *y, int batch,
                                int cin, int cout, int kh, int kw, int pad, int out_height,
                                int out_width, int ph, int pw, int origin, int dtype, void *stream);
 
+/* Scratch of the convolution launches of ONE stream -- the stream-K hand-over slots (fp32 accumulators of the tiles
+ * cut between two workgroups), their flags, and the slabs of the sliced 16-bit weight gradient -- is CALLER-OWNED like
+ * every other buffer: allocate brcnn_conv_workspace_bytes() bytes (256-byte aligned), register them for the stream
+ * once, keep them alive until brcnn_conv_set_workspace(stream, NULL, 0).  The registration enqueues a memset of the
+ * flag area on `stream`.  A stream that never registered gets a library-side hipMalloc on its first convolution
+ * (fallback for plain C callers; released by the NULL call, which synchronises that stream). */
+size_t brcnn_conv_workspace_bytes(void);
+int brcnn_conv_set_workspace(void *stream, void *workspace, size_t bytes);
+
+/* 0, or BRCNN_EHANDOVER (-62) if a K tail of a stream-K launch gave up waiting for its head since the last call
+ * (reported once, then cleared).  Every conv launch checks the same word first, so the error also surfaces as the
+ * status of the NEXT convolution; call this after a synchronisation to vet the launches already finished. */
+#define BRCNN_EHANDOVER (-62)
+int brcnn_conv_handover_status(void);
+
 /* Tuning hook: force the workgroup tile (wm: 2 -> 128 rows, 4 -> 256 rows; nt: 1 -> 64
  * columns, 2 -> 128 columns; 0 -> built-in heuristic).  Process-wide; used by the
  * benchmarking scripts (tools/conv_bench.py).  (-1, 0/1/2): register-staged / heuristic / LDS-DMA
@@ -247,7 +267,9 @@ int brcnn_conv_set_tile(int wm, int nt);
  * groups / issue them in front of the tile (default).  8844: the 256x256 eight-phase kernel
  * (csrc/conv_pp_bf16.hip).  -3 / -4 / -5: chained stream-K schedule (a tile cut between two workgroups
  * continues from the stored fp32 accumulators; bit-identical) off / by the heuristic / wherever the
- * tile count allows it.  -6 / -7: eight-phase kernel never / by the heuristic. */
+ * tile count allows it.  -6 / -7: eight-phase kernel never / by the heuristic.  -11 / -12 (test hook): stream-K heads
+ * stop / resume publishing and tails give up after 256 polls -- a lost hand-over on demand, to exercise
+ * BRCNN_EHANDOVER. */
 int brcnn_conv_set_tile_bf16(int mtnt);
 
 /* The same convolution over `num_segments` feature maps that share one set of weights (the

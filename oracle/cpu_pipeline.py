@@ -292,6 +292,9 @@ def timed_baseline(cfg, seed=0, batch=1, budget_s=20.0, threads=None):
                 if time.perf_counter() - t0 > budget_s or n >= 16:
                     break
             dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            # per-stage split of one more pass: host clock between the detector's stage marks
+            from brcnn import profiling
+            stages = profiling.stage_breakdown(lambda: m.simple_test(img, metas, rescale=True), cuda=False, iters=1)
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'stages_ms': stages,
             'sample': f'{n} synthetic 1333x800 images (batch {batch}), same model/config/weights, '
                       f'PyTorch-CPU conv/linear + C oracle RoIAlign/NMS, {dt:.1f} s'}

@@ -19,9 +19,17 @@ from tests import util  # noqa: E402
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # BRCNN_DIST_ONE_DEVICE=1 + BRCNN_DIST_BACKEND=gloo: every rank on cuda:0, collectives through gloo (RCCL refuses two
+    # ranks on one device) -- the world-size-2 control flow on a one-GPU box
+    if os.environ.get('BRCNN_DIST_ONE_DEVICE', '0') == '1':
+        local = 0
+    backend = os.environ.get('BRCNN_DIST_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'boosting_rcnn', 'boosting_rcnn_r50_pafpn_1x_utdac.py'))
     dtype = sys.argv[1] if len(sys.argv) > 1 else 'f32'
     img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10 + rank)
@@ -67,11 +75,22 @@ def main():
         for k, g in grads['plain'][0].items():
             tol = (1e-4 if dtype == 'f32' else 2e-2) * (g.abs().max().item() + 1e-12)
             assert (g - grads['own'][0][k]).abs().max().item() <= tol, ('own', k, (g - grads['own'][0][k]).abs().max().item(), tol)
+    else:
+        # several ranks, each on its own images: DDP's and the reducer's averaged gradients agree, and both equal the
+        # mean over the ranks of the unwrapped step's gradients (the second `own` pass also back-propagates the RPN
+        # branch inside the forward pass)
+        for k, g in grads['ddp'][0].items():
+            tol = (2e-4 if dtype == 'f32' else 3e-2) * (g.abs().max().item() + 1e-12)
+            assert (g - grads['own'][0][k]).abs().max().item() <= tol, ('own vs ddp', k)
+            t = grads['plain'][0][k].clone()
+            dist.all_reduce(t)
+            assert (g - t / world).abs().max().item() <= tol, ('ddp vs mean of plain', k)
     # every rank ends with identical (averaged) gradients
-    for k, g in sorted(grads['ddp'][0].items())[:8]:
-        t = g.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert torch.equal(t, g), k
+    for mode in ('ddp', 'own'):
+        for k, g in sorted(grads[mode][0].items())[:8]:
+            t = g.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert torch.equal(t, g), (mode, k)
     if rank == 0:
         print('DDP_OK', len(grads['ddp'][0]), grads['ddp'][1]['loss'], flush=True)
     dist.barrier()

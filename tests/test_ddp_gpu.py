@@ -24,16 +24,30 @@ def _port():
         return s.getsockname()[1]
 
 
-def _launch(script_args, timeout=900):
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
-           '--master-port', str(_port())] + script_args
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+def _launch(script_args, timeout=900, nproc=1, extra_env=None):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr',
+           '127.0.0.1', '--master-port', str(_port())] + script_args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT, **(extra_env or {}))
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+# two ranks on the one GPU of the box: RCCL refuses that, so the collectives go through gloo (device tensors staged
+# through the host) -- the world-size-2 control flow of the product code on real kernels
+TWO_ON_ONE = dict(BRCNN_DIST_ONE_DEVICE='1', BRCNN_DIST_BACKEND='gloo')
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_ddp_train_step_equals_plain_step(dtype):
     r = _launch([os.path.join(ROOT, 'tests', 'ddp_worker.py'), dtype])
+    assert r.returncode == 0 and 'DDP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_two_rank_train_step_reducer_and_ddp_agree(dtype):
+    """world size 2 (both ranks on cuda:0, gloo): GradReducer (with the RPN branch back-propagated inside the forward
+    pass on its second pass) and DistributedDataParallel produce the same averaged gradients = the mean of the two
+    ranks' unwrapped gradients"""
+    r = _launch([os.path.join(ROOT, 'tests', 'ddp_worker.py'), dtype], nproc=2, extra_env=TWO_ON_ONE)
     assert r.returncode == 0 and 'DDP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
@@ -57,3 +71,18 @@ def test_bench_under_the_launcher():
     # a world size that contradicts --gpus is refused instead of silently measuring one GPU
     r = _launch([os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'])
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stdout + r.stderr)
+
+
+def test_bench_two_ranks_prints_one_line_with_reduce_time():
+    """`bench.py --gpus 2` as the driver launches it, both ranks on the one GPU (gloo): every rank runs the same
+    collectives -- the roofline pass included -- and rank 0 prints ONE line carrying train.reduce_ms / grad_bytes"""
+    r = _launch([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+                 '--no-cpu-baseline'], nproc=2, extra_env=TWO_ON_ONE, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 4 and line['value'] > 0
+    tr = line['train']
+    assert tr['n_gpus'] == 2 and tr['reduce_ms'] > 0 and tr['grad_bytes'] > 150e6 and tr['roofline']['frac'] > 0
+    assert tr['grad_allreduce']['world'] == 2 and tr['grad_allreduce']['bytes_last_step'] >= tr['grad_bytes'] * 0.9

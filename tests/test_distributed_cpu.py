@@ -186,3 +186,121 @@ def test_two_rank_grad_reducer_averages_arena_and_small_gradients():
     ret = mgr.dict()
     mp.spawn(_reducer_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == 2
+
+
+def _reducer_bf16_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn import autograd as A
+        from brcnn.distributed import GradReducer
+        torch.manual_seed(9)
+        shapes = [(64, 3, 3, 32), (300,), (128, 1, 1, 64), (17,)]
+        params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        red = GradReducer(params, compress='bf16')
+        opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        for step in range(2):
+            g = torch.Generator().manual_seed(77 * step + rank)
+            local = [torch.randn(*s, generator=g) for s in shapes]
+            for p, gl in zip(params, local):
+                if p.dim() == 4:
+                    v = A.grad_arena.take(p.shape, p.device)
+                    v.copy_(gl)
+                    A.grad_arena.launched(None)
+                    p.grad = v
+                else:
+                    p.grad = gl.clone()
+            before = [p.detach().clone() for p in params]
+            bufs = [opt.state[p].get('momentum_buffer') for p in params]
+            bufs = [None if b is None else b.clone() for b in bufs]
+            red.reduce()
+            for i, p in enumerate(params):
+                allg = [torch.zeros_like(local[i]) for _ in range(world)]
+                dist.all_gather(allg, local[i])
+                if p.dim() == 4:
+                    # the wire format: each rank's fp32 gradient rounded to bf16 (nearest even), summed in bf16 by the
+                    # collective, widened back to fp32 (exact), divided by the world size (exact for 2)
+                    want = (allg[0].bfloat16() + allg[1].bfloat16()).float() / world
+                    assert p.grad.dtype == torch.float32 and torch.equal(p.grad, want), (step, i)
+                    assert (p.grad - sum(allg) / world).abs().max() <= 2.0 ** -7 * sum(a.abs() for a in allg).max()
+                else:                             # the small bucket stays fp32
+                    assert torch.allclose(p.grad, sum(allg) / world, rtol=1e-6, atol=1e-7), (step, i)
+            # the master update is fp32 arithmetic on fp32 weights: torch's SGD on the reduced gradients equals the
+            # closed form evaluated independently in fp32
+            opt.step()
+            for i, p in enumerate(params):
+                d = p.grad + 1e-4 * before[i]
+                b = d if bufs[i] is None else 0.9 * bufs[i] + d
+                assert torch.allclose(p.detach(), before[i] - 0.01 * b, rtol=1e-6, atol=1e-6), (step, i)
+                assert p.dtype == torch.float32 and opt.state[p]['momentum_buffer'].dtype == torch.float32
+            A.grad_arena.new_step()
+        assert red.describe()['bytes_last_step'] == 2 * (64 * 3 * 3 * 32 + 128 * 64) + 4 * 317
+        red.close()
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_grad_reducer_bf16_wire_format_keeps_fp32_master_update():
+    """GradReducer(compress='bf16'): the arena crosses the wire as bf16 (half the bytes), the result is exactly the
+    bf16 sum of the bf16-rounded local gradients, and the optimizer step on the fp32 master weights is fp32"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reducer_bf16_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == 2
+
+
+def _reducer_layout_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn import autograd as A
+        from brcnn.distributed import GradReducer
+        torch.manual_seed(3)
+        params = [torch.nn.Parameter(torch.randn(32, 1, 1, 16)), torch.nn.Parameter(torch.randn(24)),
+                  torch.nn.Parameter(torch.randn(8))]
+        red = GradReducer(params)
+        # step 0: identical layouts; the small gradients end up as views of ONE persistent bucket
+        v = A.grad_arena.take(params[0].shape, params[0].device)
+        v.fill_(float(rank))
+        A.grad_arena.launched(None)
+        params[0].grad = v
+        params[1].grad = torch.full((24,), float(rank))
+        params[2].grad = torch.full((8,), 2.0 * rank)
+        red.reduce()
+        assert torch.equal(params[1].grad, torch.full((24,), 0.5)) and torch.equal(params[2].grad, torch.full((8,), 1.0))
+        base = red._bucket.data_ptr()
+        assert params[1].grad.data_ptr() == base and params[2].grad.data_ptr() == base + 24 * 4
+        A.grad_arena.new_step()
+        # step 1: rank 1 "skips" a parameter (an unused branch): the ranks would post all-reduces of different sizes
+        v = A.grad_arena.take(params[0].shape, params[0].device)
+        v.fill_(1.0)
+        A.grad_arena.launched(None)
+        params[0].grad = v
+        params[1].grad = torch.ones(24)
+        params[2].grad = None if rank == 1 else torch.ones(8)
+        try:
+            red.reduce()
+            raised = False
+        except RuntimeError as e:
+            raised = 'differs from another rank' in str(e) or 'different gradient layouts' in str(e)
+        red.close()
+        ret[rank] = raised
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_grad_reducer_raises_on_layout_mismatch():
+    """a rank whose backward pass produced a different set of gradients must not pair its all-reduces with the other
+    rank's: rank 1 raises at once (its own layout changed: blocking comparison); rank 0, whose layout did not change,
+    compares through the fixed-size collective as well and raises too"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reducer_layout_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[1] is True and ret[0] is True

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: same-box A/B of two builds of the library (box-to-box spread is ~5-10 %):
-#   gpurun -- 'bash tools/ab_conv.sh gpurun_tmp/lib_old.so "python tools/conv_bench.py" 150-190'
+#   gpurun -- 'bash tools/experiments/ab_conv.sh gpurun_tmp/lib_old.so "python tools/conv_bench.py" 150-190'
 OLD=$1; CMD=$2; COLS=${3:-1-200}
 LIB=boosting-r-cnn_amd/lib/libbrcnn_hip.so
 cp $LIB /tmp/new.so

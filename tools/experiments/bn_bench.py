@@ -1,7 +1,7 @@
 """microbenchmark of the eval-BN + ReLU kernels (`brcnn_bn_eval_act_forward/backward`) on the ResNet-50
 stage 2-4 shapes of the train step: algorithmic GB/s per launch (HIP events on the launch stream)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import brcnn  # noqa
 from brcnn import lib as L

@@ -1,7 +1,7 @@
 """Experiment: do the HBM-bound early stages (stem, max-pool, layer1, layer2) run faster when the batch goes through
 them in image chunks whose activations fit the 256 MiB Infinity Cache?  BRCNN_DTYPE=f32|bf16."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from brcnn import ops

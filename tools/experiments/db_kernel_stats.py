@@ -1,4 +1,4 @@
-"""print a rocprofv3 kernel-stats CSV per train / inference step: python tools/db_kernel_stats.py <csv> <steps> [top]"""
+"""print a rocprofv3 kernel-stats CSV per train / inference step: python tools/experiments/db_kernel_stats.py <csv> <steps> [top]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0

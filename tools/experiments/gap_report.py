@@ -1,7 +1,7 @@
 """Where the device idles inside a train step: reads a rocprofv3 kernel trace CSV (`--kernel-trace -f csv`), takes the
 last full step (between two `sgd_update_kernel` groups), and prints the union of busy time over all streams, the idle
 gaps above a threshold with the kernels around them, and the time during which only small-grid kernels ran.
-    python tools/gap_report.py <dir>/step_kernel_trace.csv [gap_us=5]"""
+    python tools/experiments/gap_report.py <dir>/step_kernel_trace.csv [gap_us=5]"""
 import csv, sys, re
 
 rows = list(csv.DictReader(open(sys.argv[1])))

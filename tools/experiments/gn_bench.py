@@ -2,7 +2,7 @@
 time per call (HIP events on the launch stream) and algorithmic GB/s (fwd: 2 passes read + 1 write; bwd: 2 x 2 reads
 + 1 write)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import brcnn  # noqa
 from brcnn import ops

@@ -3,7 +3,7 @@
 for launches; a long wait means the step is device-bound."""
 import os, sys, time
 os.environ['BRCNN_TIME_SYNC'] = '1'
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.argv = ['bench.py', '--mode', 'train', '--steps', '20', '--warmup', '5', '--no-cpu-baseline']
 import bench
 from brcnn import roi_heads

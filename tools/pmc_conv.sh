@@ -1,5 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX: PMC passes (separate runs, no tracing domains) over the largest fp32 conv layer
+# under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
+# in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmcf32; mkdir -p $O
 i=0

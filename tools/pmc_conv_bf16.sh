@@ -1,3 +1,6 @@
+# under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
+# in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmcbf; mkdir -p $O
 i=0

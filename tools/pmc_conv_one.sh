@@ -1,5 +1,8 @@
 # PMC passes of ONE 16-bit conv layer (tools/conv_one_bf16.py); usage: bash tools/pmc_conv_one.sh <out name> [tile ...]
 # env CONV_SHAPE = N,H,W,Cin,Cout,k.  Counters in separate passes (MI355X_MICROARCH.md: slots per pass).
+# under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
+# in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 name=$1; shift
 for tile in "$@"; do

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX: fabric-side bytes (FETCH_SIZE x 2 on gfx950, WRITE_SIZE) and L2 hit rate of ONE conv layer.
 #   bash tools/pmc_fetch_one.sh <out name> f32|bf16     (env CONV_SHAPE = N,H,W,Cin,Cout,k for the 16-bit script)
+# under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
+# in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 name=$1; dt=${2:-f32}
 O=gpurun_out/$name; mkdir -p $O

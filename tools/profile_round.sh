@@ -1,6 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh r02'): tests, bench, rocprof kernel stats of the same
 # bench commands, PMC passes (separate runs, --kernel-trace only: no tracing domains mixed in).
+# under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
+# in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
+export GPU_MAX_HW_QUEUES=8
 R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R

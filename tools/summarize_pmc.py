@@ -2,14 +2,38 @@
 tools/prof_step.py = 4 inference passes) into profiles/r01_conv_traffic.json.
 Units/corrections per MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of wide coalesced reads -> doubled."""
-import collections, csv, json, sys
+import collections, csv, json, re, sys
+
+
+def short_name(full):
+    """`void (anonymous namespace)::gn_apply_rows_kernel<float>((anonymous namespace)::Seg, ...)` -> `gn_apply_rows_kernel`;
+    `void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>, ...>(...)` ->
+    `at::native::vectorized_elementwise_kernel<FillFunctor>`: the function's own name (the identifier in front of its
+    template / argument list, namespaces of our own kernels dropped) plus, for torch's generic element-wise kernels, the
+    functor that tells them apart"""
+    n = full.strip()
+    n = re.sub(r'^(void|int|float)\s+', '', n)
+    n = n.replace('(anonymous namespace)::', '')
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):          # the first '<' or '(' at nesting depth 0 ends the function name
+        if ch in '<(' and depth == 0:
+            cut = i
+            break
+    base = n[:cut].strip()
+    if base.startswith('at::native::') and ('elementwise' in base or 'reduce_kernel' in base):
+        m = re.search(r'(\w+Functor\w*|\w+_kernel_cuda\w*|\w+Ops?\b)', n[cut:])
+        if m:
+            base += f'<{m.group(1)}>'
+    return base or n[:60]
+
+
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for name in ('fetch', 'write'):
     for r in csv.DictReader(open(f'gpurun_out/{rnd}/pmc_{name}/step_counter_collection.csv')):
         # every conv / FC launch of the pass: the 64 x 64 two-buffer kernel and (r03) the eight-phase conv_pp_f32 kernel
-        k = 'conv_igemm_f32_kernel' if ('conv_igemm' in r['Kernel_Name'] or 'conv_pp_' in r['Kernel_Name']) else r['Kernel_Name'].split('(')[0][-40:]
+        k = 'conv_igemm_f32_kernel' if ('conv_igemm' in r['Kernel_Name'] or 'conv_pp_' in r['Kernel_Name']) else short_name(r['Kernel_Name'])
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         if name == 'fetch':
             cnt[k] += 1
