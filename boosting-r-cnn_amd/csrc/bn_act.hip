@@ -9,6 +9,7 @@
 // leave as per-strip partials that a second launch sums in a fixed order (deterministic).  The reference reaches the same
 // arithmetic through ~9 separate torch kernels per block (mul, add, add, relu; threshold_backward,
 // mul, mul, 2 x sum).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -165,39 +166,53 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ d
     }
     if (cv < cvn) {
         // U rows of the strip in flight per lane (with ~512 workgroups the loads of ONE row per lane do not
-        // cover the HBM latency; more workgroups would grow the per-strip partials the second stage reads)
+        // cover the HBM latency; more workgroups would grow the per-strip partials the second stage reads).
+        // Whole groups of U rows run WITHOUT per-row guards -- every load of the group is issued before the first use
+        // -- and the strip's last rows one at a time.  (r04: the guarded form, `if (rr < r1)` around every row of the
+        // group, compiled for fp16 into exec-masked blocks whose partial sums were re-paired through swizzled packed
+        // adds; under a co-running weight-gradient kernel two of the eight lanes of dgamma were intermittently wrong:
+        // tests/test_stress_gpu.py)  The per-lane accumulation order -- rows r, r + RL, r + 2 RL, ... -- is
+        // the same in both loops, so the sums are the guarded form's bits.
         constexpr int U = 4;
-        for (long long r = r0 + rl; r < r1; r += (long long)RL * U) {
-            float g[U][V], o[U][V], zz[U][V];
+        // (the mask source is a launch constant: deciding it per load made the compiler branch around every `out` load
+        // and drain the queue behind it)
+        auto rows = [&](auto n_c, auto out_c, long long r) {
+            constexpr int N = decltype(n_c)::value;
+            constexpr bool OUT = decltype(out_c)::value;        // ReLU mask from the saved output (residual form)
+            float g[N][V], o[OUT ? N : 1][V], zz[N][V];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const long long rr = r + (long long)u * RL;
-                if (rr < r1) {
-                    const long long idx = (rr * cvn + cv) * V;
-                    ldv(dout + idx, g[u]);
-                    if (relu && !zmask) ldv(out + idx, o[u]);
-                    ldv(z + idx, zz[u]);
-                }
+            for (int u = 0; u < N; u++) {
+                const long long idx = ((r + (long long)u * RL) * cvn + cv) * V;
+                ldv(dout + idx, g[u]);
+                if constexpr (OUT) ldv(out + idx, o[u]);
+                ldv(z + idx, zz[u]);
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const long long rr = r + (long long)u * RL;
-                if (rr < r1) {
-                    const long long idx = (rr * cvn + cv) * V;
-                    float gz[V];
+            for (int u = 0; u < N; u++) {
+                const long long idx = ((r + (long long)u * RL) * cvn + cv) * V;
+                float gz[V];
 #pragma unroll
-                    for (int e = 0; e < V; e++) {
-                        const float ov = zmask ? zz[u][e] * sc[e] + sf[e] : o[u][e];
-                        const float d = (!relu || ov > 0.f) ? g[u][e] : 0.f;
-                        g[u][e] = d;
-                        ss[e] += d * zz[u][e];
-                        sh[e] += d;
-                        gz[e] = d * sc[e];
-                    }
-                    stv(dz + idx, gz);
-                    if (dres) stv(dres + idx, g[u]);
+                for (int e = 0; e < V; e++) {
+                    float ov;
+                    if constexpr (OUT) ov = o[u][e];
+                    else ov = zz[u][e] * sc[e] + sf[e];
+                    const float d = (!relu || ov > 0.f) ? g[u][e] : 0.f;
+                    g[u][e] = d;
+                    ss[e] += d * zz[u][e];
+                    sh[e] += d;
+                    gz[e] = d * sc[e];
                 }
+                stv(dz + idx, gz);
+                if (dres) stv(dres + idx, g[u]);
             }
+        };
+        long long r = r0 + rl;
+        if (relu && !zmask) {
+            for (; r + (long long)(U - 1) * RL < r1; r += (long long)RL * U) rows(std::integral_constant<int, U>{}, std::true_type{}, r);
+            for (; r < r1; r += RL) rows(std::integral_constant<int, 1>{}, std::true_type{}, r);
+        } else {
+            for (; r + (long long)(U - 1) * RL < r1; r += (long long)RL * U) rows(std::integral_constant<int, U>{}, std::false_type{}, r);
+            for (; r < r1; r += RL) rows(std::integral_constant<int, 1>{}, std::false_type{}, r);
         }
     }
 #pragma unroll
