@@ -439,6 +439,11 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
                               const int* heights_host, const int* widths_host, int cin, int cout,
                               int kh, int kw, int stride, int pad, hipStream_t stream, int f16) {
     if ((cin & 7) || (cout & 7)) return BRCNN_EINVAL;
+    if (g_wgrad_bf16_tile == 0) {       // the eight-phase 256 x 256 kernel where whole tiles and enough rows exist
+        const int rc = brcnn_conv::wgrad_pp_bf16_try(x, dy, dw, batch, num_segments, heights_host, widths_host, cin, cout, kh, kw,
+                                                     stride, pad, stream, f16);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     WgradHParams p = {};
     p.dy = (const unsigned short*)dy; p.x = (const unsigned short*)x; p.dw = (float*)dw;
     p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad = pad;
@@ -486,6 +491,10 @@ BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
     if (wt >= 100 && wt < 1100) { g_wgrad_two_pass = wt - 100; return 0; }
     if (wt >= 2010 && wt <= 2400) { g_wgrad_slot_pct = wt - 2000; return 0; }
     if (wt >= 3010 && wt <= 3400) { g_wgrad_slot_pct_big = wt - 3000; return 0; }
+    // eight-phase kernel (conv_wgrad_pp_bf16.hip): 20 never / 21 heuristic / 22 wherever the shape allows; 4000 + n: n
+    // percent of the CUs per launch; 5000 + n: two reduce passes above n slices; 29: RETURNS the number of launches the
+    // eight-phase kernel took since the last query (tests)
+    if ((wt >= 20 && wt <= 22) || wt == 29 || (wt >= 4010 && wt <= 4400) || (wt >= 5001 && wt <= 5999)) return brcnn_conv::wgrad_pp_set(wt);
     if (wt < 0 || wt == 3 || wt > 4) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;

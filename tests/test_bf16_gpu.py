@@ -759,3 +759,61 @@ def test_bf16_stream_k_schedule_is_bit_identical(shape):
     finally:
         L.brcnn_conv_set_tile_bf16(0)
         L.brcnn_conv_set_tile_bf16(-4)
+
+
+@pytest.mark.parametrize('et', [BF, torch.float16])
+@pytest.mark.parametrize('cfg', [
+    # batch, [(H, W), ...], Cin, Cout, k, stride, pad
+    (2, [(40, 64)], 256, 256, 3, 1, 1),            # M = 5120: several slices, whole tiles
+    (2, [(37, 53)], 128, 256, 3, 1, 1),            # ragged map (M = 3922, not a multiple of 64), K = 1152: half-empty last k tile
+    (3, [(25, 42)], 512, 256, 1, 1, 0),            # plain 1x1 form, map narrower than 64 (full decode every step)
+    (2, [(41, 67)], 256, 256, 3, 2, 1),            # stride 2
+    (2, [(24, 40), (12, 20), (6, 10), (3, 5)], 256, 256, 3, 1, 1),     # pyramid levels sharing the weights (per-lane geometry)
+    (1, [(33, 70)], 64, 320, 3, 1, 1),             # Cout not a multiple of 256 (forced): out-of-range co rows are zeros
+    (4096, [(1, 1)], 1024, 1024, 1, 1, 0),         # FC shape
+])
+def test_wgrad_eight_phase_kernel_against_fp64(cfg, et):
+    """conv_wgrad_pp_bf16.hip (256 x 256 tile, eight-phase schedule, transposing LDS reads, slab reduction) against the
+    fp64 weight gradient of the same 16-bit operands: fp32 accumulation error only; bit-reproducible; the two-buffer
+    kernel of conv_wgrad_bf16.hip agrees to the same bound"""
+    import ctypes
+    from brcnn import lib
+    L = lib.load()
+    n, lv, ci, co, k, st, pd = cfg
+    g = torch.Generator().manual_seed(31)
+    xs = [torch.randn(n, h, w, ci, generator=g).to(et) for h, w in lv]
+    outs = [ops.conv_out_size(h, w, k, k, st, pd) for h, w in lv]
+    dys = [torch.randn(n, ho, wo, co, generator=g).to(et) for ho, wo in outs]
+    ref = torch.zeros(co, k, k, ci, dtype=torch.float64, device=DEV)
+    for x_, dy_ in zip(xs, dys):        # fp64 reference on the device: dW[co, kh, kw, ci] = sum dy * window(x)
+        xd = x_.to(DEV).double().permute(0, 3, 1, 2)
+        dyd = dy_.to(DEV).double().permute(0, 3, 1, 2)
+        gw = torch.nn.grad.conv2d_weight(xd, (co, ci, k, k), dyd, stride=st, padding=pd)
+        ref += gw.permute(0, 2, 3, 1)
+    x = torch.cat([t.reshape(-1, ci) for t in xs]).to(DEV)
+    dy = torch.cat([t.reshape(-1, co) for t in dys]).to(DEV)
+    hs = (ctypes.c_int * len(lv))(*[h for h, _ in lv])
+    ws = (ctypes.c_int * len(lv))(*[w for _, w in lv])
+    dt = 1 if et == BF else 3
+
+    def run(mode):
+        assert L.brcnn_conv_set_tile_wgrad_bf16(mode) == 0
+        dw = torch.zeros(co, k, k, ci, device=DEV)
+        st_ = L.brcnn_conv2d_wgrad_nhwc_multi(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, len(lv), hs, ws, ci, co, k, k,
+                                              st, pd, dt, lib.stream_handle())
+        assert st_ == 0
+        return dw
+    try:
+        L.brcnn_conv_set_tile_wgrad_bf16(29)
+        new = run(22)                   # eight-phase kernel wherever the shape allows
+        again = run(22)
+        assert L.brcnn_conv_set_tile_wgrad_bf16(29) == 2        # ... and it was taken both times
+        old = run(20)                   # two-buffer kernel
+        assert L.brcnn_conv_set_tile_wgrad_bf16(29) == 0
+    finally:
+        L.brcnn_conv_set_tile_wgrad_bf16(21)
+    m_total = sum(n * ho * wo for ho, wo in outs)
+    tol = 3e-6 * (m_total ** 0.5) * float(ref.abs().max()) + 1e-6      # fp32 accumulation of M products, random signs
+    assert float((new.double() - ref).abs().max()) <= tol, (float((new.double() - ref).abs().max()), tol)
+    assert float((old.double() - ref).abs().max()) <= tol
+    assert torch.equal(new, again)
