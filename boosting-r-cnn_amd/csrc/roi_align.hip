@@ -247,12 +247,17 @@ __device__ __forceinline__ void axis_weights(float start, float bin, int pidx, i
 // one wave per (roi, ph) ROW of bins: the level mapping (sqrt / log2), the RoI geometry (divisions,
 // ceil) and the y-axis weights are computed once per row instead of once per bin -- with 1..2 px
 // bins the per-bin address / weight arithmetic, not the bytes, is what bounds this kernel
-template <bool MULTI, typename T = float>
+// RPW: bin rows per wavefront.  1 (few RoIs: as many waves as possible) or pooled_h (thousands of RoIs: the level
+// mapping, the RoI geometry and the x-axis weights of the seven bins -- two thirds of a bin row's instructions with
+// 1-2 px bins -- are computed once per RoI instead of once per bin row).  perm (or NULL): the order in which the RoIs
+// are visited (roi_order_kernel: by level, image and row band, so that the bin rows an XCD works on at one time stay
+// inside what its L2 holds); results land at the RoI's own index.
+template <bool MULTI, typename T = float, int RPW = 1>
 __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
     const T* __restrict__ input, LevelTable lv, const float* __restrict__ rois,
     T* __restrict__ output, int32_t* __restrict__ levels_out, int channels, int height,
     int width, int n_rois, int ph_n, int pw_n, float spatial_scale, int sampling_ratio,
-    int aligned, int stream_c) {
+    int aligned, int stream_c, const int32_t* __restrict__ perm) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD x (= blockIdx % 8, the dispatcher's round robin) takes a CONTIGUOUS eighth of the bin rows: RoIs arrive
@@ -262,10 +267,13 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const long long row = (long long)bid * 4 + wave;
-    if (row >= (long long)n_rois * ph_n) return;
-    const int k = (int)(row / ph_n);
-    const int ph = (int)(row - (long long)k * ph_n);
+    const int upr = (ph_n + RPW - 1) / RPW;                  // wave units per RoI
+    const long long unit = (long long)bid * 4 + wave;
+    if (unit >= (long long)n_rois * upr) return;
+    const int kk = (int)(unit / upr);
+    const int ph_begin = (int)(unit - (long long)kk * upr) * RPW;
+    const int ph_end = min(ph_n, ph_begin + RPW);
+    const int k = perm ? perm[kk] : kk;
     const float* roi = rois + (size_t)k * 5;
     const T* feat = input;
     if (MULTI) {
@@ -274,15 +282,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
         height = lv.height[l];
         width = lv.width[l];
         spatial_scale = lv.scale[l];
-        if (levels_out && ph == 0 && lane == 0) levels_out[k] = l;
+        if (levels_out && ph_begin == 0 && lane == 0) levels_out[k] = l;
     }
     const RoiGeom g = roi_geom(roi, spatial_scale, aligned, ph_n, pw_n, sampling_ratio);
     const T* base = feat + (size_t)g.batch * height * width * channels;
-    T* out_row = output + (size_t)row * pw_n * channels;
     const bool small = g.gh <= 64 && g.gw <= 64;
-    int y0 = 0, ny = 0;
-    float Wy = 0.f;
-    if (small) axis_weights(g.start_h, g.bin_h, ph, g.gh, height, lane, y0, ny, Wy);
     // x-axis weights of ALL bins of the row at once when a bin has <= 8 samples and <= 8 footprint
     // columns (bins up to 7 px): lane group q = lane/8 is bin pw = q, slot j = lane%8
     const int q = lane >> 3, jx = lane & 7;
@@ -313,6 +317,12 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
         Wx_all = w;
         if (__ballot(nx_all > 8) != 0ull) vecx = false;
     }
+    // ---- one bin row
+    auto do_row = [&](int ph) {
+    T* out_row = output + ((size_t)k * ph_n + ph) * pw_n * channels;
+    int y0 = 0, ny = 0;
+    float Wy = 0.f;
+    if (small) axis_weights(g.start_h, g.bin_h, ph, g.gh, height, lane, y0, ny, Wy);
     // ---- column streaming (the common case: every bin of the row has <= 8 footprint columns, the row <= 4 footprint
     // rows): the footprint of the WHOLE bin row is one dense patch of ny x (X1 - X0) pixels; each pixel is loaded once
     // (adjacent bins share their border columns: with 1..2 px bins that is a third of the per-bin loads, and the
@@ -453,6 +463,8 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
             st4(out + c0, acc);
         }
     }
+    };
+    for (int ph = ph_begin; ph < ph_end; ph++) do_row(ph);
 }
 
 int g_roi_exact = 0;     // 1: exact sample-order kernel (bit-identical to the reference's CPU order)
@@ -598,7 +610,7 @@ BRCNN_API int brcnn_roi_align_forward(const float* input, const float* rois, flo
         else
             hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<false, float>), dim3(brcnn_cdiv((long long)n_rois * pooled_h, 4)), dim3(256), 0,
                                s, input, lv, rois, output, (int32_t*)nullptr, channels, height, width,
-                               n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, g_roi_stream_c);
+                               n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, g_roi_stream_c, nullptr);
     } else if (layout == BRCNN_LAYOUT_NCHW) {
         if (pool_mode == 0 && (!argmax_y || !argmax_x)) return BRCNN_EINVAL;
         int grid = brcnn_cdiv(total, 256);
@@ -660,54 +672,129 @@ static int fill_levels(LevelTable& lv, const float* const* feats, float* const* 
     return 0;
 }
 
-BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int* heights_host,
-                                        const int* widths_host, const float* scales_host,
-                                        int num_levels, const float* rois, void* output,
-                                        int32_t* levels_out, int batch, int channels, int n_rois,
-                                        int pooled_h, int pooled_w, int sampling_ratio,
-                                        float finest_scale, int dtype, void* stream) {
-    if (!brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
-    if (!feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
-        return BRCNN_EINVAL;
+// Visiting order of the RoIs for the footprint kernel: a counting sort by (image, level, 12-row band of the RoI's centre
+// on its own level) -- one workgroup, LDS histogram + scan + scatter.  Random proposals of one image touch its whole
+// level-0 map (17 MB at 800 x 1344, fp32) again and again through a 4 MB L2; visited band by band, the bin rows an XCD
+// has in flight stay inside a few rows of one map.  The order inside a bucket is whatever the atomics give: results do
+// not depend on it.
+constexpr int ORDER_BANDS = 16, ORDER_BAND_ROWS = 12;
+__global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict__ rois, int n_rois, LevelTable lv, int batch,
+                                                        int32_t* __restrict__ perm) {
+    __shared__ int cnt[BRCNN_MAX_IMAGES * BRCNN_MAX_LEVELS * ORDER_BANDS];
+    __shared__ int part[1024];
+    const int nb = batch * lv.num_levels * ORDER_BANDS;
+    auto bucket = [&](int i) {
+        const float* roi = rois + (size_t)i * 5;
+        const int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
+        int img = (int)roi[0];
+        img = img < 0 ? 0 : (img >= batch ? batch - 1 : img);
+        int band = (int)((roi[2] + roi[4]) * 0.5f * lv.scale[l]) / ORDER_BAND_ROWS;
+        band = band < 0 ? 0 : (band >= ORDER_BANDS ? ORDER_BANDS - 1 : band);
+        return (img * lv.num_levels + l) * ORDER_BANDS + band;
+    };
+    for (int i = threadIdx.x; i < nb; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_rois; i += 1024) atomicAdd(&cnt[bucket(i)], 1);
+    __syncthreads();
+    // exclusive scan: thread t owns the consecutive buckets [t per, (t + 1) per)
+    const int per = (nb + 1023) / 1024;
+    int sum = 0;
+    for (int j = 0; j < per; j++) {
+        const int bi = threadIdx.x * per + j;
+        if (bi < nb) sum += cnt[bi];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int j = 0; j < per; j++) {
+        const int bi = threadIdx.x * per + j;
+        if (bi < nb) { const int c = cnt[bi]; cnt[bi] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_rois; i += 1024) perm[atomicAdd(&cnt[bucket(i)], 1)] = i;
+}
+
+int g_roi_rpw = 0;       // tuning hook (set_exact(10 / 11 / 17)): rows per wave by the heuristic / 1 / all
+int g_roi_order = 1;     // ... (20 / 21): never / where a workspace is given and the RoI count pays for the sort
+
+template <typename T>
+static int extract_forward_impl(const void* const* feats_host, const int* heights_host, const int* widths_host,
+                                const float* scales_host, int num_levels, const float* rois, void* output,
+                                int32_t* levels_out, int batch, int channels, int n_rois, int pooled_h, int pooled_w,
+                                int sampling_ratio, float finest_scale, int32_t* order_ws, hipStream_t s) {
     LevelTable lv = {};
     if (fill_levels(lv, (const float* const*)feats_host, nullptr, heights_host, widths_host, scales_host,
                     num_levels, finest_scale))
         return BRCNN_EINVAL;
     if (n_rois == 0) return 0;
     if (!rois || !output) return BRCNN_EINVAL;
-    const long long bins = (long long)n_rois * pooled_h * pooled_w;
-    const dim3 grid(brcnn_cdiv(bins, 4)), grid_rows(brcnn_cdiv((long long)n_rois * pooled_h, 4));
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == BRCNN_DT_BF16) {
-        if (g_roi_exact)
-            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)nullptr,
-                               lv, rois, (bf16_t*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
-                               sampling_ratio, 1);
-        else
-            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, bf16_t>), grid_rows, dim3(256), 0, s,
-                               (const bf16_t*)nullptr, lv, rois, (bf16_t*)output, levels_out, channels, 0, 0, n_rois,
-                               pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c);
-    } else if (dtype == BRCNN_DT_F16) {
-        if (g_roi_exact)
-            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, f16_t>), grid, dim3(256), 0, s, (const f16_t*)nullptr,
-                               lv, rois, (f16_t*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
-                               sampling_ratio, 1);
-        else
-            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, f16_t>), grid_rows, dim3(256), 0, s,
-                               (const f16_t*)nullptr, lv, rois, (f16_t*)output, levels_out, channels, 0, 0, n_rois,
-                               pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c);
-    } else {
-        if (g_roi_exact)
-            hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, float>), grid, dim3(256), 0, s, (const float*)nullptr,
-                               lv, rois, (float*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
-                               sampling_ratio, 1);
-        else
-            hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, float>), grid_rows, dim3(256), 0, s,
-                               (const float*)nullptr, lv, rois, (float*)output, levels_out, channels, 0, 0, n_rois,
-                               pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c);
+    if (g_roi_exact) {
+        const long long bins = (long long)n_rois * pooled_h * pooled_w;
+        hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<true, T>), dim3(brcnn_cdiv(bins, 4)), dim3(256), 0, s, (const T*)nullptr,
+                           lv, rois, (T*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w, 0.f,
+                           sampling_ratio, 1);
+        BRCNN_LAUNCH_CHECK();
+        return 0;
     }
+    // many thousands of RoIs: visit them band by band (r04, 8 images: 2000 RoIs / image 382 -> 344 us, 1000 / image 184 ->
+    // 176; at 512 / image the ~4 us sort eats the gain: 100 -> 102).  One wave per bin row at every size: a wave that
+    // walks all seven rows of its RoI shares the level / geometry / x-weight arithmetic but leaves a seventh of the waves
+    // to hide the gather latency -- measured 20-80 % slower (hook 17; profiles/r04_notes.md)
+    const int32_t* perm = nullptr;
+    if (order_ws && g_roi_order && n_rois >= 6144 && batch <= BRCNN_MAX_IMAGES) {
+        hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, s, rois, n_rois, lv, batch, order_ws);
+        BRCNN_LAUNCH_CHECK();
+        perm = order_ws;
+    }
+    const bool all_rows = pooled_h == 7 && g_roi_rpw == 17;
+    if (all_rows)
+        hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, T, 7>), dim3(brcnn_cdiv((long long)n_rois, 4)), dim3(256), 0, s,
+                           (const T*)nullptr, lv, rois, (T*)output, levels_out, channels, 0, 0, n_rois, pooled_h, pooled_w,
+                           0.f, sampling_ratio, 1, g_roi_stream_c, perm);
+    else
+        hipLaunchKernelGGL((roi_align_fwd_nhwc_fp_kernel<true, T, 1>), dim3(brcnn_cdiv((long long)n_rois * pooled_h, 4)),
+                           dim3(256), 0, s, (const T*)nullptr, lv, rois, (T*)output, levels_out, channels, 0, 0, n_rois,
+                           pooled_h, pooled_w, 0.f, sampling_ratio, 1, g_roi_stream_c, perm);
     BRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+// `order_ws`: n_rois int32 of caller-owned scratch for the visiting order of the RoIs (or NULL: RoIs are visited as given)
+BRCNN_API int brcnn_roi_extract_forward_ordered(const void* const* feats_host, const int* heights_host,
+                                                const int* widths_host, const float* scales_host,
+                                                int num_levels, const float* rois, void* output,
+                                                int32_t* levels_out, int batch, int channels, int n_rois,
+                                                int pooled_h, int pooled_w, int sampling_ratio,
+                                                float finest_scale, int dtype, int32_t* order_ws, void* stream) {
+    if (!brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
+    if (!feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
+        return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == BRCNN_DT_BF16)
+        return extract_forward_impl<bf16_t>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
+                                            batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s);
+    if (dtype == BRCNN_DT_F16)
+        return extract_forward_impl<f16_t>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
+                                           batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s);
+    return extract_forward_impl<float>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
+                                       batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s);
+}
+
+BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int* heights_host,
+                                        const int* widths_host, const float* scales_host,
+                                        int num_levels, const float* rois, void* output,
+                                        int32_t* levels_out, int batch, int channels, int n_rois,
+                                        int pooled_h, int pooled_w, int sampling_ratio,
+                                        float finest_scale, int dtype, void* stream) {
+    return brcnn_roi_extract_forward_ordered(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output,
+                                             levels_out, batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio,
+                                             finest_scale, dtype, nullptr, stream);
 }
 
 BRCNN_API int brcnn_roi_extract_backward(float* const* grad_feats_host, const int* heights_host,
@@ -999,6 +1086,9 @@ BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, co
 BRCNN_API int brcnn_roi_align_set_exact(int exact) {
     // 0: footprint kernel (column streaming, XCD-contiguous bin rows), 1: exact sample order, 2: footprint kernel with
     // the per-bin loop and round-robin rows (the r02 form), 3: column streaming with round-robin rows
+    // 10 / 11 / 17: bin rows per wavefront by the heuristic / one / all seven; 20 / 21: RoI visiting order off / on
+    if (exact == 10 || exact == 11 || exact == 17) { g_roi_rpw = exact == 10 ? 0 : exact; return 0; }
+    if (exact == 20 || exact == 21) { g_roi_order = exact - 20; return 0; }
     g_roi_exact = exact == 1 ? 1 : 0;
     g_roi_stream_c = exact == 2 ? 0 : exact == 3 ? 1 : 3;
     return 0;

@@ -22,6 +22,8 @@ SIGNATURES = {
     'brcnn_roi_align_backward': (c_int, [c_ptr] * 3 + [c_int] * 7 + [c_f32] + [c_int] * 3 + [c_ptr]),
     'brcnn_roi_extract_forward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
                                   [c_f32, c_int, c_ptr]),
+    'brcnn_roi_extract_forward_ordered': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
+                                          [c_f32, c_int, c_ptr, c_ptr]),
     'brcnn_roi_extract_backward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 +
                                    [c_f32, c_ptr]),
     'brcnn_roi_extract_backward_workspace_bytes': (c_size, [c_int]),

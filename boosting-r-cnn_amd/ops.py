@@ -184,10 +184,13 @@ def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56,
     hs = (ctypes.c_int * L)(*[f.shape[1] for f in feats_nhwc])
     ws = (ctypes.c_int * L)(*[f.shape[2] for f in feats_nhwc])
     sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
-    st = _L.load().brcnn_roi_extract_forward(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out),
-                                             _ptr(levels), n, c, k, ph, pw, int(sampling_ratio),
-                                             float(finest_scale), dt, _stream())
-    _L.check(st, 'brcnn_roi_extract_forward')
+    # from a few thousand RoIs on the kernel visits them band by band of their maps: the caller provides the scratch of the
+    # visiting order (n int32)
+    order = torch.empty((k,), dtype=torch.int32, device=rois.device) if k >= 6144 else None
+    st = _L.load().brcnn_roi_extract_forward_ordered(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out),
+                                                     _ptr(levels), n, c, k, ph, pw, int(sampling_ratio),
+                                                     float(finest_scale), dt, _ptr(order), _stream())
+    _L.check(st, 'brcnn_roi_extract_forward_ordered')
     return out, levels
 
 

@@ -1029,3 +1029,40 @@ def test_f32_split_k_option_is_reproducible_and_within_round_off():
         assert torch.equal(ops.conv2d_nhwc(xb, wb, None, None, None, False, 1, 1), refb)
     finally:
         L.brcnn_conv_set_tile_bf16(-8)
+
+
+def test_roi_extract_visiting_order_and_rows_per_wave_keep_the_bits():
+    """brcnn_roi_extract_forward_ordered: the band-ordered visit (counting sort by image / level / row band, from 6144
+    RoIs on) and the all-rows-per-wave form (hook 17) give the unordered one-row-per-wave kernel's output and levels
+    bit for bit; the order workspace is the caller's"""
+    import ctypes
+    from brcnn import lib
+    L = lib.load()
+    B = 3
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11), (4, 6)]
+    g = torch.Generator().manual_seed(12)
+    feats = [torch.randn(B, h, w, 256, generator=g).to(DEV) for h, w in sizes]
+    rois = util.rand_rois(7000, B, 672., 400., seed=4, min_size=4., max_size=500.).to(DEV)     # unsorted images, tiny and huge RoIs
+    try:
+        L.brcnn_roi_align_set_exact(11); L.brcnn_roi_align_set_exact(20)
+        ref, lref = ops.roi_extract(feats, rois, 7, strides, 56, 0)
+        for rpw in (11, 17):
+            for od in (20, 21):
+                L.brcnn_roi_align_set_exact(rpw); L.brcnn_roi_align_set_exact(od)
+                out, lv = ops.roi_extract(feats, rois, 7, strides, 56, 0)
+                assert torch.equal(out, ref) and torch.equal(lv, lref), (rpw, od)
+        # raw C ABI: the order scratch is written (a permutation of 0..n-1) only when given
+        n = rois.shape[0]
+        order = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        out = torch.empty_like(ref)
+        ptrs = (ctypes.c_void_p * 5)(*[f.data_ptr() for f in feats])
+        hs = (ctypes.c_int * 5)(*[h for h, _ in sizes]); ws = (ctypes.c_int * 5)(*[w for _, w in sizes])
+        sc = (ctypes.c_float * 5)(*[1.0 / s for s in strides])
+        st = L.brcnn_roi_extract_forward_ordered(ptrs, hs, ws, sc, 5, rois.data_ptr(), out.data_ptr(), None, B, 256, n, 7, 7, 0,
+                                                 56.0, 0, order.data_ptr(), lib.stream_handle())
+        assert st == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(order.sort().values, torch.arange(n, dtype=torch.int32, device=DEV))
+    finally:
+        L.brcnn_roi_align_set_exact(10); L.brcnn_roi_align_set_exact(21); L.brcnn_roi_align_set_exact(0)

@@ -25,16 +25,17 @@ def step():
     opt.step(max_norm=35)
 for _ in range(2): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
 c = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
     if e.name.startswith('aten::') and e.device_time > 0 and e.name not in ('aten::zeros', 'aten::clone', 'aten::to', 'aten::_to_copy', 'aten::contiguous', 'aten::zeros_like', 'aten::full', 'aten::ones', 'aten::float', 'aten::linear'):
-        k = (e.name, str(e.input_shapes)[:90])
+        st = [f for f in (e.stack or []) if 'boosting-r-cnn_amd' in f or 'bench.py' in f]
+        k = (e.name, str(e.input_shapes)[:70], (st[0].split('boosting-r-cnn_amd/')[-1][:60] if st else '?'))
         c[k][0] += 1
         c[k][1] += e.device_time
 tot = sum(v[1] for v in c.values())
 print('listed aten ops: %.2f ms device time' % (tot / 1e3))
 for k, v in sorted(c.items(), key=lambda kv: -kv[1][1])[:70]:
-    print('%4d %8.1f us  %s %s' % (v[0], v[1], k[0], k[1]))
+    print('%4d %8.1f us  %s %s  <- %s' % (v[0], v[1], k[0], k[1], k[2]))
