@@ -95,7 +95,9 @@ def _wgrad_side_stream(device):
         return None
     key = (device.type, device.index)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device)
+        # BRCNN_WGRAD_PRIO: HIP stream priority of the weight-gradient stream (default: the device's default priority)
+        prio = _os.environ.get('BRCNN_WGRAD_PRIO')
+        _side_streams[key] = torch.cuda.Stream(device) if prio is None else torch.cuda.Stream(device, priority=int(prio))
     return _side_streams[key]
 
 

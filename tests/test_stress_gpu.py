@@ -214,3 +214,51 @@ def test_c_abi_caller_owned_conv_workspace():
     finally:
         L.brcnn_conv_set_tile_bf16(0)
         L.brcnn_conv_set_tile_bf16(-4)
+
+
+@pytest.mark.parametrize('dtype,scale', [('bf16', 1.0), ('f16', 512.0)])
+def test_whole_train_step_is_bit_reproducible_under_load(dtype, scale):
+    """the COCO-PAFPN train step (16-bit conv stack: fused conv + BatchNorm launches, BatchNorm backward inside the data
+    gradients, eight-phase weight gradients on the side stream, slab reductions, RPN branch back-propagated inside the
+    forward pass beside the proposal stream, gather RoI backward) holds no order-dependent sum any more: from the same
+    weights, inputs and sampler seed every repetition must give the first one's losses and EVERY gradient bit for bit,
+    also while another stream keeps the CUs busy.  Anything that differs is a race."""
+    import os
+    from brcnn import Config, build_detector, blocks
+    from brcnn import autograd as A
+    from tests import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'boosting_rcnn', 'boosting_rcnn_r50_pafpn_1x_coco.py'))
+    m = build_detector(cfg.model)
+    m.load_state_dict(util.seeded_state_dict(m, seed=19))
+    m = m.to(DEV).train()
+    blocks.conv_weights_channels_last(m)
+    m.set_compute_dtype(dtype)
+    img, metas, gts, gls = util.demo_inputs(4, 384, 640, seed=19, num_gt=12)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.clamp(max=79).to(DEV) for l in gls])
+    load = _Load()
+    first = None
+    try:
+        m.early_rpn_backward, m.early_backward_scale = True, scale
+        for rep in range(12):
+            load.push(rep)
+            m.zero_grad(set_to_none=True)
+            A.grad_arena.new_step()
+            torch.manual_seed(77)
+            loss, log_vars = m._parse_losses(m.forward_train(*args))
+            (loss * scale).backward()
+            A.join_side_streams()
+            torch.cuda.synchronize()
+            cur = (dict(log_vars), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+            assert all(torch.isfinite(g).all() for g in cur[1].values())
+            if first is None:
+                first = cur
+                continue
+            assert cur[0] == first[0], (rep, cur[0], first[0])
+            assert cur[1].keys() == first[1].keys()
+            for k, g in cur[1].items():
+                assert torch.equal(g, first[1][k]), (rep, k, (g.float() - first[1][k].float()).abs().max().item())
+        _lib.handover_status()
+    finally:
+        m.early_rpn_backward, m.early_backward_scale = False, 1.0
+        blocks.set_compute_dtype('f32')

@@ -4,7 +4,7 @@
 # under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
 # in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
 export GPU_MAX_HW_QUEUES=8
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -32,6 +32,8 @@ BRCNN_DTYPE=bf16 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE
 python tools/op_bench.py > $O/op_bench.json 2> $O/op_bench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/op_pmc_fetch -o step -- python3 tools/op_bench.py > /dev/null 2> $O/op_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/op_pmc_write -o step -- python3 tools/op_bench.py > /dev/null 2> $O/op_pmc_write.err
+python tools/wgrad_pp_bench.py 75 > $O/wgrad_pp_bench.txt 2>&1
+python tools/experiments/roi_variants.py > $O/roi_variants.txt 2>&1
 python tools/layers.py > $O/layers.txt 2>&1
 BRCNN_DTYPE=bf16 python tools/layers.py > $O/layers_bf16.txt 2>&1
 python tools/train_layers.py > $O/train_layers_bf16.txt 2>&1

@@ -9,7 +9,8 @@ dt = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 
 
 def family(name):
-    for k in ('conv_pp_bf16_kernel', 'conv_igemm_bf16_dma_kernel', 'conv_wgrad_bf16_kernel', 'wgrad_reduce_kernel',
+    for k in ('conv_wgrad_pp_bf16_kernel', 'wgrad_pp_reduce_kernel', 'conv_pp_bf16_kernel', 'conv_igemm_bf16_dma_kernel',
+              'conv_wgrad_bf16_kernel', 'wgrad_reduce_kernel',
               'conv_igemm_f32', 'conv_wgrad_f32'):
         if k in name:
             return k
