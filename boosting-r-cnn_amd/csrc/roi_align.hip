@@ -721,7 +721,7 @@ __global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict
 }
 
 int g_roi_rpw = 0;       // tuning hook (set_exact(10 / 11 / 17)): rows per wave by the heuristic / 1 / all
-int g_roi_order = 1;     // ... (20 / 21): never / where a workspace is given and the RoI count pays for the sort
+int g_roi_order = 1;     // ... (20 / 21 / 22): never / where a workspace is given and the RoI count pays for the sort / always
 
 template <typename T>
 static int extract_forward_impl(const void* const* feats_host, const int* heights_host, const int* widths_host,
@@ -742,12 +742,13 @@ static int extract_forward_impl(const void* const* feats_host, const int* height
         BRCNN_LAUNCH_CHECK();
         return 0;
     }
-    // many thousands of RoIs: visit them band by band (r04, 8 images: 2000 RoIs / image 382 -> 344 us, 1000 / image 184 ->
-    // 176; at 512 / image the ~4 us sort eats the gain: 100 -> 102).  One wave per bin row at every size: a wave that
+    // many thousands of RoIs: visit them band by band (r04, 8 images x 2000 RoIs: fabric fetch per launch 1077 -> 318 MB by
+    // the PMC counters, time 358-382 -> 344 us; at 1000 / image the gain is inside the run-to-run spread, at 512 / image
+    // the ~4 us sort eats it).  One wave per bin row at every size: a wave that
     // walks all seven rows of its RoI shares the level / geometry / x-weight arithmetic but leaves a seventh of the waves
     // to hide the gather latency -- measured 20-80 % slower (hook 17; profiles/r04_notes.md)
     const int32_t* perm = nullptr;
-    if (order_ws && g_roi_order && n_rois >= 6144 && batch <= BRCNN_MAX_IMAGES) {
+    if (order_ws && batch <= BRCNN_MAX_IMAGES && (g_roi_order == 2 || (g_roi_order == 1 && n_rois >= 12288))) {
         hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, s, rois, n_rois, lv, batch, order_ws);
         BRCNN_LAUNCH_CHECK();
         perm = order_ws;
@@ -1086,9 +1087,9 @@ BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, co
 BRCNN_API int brcnn_roi_align_set_exact(int exact) {
     // 0: footprint kernel (column streaming, XCD-contiguous bin rows), 1: exact sample order, 2: footprint kernel with
     // the per-bin loop and round-robin rows (the r02 form), 3: column streaming with round-robin rows
-    // 10 / 11 / 17: bin rows per wavefront by the heuristic / one / all seven; 20 / 21: RoI visiting order off / on
+    // 10 / 11 / 17: bin rows per wavefront by the heuristic / one / all seven; 20 / 21 / 22: RoI visiting order off / by the heuristic / forced
     if (exact == 10 || exact == 11 || exact == 17) { g_roi_rpw = exact == 10 ? 0 : exact; return 0; }
-    if (exact == 20 || exact == 21) { g_roi_order = exact - 20; return 0; }
+    if (exact >= 20 && exact <= 22) { g_roi_order = exact - 20; return 0; }
     g_roi_exact = exact == 1 ? 1 : 0;
     g_roi_stream_c = exact == 2 ? 0 : exact == 3 ? 1 : 3;
     return 0;

@@ -186,7 +186,7 @@ def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56,
     sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
     # from a few thousand RoIs on the kernel visits them band by band of their maps: the caller provides the scratch of the
     # visiting order (n int32)
-    order = torch.empty((k,), dtype=torch.int32, device=rois.device) if k >= 6144 else None
+    order = torch.empty((k,), dtype=torch.int32, device=rois.device) if k >= 2048 else None       # (the library orders from 12 288 RoIs on)
     st = _L.load().brcnn_roi_extract_forward_ordered(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out),
                                                      _ptr(levels), n, c, k, ph, pw, int(sampling_ratio),
                                                      float(finest_scale), dt, _ptr(order), _stream())

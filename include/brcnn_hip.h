@@ -93,7 +93,7 @@ int brcnn_roi_extract_forward(const void *const *feats_host, const int *heights_
                               int sampling_ratio, float finest_scale,
                               int dtype /* of feats and output: BRCNN_DT_F32 | BRCNN_DT_BF16 */,
                               void *stream);
-/* The same with `order_ws` (n_rois int32, caller-owned; NULL = visit the RoIs as given): from ~6000 RoIs on the
+/* The same with `order_ws` (n_rois int32, caller-owned; NULL = visit the RoIs as given): from ~12000 RoIs on the
  * kernel visits them sorted by (image, level, 12-row band of the RoI's centre) -- one small counting-sort launch --
  * so that the bin rows an XCD has in flight stay inside what its L2 holds.  Results are those of
  * brcnn_roi_extract_forward bit for bit. */

@@ -1032,8 +1032,8 @@ def test_f32_split_k_option_is_reproducible_and_within_round_off():
 
 
 def test_roi_extract_visiting_order_and_rows_per_wave_keep_the_bits():
-    """brcnn_roi_extract_forward_ordered: the band-ordered visit (counting sort by image / level / row band, from 6144
-    RoIs on) and the all-rows-per-wave form (hook 17) give the unordered one-row-per-wave kernel's output and levels
+    """brcnn_roi_extract_forward_ordered: the band-ordered visit (counting sort by image / level / row band, from 12 288
+    RoIs on by itself; forced here) and the all-rows-per-wave form (hook 17) give the unordered one-row-per-wave kernel's output and levels
     bit for bit; the order workspace is the caller's"""
     import ctypes
     from brcnn import lib
@@ -1048,11 +1048,12 @@ def test_roi_extract_visiting_order_and_rows_per_wave_keep_the_bits():
         L.brcnn_roi_align_set_exact(11); L.brcnn_roi_align_set_exact(20)
         ref, lref = ops.roi_extract(feats, rois, 7, strides, 56, 0)
         for rpw in (11, 17):
-            for od in (20, 21):
+            for od in (20, 22):
                 L.brcnn_roi_align_set_exact(rpw); L.brcnn_roi_align_set_exact(od)
                 out, lv = ops.roi_extract(feats, rois, 7, strides, 56, 0)
                 assert torch.equal(out, ref) and torch.equal(lv, lref), (rpw, od)
         # raw C ABI: the order scratch is written (a permutation of 0..n-1) only when given
+        L.brcnn_roi_align_set_exact(22)
         n = rois.shape[0]
         order = torch.full((n,), -1, dtype=torch.int32, device=DEV)
         out = torch.empty_like(ref)

@@ -31,7 +31,7 @@ for per_img in (256, 512, 1000, 2000):
     L.brcnn_roi_align_set_exact(11); L.brcnn_roi_align_set_exact(20)
     ref, lref = ops.roi_extract(feats, rois, 7, strides, 56, 0)
     for rpw, name_r in ((11, 'row/wave'), (17, 'RoI/wave')):
-        for od, name_o in ((20, 'as given'), (21, 'band order')):
+        for od, name_o in ((20, 'as given'), (22, 'band order')):
             L.brcnn_roi_align_set_exact(rpw); L.brcnn_roi_align_set_exact(od)
             out, lv = ops.roi_extract(feats, rois, 7, strides, 56, 0)
             assert torch.equal(out, ref) and torch.equal(lv, lref), (per_img, name_r, name_o)

@@ -16,16 +16,19 @@ HBM = 8000.0
 
 
 def timed(fn, n=20):
+    """median over n calls, one HIP-event pair each (an average over the loop let a single stall -- an allocator growth,
+    a clock ramp after a host-side pause -- show up as a 10x outlier of one entry in two rounds' reports)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record()
+    for i in range(n):
         fn()
-    e.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e-3
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+    return ts[n // 2] * 1e-3
 
 
 def roialign_bytes(rois, strides, sizes, C=256, out=7):
