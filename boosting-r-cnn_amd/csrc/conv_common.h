@@ -64,6 +64,7 @@ struct ConvParams {
     // sk_flags[slot] = sk_epoch) and its K tail (dispatched in the LAST round; it starts from those accumulators, so the
     // MFMA chain over K is the unsplit one, bit for bit, and runs the epilogue).  sk_wgs = 0: one whole tile per block.
     int pp_rows;                     // eight-phase fp32 kernel: tuning hook, 0 heuristic / 128 / 256 row tiles
+    int pp_cols;                     // ... 0 heuristic / 128: the 256 x 128 tile (Cout % 128 == 0)
     int sk_wgs;
     const int4* sk_items;
     float* sk_ws;

@@ -601,6 +601,7 @@ int launch_res(const ConvParams& p, hipStream_t s) {
 int g_use_dma = 1;                      // LDS-DMA staged kernel for the FAST path
 int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 = heuristic
 
+int g_pp_f32_n128 = 1;      // tuning hook (brcnn_conv_set_tile(-3, 0 / 1 / 2)): the 256 x 128 eight-phase tile never / heuristic / forced
 int g_pp_f32_mode = 1;      // tuning hook (brcnn_conv_set_tile(-2, 0 / 1 / 2 / 128 / 256)): eight-phase fp32 kernel never / heuristic / forced (tile rows by the heuristic / 128 / 256)
 
 int dispatch_conv(ConvParams& p, hipStream_t s) {
@@ -620,6 +621,17 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
         // equal to the unsplit sum to fp32 round-off -- the one place where the kernel choice changes the association)
         const bool few = sk_par_enabled() && t48 >= 64 && t48 < 208 && p.K / 32 >= 64 && p.dilate <= 1;
         if (g_pp_f32_mode >= 2 || ((t48 >= 208 || few) && (p.K >= 512 || !p.residual))) return dispatch_conv_pp_f32(p, s);
+    }
+    // ... and its 256 x 128 form (r04) for the layers with 128 output channels (stage 2: 3x3 128->128, 1x1 256/512->128)
+    if (fast && g_pp_f32_mode && g_pp_f32_n128 && g_force_wm == 0 && g_force_nt == 0 && !p.gstep && (p.Cout % 256) != 0 &&
+        (p.Cout % 128) == 0 && p.K >= 256 && p.KH * p.KW <= 32 && !(p.dilate > 1 && p.residual)) {
+        const long long t = (long long)((p.M + 255) / 256) * (p.Cout / 128);
+        p.pp_rows = 0;
+        p.pp_cols = 128;
+        // (measured, batch 8: stage-2 3x3 128->128 1.43 -> 1.38 ms for the four layers, 105 -> 112 TF/s; the K = 256 / 512 1x1
+        // layers are output-bound and no faster than on the 64 x 64 tile: 3x3-deep K loops only)
+        if (g_pp_f32_n128 >= 2 || (t >= 208 && p.K >= 1024)) return dispatch_conv_pp_f32(p, s);
+        p.pp_cols = 0;
     }
     // Measured on MI355X (profiles/r01_conv_tiles.txt): with LDS-DMA staging the SMALLEST tile,
     // 64x64 (4 waves x one 32x32 MFMA tile, 32 KiB LDS -> up to 5 resident workgroups / CU,
@@ -656,6 +668,7 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
     if (wm == -1) { g_use_dma = nt; return 0; }   // (-1, 0/1/2): register-staged / heuristic / always LDS-DMA
+    if (wm == -3) { if (nt < 0 || nt > 2) return BRCNN_EINVAL; g_pp_f32_n128 = nt; return 0; }
     if (wm == -2) { if (nt != 0 && nt != 1 && nt != 2 && nt != 128 && nt != 256) return BRCNN_EINVAL; g_pp_f32_mode = nt; return 0; }
     if ((wm != 0 && wm != 1 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
     g_force_wm = wm;

@@ -16,7 +16,7 @@ using namespace brcnn_conv;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int BKE = 32;         // K tile in elements (128 bytes of fp32)
-constexpr int BN = 256, NT = 2, WNW = 4, NW = 8;
+constexpr int NT = 2, NW = 8;
 constexpr int SLOT = 16384;         // bytes of one half-tile slot: 128 rows x 128 B
 
 
@@ -27,18 +27,25 @@ template <int N> using ic = std::integral_constant<int, N>;
 // hand-over slot) comes from the launch's table; a K head stores its accumulators, a K tail starts from them.
 // MT: 32-row MFMA tiles per wave along M -- 4: 256 x 256 tile, 2: 128 x 256 (the layers whose 256-row tiles would not
 // cover the device; an fp32 phase is still 16 MFMAs = 1024 matrix-pipe cycles)
-template <bool RES, bool DIL, bool SK, int MT>
+// WG: row groups of waves -- 2 (x 4 column strips of 64: 256 columns) or, r04, 4 (x 2 strips: a 256 x 128 tile with MT = 2,
+// for the layers with 128 output channels: stage 2's 3x3 and first 1x1 convs ran on the 64 x 64 kernel at 101-105 TF/s).
+// Same eight phases, same (kk, e) order per accumulator: a wave still owns 32 MT rows x 64 columns; the A half-slot is full
+// (4 groups x 32 rows), the B half-slot half empty (2 strips x 32 columns).
+template <bool RES, bool DIL, bool SK, int MT, int WG = 2>
 __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
-    constexpr int BM = 64 * MT;
+    constexpr int WNW = NW / WG;                    // column strips
+    constexpr int BM = WG * 32 * MT, BN = WNW * 32 * NT;
     constexpr int HT = MT / 2;                      // MFMA tiles of one A half per wave
     constexpr int AHW = 32 * HT;                    // rows one wave group owns in an A half-slot
-    static_assert(MT == 4 || MT == 2, "256- or 128-row tiles");
+    constexpr int AP = WG * HT / 2;                 // 8-row DMA pieces of an A half-slot per wave (WG AHW rows / 8 waves / 8)
+    static_assert((MT == 4 && WG == 2) || MT == 2, "256 x 256, 128 x 256 or (WG = 4) 256 x 128 tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nk = p.K / BKE;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int pg = wave >> 2;                       // phase group: the two waves of a SIMD run one barrier apart
     const int li = lane & 31, lh = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -73,27 +80,27 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     // per DMA instruction instead of the unpack / four compares / multiply chain (the load block of a phase has to
     // fit beside the other group's 256 cycles of MFMAs).  Zero-stuffed inputs (dilate > 1: data gradient of a
     // strided conv) keep the general form.
-    int a_off[2][HT], b_off[2][2], lc[2], lca[HT];
-    int a_ws[DIL ? 1 : 2][HT];          // !DIL: byte stride of an input row
-    unsigned a_mask[2][HT];
-    int a_hw[DIL ? 2 : 1][HT], a_HW[DIL ? 2 : 1][HT];       // DIL only: packed (hi0, wi0), (H, W)
+    int a_off[2][AP], b_off[2][2], lc[2], lca[AP];
+    int a_ws[DIL ? 1 : 2][AP];          // !DIL: byte stride of an input row
+    unsigned a_mask[2][AP];
+    int a_hw[DIL ? 2 : 1][AP], a_HW[DIL ? 2 : 1][AP];       // DIL only: packed (hi0, wi0), (H, W)
 #pragma unroll
     for (int j = 0; j < 2; j++) lc[j] = (pc ^ ((4 * j + (lane >> 4)) & 7)) * 4;     // floats
 #pragma unroll
-    for (int j = 0; j < HT; j++) lca[j] = (pc ^ ((4 * ((wave * HT + j) & 1) + (lane >> 4)) & 7)) * 4;
+    for (int j = 0; j < AP; j++) lca[j] = (pc ^ ((4 * ((wave * AP + j) & 1) + (lane >> 4)) & 7)) * 4;
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int R = 16 * wave + 8 * j + rg;
             const int co = n0 + (R >> 5) * 64 + h * 32 + (R & 31);
-            b_off[h][j] = (co < p.Cout) ? (co * p.K + lc[j]) * 4 : OOB;
+            b_off[h][j] = (co < p.Cout && (R >> 5) < WNW) ? (co * p.K + lc[j]) * 4 : OOB;
         }
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
-        for (int j = 0; j < HT; j++) {
-            const int R = 8 * (wave * HT + j) + rg;          // row of the A half-slot (2 * AHW rows)
+        for (int j = 0; j < AP; j++) {
+            const int R = 8 * (wave * AP + j) + rg;          // row of the A half-slot (WG * AHW rows)
             const int m = m0 + (R / AHW) * (32 * MT) + (h * HT + (R % AHW) / 32) * 32 + (R & 31);
             a_off[h][j] = 0;
             a_mask[h][j] = 0u;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
         }
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
     const unsigned st_dst = lds0 + (unsigned)wave * 2048u;        // this wave's rows inside a B slot (two pieces)
-    const unsigned sta_dst = lds0 + (unsigned)wave * (HT * 1024u);  // ... inside an A slot (HT pieces)
+    const unsigned sta_dst = lds0 + (unsigned)wave * (AP * 1024u);  // ... inside an A slot (AP pieces)
 
     // K tiles are visited channel chunk by channel chunk, the filter taps INSIDE a chunk (K tile kt = chunk kt / T,
     // tap kt % T; T = KH KW): the nine taps of a 3x3 filter read shifted windows of the same 128-byte pieces of the
@@ -159,14 +166,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
             const int tap = tA_kh * p.KW + tA_kw;                   // scalar
             const int s_off = (tA_kw * p.pitch + tA_ci0) * 4;
 #pragma unroll
-            for (int j = 0; j < HT; j++) {
+            for (int j = 0; j < AP; j++) {
                 const bool ok = valid & (((a_mask[h][j] >> tap) & 1u) != 0u);
                 const int off = ok ? a_off[h][j] + tA_kh * a_ws[h][j] + s_off : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(size_t)(sta_dst + slot * SLOT + j * 1024), 16, off, 0, 0, 0);
             }
         } else {
 #pragma unroll
-        for (int j = 0; j < HT; j++) {
+        for (int j = 0; j < AP; j++) {
             int hi = (a_hw[h][j] >> 16) - 4096 + tA_kh;
             int wi = (a_hw[h][j] & 0xffff) - 4096 + tA_kw;
             bool ok = valid & (a_mask[h][j] != 0u) & (hi >= 0) & (wi >= 0);
@@ -254,8 +261,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    // five stages stay in flight; they alternate A (HT instructions) and B (2): the smaller of the two window sums
-    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HT == 2 ? 10 : 7) : "memory"); };
+    // five stages stay in flight; they alternate A (AP instructions) and B (2): the smaller of the two window sums
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AP == 2 ? 10 : 7) : "memory"); };
 
     // ---- prologue: K tiles 0 (slots 0-3: B0 A0 B1 A1) and 1 (slots 4-7: B1 A0 B0 A1), in read order
     stage_B(0, 0, kb);
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * HT + 6) : "memory");      // slots 0, 1 of this wave have landed
     barrier();
     read_B(B0r, ic<0>{});                            // "phase 0": B0 of K tile 0
-    if (wm == 1) barrier();                          // the second group runs one barrier behind
+    if (pg == 1) barrier();                          // the second group runs one barrier behind
 
     const int iters = (ke - kb + 1) >> 1;
     for (int it = 0; it < iters; it++) {
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
         barrier();
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (wm == 0) barrier();
+    if (pg == 0) barrier();
     barrier();                                       // every wave is past its last fragment read and DMA: the slabs may land
     if constexpr (SK) {
         if (!finish) {
@@ -490,15 +497,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     }
 }
 
-template <bool RES, bool DIL, int MT>
+template <bool RES, bool DIL, int MT, int WG = 2>
 int launch_pp_f32(ConvParams& p, hipStream_t s) {
-    constexpr int BM = 64 * MT;
+    constexpr int BM = WG * 32 * MT, BN = (NW / WG) * 32 * NT;
     constexpr size_t lds = 8 * SLOT;
     static bool attr_done = false;
     static int num_cus = 0;
     if (!attr_done) {
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, false, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, true, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, false, MT, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BRCNN_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pp_f32_kernel<RES, DIL, true, MT, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         hipDeviceProp_t prop;
         BRCNN_HIP_CHECK(hipGetDevice(&dev));
@@ -511,9 +518,9 @@ int launch_pp_f32(ConvParams& p, hipStream_t s) {
     const int rc = sk_plan_pp_f32(p, num_cus, BM, BN, s);
     if (rc) return rc;
     if (p.sk_wgs > 0)
-        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, true, MT>), dim3(p.sk_wgs), dim3(512), lds, s, p);
+        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, true, MT, WG>), dim3(p.sk_wgs), dim3(512), lds, s, p);
     else
-        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, false, MT>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
+        hipLaunchKernelGGL((conv_pp_f32_kernel<RES, DIL, false, MT, WG>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, s, p);
     BRCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -524,6 +531,14 @@ namespace brcnn_conv {
 // 256 x 256 tile, eight-phase schedule, exact-fp32 MFMA; plain epilogue
 int dispatch_conv_pp_f32(ConvParams& p, hipStream_t s) {
     if (p.K < 2 * BKE || (p.K % BKE) || (p.Cin % BKE) || p.KH * p.KW > 32 || (p.Cout & 3) || p.z_out || p.tail_z) return BRCNN_EINVAL;
+    // 128 output channels (or an odd multiple): the 256 x 128 tile (r04)
+    if (p.pp_cols == 128 || (p.pp_cols == 0 && (p.Cout % 256) != 0 && (p.Cout % 128) == 0)) {
+        p.tiles_n = p.Cout / 128;
+        p.tiles_m = (p.M + 255) / 256;
+        if (p.dilate > 1) return p.residual ? BRCNN_EINVAL : launch_pp_f32<false, true, 2, 4>(p, s);
+        return p.residual ? launch_pp_f32<true, false, 2, 4>(p, s) : launch_pp_f32<false, false, 2, 4>(p, s);
+    }
+    constexpr int BN = 256;
     // 256-row tiles where they cover the device, else 128-row tiles
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const long long t256 = (long long)((p.M + 255) / 256) * p.tiles_n;

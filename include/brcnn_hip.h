@@ -266,7 +266,8 @@ int brcnn_conv_handover_status(void);
  * benchmarking scripts (tools/conv_bench.py).  (-1, 0/1/2): register-staged / heuristic / LDS-DMA
  * staging.  (-2, 0 / 1 / 2 / 128 / 256): the eight-phase fp32 kernel (csrc/conv_pp_f32.hip: 256- or
  * 128-row x 256-column tiles, two wave groups alternating MFMA and load blocks, chained stream-K) never /
- * by the heuristic / forced, forced with 128- / 256-row tiles.  Every choice gives the same bits. */
+ * by the heuristic / forced, forced with 128- / 256-row tiles.  (-3, 0 / 1 / 2): its 256 x 128 form for layers with 128
+ * output channels never / by the heuristic / forced.  Every choice gives the same bits. */
 int brcnn_conv_set_tile(int wm, int nt);
 
 /* Tuning hook of the bf16 kernel: 0 heuristic; 11 / 21 / 22 = 64x64 / 128x64 / 128x128 tile on

@@ -1067,3 +1067,43 @@ def test_roi_extract_visiting_order_and_rows_per_wave_keep_the_bits():
         assert torch.equal(out, ref) and torch.equal(order.sort().values, torch.arange(n, dtype=torch.int32, device=DEV))
     finally:
         L.brcnn_roi_align_set_exact(10); L.brcnn_roi_align_set_exact(21); L.brcnn_roi_align_set_exact(0)
+
+
+@pytest.mark.parametrize('cfg', [
+    # n, h, w, ci, co, k, stride, pad, residual
+    (2, 100, 168, 128, 128, 3, 1, 1, False),     # stage-2 3x3: 132 tiles of 256 x 128, even K-tile count
+    (2, 100, 168, 256, 128, 3, 2, 1, False),     # strided
+    (2, 101, 83, 512, 128, 1, 1, 0, False),      # 1x1, ragged M (last row tile partly out of range)
+    (1, 64, 96, 96, 384, 3, 1, 1, True),         # Cout = 3 x 128 (three column tiles), Cin % 32 == 0 only, residual, odd K tiles
+])
+def test_f32_eight_phase_256x128_tile_is_bit_identical(cfg):
+    """the 256 x 128 form of the fp32 eight-phase kernel (four row groups x two column strips; layers with 128 output
+    channels) against the 64 x 64 two-buffer kernel: identical bits, plain and stream-K launches"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    n, h, w_, ci, co, k, stride, pad, res = cfg
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(n, h, w_, ci, generator=g).to(DEV)
+    w = (torch.randn(co, k, k, ci, generator=g) * 0.05).to(DEV)
+    sc = (torch.rand(co, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(co, generator=g).to(DEV)
+    ho, wo = ops.conv_out_size(h, w_, k, k, stride, pad)
+    r = torch.randn(n, ho, wo, co, generator=g).to(DEV) if res else None
+    try:
+        assert L.brcnn_conv_set_tile(-3, 0) == 0
+        ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
+        y64 = ref.double()
+        xd, wd = x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2)
+        want = torch.nn.functional.conv2d(xd, wd, None, stride, pad).permute(0, 2, 3, 1) * sc.double() + sh.double()
+        if r is not None:
+            want = want + r.double()
+        assert (y64 - want.relu()).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+        assert L.brcnn_conv_set_tile(-3, 2) == 0
+        for sk in (-3, -5, -4):
+            assert L.brcnn_conv_set_tile_bf16(sk) == 0
+            for rep in range(2):
+                out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad)
+                assert torch.equal(out, ref), (sk, rep, (out - ref).abs().max().item())
+    finally:
+        L.brcnn_conv_set_tile(-3, 1)
+        L.brcnn_conv_set_tile_bf16(-4)
