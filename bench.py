@@ -325,6 +325,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline and cfg is not None:
             from oracle import cpu_pipeline
             line['cpu_baseline'] = cpu_pipeline.timed_baseline(cfg, seed=0)
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit -- AFTER the line
+        # the driver reads as the last one
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if world > 1 or args.force_reducer:
         dist.barrier()
