@@ -773,11 +773,11 @@ class ConvBnEvalActFunction(Function):
 
 # conv2 / conv3 of a Bottleneck run the BatchNorm backward of bn1 / bn2 inside their data-gradient launches
 FUSE_BN_BACKWARD_INTO_DGRAD = _os.environ.get('BRCNN_FUSE_BN_BWD', '1') != '0'
-# ... and, optionally, conv1 of the NEXT block of a stage the backward of bn3 (residual + ReLU) of the block before
-# it.  Off by default: measured 0.2 ms SLOWER per step (23.87 -> 24.07 ms) -- conv1's data gradient is a short-K
-# 1x1 launch that is output-bound already, and three more tile streams through its epilogue cost more than the
-# dedicated streaming kernel they replace (profiles/r02_notes.md).  BRCNN_FUSE_BN3_BWD=1 enables it.
-FUSE_RESIDUAL_BN_BACKWARD = _os.environ.get('BRCNN_FUSE_BN3_BWD', '0') == '1'
+# ... and conv1 of the NEXT block of a stage the backward of bn3 (residual + ReLU) of the block before it.  Round 2 measured
+# this 0.2 ms SLOWER per step (23.87 -> 24.07 ms, profiles/r02_notes.md); with round 4's kernels the same-box interleaved
+# A/B (tools/experiments/ab_train.py base=bn3:0 bn3=bn3:1) has it 0.35 ms FASTER (20.63 -> 20.28 ms, every round of four),
+# so it is on.  BRCNN_FUSE_BN3_BWD=0 disables it.
+FUSE_RESIDUAL_BN_BACKWARD = _os.environ.get('BRCNN_FUSE_BN3_BWD', '1') != '0'
 
 
 def conv_bn_eval_act_fusable(x, conv, bn, residual):

@@ -671,6 +671,14 @@ float* conv_ws_wgrad_slabs(hipStream_t s) {
     if (sk_stream_state(s, &st)) return nullptr;
     return st->slabs;
 }
+// arrival counters of the weight gradient's in-launch slab reduction: the upper half of the (zero-initialised) flag area,
+// 8192 words; every counter is back at zero when the launch that used it ends (the last arriver resets it)
+unsigned* conv_ws_wgrad_counters(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_sk_mutex);
+    SkStream* st = nullptr;
+    if (sk_stream_state(s, &st)) return nullptr;
+    return st->flags + 8192;
+}
 }  // namespace brcnn_conv
 
 BRCNN_API size_t brcnn_conv_workspace_bytes(void) { return CONV_WS_BYTES; }

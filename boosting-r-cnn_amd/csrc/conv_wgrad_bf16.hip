@@ -493,8 +493,9 @@ BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
     if (wt >= 3010 && wt <= 3400) { g_wgrad_slot_pct_big = wt - 3000; return 0; }
     // eight-phase kernel (conv_wgrad_pp_bf16.hip): 20 never / 21 heuristic / 22 wherever the shape allows; 4000 + n: n
     // percent of the CUs per launch; 5000 + n: two reduce passes above n slices; 29: RETURNS the number of launches the
-    // eight-phase kernel took since the last query (tests)
-    if ((wt >= 20 && wt <= 22) || wt == 29 || (wt >= 4010 && wt <= 4400) || (wt >= 5001 && wt <= 5999)) return brcnn_conv::wgrad_pp_set(wt);
+    // eight-phase kernel took since the last query (tests); 30 / 31: its slab reduction as separate launches / inside the
+    // producing launch
+    if ((wt >= 20 && wt <= 22) || wt == 29 || wt == 30 || wt == 31 || (wt >= 4010 && wt <= 4400) || (wt >= 5001 && wt <= 5999)) return brcnn_conv::wgrad_pp_set(wt);
     if (wt < 0 || wt == 3 || wt > 4) return BRCNN_EINVAL;
     g_wgrad_bf16_tile = wt;
     return 0;

@@ -44,6 +44,12 @@ struct WgradPPParams {
     const unsigned short* x;    // NHWC segments back to back
     float* dw;                  // (Cout, K) fp32, accumulated into
     float* slab;                // slices > 1: [slice][tile][32 register groups][512 threads] float4
+    // in-launch reduction of the slabs (fuse_group > 0): the slices of a tile form groups of fuse_group; the LAST workgroup
+    // of a group to arrive (ticket on counters[tile * (ngroups + 1) + group]) adds the group's slabs in slice order into the
+    // group's first slab, then takes a ticket on the tile's counter (index ngroups); the last group of the tile adds the
+    // group sums in group order into dw.  Fixed association whoever does the adding: reproducible.  No workgroup waits.
+    unsigned* counters;
+    int fuse_group, ngroups;
     int Cin, Cout, KH, KW, stride, pad, M, K;
     int tiles_co, tiles_k, slices;
     unsigned dy_bytes, x_bytes;
@@ -392,7 +398,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_bf16_kernel(WgradPPParam
     // ---- epilogue.  acc[a][c]: co = co0 + (a >> 1) 128 + wm 64 + (a & 1) 32 + row,  k = k0 + c 128 + (wn >> 1) 64 + (wn & 1) 32 + (lane & 31),
     // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     if (p.slab) {
-        f32x4* dst = reinterpret_cast<f32x4*>(p.slab) + ((size_t)slice * tiles + b) * (size_t)(TILE * TILE / 4) + tid;
+        const size_t tile_f4 = (size_t)(TILE * TILE / 4);
+        f32x4* slab4 = reinterpret_cast<f32x4*>(p.slab);
+        f32x4* dst = slab4 + ((size_t)slice * tiles + b) * tile_f4 + tid;
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -404,6 +412,75 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_bf16_kernel(WgradPPParam
                     v.z = acc[a][c][4 * g + 2]; v.w = acc[a][c][4 * g + 3];
                     dst[((a * 2 + c) * 4 + g) * 512] = v;
                 }
+        if (p.fuse_group <= 0) return;
+        // ---- in-launch reduction (MI355X_MICROARCH.md, inter-workgroup visibility: stores -> every wave drains ->
+        // barrier -> one lane: agent release, drained, relaxed ticket; the reader: ticket -> agent acquire -> barrier -> plain
+        // loads).  The role word lives in the (now idle) dynamic LDS: a second __shared__ object would make the compiler
+        // drain the DMA queue in front of every fragment read of the main loop.
+        int* role = reinterpret_cast<int*>(smem);
+        const int G = p.fuse_group, NG = p.ngroups;
+        const int grp = slice / G;
+        const int gs = min(G, p.slices - grp * G);
+        unsigned* cnt = p.counters + (size_t)b * (NG + 1);
+        auto arrive = [&](unsigned* c, int last_ticket) -> bool {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (int)t == last_ticket;
+                if (last) {
+                    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                role[0] = last;
+            }
+            __syncthreads();
+            const bool r = role[0] != 0;
+            __syncthreads();
+            return r;
+        };
+        if (!arrive(cnt + grp, gs - 1)) return;
+        // sum of `count` slabs first, first + step, ... (slice order) for this thread's 32 float4 positions; `to_dw`: into dw
+        // with the accumulator layout, else into the first slab
+        auto reduce = [&](int first, int step, int count, bool to_dw) {
+            const size_t sstride = (size_t)tiles * tile_f4 * step;
+            f32x4* src0 = slab4 + ((size_t)first * tiles + b) * tile_f4 + tid;
+            for (int v0 = 0; v0 < 32; v0 += 8) {
+                f32x4 s4[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s4[u] = src0[(size_t)(v0 + u) * 512];
+                for (int i = 1; i < count; i++) {
+                    f32x4 t4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) t4[u] = src0[(size_t)i * sstride + (size_t)(v0 + u) * 512];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { s4[u].x += t4[u].x; s4[u].y += t4[u].y; s4[u].z += t4[u].z; s4[u].w += t4[u].w; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int v = v0 + u;
+                    if (!to_dw) {
+                        src0[(size_t)v * 512] = s4[u];
+                    } else {
+                        const int a = v >> 3, c = (v >> 2) & 1, g = v & 3;
+                        const int kk = k0 + c * 128 + (wn >> 1) * 64 + (wn & 1) * 32 + (lane & 31);
+                        const int co = co0 + (a >> 1) * 128 + wm * 64 + (a & 1) * 32 + 8 * g + 4 * (lane >> 5);
+                        if (kk < p.K) {
+                            const float sv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (co + j < p.Cout) p.dw[(size_t)(co + j) * p.K + kk] += sv[j];
+                        }
+                    }
+                }
+            }
+        };
+        reduce(grp * G, 1, gs, NG == 1);
+        if (NG == 1) return;
+        if (!arrive(cnt + NG, NG - 1)) return;
+        reduce(0, G, NG, true);
         return;
     }
     const int li = lane & 31, lh = lane >> 5;
@@ -469,6 +546,8 @@ constexpr int NOT_TAKEN = 1 << 20;     // launch(): the slabs would not fit the 
 int g_wgrad_pp_mode = 1;        // tuning hook (brcnn_conv_set_tile_wgrad_bf16(20 / 21 / 22)): never / heuristic / wherever the shape allows
 int g_wgrad_pp_slot_pct = 75;   // ... (4000 + n): n percent of the CUs per launch (the launches share the device with the main stream)
 int g_wgrad_pp_two_pass = 24;
+int g_wgrad_pp_fuse = 0;         // ... (30 / 31): slab reduction as separate launches / inside the producing launch.  Measured (r04_notes.md):
+                                 // the in-launch form costs ~70 us per launch (one workgroup pulling 1-3 MB is latency-bound) -> off
 int g_wgrad_pp_launches = 0;     // launches taken so far (tests: hook 29 returns and clears it)
 
 void magic_for(unsigned d, unsigned* magic, unsigned* shift) {
@@ -518,15 +597,28 @@ int launch(WgradPPParams& p, hipStream_t s) {
     }
     p.slice_m0[p.slices] = p.M;
     p.slab = nullptr;
+    p.fuse_group = 0;
+    p.ngroups = 0;
     if (p.slices > 1) {
         if ((size_t)tiles * p.slices * TILE * TILE * sizeof(float) > ((size_t)160 << 20)) return NOT_TAKEN;
         p.slab = conv_ws_wgrad_slabs(s);
         if (!p.slab) return BRCNN_EINVAL;
+        if (g_wgrad_pp_fuse) {      // groups of ~sqrt(slices): two serial passes of <= ~6 slabs each on the last arrivers
+            int group = 2;
+            while (group * group < p.slices) group++;
+            const int ngroups = (p.slices + group - 1) / group;
+            if ((long long)tiles * (ngroups + 1) <= 8192) {
+                p.counters = conv_ws_wgrad_counters(s);
+                if (!p.counters) return BRCNN_EINVAL;
+                p.fuse_group = group;
+                p.ngroups = ngroups;
+            }
+        }
     }
     g_wgrad_pp_launches++;
     hipLaunchKernelGGL((conv_wgrad_pp_bf16_kernel<ET, PLAIN>), dim3(tiles * p.slices), dim3(512), lds, s, p);
     BRCNN_LAUNCH_CHECK();
-    if (p.slab) {
+    if (p.slab && p.fuse_group == 0) {
         int stride = 1, count = p.slices;
         if (p.slices > g_wgrad_pp_two_pass) {
             int group = 4;
@@ -600,6 +692,7 @@ int wgrad_pp_bf16_try(const void* x, const void* dy, void* dw, int batch, int nu
 int wgrad_pp_set(int v) {
     if (v >= 20 && v <= 22) { g_wgrad_pp_mode = v - 20; return 0; }
     if (v == 29) { const int n = g_wgrad_pp_launches; g_wgrad_pp_launches = 0; return n; }
+    if (v == 30 || v == 31) { g_wgrad_pp_fuse = v - 30; return 0; }
     if (v >= 4010 && v <= 4400) { g_wgrad_pp_slot_pct = v - 4000; return 0; }
     if (v >= 5001 && v <= 5999) { g_wgrad_pp_two_pass = v - 5000; return 0; }
     return BRCNN_EINVAL;

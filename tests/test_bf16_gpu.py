@@ -805,15 +805,25 @@ def test_wgrad_eight_phase_kernel_against_fp64(cfg, et):
         return dw
     try:
         L.brcnn_conv_set_tile_wgrad_bf16(29)
+        L.brcnn_conv_set_tile_wgrad_bf16(31)    # slabs added inside the producing launch (last arriver of each slice group)
         new = run(22)                   # eight-phase kernel wherever the shape allows
         again = run(22)
         assert L.brcnn_conv_set_tile_wgrad_bf16(29) == 2        # ... and it was taken both times
+        for _ in range(30):             # whoever arrives last adds in the same order: same bits; counters back at zero
+            assert torch.equal(run(22), new)
+        L.brcnn_conv_set_tile_wgrad_bf16(29)
+        L.brcnn_conv_set_tile_wgrad_bf16(30)    # slabs added by separate launches
+        sep = run(22)
+        assert torch.equal(run(22), sep)
+        assert L.brcnn_conv_set_tile_wgrad_bf16(29) == 2
         old = run(20)                   # two-buffer kernel
         assert L.brcnn_conv_set_tile_wgrad_bf16(29) == 0
     finally:
         L.brcnn_conv_set_tile_wgrad_bf16(21)
+        L.brcnn_conv_set_tile_wgrad_bf16(30)
     m_total = sum(n * ho * wo for ho, wo in outs)
     tol = 3e-6 * (m_total ** 0.5) * float(ref.abs().max()) + 1e-6      # fp32 accumulation of M products, random signs
     assert float((new.double() - ref).abs().max()) <= tol, (float((new.double() - ref).abs().max()), tol)
     assert float((old.double() - ref).abs().max()) <= tol
+    assert float((sep.double() - ref).abs().max()) <= tol
     assert torch.equal(new, again)

@@ -1,6 +1,6 @@
 """interleaved A/B of the bf16 train step on ONE box: python tools/experiments/ab_train.py name=hook:arg[,hook:arg] ...
 hooks: wgrad (brcnn_conv_set_tile_wgrad_bf16), conv (brcnn_conv_set_tile_bf16), f32 (brcnn_conv_set_tile(-2, arg)),
-side (autograd.WGRAD_SIDE_STREAM), early (model.early_rpn_backward).  Example: tools/experiments/ab_train.py atomics=wgrad:10 slabs=wgrad:11"""
+side (autograd.WGRAD_SIDE_STREAM), early (model.early_rpn_backward), bn3 (autograd.FUSE_RESIDUAL_BN_BACKWARD).  Example: tools/experiments/ab_train.py atomics=wgrad:10 slabs=wgrad:11"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
@@ -38,6 +38,7 @@ def apply(spec):
         elif hook == 'f32': assert L.brcnn_conv_set_tile(-2, arg) == 0
         elif hook == 'side': A.WGRAD_SIDE_STREAM = bool(arg)
         elif hook == 'early': model.early_rpn_backward = bool(arg)
+        elif hook == 'bn3': A.FUSE_RESIDUAL_BN_BACKWARD = bool(arg)
         else: raise SystemExit(f'unknown hook {hook}')
 
 

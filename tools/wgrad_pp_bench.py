@@ -45,7 +45,7 @@ for name, N, lv, Ci, Co, k, st, pd, times in shapes:
     h = lib.stream_handle()
     line = f'{name:30s} M={M:7d} x{times}'
     ref = None
-    for label, hooks in [('two-buffer', [20])] + [(f'pp {p}%', [22, 4000 + p]) for p in pcts]:
+    for label, hooks in [('two-buffer', [20])] + [(f'pp {p}%{"" if f else " sep"}', [22, 4000 + p, 30 + f]) for p in pcts for f in (1, 0)]:
         for hk in hooks:
             assert L.brcnn_conv_set_tile_wgrad_bf16(hk) == 0
         dw = torch.zeros(Co, k, k, Ci, device='cuda')
