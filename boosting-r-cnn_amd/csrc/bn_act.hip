@@ -32,11 +32,7 @@ __device__ __forceinline__ void ldv(const bf16_t* p, float v[8]) {
         v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
     }
 }
-__device__ __forceinline__ unsigned f2bf(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned f2bf(float v) { return brcnn_f2b(v); }
 __device__ __forceinline__ void ldv(const f16_t* p, float v[8]) {
     const uint4 u = *reinterpret_cast<const uint4*>(p);
     const unsigned w[4] = {u.x, u.y, u.z, u.w};
@@ -48,10 +44,10 @@ __device__ __forceinline__ void ldv(const f16_t* p, float v[8]) {
 }
 __device__ __forceinline__ void stv(f16_t* p, const float v[8]) {
     uint4 u;
-    u.x = (unsigned)brcnn_f2h(v[0]) | ((unsigned)brcnn_f2h(v[1]) << 16);
-    u.y = (unsigned)brcnn_f2h(v[2]) | ((unsigned)brcnn_f2h(v[3]) << 16);
-    u.z = (unsigned)brcnn_f2h(v[4]) | ((unsigned)brcnn_f2h(v[5]) << 16);
-    u.w = (unsigned)brcnn_f2h(v[6]) | ((unsigned)brcnn_f2h(v[7]) << 16);
+    u.x = brcnn_pk2h(v[0], v[1]);
+    u.y = brcnn_pk2h(v[2], v[3]);
+    u.z = brcnn_pk2h(v[4], v[5]);
+    u.w = brcnn_pk2h(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void stv(float* p, const float v[4]) {
@@ -59,10 +55,10 @@ __device__ __forceinline__ void stv(float* p, const float v[4]) {
 }
 __device__ __forceinline__ void stv(bf16_t* p, const float v[8]) {
     uint4 u;
-    u.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
-    u.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
-    u.z = f2bf(v[4]) | (f2bf(v[5]) << 16);
-    u.w = f2bf(v[6]) | (f2bf(v[7]) << 16);
+    u.x = brcnn_pk2b(v[0], v[1]);
+    u.y = brcnn_pk2b(v[2], v[3]);
+    u.z = brcnn_pk2b(v[4], v[5]);
+    u.w = brcnn_pk2b(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = u;
 }
 

@@ -40,9 +40,19 @@ static inline bool brcnn_out_f32(int dt) { return dt == BRCNN_DT_BF16_OUT_F32 ||
 __device__ __forceinline__ float brcnn_h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ unsigned short brcnn_f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
 __device__ __forceinline__ float brcnn_b2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short brcnn_f2b(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// float -> 16 bit, round to nearest even: gfx950 has the conversions in hardware, two values per instruction
+// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32) -- one VALU operation per pair instead of the five of the integer form
+typedef __bf16 brcnn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 brcnn_f16x2 __attribute__((ext_vector_type(2)));
+typedef float brcnn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short brcnn_f2b(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// the pair (lo, hi) as one 32-bit word, lo in bits 0..15
+__device__ __forceinline__ unsigned brcnn_pk2b(float lo, float hi) {
+    const brcnn_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, brcnn_bf16x2));
+}
+__device__ __forceinline__ unsigned brcnn_pk2h(float lo, float hi) {
+    const brcnn_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, brcnn_f16x2));
 }
 #endif

@@ -110,8 +110,8 @@ int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s);
 // fills p.sk_*; p.sk_wgs = 0 when the plain one-tile-per-workgroup launch is the better one
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
 int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
-float* conv_ws_wgrad_slabs(hipStream_t s);
-unsigned* conv_ws_wgrad_counters(hipStream_t s);   // 8192 zero-initialised, self-resetting arrival counters     // the weight-gradient slab part of the stream's conv workspace (160 MiB)
+float* conv_ws_wgrad_slabs(hipStream_t s);          // the weight-gradient slab part of the stream's conv workspace (160 MiB)
+unsigned* conv_ws_wgrad_counters(hipStream_t s);   // 8192 zero-initialised, self-resetting arrival counters
 // eight-phase 256 x 256 weight gradient (conv_wgrad_pp_bf16.hip): 1 launched, 0 shape not taken, < 0 error
 int wgrad_pp_bf16_try(const void* x, const void* dy, void* dw, int batch, int num_segments, const int* heights_host,
                       const int* widths_host, int cin, int cout, int kh, int kw, int stride, int pad, hipStream_t stream,

@@ -949,14 +949,13 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
         }
         if (BF16 == 2) {
             uint2 u;
-            u.x = (unsigned)brcnn_f2h(v.x) | ((unsigned)brcnn_f2h(v.y) << 16);
+            u.x = brcnn_pk2h(v.x, v.y);
             u.y = (unsigned)brcnn_f2h(v.z);
             reinterpret_cast<uint2*>(out)[i] = u;
         } else if (BF16) {
-            auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
             uint2 u;
-            u.x = bf(v.x) | (bf(v.y) << 16);
-            u.y = bf(v.z);
+            u.x = brcnn_pk2b(v.x, v.y);
+            u.y = (unsigned)brcnn_f2b(v.z);
             reinterpret_cast<uint2*>(out)[i] = u;
         } else {
             reinterpret_cast<float4*>(out)[i] = v;

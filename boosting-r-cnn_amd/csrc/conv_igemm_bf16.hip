@@ -25,16 +25,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int BKE = 64;     // K tile in elements (128 bytes)
 
-__device__ __forceinline__ unsigned short f2bf(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float v) { return brcnn_f2b(v); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 // ET: element type of the 16-bit operands / result, 0 = bf16, 1 = IEEE fp16 (v_mfma_f32_32x32x16_f16); the
 // staging path moves bytes and is the same for both
 template <int ET> __device__ __forceinline__ float e2f(unsigned short h) { return ET ? brcnn_h2f(h) : bf2f(h); }
 template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { return ET ? brcnn_f2h(v) : f2bf(v); }
+template <int ET> __device__ __forceinline__ unsigned pk2e(float lo, float hi) { return ET ? brcnn_pk2h(lo, hi) : brcnn_pk2b(lo, hi); }
 
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
@@ -81,6 +78,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
     const int rg = lane >> 3, pc = lane & 7;
+    const bool plain = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && p.dilate <= 1;
     int a_base[AG], a_hw[AG], a_H[AG], a_W[AG], a_lc[AG];
     int b_off[BG];
 #pragma unroll
@@ -88,7 +86,13 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         const int r = (wave * AG + j) * 8 + rg;
         a_lc[j] = (pc ^ ((r >> 1) & 7)) * 8;          // logical k offset (elements) of this lane's chunk
         const int m = m0 + r;
-        if (m < p.M) {
+        if (plain) {
+            // a 1x1 stride-1 layer on one map reads row m of x for row m of the output: no map lookup, no divisions
+            // (the short-K layers of the backbone are VALU-bound, and this set-up was a fifth of their instructions)
+            a_base[j] = m < p.M ? (int)p.seg_xoff[0] + m * p.pitch : -1;
+            a_hw[j] = (4096 << 16) | 4096;
+            a_H[j] = a_W[j] = 1;
+        } else if (m < p.M) {
             int sg = 0;
 #pragma unroll
             for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
@@ -475,10 +479,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             if (vec_ok) {
                 if constexpr (DUAL) {
                     uint4 zq;
-                    zq.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
-                    zq.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
-                    zq.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
-                    zq.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    zq.x = pk2e<ET>(v[0], v[1]);
+                    zq.y = pk2e<ET>(v[2], v[3]);
+                    zq.z = pk2e<ET>(v[4], v[5]);
+                    zq.w = pk2e<ET>(v[6], v[7]);
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.z_out) + ro + co) = zq;
                     // the affine sees the STORED (rounded) z: bit-identical to the conv kernel followed by
                     // bn_act_fwd_kernel, and the mask the backward recomputes from z is the forward's own
@@ -531,10 +535,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                         v[e] = d * sc8[e];
                     }
                     uint4 dq;
-                    dq.x = f2e<ET>(d8[0]) | ((unsigned)f2e<ET>(d8[1]) << 16);
-                    dq.y = f2e<ET>(d8[2]) | ((unsigned)f2e<ET>(d8[3]) << 16);
-                    dq.z = f2e<ET>(d8[4]) | ((unsigned)f2e<ET>(d8[5]) << 16);
-                    dq.w = f2e<ET>(d8[6]) | ((unsigned)f2e<ET>(d8[7]) << 16);
+                    dq.x = pk2e<ET>(d8[0], d8[1]);
+                    dq.y = pk2e<ET>(d8[2], d8[3]);
+                    dq.z = pk2e<ET>(d8[4], d8[5]);
+                    dq.w = pk2e<ET>(d8[6], d8[7]);
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.tail_dres) + ro + co) = dq;
                 }
                 if (p.relu) {
@@ -547,10 +551,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
                     uint4 o;
-                    o.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
-                    o.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
-                    o.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
-                    o.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    o.x = pk2e<ET>(v[0], v[1]);
+                    o.y = pk2e<ET>(v[2], v[3]);
+                    o.z = pk2e<ET>(v[4], v[5]);
+                    o.w = pk2e<ET>(v[6], v[7]);
                     *reinterpret_cast<uint4*>(yh + ro + co) = o;
                 }
             } else {       // ragged channel count (fused heads: 54, 21): element-wise tail

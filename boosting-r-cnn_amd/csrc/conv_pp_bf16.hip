@@ -33,6 +33,7 @@ constexpr int SLOT = 16384;         // bytes of one half-tile slot: 128 rows x 1
 
 template <int ET> __device__ __forceinline__ float e2f(unsigned short h) { return ET ? brcnn_h2f(h) : brcnn_b2f(h); }
 template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { return ET ? brcnn_f2h(v) : brcnn_f2b(v); }
+template <int ET> __device__ __forceinline__ unsigned pk2e(float lo, float hi) { return ET ? brcnn_pk2h(lo, hi) : brcnn_pk2b(lo, hi); }
 
 template <int N> using ic = std::integral_constant<int, N>;
 
@@ -543,10 +544,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
             if (vec_ok) {
                 if constexpr (MODE == 1) {
                     uint4 zq;
-                    zq.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
-                    zq.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
-                    zq.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
-                    zq.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    zq.x = pk2e<ET>(v[0], v[1]);
+                    zq.y = pk2e<ET>(v[2], v[3]);
+                    zq.z = pk2e<ET>(v[4], v[5]);
+                    zq.w = pk2e<ET>(v[6], v[7]);
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.z_out) + ro + co) = zq;
                     const unsigned zw[4] = {zq.x, zq.y, zq.z, zq.w};
 #pragma unroll
@@ -586,10 +587,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
                     dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
                     uint4 o;
-                    o.x = f2e<ET>(v[0]) | ((unsigned)f2e<ET>(v[1]) << 16);
-                    o.y = f2e<ET>(v[2]) | ((unsigned)f2e<ET>(v[3]) << 16);
-                    o.z = f2e<ET>(v[4]) | ((unsigned)f2e<ET>(v[5]) << 16);
-                    o.w = f2e<ET>(v[6]) | ((unsigned)f2e<ET>(v[7]) << 16);
+                    o.x = pk2e<ET>(v[0], v[1]);
+                    o.y = pk2e<ET>(v[2], v[3]);
+                    o.z = pk2e<ET>(v[4], v[5]);
+                    o.w = pk2e<ET>(v[6], v[7]);
                     *reinterpret_cast<uint4*>(yh + ro + co) = o;
                 }
             } else {       // ragged channel count: element-wise tail (MODE 0 only: the host checks)

@@ -15,15 +15,11 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
-__device__ __forceinline__ unsigned f2bf(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned f2bf(float v) { return brcnn_f2b(v); }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = f2bf(v.x) | (f2bf(v.y) << 16);
-    u.y = f2bf(v.z) | (f2bf(v.w) << 16);
+    u.x = brcnn_pk2b(v.x, v.y);
+    u.y = brcnn_pk2b(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 __device__ __forceinline__ float4 ld4(const f16_t* p) {
@@ -33,8 +29,8 @@ __device__ __forceinline__ float4 ld4(const f16_t* p) {
 }
 __device__ __forceinline__ void st4(f16_t* p, float4 v) {
     uint2 u;
-    u.x = (unsigned)brcnn_f2h(v.x) | ((unsigned)brcnn_f2h(v.y) << 16);
-    u.y = (unsigned)brcnn_f2h(v.z) | ((unsigned)brcnn_f2h(v.w) << 16);
+    u.x = brcnn_pk2h(v.x, v.y);
+    u.y = brcnn_pk2h(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 // two adjacent channel quads as ONE 16-byte access of a 16-bit tensor (fp32: two 16-byte accesses)
@@ -49,8 +45,8 @@ __device__ __forceinline__ void ld8(const bf16_t* p, float4& a, float4& b) {
 }
 __device__ __forceinline__ void st8(bf16_t* p, float4 a, float4 b) {
     uint4 u;
-    u.x = f2bf(a.x) | (f2bf(a.y) << 16); u.y = f2bf(a.z) | (f2bf(a.w) << 16);
-    u.z = f2bf(b.x) | (f2bf(b.y) << 16); u.w = f2bf(b.z) | (f2bf(b.w) << 16);
+    u.x = brcnn_pk2b(a.x, a.y); u.y = brcnn_pk2b(a.z, a.w);
+    u.z = brcnn_pk2b(b.x, b.y); u.w = brcnn_pk2b(b.z, b.w);
     *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void ld8(const f16_t* p, float4& a, float4& b) {
@@ -62,10 +58,10 @@ __device__ __forceinline__ void ld8(const f16_t* p, float4& a, float4& b) {
 }
 __device__ __forceinline__ void st8(f16_t* p, float4 a, float4 b) {
     uint4 u;
-    u.x = (unsigned)brcnn_f2h(a.x) | ((unsigned)brcnn_f2h(a.y) << 16);
-    u.y = (unsigned)brcnn_f2h(a.z) | ((unsigned)brcnn_f2h(a.w) << 16);
-    u.z = (unsigned)brcnn_f2h(b.x) | ((unsigned)brcnn_f2h(b.y) << 16);
-    u.w = (unsigned)brcnn_f2h(b.z) | ((unsigned)brcnn_f2h(b.w) << 16);
+    u.x = brcnn_pk2h(a.x, a.y);
+    u.y = brcnn_pk2h(a.z, a.w);
+    u.z = brcnn_pk2h(b.x, b.y);
+    u.w = brcnn_pk2h(b.z, b.w);
     *reinterpret_cast<uint4*>(p) = u;
 }
 // one element from fp32 (weight packing)
@@ -135,10 +131,10 @@ __device__ __forceinline__ Vec8 ldv(const f16_t* p) {
 }
 __device__ __forceinline__ void stv(f16_t* p, const Vec8& m) {       // (max of fp16 values: exact, like bf16)
     uint4 u;
-    u.x = (unsigned)brcnn_f2h(m.v[0]) | ((unsigned)brcnn_f2h(m.v[1]) << 16);
-    u.y = (unsigned)brcnn_f2h(m.v[2]) | ((unsigned)brcnn_f2h(m.v[3]) << 16);
-    u.z = (unsigned)brcnn_f2h(m.v[4]) | ((unsigned)brcnn_f2h(m.v[5]) << 16);
-    u.w = (unsigned)brcnn_f2h(m.v[6]) | ((unsigned)brcnn_f2h(m.v[7]) << 16);
+    u.x = brcnn_pk2h(m.v[0], m.v[1]);
+    u.y = brcnn_pk2h(m.v[2], m.v[3]);
+    u.z = brcnn_pk2h(m.v[4], m.v[5]);
+    u.w = brcnn_pk2h(m.v[6], m.v[7]);
     *reinterpret_cast<uint4*>(p) = u;
 }
 __device__ __forceinline__ void stv(float* p, const Vec8& m) { *reinterpret_cast<float4*>(p) = make_float4(m.v[0], m.v[1], m.v[2], m.v[3]); }

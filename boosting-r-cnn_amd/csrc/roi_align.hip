@@ -24,15 +24,11 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
-__device__ __forceinline__ unsigned f2bf(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned f2bf(float v) { return brcnn_f2b(v); }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = f2bf(v.x) | (f2bf(v.y) << 16);
-    u.y = f2bf(v.z) | (f2bf(v.w) << 16);
+    u.x = brcnn_pk2b(v.x, v.y);
+    u.y = brcnn_pk2b(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 
@@ -43,8 +39,8 @@ __device__ __forceinline__ float4 ld4(const f16_t* p) {
 }
 __device__ __forceinline__ void st4(f16_t* p, float4 v) {
     uint2 u;
-    u.x = (unsigned)brcnn_f2h(v.x) | ((unsigned)brcnn_f2h(v.y) << 16);
-    u.y = (unsigned)brcnn_f2h(v.z) | ((unsigned)brcnn_f2h(v.w) << 16);
+    u.x = brcnn_pk2h(v.x, v.y);
+    u.y = brcnn_pk2h(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 
