@@ -102,6 +102,32 @@ __device__ __forceinline__ static long long out_row_offset(const ConvParams& p, 
     return (((long long)n * p.sc_H + 2 * a + p.sc_ph) * p.sc_W + 2 * b + p.sc_pw) * p.Cout;
 }
 
+// ---- straight-line read-out of a full output tile of the 16-bit kernels (conv_igemm_bf16.hip, conv_pp_bf16.hip) ----------
+// The short-K layers of the backbone are bound by VALU instructions, not by bytes or MFMA (PMC: 83 % of the SIMD cycles of
+// the 64 -> 64 layer were VALU), and most of those were the guards of the general read-out: a branch per scale / shift
+// element, bounds and scatter tests per row, 64-bit multiplies per address.  A tile that lies inside the output
+// (wave-uniform test) takes this form instead: vector loads of scale / shift, pointers advanced by a constant, packed fp32
+// multiplies / adds, the hardware conversions, ReLU as a packed signed-16-bit max on the converted pair (bf16 / fp16 are
+// sign-magnitude: max_i16 with 0 clears exactly the negative values; with -32768 it is the identity).  Same arithmetic per
+// element as the general form: both give the same bits.
+typedef short brcnn_i16x2 __attribute__((ext_vector_type(2)));
+template <int ET> __device__ __forceinline__ brcnn_f32x2 brcnn_unpk2(unsigned w) {
+    brcnn_f32x2 r;
+    if constexpr (ET) {
+        r.x = brcnn_h2f((unsigned short)(w & 0xffffu));
+        r.y = brcnn_h2f((unsigned short)(w >> 16));
+    } else {
+        r.x = __uint_as_float(w << 16);
+        r.y = __uint_as_float(w & 0xffff0000u);
+    }
+    return r;
+}
+template <int ET> __device__ __forceinline__ unsigned brcnn_pk2(brcnn_f32x2 v) { return ET ? brcnn_pk2h(v.x, v.y) : brcnn_pk2b(v.x, v.y); }
+__device__ __forceinline__ unsigned brcnn_relu_pk(unsigned w, unsigned floor2) {
+    const brcnn_i16x2 a = __builtin_bit_cast(brcnn_i16x2, w), f = __builtin_bit_cast(brcnn_i16x2, floor2);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, f));
+}
+
 // bf16 dispatch (conv_igemm_bf16.hip)
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s);
 // 256 x 256 tile on the eight-phase two-group schedule (conv_pp_bf16.hip)

@@ -481,6 +481,85 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (MODE <= 1 && !OUTF32) {
+        // the block tile lies inside the output (wave-uniform): the straight-line read-out (conv_common.h)
+        if (vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+            const size_t row0 = (size_t)(m0 + wm * 32 * MT + rl) * p.Cout + cw0 + cl;
+            unsigned short* __restrict__ yrow = reinterpret_cast<unsigned short*>(p.y) + row0;
+            unsigned short* __restrict__ zrow = reinterpret_cast<unsigned short*>(p.z_out) + row0;
+            const unsigned short* __restrict__ rrow = res + row0;
+            const unsigned floor2 = p.relu ? 0u : 0x80008000u;
+            brcnn_f32x2 scp[NT][4][2], shp[NT][4][2];
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int co = cw0 + tn * 32 + 8 * g + 4 * lh;
+                        const float4 a = p.scale ? *reinterpret_cast<const float4*>(p.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+                        const float4 b = p.shift ? *reinterpret_cast<const float4*>(p.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        scp[tn][g][0] = brcnn_f32x2{a.x, a.y}; scp[tn][g][1] = brcnn_f32x2{a.z, a.w};
+                        shp[tn][g][0] = brcnn_f32x2{b.x, b.y}; shp[tn][g][1] = brcnn_f32x2{b.z, b.w};
+                    }
+            }
+            brcnn_f32x2 sc8p[4], sh8p[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { sc8p[e] = brcnn_f32x2{sc8[2 * e], sc8[2 * e + 1]}; sh8p[e] = brcnn_f32x2{sh8[2 * e], sh8[2 * e + 1]}; }
+#pragma unroll
+            for (int tm = 0; tm < MT; tm++) {
+                uint4 rq[32 / RPI];
+                if (RES) {
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; it++)
+                        rq[it] = *reinterpret_cast<const uint4*>(rrow + (size_t)(tm * 32 + it * RPI) * p.Cout);
+                }
+#pragma unroll
+                for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        brcnn_f32x2 lo = {acc[tm][tn][4 * g + 0], acc[tm][tn][4 * g + 1]};
+                        brcnn_f32x2 hi = {acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]};
+                        if constexpr (MODE == 0) {
+                            lo = lo * scp[tn][g][0] + shp[tn][g][0];
+                            hi = hi * scp[tn][g][1] + shp[tn][g][1];
+                        } else {        // the general form's x * 1 + 0 (a -0 leaves as +0)
+                            lo = lo + brcnn_f32x2{0.f, 0.f};
+                            hi = hi + brcnn_f32x2{0.f, 0.f};
+                        }
+                        *reinterpret_cast<float4*>(cs + li * PITCH + tn * 32 + 8 * g + 4 * lh) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; it++) {
+                    const int row = it * RPI + rl;
+                    const float4 lo = *reinterpret_cast<const float4*>(cs + row * PITCH + cl);
+                    const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
+                    brcnn_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+                    const size_t off = (size_t)(tm * 32 + it * RPI) * p.Cout;
+                    if constexpr (MODE == 1) {
+                        const unsigned zw[4] = {brcnn_pk2<ET>(v[0]), brcnn_pk2<ET>(v[1]), brcnn_pk2<ET>(v[2]), brcnn_pk2<ET>(v[3])};
+                        *reinterpret_cast<uint4*>(zrow + off) = make_uint4(zw[0], zw[1], zw[2], zw[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = brcnn_unpk2<ET>(zw[e]) * sc8p[e] + sh8p[e];
+                    }
+                    if (RES) {
+                        const unsigned rr[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] += brcnn_unpk2<ET>(rr[e]);
+                    }
+                    uint4 o;
+                    o.x = brcnn_relu_pk(brcnn_pk2<ET>(v[0]), floor2);
+                    o.y = brcnn_relu_pk(brcnn_pk2<ET>(v[1]), floor2);
+                    o.z = brcnn_relu_pk(brcnn_pk2<ET>(v[2]), floor2);
+                    o.w = brcnn_relu_pk(brcnn_pk2<ET>(v[3]), floor2);
+                    *reinterpret_cast<uint4*>(yrow + off) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+    }
     float4 scv[NT][4], shv[NT][4];
     if constexpr (MODE == 0) {
 #pragma unroll
