@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 
     // ---- DMA assignment: wave w moves row groups w*AG+j; lane -> (row in group, physical chunk)
     const int rg = lane >> 3, pc = lane & 7;
+    const bool plain = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && p.dilate <= 1;
     int a_base[AG], a_hw[AG], a_H[AG], a_W[AG], a_lc[AG];
     int b_off[BG];
 #pragma unroll
@@ -317,7 +318,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
         const int r = (wave * AG + j) * 8 + rg;
         a_lc[j] = (pc ^ ((r >> 1) & 7)) * 4;          // logical k offset (floats) of this lane's chunk
         const int m = m0 + r;
-        if (m < p.M) {
+        if (plain) {
+            // a 1x1 stride-1 layer on one map reads row m of x for row m of the output: no map lookup, no divisions
+            a_base[j] = m < p.M ? (int)p.seg_xoff[0] + m * p.pitch : -1;
+            a_hw[j] = (4096 << 16) | 4096;
+            a_H[j] = a_W[j] = 1;
+        } else if (m < p.M) {
             int sg = 0;
 #pragma unroll
             for (int t = 1; t < BRCNN_MAX_LEVELS; t++)
@@ -405,7 +411,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     const bool vec = (p.Cout & 3) == 0;
     const int vrow = lane >> 3, vcol = (lane & 7) * 4;
     float rv[MT][NT][16];
+    // the block tile lies inside the output (wave-uniform): residual loads and the read-out without guards
+    const bool full = vec && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout;
+    const size_t row0 = (size_t)(m0 + wm * 32 * MT + vrow) * p.Cout + n0 + wn * 32 * NT + vcol;
     auto load_residual = [&]() {
+        if (full) {
+            const float* __restrict__ rrow = res + row0;
+#pragma unroll
+            for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+                for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+                    for (int it = 0; it < 4; it++) {
+                        const float4 q = *reinterpret_cast<const float4*>(rrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32);
+                        rv[tm][tn][4 * it + 0] = q.x; rv[tm][tn][4 * it + 1] = q.y;
+                        rv[tm][tn][4 * it + 2] = q.z; rv[tm][tn][4 * it + 3] = q.w;
+                    }
+            return;
+        }
 #pragma unroll
         for (int tn = 0; tn < NT; tn++) {
 #pragma unroll
@@ -508,6 +531,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     // of 16 scalar ones (the store tail is issue bound).
     float* __restrict__ yout = p.y;
     float* slab = (wave < 2 ? As + (cur ^ 1) * BM * 32 : Bs + (cur ^ 1) * BN * 32) + (wave & 1) * 1024;
+    if (full) {
+        // straight-line read-out (the short-K 1x1 layers spend as many SIMD cycles on VALU as on MFMA, most of them in the
+        // guards of the general form below): same arithmetic per element -- x * 1 is x, so the scale multiply is unconditional
+        float* __restrict__ yrow = yout + row0;
+#pragma unroll
+        for (int tn = 0; tn < NT; tn++) {
+            const int co = n0 + wn * 32 * NT + tn * 32 + li;
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < MT; tm++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[tm][tn][r] * sc + sh;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    float4 v = *reinterpret_cast<const float4*>(slab + (it * 8 + vrow) * 32 + vcol);
+                    if (RES) {
+                        v.x += rv[tm][tn][4 * it + 0]; v.y += rv[tm][tn][4 * it + 1];
+                        v.z += rv[tm][tn][4 * it + 2]; v.w += rv[tm][tn][4 * it + 3];
+                    }
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(yrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < NT; tn++) {
         const int co = n0 + wn * 32 * NT + tn * 32 + li;

@@ -451,6 +451,44 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     const int vrow = lane >> 3, vcol = (lane & 7) * 4;
     const float* __restrict__ res = p.residual;
     float* __restrict__ yout = p.y;
+    if ((p.Cout & 3) == 0 && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        // the block tile lies inside the output (wave-uniform): the same arithmetic without the guards, pointers advanced by
+        // constants (conv_igemm.hip has the measurement)
+        const size_t row0 = (size_t)(m0 + wm * 32 * MT + vrow) * p.Cout + n0 + wn * 32 * NT + vcol;
+        float* __restrict__ yrow = yout + row0;
+        const float* __restrict__ rrow = res + row0;
+#pragma unroll
+        for (int tn = 0; tn < NT; tn++) {
+            const int co = n0 + wn * 32 * NT + tn * 32 + li;
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < MT; tm++) {
+                float4 rv[4];
+                if (RES) {
+#pragma unroll
+                    for (int it = 0; it < 4; it++)
+                        rv[it] = *reinterpret_cast<const float4*>(rrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[tm][tn][r] * sc + sh;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    float4 v = *reinterpret_cast<const float4*>(slab + (it * 8 + vrow) * 32 + vcol);
+                    if (RES) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(yrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32) = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < NT; tn++) {
         const int co = n0 + wn * 32 * NT + tn * 32 + li;
