@@ -111,6 +111,7 @@ __device__ __forceinline__ static long long out_row_offset(const ConvParams& p, 
 // sign-magnitude: max_i16 with 0 clears exactly the negative values; with -32768 it is the identity).  Same arithmetic per
 // element as the general form: both give the same bits.
 typedef short brcnn_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float brcnn_relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 template <int ET> __device__ __forceinline__ brcnn_f32x2 brcnn_unpk2(unsigned w) {
     brcnn_f32x2 r;
     if constexpr (ET) {

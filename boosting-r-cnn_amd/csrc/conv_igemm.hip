@@ -363,8 +363,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     // K tiles are staged in order, so the filter tap (kh, kw) and the channel offset of the next
     // tile are carried as scalar state instead of being re-derived by two integer divisions
     int d_k0 = 0, d_ci0 = 0, d_kh = 0, d_kw = 0;
+    // plain (1x1 stride-1, one map) layers: the byte offset of every piece is its offset in K tile 0 plus 128 bytes per K
+    // tile -- one add per piece and tile instead of the tap / bounds arithmetic (a row beyond M starts at OOB and the sum
+    // stays beyond the buffer's extent: x and w are < 2 GiB)
+    unsigned a_off4[AG], b_off4[BG];
+#pragma unroll
+    for (int j = 0; j < AG; j++) a_off4[j] = a_base[j] >= 0 ? (unsigned)(a_base[j] + a_lc[j] + tile_n * p.gstep) * 4u : (unsigned)OOB;
+#pragma unroll
+    for (int j = 0; j < BG; j++) b_off4[j] = b_off[j] >= 0 ? (unsigned)b_off[j] * 4u : (unsigned)OOB;
+    unsigned d_plain = 0;
+    auto dma_tile_plain = [&](int buf) {
+        const unsigned step = d_plain;
+        d_plain += BK * 4;
+#pragma unroll
+        for (int j = 0; j < AG; j++) {
+            float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, (int)(a_off4[j] + step), 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BG; j++) {
+            float* dst = Bs + buf * BN * 32 + (wave * BG + j) * 8 * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)dst, 16, (int)(b_off4[j] + step), 0, 0, 0);
+        }
+    };
     auto dma_tile = [&](int kt, int buf) {
         (void)kt;
+        if (plain) { dma_tile_plain(buf); return; }
         // (channel chunk by channel chunk, the filter taps inside a chunk: see conv_pp_f32.hip; every fp32 kernel
         // visits K in this order, so their results stay bit-identical to each other)
         const int ci0 = d_ci0, kh = d_kh, kw = d_kw;
@@ -543,7 +567,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 #pragma unroll
             for (int tm = 0; tm < MT; tm++) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[tm][tn][r] * sc + sh;
+                for (int r = 0; r < 16; r += 2) {       // (v_pk_mul_f32 / v_pk_add_f32: two values per instruction)
+                    const brcnn_f32x2 a = brcnn_f32x2{acc[tm][tn][r], acc[tm][tn][r + 1]} * brcnn_f32x2{sc, sc} + brcnn_f32x2{sh, sh};
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = a.x;
+                    slab[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * 32 + li] = a.y;
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int it = 0; it < 4; it++) {
@@ -552,8 +580,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
                         v.x += rv[tm][tn][4 * it + 0]; v.y += rv[tm][tn][4 * it + 1];
                         v.z += rv[tm][tn][4 * it + 2]; v.w += rv[tm][tn][4 * it + 3];
                     }
-                    if (p.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    if (p.relu) {       // med3(v, 0, inf) = max(v, 0) in one instruction (fmaxf costs a canonicalising second one)
+                        v.x = brcnn_relu1(v.x); v.y = brcnn_relu1(v.y); v.z = brcnn_relu1(v.z); v.w = brcnn_relu1(v.w);
                     }
                     *reinterpret_cast<float4*>(yrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32) = v;
                 }

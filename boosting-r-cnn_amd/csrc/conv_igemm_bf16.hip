@@ -155,8 +155,19 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         d_next.k0 = (d_next.kh * p.KW + d_next.kw) * p.Cin + d_next.ci0;
         return t;
     };
+    // byte offsets of the pieces in K tile 0: the weight rows always, the input rows of a plain (1x1 stride-1, one map)
+    // layer -- one add per piece and K tile instead of the tap / bounds arithmetic (an absent row starts at OOB and the sum
+    // stays beyond the buffer's extent: x and w are < 2 GiB)
+    unsigned a_off2[AG], b_off2[BG];
+#pragma unroll
+    for (int j = 0; j < AG; j++) a_off2[j] = a_base[j] >= 0 ? (unsigned)(a_base[j] + a_lc[j] + tile_n * p.gstep) * 2u : (unsigned)OOB;
+#pragma unroll
+    for (int j = 0; j < BG; j++) b_off2[j] = b_off[j] >= 0 ? (unsigned)b_off[j] * 2u : (unsigned)OOB;
     auto dma_piece = [&](const TileK& t, int buf, int j) {
-        if (j < AG) {
+        if (j < AG && plain) {
+            float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, (int)(a_off2[j] + (unsigned)t.ci0 * 2u), 0, 0, 0);
+        } else if (j < AG) {
             int hi = (a_hw[j] >> 16) - 4096 + t.kh;
             int wi = (a_hw[j] & 0xffff) - 4096 + t.kw;
             bool ok = a_base[j] >= 0;
@@ -173,9 +184,8 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
         } else {
             const int jb = j - AG;
-            const int off = (b_off[jb] >= 0) ? (b_off[jb] + t.k0) * 2 : OOB;
             float* dst = Bs + buf * BN * 32 + (wave * BG + jb) * 8 * 32;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)dst, 16, (int)(b_off2[jb] + (unsigned)t.k0 * 2u), 0, 0, 0);
         }
     };
     auto dma_tile = [&](int kt, int buf) {

@@ -471,7 +471,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
                         rv[it] = *reinterpret_cast<const float4*>(rrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; r++) slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[tm][tn][r] * sc + sh;
+                for (int r = 0; r < 16; r += 2) {
+                    const brcnn_f32x2 a = brcnn_f32x2{acc[tm][tn][r], acc[tm][tn][r + 1]} * brcnn_f32x2{sc, sc} + brcnn_f32x2{sh, sh};
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = a.x;
+                    slab[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * 32 + li] = a.y;
+                }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
                     float4 v = *reinterpret_cast<const float4*>(slab + (it * 8 + vrow) * 32 + vcol);
                     if (RES) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
                     if (p.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        v.x = brcnn_relu1(v.x); v.y = brcnn_relu1(v.y); v.z = brcnn_relu1(v.z); v.w = brcnn_relu1(v.w);
                     }
                     *reinterpret_cast<float4*>(yrow + (size_t)(tm * 32 + it * 8) * p.Cout + tn * 32) = v;
                 }
