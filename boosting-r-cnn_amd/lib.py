@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libbrcnn_hip.so')
+# (BRCNN_LIB_PATH: a development switch -- tools/experiments/ab_lib.sh times two builds of the library on one box)
+LIB_PATH = os.environ.get('BRCNN_LIB_PATH') or os.path.join(_HERE, 'lib', 'libbrcnn_hip.so')
 _lib = None
 
 c_int, c_i64, c_f32, c_f64, c_ptr, c_size = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
