@@ -102,6 +102,24 @@ __device__ __forceinline__ static long long out_row_offset(const ConvParams& p, 
     return (((long long)n * p.sc_H + 2 * a + p.sc_ph) * p.sc_W + 2 * b + p.sc_pw) * p.Cout;
 }
 
+// zero-stuffed input (the data gradient of a strided conv reads dy with `dilate` - 1 zeros between its pixels): coordinate
+// (hi, wi) of the stuffed map -> the dy pixel, `ok` cleared where a stuffed zero is addressed.  The model only strides by
+// 2: a shift and a mask per piece and K tile; other strides pay the two integer divisions (~30 VALU instructions each --
+// the stride-2 3x3 data gradients spent 44 % of their SIMD cycles on VALU with them).
+__device__ __forceinline__ void brcnn_undilate(int dilate, int& hi, int& wi, bool& ok) {
+    ok = ok & (hi >= 0) & (wi >= 0);
+    if (dilate == 2) {
+        ok = ok & (((hi | wi) & 1) == 0);
+        hi >>= 1;
+        wi >>= 1;
+    } else {
+        const int qh = hi / dilate, qw = wi / dilate;
+        ok = ok & (qh * dilate == hi) & (qw * dilate == wi);
+        hi = qh;
+        wi = qw;
+    }
+}
+
 // ---- straight-line read-out of a full output tile of the 16-bit kernels (conv_igemm_bf16.hip, conv_pp_bf16.hip) ----------
 // The short-K layers of the backbone are bound by VALU instructions, not by bytes or MFMA (PMC: 83 % of the SIMD cycles of
 // the 64 -> 64 layer were VALU), and most of those were the guards of the general read-out: a branch per scale / shift

@@ -126,11 +126,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_igemm_f32_kernel(ConvParams 
                 int wi = (a_hw[j] & 0xffff) - 4096 + kw;
                 bool ok = a_base[j] >= 0;
                 if (p.dilate > 1) {      // zero-stuffed input: only multiples of `dilate` exist
-                    ok = ok & (hi >= 0) & (wi >= 0);
-                    const int qh = hi / p.dilate, qw = wi / p.dilate;
-                    ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
-                    hi = qh;
-                    wi = qw;
+                    brcnn_undilate(p.dilate, hi, wi, ok);
                 }
                 ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
                 const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci) * 4 : OOB;
@@ -404,11 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
             int wi = (a_hw[j] & 0xffff) - 4096 + kw;
             bool ok = a_base[j] >= 0;
             if (p.dilate > 1) {
-                ok = ok & (hi >= 0) & (wi >= 0);
-                const int qh = hi / p.dilate, qw = wi / p.dilate;
-                ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
-                hi = qh;
-                wi = qw;
+                brcnn_undilate(p.dilate, hi, wi, ok);
             }
             ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
             const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + ci0 + a_lc[j] + tile_n * p.gstep) * 4 : OOB;

@@ -172,11 +172,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             int wi = (a_hw[j] & 0xffff) - 4096 + t.kw;
             bool ok = a_base[j] >= 0;
             if (p.dilate > 1) {      // zero-stuffed input (data gradient of a strided conv)
-                ok = ok & (hi >= 0) & (wi >= 0);
-                const int qh = hi / p.dilate, qw = wi / p.dilate;
-                ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
-                hi = qh;
-                wi = qw;
+                brcnn_undilate(p.dilate, hi, wi, ok);
             }
             ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
             const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + t.ci0 + a_lc[j] + tile_n * p.gstep) * 2 : OOB;
@@ -515,6 +511,94 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             return;
         }
     }
+    bool done = false;
+    if constexpr (MODE >= 2 && !OUTF32) {
+        // ... and of the data-gradient launches that run a BatchNorm backward (the same arithmetic per element and the same
+        // order of the per-channel sums as the general form below)
+        if (vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+            const size_t row0 = (size_t)(m0 + wm * 32 * MT + rl) * p.Cout + cw0 + cl;
+            unsigned short* __restrict__ yrow = reinterpret_cast<unsigned short*>(p.y) + row0;
+            unsigned short* __restrict__ drow = reinterpret_cast<unsigned short*>(p.tail_dres) + row0;
+            const unsigned floor2 = p.relu ? 0u : 0x80008000u;
+            const bool mask_on = p.tail_relu != 0;
+            brcnn_f32x2 sc8p[4], sh8p[4], sdz[4], sd[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sc8p[e] = brcnn_f32x2{sc8[2 * e], sc8[2 * e + 1]}; sh8p[e] = brcnn_f32x2{sh8[2 * e], sh8[2 * e + 1]};
+                sdz[e] = brcnn_f32x2{0.f, 0.f}; sd[e] = brcnn_f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int tm = 0; tm < MT; tm++) {
+#pragma unroll
+                for (int tn = 0; tn < NT; tn++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const brcnn_f32x2 lo = brcnn_f32x2{acc[tm][tn][4 * g + 0], acc[tm][tn][4 * g + 1]} + brcnn_f32x2{0.f, 0.f};
+                        const brcnn_f32x2 hi = brcnn_f32x2{acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]} + brcnn_f32x2{0.f, 0.f};
+                        *reinterpret_cast<float4*>(cs + li * PITCH + tn * 32 + 8 * g + 4 * lh) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; it++) {
+                    const int row = it * RPI + rl;
+                    const float4 lo = *reinterpret_cast<const float4*>(cs + row * PITCH + cl);
+                    const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
+                    brcnn_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+                    const size_t off = (size_t)(tm * 32 + it * RPI) * p.Cout;
+                    if constexpr (MODE == 2) {
+                        const unsigned zw[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const brcnn_f32x2 zz = brcnn_unpk2<ET>(zw[e]);
+                            const brcnn_f32x2 g = brcnn_unpk2<ET>(brcnn_pk2<ET>(v[e]));
+                            const brcnn_f32x2 pre = zz * sc8p[e] + sh8p[e];
+                            brcnn_f32x2 d;
+                            d.x = (!mask_on || pre.x > 0.f) ? g.x : 0.f;
+                            d.y = (!mask_on || pre.y > 0.f) ? g.y : 0.f;
+                            sdz[e] += d * zz;
+                            sd[e] += d;
+                            v[e] = d * sc8p[e];
+                        }
+                    } else {
+                        const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
+                        const unsigned zw[4] = {rq2[tm][it].x, rq2[tm][it].y, rq2[tm][it].z, rq2[tm][it].w};
+                        const unsigned ow[4] = {rq3[tm][it].x, rq3[tm][it].y, rq3[tm][it].z, rq3[tm][it].w};
+                        unsigned dq[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (RES) v[e] += brcnn_unpk2<ET>(rr[e]);
+                            const brcnn_f32x2 zz = brcnn_unpk2<ET>(zw[e]);
+                            const brcnn_f32x2 oo = brcnn_unpk2<ET>(ow[e]);
+                            const brcnn_f32x2 g = brcnn_unpk2<ET>(brcnn_pk2<ET>(v[e]));
+                            brcnn_f32x2 d;
+                            d.x = (!mask_on || oo.x > 0.f) ? g.x : 0.f;
+                            d.y = (!mask_on || oo.y > 0.f) ? g.y : 0.f;
+                            sdz[e] += d * zz;
+                            sd[e] += d;
+                            dq[e] = brcnn_pk2<ET>(d);
+                            v[e] = d * sc8p[e];
+                        }
+                        *reinterpret_cast<uint4*>(drow + off) = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+                    }
+                    uint4 o;
+                    o.x = brcnn_relu_pk(brcnn_pk2<ET>(v[0]), floor2);
+                    o.y = brcnn_relu_pk(brcnn_pk2<ET>(v[1]), floor2);
+                    o.z = brcnn_relu_pk(brcnn_pk2<ET>(v[2]), floor2);
+                    o.w = brcnn_relu_pk(brcnn_pk2<ET>(v[3]), floor2);
+                    *reinterpret_cast<uint4*>(yrow + off) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sum_dz[2 * e] = sdz[e].x; sum_dz[2 * e + 1] = sdz[e].y;
+                sum_d[2 * e] = sd[e].x; sum_d[2 * e + 1] = sd[e].y;
+            }
+            done = true;
+        }
+    }
+    if (!done) {
     float4 scv[NT][4], shv[NT][4];
 #pragma unroll
     for (int tn = 0; tn < NT; tn++)
@@ -654,6 +738,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
         }
         __builtin_amdgcn_wave_barrier();
     }
+    }   // !done
     if constexpr (MODE >= 2) {
         // lanes that share the channel vector (equal lane % LPR) hold different rows: butterfly over the
         // row bits, then the WM waves of one channel range add up through their slabs in a fixed order

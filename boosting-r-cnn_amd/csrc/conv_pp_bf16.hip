@@ -169,11 +169,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
         for (int j = 0; j < 2; j++) {
             int hi = (a_hw[h][j] >> 16) - 4096 + tA_kh;
             int wi = (a_hw[h][j] & 0xffff) - 4096 + tA_kw;
-            bool ok = valid & (a_mask[h][j] != 0u) & (hi >= 0) & (wi >= 0);
-            const int qh = hi / p.dilate, qw = wi / p.dilate;
-            ok = ok & (qh * p.dilate == hi) & (qw * p.dilate == wi);
-            hi = qh;
-            wi = qw;
+            bool ok = valid & (a_mask[h][j] != 0u);
+            brcnn_undilate(p.dilate, hi, wi, ok);
             const int H = a_HW[h][j] >> 16, W = a_HW[h][j] & 0xffff;
             ok = ok & ((unsigned)hi < (unsigned)H) & ((unsigned)wi < (unsigned)W);
             const int off = ok ? (a_off[h][j] + (hi * W + wi) * p.pitch + tA_ci0 + lc[j] + tile_n * p.gstep) * 2 : OOB;
