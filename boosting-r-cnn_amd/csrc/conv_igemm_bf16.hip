@@ -232,6 +232,23 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(MODE == 2 ? p.tail_z : (const void*)p.residual);
     static_assert(!RES || MT * (32 / RPI) <= 16, "residual prefetch registers: use the non-residual form for 4x4 register tiles");
     uint4 rq[MT][32 / RPI];
+    // MODE 0, tile inside the output: scale / shift of the lane's 8 read-out channels are requested here, in front of the
+    // K loop, and applied behind the LDS transposition -- on the one- and two-tile K loops of the 1x1 layers the load was a
+    // second full memory latency between the last MFMA and the first store
+    const bool full_tile = vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout;
+    float4 pre_sc[2], pre_sh[2];
+    pre_sc[0] = pre_sc[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+    pre_sh[0] = pre_sh[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_pre = [&]() {
+        if (p.scale) { pre_sc[0] = *reinterpret_cast<const float4*>(p.scale + cw0 + cl); pre_sc[1] = *reinterpret_cast<const float4*>(p.scale + cw0 + cl + 4); }
+        if (p.shift) { pre_sh[0] = *reinterpret_cast<const float4*>(p.shift + cw0 + cl); pre_sh[1] = *reinterpret_cast<const float4*>(p.shift + cw0 + cl + 4); }
+    };
+    // (early only where registers are free: not on the 16-wave tiles with 128 VGPRs per lane, and not next to the residual
+    // prefetch -- measured: with both, the residual layers lose more occupancy than the latency is worth, 89 -> 103 us)
+    constexpr bool PRE_EARLY = WM * WNW < 16 && !RES;
+    if constexpr (MODE == 0 && !OUTF32 && PRE_EARLY) {
+        if (full_tile && finish) load_pre();
+    }
     // MODE 3: two more tiles, the producer's z and its output (the ReLU mask); they are requested at the start of
     // the epilogue (behind the K loop, whose fragment registers they would otherwise compete with: 135 VGPRs and one
     // workgroup per CU instead of two) and arrive while the affine vectors are derived and the first slab is written
@@ -440,27 +457,22 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     }
     if constexpr (MODE <= 1 && !OUTF32) {
         // the block tile lies inside the output (wave-uniform): the straight-line read-out (conv_common.h)
-        if (vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        if (full_tile) {
             const size_t row0 = (size_t)(m0 + wm * 32 * MT + rl) * p.Cout + cw0 + cl;
             unsigned short* __restrict__ yrow = reinterpret_cast<unsigned short*>(p.y) + row0;
             unsigned short* __restrict__ zrow = reinterpret_cast<unsigned short*>(p.z_out) + row0;
             const unsigned floor2 = p.relu ? 0u : 0x80008000u;
-            brcnn_f32x2 scp[NT][4][2], shp[NT][4][2];
-            if constexpr (MODE == 0) {
-#pragma unroll
-                for (int tn = 0; tn < NT; tn++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int co = cw0 + tn * 32 + 8 * g + 4 * lh;
-                        const float4 a = p.scale ? *reinterpret_cast<const float4*>(p.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
-                        const float4 b = p.shift ? *reinterpret_cast<const float4*>(p.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        scp[tn][g][0] = brcnn_f32x2{a.x, a.y}; scp[tn][g][1] = brcnn_f32x2{a.z, a.w};
-                        shp[tn][g][0] = brcnn_f32x2{b.x, b.y}; shp[tn][g][1] = brcnn_f32x2{b.z, b.w};
-                    }
-            }
             brcnn_f32x2 sc8p[4], sh8p[4];
+            if constexpr (MODE == 0) {      // (the prefetched vectors; applied in the read-out layout: the same products and sums)
+                if constexpr (!PRE_EARLY) load_pre();
+                sc8p[0] = brcnn_f32x2{pre_sc[0].x, pre_sc[0].y}; sc8p[1] = brcnn_f32x2{pre_sc[0].z, pre_sc[0].w};
+                sc8p[2] = brcnn_f32x2{pre_sc[1].x, pre_sc[1].y}; sc8p[3] = brcnn_f32x2{pre_sc[1].z, pre_sc[1].w};
+                sh8p[0] = brcnn_f32x2{pre_sh[0].x, pre_sh[0].y}; sh8p[1] = brcnn_f32x2{pre_sh[0].z, pre_sh[0].w};
+                sh8p[2] = brcnn_f32x2{pre_sh[1].x, pre_sh[1].y}; sh8p[3] = brcnn_f32x2{pre_sh[1].z, pre_sh[1].w};
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) { sc8p[e] = brcnn_f32x2{sc8[2 * e], sc8[2 * e + 1]}; sh8p[e] = brcnn_f32x2{sh8[2 * e], sh8[2 * e + 1]}; }
+                for (int e = 0; e < 4; e++) { sc8p[e] = brcnn_f32x2{sc8[2 * e], sc8[2 * e + 1]}; sh8p[e] = brcnn_f32x2{sh8[2 * e], sh8[2 * e + 1]}; }
+            }
 #pragma unroll
             for (int tm = 0; tm < MT; tm++) {
 #pragma unroll
@@ -469,10 +481,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     for (int g = 0; g < 4; g++) {
                         brcnn_f32x2 lo = {acc[tm][tn][4 * g + 0], acc[tm][tn][4 * g + 1]};
                         brcnn_f32x2 hi = {acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]};
-                        if constexpr (MODE == 0) {
-                            lo = lo * scp[tn][g][0] + shp[tn][g][0];
-                            hi = hi * scp[tn][g][1] + shp[tn][g][1];
-                        } else {        // the general form's x * 1 + 0 (a -0 leaves as +0)
+                        if constexpr (MODE != 0) {        // the general form's x * 1 + 0 (a -0 leaves as +0)
                             lo = lo + brcnn_f32x2{0.f, 0.f};
                             hi = hi + brcnn_f32x2{0.f, 0.f};
                         }
@@ -487,6 +496,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
                     const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
                     brcnn_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
                     const size_t off = (size_t)(tm * 32 + it * RPI) * p.Cout;
+                    if constexpr (MODE == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] * sc8p[e] + sh8p[e];
+                    }
                     if constexpr (DUAL) {
                         // the affine sees the STORED (rounded) z, as in the general form
                         const unsigned zw[4] = {brcnn_pk2<ET>(v[0]), brcnn_pk2<ET>(v[1]), brcnn_pk2<ET>(v[2]), brcnn_pk2<ET>(v[3])};
@@ -515,7 +528,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     if constexpr (MODE >= 2 && !OUTF32) {
         // ... and of the data-gradient launches that run a BatchNorm backward (the same arithmetic per element and the same
         // order of the per-channel sums as the general form below)
-        if (vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        if (full_tile) {
             const size_t row0 = (size_t)(m0 + wm * 32 * MT + rl) * p.Cout + cw0 + cl;
             unsigned short* __restrict__ yrow = reinterpret_cast<unsigned short*>(p.y) + row0;
             unsigned short* __restrict__ drow = reinterpret_cast<unsigned short*>(p.tail_dres) + row0;
