@@ -75,6 +75,7 @@ struct ConvParams {
     unsigned* sk_err;
     int sk_spin_limit;
     int sk_drop_publish;             // test hook (brcnn_conv_set_tile_bf16(-11)): heads do not publish
+    int no_fast;                     // test hook (brcnn_conv_set_tile(-4, 1)): the general set-up and read-out everywhere
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
     int seg_m0[BRCNN_MAX_LEVELS + 1];

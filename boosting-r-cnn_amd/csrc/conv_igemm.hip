@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
 
     // ---- DMA assignment: wave w moves row groups w*AG+j; lane -> (row in group, physical chunk)
     const int rg = lane >> 3, pc = lane & 7;
-    const bool plain = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && p.dilate <= 1;
+    const bool plain = !p.no_fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && p.dilate <= 1;
     int a_base[AG], a_hw[AG], a_H[AG], a_W[AG], a_lc[AG];
     int b_off[BG];
 #pragma unroll
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_dma_kernel(ConvParams p
     const int vrow = lane >> 3, vcol = (lane & 7) * 4;
     float rv[MT][NT][16];
     // the block tile lies inside the output (wave-uniform): residual loads and the read-out without guards
-    const bool full = vec && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout;
+    const bool full = !p.no_fast && vec && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout;
     const size_t row0 = (size_t)(m0 + wm * 32 * MT + vrow) * p.Cout + n0 + wn * 32 * NT + vcol;
     auto load_residual = [&]() {
         if (full) {
@@ -675,6 +675,7 @@ int launch_res(const ConvParams& p, hipStream_t s) {
 int g_use_dma = 1;                      // LDS-DMA staged kernel for the FAST path
 int g_force_wm = 0, g_force_nt = 0;   // tuning hooks (brcnn_conv_set_tile): 0 = heuristic
 
+int g_no_fast = 0;          // test hook (brcnn_conv_set_tile(-4, 0 / 1)): 1 = no straight-line read-out, no plain-layer set-up (every kernel, every dtype)
 int g_pp_f32_n128 = 1;      // tuning hook (brcnn_conv_set_tile(-3, 0 / 1 / 2)): the 256 x 128 eight-phase tile never / heuristic / forced
 int g_pp_f32_mode = 1;      // tuning hook (brcnn_conv_set_tile(-2, 0 / 1 / 2 / 128 / 256)): eight-phase fp32 kernel never / heuristic / forced (tile rows by the heuristic / 128 / 256)
 
@@ -743,6 +744,7 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
     if (wm == -1) { g_use_dma = nt; return 0; }   // (-1, 0/1/2): register-staged / heuristic / always LDS-DMA
     if (wm == -3) { if (nt < 0 || nt > 2) return BRCNN_EINVAL; g_pp_f32_n128 = nt; return 0; }
+    if (wm == -4) { if (nt != 0 && nt != 1) return BRCNN_EINVAL; g_no_fast = nt; return 0; }
     if (wm == -2) { if (nt != 0 && nt != 1 && nt != 2 && nt != 128 && nt != 256) return BRCNN_EINVAL; g_pp_f32_mode = nt; return 0; }
     if ((wm != 0 && wm != 1 && wm != 2 && wm != 4) || nt < 0 || nt > 2) return BRCNN_EINVAL;
     g_force_wm = wm;
@@ -786,6 +788,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     if (dilate > 1 && (cin % 32 != 0 || stride != 1)) return BRCNN_EINVAL;
     if (bf16 && (cout & 7) && !brcnn_out_f32(dtype) && residual) return BRCNN_EINVAL;
     ConvParams p = {};
+    p.no_fast = g_no_fast;
     p.x = (const float*)x; p.w = (const float*)w; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
     p.batch = batch; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
@@ -924,6 +927,7 @@ static int grouped_launch(const void* x, const void* w_tiles, const float* scale
     const int esz = dtype == BRCNN_DT_F32 ? 4 : 2;
     if (Ho <= 0 || Wo <= 0 || Ho >= 4096 || Wo >= 4096) return BRCNN_EINVAL;
     ConvParams p = {};
+    p.no_fast = g_no_fast;
     p.x = (const float*)x; p.w = (const float*)w_tiles; p.scale = scale; p.shift = shift;
     p.residual = (const float*)residual; p.y = (float*)y;
     p.batch = batch; p.Cin = window; p.Cout = cout; p.KH = kh; p.KW = kw;

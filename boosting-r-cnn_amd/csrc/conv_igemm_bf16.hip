@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
     const int rg = lane >> 3, pc = lane & 7;
-    const bool plain = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && p.dilate <= 1;
+    const bool plain = !p.no_fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && p.dilate <= 1;
     int a_base[AG], a_hw[AG], a_H[AG], a_W[AG], a_lc[AG];
     int b_off[BG];
 #pragma unroll
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
     // MODE 0, tile inside the output: scale / shift of the lane's 8 read-out channels are requested here, in front of the
     // K loop, and applied behind the LDS transposition -- on the one- and two-tile K loops of the 1x1 layers the load was a
     // second full memory latency between the last MFMA and the first store
-    const bool full_tile = vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout;
+    const bool full_tile = !p.no_fast && vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout;
     float4 pre_sc[2], pre_sh[2];
     pre_sc[0] = pre_sc[1] = make_float4(1.f, 1.f, 1.f, 1.f);
     pre_sh[0] = pre_sh[1] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_bf16_kernel(ConvParams p) {
     }
     if constexpr (MODE <= 1 && !OUTF32) {
         // the block tile lies inside the output (wave-uniform): the straight-line read-out (conv_common.h)
-        if (vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        if (!p.no_fast && vec_ok && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
             const size_t row0 = (size_t)(m0 + wm * 32 * MT + rl) * p.Cout + cw0 + cl;
             unsigned short* __restrict__ yrow = reinterpret_cast<unsigned short*>(p.y) + row0;
             unsigned short* __restrict__ zrow = reinterpret_cast<unsigned short*>(p.z_out) + row0;

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_f32_kernel(ConvParams p) {
     const int vrow = lane >> 3, vcol = (lane & 7) * 4;
     const float* __restrict__ res = p.residual;
     float* __restrict__ yout = p.y;
-    if ((p.Cout & 3) == 0 && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+    if (!p.no_fast && (p.Cout & 3) == 0 && !p.scatter && m0 + BM <= p.M && n0 + BN <= p.Cout) {
         // the block tile lies inside the output (wave-uniform): the same arithmetic without the guards, pointers advanced by
         // constants (conv_igemm.hip has the measurement)
         const size_t row0 = (size_t)(m0 + wm * 32 * MT + vrow) * p.Cout + n0 + wn * 32 * NT + vcol;

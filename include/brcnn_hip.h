@@ -267,7 +267,9 @@ int brcnn_conv_handover_status(void);
  * staging.  (-2, 0 / 1 / 2 / 128 / 256): the eight-phase fp32 kernel (csrc/conv_pp_f32.hip: 256- or
  * 128-row x 256-column tiles, two wave groups alternating MFMA and load blocks, chained stream-K) never /
  * by the heuristic / forced, forced with 128- / 256-row tiles.  (-3, 0 / 1 / 2): its 256 x 128 form for layers with 128
- * output channels never / by the heuristic / forced.  Every choice gives the same bits. */
+ * output channels never / by the heuristic / forced.  (-4, 0 / 1): test hook -- 1 = every conv launch (all dtypes) takes the
+ * general set-up and read-out instead of the straight-line forms of full tiles and plain 1x1 layers.  Every choice gives the
+ * same bits. */
 int brcnn_conv_set_tile(int wm, int nt);
 
 /* Tuning hook of the bf16 kernel: 0 heuristic; 11 / 21 / 22 = 64x64 / 128x64 / 128x128 tile on

@@ -827,3 +827,60 @@ def test_wgrad_eight_phase_kernel_against_fp64(cfg, et):
     assert float((old.double() - ref).abs().max()) <= tol
     assert float((sep.double() - ref).abs().max()) <= tol
     assert torch.equal(new, again)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_straight_line_readout_and_plain_setup_keep_the_bits(dtype):
+    """round 4: tiles inside the output take a read-out without guards (vector scale / shift loads, packed fp32 math,
+    hardware conversions, packed-int16 ReLU), 1x1 stride-1 layers a set-up without the map decode.  With the test hook
+    brcnn_conv_set_tile(-4, 1) every launch takes the general forms instead: same bits -- inference layers (scale /
+    shift / residual / ReLU, 1x1 and 3x3, full and ragged tiles, stride 2), and a whole training stage (dual store,
+    the BatchNorm backward inside the data-gradient launches with and without the residual producer, stride-2 data
+    gradients)."""
+    from brcnn import lib, autograd as A
+    from brcnn.backbones import Bottleneck, ResLayer
+    L = lib.load()
+    g = torch.Generator().manual_seed(5)
+
+    def layers():
+        outs = []
+        for (n, h, w, ci, co, k, st, res, relu) in [(4, 32, 64, 64, 256, 1, 1, True, True), (2, 50, 84, 256, 64, 1, 1, False, True),
+                                                    (2, 33, 41, 128, 512, 1, 1, True, False), (2, 32, 32, 128, 128, 3, 1, False, True),
+                                                    (2, 32, 32, 256, 256, 3, 2, False, False), (1, 64, 64, 512, 256, 1, 1, False, False)]:
+            x = torch.randn(n, h, w, ci, generator=g).to(dtype).to(DEV)
+            wt = (torch.randn(co, k, k, ci, generator=g) * 0.05).to(dtype).to(DEV)
+            sc = (torch.rand(co, generator=g) + 0.5).to(DEV); sh = torch.randn(co, generator=g).to(DEV)
+            ho, wo = ops.conv_out_size(h, w, k, k, st, k // 2)
+            r = torch.randn(n, ho, wo, co, generator=g).to(dtype).to(DEV) if res else None
+            outs.append(ops.conv2d_nhwc(x, wt, scale=sc, shift=sh, residual=r, relu=relu, stride=st, pad=k // 2))
+        return outs
+
+    def stage():
+        if dtype == torch.float32:
+            return []
+        torch.manual_seed(11)
+        layer = ResLayer(Bottleneck, 256, 128, 3, 2).to(DEV)
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+        layer.eval()
+        x = torch.randn(4, 64, 64, 256, device=DEV, generator=torch.Generator(DEV).manual_seed(2)).to(dtype).requires_grad_()
+        out = layer.forward_nhwc(x)
+        out.backward(torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(dtype))
+        return [out.detach(), x.grad] + [p.grad for _, p in sorted(layer.named_parameters()) if p.dim() == 1]
+
+    saved = A.WGRAD_SIDE_STREAM
+    try:
+        A.WGRAD_SIDE_STREAM = False
+        g.manual_seed(5)
+        fast = layers() + stage()
+        assert L.brcnn_conv_set_tile(-4, 1) == 0
+        g.manual_seed(5)
+        general = layers() + stage()
+    finally:
+        L.brcnn_conv_set_tile(-4, 0)
+        A.WGRAD_SIDE_STREAM = saved
+    assert len(fast) == len(general)
+    for i, (a, b) in enumerate(zip(fast, general)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
