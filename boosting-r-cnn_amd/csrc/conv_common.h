@@ -75,6 +75,7 @@ struct ConvParams {
     unsigned* sk_err;
     int sk_spin_limit;
     int sk_drop_publish;             // test hook (brcnn_conv_set_tile_bf16(-11)): heads do not publish
+    int st_strips;                   // conv1x1_stream_bf16.hip: row strips per column block
     int no_fast;                     // test hook (brcnn_conv_set_tile(-4, 1)): the general set-up and read-out everywhere
     // segment s covers output rows [seg_m0[s], seg_m0[s+1]) with its own geometry / input offset
     int nseg;
@@ -148,6 +149,9 @@ __device__ __forceinline__ unsigned brcnn_relu_pk(unsigned w, unsigned floor2) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, f));
 }
 
+// persistent streaming kernel of the short-K plain 1x1 layers (conv1x1_stream_bf16.hip): 1 launched, 0 not taken, < 0 error
+int conv1x1_stream_try(ConvParams& p, hipStream_t s, int f16);
+int conv1x1_stream_set(int mode);
 // bf16 dispatch (conv_igemm_bf16.hip)
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s);
 // 256 x 256 tile on the eight-phase two-group schedule (conv_pp_bf16.hip)

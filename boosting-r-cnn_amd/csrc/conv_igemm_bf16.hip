@@ -1213,6 +1213,7 @@ int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s) { re
 // fp16 operands: the production tile shapes only (the tuning-hook variants stay bf16)
 static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     p.il = 0;
+    if (const int rc = conv1x1_stream_try(p, s, 1)) return rc < 0 ? rc : 0;
     if (p.gstep) return launch2<1, 1, 4, 2, 2, 1>(p, s);
     if (pp_wins(p)) return dispatch_conv_pp_bf16(p, s);
     const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
@@ -1232,6 +1233,9 @@ static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
     if (p.f16) return dispatch_conv_f16(p, s);
     p.il = g_bf16_il;
+    if (g_bf16_tile == 0) {
+        if (const int rc = conv1x1_stream_try(p, s, 0)) return rc < 0 ? rc : 0;
+    }
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
     int t = ((p.z_out || p.tail_z) && g_bf16_tile != 8844) ? 0 : g_bf16_tile;
     if (t == 0 && pp_wins(p)) return dispatch_conv_pp_bf16(p, s);
@@ -1292,6 +1296,7 @@ BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -6 || mtnt == -7) { g_pp_mode = mtnt == -7; return 0; }      // eight-phase kernel: -6 never, -7 heuristic
     // test hook: -11 = the K heads of the following stream-K launches do not publish and the tails give up after 256
     // polls (a lost hand-over, to exercise BRCNN_EHANDOVER); -12 = back to normal
+    if (mtnt == -15 || mtnt == -16 || mtnt == -17) return conv1x1_stream_set(-15 - mtnt);      // persistent short-K 1x1 kernel never / heuristic / forced
     if (mtnt == -11 || mtnt == -12) { g_sk_drop_publish = mtnt == -11; g_sk_spin_limit = mtnt == -11 ? 256 : 1 << 24; return 0; }
     const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844};
     bool found = false;

@@ -262,3 +262,35 @@ def test_whole_train_step_is_bit_reproducible_under_load(dtype, scale):
     finally:
         m.early_rpn_backward, m.early_backward_scale = False, 1.0
         blocks.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_persistent_short_k_kernel_equals_the_tile_kernels_under_repetition(dtype):
+    """conv1x1_stream_bf16.hip: a workgroup walks a strip of 64-row tiles with the weights resident in LDS, x and residual
+    tiles arriving through LDS-DMA rings D-1 tiles ahead, ONE counted vmcnt wait per tile with loads and stores in flight
+    around it.  100 repetitions per shape against the one-tile-per-workgroup kernel, bit for bit -- a wait that let a tile
+    through early would read a stale ring slot in some repetition"""
+    from brcnn import lib, ops
+    L = lib.load()
+    g = torch.Generator().manual_seed(9)
+    try:
+        for (n, h, w_, k, co, res, relu) in [(8, 100, 168, 128, 512, True, True), (8, 200, 336, 64, 256, False, True),
+                                             (4, 99, 131, 64, 256, True, False), (3, 77, 53, 128, 128, False, True)]:
+            x = torch.randn(n, h, w_, k, generator=g).to(dtype).cuda()
+            wt = (torch.randn(co, 1, 1, k, generator=g) * 0.05).to(dtype).cuda()
+            sc = (torch.rand(co, generator=g) + 0.5).cuda(); sh = torch.randn(co, generator=g).cuda()
+            r = torch.randn(n, h, w_, co, generator=g).to(dtype).cuda() if res else None
+            assert L.brcnn_conv_set_tile_bf16(-15) == 0
+            ref = ops.conv2d_nhwc(x, wt, scale=sc, shift=sh, residual=r, relu=relu)
+            assert L.brcnn_conv_set_tile_bf16(-17) == 0
+            other = torch.randn(4096, 4096, device='cuda')          # a co-running load on a second stream
+            side = torch.cuda.Stream()
+            for rep in range(100):
+                if rep % 10 == 0:
+                    with torch.cuda.stream(side):
+                        other @ other
+                got = ops.conv2d_nhwc(x, wt, scale=sc, shift=sh, residual=r, relu=relu)
+                assert torch.equal(got, ref), (rep, (n, h, w_, k, co, res, relu), int((got != ref).sum()))
+            torch.cuda.synchronize()
+    finally:
+        L.brcnn_conv_set_tile_bf16(-16)

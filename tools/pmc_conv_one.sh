@@ -19,11 +19,11 @@ agg = collections.defaultdict(float); n = collections.defaultdict(int)
 dur = []
 for f in glob.glob('$O/p*/one_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'conv_' in r['Kernel_Name'] and ('igemm' in r['Kernel_Name'] or 'conv_pp' in r['Kernel_Name']):
+        if 'conv' in r['Kernel_Name'] and ('igemm' in r['Kernel_Name'] or 'conv_pp' in r['Kernel_Name'] or 'stream' in r['Kernel_Name']):
             agg[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 for f in glob.glob('$O/p1/one_kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
-        if 'conv_' in r['Kernel_Name'] and ('igemm' in r['Kernel_Name'] or 'conv_pp' in r['Kernel_Name']):
+        if 'conv' in r['Kernel_Name'] and ('igemm' in r['Kernel_Name'] or 'conv_pp' in r['Kernel_Name'] or 'stream' in r['Kernel_Name']):
             dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 print('tile $tile shape ${CONV_SHAPE:-default}: kernel us (profiled)', [round(d, 1) for d in dur])
 v = {k: agg[k] / n[k] for k in agg}
