@@ -282,7 +282,9 @@ int brcnn_conv_set_tile(int wm, int nt);
  * continues from the stored fp32 accumulators; bit-identical) off / by the heuristic / wherever the
  * tile count allows it.  -6 / -7: eight-phase kernel never / by the heuristic.  -11 / -12 (test hook): stream-K heads
  * stop / resume publishing and tails give up after 256 polls -- a lost hand-over on demand, to exercise
- * BRCNN_EHANDOVER. */
+ * BRCNN_EHANDOVER.  -15 / -16 / -17: the persistent kernel of the plain K = 64 / 128 1x1 layers (csrc/conv1x1_stream_bf16.hip:
+ * weights resident in LDS, x / residual tiles through LDS-DMA rings) never / by the heuristic (default) / wherever the shape
+ * allows; bit-identical. */
 int brcnn_conv_set_tile_bf16(int mtnt);
 
 /* The same convolution over `num_segments` feature maps that share one set of weights (the
