@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(ConvParams p) {
         sh8p[0] = brcnn_f32x2{b0.x, b0.y}; sh8p[1] = brcnn_f32x2{b0.z, b0.w}; sh8p[2] = brcnn_f32x2{b1.x, b1.y}; sh8p[3] = brcnn_f32x2{b1.z, b1.w};
     }
     const unsigned floor2 = p.relu ? 0u : 0x80008000u;
-    const unsigned short* __restrict__ res = reinterpret_cast<const unsigned short*>(p.residual);
     unsigned short* __restrict__ yh = reinterpret_cast<unsigned short*>(p.y);
 
     // fragment addresses (conv_igemm_bf16.hip's layout: row R, logical 16-byte chunk c at physical c ^ ((R >> 1) & 7))
