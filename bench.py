@@ -320,11 +320,20 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # Memory pool up front (the part has 288 GB): one 64 GiB block taken and handed back to PyTorch's caching allocator,
+    # which then serves the models, activations and workspaces of both legs out of it.  Without it the allocator goes back
+    # to hipMalloc whenever a step needs a size it has not cached yet, and on a freshly booted box such a call inside the
+    # timed region took 1-2 s in 4 of ~16 first runs (profiles/r04_notes.md) -- the runner can afford that once per
+    # training, a 20-step measurement cannot.
+    try:
+        pool = torch.empty(int(os.environ.get('BRCNN_BENCH_POOL_GIB', '64')) << 30, dtype=torch.uint8, device=device)
+        del pool
+    except RuntimeError:
+        pass
     line, cfg = None, None
     if args.mode in ('both', 'inference'):
         line, cfg, model = inference_bench(args, world, rank, device)
         del model
-        torch.cuda.empty_cache()
     if args.mode in ('both', 'train'):
         tr = train_bench(args, world, rank, device)
         if line is None:

@@ -80,11 +80,14 @@ def main():
         # mean over the ranks of the unwrapped step's gradients (the second `own` pass also back-propagates the RPN
         # branch inside the forward pass)
         for k, g in grads['ddp'][0].items():
-            tol = (2e-4 if dtype == 'f32' else 3e-2) * (g.abs().max().item() + 1e-12)
-            assert (g - grads['own'][0][k]).abs().max().item() <= tol, ('own vs ddp', k)
+            # (fp32 weight gradients accumulate with atomics and the three passes run on two processes sharing the device:
+            # the order of the sums varies from pass to pass; 2e-4 of the largest entry was exceeded in 2 of ~10 suite runs,
+            # 1e-3 is the tolerance the north star states for fp32 tensors)
+            tol = (1e-3 if dtype == 'f32' else 3e-2) * (g.abs().max().item() + 1e-12)
+            assert (g - grads['own'][0][k]).abs().max().item() <= tol, ('own vs ddp', k, (g - grads['own'][0][k]).abs().max().item(), tol)
             t = grads['plain'][0][k].clone()
             dist.all_reduce(t)
-            assert (g - t / world).abs().max().item() <= tol, ('ddp vs mean of plain', k)
+            assert (g - t / world).abs().max().item() <= tol, ('ddp vs mean of plain', k, (g - t / world).abs().max().item(), tol)
     # every rank ends with identical (averaged) gradients
     for mode in ('ddp', 'own'):
         for k, g in sorted(grads[mode][0].items())[:8]:
