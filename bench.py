@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-bs1', action='store_true',
+                    help='skip the batch-1 latency loop (profiling runs: tools/profile_round.sh takes the per-pass kernel '
+                         'statistics of the batch-8 workload from a run without it)')
     ap.add_argument('--dtype', choices=['f32', 'bf16', 'f16'], default='f32',
                     help="arithmetic type of the conv stack at inference: 'f32' (BASELINE configs[1], the parity "
                          "path, default), 'bf16' / 'f16' (16-bit MFMA, fp32 accumulate; proposal stage, head outputs "
@@ -105,7 +108,9 @@ def synthetic_gt(batch, device, num_classes, seed=0, num_gt=20):
 
 
 def timed(step, steps, warmup, world, device):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks"""
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks.  Returns (seconds,
+    per-step statistics): a HIP event on the main stream after every step gives each step's DEVICE time (median / p90 /
+    max say whether the mean is the steady state or carries a hiccup), the host marks give the enqueue time per step"""
     import torch
     import torch.distributed as dist
     for _ in range(warmup):
@@ -114,29 +119,38 @@ def timed(step, steps, warmup, world, device):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    evs[0].record()
     marks = []
-    for _ in range(steps):
+    for i in range(steps):
         step()
+        evs[i + 1].record()
         marks.append(time.perf_counter())      # host time after the step's enqueue (no synchronisation)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # a one-off stall inside the timed region (seen twice in ~12 first runs on fresh boxes: ~2 s in one step) is reported,
-    # never removed: the line still times exactly K steps
+    dev_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     gaps = [b - a for a, b in zip([t0] + marks[:-1], marks)]
-    med = sorted(gaps)[len(gaps) // 2]
-    worst = max(range(len(gaps)), key=lambda i: gaps[i])
-    if gaps[worst] > 20 * med and gaps[worst] > 0.25:
-        print(f'bench: step {worst} of {steps} took {gaps[worst] * 1e3:.0f} ms on the host (median {med * 1e3:.1f} ms): a one-off '
-              f'stall is inside the timed region', file=sys.stderr, flush=True)
+    host_ms = sorted(1e3 * g for g in gaps)
+    stats = {'step_ms_median': dev_ms[steps // 2], 'step_ms_p90': dev_ms[min(steps - 1, (9 * steps) // 10)],
+             'step_ms_min': dev_ms[0], 'step_ms_max': dev_ms[-1],
+             'host_enqueue_ms_median': host_ms[steps // 2], 'host_enqueue_ms_max': host_ms[-1]}
+    # a one-off stall inside the timed region (seen on fresh boxes: up to ~2 s in one step) is reported, never removed:
+    # the line still times exactly K steps
+    med = dev_ms[steps // 2]
+    for i in range(steps):
+        d = evs[i].elapsed_time(evs[i + 1])
+        if d > 5 * med or 1e3 * gaps[i] > max(5 * host_ms[steps // 2], 5 * med):
+            print(f'bench: step {i} of {steps}: {d:.1f} ms on the device, {1e3 * gaps[i]:.1f} ms on the host (medians {med:.1f} / '
+                  f'{host_ms[steps // 2]:.1f} ms): a one-off stall is inside the timed region', file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt
+    return dt, stats
 
 
 def train_bench(args, world, rank, device):
@@ -200,7 +214,16 @@ def train_bench(args, world, rank, device):
         last['log_vars'] = log_vars
 
     steps = args.train_steps or args.steps
-    dt = timed(step, steps, args.warmup, world, device)
+    # host slack at the step's one synchronisation (roi_heads.sample_device: the sampler's candidate counts): how long
+    # the host WAITED there = how far it runs ahead of the device; ~0 means the step is launch-bound from there on
+    from brcnn import roi_heads as _rh
+    for _ in range(args.warmup):
+        step()
+    _rh.SYNC_WAIT = [0.0, 0]
+    dt, step_stats = timed(step, steps, 0, world, device)
+    sync_wait = _rh.SYNC_WAIT
+    _rh.SYNC_WAIT = None
+    step_stats['host_slack_at_sync_ms'] = 1e3 * sync_wait[0] / max(1, sync_wait[1])
     from brcnn import lib as _lib
     _lib.handover_status()          # a lost stream-K hand-over inside the timed steps is an error, not a number
     # HIP-event time of GradReducer.reduce() on the main stream over the timed steps: join of the weight-gradient
@@ -217,7 +240,7 @@ def train_bench(args, world, rank, device):
     return {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN train step',
         'value': world * args.batch * steps / dt, 'unit': 'images/sec', 'ms_per_step': 1000.0 * dt / steps,
-        'steps': steps, 'warmup': args.warmup, 'dtype': args.train_dtype, 'n_gpus': world,
+        'steps': steps, 'warmup': args.warmup, 'dtype': args.train_dtype, 'n_gpus': world, **step_stats,
         'config': {'workload': f'boosting_rcnn_r50_pafpn_1x_coco.py full train step, batch {args.batch} x 3x800x1344 '
                                f'per GPU, 20 GT/img, 512 RoIs/img, SGD+clip, {args.train_dtype} conv stack, '
                                'device-resident targets / losses' +
@@ -246,7 +269,7 @@ def inference_bench(args, world, rank, device):
         with torch.no_grad():
             last['out'] = model(return_loss=False, rescale=True, img=[img], img_metas=[metas])
 
-    dt = timed(step, args.steps, args.warmup, world, device)
+    dt, step_stats = timed(step, args.steps, args.warmup, world, device)
     from brcnn import lib as _lib
     _lib.handover_status()          # a lost stream-K hand-over inside the timed steps is an error, not a number
     from brcnn import profiling
@@ -260,20 +283,22 @@ def inference_bench(args, world, rank, device):
     # batch-1 latency (benchmark.py runs samples_per_gpu=1; the only published neighbours, BASELINE.md, are batch 1):
     # synchronised passes over one image, mean of `steps`
     img1, metas1 = img[:1].contiguous(), metas[:1]
-    with torch.no_grad():
-        for _ in range(max(2, args.warmup)):
-            model(return_loss=False, rescale=True, img=[img1], img_metas=[metas1])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model(return_loss=False, rescale=True, img=[img1], img_metas=[metas1])
-        torch.cuda.synchronize()
-        lat1 = (time.perf_counter() - t0) / args.steps * 1000.0
+    lat1 = None
+    if not args.no_bs1:
+        with torch.no_grad():
+            for _ in range(max(2, args.warmup)):
+                model(return_loss=False, rescale=True, img=[img1], img_metas=[metas1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model(return_loss=False, rescale=True, img=[img1], img_metas=[metas1])
+            torch.cuda.synchronize()
+            lat1 = (time.perf_counter() - t0) / args.steps * 1000.0
     line = {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN inference',
         'value': world * args.batch * args.steps / dt, 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        **step_stats, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'boosting_rcnn_r50_pafpn_1x_utdac.py inference (model(return_loss=False, rescale=True): '
                                'device pass + result copy + bbox2result), '
                                f'batch {args.batch} x 3x800x1344 per GPU, {args.dtype} MFMA conv stack, '
@@ -281,7 +306,7 @@ def inference_bench(args, world, rank, device):
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         'roofline': roof,
         'stages_ms': stages,
-        'latency_bs1_ms': lat1, 'fps_bs1': 1000.0 / lat1,
+        'latency_bs1_ms': lat1, 'fps_bs1': None if lat1 is None else 1000.0 / lat1,
         'detections_last_step': int(sum(len(c) for im in last['out'] for c in im)),
     }
     return line, cfg, model

@@ -226,6 +226,9 @@ class EpochBasedRunner:
         self.loss_scaler, self.loss_scale = None, None      # fp16 recipes: static loss scaling (train_detector)
         self.reducer = None                                  # distributed.GradReducer (data parallel without DDP)
         self.early_rpn_backward = True                       # see _early_rpn_backward (cfg.early_rpn_backward)
+        # data parallel: compare the replicas' parameters bit for bit after every optimizer step (a host sync per
+        # step: a debugging / test switch -- `check_replicas = True` in the config or BRCNN_CHECK_REPLICAS=1)
+        self.check_replicas = os.environ.get('BRCNN_CHECK_REPLICAS', '0') == '1'
         self.log_buffer = OrderedDict()
         self.history = []          # (epoch, iter, lr, {name: value}) rows the text logger printed
         self.eval_history = []
@@ -360,6 +363,12 @@ class EpochBasedRunner:
                     if gn is not None:
                         outputs['log_vars']['grad_norm'] = float(gn)
                 self.optimizer.step()
+            if self.check_replicas and torch.distributed.is_available() and torch.distributed.is_initialized():
+                from .distributed import replicas_identical
+                if not replicas_identical(self.model):
+                    raise RuntimeError(f'iteration {self.iter}: the data-parallel replicas no longer hold identical '
+                                       f'parameters (rank {get_dist_info()[0]})')
+                self.replica_checks = getattr(self, 'replica_checks', 0) + 1
             for k, v in outputs['log_vars'].items():
                 self.log_buffer.setdefault(k, []).append(v)
             self.iter += 1
@@ -371,6 +380,9 @@ class EpochBasedRunner:
                     from . import lib as _lib
                     _lib.handover_status()      # a lost stream-K hand-over since the last log line raises here
                 t_last, n_since = now, 0
+        if getattr(self, 'replica_checks', 0):
+            self.logger.info(f'replica check: parameters and buffers bit-identical on every rank after each of '
+                             f'{self.replica_checks} optimizer steps')
         self.epoch += 1
 
     def _ddp_step(self, data):
@@ -474,6 +486,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     runner.timestamp = timestamp
     runner.reducer = reducer
     runner.early_rpn_backward = bool(cfg.get('early_rpn_backward', True))
+    runner.check_replicas = bool(cfg.get('check_replicas', runner.check_replicas))
     if cfg.get('fp16', None) is not None:
         # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->
         # mmdet/apis/train.py:115-119, mmcv Fp16OptimizerHook): fp16 MFMA conv stack (fp32 accumulation, fp32

@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 
 from . import lib as _L
 from . import ops
-from .ops import DT_F32, DT_BF16, _dt, _ptr, _require_gpu, _stream, conv_out_size
+from .ops import DT_F32, DT_BF16, _dt, _ptr, _require_gpu, _stream, _conv_stream, conv_out_size
 
 
 def _ints(vals):
@@ -38,6 +38,7 @@ class _GradArena:
         self.buf, self.off, self.used, self.hint = None, 0, 0, 0
         self.listener = None        # distributed.GradReducer: all-reduces the arena in place, slice by slice
         self._chunks = []           # [(chunk, elements handed out)] of the running step (listener only)
+        self._last = (0, 0)         # element range of the view handed out last
 
     def take(self, shape, device):
         if _ARENA_OFF:
@@ -53,16 +54,19 @@ class _GradArena:
                 self._chunks.append([self.buf, 0])
                 self.listener.chunk_opened(self.buf)
         v = self.buf[self.off:self.off + n].view(shape)
+        self._last = (self.off, self.off + n_al)
         self.off += n_al
         self.used += n_al
         if self.listener is not None:
             self._chunks[-1][1] = self.off
         return v
 
-    def launched(self, stream):
-        """the kernel that writes the view handed out last has been issued on `stream`"""
+    def launched(self, stream, in_place=True, param=None):
+        """the kernel that writes the view handed out last has been issued on `stream`.  `in_place`: autograd takes
+        that view as the parameter's `.grad` as it is (nobody copies it on the main stream afterwards) -- only such
+        ranges may be all-reduced in place while the backward pass is still running (distributed.GradReducer)"""
         if self.listener is not None and self.buf is not None:
-            self.listener.writers_launched(self.buf, self.off, stream)
+            self.listener.writers_launched(self.buf, self._last[0], self._last[1], stream, in_place, param)
 
     def used_of(self, buf):
         for b, n in self._chunks:
@@ -77,6 +81,12 @@ class _GradArena:
 
 grad_arena = _GradArena()
 
+
+# BRCNN_TEST_WGRAD_STALL_CYCLES=n (tests/ddp_worker.py): with a gradient reducer attached, the main stream idles n
+# clock cycles after every weight-gradient launch -- whatever autograd queues there next (its copies of dW included)
+# then runs AFTER an overlapped all-reduce of the same arena slice had the time to complete, the order that made the
+# round-4 two-rank mismatch (profiles/r05_notes.md)
+_TEST_STALL_CYCLES = int(_os.environ.get('BRCNN_TEST_WGRAD_STALL_CYCLES', '0'))
 
 # weight-gradient launches on a second HIP stream (see _conv_backward); BRCNN_WGRAD_STREAM=0 keeps one stream
 WGRAD_SIDE_STREAM = _os.environ.get('BRCNN_WGRAD_STREAM', '1') != '0'
@@ -221,7 +231,7 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
             w_t = weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).to(x_cat.dtype).contiguous()   # (Cin,KH,KW,Cout)
         dx = torch.empty_like(x_cat)
         st = lib.brcnn_conv2d_dgrad_nhwc_multi(_ptr(dy), _ptr(w_t), _ptr(dx), batch, L, hs, ws, ohs,
-                                               ows, cin, cout, kh, kw, stride, pad, dt, _stream())
+                                               ows, cin, cout, kh, kw, stride, pad, dt, _conv_stream())
         _L.check(st, 'brcnn_conv2d_dgrad_nhwc_multi')
     if need_dw:
         dwp = grad_arena.take((cout, kh, kw, cin), dy.device)
@@ -234,7 +244,7 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
         side = _side_stream_for(weight, dy.device) if takes else None
         if side is None:
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
-                                                   cin, cout, kh, kw, stride, pad, dt, _stream())
+                                                   cin, cout, kh, kw, stride, pad, dt, _conv_stream())
         else:
             # nothing in the backward pass waits for dW: the weight-gradient launch goes to a second HIP stream and
             # overlaps the data-gradient chain of the layers above (its atomics tail and the other kernel's
@@ -248,7 +258,13 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
             _queue_stream_join(main, side)
         _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
         if grad_arena.listener is not None and dy.is_cuda:
-            grad_arena.launched(side if side is not None else torch.cuda.current_stream(dy.device))
+            # `takes`: dW is `.grad` itself.  Otherwise autograd (or the caller) COPIES it on the main stream after
+            # this function returns (AccumulateGrad's clone of a gradient whose strides are not the parameter's, the
+            # backward of a cat / pad / permute in front of the weight) and the copy is what gets reduced: such a
+            # range must not be all-reduced in place under that copy
+            grad_arena.launched(side if side is not None else torch.cuda.current_stream(dy.device), bool(takes), weight)
+            if _TEST_STALL_CYCLES:      # test switch: hold the main stream back behind every weight-gradient launch
+                torch.cuda._sleep(_TEST_STALL_CYCLES)
         # (Cout,KH,KW,Cin) -> the parameter's (Cout,Cin,KH,KW): for 1x1 filters the two coincide in
         # memory (a plain view with the parameter's own strides, what DDP's bucket views expect)
         dw = dwp.view(cout, cin, 1, 1) if kh == 1 and kw == 1 else dwp.permute(0, 3, 1, 2)
@@ -381,7 +397,7 @@ def _dgrad_stride2(dy, weight, batch, in_size, out_size, k, pad, dtype):
     for ph, pw, wt, cpad, origin in classes:
         wt = wt.to(dtype).contiguous()                                         # (Cin, KH', KW', Cout)
         st = lib.brcnn_conv2d_nhwc_scatter2(_ptr(dy), _ptr(wt), _ptr(dx), batch, Ho, Wo, cout, cin,
-                                            wt.shape[1], wt.shape[2], cpad, H, W, ph, pw, origin, dt, _stream())
+                                            wt.shape[1], wt.shape[2], cpad, H, W, ph, pw, origin, dt, _conv_stream())
         _L.check(st, 'brcnn_conv2d_nhwc_scatter2')
     return dx
 
@@ -522,12 +538,12 @@ class GroupedConvFunction(Function):
             wt_tiles = wt_tiles.to(x.dtype)
             dx = torch.empty_like(x)
             st = lib.brcnn_conv2d_dgrad_nhwc_grouped(_ptr(dy), _ptr(wt_tiles), _ptr(dx), n, h, w, yshape[1], yshape[2],
-                                                     cin, cout, kh, kw, stride, pad, win_t, gdt, _stream())
+                                                     cin, cout, kh, kw, stride, pad, win_t, gdt, _conv_stream())
             _L.check(st, 'brcnn_conv2d_dgrad_nhwc_grouped')
         if ctx.needs_input_grad[1]:
             dwt = torch.zeros((cout, kh, kw, window), dtype=torch.float32, device=x.device)
             st = lib.brcnn_conv2d_wgrad_nhwc_grouped(_ptr(x), _ptr(dy), _ptr(dwt), n, h, w, cin, cout, kh, kw,
-                                                     stride, pad, window, gdt, _stream())
+                                                     stride, pad, window, gdt, _conv_stream())
             _L.check(st, 'brcnn_conv2d_wgrad_nhwc_grouped')
             co = torch.arange(cout, device=x.device)
             start = ((co // cg_out) * cg_in) - (co // 64) * window
@@ -698,7 +714,7 @@ class ConvBnEvalActFunction(Function):
         st = _L.load().brcnn_conv2d_bn_act_nhwc_multi(_ptr(x_cat), _ptr(w_p), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32),
                                                       float(eps), _ptr(r), _ptr(z), _ptr(out), batch, 1, _ints([h]),
                                                       _ints([w_]), cin, cout, kh, kw, int(stride), int(pad), int(relu),
-                                                      _dt(x_cat), _stream())
+                                                      _dt(x_cat), _conv_stream())
         _L.check(st, 'brcnn_conv2d_bn_act_nhwc_multi')
         ctx.w_t = w_t
         ctx.save_for_backward(x_cat, weight, z, g32, b32, m32, v32, out if relu and res is not None else None)
@@ -757,7 +773,7 @@ class ConvBnEvalActFunction(Function):
                                                          _ptr(t.v), t.eps, int(t.relu), _ptr(dskip), _ptr(t.out), _ptr(t.dres),
                                                          _ptr(dzp), _ptr(t.dgamma),
                                                          _ptr(t.dbeta), _ptr(ws), nb, batch, h, w_, ho, wo, cin, cout, kh, kw,
-                                                         stride, pad, dt, _stream())
+                                                         stride, pad, dt, _conv_stream())
             _L.check(st, 'brcnn_conv2d_dgrad_bn_backward_nhwc')
             t.done = True
             _, dw, _ = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), None, False,

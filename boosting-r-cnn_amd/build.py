@@ -24,6 +24,13 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=
          '-munsafe-fp-atomics']
 
 
+# per-source additions.  -fno-slp-vectorize: in these translation units every packed-fp32 instruction came from the SLP
+# vectoriser, some of them in the cross-swizzled op_sel form that tools/check_isa.py refuses; the kernels
+# are latency- or HBM-bound, the scalar form costs nothing measurable
+EXTRA_FLAGS = {'roi_align.hip': ['-fno-slp-vectorize'], 'focal_loss.hip': ['-fno-slp-vectorize'],
+               'train_loss.hip': ['-fno-slp-vectorize'], 'deform.hip': ['-fno-slp-vectorize']}
+
+
 def hipcc():
     for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if c and os.path.exists(c):
@@ -44,12 +51,13 @@ def _stamp():
             h.update(f.encode())
             h.update(open(p, 'rb').read())
     h.update(' '.join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
 def _compile(src):
     obj = os.path.join(LIBDIR, 'obj', src.replace('.hip', '.o'))
-    cmd = [hipcc()] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
@@ -64,8 +72,19 @@ def build_library(force=False, verbose=False):
             open(stamp_file).read() == stamp:
         return LIB
     srcs = _sources()
+    objdir = os.path.join(LIBDIR, 'obj')
+    for f in os.listdir(objdir):            # objects of sources that no longer exist
+        if f.endswith('.o') and f.replace('.o', '.hip') not in srcs:
+            os.remove(os.path.join(objdir, f))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
+    # ISA gate: no cross-swizzled packed-fp32 instruction in any code object (tools/check_isa.py)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
+    try:
+        import check_isa
+    finally:
+        sys.path.pop(0)
+    check_isa.check_objects(objs, verbose=verbose)
     cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -785,9 +785,10 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
 }
 
 // ---- chained stream-K schedule: host side ---------------------------------------------------------------------
-// Per stream: the hand-over slots (fp32 accumulators of one tile each), their flags and the launch epoch.  Launches
-// on one stream are serialised, so a slot is free again when the next launch starts.
-struct SkStream { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; float* slabs; char* base; int owned; };
+// Per (device, stream): the hand-over slots (fp32 accumulators of one tile each), their flags and the launch epoch.
+// Launches on one stream are serialised, so a slot is free again when the next launch starts.  The device is part of
+// the key: the default stream is handle 0 on EVERY device, and a workspace lives in one device's memory.
+struct SkStream { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; float* slabs; char* base; int owned; int device; };
 struct SkTable { long long tiles; int nk, slots, blocks; int4* items; int par; };
 constexpr size_t SK_WS_BYTES = (size_t)128 << 20;
 constexpr int SK_MAX_SLOTS = 2048;
@@ -833,11 +834,13 @@ static void sk_carve(SkStream& e, char* base) {
 
 int sk_stream_state(hipStream_t s, SkStream** out) {
     if (int rc = sk_error_word()) return rc;
+    int dev = 0;
+    BRCNN_HIP_CHECK(hipGetDevice(&dev));        // the device the caller is about to launch on
     for (auto& e : g_sk_streams)
-        if (e.stream == s) { *out = &e; return 0; }
+        if (e.stream == s && e.device == dev) { *out = &e; return 0; }
     if (g_sk_streams.capacity() < 64) g_sk_streams.reserve(64);       // pointers handed out stay valid
     if (g_sk_streams.size() >= 64) return BRCNN_EINVAL;
-    SkStream e = {s, nullptr, nullptr, 0, nullptr, nullptr, 1};
+    SkStream e = {s, nullptr, nullptr, 0, nullptr, nullptr, 1, dev};
     char* base = nullptr;
     BRCNN_HIP_CHECK(hipMalloc((void**)&base, CONV_WS_BYTES));
     sk_carve(e, base);
@@ -873,9 +876,11 @@ BRCNN_API int brcnn_conv_set_workspace(void* stream, void* workspace, size_t byt
     std::lock_guard<std::mutex> lock(g_sk_mutex);
     if (int rc = sk_error_word()) return rc;
     if (workspace != nullptr && (bytes < CONV_WS_BYTES || ((uintptr_t)workspace & 255))) return BRCNN_EINVAL;
+    int dev = 0;
+    BRCNN_HIP_CHECK(hipGetDevice(&dev));        // (the current device: the one `workspace` was allocated on)
     SkStream* e = nullptr;
     for (auto& c : g_sk_streams)
-        if (c.stream == s) e = &c;
+        if (c.stream == s && c.device == dev) e = &c;
     if (workspace == nullptr) {             // release: the stream falls back to a library allocation on its next use
         if (e) {
             if (e->owned && e->base) {
@@ -892,7 +897,7 @@ BRCNN_API int brcnn_conv_set_workspace(void* stream, void* workspace, size_t byt
     if (e == nullptr) {
         if (g_sk_streams.capacity() < 64) g_sk_streams.reserve(64);
         if (g_sk_streams.size() >= 64) return BRCNN_EINVAL;
-        g_sk_streams.push_back({s, nullptr, nullptr, 0, nullptr, nullptr, 0});
+        g_sk_streams.push_back({s, nullptr, nullptr, 0, nullptr, nullptr, 0, dev});
         e = &g_sk_streams.back();
     } else if (e->owned && e->base) {
         BRCNN_HIP_CHECK(hipStreamSynchronize(s));

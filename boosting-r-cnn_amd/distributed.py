@@ -24,10 +24,15 @@ second stream, dW handed to `.grad` unchanged):
   weights and the optimizer step stay fp32 (tests/test_distributed_cpu.py pins the update against an independent
   computation from the bf16-rounded local gradients);
 * every rank must post the same collectives: the layout (chunk sizes in use, small-bucket length and count) is
-  compared across the ranks through a fixed-size 2-word collective -- read at once on the first step, whenever this
-  rank's layout changes, on CPU tensors and with `strict=True`; read one step later otherwise (no host
-  synchronisation in the steady state) -- and a mismatch raises
-  instead of hanging or averaging unrelated gradients (DistributedDataParallel's reducer raises in the same case).
+  compared across the ranks through a fixed-size 2-word collective AHEAD of the payload collectives and read on the
+  host by EVERY rank on EVERY step (`strict=True`, the default: ~0.1 ms on the GPU, measured at world size 1) -- a
+  mismatch raises on all ranks at the same point, before anything unpaired has been posted and before the optimizer
+  can consume an invalid average (DistributedDataParallel's reducer raises in the same case).  `strict=False` reads
+  the comparison one step late in the steady state (no host synchronisation): detection is then ASYMMETRIC -- the rank
+  whose layout changed raises at once, a rank whose own layout did not change has already posted payload collectives
+  that no longer pair and may block in RCCL until the failing rank's exit tears the job down (torchrun does); it
+  raises at its next reduce() / finish() if it gets there.  Use it only where a hang-then-abort on a layout bug is
+  acceptable.
 
 One process per GPU; the image batch is sharded by the sampler, weights are replicated (`broadcast_parameters`).
 """
@@ -37,8 +42,47 @@ import torch.distributed as dist
 from . import autograd as _A
 
 
+def replicas_identical(module, process_group=None):
+    """True iff every rank holds bit-identical parameters and buffers (one int64 checksum per rank -- the wrapping sum of
+    the values' bit patterns -- compared through a 2-word MAX all-reduce; a host synchronisation).  What
+    DistributedDataParallel verifies once at construction; the runner can ask for it after every optimizer step
+    (`check_replicas = True` in the config / BRCNN_CHECK_REPLICAS=1): data-parallel training is only correct while the
+    replicas stay identical (mmdet/apis/train.py:75-83)."""
+    total = None
+    for t in list(module.parameters()) + list(module.buffers()):
+        d = t.detach().contiguous()
+        if d.numel() == 0:
+            continue
+        bits = d.view(torch.uint8).view(-1).to(torch.int64).sum() if d.element_size() not in (2, 4, 8) else \
+            d.view({2: torch.int16, 4: torch.int32, 8: torch.int64}[d.element_size()]).view(-1).to(torch.int64).sum()
+        total = bits if total is None else total * 31 + bits       # (order-dependent mix; int64 wraps)
+    if total is None:
+        return True
+    t = torch.stack([total, -total])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=process_group)
+    hi, neg_lo = t.tolist()
+    return hi == -neg_lo
+
+
+def _subtract(live, issued):
+    """the parts of the sorted ranges `live` that no range of `issued` (sorted, disjoint) covers"""
+    out = []
+    for lo, hi in live:
+        for a, b in issued:
+            if b <= lo or a >= hi:
+                continue
+            if a > lo:
+                out.append((lo, a))
+            lo = max(lo, b)
+            if lo >= hi:
+                break
+        if lo < hi:
+            out.append((lo, hi))
+    return out
+
+
 class GradReducer:
-    def __init__(self, params, process_group=None, slice_mb=64, overlap=False, compress=None, strict=False):
+    def __init__(self, params, process_group=None, slice_mb=64, overlap=False, compress=None, strict=True):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('GradReducer needs an initialised torch.distributed process group')
         if compress not in (None, 'bf16'):
@@ -50,7 +94,7 @@ class GradReducer:
         self.slice_elems = max(1, int(slice_mb * (1 << 20) // 4))
         self.overlap = bool(overlap)
         self.compress = compress
-        self.strict = bool(strict)   # compare the layouts with a host synchronisation on EVERY step (~0.1 ms on the GPU)
+        self.strict = bool(strict)   # every rank reads the layout comparison on the host on EVERY step (see above)
         if self.overlap and self.compress:
             raise ValueError('GradReducer: compress needs overlap=False (the slices are all-reduced in place)')
         self._avg = dist.get_backend(process_group) == 'nccl'
@@ -58,6 +102,7 @@ class GradReducer:
         self._comm = {}
         # chunk -> [elements already handed to a collective, elements whose writers have all been launched]
         self._progress = []
+        self._seen = set()           # ids of the parameters that had a weight-gradient launch in the running pass
         self._bucket = None          # persistent flat fp32 storage of the gradients outside the arena
         self._cbuf = None            # persistent bf16 staging of the arena (compress='bf16')
         self._layout = None          # the layout signature the ranks last agreed on
@@ -66,7 +111,12 @@ class GradReducer:
         _A._OWN_REDUCER[0] = True
         _A.grad_arena.listener = self
 
+    def finish(self):
+        """end of training: the last step's deferred layout comparison (strict=False) is read and checked"""
+        self._check_lazy()
+
     def close(self):
+        self._lazy = None
         if _A.grad_arena.listener is self:
             _A.grad_arena.listener = None
         _A._OWN_REDUCER[0] = False
@@ -86,27 +136,52 @@ class GradReducer:
 
     # ---- arena listener (called by autograd._GradArena / _conv_backward) ---------------------------
     def chunk_opened(self, buf):
-        self._progress.append([buf, 0, 0])
+        if not self._progress:
+            self.last_bytes = 0         # first chunk of a new step: the overlapped slices of THIS step count from here
+        # [chunk, ranges already handed to a collective, the running in-place run [lo, hi) or None]
+        self._progress.append([buf, [], None])
 
     def shared_parameter(self, param):
-        """a parameter reached a second weight-gradient launch in one backward pass (autograd._side_stream_for):
-        autograd will ADD that result into the first one's arena slice, which the overlapped form may already have
-        handed to the communication stream"""
+        """a parameter reached a second weight-gradient launch in one backward pass (autograd._side_stream_for, or
+        the listener's own bookkeeping below): autograd will ADD that result to the first one's, whose arena slice the
+        overlapped form may already have handed to the communication stream"""
         if self.overlap:
             raise RuntimeError('GradReducer(overlap=True): a parameter is used twice in one backward pass (its second '
                                'gradient is accumulated into an arena slice that may already be in flight); use '
                                'overlap=False for this model')
 
-    def writers_launched(self, buf, upto, stream):
-        """every weight-gradient launch writing arena elements [0, upto) of `buf` has been issued, the last one on
-        `stream`: hand the finished slices to the communication stream"""
+    def writers_launched(self, buf, lo, hi, stream, in_place=True, param=None):
+        """the weight-gradient launch writing arena elements [lo, hi) of `buf` has been issued on `stream`.
+
+        Overlapped form: a range joins the running RUN of ranges that may be all-reduced in place during the backward
+        pass only if `in_place` -- autograd hands that very storage to the parameter as `.grad`.  Anything else is
+        copied by autograd on the main stream after the launch returns (AccumulateGrad clones a gradient whose strides
+        are not the parameter's; a cat / pad / permute in front of the weight has a copying backward), and the COPY is
+        the gradient reduce() all-reduces.  Round 4 sliced the arena by offset alone: the in-place all-reduce of a
+        slice raced with those main-stream copies, and a copy that read already-reduced values was reduced a second
+        time (tests/ddp_worker.py; profiles/r05_notes.md).  A range that is not `in_place` ends the run; what is left
+        of the run, and the range itself if a gradient still refers to it, is picked up by reduce()."""
+        if param is not None:
+            if id(param) in self._seen:
+                self.shared_parameter(param)
+                in_place = False
+            self._seen.add(id(param))
+        if not (self.overlap and buf.is_cuda):
+            return
         for pr in self._progress:
             if pr[0] is buf:
-                pr[2] = max(pr[2], upto)
-                if self.overlap and buf.is_cuda:
-                    while pr[2] - pr[1] >= self.slice_elems:
-                        self._issue(buf, pr[1], pr[1] + self.slice_elems, stream)
-                        pr[1] += self.slice_elems
+                run = pr[2]
+                if not in_place:
+                    pr[2] = None
+                    return
+                if run is not None and run[1] == lo:
+                    run[1] = hi
+                else:
+                    run = pr[2] = [lo, hi]
+                while run[1] - run[0] >= self.slice_elems:
+                    self._issue(buf, run[0], run[0] + self.slice_elems, stream)
+                    pr[1].append((run[0], run[0] + self.slice_elems))
+                    run[0] += self.slice_elems
                 return
 
     def _comm_stream(self, device):
@@ -185,13 +260,14 @@ class GradReducer:
         cuda = any(pr[0].is_cuda for pr in self._progress) or any(p.is_cuda for p in self.params)
         if cuda:
             _A.join_side_streams()              # the last weight-gradient launches, on whatever stream they ran
-        self.last_bytes = 0
+        if not self._progress:
+            self.last_bytes = 0                 # (a step without an arena chunk: nothing was counted during backward)
         self._check_lazy()
         arena_ptrs, chunks = [], []
-        for buf, done, _ in self._progress:
+        for buf, issued, _ in self._progress:
             used = _A.grad_arena.used_of(buf)
             arena_ptrs.append((buf.untyped_storage().data_ptr(), buf.numel() * 4))
-            chunks.append((buf, done, used, []))
+            chunks.append((buf, issued, used, []))
         # the gradients outside the arena (BatchNorm / GroupNorm affine, biases, Scale, FC weights of odd shapes), and --
         # per chunk -- the element ranges that a parameter's gradient actually refers to: a weight gradient that autograd
         # re-laid out on its way to the parameter (the first FC: (7,7,C) columns back to the reference's (C,7,7)) left a
@@ -213,14 +289,15 @@ class GradReducer:
                 lo = (g.data_ptr() - hit[0].data_ptr()) // 4
                 hit[3].append((lo, lo + g.numel()))
         pending = []            # (chunk, first element, end element) to all-reduce
-        for buf, done, used, live in chunks:
+        for buf, issued, used, live in chunks:
             live.sort()
             cur = None
-            for lo, hi in live:
-                lo, hi = max(lo, done), min(hi, used)
+            for lo, hi in _subtract(live, issued):      # (the overlapped slices cut gradients wherever they fall)
+                lo, hi = max(lo, 0), min(hi, used)
                 if hi <= lo:
                     continue
-                if cur is not None and lo - cur[1] <= 4096:     # alignment padding / tiny gaps: one collective
+                # alignment padding / tiny gaps: one collective -- unless the gap holds an issued slice's elements
+                if cur is not None and lo - cur[1] <= 4096 and not any(a < lo and b > cur[1] for a, b in issued):
                     cur[1] = max(cur[1], hi)
                 else:
                     if cur is not None:
@@ -274,8 +351,9 @@ class GradReducer:
                 buf[lo:hi].copy_(self._cbuf[off:off + hi - lo])         # bf16 -> fp32 (exact)
                 off += hi - lo
         if not self._avg:
-            for buf, done, used, _ in chunks:
+            for buf, issued, used, _ in chunks:
                 if used:
                     buf[:used].mul_(1.0 / self.world)
         self._works = []
         self._progress = []
+        self._seen = set()

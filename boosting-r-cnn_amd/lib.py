@@ -163,24 +163,37 @@ def check(status, what):
 
 
 # ---- caller-owned conv scratch (include/brcnn_hip.h: brcnn_conv_set_workspace) ------------------------------------
-_workspaces = {}        # hipStream_t handle -> the torch tensor registered as that stream's conv workspace
+_workspaces = {}        # (device index, hipStream_t handle) -> the torch tensor registered as that stream's conv workspace
+
+
+def raw_stream_handle(stream=None):
+    """the hipStream_t of `stream` (default: torch's current stream) for a C-ABI call that launches no convolution"""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return stream.cuda_stream
 
 
 def stream_handle(stream=None):
-    """the hipStream_t of `stream` (default: torch's current stream) for a C-ABI call; on first sight of a stream its
-    convolution scratch (stream-K hand-over slots, weight-gradient slabs) is allocated HERE, by the caller, and
-    registered -- the library allocates nothing for the streams this module drives"""
+    """the hipStream_t of `stream` (default: torch's current stream) for a C-ABI call that launches a convolution
+    (forward, data gradient, weight gradient); on first sight of a (device, stream) pair its convolution scratch
+    (stream-K hand-over slots, weight-gradient slabs: 288 MiB) is allocated HERE, by the caller, and registered -- the
+    library allocates nothing for the streams this module drives.  The device is part of the key: the default stream
+    is handle 0 on every device, and the scratch lives in one device's memory (the library keys its table the same way).
+    Streams that only ever run the other kernels (proposal stage, losses, copies) go through `raw_stream_handle` and
+    pin nothing."""
     import torch
     if stream is None:
         stream = torch.cuda.current_stream()
     h = stream.cuda_stream
-    if h not in _workspaces:
+    key = (stream.device.index, h)
+    if key not in _workspaces:
         lib = load()
         nb = int(lib.brcnn_conv_workspace_bytes())
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream):         # (also makes the stream's device current for the registration call)
             ws = torch.empty(nb, dtype=torch.uint8, device=stream.device)
-        check(lib.brcnn_conv_set_workspace(h, ws.data_ptr(), nb), 'brcnn_conv_set_workspace')
-        _workspaces[h] = ws
+            check(lib.brcnn_conv_set_workspace(h, ws.data_ptr(), nb), 'brcnn_conv_set_workspace')
+        _workspaces[key] = ws
     return h
 
 

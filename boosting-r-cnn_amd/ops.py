@@ -47,6 +47,11 @@ def _require_gpu(*tensors):
 
 
 def _stream():
+    return _L.raw_stream_handle()
+
+
+def _conv_stream():
+    """for the entry points that launch a convolution: registers the stream's conv workspace on first sight"""
     return _L.stream_handle()
 
 
@@ -530,7 +535,7 @@ def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, relu=False, stride=
         assert residual.shape == y.shape and residual.is_contiguous() and residual.dtype == x.dtype
     st = _L.load().brcnn_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual),
                                      _ptr(y), n, h, wd, cin, cout, kh, kw, int(stride), int(pad),
-                                     int(bool(relu)), dt, _stream())
+                                     int(bool(relu)), dt, _conv_stream())
     _L.check(st, 'brcnn_conv2d_nhwc')
     return y
 
@@ -568,7 +573,7 @@ def conv2d_nhwc_grouped(x, w_tiles, window, scale=None, shift=None, residual=Non
         assert residual.shape == y.shape and residual.is_contiguous()
     st = _L.load().brcnn_conv2d_nhwc_grouped(_ptr(x), _ptr(w_tiles), _ptr(scale), _ptr(shift), _ptr(residual),
                                              _ptr(y), n, h, wd, cin, cout, kh, kw, int(stride), int(pad),
-                                             int(window), int(bool(relu)), dt, _stream())
+                                             int(window), int(bool(relu)), dt, _conv_stream())
     _L.check(st, 'brcnn_conv2d_nhwc_grouped')
     return y
 
@@ -599,7 +604,7 @@ def conv2d_nhwc_multi(x_cat, w, batch, sizes, scale=None, shift=None, residual=N
     st = _L.load().brcnn_conv2d_nhwc_multi(_ptr(x_cat), _ptr(w), _ptr(scale), _ptr(shift),
                                            _ptr(residual), _ptr(y), batch, L, hs, ws, cin, cout, kh,
                                            kw, int(stride), int(pad), int(bool(relu)), dt,
-                                           _stream())
+                                           _conv_stream())
     _L.check(st, 'brcnn_conv2d_nhwc_multi')
     return y, out_sizes
 

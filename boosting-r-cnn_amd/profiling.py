@@ -140,8 +140,11 @@ def conv_stack_roofline(model, img, metas, iters=3, dtype='f32'):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         cands = sorted(f for f in os.listdir(os.path.join(root, 'profiles')) if f.endswith('_conv_traffic.json'))
         t = json.load(open(os.path.join(root, 'profiles', cands[-1])))
-        traffic = t['kernels']['conv_igemm_f32_kernel' if dtype == 'f32' else
-                               'conv_igemm_bf16_dma_kernel']['hbm_bytes_per_launch']
+        ks = t['kernels']
+        # r05 on: the aggregate over every conv / FC launch of the pass under its own key (the stored summaries of
+        # earlier rounds lumped the two fp32 kernels under the name of one of them)
+        traffic = (ks.get('conv_stack_all_launches') or ks['conv_igemm_f32_kernel'])['hbm_bytes_per_launch'] \
+            if dtype == 'f32' else None
     except Exception:
         pass
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS

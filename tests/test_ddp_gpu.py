@@ -44,10 +44,20 @@ def test_ddp_train_step_equals_plain_step(dtype):
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_two_rank_train_step_reducer_and_ddp_agree(dtype):
-    """world size 2 (both ranks on cuda:0, gloo): GradReducer (with the RPN branch back-propagated inside the forward
-    pass on its second pass) and DistributedDataParallel produce the same averaged gradients = the mean of the two
-    ranks' unwrapped gradients"""
+    """world size 2 (both ranks on cuda:0, gloo): DistributedDataParallel, GradReducer and its overlapped form (each
+    with the RPN branch back-propagated inside the forward pass or not, weights as loaded or channels-last) all deliver
+    the mean of the two ranks' unwrapped gradients"""
     r = _launch([os.path.join(ROOT, 'tests', 'ddp_worker.py'), dtype], nproc=2, extra_env=TWO_ON_ONE)
+    assert r.returncode == 0 and 'DDP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_two_rank_overlap_with_stalled_main_stream():
+    """the overlapped reducer with the main stream held back 6 ms behind every weight-gradient launch: autograd's
+    main-stream copies of a weight gradient then run AFTER an in-place all-reduce of the same arena slice would have
+    completed.  Round 4 sliced the arena by offset alone and reduced such a copy a second time (intermittently: the
+    driver's red run); slices now hold only ranges that ARE `.grad` (distributed.GradReducer.writers_launched)."""
+    r = _launch([os.path.join(ROOT, 'tests', 'ddp_worker.py'), 'f32', 'overlap'], nproc=2,
+                extra_env=dict(TWO_ON_ONE, DDP_WORKER_STALL_MS='6'), timeout=1500)
     assert r.returncode == 0 and 'DDP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
@@ -60,6 +70,23 @@ def test_train_tool_distributed_launcher(tmp_path):
                  'pytorch', '--allow-random-init'])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert os.path.exists(os.path.join(work, 'epoch_1.pth'))
+
+
+def test_train_tool_two_ranks_keep_identical_replicas(tmp_path):
+    """tools/train.py --launcher pytorch on two ranks (both on cuda:0, gloo): DistributedGroupSampler shards, the
+    GradReducer averages, and after EVERY optimizer step the two replicas hold bit-identical parameters and buffers
+    (runner.check_replicas: a checksum compared across the ranks)"""
+    cfg = _tiny_cfg(tmp_path, max_epochs=1)
+    cfg.check_replicas = True
+    cfg_path = str(tmp_path / 'tiny_cfg.py')
+    cfg.dump(cfg_path)
+    work = str(tmp_path / 'work_two')
+    r = _launch([os.path.join(ROOT, 'tools', 'train.py'), cfg_path, '--work-dir', work, '--seed', '0', '--launcher',
+                 'pytorch', '--allow-random-init'], nproc=2, extra_env=TWO_ON_ONE, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert os.path.exists(os.path.join(work, 'epoch_1.pth'))
+    out = r.stdout + r.stderr
+    assert 'replica check: parameters and buffers bit-identical on every rank after each of' in out, out[-3000:]
 
 
 def test_bench_under_the_launcher():
@@ -86,3 +113,20 @@ def test_bench_two_ranks_prints_one_line_with_reduce_time():
     tr = line['train']
     assert tr['n_gpus'] == 2 and tr['reduce_ms'] > 0 and tr['grad_bytes'] > 150e6 and tr['roofline']['frac'] > 0
     assert tr['grad_allreduce']['world'] == 2 and tr['grad_allreduce']['bytes_last_step'] >= tr['grad_bytes'] * 0.9
+
+
+def test_bench_two_ranks_overlapped_and_bf16_wire_format():
+    """the two other forms of the gradient exchange through `bench.py --gpus 2` (both ranks on the one GPU, gloo):
+    overlapped in-place slices (BRCNN_REDUCER_OVERLAP=1) and the bf16 wire format (BRCNN_REDUCER_COMPRESS=bf16); every
+    N line carries reduce_ms / grad_bytes / what was exchanged"""
+    for env, check in ((dict(BRCNN_REDUCER_OVERLAP='1', BRCNN_REDUCER_SLICE_MB='16'), lambda d: d['overlap'] is True),
+                       (dict(BRCNN_REDUCER_COMPRESS='bf16'), lambda d: 'bf16' in d['arena'])):
+        r = _launch([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+                     '--mode', 'train', '--no-cpu-baseline'], nproc=2, extra_env=dict(TWO_ON_ONE, **env), timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        line = json.loads(lines[0])
+        assert line['n_gpus'] == 2 and line['value'] > 0 and line['reduce_ms'] > 0 and line['grad_bytes'] > 150e6
+        assert check(line['grad_allreduce']), line['grad_allreduce']
+        assert line['step_ms_median'] > 0 and line['step_ms_max'] >= line['step_ms_median']

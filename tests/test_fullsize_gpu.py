@@ -417,3 +417,90 @@ def test_r101_softnms_fp32_midsize_equals_cpu_oracle_pipeline():
         return n
     assert matched(a, d) >= 0.95 * len(a), (matched(a, d), len(a))
     assert matched(d, a) >= 0.95 * len(d), (matched(d, a), len(d))
+
+
+def test_r101_softnms_f16_fullsize_end_to_end():
+    """BASELINE configs[4] on ONE GPU at FULL size: boosting_rcnn_r101_pafpn_softnms_coco.py (R101, 2000 proposals /
+    image, score_thr 1e-4, soft-NMS over proposals x 80 classes, 200 per image), fp16 MFMA conv stack, batch 2 x
+    3 x 800 x 1344.
+    (1) the fp16 device run against the CPU oracle pipeline (fp32: PyTorch-CPU convs + C oracle RoIAlign / NMS /
+        soft-NMS) on the same seeded weights: of each image's 30 strongest oracle detections at least 27 reappear (same
+        class, within 2 px, score within 0.03 -- the bar of the 128 x 192 fp16 test above, now through 100 x 168 maps);
+    (2) the pick order of the whole-batch segmented soft-NMS on the run's OWN candidates (what g21 pins on synthetic
+        candidates): the (boxes, scores, labels, valid) the device handed to its soft-NMS, taken through `multiclass_nms`
+        over the C oracle's soft-NMS on the host -- labels, boxes and decayed scores bit for bit."""
+    from oracle import cpu_pipeline, orc
+    from brcnn import core, postprocess
+    path = CFG.replace('boosting_rcnn_r50_pafpn_1x_utdac.py', 'boosting_rcnn_r101_pafpn_softnms_coco.py')
+    cfg = Config.fromfile(path)
+    B = 2
+    g = torch.Generator().manual_seed(40)
+    img = torch.randn(B, 3, 800, 1344, generator=g)
+    metas = [dict(img_shape=(800, 1333, 3), pad_shape=(800, 1344, 3), ori_shape=(800, 1333, 3),
+                  scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), flip=False) for _ in range(B)]
+    with cpu_pipeline.patched():
+        m = build_detector(cfg.model)
+        sd = util.seeded_state_dict(m, seed=4)
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            ref = m(return_loss=False, rescale=True, img=[img], img_metas=[[dict(x) for x in metas]])
+    captured = {}
+    orig = postprocess.batched_nms_images_by_level
+
+    def spy(bb, sc, lb, va, level_sizes, iou_thr, max_per_img, offset=0, **kw):
+        out = orig(bb, sc, lb, va, level_sizes, iou_thr, max_per_img, offset, **kw)
+        if kw.get('soft') is not None:
+            captured['in'] = (bb.cpu(), sc.cpu(), lb.cpu(), va.cpu(), list(level_sizes), dict(kw['soft']), max_per_img)
+            captured['out'] = tuple(t.cpu() for t in out)
+        return out
+    try:
+        postprocess.batched_nms_images_by_level = spy
+        m = build_detector(cfg.model)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        m.set_compute_dtype('f16')
+        assert m._device_path_ok()
+        with torch.no_grad():
+            feats = m.extract_feat_nhwc(img.to(DEV))
+            rpn = m.rpn_head
+            cls, reg, iou = rpn.split_fused(rpn.forward_fused(list(feats)))
+            _, num = rpn.get_bboxes_padded(cls, reg, iou, metas)
+            got = m.simple_test(img.to(DEV), metas, rescale=True)
+    finally:
+        postprocess.batched_nms_images_by_level = orig
+        blocks.set_compute_dtype('f32')
+    assert int(num.min()) >= 1500, num.tolist()          # ~2000 RoIs per image really reach the second stage
+    # ---- (1) fp16 device run vs the fp32 CPU oracle pipeline
+    for b in range(B):
+        a = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], 1) for c, r in enumerate(ref[b])])
+        d = np.concatenate([np.concatenate([r, np.full((len(r), 1), c)], 1) for c, r in enumerate(got[b])])
+        assert len(a) > 50 and len(d) > 50
+        top = a[np.argsort(-a[:, 4])[:30]]
+        hit = sum(1 for t in top if ((np.abs(d[:, :4] - t[:4]).max(1) < 2) & (d[:, 5] == t[5]) &
+                                     (np.abs(d[:, 4] - t[4]) < 0.03)).any())
+        assert hit >= 27, (b, hit)
+    # ---- (2) soft-NMS pick order on the run's own candidates, bit for bit against the C oracle
+    assert 'in' in captured, 'the whole-batch segmented soft-NMS did not run'
+    bb, sc, lb, va, level_sizes, soft, max_per_img = captured['in']
+    det, lab, nd = captured['out'][:3]
+    C = len(level_sizes)
+    K = level_sizes[0]
+    assert K * C >= 100000          # 2000 x 80 candidate slots per image
+    nms_cfg = dict(type='soft_nms', iou_threshold=soft['iou_threshold'], min_score=soft.get('min_score', 1e-3))
+    for k in ('method', 'sigma', 'split_thr'):
+        if k in soft:
+            nms_cfg[k] = soft[k]
+    with cpu_pipeline.patched():
+        for b in range(B):
+            # class-major slots back to multiclass_nms' (n, 4C) / (n, C+1) layout, invalid slots below any threshold
+            boxes = bb[b].view(C, K, 4).transpose(0, 1).reshape(K, 4 * C).contiguous()
+            scores = torch.where(va[b], sc[b], torch.full_like(sc[b], -1.0)).view(C, K).t().contiguous()
+            scores = torch.cat([scores, torch.zeros(K, 1)], 1)
+            rd, rl = core.multiclass_nms(boxes, scores, -0.5, nms_cfg, max_per_img)
+            n = int(nd[b])
+            assert n == rd.shape[0] > 0, (b, n, rd.shape)
+            assert torch.equal(lab[b, :n].long(), rl.long()), f'pick order / labels, image {b}'
+            assert torch.equal(det[b, :n, 4], rd[:, 4]), f'decayed scores, image {b}'
+            assert torch.equal(det[b, :n, :4], rd[:, :4]), f'boxes, image {b}'
+    del orc

@@ -5,6 +5,8 @@ src, dst = f'gpurun_out/{r}', 'profiles'
 pairs = [('bench_f16.json', 'bench_f16.json'), ('bench_bf16_trainf32.json', 'bench_bf16_trainf32.json'),
          ('bench_under_rocprof.json', 'bench_under_rocprof.json'),
          ('stats_inf/step_kernel_stats.csv', 'inference_kernel_stats.csv'),
+         ('stats_inf_bs1/step_kernel_stats.csv', 'inference_bs1_kernel_stats.csv'),
+         ('bench_inf_under_rocprof.json', 'bench_inf_under_rocprof.json'),
          ('stats_inf_bf16/step_kernel_stats.csv', 'inference_bf16_kernel_stats.csv'),
          ('stats_train_f32/step_kernel_stats.csv', 'train_f32_kernel_stats.csv'),
          ('train_layers_bf16.txt', 'train_layers_bf16.txt'), ('train_layers_f32.txt', 'train_layers_f32.txt'),

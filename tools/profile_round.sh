@@ -4,7 +4,7 @@
 # under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
 # in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
 export GPU_MAX_HW_QUEUES=8
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -14,10 +14,13 @@ python bench.py --dtype bf16 --train-dtype f32 --no-cpu-baseline > $O/bench_bf16
 python bench.py --dtype f16 --train-dtype f16 --no-cpu-baseline > $O/bench_f16.json 2>> $O/bench.err
 # kernel statistics of the SAME default bench command (inference headline + train step)
 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o step -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
-rocprofv3 --kernel-trace --stats -f csv -d $O/stats_inf -o step -- python3 bench.py --mode inference --no-cpu-baseline > /dev/null 2>> $O/rocprof_stats.err
+# per-pass kernel statistics of the batch-8 headline workload alone (no batch-1 latency loop: `roofline` of the bench line
+# follows from this file), and of the batch-1 loop separately
+rocprofv3 --kernel-trace --stats -f csv -d $O/stats_inf -o step -- python3 bench.py --mode inference --no-cpu-baseline --no-bs1 > $O/bench_inf_under_rocprof.json 2>> $O/rocprof_stats.err
+rocprofv3 --kernel-trace --stats -f csv -d $O/stats_inf_bs1 -o step -- python3 bench.py --mode inference --batch 1 --no-cpu-baseline --no-bs1 > /dev/null 2>> $O/rocprof_stats.err
 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_train_bf16 -o step -- python3 bench.py --mode train --train-dtype bf16 --steps 10 --warmup 3 > /dev/null 2>> $O/rocprof_stats.err
 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_train_f32 -o step -- python3 bench.py --mode train --train-dtype f32 --steps 10 --warmup 3 > /dev/null 2>> $O/rocprof_stats.err
-rocprofv3 --kernel-trace --stats -f csv -d $O/stats_inf_bf16 -o step -- python3 bench.py --mode inference --dtype bf16 --no-cpu-baseline > /dev/null 2>> $O/rocprof_stats.err
+rocprofv3 --kernel-trace --stats -f csv -d $O/stats_inf_bf16 -o step -- python3 bench.py --mode inference --dtype bf16 --no-cpu-baseline --no-bs1 > /dev/null 2>> $O/rocprof_stats.err
 # PMC: conv traffic / MFMA utilisation (inference pass), op-level kernels
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o step -- python3 tools/prof_step.py > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o step -- python3 tools/prof_step.py > /dev/null 2> $O/pmc_write.err
