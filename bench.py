@@ -199,6 +199,11 @@ def train_bench(args, world, rank, device):
         model.early_rpn_backward = True
         model.early_backward_scale = scale
 
+    # backbone + neck, forward and backward, replayed from two HIP graphs from the second step on (brcnn/graphs.py): ~350 of
+    # the step's ~770 launches become two graph launches; off under DDP and with BRCNN_GRAPH_TRUNK=0
+    if net is model:
+        model.graph_trunk = True
+
     def step():
         opt.zero_grad(set_to_none=True)
         losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
@@ -236,6 +241,11 @@ def train_bench(args, world, rank, device):
     from brcnn import profiling
     # every rank runs the roofline pass: step() contains collectives (gradient all-reduce, the fused RPN normaliser,
     # the log scalars), so a rank-0-only pass would pair them with nothing and hang at N > 1
+    graphed = model.__dict__.get('_graphed_trunk')
+    graph_info = None if graphed is None else {'captures': graphed.captures,
+                                               'replays': sum(c.replays for c in graphed.caps.values()),
+                                               'disabled': graphed.disabled_reason}
+    model.graph_trunk = False       # the roofline pass times every conv launch by its own pair of events: eager launches
     roof = profiling.train_conv_roofline(step, dtype=args.train_dtype)
     return {
         'metric': 'images/sec (1333x800) Boosting R-CNN R50-PAFPN train step',
@@ -251,6 +261,7 @@ def train_bench(args, world, rank, device):
         'lr': cfg.optimizer.lr * warm,
         'grad_bytes': grad_bytes, 'reduce_ms': reduce_ms,
         'grad_allreduce': None if reducer is None else reducer.describe(),
+        'graph_trunk': graph_info,
         'roofline': roof,
     }
 

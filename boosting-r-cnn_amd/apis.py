@@ -50,7 +50,13 @@ def init_dist(launcher='pytorch', backend='nccl', **kwargs):
     WORLD_SIZE / MASTER_* come from the environment (backend 'nccl' is RCCL on ROCm)."""
     assert launcher == 'pytorch', f'launcher {launcher} is not available on this platform'
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if backend == 'nccl':
+    # test hook (tests/test_ddp_gpu.py, as in bench.py): BRCNN_DIST_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # BRCNN_DIST_BACKEND=gloo routes the collectives through gloo (RCCL refuses two ranks per device) -- the N > 1 control
+    # flow of the drivers on a one-GPU box; not a training configuration
+    backend = os.environ.get('BRCNN_DIST_BACKEND', backend)
+    if os.environ.get('BRCNN_DIST_ONE_DEVICE', '0') == '1':
+        local_rank = 0
+    if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -226,6 +232,7 @@ class EpochBasedRunner:
         self.loss_scaler, self.loss_scale = None, None      # fp16 recipes: static loss scaling (train_detector)
         self.reducer = None                                  # distributed.GradReducer (data parallel without DDP)
         self.early_rpn_backward = True                       # see _early_rpn_backward (cfg.early_rpn_backward)
+        self.graph_trunk = True                              # cfg.graph_trunk (brcnn/graphs.py)
         # data parallel: compare the replicas' parameters bit for bit after every optimizer step (a host sync per
         # step: a debugging / test switch -- `check_replicas = True` in the config or BRCNN_CHECK_REPLICAS=1)
         self.check_replicas = os.environ.get('BRCNN_CHECK_REPLICAS', '0') == '1'
@@ -310,6 +317,11 @@ class EpochBasedRunner:
         if hasattr(type(m), 'early_rpn_backward'):
             m.early_rpn_backward = bool(on)
             m.early_backward_scale = float(self.loss_scale or 1.0)
+        # backbone + neck replayed from HIP graphs once an input shape repeats (brcnn/graphs.py): wherever the trunk's
+        # parameter gradients may be assigned directly (no DistributedDataParallel wrapper); `graph_trunk = False` in the
+        # config or BRCNN_GRAPH_TRUNK=0 keeps the eager launches
+        if hasattr(type(m), 'graph_trunk'):
+            m.graph_trunk = bool(self.graph_trunk and not hasattr(m, 'module'))
         return on
 
     def train(self, data_loader):
@@ -486,6 +498,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     runner.timestamp = timestamp
     runner.reducer = reducer
     runner.early_rpn_backward = bool(cfg.get('early_rpn_backward', True))
+    runner.graph_trunk = bool(cfg.get('graph_trunk', True))
     runner.check_replicas = bool(cfg.get('check_replicas', runner.check_replicas))
     if cfg.get('fp16', None) is not None:
         # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->

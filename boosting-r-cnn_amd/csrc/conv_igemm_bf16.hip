@@ -1054,6 +1054,13 @@ static int sk_plan(ConvParams& p, int slots, int bm, int bn, hipStream_t s, int 
     p.sk_wgs = 0;
     if (int e = sk_take_error()) return e;          // a K tail of an EARLIER launch gave up waiting for its head
     if (g_sk_mode == 0 || slots <= 0 || slots > SK_MAX_SLOTS) return 0;
+    {
+        // under stream capture (brcnn/graphs.py: the trunk's forward / backward as HIP graphs) the launch is replayed with
+        // the epoch baked into its arguments, and a flag left behind by the previous replay would pass for this one's:
+        // captured launches take the plain schedule (same bits: the chained form only moves work between workgroups)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
+    }
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
     const int nk = p.K / bke;
     if (nk < 2 || tiles * nk >= 0x7fffffffLL) return 0;

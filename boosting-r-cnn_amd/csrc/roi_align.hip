@@ -716,6 +716,7 @@ __global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict
     for (int i = threadIdx.x; i < n_rois; i += 1024) perm[atomicAdd(&cnt[bucket(i)], 1)] = i;
 }
 
+constexpr int ROI_ORDER_MIN_ROIS = 12288;        // brcnn_roi_extract_order_min_rois(): what the caller sizes its scratch by
 int g_roi_rpw = 0;       // tuning hook (set_exact(10 / 11 / 17)): rows per wave by the heuristic / 1 / all
 int g_roi_order = 1;     // ... (20 / 21 / 22): never / where a workspace is given and the RoI count pays for the sort / always
 
@@ -744,7 +745,7 @@ static int extract_forward_impl(const void* const* feats_host, const int* height
     // walks all seven rows of its RoI shares the level / geometry / x-weight arithmetic but leaves a seventh of the waves
     // to hide the gather latency -- measured 20-80 % slower (hook 17; profiles/r04_notes.md)
     const int32_t* perm = nullptr;
-    if (order_ws && batch <= BRCNN_MAX_IMAGES && (g_roi_order == 2 || (g_roi_order == 1 && n_rois >= 12288))) {
+    if (order_ws && batch <= BRCNN_MAX_IMAGES && (g_roi_order == 2 || (g_roi_order == 1 && n_rois >= ROI_ORDER_MIN_ROIS))) {
         hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, s, rois, n_rois, lv, batch, order_ws);
         BRCNN_LAUNCH_CHECK();
         perm = order_ws;

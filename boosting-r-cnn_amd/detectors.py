@@ -215,7 +215,8 @@ class TwoStageDetector(BaseDetector):
         assignment, then -- while the (B,2) sampler counts travel to the host -- the RPN assignment and
         loss kernels, then sampling, RoI head and the boosting loss.  One host synchronisation."""
         from . import train_ops
-        feats = self.extract_feat_nhwc(img)
+        from .graphs import trunk_features
+        feats = trunk_features(self, img)           # backbone + neck: eager, or replayed from HIP graphs (graph_trunk)
         rpn = self.rpn_head
         if self._early_rpn_backward_ok(feats):
             return self._forward_train_device_early(feats, img_metas, gt_bboxes, gt_labels)
@@ -245,6 +246,10 @@ class TwoStageDetector(BaseDetector):
     # pass whose losses are never back-propagated still leaves gradients behind.
     early_rpn_backward = False
     early_backward_scale = 1.0
+    # backbone + neck of the device-resident train step replayed from two HIP graphs (forward, backward) once an input
+    # shape has come up twice: brcnn/graphs.py.  OPT-IN like early_rpn_backward (bench.py's train leg and the runner
+    # switch it on): the trunk's parameter gradients are assigned by the graph's backward, not by AccumulateGrad nodes
+    graph_trunk = False
 
     def _early_rpn_backward_ok(self, feats):
         return bool(self.early_rpn_backward) and torch.is_grad_enabled() and feats[0].is_cuda and \

@@ -16,6 +16,7 @@ from . import ops
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 v_mfma_f32_32x32x16_bf16 (16x the f32 rate)
 HBM_PEAK_GBS = 8000.0
+HBM_STREAM_TBS = 6.3              # what a streaming kernel sustains on this part (the guide's measured copy rate)
 
 
 # ---------------------------------------------------------------------------- per-stage breakdown
@@ -179,25 +180,49 @@ def _out_rows(batch, hs, ws, nl, kh, kw, stride, pad):
     return sum(batch * ((hs[i] + 2 * pad - kh) // stride + 1) * ((ws[i] + 2 * pad - kw) // stride + 1) for i in range(nl))
 
 
-# C-ABI entry -> (kind, shape function of its argument tuple -> (M, N, K) of the implicit GEMM)
+def _in_rows(batch, hs, ws, nl):
+    return sum(batch * hs[i] * ws[i] for i in range(nl))
+
+
+def _esz(dt):
+    return 4 if int(dt) == 0 else 2        # BRCNN_DT_F32 = 0; bf16 / f16 otherwise
+
+
+# C-ABI entry -> (kind, its argument tuple -> (M, N, K) of the implicit GEMM, its argument tuple -> ALGORITHMIC bytes: every
+# operand the launch has to read or write once -- activations in the compute dtype, weight gradients fp32)
 _TRAIN_ENTRIES = {
     # (x,w,gamma,beta,mean,var,eps,res,z,y,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,relu,dt,stream)
-    'brcnn_conv2d_bn_act_nhwc_multi': ('forward', lambda a: (_out_rows(a[10], a[12], a[13], a[11], a[16], a[17], a[18], a[19]),
-                                                           a[15], a[16] * a[17] * a[14])),
-    # (dy,w_t,z,g,b,m,v,eps,relu,dskip,prev_out,dres,dz,dg,db,ws,nb,batch,ih,iw,oh,ow,cin,cout,kh,kw,...)
-    'brcnn_conv2d_dgrad_bn_backward_nhwc': ('dgrad', lambda a: (a[17] * a[18] * a[19], a[22], a[24] * a[25] * a[23])),
+    'brcnn_conv2d_bn_act_nhwc_multi': (
+        'forward', lambda a: (_out_rows(a[10], a[12], a[13], a[11], a[16], a[17], a[18], a[19]), a[15], a[16] * a[17] * a[14]),
+        lambda a: _esz(a[21]) * (_in_rows(a[10], a[12], a[13], a[11]) * a[14] + a[15] * a[16] * a[17] * a[14] +
+                                 _out_rows(a[10], a[12], a[13], a[11], a[16], a[17], a[18], a[19]) * a[15] * (2 + (1 if a[7] else 0)))),
+    # (dy,w_t,z,g,b,m,v,eps,relu,dskip,prev_out,dres,dz,dg,db,ws,nb,batch,ih,iw,oh,ow,cin,cout,kh,kw,stride,pad,dt,stream)
+    'brcnn_conv2d_dgrad_bn_backward_nhwc': (
+        'dgrad', lambda a: (a[17] * a[18] * a[19], a[22], a[24] * a[25] * a[23]),
+        lambda a: _esz(a[28]) * (a[17] * a[20] * a[21] * a[23] + a[22] * a[24] * a[25] * a[23] +
+                                 a[17] * a[18] * a[19] * a[22] * (2 + sum(1 for i in (9, 10, 11) if a[i])))),
     # (x,w,scale,shift,res,y,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,relu,dt,stream)
-    'brcnn_conv2d_nhwc_multi': ('forward', lambda a: (_out_rows(a[6], a[8], a[9], a[7], a[12], a[13], a[14], a[15]), a[11],
-                                                    a[12] * a[13] * a[10])),
+    'brcnn_conv2d_nhwc_multi': (
+        'forward', lambda a: (_out_rows(a[6], a[8], a[9], a[7], a[12], a[13], a[14], a[15]), a[11], a[12] * a[13] * a[10]),
+        lambda a: _esz(a[17]) * (_in_rows(a[6], a[8], a[9], a[7]) * a[10] + a[11] * a[12] * a[13] * a[10] +
+                                 _out_rows(a[6], a[8], a[9], a[7], a[12], a[13], a[14], a[15]) * a[11] * (1 + (1 if a[4] else 0)))),
     # (x,w,scale,shift,res,y,n,h,w,cin,cout,kh,kw,stride,pad,relu,dt,stream)
-    'brcnn_conv2d_nhwc': ('forward', lambda a: (a[6] * ((a[7] + 2 * a[14] - a[11]) // a[13] + 1) * ((a[8] + 2 * a[14] - a[12]) // a[13] + 1),
-                                              a[10], a[11] * a[12] * a[9])),
+    'brcnn_conv2d_nhwc': (
+        'forward', lambda a: (a[6] * ((a[7] + 2 * a[14] - a[11]) // a[13] + 1) * ((a[8] + 2 * a[14] - a[12]) // a[13] + 1),
+                              a[10], a[11] * a[12] * a[9]),
+        lambda a: _esz(a[16]) * (a[6] * a[7] * a[8] * a[9] + a[10] * a[11] * a[12] * a[9] +
+                                 a[6] * ((a[7] + 2 * a[14] - a[11]) // a[13] + 1) * ((a[8] + 2 * a[14] - a[12]) // a[13] + 1) *
+                                 a[10] * (1 + (1 if a[4] else 0)))),
     # (dy,wt,dx,batch,L,hs,ws,ohs,ows,cin,cout,kh,kw,stride,pad,dt,stream): output rows = input pixels
-    'brcnn_conv2d_dgrad_nhwc_multi': ('dgrad', lambda a: (sum(a[3] * a[5][i] * a[6][i] for i in range(a[4])), a[9],
-                                                        a[11] * a[12] * a[10])),
+    'brcnn_conv2d_dgrad_nhwc_multi': (
+        'dgrad', lambda a: (sum(a[3] * a[5][i] * a[6][i] for i in range(a[4])), a[9], a[11] * a[12] * a[10]),
+        lambda a: _esz(a[15]) * (sum(a[3] * a[7][i] * a[8][i] for i in range(a[4])) * a[10] + a[9] * a[11] * a[12] * a[10] +
+                                 sum(a[3] * a[5][i] * a[6][i] for i in range(a[4])) * a[9])),
     # (x,dy,dw,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,dt,stream)
-    'brcnn_conv2d_wgrad_nhwc_multi': ('wgrad', lambda a: (_out_rows(a[3], a[5], a[6], a[4], a[9], a[10], a[11], a[12]), a[8],
-                                                        a[9] * a[10] * a[7])),
+    'brcnn_conv2d_wgrad_nhwc_multi': (
+        'wgrad', lambda a: (_out_rows(a[3], a[5], a[6], a[4], a[9], a[10], a[11], a[12]), a[8], a[9] * a[10] * a[7]),
+        lambda a: _esz(a[13]) * (_in_rows(a[3], a[5], a[6], a[4]) * a[7] +
+                                 _out_rows(a[3], a[5], a[6], a[4], a[9], a[10], a[11], a[12]) * a[8]) + 4 * a[8] * a[9] * a[10] * a[7]),
 }
 
 
@@ -206,7 +231,7 @@ def record_train_conv_launches(records):
     """every conv / FC launch of the train step (forward incl. the fused conv+BN form, data gradient incl. the fused
     BatchNorm backward, weight gradient) bracketed by HIP events on the stream it is launched on; the weight-gradient
     side stream is switched off meanwhile so that one stream carries, and one event pair times, each launch.
-    `records` receives (entry, kind, (M, N, K), start event, end event).  (`brcnn_conv2d_nhwc` calls reach the device
+    `records` receives (entry, kind, (M, N, K), start event, end event, algorithmic bytes).  (`brcnn_conv2d_nhwc` calls reach the device
     through `brcnn_conv2d_nhwc_multi` inside the library, not through this table: no double counting.)"""
     from . import autograd as _A
     from . import lib as _L
@@ -215,7 +240,7 @@ def record_train_conv_launches(records):
     _A.WGRAD_SIDE_STREAM = False
     originals = {}
 
-    def wrap(name, kind, shape_fn):
+    def wrap(name, kind, shape_fn, bytes_fn):
         orig = getattr(lib, name)
         originals[name] = orig
 
@@ -224,11 +249,11 @@ def record_train_conv_launches(records):
             s.record()
             r = orig(*a)
             e.record()
-            records.append((name, kind, shape_fn(a), s, e))
+            records.append((name, kind, shape_fn(a), s, e, float(bytes_fn(a))))
             return r
         setattr(lib, name, f)
-    for name, (kind, fn) in _TRAIN_ENTRIES.items():
-        wrap(name, kind, fn)
+    for name, (kind, fn, bfn) in _TRAIN_ENTRIES.items():
+        wrap(name, kind, fn, bfn)
     try:
         yield
     finally:
@@ -248,19 +273,33 @@ def train_conv_roofline(step, dtype='bf16', iters=2):
         with record_train_conv_launches(recs):
             step()
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for *_, s, e in recs)
+        ms = sum(r[3].elapsed_time(r[4]) for r in recs)
         if best is None or ms < best[0]:
             best = (ms, recs)
     ms, recs = best
-    by_kind = {}
-    for _, kind, (m, n, k), s, e in recs:
-        a = by_kind.setdefault(kind, [0.0, 0.0, 0])
-        a[0] += 2.0 * m * n * k
-        a[1] += s.elapsed_time(e)
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    # two roofs per launch: the MFMA peak of the dtype and the HBM stream rate a kernel can sustain (6.3 TB/s measured
+    # copy rate, MI355X_MICROARCH.md; 8 TB/s is the pin rate).  A launch cannot finish before max(flops / peak, bytes /
+    # rate); `frac_of_bound` = sum of those floors / measured time says how far the stack is from what the hardware
+    # allows for THESE shapes, which the single MFMA fraction cannot (half of the 1x1 launches are byte-bound)
+    by_kind, bound_ms, hbm_bound = {}, 0.0, [0, 0.0, 0.0]
+    for _, kind, (m, n, k), s, e, nbytes in recs:
+        a = by_kind.setdefault(kind, [0.0, 0.0, 0, 0.0, 0.0])
+        t = s.elapsed_time(e)
+        fl = 2.0 * m * n * k
+        t_mfma, t_hbm = fl / (peak * 1e12) * 1e3, nbytes / (HBM_STREAM_TBS * 1e12) * 1e3
+        a[0] += fl
+        a[1] += t
         a[2] += 1
+        a[3] += nbytes
+        a[4] += max(t_mfma, t_hbm)
+        bound_ms += max(t_mfma, t_hbm)
+        if t_hbm > t_mfma:
+            hbm_bound[0] += 1
+            hbm_bound[1] += t
+            hbm_bound[2] += t_hbm
     flops = sum(a[0] for a in by_kind.values())
     achieved = flops / (ms * 1e-3) / 1e12
-    peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     traffic, src = None, None
     try:
         import json
@@ -279,7 +318,12 @@ def train_conv_roofline(step, dtype='bf16', iters=2):
         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
         'launches': len(recs), 'avg_launch_us': 1000.0 * ms / max(len(recs), 1),
         'algorithmic_tflop_per_step': flops / 1e12, 'kernel_ms_per_step': ms,
-        'by_kind': {k: {'tflop': a[0] / 1e12, 'ms': a[1], 'launches': a[2], 'tflops': a[0] / (a[1] * 1e-3) / 1e12 if a[1] else 0.0}
+        'frac_of_bound': bound_ms / ms if ms else 0.0, 'bound_ms_per_step': bound_ms,
+        'hbm_stream_rate_TBs': HBM_STREAM_TBS,
+        'hbm_bound_launches': {'count': hbm_bound[0], 'ms': hbm_bound[1], 'floor_ms': hbm_bound[2]},
+        'algorithmic_gbytes_per_step': sum(a[3] for a in by_kind.values()) / 1e9,
+        'by_kind': {k: {'tflop': a[0] / 1e12, 'ms': a[1], 'launches': a[2], 'tflops': a[0] / (a[1] * 1e-3) / 1e12 if a[1] else 0.0,
+                        'gbytes': a[3] / 1e9, 'frac_of_bound': a[4] / a[1] if a[1] else 0.0}
                     for k, a in by_kind.items()},
         'note': 'timed with the weight-gradient side stream off (one stream, one HIP-event pair per launch); '
                 'ms_per_step of the bench is measured with it on',

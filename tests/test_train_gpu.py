@@ -694,3 +694,59 @@ def test_fused_sgd_matches_torch_sgd_with_clipping(channels_last):
     ctl = oa.step(max_norm=35, skip_nonfinite=True)
     assert float(ctl[2]) == 1.0 and all(torch.equal(x, y) for x, y in zip(pa, before))
     assert set(oa.state_dict()['state'][0].keys()) == {'momentum_buffer'}
+
+
+@pytest.mark.parametrize('dtype,early', [('bf16', True), ('bf16', False), ('f32', True), ('f16', True)])
+def test_graphed_trunk_trains_like_the_eager_trunk(dtype, early):
+    """`graph_trunk`: backbone + neck, forward and backward, replayed from two HIP graphs (brcnn/graphs.py) against the
+    eager launches of the same kernels -- two models from the same seed, FusedSGD + clipping, five steps each on the
+    same inputs and sampler seeds: the losses of every step and every parameter after the last one agree (16-bit conv
+    stacks: bit for bit -- the slab sums of their weight gradients are fixed-order and the chained stream-K schedule,
+    off under capture, only moves work between workgroups; fp32: up to the order of the weight-gradient atomics).  The
+    first step of the graphed model runs eagerly (a key is captured the second time it comes up), the capture happens
+    once, steps 2..5 replay it; the early RPN backward injects its pyramid gradients into the replayed backward."""
+    from brcnn import blocks
+    from brcnn.optim import FusedSGD
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    scale = 512.0 if dtype == 'f16' else 1.0
+    out = {}
+    try:
+        for graphed in (False, True):
+            m = _model()
+            blocks.conv_weights_channels_last(m)
+            m.set_compute_dtype(dtype)
+            opt = FusedSGD([p for p in m.parameters() if p.requires_grad], lr=2e-3, momentum=0.9, weight_decay=1e-4)
+            opt.register_conv_weights(m, blocks.compute_dtype())
+            m.graph_trunk = graphed
+            m.early_rpn_backward, m.early_backward_scale = early, scale
+            losses = []
+            for it in range(5):
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(100 + it)
+                loss, log_vars = m._parse_losses(m.forward_train(*args))
+                (loss * scale).backward()
+                opt.step(max_norm=35, loss_scale=scale)
+                losses.append(dict(log_vars))
+            torch.cuda.synchronize()
+            out[graphed] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()})
+            if graphed:
+                gt = m.__dict__['_graphed_trunk']
+                assert gt.disabled_reason is None and gt.captures == 1, (gt.disabled_reason, gt.captures)
+                assert sum(c.replays for c in gt.caps.values()) == 4
+            else:
+                assert '_graphed_trunk' not in m.__dict__
+    finally:
+        blocks.set_compute_dtype('f32')
+    for it, (a, b) in enumerate(zip(out[False][0], out[True][0])):
+        for k in a:
+            if dtype == 'f32':
+                assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+            else:
+                assert a[k] == b[k], (it, k, a[k], b[k])
+    for k, pa in out[False][1].items():
+        pb = out[True][1][k]
+        if dtype == 'f32':
+            assert (pa - pb).abs().max().item() <= 1e-5 * (pa.abs().max().item() + 1e-12), k
+        else:
+            assert torch.equal(pa, pb), (k, (pa - pb).abs().max().item())

@@ -53,6 +53,28 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
+    # HUNT_TRACE_S=t: every collective this rank posts is logged (thread, size, async); after t seconds without progress a
+    # daemon thread prints the tail of the log and the totals -- for a hang: do the two ranks stand at the same collective?
+    trace_s = float(os.environ.get('HUNT_TRACE_S', '0'))
+    if trace_s > 0:
+        import threading
+        import time
+        log, last = [], [time.time()]
+        orig_ar = dist.all_reduce
+
+        def traced(t, *a, **kw):
+            log.append((threading.current_thread().name, tuple(t.shape), str(t.dtype), bool(kw.get('async_op', False)), t.is_cuda))
+            last[0] = time.time()
+            return orig_ar(t, *a, **kw)
+        dist.all_reduce = traced
+
+        def watch():
+            while True:
+                time.sleep(5)
+                if time.time() - last[0] > trace_s:
+                    print(f'TRACE rank {rank}: {len(log)} collectives posted; last 14: {log[-14:]}', flush=True)
+                    return
+        threading.Thread(target=watch, daemon=True).start()
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     want = sys.argv[2].split(',') if len(sys.argv) > 2 else None
     dtype = os.environ.get('HUNT_DTYPE', 'f32')
@@ -136,7 +158,7 @@ def main():
             net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[local], broadcast_buffers=False)
         elif red_kind != 'none':
             cls = R04Reducer if red_kind == 'own_overlap_r04' else GradReducer
-            red = cls([p for p in m.parameters() if p.requires_grad], slice_mb=8, overlap=red_kind != 'own')
+            red = cls([p for p in m.parameters() if p.requires_grad], slice_mb=float(os.environ.get('HUNT_SLICE_MB', '8')), overlap=red_kind != 'own')
             red.broadcast_parameters(m)
             if cl:
                 from brcnn.blocks import conv_weights_channels_last
@@ -144,8 +166,13 @@ def main():
             A._TEST_STALL_CYCLES = stall_cycles
         ref = local_ref if red_kind == 'none' else mean_ref
         bad_reps, worst, reports = 0, 0.0, []
+        import time as _time
+        t_cell = _time.time()
         for r in range(reps):
+            t_rep = _time.time()
             g = step(m, net, red, bool(early))
+            if os.environ.get('HUNT_PROGRESS') == '1' and rank == 0 and _time.time() - t_rep > 5:
+                print(f'  SLOW rep {r} of {name}: {_time.time() - t_rep:.1f} s (cell so far {_time.time() - t_cell:.0f} s)', flush=True)
             bad = []
             for k, v in g.items():
                 d = (v - ref[k]).abs().max().item() / (ref[k].abs().max().item() + 1e-12)
