@@ -199,9 +199,11 @@ def train_bench(args, world, rank, device):
         model.early_rpn_backward = True
         model.early_backward_scale = scale
 
-    # backbone + neck, forward and backward, replayed from two HIP graphs from the second step on (brcnn/graphs.py): ~350 of
-    # the step's ~770 launches become two graph launches; off under DDP and with BRCNN_GRAPH_TRUNK=0
-    if net is model:
+    # BRCNN_BENCH_GRAPH_TRUNK=1: backbone + neck, forward and backward, replayed from two HIP graphs from the second step on
+    # (brcnn/graphs.py): ~350 of the step's ~770 launches become two graph launches and the host runs 12 ms ahead instead of
+    # 6 -- but ROCm 7.2 executes the captured weight-gradient branch serially with the main chain (20.0 ms per step against
+    # 18.1 eager, 19.4 eager without the second stream; profiles/r05_notes.md), so it stays OFF in the measured line
+    if net is model and os.environ.get('BRCNN_BENCH_GRAPH_TRUNK', '0') == '1':
         model.graph_trunk = True
 
     def step():

@@ -232,7 +232,7 @@ class EpochBasedRunner:
         self.loss_scaler, self.loss_scale = None, None      # fp16 recipes: static loss scaling (train_detector)
         self.reducer = None                                  # distributed.GradReducer (data parallel without DDP)
         self.early_rpn_backward = True                       # see _early_rpn_backward (cfg.early_rpn_backward)
-        self.graph_trunk = True                              # cfg.graph_trunk (brcnn/graphs.py)
+        self.graph_trunk = False                             # cfg.graph_trunk (brcnn/graphs.py): opt-in, see there
         # data parallel: compare the replicas' parameters bit for bit after every optimizer step (a host sync per
         # step: a debugging / test switch -- `check_replicas = True` in the config or BRCNN_CHECK_REPLICAS=1)
         self.check_replicas = os.environ.get('BRCNN_CHECK_REPLICAS', '0') == '1'
@@ -317,9 +317,9 @@ class EpochBasedRunner:
         if hasattr(type(m), 'early_rpn_backward'):
             m.early_rpn_backward = bool(on)
             m.early_backward_scale = float(self.loss_scale or 1.0)
-        # backbone + neck replayed from HIP graphs once an input shape repeats (brcnn/graphs.py): wherever the trunk's
-        # parameter gradients may be assigned directly (no DistributedDataParallel wrapper); `graph_trunk = False` in the
-        # config or BRCNN_GRAPH_TRUNK=0 keeps the eager launches
+        # `graph_trunk = True` in the config: backbone + neck replayed from HIP graphs once an input shape repeats
+        # (brcnn/graphs.py) wherever the trunk's parameter gradients may be assigned directly (no DistributedDataParallel
+        # wrapper).  Off by default: on ROCm 7.2 the replay is slower than the eager launches on a host that keeps up
         if hasattr(type(m), 'graph_trunk'):
             m.graph_trunk = bool(self.graph_trunk and not hasattr(m, 'module'))
         return on
@@ -498,7 +498,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     runner.timestamp = timestamp
     runner.reducer = reducer
     runner.early_rpn_backward = bool(cfg.get('early_rpn_backward', True))
-    runner.graph_trunk = bool(cfg.get('graph_trunk', True))
+    runner.graph_trunk = bool(cfg.get('graph_trunk', False))
     runner.check_replicas = bool(cfg.get('check_replicas', runner.check_replicas))
     if cfg.get('fp16', None) is not None:
         # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->

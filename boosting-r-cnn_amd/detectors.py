@@ -247,8 +247,9 @@ class TwoStageDetector(BaseDetector):
     early_rpn_backward = False
     early_backward_scale = 1.0
     # backbone + neck of the device-resident train step replayed from two HIP graphs (forward, backward) once an input
-    # shape has come up twice: brcnn/graphs.py.  OPT-IN like early_rpn_backward (bench.py's train leg and the runner
-    # switch it on): the trunk's parameter gradients are assigned by the graph's backward, not by AccumulateGrad nodes
+    # shape has come up twice: brcnn/graphs.py.  OPT-IN (the trunk's parameter gradients are assigned by the graph's
+    # backward, not by AccumulateGrad nodes) and off everywhere by default: measured slower than the eager launches on
+    # ROCm 7.2 unless the host is the bottleneck
     graph_trunk = False
 
     def _early_rpn_backward_ok(self, feats):

@@ -16,8 +16,8 @@ How (no tracing compiler: plain HIP stream capture of the launches the eager cod
 * graph F: `detector.extract_feat_nhwc(static_img)` with autograd recording -- the saved activations land in the
   graphs' private memory pool, at fixed addresses;
 * graph B: `torch.autograd.backward(feats, static_grad_outputs)` over that recording.  The weight-gradient kernels
-  write into an arena chunk allocated (and zero-filled: a memset node) inside the capture; what autograd hands to the
-  parameters as `.grad` during the capture are the STATIC gradient tensors of every later step;
+  write into an arena chunk allocated (and zero-filled: a memset node) inside the capture; the gradients
+  `torch.autograd.grad` returns for the parameters during the capture are the STATIC gradient tensors of every later step;
 * per step: `TrunkFunction.forward` copies the image into the static input (skipped when it already is that tensor),
   replays F and returns detached views of the static pyramid; `TrunkFunction.backward` copies the incoming pyramid
   gradients into the static buffers, replays B and assigns the static gradients to `param.grad` (accumulating where a
@@ -28,12 +28,20 @@ How (no tracing compiler: plain HIP stream capture of the launches the eager cod
 * the chained stream-K schedule is off under capture (conv_igemm_bf16.hip, `sk_plan`): its epoch flags are not
   replay-safe.  Same bits either way.
 
+MEASURED (round 5, one MI355X, bf16 step of bench.py, `profiles/r05_notes.md`): the replayed step is bit-identical to
+the eager one and the host runs 12.4 ms ahead of the device at the sampler's synchronisation instead of 6.0 -- but the
+step takes 20.0 ms instead of 18.1: ROCm 7.2's graph executor runs the captured weight-gradient branch serially with
+the main chain (the replay costs what the eager step costs WITHOUT the second stream, 19.4 ms, plus ~6 us per node;
+DEBUG_HIP_FORCE_GRAPH_QUEUES / DEBUG_HIP_GRAPH_BATCH_SIZE / DEBUG_CLR_GRAPH_PACKET_CAPTURE change nothing).  It
+therefore pays only where the host cannot keep up with ~770 launches per step, and is OFF by default everywhere.
+
 The capture is keyed by everything its addresses and branches depend on -- input shape and dtype, compute dtype,
 the fusion switches of `autograd`, the storage addresses of every parameter / buffer / packed conv operand of the
 trunk and each module's `training` flag -- and is redone when any of it changes (a handful of keys are kept: multi-scale
-training re-captures per shape).  Off by default; `detector.graph_trunk = True` (bench.py's train leg, the runner
-under FusedSGD) switches it on, BRCNN_GRAPH_TRUNK=0 vetoes it.
+training re-captures per shape).  Off by default; `detector.graph_trunk = True` (`graph_trunk = True` in a config for the
+runner, BRCNN_BENCH_GRAPH_TRUNK=1 for bench.py's train leg) switches it on, BRCNN_GRAPH_TRUNK=0 vetoes it.
 """
+import contextlib
 import os
 
 import torch
@@ -47,6 +55,38 @@ MAX_KEYS = 4            # captures kept at one time (the oldest goes first)
 MIN_SEEN = 2            # a key is captured when it comes up for the second time: a run whose input shape changes from
                         # batch to batch (aspect-ratio grouped padding) never pays for a capture it would use once
 MAX_CAPTURES = 16       # ... and a run that keeps cycling through more shapes than MAX_KEYS stops capturing
+
+
+@contextlib.contextmanager
+def _fresh_leaves(modules):
+    """every parameter of `modules` replaced, for the duration, by a NEW leaf that shares its storage (and its packed
+    conv operands).  Why: autograd caches a leaf's gradient accumulator node, and a node remembers the stream it was
+    created on.  A parameter that took part in any eager step has its accumulator on the DEFAULT stream (kept alive by
+    whatever still holds that step's graph: log scalars, outputs); `torch.autograd.grad(..., inputs=params)` inside a
+    capture then makes the engine synchronise the default stream with the capturing one -- which drags the NULL stream
+    into the capture (`hipStreamWaitEvent(stream:<null>, ...)` in the runtime's trace) and `hipStreamEndCapture`
+    segfaults.  Leaves born inside the capture's own forward pass get their accumulators on the capture stream.
+    Yields {id(original): alias}."""
+    alias, undo = {}, []
+    for root in modules:
+        for m in root.modules():
+            for name, p in list(m._parameters.items()):
+                if p is None:
+                    continue
+                a = alias.get(id(p))
+                if a is None:
+                    a = torch.nn.Parameter(p.detach(), requires_grad=p.requires_grad)
+                    pk = getattr(p, '_brcnn_pack', None)
+                    if pk is not None:
+                        a._brcnn_pack = pk
+                    alias[id(p)] = a
+                undo.append((m, name, p))
+                m._parameters[name] = a
+    try:
+        yield alias
+    finally:
+        for m, name, p in undo:
+            m._parameters[name] = p
 
 
 class _Captured:
@@ -150,33 +190,35 @@ class GraphedTrunk:
         try:
             _A.grad_arena.listener = None               # (a gradient reducer must not see, let alone slice, the capture)
             _A._side_streams[skey] = self._side         # the capture's own weight-gradient stream (own conv scratch)
-            # warm-up on the capture stream: lazy one-off work (conv scratch registration, kernel attributes, folded
-            # BatchNorm caches, schedule tables) must not fall into the capture
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    for p in params:
-                        p.grad = None
-                    _A.grad_arena.new_step()
+            with _fresh_leaves(self._modules()) as alias:
+                leaves = [alias[id(p)] for p in params]
+                # warm-up on the capture stream: lazy one-off work (conv scratch registration, kernel attributes, folded
+                # BatchNorm caches, schedule tables) must not fall into the capture
+                s.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        _A.grad_arena.new_step()
+                        feats = det.extract_feat_nhwc(cap.static_img)
+                        torch.autograd.grad(feats, leaves, [torch.zeros_like(f) for f in feats], allow_unused=True)
+                        _A.join_side_streams(dev)
+                    del feats
+                torch.cuda.current_stream(dev).wait_stream(s)
+                torch.cuda.synchronize(dev)
+                cap.fwd, cap.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cap.fwd, stream=s):
                     feats = det.extract_feat_nhwc(cap.static_img)
-                    torch.autograd.backward(feats, [torch.zeros_like(f) for f in feats])
-                    _A.join_side_streams(dev)
-                for p in params:
-                    p.grad = None
-                cap.gouts = None
-            torch.cuda.current_stream(dev).wait_stream(s)
-            torch.cuda.synchronize(dev)
-            cap.fwd, cap.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cap.fwd, stream=s):
-                feats = det.extract_feat_nhwc(cap.static_img)
-            cap.feats = tuple(feats)
-            cap.gouts = [torch.zeros_like(f) for f in cap.feats]
-            with torch.cuda.graph(cap.bwd, pool=cap.fwd.pool(), stream=s):
-                _A.grad_arena.new_step()                 # a chunk of its own, zero-filled by a memset node of the graph
-                torch.autograd.backward(cap.feats, cap.gouts)
-                _A.join_side_streams(dev)
-            cap.grads = [(p, p.grad) for p in params if p.grad is not None]
+                cap.feats = tuple(feats)
+                cap.gouts = [torch.zeros_like(f) for f in cap.feats]
+                with torch.cuda.graph(cap.bwd, pool=cap.fwd.pool(), stream=s):
+                    _A.grad_arena.new_step()             # a chunk of its own, zero-filled by a memset node of the graph
+                    # (autograd.grad over the fresh leaves: no AccumulateGrad node of an earlier eager step, see
+                    # _fresh_leaves.  The side stream is joined by the end-of-pass callback of the weight-gradient launches
+                    # that forked it; an explicit join here would make the capture wait for a stream that never entered it
+                    # when no launch did)
+                    grads = torch.autograd.grad(cap.feats, leaves, cap.gouts, allow_unused=True)
+            cap.grads = [(p, g if g.dtype == p.dtype else g.to(p.dtype)) for p, g in zip(params, grads) if g is not None]
             cap.feats = tuple(f.detach() for f in cap.feats)     # (drop the capture-time autograd graph)
+            del feats, grads, leaves
         finally:
             if eager_side is None:
                 _A._side_streams.pop(skey, None)

