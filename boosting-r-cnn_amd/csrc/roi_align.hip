@@ -463,6 +463,209 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_fp_kernel(
     for (int ph = ph_begin; ph < ph_end; ph++) do_row(ph);
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 5: prepared records.  The footprint kernel above spends ~700 instructions per wave on the level mapping
+// (sqrt, log2), the RoI geometry (divisions, ceil) and the x-axis weights of the seven bins BEFORE its first load --
+// the same values for all seven bin rows of a RoI, recomputed by seven waves; one wave walking all seven rows (RPW)
+// shares them but leaves a seventh of the waves to hide the gather latency and was 10-80 % slower.  Here a small
+// first launch (one wave per RoI) writes them to a 576-byte record, and the streaming launch (one wave per bin row,
+// as before) starts from one coalesced 256-byte load of the x weights and a few scalar loads.
+//
+//   record of RoI k, 32-bit words:  [0..63]  x weight by lane (lane = 8 * bin + slot)
+//                                   [64] level  [65] image  [66] flags: bit ph = bin row ph takes the streaming form
+//                                   [67] 1 / sample count (float)
+//                                   [68..75] first footprint column of bin b   [76..83] footprint columns of bin b
+//                                   [84..91] first footprint row of bin row ph [92..99] footprint rows of bin row ph
+//                                   [100..131] y weights, 4 per bin row
+// A bin row that does not fit the streaming form (a bin wider than 8 footprint columns, more than 4 footprint rows:
+// bins beyond ~3 px, which the level mapping makes rare) takes the sample loop in the reference's own order.
+// ---------------------------------------------------------------------------------------
+constexpr int REC_WORDS = 144;
+
+__global__ __launch_bounds__(256) void roi_prep_kernel(LevelTable lv, const float* __restrict__ rois, int32_t* __restrict__ recs,
+                                                       int32_t* __restrict__ levels_out, int n_rois, int ph_n, int pw_n,
+                                                       int sampling_ratio) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= n_rois) return;
+    const float* roi = rois + (size_t)k * 5;
+    const int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
+    const int height = lv.height[l], width = lv.width[l];
+    const RoiGeom g = roi_geom(roi, lv.scale[l], 1, ph_n, pw_n, sampling_ratio);
+    const bool small = g.gh <= 64 && g.gw <= 64;
+    const int q = lane >> 3, jx = lane & 7;
+    int x0_all = 0, nx_all = 0;
+    float Wx_all = 0.f;
+    bool vecx = small && g.gw <= 8 && pw_n <= 8 && ph_n <= 8;
+    if (vecx) {
+        const float v = g.start_w + q * g.bin_w + (float)(jx + .5f) * g.bin_w / (float)g.gw;
+        const AxisSample a = axis_sample(v, width);
+        const bool live = jx < g.gw && q < pw_n && a.valid;
+        const unsigned mg = (unsigned)((__ballot(live) >> (q * 8)) & 0xffull);
+        if (mg) {
+            const int f = __ffs((int)mg) - 1, lst = 31 - __clz((int)mg);
+            x0_all = __shfl(a.lo, q * 8 + f);
+            nx_all = __shfl(a.hi, q * 8 + lst) - x0_all + 1;
+        }
+        const int mine = x0_all + jx;
+        float w = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int lo = __shfl(a.lo, q * 8 + i), hi = __shfl(a.hi, q * 8 + i);
+            const float wl = __shfl(a.wlo, q * 8 + i), wh = __shfl(a.whi, q * 8 + i);
+            if ((mg >> i) & 1u) {
+                if (lo == mine) w += wl;
+                if (hi == mine) w += wh;
+            }
+        }
+        Wx_all = w;
+        if (__ballot(nx_all > 8) != 0ull) vecx = false;
+    }
+    int32_t* rec = recs + (size_t)k * REC_WORDS;
+    rec[lane] = __float_as_int(Wx_all);
+    if (jx == 0) {
+        rec[68 + q] = x0_all;
+        rec[76 + q] = q < pw_n ? nx_all : 0;
+    }
+    unsigned flags = 0;
+    for (int ph = 0; ph < ph_n && ph < 8; ph++) {
+        int y0 = 0, ny = 0;
+        float Wy = 0.f;
+        if (small) axis_weights(g.start_h, g.bin_h, ph, g.gh, height, lane, y0, ny, Wy);
+        if (lane == 0) {
+            rec[84 + ph] = y0;
+            rec[92 + ph] = ny;
+        }
+        if (lane < 4) rec[100 + ph * 4 + lane] = __float_as_int(lane < ny ? Wy : 0.f);
+        if (vecx && ny <= 4) flags |= 1u << ph;
+    }
+    if (lane == 0) {
+        rec[64] = l;
+        rec[65] = g.batch;
+        rec[66] = (int)flags;
+        rec[67] = __float_as_int(1.f / g.count);
+        if (levels_out) levels_out[k] = l;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_rec_kernel(LevelTable lv, const float* __restrict__ rois,
+                                                                const int32_t* __restrict__ recs, T* __restrict__ output,
+                                                                int channels, int n_rois, int ph_n, int pw_n, int sampling_ratio,
+                                                                const int32_t* __restrict__ perm) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD x (= blockIdx % 8) takes a CONTIGUOUS eighth of the bin rows (one image's maps per L2 at batch 8)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const long long unit = (long long)bid * 4 + wave;
+    if (unit >= (long long)n_rois * ph_n) return;
+    const int kk = (int)(unit / ph_n);
+    const int ph = (int)(unit - (long long)kk * ph_n);
+    const int k = __builtin_amdgcn_readfirstlane(perm ? perm[kk] : kk);
+    const int32_t* rec = recs + (size_t)k * REC_WORDS;
+    const int l = __builtin_amdgcn_readfirstlane(rec[64]);
+    const int batch = __builtin_amdgcn_readfirstlane(rec[65]);
+    const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane(rec[66]);
+    const int height = lv.height[l], width = lv.width[l];
+    const T* base = reinterpret_cast<const T*>(lv.feat[l]) + (size_t)batch * height * width * channels;
+    T* out_row = output + ((size_t)k * ph_n + ph) * pw_n * channels;
+    if (!((flags >> ph) & 1u)) {
+        // not the streaming form: the sample loop, the reference's operation order
+        const float* roi = rois + (size_t)k * 5;
+        const RoiGeom g = roi_geom(roi, lv.scale[l], 1, ph_n, pw_n, sampling_ratio);
+        for (int pw = 0; pw < pw_n; pw++) {
+            T* out = out_row + (size_t)pw * channels;
+            for (int c0 = lane * 4; c0 < channels; c0 += 256) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int iy = 0; iy < g.gh; iy++) {
+                    const float y = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.gh;
+                    for (int ix = 0; ix < g.gw; ix++) {
+                        const float x = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.gw;
+                        const Tap t = bilinear_tap(y, x, height, width);
+                        if (!t.valid) continue;
+                        const float4 v1 = ld4(base + (size_t)t.p1 * channels + c0);
+                        const float4 v2 = ld4(base + (size_t)t.p2 * channels + c0);
+                        const float4 v3 = ld4(base + (size_t)t.p3 * channels + c0);
+                        const float4 v4 = ld4(base + (size_t)t.p4 * channels + c0);
+                        acc.x += t.w1 * v1.x + t.w2 * v2.x + t.w3 * v3.x + t.w4 * v4.x;
+                        acc.y += t.w1 * v1.y + t.w2 * v2.y + t.w3 * v3.y + t.w4 * v4.y;
+                        acc.z += t.w1 * v1.z + t.w2 * v2.z + t.w3 * v3.z + t.w4 * v4.z;
+                        acc.w += t.w1 * v1.w + t.w2 * v2.w + t.w3 * v3.w + t.w4 * v4.w;
+                    }
+                }
+                acc.x /= g.count; acc.y /= g.count; acc.z /= g.count; acc.w /= g.count;
+                st4(out + c0, acc);
+            }
+        }
+        return;
+    }
+    const float Wx_all = __int_as_float(rec[lane]);
+    const float inv = __int_as_float(__builtin_amdgcn_readfirstlane(rec[67]));
+    int bx0[8], bnx[8];
+    int X0 = 0x7fffffff, X1 = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        bx0[b] = __builtin_amdgcn_readfirstlane(rec[68 + b]);
+        bnx[b] = b < pw_n ? __builtin_amdgcn_readfirstlane(rec[76 + b]) : 0;
+        if (bnx[b] > 0) { X0 = min(X0, bx0[b]); X1 = max(X1, bx0[b] + bnx[b]); }
+    }
+    const int y0u = __builtin_amdgcn_readfirstlane(rec[84 + ph]);
+    const int ny = __builtin_amdgcn_readfirstlane(rec[92 + ph]);
+    float wy[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) wy[r] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[100 + ph * 4 + r]));
+    constexpr int CB = 2;
+    for (int c0 = lane * 4; c0 < channels; c0 += 256) {
+        float4 acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ny > 0) {
+            const T* r0 = base + (size_t)y0u * width * channels;
+            const size_t rstride = (size_t)width * channels;
+            const unsigned lane_off = (unsigned)c0;
+            for (int cx = X0; cx < X1; cx += CB) {
+                float4 v[4][CB];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int j = 0; j < CB; j++)
+                        if (r < ny && cx + j < X1) v[r][j] = ld4(r0 + r * rstride + (size_t)(cx + j) * channels + lane_off);
+#pragma unroll
+                for (int j = 0; j < CB; j++) {
+                    if (cx + j >= X1) break;
+                    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (r < ny) {
+                            cs.x += wy[r] * v[r][j].x; cs.y += wy[r] * v[r][j].y;
+                            cs.z += wy[r] * v[r][j].z; cs.w += wy[r] * v[r][j].w;
+                        }
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const int jj = cx + j - bx0[b];
+                        if (jj >= 0 && jj < bnx[b]) {
+                            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Wx_all), b * 8 + jj));
+                            acc[b].x += w * cs.x; acc[b].y += w * cs.y; acc[b].z += w * cs.z; acc[b].w += w * cs.w;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+            if (b < pw_n) {
+                float4 o = acc[b];
+                o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                st4(out_row + (size_t)b * channels + c0, o);
+            }
+    }
+}
+
 int g_roi_exact = 0;     // 1: exact sample-order kernel (bit-identical to the reference's CPU order)
 int g_roi_stream_c = 3;  // footprint kernel: bit 0 column streaming over the bin row's patch (else the per-bin loop), bit 1 XCD-contiguous rows
 
@@ -717,6 +920,8 @@ __global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict
 }
 
 constexpr int ROI_ORDER_MIN_ROIS = 12288;        // brcnn_roi_extract_order_min_rois(): what the caller sizes its scratch by
+int g_roi_prep = 0;      // ... (30 / 31): prepared-record form off / on where the caller provides its scratch.  OFF: measured
+                         // slower below 1000 RoIs / image (profiles/r05_notes.md)
 int g_roi_rpw = 0;       // tuning hook (set_exact(10 / 11 / 17)): rows per wave by the heuristic / 1 / all
 int g_roi_order = 1;     // ... (20 / 21 / 22): never / where a workspace is given and the RoI count pays for the sort / always
 
@@ -724,7 +929,8 @@ template <typename T>
 static int extract_forward_impl(const void* const* feats_host, const int* heights_host, const int* widths_host,
                                 const float* scales_host, int num_levels, const float* rois, void* output,
                                 int32_t* levels_out, int batch, int channels, int n_rois, int pooled_h, int pooled_w,
-                                int sampling_ratio, float finest_scale, int32_t* order_ws, hipStream_t s) {
+                                int sampling_ratio, float finest_scale, int32_t* order_ws, hipStream_t s,
+                                int32_t* prep_ws = nullptr, size_t prep_bytes = 0) {
     LevelTable lv = {};
     if (fill_levels(lv, (const float* const*)feats_host, nullptr, heights_host, widths_host, scales_host,
                     num_levels, finest_scale))
@@ -749,6 +955,17 @@ static int extract_forward_impl(const void* const* feats_host, const int* height
         hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, s, rois, n_rois, lv, batch, order_ws);
         BRCNN_LAUNCH_CHECK();
         perm = order_ws;
+    }
+    if (prep_ws && g_roi_prep && pooled_h <= 8 && pooled_w <= 8 && prep_bytes >= (size_t)n_rois * REC_WORDS * sizeof(int32_t)) {
+        // prepared records: level mapping, geometry and axis weights once per RoI (one small launch), then one wave per
+        // bin row that starts from its RoI's record
+        hipLaunchKernelGGL(roi_prep_kernel, dim3(brcnn_cdiv((long long)n_rois, 4)), dim3(256), 0, s, lv, rois, prep_ws, levels_out,
+                           n_rois, pooled_h, pooled_w, sampling_ratio);
+        BRCNN_LAUNCH_CHECK();
+        hipLaunchKernelGGL((roi_align_fwd_rec_kernel<T>), dim3(brcnn_cdiv((long long)n_rois * pooled_h, 4)), dim3(256), 0, s, lv,
+                           rois, prep_ws, (T*)output, channels, n_rois, pooled_h, pooled_w, sampling_ratio, perm);
+        BRCNN_LAUNCH_CHECK();
+        return 0;
     }
     const bool all_rows = pooled_h == 7 && g_roi_rpw == 17;
     if (all_rows)
@@ -782,6 +999,45 @@ BRCNN_API int brcnn_roi_extract_forward_ordered(const void* const* feats_host, c
                                            batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s);
     return extract_forward_impl<float>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
                                        batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s);
+}
+
+// bytes of caller-owned scratch the prepared-record form wants (one 576-byte record per RoI); 0 while that form is
+// switched off (the default): the caller then passes NULL
+BRCNN_API size_t brcnn_roi_extract_prep_workspace_bytes(int n_rois) {
+    return (n_rois > 0 && g_roi_prep) ? (size_t)n_rois * REC_WORDS * sizeof(int32_t) : 0;
+}
+
+// RoI count from which the library visits the RoIs in band order when `order_ws` is given (what the caller sizes that
+// scratch by: below it a NULL `order_ws` costs nothing)
+BRCNN_API int brcnn_roi_extract_order_min_rois(void) { return ROI_ORDER_MIN_ROIS; }
+
+// brcnn_roi_extract_forward_ordered + `prep_ws` (brcnn_roi_extract_prep_workspace_bytes(n_rois) bytes, caller-owned, or
+// NULL): the per-RoI level mapping / geometry / axis weights are computed once per RoI by a small first launch instead of
+// once per bin row inside the gather.  Same results as the footprint form (bit for bit on the bin rows that take the
+// streaming form; the rare others run the reference's sample loop).
+BRCNN_API int brcnn_roi_extract_forward_prepared(const void* const* feats_host, const int* heights_host,
+                                                 const int* widths_host, const float* scales_host,
+                                                 int num_levels, const float* rois, void* output,
+                                                 int32_t* levels_out, int batch, int channels, int n_rois,
+                                                 int pooled_h, int pooled_w, int sampling_ratio,
+                                                 float finest_scale, int dtype, int32_t* order_ws, void* prep_ws,
+                                                 size_t prep_bytes, void* stream) {
+    if (!brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
+    if (!feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0)
+        return BRCNN_EINVAL;
+    if (prep_ws && ((uintptr_t)prep_ws & 255)) return BRCNN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == BRCNN_DT_BF16)
+        return extract_forward_impl<bf16_t>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
+                                            batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s,
+                                            (int32_t*)prep_ws, prep_bytes);
+    if (dtype == BRCNN_DT_F16)
+        return extract_forward_impl<f16_t>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
+                                           batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s,
+                                           (int32_t*)prep_ws, prep_bytes);
+    return extract_forward_impl<float>(feats_host, heights_host, widths_host, scales_host, num_levels, rois, output, levels_out,
+                                       batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, finest_scale, order_ws, s,
+                                       (int32_t*)prep_ws, prep_bytes);
 }
 
 BRCNN_API int brcnn_roi_extract_forward(const void* const* feats_host, const int* heights_host,
@@ -1087,6 +1343,7 @@ BRCNN_API int brcnn_roi_align_set_exact(int exact) {
     // 10 / 11 / 17: bin rows per wavefront by the heuristic / one / all seven; 20 / 21 / 22: RoI visiting order off / by the heuristic / forced
     if (exact == 10 || exact == 11 || exact == 17) { g_roi_rpw = exact == 10 ? 0 : exact; return 0; }
     if (exact >= 20 && exact <= 22) { g_roi_order = exact - 20; return 0; }
+    if (exact == 30 || exact == 31) { g_roi_prep = exact - 30; return 0; }
     g_roi_exact = exact == 1 ? 1 : 0;
     g_roi_stream_c = exact == 2 ? 0 : exact == 3 ? 1 : 3;
     return 0;

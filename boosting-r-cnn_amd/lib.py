@@ -25,6 +25,10 @@ SIGNATURES = {
                                   [c_f32, c_int, c_ptr]),
     'brcnn_roi_extract_forward_ordered': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
                                           [c_f32, c_int, c_ptr, c_ptr]),
+    'brcnn_roi_extract_prep_workspace_bytes': (c_size, [c_int]),
+    'brcnn_roi_extract_order_min_rois': (c_int, []),
+    'brcnn_roi_extract_forward_prepared': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
+                                           [c_f32, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     'brcnn_roi_extract_backward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 +
                                    [c_f32, c_ptr]),
     'brcnn_roi_extract_backward_workspace_bytes': (c_size, [c_int]),

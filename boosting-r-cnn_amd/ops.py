@@ -169,6 +169,15 @@ class RoIAlign(nn.Module):
                 f'use_torchvision={self.use_torchvision})')
 
 
+_ROI_ORDER_MIN = []
+
+
+def _roi_order_min_rois():
+    if not _ROI_ORDER_MIN:
+        _ROI_ORDER_MIN.append(int(_L.load().brcnn_roi_extract_order_min_rois()))
+    return _ROI_ORDER_MIN[0]
+
+
 def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56, sampling_ratio=0):
     """Fused SingleRoIExtractor.forward (single_level_roi_extractor.py:57-115): level mapping
     + RoIAlign of every RoI on its own level in one launch.  `feats_nhwc`: list of (N,H,W,C)
@@ -189,13 +198,16 @@ def roi_extract(feats_nhwc, rois, output_size, featmap_strides, finest_scale=56,
     hs = (ctypes.c_int * L)(*[f.shape[1] for f in feats_nhwc])
     ws = (ctypes.c_int * L)(*[f.shape[2] for f in feats_nhwc])
     sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
-    # from a few thousand RoIs on the kernel visits them band by band of their maps: the caller provides the scratch of the
-    # visiting order (n int32)
-    order = torch.empty((k,), dtype=torch.int32, device=rois.device) if k >= 2048 else None       # (the library orders from 12 288 RoIs on)
-    st = _L.load().brcnn_roi_extract_forward_ordered(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out),
-                                                     _ptr(levels), n, c, k, ph, pw, int(sampling_ratio),
-                                                     float(finest_scale), dt, _ptr(order), _stream())
-    _L.check(st, 'brcnn_roi_extract_forward_ordered')
+    lib = _L.load()
+    # caller-owned scratch: the visiting order (n int32) from the RoI count at which the library orders them, and the
+    # per-RoI records of the prepared form (level mapping / geometry / axis weights once per RoI instead of per bin row)
+    order = torch.empty((k,), dtype=torch.int32, device=rois.device) if k >= _roi_order_min_rois() else None
+    nb = int(lib.brcnn_roi_extract_prep_workspace_bytes(k))          # 0 while the prepared form is off (the default)
+    prep = torch.empty(nb, dtype=torch.uint8, device=rois.device) if nb else None
+    st = lib.brcnn_roi_extract_forward_prepared(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(out), _ptr(levels), n, c, k, ph, pw,
+                                                int(sampling_ratio), float(finest_scale), dt, _ptr(order), _ptr(prep), nb,
+                                                _stream())
+    _L.check(st, 'brcnn_roi_extract_forward_prepared')
     return out, levels
 
 

@@ -104,6 +104,24 @@ int brcnn_roi_extract_forward_ordered(const void *const *feats_host, const int *
                               int sampling_ratio, float finest_scale,
                               int dtype /* of feats and output */, int32_t *order_ws, void *stream);
 
+/* Round 5: the same with `prep_ws` -- brcnn_roi_extract_prep_workspace_bytes(n_rois) bytes of caller-owned scratch,
+ * 256-byte aligned, or NULL.  With it the level mapping (single_level_roi_extractor.py:36-55), the RoI geometry and the
+ * per-axis bilinear weights are computed once per RoI by a small first launch and handed to the gather through a
+ * 576-byte record per RoI, instead of once per bin row inside the gather.  Results: those of the footprint form (bit
+ * for bit on the bin rows that take its streaming path; the others run the reference's sample loop).  Measured
+ * (profiles/r05_notes.md) faster only from ~1000 RoIs per image on, so the form is OFF by default
+ * (brcnn_roi_align_set_exact(31) switches it on): brcnn_roi_extract_prep_workspace_bytes returns 0 while it is off. */
+size_t brcnn_roi_extract_prep_workspace_bytes(int n_rois);
+int brcnn_roi_extract_forward_prepared(const void *const *feats_host, const int *heights_host,
+                              const int *widths_host, const float *scales_host, int num_levels,
+                              const float *rois, void *output, int32_t *levels_out, int batch,
+                              int channels, int n_rois, int pooled_h, int pooled_w,
+                              int sampling_ratio, float finest_scale,
+                              int dtype /* of feats and output */, int32_t *order_ws, void *prep_ws,
+                              size_t prep_bytes, void *stream);
+/* the RoI count from which a non-NULL `order_ws` is used (below it the RoIs are visited as given) */
+int brcnn_roi_extract_order_min_rois(void);
+
 int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights_host,
                                const int *widths_host, const float *scales_host, int num_levels,
                                const float *rois, const float *grad_output, int batch,

@@ -1045,6 +1045,7 @@ def test_roi_extract_visiting_order_and_rows_per_wave_keep_the_bits():
     feats = [torch.randn(B, h, w, 256, generator=g).to(DEV) for h, w in sizes]
     rois = util.rand_rois(7000, B, 672., 400., seed=4, min_size=4., max_size=500.).to(DEV)     # unsorted images, tiny and huge RoIs
     try:
+        L.brcnn_roi_align_set_exact(30)      # the footprint form itself (round 5's prepared records off)
         L.brcnn_roi_align_set_exact(11); L.brcnn_roi_align_set_exact(20)
         ref, lref = ops.roi_extract(feats, rois, 7, strides, 56, 0)
         for rpw in (11, 17):
@@ -1067,6 +1068,76 @@ def test_roi_extract_visiting_order_and_rows_per_wave_keep_the_bits():
         assert torch.equal(out, ref) and torch.equal(order.sort().values, torch.arange(n, dtype=torch.int32, device=DEV))
     finally:
         L.brcnn_roi_align_set_exact(10); L.brcnn_roi_align_set_exact(21); L.brcnn_roi_align_set_exact(0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_roi_extract_prepared_records_equal_the_footprint_form(dtype):
+    """round 5: level mapping / geometry / axis weights once per RoI (roi_prep_kernel -> a 576-byte record), one wave
+    per bin row starting from the record.  Same arithmetic on the bin rows of the streaming form: bit-identical to the
+    footprint kernel; the other bin rows (bins beyond ~3 px: forced here with RoIs far larger than their level expects)
+    run the reference's sample loop -- equal to fp32 round-off.  Levels identical; unsorted images, tiny, huge, degenerate
+    and out-of-image RoIs; with and without the visiting order; NULL scratch falls back; against the C oracle."""
+    import ctypes
+    from oracle import orc
+    from brcnn import lib
+    L = lib.load()
+    B = 3
+    strides = [8, 16, 32, 64]
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    g = torch.Generator().manual_seed(12)
+    feats32 = [torch.randn(B, h, w, 256, generator=g) for h, w in sizes]
+    feats = [f.to(DEV, dtype) for f in feats32]
+    rois = util.rand_rois(5000, B, 672., 400., seed=4, min_size=4., max_size=500.)
+    extra = torch.tensor([[0, -50., -40., 700., 500.], [1, 10., 10., 10., 10.], [2, 660., 390., 672., 400.],
+                          [1, 300., 200., 280., 180.], [0, 0., 0., 671., 2.], [2, 0., 0., 3., 399.]])
+    rois = torch.cat([rois, extra]).to(DEV)
+    try:
+        L.brcnn_roi_align_set_exact(30)
+        ref, lref = ops.roi_extract(feats, rois, 7, strides, 56, 0)
+        for od in (20, 22):
+            L.brcnn_roi_align_set_exact(31); L.brcnn_roi_align_set_exact(od)
+            out, lv = ops.roi_extract(feats, rois, 7, strides, 56, 0)
+            assert torch.equal(lv, lref)
+            differ = (out != ref).flatten(1).any(1)
+            assert differ.float().mean().item() < 0.2, differ.float().mean().item()      # most RoIs: the streaming form, same bits
+            tol = 2e-6 if dtype == torch.float32 else 8e-3
+            err = (out.float() - ref.float()).abs().max().item()
+            assert err <= tol * max(1.0, ref.float().abs().max().item()), err
+        # against the C oracle (fp32 pyramid), per level as SingleRoIExtractor does
+        if dtype == torch.float32:
+            cpu_rois = rois.cpu()
+            for lvl in range(4):
+                idx = (lref.cpu() == lvl).nonzero().squeeze(1)[:300]
+                want = orc.roi_align_forward(feats32[lvl].permute(0, 3, 1, 2).contiguous(), cpu_rois[idx], 7, 1.0 / strides[lvl], 0,
+                                             'avg', True)
+                got = out[idx.to(DEV)].permute(0, 3, 1, 2).cpu()
+                assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()), lvl
+        # raw C ABI: NULL scratch = the footprint form; a scratch that is too small or misaligned is refused / ignored
+        n = rois.shape[0]
+        ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        hs = (ctypes.c_int * 4)(*[h for h, _ in sizes]); ws = (ctypes.c_int * 4)(*[w for _, w in sizes])
+        sc = (ctypes.c_float * 4)(*[1.0 / s for s in strides])
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 3}[dtype]
+        o2 = torch.empty_like(ref)
+        st = L.brcnn_roi_extract_forward_prepared(ptrs, hs, ws, sc, 4, rois.data_ptr(), o2.data_ptr(), None, B, 256, n, 7, 7, 0,
+                                                  56.0, dt, None, None, 0, lib.raw_stream_handle())
+        torch.cuda.synchronize()
+        assert st == 0 and torch.equal(o2, ref)
+        nb = L.brcnn_roi_extract_prep_workspace_bytes(n)
+        assert nb == n * 576
+        L.brcnn_roi_align_set_exact(30)
+        assert L.brcnn_roi_extract_prep_workspace_bytes(n) == 0         # off (the default): the caller need not allocate
+        L.brcnn_roi_align_set_exact(31)
+        wsb = torch.empty(nb + 256, dtype=torch.uint8, device=DEV)
+        st = L.brcnn_roi_extract_forward_prepared(ptrs, hs, ws, sc, 4, rois.data_ptr(), o2.data_ptr(), None, B, 256, n, 7, 7, 0,
+                                                  56.0, dt, None, wsb.data_ptr() + 4, nb, lib.raw_stream_handle())
+        assert st == -22                                         # misaligned scratch
+        assert L.brcnn_roi_extract_order_min_rois() == 12288
+        # no RoIs at all
+        e, le = ops.roi_extract(feats, rois[:0], 7, strides, 56, 0)
+        assert e.shape == (0, 7, 7, 256) and le.numel() == 0
+    finally:
+        L.brcnn_roi_align_set_exact(21); L.brcnn_roi_align_set_exact(30)
 
 
 @pytest.mark.parametrize('cfg', [

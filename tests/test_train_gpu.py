@@ -696,7 +696,7 @@ def test_fused_sgd_matches_torch_sgd_with_clipping(channels_last):
     assert set(oa.state_dict()['state'][0].keys()) == {'momentum_buffer'}
 
 
-@pytest.mark.parametrize('dtype,early', [('bf16', True), ('bf16', False), ('f32', True), ('f16', True)])
+@pytest.mark.parametrize('dtype,early', [('bf16', True), ('bf16', False), ('f16', True)])
 def test_graphed_trunk_trains_like_the_eager_trunk(dtype, early):
     """`graph_trunk`: backbone + neck, forward and backward, replayed from two HIP graphs (brcnn/graphs.py) against the
     eager launches of the same kernels -- two models from the same seed, FusedSGD + clipping, five steps each on the
@@ -750,3 +750,44 @@ def test_graphed_trunk_trains_like_the_eager_trunk(dtype, early):
             assert (pa - pb).abs().max().item() <= 1e-4 * (pa.abs().max().item() + 1e-12), k
         else:
             assert torch.equal(pa, pb), (k, (pa - pb).abs().max().item())
+
+
+def test_graphed_trunk_fp32_step_equals_the_eager_step():
+    """fp32: the weight-gradient kernel accumulates with atomics, so two runs of the SAME step differ by ~2e-7 of a
+    gradient's largest entry, and a trajectory of SGD steps over random weights amplifies that through the proposal
+    stage's thresholds -- the comparison is per step instead: from the same parameters, inputs and sampler seed the step
+    with the replayed trunk gives the eager step's losses (1e-6) and gradients (2e-5 of the largest entry), three
+    replays in a row"""
+    m = _model()
+    from brcnn import blocks
+    blocks.conv_weights_channels_last(m)
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=10)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    m.early_rpn_backward = True
+
+    def step(graphed):
+        m.graph_trunk = graphed
+        m.zero_grad(set_to_none=True)
+        from brcnn import autograd as A
+        A.grad_arena.new_step()
+        torch.manual_seed(77)
+        loss, log_vars = m._parse_losses(m.forward_train(*args))
+        loss.backward()
+        A.join_side_streams()
+        torch.cuda.synchronize()
+        return dict(log_vars), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    try:
+        ref = step(False)
+        step(True)                      # first sight of the key: still eager
+        for _ in range(3):
+            cur = step(True)
+            for k, v in ref[0].items():
+                assert abs(v - cur[0][k]) <= 1e-6 * max(1.0, abs(v)), (k, v, cur[0][k])
+            assert cur[1].keys() == ref[1].keys()
+            for k, g in ref[1].items():
+                d = (cur[1][k] - g).abs().max().item()
+                assert d <= 2e-5 * (g.abs().max().item() + 1e-12), (k, d)
+        gt = m.__dict__['_graphed_trunk']
+        assert gt.captures == 1 and sum(c.replays for c in gt.caps.values()) == 3 and gt.disabled_reason is None
+    finally:
+        m.graph_trunk, m.early_rpn_backward = False, False
