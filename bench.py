@@ -286,7 +286,7 @@ def inference_bench(args, world, rank, device):
     from brcnn import lib as _lib
     _lib.handover_status()          # a lost stream-K hand-over inside the timed steps is an error, not a number
     from brcnn import profiling
-    roof = profiling.conv_stack_roofline(model, img, metas, iters=3, dtype=args.dtype)
+    roof = profiling.conv_stack_roofline(model, img, metas, iters=5, dtype=args.dtype)
 
     def device_pass():
         with torch.no_grad():

@@ -120,18 +120,20 @@ def record_conv_launches(records):
         ops.conv2d_nhwc_multi = orig_multi
 
 
-def conv_stack_roofline(model, img, metas, iters=3, dtype='f32'):
-    """returns the `roofline` object of the bench line for the conv/FC stack"""
-    best = None
+def conv_stack_roofline(model, img, metas, iters=5, dtype='f32'):
+    """returns the `roofline` object of the bench line for the conv/FC stack: HIP-event time of every conv / FC launch
+    of one pass, the MEDIAN pass of `iters` (round 4 reported the best of three, which sat 3 % above what the rocprofv3
+    kernel statistics of the same command average to; the best pass stays in the line as `frac_best`)"""
+    runs = []
     for _ in range(iters):
         recs = []
         with record_conv_launches(recs), torch.no_grad():
             model.simple_test_device(img, metas, rescale=True)
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, *_ in recs)
-        if best is None or ms < best[0]:
-            best = (ms, recs)
-    ms, recs = best
+        runs.append((sum(s.elapsed_time(e) for s, e, *_ in recs), recs))
+    runs.sort(key=lambda t: t[0])
+    ms_best = runs[0][0]
+    ms, recs = runs[len(runs) // 2]
     flops = sum(r[2] for r in recs)
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
@@ -162,6 +164,7 @@ def conv_stack_roofline(model, img, metas, iters=3, dtype='f32'):
         'algorithmic_bytes_per_launch': sum(r[3] for r in recs) / max(len(recs), 1),
         'launches': len(recs), 'avg_launch_us': 1000.0 * ms / max(len(recs), 1),
         'algorithmic_gflop_per_pass': flops / 1e9, 'kernel_ms_per_pass': ms,
+        'passes': iters, 'kernel_ms_best_pass': ms_best, 'frac_best': flops / (ms_best * 1e-3) / 1e12 / peak,
     }
 
 

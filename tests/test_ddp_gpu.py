@@ -119,7 +119,8 @@ def test_bench_two_ranks_overlapped_and_bf16_wire_format():
     """the two other forms of the gradient exchange through `bench.py --gpus 2` (both ranks on the one GPU, gloo):
     overlapped in-place slices (BRCNN_REDUCER_OVERLAP=1) and the bf16 wire format (BRCNN_REDUCER_COMPRESS=bf16); every
     N line carries reduce_ms / grad_bytes / what was exchanged"""
-    for env, check in ((dict(BRCNN_REDUCER_OVERLAP='1', BRCNN_REDUCER_SLICE_MB='16'), lambda d: d['overlap'] is True),
+    # (the default 64 MiB slices: with many small slices in flight this one-GPU gloo harness crawls, profiles/r05_notes.md)
+    for env, check in ((dict(BRCNN_REDUCER_OVERLAP='1'), lambda d: d['overlap'] is True),
                        (dict(BRCNN_REDUCER_COMPRESS='bf16'), lambda d: 'bf16' in d['arena'])):
         r = _launch([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
                      '--mode', 'train', '--no-cpu-baseline'], nproc=2, extra_env=dict(TWO_ON_ONE, **env), timeout=1500)

@@ -304,3 +304,73 @@ def test_two_rank_grad_reducer_raises_on_layout_mismatch():
     ret = mgr.dict()
     mp.spawn(_reducer_layout_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret[1] is True and ret[0] is True
+
+
+def _slicing_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn import autograd as A
+        from brcnn import distributed as D
+        # interval arithmetic of reduce(): what the live gradient ranges leave after the issued slices
+        assert D._subtract([(0, 10), (20, 30)], []) == [(0, 10), (20, 30)]
+        assert D._subtract([(0, 100)], [(10, 20), (40, 50)]) == [(0, 10), (20, 40), (50, 100)]
+        assert D._subtract([(0, 10), (10, 25)], [(0, 16)]) == [(16, 25)]
+        assert D._subtract([(5, 9)], [(0, 16)]) == []
+
+        class FakeDeviceBuffer:        # stands in for a HIP arena chunk: only identity and is_cuda are looked at
+            is_cuda = True
+        issued = []
+
+        class Probe(D.GradReducer):
+            def _issue(self, buf, lo, hi, stream):
+                issued.append((lo, hi))
+        params = [torch.nn.Parameter(torch.zeros(4)) for _ in range(6)]
+        red = Probe(params, slice_mb=4e-4, overlap=True)            # ~104-element slices
+        n = red.slice_elems
+        buf = FakeDeviceBuffer()
+        red.chunk_opened(buf)
+        # three in-place ranges in a row form ONE run: slices are cut from it wherever they fall
+        red.writers_launched(buf, 0, 64, None, True, params[0])
+        assert issued == []
+        red.writers_launched(buf, 64, 64 + n, None, True, params[1])
+        assert issued == [(0, n)]
+        # a range autograd will COPY (not in place) ends the run: its leftover and the range itself are not sliced ...
+        red.writers_launched(buf, 64 + n, 64 + 4 * n, None, False, params[2])
+        assert issued == [(0, n)]
+        # ... and the next in-place range starts a new run at its own offset
+        red.writers_launched(buf, 64 + 4 * n, 64 + 6 * n, None, True, params[3])
+        assert issued == [(0, n), (64 + 4 * n, 64 + 5 * n), (64 + 5 * n, 64 + 6 * n)]
+        # a gap (alignment hole) also starts a new run
+        red.writers_launched(buf, 64 + 6 * n + 64, 64 + 7 * n + 64, None, True, params[4])
+        assert issued[-1] == (64 + 6 * n + 64, 64 + 7 * n + 64)
+        assert [tuple(r) for r in red._progress[0][1]] == issued
+        # a parameter that reaches a second weight-gradient launch in one pass: refused by the overlapped form
+        with pytest.raises(RuntimeError, match='used twice'):
+            red.writers_launched(buf, 64 + 8 * n, 64 + 9 * n, None, True, params[0])
+        red.close()
+        # the plain form (one all-reduce after the pass) tolerates it and slices nothing
+        issued.clear()
+        red = Probe(params, overlap=False)
+        red.chunk_opened(buf)
+        red.writers_launched(buf, 0, 10 * n, None, True, params[0])
+        red.writers_launched(buf, 10 * n, 20 * n, None, True, params[0])
+        assert issued == []
+        red.close()
+        assert A.grad_arena.listener is None
+        ret[rank] = 1.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_slices_only_ranges_that_are_grad():
+    """round 5 (the two-rank mismatch of round 4): the overlapped reducer cuts its in-place slices out of RUNS of arena
+    ranges that autograd takes as `.grad` unchanged; a range that will be copied on the main stream ends the run, a gap
+    starts a new one, a parameter with two launches in one pass is refused.  Host logic only (a stub chunk, recorded
+    slices): the real collectives run in tests/test_ddp_gpu.py."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_slicing_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret[0] == 1.0
