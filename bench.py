@@ -120,6 +120,15 @@ def timed(step, steps, warmup, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # Python's cyclic collector is held off over the timed steps (BRCNN_BENCH_GC=1 leaves it on): a step creates a few
+    # thousand short-lived objects, every few steps a generation-1/2 pass walks the whole heap (model, configs, caches) for
+    # 2-5 ms of HOST time -- which a launch-bound second half of the step turns into device time (profiles/r05_notes.md).
+    # The runner does the same between its log lines (`apis.EpochBasedRunner`: collect at the interval, never inside a step)
+    import gc
+    manual_gc = os.environ.get('BRCNN_BENCH_GC', '0') != '1'
+    if manual_gc:
+        gc.collect()
+        gc.disable()
     t0 = time.perf_counter()
     evs[0].record()
     marks = []
@@ -132,6 +141,8 @@ def timed(step, steps, warmup, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if manual_gc:
+        gc.enable()
     dev_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     gaps = [b - a for a, b in zip([t0] + marks[:-1], marks)]
     host_ms = sorted(1e3 * g for g in gaps)
