@@ -338,6 +338,9 @@ def inference_bench(args, world, rank, device):
 
 def main():
     args = parse_args()
+    if os.environ.get('BRCNN_WATCHDOG_S'):          # a hang (an unpaired collective) ends with every thread's stack on stderr
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['BRCNN_WATCHDOG_S']), exit=True)
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args))            # nothing has touched the GPU yet

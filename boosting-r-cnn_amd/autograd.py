@@ -201,6 +201,9 @@ def _conv_operands(weight, x_cat):
     return w_p, w_t
 
 
+_GEOM = {}
+
+
 def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
     """data / weight gradient of ConvNHWCFunction's forward (dy already in the activation dtype, contiguous);
     returns (dx, dw, dskip not yet added)"""
@@ -209,8 +212,13 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
     dt = _dt(x_cat)
     lib = _L.load()
     L = len(sizes)
-    hs, ws = _ints([h for h, _ in sizes]), _ints([w for _, w in sizes])
-    ohs, ows = _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes])
+    geo = _GEOM.get((sizes, out_sizes))            # (the ctypes arrays of a geometry are built once: ~60 layers x 4 per step)
+    if geo is None:
+        if len(_GEOM) > 512:
+            _GEOM.clear()
+        geo = _GEOM[(sizes, out_sizes)] = (_ints([h for h, _ in sizes]), _ints([w for _, w in sizes]),
+                                           _ints([h for h, _ in out_sizes]), _ints([w for _, w in out_sizes]))
+    hs, ws, ohs, ows = geo
     dx = dw = None
     # (fp32 only: in bf16 the zero-stuffed MFMA pass is cheaper than four more launches and
     # their weight slices -- measured 54.1 vs 57.6 ms per train step)

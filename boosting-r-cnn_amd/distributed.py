@@ -184,6 +184,12 @@ class GradReducer:
                     run[0] += self.slice_elems
                 return
 
+    def _ctrl_stream(self, device):
+        key = ('ctrl', device.type, device.index)
+        if key not in self._comm:
+            self._comm[key] = torch.cuda.Stream(device)
+        return self._comm[key]
+
     def _comm_stream(self, device):
         key = (device.type, device.index)
         if key not in self._comm:
@@ -221,10 +227,26 @@ class GradReducer:
     def _agree(self, sig, values, device, blocking):
         """all-reduce (MAX) of [sig, -sig]: equal on every rank iff max(sig) == -max(-sig).  Fixed size, so it pairs
         across ranks whatever their layouts are."""
-        t = torch.tensor([sig, -sig], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         if blocking:
-            hi, neg_lo = t.tolist()
+            # The signature is HOST data (which arena ranges and bucket this rank is about to post): its comparison need
+            # not wait for the backward pass the main stream is still executing.  RCCL: the two words travel on a
+            # control stream of their own (the process group runs its collectives in the order they are issued: this one
+            # first, the payload behind the main stream's events), and the host waits for THAT stream only -- ~0.1 ms,
+            # the device keeps its queue; reading the result on the main stream instead cost the step ~0.5 ms (round 5,
+            # world size 1: the host sat out the whole backward pass before it could enqueue the optimizer).  Other
+            # backends keep the words on the tensors' device and the main stream: gloo stages device tensors through the
+            # host, and the one-GPU two-rank test harness crawls (minutes per step) when those staged copies run under
+            # both processes' backward kernels -- reading the comparison there drains the device first, as it always did.
+            if self._avg and device.type == 'cuda':
+                ctrl = self._ctrl_stream(device)
+                with torch.cuda.stream(ctrl):
+                    t = torch.tensor([sig, -sig], dtype=torch.int64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                    hi, neg_lo = t.tolist()
+            else:
+                t = torch.tensor([sig, -sig], dtype=torch.int64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                hi, neg_lo = t.tolist()
             if hi != -neg_lo:
                 raise RuntimeError(f'GradReducer: rank {self.rank} is about to all-reduce a gradient layout that differs '
                                    f'from another rank\'s (arena chunks in use / small-gradient bucket: {values}); every '
@@ -232,6 +254,8 @@ class GradReducer:
                                    'parameters on some ranks only)')
             self._layout = sig
             return
+        t = torch.tensor([sig, -sig], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         if t.is_cuda:
             host = torch.empty(2, dtype=torch.int64).pin_memory()
             host.copy_(t, non_blocking=True)
