@@ -151,8 +151,21 @@ def conv_stack_roofline(model, img, metas, iters=5, dtype='f32'):
     except Exception:
         pass
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    # two roofs per launch (as in train_conv_roofline): a launch cannot finish before max(flops / MFMA peak, algorithmic
+    # bytes / 6.3 TB/s) -- x, weights, residual operand and output, each once.  The short-K 1x1 layers of stages 1 / 2 are
+    # byte-bound by that measure (K = 64: 25 flop per byte against the 25 of peak / stream rate in fp32)
+    bound_ms, hbm_n, hbm_ms, hbm_floor = 0.0, 0, 0.0, 0.0
+    for s_, e_, fl, nb, _ in recs:
+        t_mfma, t_hbm = fl / (peak * 1e12) * 1e3, nb / (HBM_STREAM_TBS * 1e12) * 1e3
+        bound_ms += max(t_mfma, t_hbm)
+        if t_hbm > t_mfma:
+            hbm_n += 1
+            hbm_ms += s_.elapsed_time(e_)
+            hbm_floor += t_hbm
     return {
         'bound': 'mfma',
+        'frac_of_bound': bound_ms / ms if ms else 0.0, 'bound_ms_per_pass': bound_ms, 'hbm_stream_rate_TBs': HBM_STREAM_TBS,
+        'hbm_bound_launches': {'count': hbm_n, 'ms': hbm_ms, 'floor_ms': hbm_floor},
         'kernel': ('conv_pp_f32_kernel (eight-phase 256x256 / 128x256 tiles) + conv_igemm_f32_dma_kernel (64x64 tiles)'
                    if dtype == 'f32' else 'conv_pp_bf16_kernel + conv_igemm_bf16_dma_kernel') +
                   ': every conv / FC launch of one pass',
