@@ -550,6 +550,8 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     elif cfg.get('load_from', None):
         runner.load_checkpoint(cfg.load_from)
     runner.run(loaders, cfg.get('workflow', [('train', 1)]))
+    if reducer is not None:
+        reducer.finish()            # (strict=False only: the last step's deferred layout comparison is read and checked)
     return runner
 
 
