@@ -217,11 +217,14 @@ def train_bench(args, world, rank, device):
     if net is model and os.environ.get('BRCNN_BENCH_GRAPH_TRUNK', '0') == '1':
         model.graph_trunk = True
 
+    from brcnn.profiling import stage_mark
+
     def step():
         opt.zero_grad(set_to_none=True)
         losses = net(img=img, img_metas=metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
         loss, log_vars = model._parse_losses(losses)
         (loss * scale if scale != 1.0 else loss).backward()
+        stage_mark('backward')
         if reducer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -229,6 +232,7 @@ def train_bench(args, world, rank, device):
             e1.record()
             reduce_ev.append((e0, e1))
         opt.step(max_norm=35, loss_scale=scale)        # clip + unscale + skip-on-inf + SGD + next step's conv operands
+        stage_mark('reduce_and_optimizer')
         last['log_vars'] = log_vars
 
     steps = args.train_steps or args.steps
@@ -258,6 +262,11 @@ def train_bench(args, world, rank, device):
     graph_info = None if graphed is None else {'captures': graphed.captures,
                                                'replays': sum(c.replays for c in graphed.caps.values()),
                                                'disabled': graphed.disabled_reason}
+    # where the MAIN stream's time goes (HIP events between the stages as they are queued; the weight-gradient stream and
+    # the proposal stream run beside it): backbone, neck, RPN tower, RPN loss + its backward pass (inside the forward pass),
+    # sampler (= the wait for proposals / assignment / the host's draw), RoIAlign, FC head, boosting loss, backward,
+    # reduce + optimizer
+    stages = profiling.stage_breakdown(step, cuda=True, iters=3, tail=None)
     model.graph_trunk = False       # the roofline pass times every conv launch by its own pair of events: eager launches
     roof = profiling.train_conv_roofline(step, dtype=args.train_dtype)
     return {
@@ -275,6 +284,7 @@ def train_bench(args, world, rank, device):
         'grad_bytes': grad_bytes, 'reduce_ms': reduce_ms,
         'grad_allreduce': None if reducer is None else reducer.describe(),
         'graph_trunk': graph_info,
+        'stages_ms': stages,
         'roofline': roof,
     }
 

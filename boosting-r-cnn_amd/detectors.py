@@ -266,6 +266,7 @@ class TwoStageDetector(BaseDetector):
             side = self.__dict__['_proposal_stream'] = torch.cuda.Stream(dev)
         cut = [f.detach().requires_grad_(f.requires_grad) for f in feats]
         y, sizes = rpn.forward_head_fused(cut)
+        stage_mark('rpn_tower')
         gt_flat = train_ops.flatten_gts(gt_bboxes, gt_labels)
         proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
         side.wait_stream(main)
@@ -300,6 +301,7 @@ class TwoStageDetector(BaseDetector):
                         p.grad = g if g.dtype == p.dtype else g.to(p.dtype)
                     else:
                         p.grad = p.grad + g
+            stage_mark('rpn_loss_and_backward')
             return {k: ([e.detach() for e in v] if isinstance(v, list) else v.detach()) for k, v in losses.items()}
 
         roi_losses, rpn_losses = self.roi_head.forward_train_device(

@@ -71,13 +71,15 @@ class StageRecorder:
         return out
 
 
-def stage_breakdown(run, cuda, iters=3):
-    """per-stage milliseconds of `run()` (one pass), the minimum-total of `iters` passes"""
+def stage_breakdown(run, cuda, iters=3, tail='copy_out'):
+    """per-stage milliseconds of `run()` (one pass), the minimum-total of `iters` passes; `tail`: name of a last mark set
+    after `run()` returns (None: the run sets its own last mark)"""
     best = None
     for _ in range(iters):
         with StageRecorder(cuda) as r:
             run()
-            r.mark('copy_out')
+            if tail:
+                r.mark(tail)
         ms = r.ms()
         if best is None or sum(ms.values()) < sum(best.values()):
             best = ms

@@ -536,14 +536,18 @@ class ProbRoIHead(nn.Module):
         `feats_nhwc` may be a callable that yields the pyramid once `overlap_work` has run."""
         from . import train_ops
         smp, extra = self.sample_device(dets, num, gt_flat, overlap_work, proposal_stream)
+        stage_mark('sampler')                # (incl. the wait for the proposal stream: proposals, assignment, counts)
         if callable(feats_nhwc):
             feats_nhwc = feats_nhwc()
         roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, smp['rois'])
+        stage_mark('roi_align')
         cls_score, bbox_pred = self.bbox_head.forward_nhwc(roi_feats)
+        stage_mark('fc_head')
         h = self.bbox_head
         out3 = train_ops.boost_loss(cls_score, bbox_pred, smp['labels'], smp['priors'], smp['bbox_targets'],
                                     h.num_classes, self.gamma, self.alpha, smp.get('ious'), self.iou_gamma,
                                     h.loss_cls.loss_weight, h.loss_bbox.loss_weight, self.reg_norm, h.reg_class_agnostic)
+        stage_mark('boost_loss')
         self.last_samples = smp
         return dict(loss_cls=out3[0], loss_bbox=out3[1], acc=out3[2].reshape(1)), extra
 
