@@ -320,4 +320,5 @@ int conv1x1_stream_try(ConvParams& p, hipStream_t s, int f16) {
     return (p.residual ? launch_stream<2, true, 0>(p, s) : launch_stream<2, false, 0>(p, s)) ? BRCNN_EINVAL : 1;
 }
 int conv1x1_stream_set(int mode) { g_stream_mode = mode; return 0; }
+int tuning_get_persistent_1x1() { return g_stream_mode; }
 }  // namespace brcnn_conv

@@ -741,6 +741,10 @@ int dispatch_conv(ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
+namespace brcnn_conv {
+int tuning_get_eight_phase_f32() { return g_pp_f32_mode; }
+}  // namespace brcnn_conv
+
 BRCNN_API int brcnn_conv_set_tile(int wm, int nt) {
     if (wm == -1) { g_use_dma = nt; return 0; }   // (-1, 0/1/2): register-staged / heuristic / always LDS-DMA
     if (wm == -3) { if (nt < 0 || nt > 2) return BRCNN_EINVAL; g_pp_f32_n128 = nt; return 0; }

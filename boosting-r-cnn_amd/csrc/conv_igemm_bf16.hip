@@ -1301,6 +1301,12 @@ BRCNN_API int brcnn_conv_handover_status(void) {
     return sk_take_error();
 }
 
+namespace brcnn_conv {
+int tuning_get_stream_k() { return g_sk_mode; }
+int tuning_get_split_k() { return g_sk_par; }
+int tuning_get_eight_phase_16() { return g_pp_mode; }
+}  // namespace brcnn_conv
+
 BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt == -1 || mtnt == -2) { g_bf16_il = (mtnt == -1); return 0; }
     if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced

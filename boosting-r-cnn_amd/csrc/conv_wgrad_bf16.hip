@@ -486,6 +486,11 @@ int brcnn_wgrad_bf16_dispatch(const void* x, const void* dy, void* dw, int batch
     return wt == 2 ? launch<2>(p, stream) : launch<1>(p, stream);
 }
 
+namespace brcnn_conv {
+int tuning_get_wgrad_slabs() { return g_wgrad_slabs; }
+int tuning_get_wgrad_generation_percent() { return g_wgrad_slot_pct; }
+}  // namespace brcnn_conv
+
 BRCNN_API int brcnn_conv_set_tile_wgrad_bf16(int wt) {
     if (wt == 10 || wt == 11) { g_wgrad_slabs = wt - 10; return 0; }      // reduction over the M slices: atomics / slabs
     if (wt >= 100 && wt < 1100) { g_wgrad_two_pass = wt - 100; return 0; }

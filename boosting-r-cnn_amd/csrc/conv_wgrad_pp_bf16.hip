@@ -689,6 +689,9 @@ int wgrad_pp_bf16_try(const void* x, const void* dy, void* dw, int batch, int nu
     return rc ? rc : 1;
 }
 
+int tuning_get_wgrad_eight_phase() { return g_wgrad_pp_mode; }
+int tuning_get_wgrad_reduce_in_launch() { return g_wgrad_pp_fuse; }
+int tuning_get_wgrad_cu_percent() { return g_wgrad_pp_slot_pct; }
 int wgrad_pp_set(int v) {
     if (v >= 20 && v <= 22) { g_wgrad_pp_mode = v - 20; return 0; }
     if (v == 29) { const int n = g_wgrad_pp_launches; g_wgrad_pp_launches = 0; return n; }

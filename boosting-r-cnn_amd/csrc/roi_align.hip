@@ -1348,3 +1348,58 @@ BRCNN_API int brcnn_roi_align_set_exact(int exact) {
     g_roi_stream_c = exact == 2 ? 0 : exact == 3 ? 1 : 3;
     return 0;
 }
+
+// ---- the policy switches as one documented struct (include/brcnn_hip.h: brcnn_tuning) ---------------------------
+namespace brcnn_conv {
+int tuning_get_stream_k(); int tuning_get_split_k(); int tuning_get_eight_phase_16(); int tuning_get_persistent_1x1();
+int tuning_get_eight_phase_f32(); int tuning_get_wgrad_slabs(); int tuning_get_wgrad_generation_percent();
+int tuning_get_wgrad_eight_phase(); int tuning_get_wgrad_reduce_in_launch(); int tuning_get_wgrad_cu_percent();
+}  // namespace brcnn_conv
+
+BRCNN_API int brcnn_get_tuning(brcnn_tuning* t) {
+    if (!t || t->size != (int)sizeof(brcnn_tuning)) return BRCNN_EINVAL;
+    t->conv_stream_k = brcnn_conv::tuning_get_stream_k();
+    t->conv_split_k = brcnn_conv::tuning_get_split_k();
+    t->conv_eight_phase_16bit = brcnn_conv::tuning_get_eight_phase_16();
+    t->conv_persistent_1x1 = brcnn_conv::tuning_get_persistent_1x1();
+    t->conv_eight_phase_f32 = brcnn_conv::tuning_get_eight_phase_f32();
+    t->wgrad_slab_reduction = brcnn_conv::tuning_get_wgrad_slabs();
+    t->wgrad_eight_phase = brcnn_conv::tuning_get_wgrad_eight_phase();
+    t->wgrad_reduce_in_launch = brcnn_conv::tuning_get_wgrad_reduce_in_launch();
+    t->wgrad_generation_percent = brcnn_conv::tuning_get_wgrad_generation_percent();
+    t->wgrad_eight_phase_cu_percent = brcnn_conv::tuning_get_wgrad_cu_percent();
+    t->roi_exact_order = g_roi_exact;
+    t->roi_rows_per_wave = g_roi_rpw == 0 ? 0 : (g_roi_rpw == 17 ? 7 : 1);
+    t->roi_visit_order = g_roi_order;
+    t->roi_prepared_records = g_roi_prep;
+    return 0;
+}
+
+BRCNN_API int brcnn_set_tuning(const brcnn_tuning* t) {
+    if (!t || t->size != (int)sizeof(brcnn_tuning)) return BRCNN_EINVAL;
+    auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+    if (!in(t->conv_stream_k, 0, 2) || !in(t->conv_split_k, 0, 2) || !in(t->conv_eight_phase_16bit, 0, 1) ||
+        !in(t->conv_persistent_1x1, 0, 2) ||
+        !(in(t->conv_eight_phase_f32, 0, 2) || t->conv_eight_phase_f32 == 128 || t->conv_eight_phase_f32 == 256) ||
+        !in(t->wgrad_slab_reduction, 0, 1) || !in(t->wgrad_eight_phase, 0, 2) || !in(t->wgrad_reduce_in_launch, 0, 1) ||
+        !in(t->wgrad_generation_percent, 10, 400) || !in(t->wgrad_eight_phase_cu_percent, 10, 400) ||
+        !in(t->roi_exact_order, 0, 1) || !(t->roi_rows_per_wave == 0 || t->roi_rows_per_wave == 1 || t->roi_rows_per_wave == 7) ||
+        !in(t->roi_visit_order, 0, 2) || !in(t->roi_prepared_records, 0, 1))
+        return BRCNN_EINVAL;
+    int rc = 0;
+    rc |= brcnn_conv_set_tile_bf16(-3 - t->conv_stream_k);
+    rc |= brcnn_conv_set_tile_bf16(-8 - t->conv_split_k);
+    rc |= brcnn_conv_set_tile_bf16(-6 - t->conv_eight_phase_16bit);
+    rc |= brcnn_conv_set_tile_bf16(-15 - t->conv_persistent_1x1);
+    rc |= brcnn_conv_set_tile(-2, t->conv_eight_phase_f32);
+    rc |= brcnn_conv_set_tile_wgrad_bf16(10 + t->wgrad_slab_reduction);
+    rc |= brcnn_conv_set_tile_wgrad_bf16(20 + t->wgrad_eight_phase);
+    rc |= brcnn_conv_set_tile_wgrad_bf16(30 + t->wgrad_reduce_in_launch);
+    rc |= brcnn_conv_set_tile_wgrad_bf16(2000 + t->wgrad_generation_percent);
+    rc |= brcnn_conv_set_tile_wgrad_bf16(4000 + t->wgrad_eight_phase_cu_percent);
+    rc |= brcnn_roi_align_set_exact(t->roi_exact_order);
+    rc |= brcnn_roi_align_set_exact(t->roi_rows_per_wave == 0 ? 10 : (t->roi_rows_per_wave == 7 ? 17 : 11));
+    rc |= brcnn_roi_align_set_exact(20 + t->roi_visit_order);
+    rc |= brcnn_roi_align_set_exact(30 + t->roi_prepared_records);
+    return rc ? BRCNN_EINVAL : 0;
+}

@@ -29,6 +29,8 @@ SIGNATURES = {
     'brcnn_roi_extract_order_min_rois': (c_int, []),
     'brcnn_roi_extract_forward_prepared': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 3 + [c_int] * 6 +
                                            [c_f32, c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    'brcnn_get_tuning': (c_int, [c_ptr]),
+    'brcnn_set_tuning': (c_int, [c_ptr]),
     'brcnn_roi_extract_backward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 +
                                    [c_f32, c_ptr]),
     'brcnn_roi_extract_backward_workspace_bytes': (c_size, [c_int]),
@@ -130,6 +132,32 @@ SIGNATURES = {
 
 class BrcnnHipError(RuntimeError):
     pass
+
+
+class Tuning(ctypes.Structure):
+    """include/brcnn_hip.h: brcnn_tuning -- the library's policy switches as one struct (`get_tuning()` / `set_tuning()`)"""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        'size', 'conv_stream_k', 'conv_split_k', 'conv_eight_phase_16bit', 'conv_persistent_1x1', 'conv_eight_phase_f32',
+        'wgrad_slab_reduction', 'wgrad_eight_phase', 'wgrad_reduce_in_launch', 'wgrad_generation_percent',
+        'wgrad_eight_phase_cu_percent', 'roi_exact_order', 'roi_rows_per_wave', 'roi_visit_order', 'roi_prepared_records')]
+
+
+def get_tuning():
+    t = Tuning()
+    t.size = ctypes.sizeof(Tuning)
+    check(load().brcnn_get_tuning(ctypes.addressof(t)), 'brcnn_get_tuning')
+    return t
+
+
+def set_tuning(**fields):
+    """change some of the policy switches (the others keep their current values); returns the struct that was set"""
+    t = get_tuning()
+    for k, v in fields.items():
+        if k == 'size' or not hasattr(t, k):
+            raise KeyError(f'brcnn_tuning has no field {k!r}')
+        setattr(t, k, int(v))
+    check(load().brcnn_set_tuning(ctypes.addressof(t)), 'brcnn_set_tuning')
+    return t
 
 
 def load():

@@ -149,6 +149,34 @@ int brcnn_roi_extract_backward_gather(void *const *grad_feats_host, const int *h
  * rounds 1-2 (per-bin loop, round-robin rows), 3 = column streaming with round-robin rows (tuning / A-B hooks). */
 int brcnn_roi_align_set_exact(int exact);
 
+/* The policy switches of the library as ONE documented struct (round 5; VERDICT r04: the integer hooks had become what
+ * product defaults depend on).  Process-wide, unsynchronised: read / written from one thread while no other thread is
+ * inside the library.  Every choice yields the same results bit for bit EXCEPT conv_split_k (the association of the K
+ * sum changes: results then depend on the tile count, i.e. on the batch size), roi_exact_order (the footprint form
+ * equals the exact form to fp32 round-off) and wgrad_slab_reduction = 0 (fp32 atomics: order-dependent sums).
+ * `size` must be sizeof(brcnn_tuning) (a caller built against another layout gets BRCNN_EINVAL).
+ * The integer hooks (brcnn_conv_set_tile*, brcnn_roi_align_set_exact) stay as the fine-grained test / tuning interface;
+ * brcnn_set_tuning is expressed through them. */
+typedef struct brcnn_tuning {
+    int size;
+    int conv_stream_k;                /* chained stream-K schedule of the conv kernels: 0 off, 1 by the heuristic (default), 2 wherever the tile count allows */
+    int conv_split_k;                 /* split-K of launches with fewer tiles than CUs: 0 off (default), 1 heuristic, 2 forced */
+    int conv_eight_phase_16bit;       /* eight-phase 256x256 kernel for bf16 / fp16: 0 never, 1 heuristic (default) */
+    int conv_persistent_1x1;          /* persistent LDS-resident-weights kernel for the short-K 1x1 layers: 0 never, 1 heuristic (default), 2 forced */
+    int conv_eight_phase_f32;         /* fp32 eight-phase kernel: 0 never, 1 heuristic (default), 2 forced, 128 / 256 forced with that tile height */
+    int wgrad_slab_reduction;         /* weight gradient over the M slices: 0 fp32 atomics, 1 slabs + fixed-order second stage (default: deterministic) */
+    int wgrad_eight_phase;            /* eight-phase weight-gradient kernel: 0 never, 1 heuristic (default), 2 wherever the shape allows */
+    int wgrad_reduce_in_launch;       /* its slab reduction: 0 separate launches (default), 1 inside the producing launch (measured slower) */
+    int wgrad_generation_percent;     /* two-buffer weight-gradient launches: percent of one generation of resident workgroups (default 75: they share the device with the main stream) */
+    int wgrad_eight_phase_cu_percent; /* eight-phase weight-gradient launches: percent of the CUs (default 75) */
+    int roi_exact_order;              /* RoIAlign forward: 0 footprint form (default), 1 the reference's sample order bit for bit */
+    int roi_rows_per_wave;            /* bin rows per wavefront: 0 heuristic (default), 1, 7 */
+    int roi_visit_order;              /* band-ordered visit of the RoIs: 0 off, 1 from brcnn_roi_extract_order_min_rois() RoIs on (default), 2 always */
+    int roi_prepared_records;         /* per-RoI records written by a first launch: 0 off (default), 1 on where the caller gives the scratch */
+} brcnn_tuning;
+int brcnn_get_tuning(brcnn_tuning *t);          /* t->size set by the caller */
+int brcnn_set_tuning(const brcnn_tuning *t);
+
 /* Whole-batch candidate preparation / collection around brcnn_nms for fixed per-image slots of
  * `slot` candidates (the device-resident form of mmcv.ops.batched_nms below split_thr, called per
  * image by atss_rpn_head.py:756 and bbox_nms.py:86): brcnn_nms_prepare compacts the valid rows of

@@ -379,3 +379,35 @@ def test_loss_leaf_rules():
                        [0.4, 0.7, 0.1, 0.1], [0.0, 0.0, 0.99, 0]])
     assert losses.accuracy(pr, torch.Tensor([2, 3, 0, 1, 2]).long()).item() == 100
     assert losses.accuracy(pr, torch.Tensor([2, 3, 0, 1, 2]).long(), 1, 0.8).item() == 40
+
+
+def test_tuning_struct_round_trip_without_a_gpu():
+    """include/brcnn_hip.h: brcnn_tuning -- the library's policy switches as one documented struct.  get / set touch host
+    state only (no device call): defaults as documented, a change reads back, the integer hooks and the struct see the
+    same state, out-of-range values and a wrong `size` are refused"""
+    import ctypes
+    from brcnn import lib
+    L = lib.load()
+    t = lib.get_tuning()
+    want = dict(conv_stream_k=1, conv_split_k=0, conv_eight_phase_16bit=1, conv_persistent_1x1=1, conv_eight_phase_f32=1,
+                wgrad_slab_reduction=1, wgrad_eight_phase=1, wgrad_reduce_in_launch=0, wgrad_generation_percent=75,
+                wgrad_eight_phase_cu_percent=75, roi_exact_order=0, roi_rows_per_wave=0, roi_visit_order=1,
+                roi_prepared_records=0)
+    assert {k: getattr(t, k) for k in want} == want and t.size == ctypes.sizeof(lib.Tuning) == 15 * 4
+    try:
+        lib.set_tuning(conv_split_k=1, roi_rows_per_wave=7, wgrad_generation_percent=50)
+        t = lib.get_tuning()
+        assert (t.conv_split_k, t.roi_rows_per_wave, t.wgrad_generation_percent) == (1, 7, 50)
+        assert t.conv_stream_k == 1 and t.roi_visit_order == 1                  # the others keep their values
+        assert L.brcnn_conv_set_tile_bf16(-10) == 0 and lib.get_tuning().conv_split_k == 2      # hook and struct: one state
+        assert L.brcnn_roi_align_set_exact(31) == 0 and lib.get_tuning().roi_prepared_records == 1
+        with pytest.raises(lib.BrcnnHipError):
+            lib.set_tuning(conv_stream_k=5)
+        with pytest.raises(KeyError):
+            lib.set_tuning(no_such_field=1)
+        bad = lib.get_tuning()
+        bad.size = 8
+        assert L.brcnn_set_tuning(ctypes.addressof(bad)) == -22 and L.brcnn_get_tuning(ctypes.addressof(bad)) == -22
+    finally:
+        lib.set_tuning(**want)
+    assert {k: getattr(lib.get_tuning(), k) for k in want} == want
