@@ -11,7 +11,12 @@ second stream, dW handed to `.grad` unchanged):
 * at the end of the backward pass (`reduce()`): the arena in ONE all-reduce, and the few hundred small gradients that
   do not live in it (BatchNorm / GroupNorm affine, biases, Scale) as one flattened bucket;
 * `overlap=True` (off by default): as the backward pass fills the arena, every finished slice of `slice_mb` MiB is
-  all-reduced on a communication stream behind an event of the stream that launched its last writer.  Measured at
+  all-reduced IN PLACE on a communication stream behind an event of the stream that launched its last writer -- but
+  only slices cut from runs of ranges that autograd takes as `.grad` unchanged (`writers_launched(..., in_place)`):
+  anything autograd copies on the main stream after the launch (a gradient whose strides are not the parameter's, the
+  first FC's re-layout, weights behind a cat / pad) is reduced after the pass from the copy.  Round 4 sliced by offset
+  alone; the in-place all-reduce raced with those copies and some gradients were reduced twice (profiles/r05_notes.md).
+  Measured at
   world size 1 on MI355X (profiles/r03_notes.md): with three streams already busy (main, weight gradients, proposals)
   a fourth stream that WAITS on a weight-gradient event costs the step 1.4-4 ms (19.7 -> 21.6-24 ms, depending on
   which pooled stream it is; the wait alone, without any RCCL call, 3.3 ms) -- more than the ~1.3 ms of ring
@@ -25,7 +30,9 @@ second stream, dW handed to `.grad` unchanged):
   computation from the bf16-rounded local gradients);
 * every rank must post the same collectives: the layout (chunk sizes in use, small-bucket length and count) is
   compared across the ranks through a fixed-size 2-word collective AHEAD of the payload collectives and read on the
-  host by EVERY rank on EVERY step (`strict=True`, the default: ~0.1 ms on the GPU, measured at world size 1) -- a
+  host by EVERY rank on EVERY step (`strict=True`, the default).  The signature is host data, so under RCCL the two
+  words travel on a control stream of their own and the host waits for that stream only (~0.1 ms; read on the main
+  stream the same comparison cost the host its whole lead over the device: slack 2.6 instead of 5-6 ms) -- a
   mismatch raises on all ranks at the same point, before anything unpaired has been posted and before the optimizer
   can consume an invalid average (DistributedDataParallel's reducer raises in the same case).  `strict=False` reads
   the comparison one step late in the steady state (no host synchronisation): detection is then ASYMMETRIC -- the rank
