@@ -791,3 +791,49 @@ def test_graphed_trunk_fp32_step_equals_the_eager_step():
         assert gt.captures == 1 and sum(c.replays for c in gt.caps.values()) == 3 and gt.disabled_reason is None
     finally:
         m.graph_trunk, m.early_rpn_backward = False, False
+
+
+def test_graphed_trunk_keys_per_input_shape_and_falls_back():
+    """`graph_trunk` bookkeeping: a capture per input shape, taken the second time the shape comes up (a shape seen once
+    never pays for one), kept for the shapes that recur; a parameter whose storage moves (here: a weight re-laid out
+    channels-last after the capture) changes the key, so the stale graphs are not replayed; `BRCNN_GRAPH_TRUNK=0`-style
+    veto (`graphs.ENABLED`) and no-grad mode run the eager trunk"""
+    from brcnn import blocks, graphs
+    m = _model()
+    m.set_compute_dtype('bf16')
+    try:
+        m.graph_trunk = True
+        data = {}
+        for h, w in ((128, 192), (160, 160)):
+            img, metas, gts, gls = util.demo_inputs(2, h, w, seed=h)
+            data[(h, w)] = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+
+        def step(key):
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            loss, log_vars = m._parse_losses(m.forward_train(*data[key]))
+            loss.backward()
+            torch.cuda.synchronize()
+            return dict(log_vars)
+        a, b = (128, 192), (160, 160)
+        first = {k: step(k) for k in (a, b)}                     # seen once each: eager
+        gt = m.__dict__['_graphed_trunk']
+        assert gt.captures == 0
+        for k in (a, b, a, b):
+            assert step(k) == first[k]                           # bf16: replay = eager, bit for bit
+        assert gt.captures == 2 and sorted(c.replays for c in gt.caps.values()) == [2, 2]
+        with torch.no_grad():                                    # no gradients wanted: the eager trunk
+            assert not gt.usable(data[a][0])
+        saved, graphs.ENABLED = graphs.ENABLED, False
+        try:
+            assert step(a) == first[a] and gt.captures == 2
+        finally:
+            graphs.ENABLED = saved
+        assert blocks.conv_weights_channels_last(m) > 0          # parameter storage moved: new keys
+        step(a)
+        assert gt.captures == 2                                  # first sight of the new key: eager
+        step(a)
+        assert gt.captures == 3
+    finally:
+        m.graph_trunk = False
+        blocks.set_compute_dtype('f32')
