@@ -374,3 +374,43 @@ def test_overlapped_reducer_slices_only_ranges_that_are_grad():
     ret = mp.Manager().dict()
     mp.spawn(_slicing_worker, args=(1, port, ret), nprocs=1, join=True)
     assert ret[0] == 1.0
+
+
+def _replica_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn.distributed import replicas_identical
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Linear(4, 2))
+        m[0].weight.data = m[0].weight.data.contiguous(memory_format=torch.channels_last)      # a non-default layout too
+        assert replicas_identical(m)                       # same seed on both ranks
+        if rank == 1:
+            with torch.no_grad():
+                m[2].bias[1] += 1e-7                       # one bit pattern in one parameter of one rank
+        assert not replicas_identical(m)                   # ... and EVERY rank sees it
+        if rank == 1:
+            with torch.no_grad():
+                m[2].bias[1] -= 1e-7
+        same_again = replicas_identical(m)                 # (1e-7 on a bias of ~0.3 does not round-trip exactly in general)
+        with torch.no_grad():
+            for p in m.parameters():
+                dist.broadcast(p.data, 0)
+            if rank == 1:
+                m[1].running_mean[0] = 5.0                 # buffers count as well
+        assert not replicas_identical(m)
+        ret[rank] = float(same_again) + 1.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_identical_sees_one_differing_bit_on_every_rank():
+    """`distributed.replicas_identical` (the runner's `check_replicas`): bit-identical parameters and buffers on every
+    rank or not -- a single changed value on one rank turns the answer on ALL ranks, channels-last parameters and
+    BatchNorm buffers included"""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_replica_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] >= 1.0 and ret[1] >= 1.0
