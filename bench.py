@@ -245,6 +245,7 @@ def train_bench(args, world, rank, device):
     dt, step_stats = timed(step, steps, 0, world, device)
     sync_wait = _rh.SYNC_WAIT
     _rh.SYNC_WAIT = None
+    loss_last_timed = float(last['log_vars']['loss'])       # (the passes below run further steps)
     step_stats['host_slack_at_sync_ms'] = 1e3 * sync_wait[0] / max(1, sync_wait[1])
     from brcnn import lib as _lib
     _lib.handover_status()          # a lost stream-K hand-over inside the timed steps is an error, not a number
@@ -279,7 +280,7 @@ def train_bench(args, world, rank, device):
                                (', gradient arena all-reduced in place over RCCL' if reducer is not None else
                                 ', DDP over RCCL' if world > 1 else ''),
                    'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
-        'loss': float(last['log_vars']['loss']),
+        'loss': loss_last_timed,
         'lr': cfg.optimizer.lr * warm,
         'grad_bytes': grad_bytes, 'reduce_ms': reduce_ms,
         'grad_allreduce': None if reducer is None else reducer.describe(),

@@ -90,6 +90,9 @@ _TEST_STALL_CYCLES = int(_os.environ.get('BRCNN_TEST_WGRAD_STALL_CYCLES', '0'))
 
 # weight-gradient launches on a second HIP stream (see _conv_backward); BRCNN_WGRAD_STREAM=0 keeps one stream
 WGRAD_SIDE_STREAM = _os.environ.get('BRCNN_WGRAD_STREAM', '1') != '0'
+# weight gradients of layers without a data gradient (the trunk's entry layers, last in the backward pass) stay on the main
+# stream (see _conv_backward); BRCNN_WGRAD_TAIL_MAIN=0 sends them to the second stream like the others
+WGRAD_TAIL_ON_MAIN = _os.environ.get('BRCNN_WGRAD_TAIL_MAIN', '1') != '0'
 _side_streams = {}
 _join_queued = {}        # (device type, index) -> True while a join callback of the running backward pass is queued
 _side_seen = {}          # (device type, index) -> ids of the parameters whose gradient went to the side stream in this pass
@@ -204,7 +207,7 @@ def _conv_operands(weight, x_cat):
 _GEOM = {}
 
 
-def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
+def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw, has_dgrad=None):
     """data / weight gradient of ConvNHWCFunction's forward (dy already in the activation dtype, contiguous);
     returns (dx, dw, dskip not yet added)"""
     batch, sizes, out_sizes, stride, pad = cfg
@@ -212,6 +215,8 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
     dt = _dt(x_cat)
     lib = _L.load()
     L = len(sizes)
+    if has_dgrad is None:           # (the caller that computes the data gradient in a launch of its own says so)
+        has_dgrad = need_dx
     geo = _GEOM.get((sizes, out_sizes))            # (the ctypes arrays of a geometry are built once: ~60 layers x 4 per step)
     if geo is None:
         if len(_GEOM) > 512:
@@ -249,7 +254,16 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw):
         takes = weight.is_leaf and weight.grad is None and not weight._backward_hooks and \
             not getattr(weight, '_post_accumulate_grad_hooks', None) and \
             (weight.is_contiguous() if kh * kw == 1 else weight.is_contiguous(memory_format=torch.channels_last))
-        side = _side_stream_for(weight, dy.device) if takes else None
+        # ... or when the ONE consumer of dW is a node that does its work on the second stream itself
+        # (PermutedWeightFunction: the first FC's re-layout): the launch may leave the main stream, but the arena range is
+        # not `.grad` -- the gradient reducer must not slice it in place (`takes` stays False for it)
+        side_ok = takes or bool(getattr(weight, '_brcnn_dw_consumer_on_side', False))
+        # ... and only when this layer HAS a data gradient for the launch to hide behind: the first trainable layers of the
+        # trunk (their input comes from the frozen stage: no dx) are the last nodes of the backward pass -- the main
+        # stream has nothing left to do, the second stream still has its backlog, and the launch would only lengthen the
+        # tail the main stream waits for at the end-of-pass join (0.34 ms per bf16 step of bench.py: tools/experiments/
+        # join_wait.py); on the main stream it runs beside that backlog
+        side = _side_stream_for(weight, dy.device) if (side_ok and (has_dgrad or not WGRAD_TAIL_ON_MAIN)) else None
         if side is None:
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
                                                    cin, cout, kh, kw, stride, pad, dt, _conv_stream())
@@ -449,11 +463,61 @@ def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad):
     return y if cout == weight.shape[0] else y[:, :cout]
 
 
+FC0_ON_SIDE = _os.environ.get('BRCNN_FC0_SIDE', '1') != '0'      # A/B switch of PermutedWeightFunction
+
+
+class PermutedWeightFunction(Function):
+    """The first FC of the box head: the parameter (out, C*ph*pw) -- the reference's column order -- as the (out, ph*pw*C)
+    matrix the NHWC RoI features multiply.  Forward: one copy.  Backward: the weight-gradient kernel writes dW in the
+    (ph, pw, C) order on the second stream; the copy back to the parameter's order runs THERE, behind it, and its result
+    is what autograd hands to the parameter as `.grad` (contiguous, the parameter's layout: no further kernel) -- where
+    autograd's own view / permute backward put the weight-gradient launch (0.13 ms at 4096 RoIs) and a 51 MB copy on the
+    main stream at the very start of the backward pass."""
+
+    @staticmethod
+    def forward(ctx, w2d, c, ph, pw):
+        ctx.cfg = (c, ph, pw)
+        out = w2d.shape[0]
+        return w2d.view(out, c, ph, pw).permute(0, 2, 3, 1).reshape(out, -1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        c, ph, pw = ctx.cfg
+        out = g.shape[0]
+        side = _wgrad_side_stream(g.device) if g.is_cuda else None
+        if side is None:            # no second stream (switched off, or DistributedDataParallel's hooks): the plain copy
+            return g.reshape(out, ph, pw, c).permute(0, 3, 1, 2).reshape(out, -1), None, None, None
+        main = torch.cuda.current_stream(g.device)
+        side.wait_event(main.record_event())        # (the launch that wrote g ran on `side` or, failing that, on `main`)
+        with torch.cuda.stream(side):
+            r = g.reshape(out, ph, pw, c).permute(0, 3, 1, 2).reshape(out, -1)
+        g.record_stream(side)
+        r.record_stream(main)                       # (read on the main stream after the end-of-pass join)
+        _queue_stream_join(main, side)
+        return r, None, None, None
+
+
+def permuted_fc_weight(w2d, c, ph, pw):
+    """(out, C*ph*pw) -> (out, ph*pw*C), differentiable; the result may be fed to `linear_autograd` only (its
+    weight-gradient launch then goes to the second stream)"""
+    if not FC0_ON_SIDE:
+        out = w2d.shape[0]
+        return w2d.view(out, c, ph, pw).permute(0, 2, 3, 1).reshape(out, -1)
+    w = PermutedWeightFunction.apply(w2d, c, ph, pw)
+    if w.requires_grad:
+        w._brcnn_dw_consumer_on_side = True
+    return w
+
+
 def linear_autograd(x, weight, bias):
     """x (M,K) @ weight(N,K)^T + bias, differentiable (the 1x1 case with H=W=1)"""
+    on_side = getattr(weight, '_brcnn_dw_consumer_on_side', False)
     weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)
-    y = ConvNHWCFunction.apply(x.contiguous(), weight.view(weight.shape[0], weight.shape[1], 1, 1),
-                               bias, x.shape[0], ((1, 1),), 1, 0)
+    w4 = weight.view(weight.shape[0], weight.shape[1], 1, 1)
+    if on_side and cout == weight.shape[0]:         # (no padding cat in between: dW travels back through views only)
+        w4._brcnn_dw_consumer_on_side = True
+    y = ConvNHWCFunction.apply(x.contiguous(), w4, bias, x.shape[0], ((1, 1),), 1, 0)
     return y if cout == weight.shape[0] else y[:, :cout]
 
 
@@ -785,7 +849,7 @@ class ConvBnEvalActFunction(Function):
             _L.check(st, 'brcnn_conv2d_dgrad_bn_backward_nhwc')
             t.done = True
             _, dw, _ = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), None, False,
-                                      ctx.needs_input_grad[1])
+                                      ctx.needs_input_grad[1], has_dgrad=True)
             dx = dzp
         else:
             dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), dskip,

@@ -207,15 +207,15 @@ class ProbConvFCBBoxHead(nn.Module):
             return self._forward_general(roi_feats)
         k, ph, pw, c = roi_feats.shape
         x = roi_feats.reshape(k, ph * pw * c)
-        from .autograd import linear_autograd, wants_grad
+        from .autograd import linear_autograd, permuted_fc_weight, wants_grad
         if wants_grad(x, self.fc_cls.weight, self.shared_fcs[0].weight):
             from .blocks import compute_dtype
             if compute_dtype() != torch.float32:
                 x = x.to(compute_dtype())     # 16-bit modes: the FC GEMMs (fwd / dgrad / wgrad) on bf16 / fp16 MFMA
             for i, fc in enumerate(self.shared_fcs):
                 w = fc.weight
-                if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable view
-                    w = w.view(-1, c, ph, pw).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
+                if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable (its gradient's way back on the second stream)
+                    w = permuted_fc_weight(w, c, ph, pw)
                 x = linear_autograd(x, w, fc.bias).relu()
             y = linear_autograd(x, torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0),
                                 torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)).float()
@@ -249,7 +249,7 @@ class ProbConvFCBBoxHead(nn.Module):
         """x (K, features) through nn.Linear `fc` on the MFMA linear kernel.  `spatial` =
         (ph, pw, C) when x is a flattened NHWC map: the reference flattens (C, ph, pw), so the
         weight columns are permuted once to the NHWC order."""
-        from .autograd import linear_autograd, wants_grad
+        from .autograd import linear_autograd, permuted_fc_weight, wants_grad
         if wants_grad(x, fc.weight, fc.bias):
             w = fc.weight
             if spatial is not None:
