@@ -93,6 +93,17 @@ WGRAD_SIDE_STREAM = _os.environ.get('BRCNN_WGRAD_STREAM', '1') != '0'
 # weight gradients of layers without a data gradient (the trunk's entry layers, last in the backward pass) stay on the main
 # stream (see _conv_backward); BRCNN_WGRAD_TAIL_MAIN=0 sends them to the second stream like the others
 WGRAD_TAIL_ON_MAIN = _os.environ.get('BRCNN_WGRAD_TAIL_MAIN', '1') != '0'
+# BRCNN_WGRAD_DEFER=1: the second stages (slab reductions) of the 16-bit weight-gradient launches on the second stream
+# are batched into one table-driven launch per WGRAD_DEFER_ITEMS layers and at the end-of-pass join
+# (csrc/wgrad_defer.hip): 85 launches less per bf16 step of bench.py, same bits.  OFF by default: on one MI355X the step
+# is 0.15-0.2 ms LONGER with it (17.96 -> 18.15 ms; the small per-layer reductions fill gaps of the main stream's kernels,
+# a batched one competes with them for HBM and its last instance sits in front of the join), and with every launch made
+# dearer for the host (under rocprofv3) it does not gain either (19.8 -> 20.1 ms): profiles/r05_notes.md.  Not used while
+# a gradient reducer slices the arena during the backward pass (it would have to hear about a range after its flush).
+WGRAD_DEFER = _os.environ.get('BRCNN_WGRAD_DEFER', '0') == '1'
+WGRAD_DEFER_BYTES = int(_os.environ.get('BRCNN_WGRAD_DEFER_MB', '1024')) << 20
+WGRAD_DEFER_ITEMS = int(_os.environ.get('BRCNN_WGRAD_DEFER_ITEMS', '16'))
+_defer_arenas = {}       # side stream handle -> the slab arena handed to brcnn_wgrad_defer_begin (kept alive here)
 _side_streams = {}
 _join_queued = {}        # (device type, index) -> True while a join callback of the running backward pass is queued
 _side_seen = {}          # (device type, index) -> ids of the parameters whose gradient went to the side stream in this pass
@@ -114,6 +125,44 @@ def _wgrad_side_stream(device):
     return _side_streams[key]
 
 
+def _defer_on(side):
+    """deferral of the slab reductions on `side` (set up on first use); False: off"""
+    h = side.cuda_stream
+    if not WGRAD_DEFER or grad_arena.listener is not None:
+        if h in _defer_arenas:              # (switched off, or a reducer attached since: back to the per-layer form)
+            flush_deferred(side)
+            _L.check(_L.load().brcnn_wgrad_defer_begin(h, None, 0, 0), 'brcnn_wgrad_defer_begin')
+            del _defer_arenas[h]
+        return False
+    if h not in _defer_arenas:
+        arena = torch.empty(WGRAD_DEFER_BYTES, dtype=torch.uint8, device=side.device)
+        with torch.cuda.device(side.device):
+            st = _L.load().brcnn_wgrad_defer_begin(h, arena.data_ptr(), arena.numel(), WGRAD_DEFER_ITEMS)
+        _L.check(st, 'brcnn_wgrad_defer_begin')
+        _defer_arenas[h] = arena
+    return True
+
+
+def set_wgrad_defer(on):
+    """switch the deferral at run time (tests, A/B measurements); off: pending reductions are launched, the arenas released"""
+    global WGRAD_DEFER
+    WGRAD_DEFER = bool(on)
+    if not on:
+        for side in list(_side_streams.values()):
+            _defer_on(side)
+
+
+def flush_deferred(side):
+    """launch the batched slab reduction of the weight-gradient launches pending on `side`"""
+    h = side.cuda_stream
+    if h not in _defer_arenas:
+        return
+    with torch.cuda.device(side.device):
+        st = _L.load().brcnn_wgrad_defer_flush(h)
+    if st < 0:
+        _L.check(st, 'brcnn_wgrad_defer_flush')
+
+
 # parallel.GradReducer reduces the gradients after the end-of-backward join (no accumulator hooks): the side stream
 # stays on under torch.distributed while one is active
 _OWN_REDUCER = [False]
@@ -132,6 +181,7 @@ def _side_stream_for(param, device):
     if id(param) in seen:
         if grad_arena.listener is not None and hasattr(grad_arena.listener, 'shared_parameter'):
             grad_arena.listener.shared_parameter(param)
+        flush_deferred(side)
         torch.cuda.current_stream(device).wait_stream(side)
         return None
     seen.add(id(param))
@@ -145,6 +195,7 @@ def join_side_streams(device=None):
     for key, side in list(_side_streams.items()):
         if device is not None and key != (device.type, device.index):
             continue
+        flush_deferred(side)
         torch.cuda.current_stream(torch.device(*key)).wait_stream(side)
         _join_queued[key] = False
         _side_seen.pop(key, None)
@@ -176,6 +227,7 @@ def _queue_stream_join(main, side):
     def join():
         _join_queued[key] = False
         _side_seen.pop(key, None)
+        flush_deferred(side)
         main.wait_stream(side)
     _join_queued[key] = True
     try:
@@ -264,6 +316,7 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw, h
         # tail the main stream waits for at the end-of-pass join (0.34 ms per bf16 step of bench.py: tools/experiments/
         # join_wait.py); on the main stream it runs beside that backlog
         side = _side_stream_for(weight, dy.device) if (side_ok and (has_dgrad or not WGRAD_TAIL_ON_MAIN)) else None
+        deferred = False
         if side is None:
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
                                                    cin, cout, kh, kw, stride, pad, dt, _conv_stream())
@@ -273,12 +326,18 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw, h
             # LDS-DMA / MFMA phases fill each other's gaps); the streams join at the end of the backward pass
             main = torch.cuda.current_stream(dy.device)
             side.wait_event(main.record_event())            # dy, x and the zero fill of dW are complete here
+            deferred = x_cat.dtype != torch.float32 and _defer_on(side)
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
                                                    cin, cout, kh, kw, stride, pad, dt, _L.stream_handle(side))
             dy.record_stream(side)                          # the allocator must not recycle them under the launch
             x_cat.record_stream(side)
             _queue_stream_join(main, side)
         _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
+        # `deferred`: the slab reduction of this launch may be pending (wgrad_defer.hip).  A consumer on the second
+        # stream (`takes` False: PermutedWeightFunction) reads dW right behind this call: reduce now.  Otherwise dW is
+        # `.grad`, read after the end-of-pass join, which flushes.
+        if deferred and not takes:
+            flush_deferred(side)
         if grad_arena.listener is not None and dy.is_cuda:
             # `takes`: dW is `.grad` itself.  Otherwise autograd (or the caller) COPIES it on the main stream after
             # this function returns (AccumulateGrad's clone of a gradient whose strides are not the parameter's, the

@@ -161,6 +161,12 @@ int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s);
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
 int sk_plan_pp_f32(ConvParams& p, int slots, int bm, int bn, hipStream_t s);
 float* conv_ws_wgrad_slabs(hipStream_t s);          // the weight-gradient slab part of the stream's conv workspace (160 MiB)
+// deferred second stage of the sliced weight gradients (wgrad_defer.hip): slabs from the stream's deferral arena (nullptr:
+// deferral off / request larger than the arena; *err < 0: the flush it had to launch first failed), and the item of a
+// producing launch just issued.  kind: 0 = eight-phase 256 x 256 register order, else (WT << 4) | WG of conv_wgrad_bf16_kernel
+float* wgrad_defer_slabs(hipStream_t s, size_t bytes, int* err);
+void wgrad_defer_push(hipStream_t s, float* slab, float* dw, int tiles, int tiles_k, int slices, int group, int Cout, int K,
+                      int kind);
 unsigned* conv_ws_wgrad_counters(hipStream_t s);   // 8192 zero-initialised, self-resetting arrival counters
 // eight-phase 256 x 256 weight gradient (conv_wgrad_pp_bf16.hip): 1 launched, 0 shape not taken, < 0 error
 int wgrad_pp_bf16_try(const void* x, const void* dy, void* dw, int batch, int num_segments, const int* heights_host,

@@ -407,11 +407,25 @@ int launch(WgradHParams& p, hipStream_t s) {
         attr_done = true;
     }
     p.slab = nullptr;
-    if (g_wgrad_slabs && p.slices > 1 && (size_t)tiles * p.slices * T * T * sizeof(float) <= WGRAD_WS_BYTES)
-        p.slab = brcnn_conv::conv_ws_wgrad_slabs(s);
+    bool deferred = false;
+    if (g_wgrad_slabs && p.slices > 1 && (size_t)tiles * p.slices * T * T * sizeof(float) <= WGRAD_WS_BYTES) {
+        // second stage postponed to the stream's batched reduction (wgrad_defer.hip)?
+        int derr = 0;
+        p.slab = brcnn_conv::wgrad_defer_slabs(s, (size_t)tiles * p.slices * T * T * sizeof(float), &derr);
+        if (derr) return derr;
+        deferred = p.slab != nullptr;
+        if (!p.slab) p.slab = brcnn_conv::conv_ws_wgrad_slabs(s);
+    }
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<WT, ET, WG>), dim3(tiles * p.slices), dim3(64 * WG * WG), lds, s, p);
     BRCNN_LAUNCH_CHECK();
-    if (p.slab) {
+    if (deferred) {
+        int group = p.slices;
+        if (p.slices > g_wgrad_two_pass) {
+            group = 4;
+            while (group * group < p.slices) group++;
+        }
+        brcnn_conv::wgrad_defer_push(s, p.slab, p.dw, tiles, p.tiles_k, p.slices, group, p.Cout, p.K, (WT << 4) | WG);
+    } else if (p.slab) {
         int stride = 1, count = p.slices;
         if (p.slices > g_wgrad_two_pass) {   // few output tiles, many slices: groups of ~sqrt(slices) first (more workgroups, shorter chains)
             int group = 4;

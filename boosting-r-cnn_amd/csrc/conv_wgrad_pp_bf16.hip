@@ -599,9 +599,16 @@ int launch(WgradPPParams& p, hipStream_t s) {
     p.slab = nullptr;
     p.fuse_group = 0;
     p.ngroups = 0;
+    bool deferred = false;
     if (p.slices > 1) {
         if ((size_t)tiles * p.slices * TILE * TILE * sizeof(float) > ((size_t)160 << 20)) return NOT_TAKEN;
-        p.slab = conv_ws_wgrad_slabs(s);
+        if (!g_wgrad_pp_fuse) {      // second stage postponed to the stream's batched reduction (wgrad_defer.hip)?
+            int derr = 0;
+            p.slab = wgrad_defer_slabs(s, (size_t)tiles * p.slices * TILE * TILE * sizeof(float), &derr);
+            if (derr) return derr;
+            deferred = p.slab != nullptr;
+        }
+        if (!p.slab) p.slab = conv_ws_wgrad_slabs(s);
         if (!p.slab) return BRCNN_EINVAL;
         if (g_wgrad_pp_fuse) {      // groups of ~sqrt(slices): two serial passes of <= ~6 slabs each on the last arrivers
             int group = 2;
@@ -618,7 +625,14 @@ int launch(WgradPPParams& p, hipStream_t s) {
     g_wgrad_pp_launches++;
     hipLaunchKernelGGL((conv_wgrad_pp_bf16_kernel<ET, PLAIN>), dim3(tiles * p.slices), dim3(512), lds, s, p);
     BRCNN_LAUNCH_CHECK();
-    if (p.slab && p.fuse_group == 0) {
+    if (deferred) {
+        int group = p.slices;
+        if (p.slices > g_wgrad_pp_two_pass) {
+            group = 4;
+            while (group * group < p.slices) group++;
+        }
+        wgrad_defer_push(s, p.slab, p.dw, tiles, p.tiles_k, p.slices, group, p.Cout, p.K, 0);
+    } else if (p.slab && p.fuse_group == 0) {
         int stride = 1, count = p.slices;
         if (p.slices > g_wgrad_pp_two_pass) {
             int group = 4;

@@ -56,6 +56,10 @@ SIGNATURES = {
                                       [c_ptr]),
     'brcnn_conv2d_wgrad_nhwc_multi': (c_int, [c_ptr] * 3 + [c_int, c_int] + [c_ptr] * 2 + [c_int] * 7 +
                                       [c_ptr]),
+    'brcnn_wgrad_defer_begin': (c_int, [c_ptr, c_ptr, c_size, c_int]),
+    'brcnn_wgrad_defer_flush': (c_int, [c_ptr]),
+    'brcnn_wgrad_defer_pending': (c_int, [c_ptr]),
+    'brcnn_wgrad_defer_stats': (c_int, [c_ptr, c_ptr, c_ptr]),
     'brcnn_stem_workspace_bytes': (c_size, [c_int, c_int, c_int]),
     'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 6 + [c_ptr]),
     'brcnn_conv_set_tile_bf16': (c_int, [c_int]),

@@ -377,6 +377,20 @@ int brcnn_conv2d_wgrad_nhwc_multi(const void *x, const void *dy, void *dw, int b
                                   int num_segments, const int *heights_host,
                                   const int *widths_host, int cin, int cout, int kh, int kw,
                                   int stride, int pad, int dtype, void *stream);
+/* Deferred second stage of the sliced 16-bit weight gradients (csrc/wgrad_defer.hip).  A sliced launch of
+ * brcnn_conv2d_wgrad_nhwc_multi / _grouped (bf16, fp16) writes one fp32 slab per slice of the pixel dimension and adds the
+ * slabs into dw with a second launch.  After brcnn_wgrad_defer_begin(stream, arena, bytes, max_items) the launches on
+ * `stream` take their slabs from the caller-owned `arena` (device memory, 256-byte aligned, >= 1 MiB; a launch whose slabs
+ * exceed it keeps the immediate form) and the second stages of up to `max_items` (<= 64; <= 0: 64) launches wait for
+ * brcnn_wgrad_defer_flush(stream): ONE table-driven launch with the same additions in the same order -- dw is bit for bit
+ * the immediate result, but complete only after the flush.  A full arena / table flushes by itself before the next
+ * producing launch.  arena NULL: deferral off (pending items are flushed first).  _flush returns the number of items
+ * reduced (>= 0) or an error; _pending the number waiting.  The reference has no counterpart (cuDNN's weight gradient is
+ * one call, mmdet/models/backbones/resnet.py:263-302 via torch.nn.Conv2d). */
+int brcnn_wgrad_defer_begin(void *stream, void *arena, size_t bytes, int max_items);
+int brcnn_wgrad_defer_flush(void *stream);
+int brcnn_wgrad_defer_pending(void *stream);
+int brcnn_wgrad_defer_stats(void *stream, long long *flushes, long long *items);
 /* per-step operand preparation of a trainable conv: weight (Cout,Cin,KH,KW) fp32 (the reference's
  * parameter layout) -> fwd (Cout,KH,KW,Cin) and / or dgrad (Cin,KH,KW,Cout) with flipped taps, in
  * `dtype`; either output may be NULL. */

@@ -884,3 +884,76 @@ def test_straight_line_readout_and_plain_setup_keep_the_bits(dtype):
     assert len(fast) == len(general)
     for i, (a, b) in enumerate(zip(fast, general)):
         assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize('et', [BF, torch.float16])
+def test_deferred_slab_reduction_equals_the_per_layer_second_stage(et):
+    """csrc/wgrad_defer.hip: with deferral on for a stream the sliced weight-gradient launches only record an item and ONE
+    table-driven launch (brcnn_wgrad_defer_flush) adds the slabs -- bit for bit the dW of the per-layer second stage, for
+    the three two-buffer tiles, the eight-phase kernel, one- and two-level slice grouping, accumulation into an existing dW,
+    an arena too small for all layers (it flushes by itself) and a layer too large for the arena (immediate form)"""
+    import ctypes
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(23)
+    LV = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    # batch, levels, Cin, Cout, k, stride, pad, tile hook (0: heuristic -> eight-phase where the shape allows)
+    cases = [(2, LV, 256, 256, 3, 1, 1, 0), (8, LV[1:2], 256, 256, 3, 1, 1, 0), (8, LV[1:2], 1024, 256, 1, 1, 0, 0),
+             (3, LV[:1], 128, 128, 3, 2, 1, 2), (8, LV[:1], 64, 64, 1, 1, 0, 1), (2, LV[:1], 128, 64, 3, 1, 1, 1),
+             (8, LV[1:2], 512, 256, 1, 1, 0, 4), (4096, [(1, 1)], 1024, 1024, 1, 1, 0, 0), (8, LV[2:3], 512, 2048, 1, 1, 0, 0)]
+    dt = 1 if et == BF else 3
+    stream = torch.cuda.Stream(DEV)
+    h = stream.cuda_stream
+    layers = []
+    for (N, lv, ci, co, k, st, pd, tile) in cases:
+        outs = [ops.conv_out_size(H, W, k, k, st, pd) for H, W in lv]
+        M = sum(N * ho * wo for ho, wo in outs)
+        x = torch.randn(sum(N * H * W for H, W in lv), ci, generator=g).to(DEV, et)
+        dy = torch.randn(M, co, generator=g).to(DEV, et)
+        base = torch.randn(co, k, k, ci, generator=g).to(DEV)
+        hs = (ctypes.c_int * len(lv))(*[h_ for h_, _ in lv]); ws = (ctypes.c_int * len(lv))(*[w for _, w in lv])
+        layers.append((x, dy, base, (N, len(lv), hs, ws, ci, co, k, k, st, pd, dt), tile))
+
+    def run_all():
+        outs = []
+        for x, dy, base, args, tile in layers:
+            assert L.brcnn_conv_set_tile_wgrad_bf16(tile) == 0
+            dw = base.clone()
+            assert L.brcnn_conv2d_wgrad_nhwc_multi(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), *args, h) == 0
+            outs.append(dw)
+        return outs
+    flushes, items = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    try:
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            ref = run_all()
+            stream.synchronize()
+            for mb, max_items, want_flushes in ((1024, 64, 1), (1024, 3, None), (96, 64, None), (8, 64, None)):
+                arena = torch.empty(mb << 20, dtype=torch.uint8, device=DEV)
+                L.brcnn_wgrad_defer_stats(h, ctypes.byref(flushes), ctypes.byref(items))
+                f0, i0 = flushes.value, items.value
+                assert L.brcnn_wgrad_defer_begin(h, arena.data_ptr(), arena.numel(), max_items) == 0
+                got = run_all()
+                pending = L.brcnn_wgrad_defer_pending(h)
+                if mb == 1024 and max_items == 64:
+                    assert pending >= 6, pending          # (the sliced layers; a one-slice launch has no second stage)
+                    stream.synchronize()
+                    assert not torch.equal(got[0], ref[0])      # ... and their dW is not complete before the flush
+                assert L.brcnn_wgrad_defer_flush(h) == pending
+                assert L.brcnn_wgrad_defer_pending(h) == 0 and L.brcnn_wgrad_defer_flush(h) == 0
+                stream.synchronize()
+                L.brcnn_wgrad_defer_stats(h, ctypes.byref(flushes), ctypes.byref(items))
+                if want_flushes is not None:
+                    assert flushes.value - f0 == want_flushes
+                if mb == 8:
+                    assert items.value - i0 < 6         # (most layers' slabs do not fit 8 MiB: immediate form)
+                for i, (a, b) in enumerate(zip(got, ref)):
+                    assert torch.equal(a, b), (mb, max_items, i, float((a - b).abs().max()))
+                assert L.brcnn_wgrad_defer_begin(h, None, 0, 0) == 0
+            again = run_all()           # deferral off again: the immediate form, complete without a flush
+            stream.synchronize()
+            for a, b in zip(again, ref):
+                assert torch.equal(a, b)
+    finally:
+        L.brcnn_wgrad_defer_begin(h, None, 0, 0)
+        L.brcnn_conv_set_tile_wgrad_bf16(0)

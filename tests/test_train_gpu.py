@@ -497,6 +497,54 @@ def test_wgrad_side_stream_gives_the_same_gradients():
         blocks.set_compute_dtype('f32')
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_deferred_slab_reductions_give_the_same_bits(dtype):
+    """autograd.set_wgrad_defer (BRCNN_WGRAD_DEFER=1, csrc/wgrad_defer.hip): the slab reductions of the weight-gradient
+    launches on the second stream batched into table-driven launches -- every parameter gradient of a 16-bit train step
+    (early RPN backward on: two backward passes, the first without a join) equals the per-layer form BIT FOR BIT, over
+    several steps; the batched launches really ran; switching off again releases the arena"""
+    import ctypes
+    from brcnn import autograd as A, blocks, lib
+    L = lib.load()
+    m = _model()
+    blocks.conv_weights_channels_last(m)
+    m.set_compute_dtype(dtype)
+    img, metas, gts, gls = util.demo_inputs(2, 256, 320, seed=12)
+    args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+    scale = 512.0 if dtype == 'f16' else 1.0
+    saved = (A.WGRAD_DEFER, A.WGRAD_DEFER_ITEMS, m.early_rpn_backward, m.early_backward_scale)
+    ref = None
+    try:
+        m.early_rpn_backward, m.early_backward_scale = True, scale
+        for mode in (False, True, True, True, False):
+            A.set_wgrad_defer(mode)
+            m.zero_grad(set_to_none=True)
+            A.grad_arena.new_step()
+            torch.manual_seed(77)
+            loss, _ = m._parse_losses(m.forward_train(*args))
+            (loss * scale).backward()
+            torch.cuda.current_stream().synchronize()
+            grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+            if ref is None:
+                ref = grads
+                continue
+            assert grads.keys() == ref.keys()
+            for k, ga in grads.items():
+                assert torch.equal(ga, ref[k]), (mode, k, float((ga.float() - ref[k].float()).abs().max()))
+            if mode:
+                side = A._side_streams[('cuda', 0)]
+                fl, it = ctypes.c_longlong(0), ctypes.c_longlong(0)
+                L.brcnn_wgrad_defer_stats(side.cuda_stream, ctypes.byref(fl), ctypes.byref(it))
+                assert it.value >= 10 and fl.value >= 1 and it.value > 2 * fl.value, (fl.value, it.value)
+                assert L.brcnn_wgrad_defer_pending(side.cuda_stream) == 0
+        assert not A._defer_arenas
+    finally:
+        A.WGRAD_DEFER_ITEMS = saved[1]
+        A.set_wgrad_defer(saved[0])
+        m.early_rpn_backward, m.early_backward_scale = saved[2], saved[3]
+        blocks.set_compute_dtype('f32')
+
+
 @pytest.mark.parametrize('dtype,scale', [('f32', 1.0), ('bf16', 1.0), ('f16', 512.0)])
 def test_early_rpn_backward_gives_the_same_step(dtype, scale):
     """`early_rpn_backward`: the RPN branch back-propagated inside the forward pass (proposal stage on a second

@@ -1,0 +1,28 @@
+"""(backward nodes in the calling thread) host-side profile of bench.py's OWN train step (FusedSGD, early RPN backward, arena): cProfile over the timed steps,
+plus the per-step statistics of the bench line.  Where the Python / launch overhead of the second half of the step
+(everything behind the sampler's host synchronisation) goes decides whether the step is device- or launch-bound."""
+import cProfile, io, os, pstats, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.argv = ['bench.py', '--mode', 'train', '--steps', '10', '--warmup', '5', '--no-cpu-baseline'] + sys.argv[1:]
+import torch
+torch.autograd.set_multithreading_enabled(False)     # the backward nodes run in the calling thread: cProfile sees them
+import bench
+_orig = bench.timed
+
+
+def timed(step, steps, warmup, world, device):
+    if warmup:                       # bench's own warm-up call
+        return _orig(step, steps, warmup, world, device)
+    pr = cProfile.Profile()
+    pr.enable()
+    out = _orig(step, steps, warmup, world, device)
+    pr.disable()
+    for key, n in (('tottime', 70), ('cumulative', 120)):
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats(key).print_stats(n)
+        print(s.getvalue()[:30000], file=sys.stderr)
+    return out
+
+
+bench.timed = timed
+bench.main()
