@@ -469,7 +469,7 @@ int fill_rpn_params(RpnLossParams& p, const float* y, int ystride, int batch, in
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { B_L = 0, B_WL, B_L1, B_CORRECT, B_NPOS, B_N };
+enum { B_L = 0, B_WL, B_L1, B_CORRECT, B_NPOS, B_WPOS, B_N };
 
 struct BoostParams {
     const float* cls;          // (N, C+1)
@@ -481,7 +481,18 @@ struct BoostParams {
     int N, C, agnostic;
     float gamma, alpha, iou_gamma, lw_cls, lw_bbox;
     int reg_mean;              // reg_norm == 'mean'
+    // plain: the boosted weights are label weights of the head's own loss (DyProbRoIHead / BoostRoIHead,
+    // prob_roi_head.py:438-468,604-623 over bbox_head.py loss: avg_factor = max(#{w > 0}, 1)) instead of norm_loss
+    int plain;
+    float beta;                // SmoothL1Loss beta of the box term (<= 0: L1Loss)
 };
+
+// smooth_l1_loss (mmdet/models/losses/smooth_l1_loss.py:9-32): 0.5 d^2 / beta below beta, d - 0.5 beta above; beta <= 0: |d|
+__device__ __forceinline__ float box_term(float d, float beta) {
+    const float a = fabsf(d);
+    if (beta > 0.f && a < beta) return 0.5f * a * a / beta;
+    return beta > 0.f ? a - 0.5f * beta : a;
+}
 
 // one wavefront per row: lanes over the classes
 __device__ __forceinline__ void row_softmax(const float* row, int nc, int lane, float& mx, float& se, int& amax) {
@@ -515,7 +526,7 @@ __global__ __launch_bounds__(256) void boost_loss_fwd_kernel(const BoostParams p
     __shared__ float s_part[4][B_N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
-    float v[B_N] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[B_N] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < p.N) {
         const int nc = p.C + 1;
         const float* row = p.cls + (size_t)i * nc;
@@ -529,12 +540,14 @@ __global__ __launch_bounds__(256) void boost_loss_fwd_kernel(const BoostParams p
         const float w = boost_weight(p, i, expf(xl - mx) / se);
         v[B_L] = L;
         v[B_WL] = w * L;
+        v[B_WPOS] = w > 0.f ? 1.f : 0.f;
         v[B_CORRECT] = amax == lab ? 1.f : 0.f;
         if (lab >= 0 && lab < p.C) {
             v[B_NPOS] = 1.f;
             const float* bp = p.bbox + (size_t)i * (p.agnostic ? 4 : 4 * p.C) + (p.agnostic ? 0 : 4 * lab);
             const float* tg = p.targets + (size_t)i * 4;
-            v[B_L1] = fabsf(bp[0] - tg[0]) + fabsf(bp[1] - tg[1]) + fabsf(bp[2] - tg[2]) + fabsf(bp[3] - tg[3]);
+            v[B_L1] = box_term(bp[0] - tg[0], p.beta) + box_term(bp[1] - tg[1], p.beta) + box_term(bp[2] - tg[2], p.beta) +
+                      box_term(bp[3] - tg[3], p.beta);
         }
     }
     if (lane == 0)
@@ -560,7 +573,8 @@ __global__ __launch_bounds__(256) void boost_loss_finalize_kernel(const float* _
     __syncthreads();
     if (threadIdx.x == 0) {
         const float n = (float)p.N;
-        const float c = s_sum[B_L] / s_sum[B_WL];                  // weights * (loss.sum() / (weights * loss).sum())
+        // norm_loss: weights * (loss.sum() / (weights * loss).sum()), mean over n; plain: weighted sum / #{w > 0}
+        const float c = p.plain ? n / fmaxf(s_sum[B_WPOS], 1.f) : s_sum[B_L] / s_sum[B_WL];
         out3[0] = c * s_sum[B_WL] / n;
         const float norm = p.reg_mean ? 4.f * s_sum[B_NPOS] : n;
         out3[1] = s_sum[B_NPOS] > 0.f ? p.lw_bbox * s_sum[B_L1] / norm : 0.f;
@@ -596,7 +610,7 @@ __global__ __launch_bounds__(256) void boost_loss_bwd_kernel(const BoostParams p
         float gv = 0.f;
         if (pos && c >= c0 && c < c0 + 4) {
             const float d = p.bbox[(size_t)i * nb + c] - p.targets[(size_t)i * 4 + (c - c0)];
-            gv = d > 0.f ? kb : (d < 0.f ? -kb : 0.f);
+            gv = (p.beta > 0.f && fabsf(d) < p.beta) ? kb * d / p.beta : (d > 0.f ? kb : (d < 0.f ? -kb : 0.f));
         }
         dbbox[(size_t)i * nb + c] = gv;
     }
@@ -607,9 +621,11 @@ int fill_boost(BoostParams& p, const float* cls, const float* bbox, const int64_
     if (!cls || !bbox || !labels || !priors || !targets || !cfg || n <= 0 || num_classes <= 0) return BRCNN_EINVAL;
     p.cls = cls; p.bbox = bbox; p.labels = (const long long*)labels; p.priors = priors; p.ious = ious; p.targets = targets;
     p.N = n; p.C = num_classes; p.agnostic = agnostic ? 1 : 0;
-    // cfg: [gamma, alpha, iou_gamma, lw_cls, lw_bbox, reg_mean]
+    // cfg: [gamma, alpha, iou_gamma, lw_cls, lw_bbox, reg_mean, plain label weights, smooth-L1 beta]
     p.gamma = cfg[0]; p.alpha = cfg[1]; p.iou_gamma = cfg[2]; p.lw_cls = cfg[3]; p.lw_bbox = cfg[4];
     p.reg_mean = cfg[5] != 0.f;
+    p.plain = cfg[6] != 0.f;
+    p.beta = cfg[7];
     return 0;
 }
 
@@ -681,14 +697,14 @@ BRCNN_API size_t brcnn_boost_loss_workspace_bytes(int n) {
     return (size_t)brcnn_cdiv(n > 0 ? n : 1, 4) * B_N * sizeof(float) + 256;
 }
 
-BRCNN_API int brcnn_boost_loss_forward(const float* cls_score, const float* bbox_pred, const int64_t* labels,
-                                       const float* priors, const float* ious, const float* bbox_targets, int n,
-                                       int num_classes, int reg_class_agnostic, const float* cfg6_host,
-                                       void* workspace, size_t workspace_bytes, float* out3, float* coef2,
-                                       void* stream) {
+BRCNN_API int brcnn_boost_loss_forward_ex(const float* cls_score, const float* bbox_pred, const int64_t* labels,
+                                          const float* priors, const float* ious, const float* bbox_targets, int n,
+                                          int num_classes, int reg_class_agnostic, const float* cfg8_host,
+                                          void* workspace, size_t workspace_bytes, float* out3, float* coef2,
+                                          void* stream) {
     BoostParams p;
     if (int st = fill_boost(p, cls_score, bbox_pred, labels, priors, ious, bbox_targets, n, num_classes,
-                            reg_class_agnostic, cfg6_host))
+                            reg_class_agnostic, cfg8_host))
         return st;
     const int blocks = brcnn_cdiv(n, 4);
     if (!workspace || !out3 || !coef2 || workspace_bytes < (size_t)blocks * B_N * sizeof(float)) return BRCNN_EINVAL;
@@ -701,18 +717,40 @@ BRCNN_API int brcnn_boost_loss_forward(const float* cls_score, const float* bbox
     return 0;
 }
 
-BRCNN_API int brcnn_boost_loss_backward(const float* cls_score, const float* bbox_pred, const int64_t* labels,
-                                        const float* priors, const float* ious, const float* bbox_targets, int n,
-                                        int num_classes, int reg_class_agnostic, const float* cfg6_host,
-                                        const float* grad3, const float* coef2, float* dcls, float* dbbox,
-                                        void* stream) {
+BRCNN_API int brcnn_boost_loss_forward(const float* cls_score, const float* bbox_pred, const int64_t* labels,
+                                       const float* priors, const float* ious, const float* bbox_targets, int n,
+                                       int num_classes, int reg_class_agnostic, const float* cfg6_host,
+                                       void* workspace, size_t workspace_bytes, float* out3, float* coef2,
+                                       void* stream) {
+    if (!cfg6_host) return BRCNN_EINVAL;
+    const float cfg8[8] = {cfg6_host[0], cfg6_host[1], cfg6_host[2], cfg6_host[3], cfg6_host[4], cfg6_host[5], 0.f, 0.f};
+    return brcnn_boost_loss_forward_ex(cls_score, bbox_pred, labels, priors, ious, bbox_targets, n, num_classes,
+                                       reg_class_agnostic, cfg8, workspace, workspace_bytes, out3, coef2, stream);
+}
+
+BRCNN_API int brcnn_boost_loss_backward_ex(const float* cls_score, const float* bbox_pred, const int64_t* labels,
+                                           const float* priors, const float* ious, const float* bbox_targets, int n,
+                                           int num_classes, int reg_class_agnostic, const float* cfg8_host,
+                                           const float* grad3, const float* coef2, float* dcls, float* dbbox,
+                                           void* stream) {
     BoostParams p;
     if (int st = fill_boost(p, cls_score, bbox_pred, labels, priors, ious, bbox_targets, n, num_classes,
-                            reg_class_agnostic, cfg6_host))
+                            reg_class_agnostic, cfg8_host))
         return st;
     if (!grad3 || !coef2 || !dcls || !dbbox) return BRCNN_EINVAL;
     hipLaunchKernelGGL(boost_loss_bwd_kernel, dim3(brcnn_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, p, grad3, coef2,
                        dcls, dbbox);
     BRCNN_LAUNCH_CHECK();
     return 0;
+}
+
+BRCNN_API int brcnn_boost_loss_backward(const float* cls_score, const float* bbox_pred, const int64_t* labels,
+                                        const float* priors, const float* ious, const float* bbox_targets, int n,
+                                        int num_classes, int reg_class_agnostic, const float* cfg6_host,
+                                        const float* grad3, const float* coef2, float* dcls, float* dbbox,
+                                        void* stream) {
+    if (!cfg6_host) return BRCNN_EINVAL;
+    const float cfg8[8] = {cfg6_host[0], cfg6_host[1], cfg6_host[2], cfg6_host[3], cfg6_host[4], cfg6_host[5], 0.f, 0.f};
+    return brcnn_boost_loss_backward_ex(cls_score, bbox_pred, labels, priors, ious, bbox_targets, n, num_classes,
+                                        reg_class_agnostic, cfg8, grad3, coef2, dcls, dbbox, stream);
 }

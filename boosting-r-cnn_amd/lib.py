@@ -131,6 +131,8 @@ SIGNATURES = {
     'brcnn_boost_loss_workspace_bytes': (c_size, [c_int]),
     'brcnn_boost_loss_forward': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr, c_ptr, c_ptr]),
     'brcnn_boost_loss_backward': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int] + [c_ptr] * 6),
+    'brcnn_boost_loss_forward_ex': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr, c_ptr, c_ptr]),
+    'brcnn_boost_loss_backward_ex': (c_int, [c_ptr] * 6 + [c_int, c_int, c_int] + [c_ptr] * 6),
 }
 
 

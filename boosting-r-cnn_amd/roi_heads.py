@@ -460,17 +460,26 @@ class ProbRoIHead(nn.Module):
     def device_train_ok(self):
         """the configuration the whole-batch assignment / sampling / boosting-loss kernels cover: the
         shipped ProbRoIHead recipes (boost=True, CrossEntropy + L1, MaxIoU assignment, RandomSampler)"""
+        from .losses import L1Loss
+        return bool(type(self) is ProbRoIHead and self.boost and self._device_common_ok() and
+                    type(self.bbox_head.loss_bbox) is L1Loss)
+
+    def _device_common_ok(self):
+        """what every whole-batch variant needs: MaxIoU assignment, RandomSampler, softmax cross-entropy, encoded box
+        targets, the fused RoI extractor"""
         from .core import MaxIoUAssigner, RandomSampler
-        from .losses import CrossEntropyLoss, L1Loss
+        from .losses import CrossEntropyLoss
         h = self.bbox_head
         return bool(
-            type(self) is ProbRoIHead and self.boost and self.train_cfg is not None and
+            self.train_cfg is not None and
             type(self.bbox_assigner) is MaxIoUAssigner and self.bbox_assigner.ignore_iof_thr <= 0 and
             (not self.bbox_assigner.match_low_quality or self.bbox_assigner.gt_max_assign_all) and
             type(self.bbox_sampler) is RandomSampler and self.bbox_sampler.num <= 2048 and
             type(h.loss_cls) is CrossEntropyLoss and not h.loss_cls.use_sigmoid and h.loss_cls.class_weight is None and
-            h.loss_cls.ignore_index is None and type(h.loss_bbox) is L1Loss and not h.focal_reg and
+            h.loss_cls.ignore_index is None and not h.focal_reg and
             not h.reg_decoded_bbox and self.train_cfg.pos_weight <= 0 and self.bbox_roi_extractor._fusable())
+
+    _needs_overlaps = False     # (DyProbRoIHead: the assignment's max_overlaps also without `quality`)
 
     def sample_device(self, dets, num, gt_flat, overlap_work=None, proposal_stream=None):
         """assignment + RandomSampler + targets + priors of the whole batch (prob_roi_head.py:23-69,
@@ -491,9 +500,9 @@ class ProbRoIHead(nn.Module):
         import contextlib
         with (torch.cuda.stream(proposal_stream) if proposal_stream is not None else contextlib.nullcontext()):
             res = train_ops.assign_max_iou(dets, gts, offs, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou,
-                                           a.match_low_quality, num_boxes=num, want_overlaps=self.quality,
-                                           want_counts=True)
-            gt_inds, mo, counts = (res[0], res[1], res[2]) if self.quality else (res[0], None, res[1])
+                                           a.match_low_quality, num_boxes=num,
+                                           want_overlaps=self.quality or self._needs_overlaps, want_counts=True)
+            gt_inds, mo, counts = (res[0], res[1], res[2]) if (self.quality or self._needs_overlaps) else (res[0], None, res[1])
             host['counts'].copy_(counts, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -529,6 +538,9 @@ class ProbRoIHead(nn.Module):
                                     add_gt_as_proposals=sp.add_gt_as_proposals,
                                     reg_decoded_bbox=self.bbox_head.reg_decoded_bbox, want_ious=self.quality)
         out['rows'] = rows
+        # host-side knowledge of the draw: sampled positives of the batch, the proposals' overlaps (DyProbRoIHead)
+        out['num_pos_host'] = sum(train_ops.sample_counts(p_, n_, sp.num, num_pos, sp.neg_pos_ub)[0] for p_, n_ in cnt)
+        out['max_overlaps'], out['num_gts_host'] = mo, [offs[b + 1] - offs[b] for b in range(B)]
         return out, extra
 
     def forward_train_device(self, feats_nhwc, img_metas, dets, num, gt_flat, overlap_work=None, proposal_stream=None):
@@ -762,6 +774,39 @@ class BoostRoIHead(ProbRoIHead):
         losses.update(bbox_results['loss_bbox'])
         return losses
 
+    # ---- device-resident train step (whole batch) ------------------------------------------------
+    def device_train_ok(self):
+        """the one training case the reference runs (a single foreground class: its assigner rejects (n, 4 + P) rows
+        for P > 1; `quality` broadcasts an (n, n) weight matrix -- left to the per-image chain): proposals are then
+        (n, 5) rows like ProbRoIHead's, and the whole-batch kernels apply"""
+        from .losses import L1Loss
+        return bool(type(self) is BoostRoIHead and self._device_common_ok() and not self.quality and
+                    self.bbox_head.num_classes == 1 and type(self.bbox_head.loss_bbox) in (L1Loss, SmoothL1Loss))
+
+    def forward_train_device(self, feats_nhwc, img_metas, dets, num, gt_flat, overlap_work=None, proposal_stream=None):
+        """forward_train below on the padded device proposals (P = 1): the prior gathered at the label is the score for
+        a positive and ALSO for a negative (bg column = max_p s_p, :318-326) where ProbRoIHead uses 1 - score; the
+        boosted weights are plain label weights of the head's loss (:438-468)"""
+        from . import train_ops
+        smp, extra = self.sample_device(dets, num, gt_flat, overlap_work, proposal_stream)
+        stage_mark('sampler')
+        if callable(feats_nhwc):
+            feats_nhwc = feats_nhwc()
+        roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, smp['rois'])
+        stage_mark('roi_align')
+        cls_score, bbox_pred = self.bbox_head.forward_nhwc(roi_feats)
+        stage_mark('fc_head')
+        h = self.bbox_head
+        labels = smp['labels']
+        priors = torch.where(labels >= h.num_classes, 1 - smp['priors'], smp['priors'])
+        out3 = train_ops.boost_loss(cls_score, bbox_pred, labels, priors, smp['bbox_targets'], h.num_classes,
+                                    self.gamma if self.boost else 0.0, self.alpha if self.boost else 0.0, None, 0.0,
+                                    h.loss_cls.loss_weight, h.loss_bbox.loss_weight, 'bbox_num', h.reg_class_agnostic,
+                                    plain_label_weights=True, smooth_l1_beta=getattr(h.loss_bbox, 'beta', 0.0))
+        stage_mark('boost_loss')
+        self.last_samples = smp
+        return dict(loss_cls=out3[0], loss_bbox=out3[1], acc=out3[2].reshape(1)), extra
+
     def _bbox_forward_train_boost(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
                                   priors, ious=None):
         rois = bbox2roi([res.bboxes for res in sampling_results])
@@ -844,6 +889,67 @@ class DyProbRoIHead(ProbRoIHead):
             self.update_hyperparameters()
         return losses
 
+    # ---- device-resident train step (whole batch) ------------------------------------------------
+    _needs_overlaps = True
+
+    def device_train_ok(self):
+        """DyProbRoIHead on the whole-batch kernels: the common conditions + SmoothL1Loss; boosted or not"""
+        return bool(type(self) is DyProbRoIHead and self._device_common_ok() and not self.quality and
+                    type(self.bbox_head.loss_bbox) is SmoothL1Loss)
+
+    def forward_train_device(self, feats_nhwc, img_metas, dets, num, gt_flat, overlap_work=None, proposal_stream=None):
+        """forward_train above on the padded device proposals: the same sampling / target kernels as ProbRoIHead's
+        step, the Dynamic R-CNN statistics from device tensors (resolved on the host only when the schedule is due:
+        every update_iter_interval iterations instead of the reference's per-image reads), the boosted weights as
+        plain label weights and SmoothL1(beta) inside the boosting-loss kernels"""
+        from . import train_ops
+        dyn = self.train_cfg.dynamic_rcnn
+        smp, extra = self.sample_device(dets, num, gt_flat, overlap_work, proposal_stream)
+        stage_mark('sampler')
+        # k-th largest overlap of [1.0 x ground truths (added by the sampler), proposals] per image (:515-517; the sampler's
+        # add_gt_ has already extended assign_result.max_overlaps when the reference takes the top-k)
+        mo = smp['max_overlaps']
+        B, K = mo.shape
+        valid = torch.arange(K, device=mo.device)[None, :] < num.reshape(B, 1)
+        srt = torch.where(valid, mo, mo.new_full((), -1.0)).sort(dim=1, descending=True)[0]
+        g_t = torch.tensor([g if self.bbox_sampler.add_gt_as_proposals else 0 for g in smp['num_gts_host']],
+                           dtype=torch.int64, device=mo.device)
+        k_t = torch.clamp(g_t + num.reshape(B).to(torch.int64), max=int(dyn.iou_topk))     # min(iou_topk, len(max_overlaps))
+        idx = k_t - g_t - 1                                                                # < 0: the k-th is a ground truth's 1.0
+        kth = torch.where(idx >= 0, srt.gather(1, idx.clamp(min=0).reshape(B, 1)).reshape(B), srt.new_ones(B))
+        self.iou_history.append(kth.mean())
+        if callable(feats_nhwc):
+            feats_nhwc = feats_nhwc()
+        roi_feats = self.bbox_roi_extractor.forward_nhwc(feats_nhwc, smp['rois'])
+        stage_mark('roi_align')
+        cls_score, bbox_pred = self.bbox_head.forward_nhwc(roi_feats)
+        stage_mark('fc_head')
+        h = self.bbox_head
+        # beta statistic (:562-567): beta_topk-th smallest mean |dx|, |dy| target over the batch's positives
+        labels, tg = smp['labels'], smp['bbox_targets']
+        n_pos = int(smp['num_pos_host'])
+        cur = torch.where(labels < h.num_classes, tg[:, :2].abs().mean(dim=1), tg.new_full((), float('inf')))
+        beta_topk = min(dyn.beta_topk * B, n_pos)
+        self.beta_history.append(cur.sort()[0][beta_topk - 1])
+        out3 = train_ops.boost_loss(cls_score, bbox_pred, labels, smp['priors'], tg, h.num_classes,
+                                    self.gamma if self.boost else 0.0, self.alpha if self.boost else 0.0, None, 0.0,
+                                    h.loss_cls.loss_weight, h.loss_bbox.loss_weight, 'bbox_num', h.reg_class_agnostic,
+                                    plain_label_weights=True, smooth_l1_beta=h.loss_bbox.beta)
+        stage_mark('boost_loss')
+        self.last_samples = smp
+        if len(self.iou_history) % dyn.update_iter_interval == 0:
+            self.update_hyperparameters()
+        return dict(loss_cls=out3[0], loss_bbox=out3[1], acc=out3[2].reshape(1)), extra
+
+    @staticmethod
+    def _resolved(history):
+        """history entries as host floats (the device path appends device scalars: one transfer here)"""
+        if any(torch.is_tensor(v) for v in history):
+            dev = [v for v in history if torch.is_tensor(v)]
+            vals = iter(torch.stack([v.detach().float().reshape(()) for v in dev]).tolist())
+            return [next(vals) if torch.is_tensor(v) else v for v in history]
+        return list(history)
+
     def _record_beta(self, bbox, bbox_weights, num_imgs):
         pos_inds = bbox_weights[:, 0].nonzero().squeeze(1)
         cur_target = bbox[pos_inds, :2].abs().mean(dim=1)
@@ -876,6 +982,7 @@ class DyProbRoIHead(ProbRoIHead):
 
     def update_hyperparameters(self):
         dyn = self.train_cfg.dynamic_rcnn
+        self.iou_history, self.beta_history = self._resolved(self.iou_history), self._resolved(self.beta_history)
         new_iou_thr = max(dyn.initial_iou, np.mean(self.iou_history))
         self.iou_history = []
         self.bbox_assigner.pos_iou_thr = new_iou_thr

@@ -291,10 +291,10 @@ class BoostLossFunction(Function):
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
         coef = torch.empty((2,), dtype=torch.float32, device=dev)
         cfg = _floats(cfg6)
-        st = lib.brcnn_boost_loss_forward(_ptr(cls_c), _ptr(bb_c), _ptr(labels), _ptr(priors), _ptr(io), _ptr(tg), n,
-                                          int(num_classes), int(bool(agnostic)), cfg, _ptr(ws), nb, _ptr(out3), _ptr(coef),
-                                          _stream())
-        _L.check(st, 'brcnn_boost_loss_forward')
+        st = lib.brcnn_boost_loss_forward_ex(_ptr(cls_c), _ptr(bb_c), _ptr(labels), _ptr(priors), _ptr(io), _ptr(tg), n,
+                                             int(num_classes), int(bool(agnostic)), cfg, _ptr(ws), nb, _ptr(out3),
+                                             _ptr(coef), _stream())
+        _L.check(st, 'brcnn_boost_loss_forward_ex')
         ctx.save_for_backward(cls_c, bb_c, labels, priors, tg, coef, *([io] if io is not None else []))
         ctx.cfg = (n, int(num_classes), bool(agnostic), tuple(cfg6), cls_score.dtype, bbox_pred.dtype)
         return out3
@@ -307,17 +307,20 @@ class BoostLossFunction(Function):
         n, num_classes, agnostic, cfg6, cdt, bdt = ctx.cfg
         dcls, dbb = torch.empty_like(cls_c), torch.empty_like(bb_c)
         g3 = g3.float().contiguous()
-        st = _L.load().brcnn_boost_loss_backward(_ptr(cls_c), _ptr(bb_c), _ptr(labels), _ptr(priors), _ptr(io), _ptr(tg),
-                                                 n, num_classes, int(agnostic), _floats(cfg6), _ptr(g3), _ptr(coef),
-                                                 _ptr(dcls), _ptr(dbb), _stream())
-        _L.check(st, 'brcnn_boost_loss_backward')
+        st = _L.load().brcnn_boost_loss_backward_ex(_ptr(cls_c), _ptr(bb_c), _ptr(labels), _ptr(priors), _ptr(io), _ptr(tg),
+                                                    n, num_classes, int(agnostic), _floats(cfg6), _ptr(g3), _ptr(coef),
+                                                    _ptr(dcls), _ptr(dbb), _stream())
+        _L.check(st, 'brcnn_boost_loss_backward_ex')
         return dcls.to(cdt), dbb.to(bdt), None, None, None, None, None, None, None
 
 
 def boost_loss(cls_score, bbox_pred, labels, priors, bbox_targets, num_classes, gamma, alpha=0.0, ious=None,
-               iou_gamma=0.0, loss_cls_weight=1.0, loss_bbox_weight=1.0, reg_norm='bbox_num', reg_class_agnostic=False):
-    """[loss_cls, loss_bbox, acc] as a (3,) tensor (differentiable w.r.t. cls_score and bbox_pred)"""
-    cfg6 = (float(gamma), float(alpha), float(iou_gamma), float(loss_cls_weight), float(loss_bbox_weight),
-            1.0 if reg_norm == 'mean' else 0.0)
+               iou_gamma=0.0, loss_cls_weight=1.0, loss_bbox_weight=1.0, reg_norm='bbox_num', reg_class_agnostic=False,
+               plain_label_weights=False, smooth_l1_beta=0.0):
+    """[loss_cls, loss_bbox, acc] as a (3,) tensor (differentiable w.r.t. cls_score and bbox_pred).
+    `plain_label_weights`: the boosted weights enter the head's own loss as label weights (DyProbRoIHead,
+    prob_roi_head.py:604-623) instead of ProbRoIHead's norm_loss; `smooth_l1_beta` > 0: SmoothL1Loss box term"""
+    cfg8 = (float(gamma), float(alpha), float(iou_gamma), float(loss_cls_weight), float(loss_bbox_weight),
+            1.0 if reg_norm == 'mean' else 0.0, 1.0 if plain_label_weights else 0.0, float(smooth_l1_beta))
     return BoostLossFunction.apply(cls_score, bbox_pred, labels, priors, ious, bbox_targets, int(num_classes),
-                                   bool(reg_class_agnostic), cfg6)
+                                   bool(reg_class_agnostic), cfg8)

@@ -746,6 +746,22 @@ int brcnn_boost_loss_backward(const float *cls_score, const float *bbox_pred, co
                               int num_classes, int reg_class_agnostic, const float *cfg6_host,
                               const float *grad3, const float *coef2, float *dcls, float *dbbox,
                               void *stream);
+/* the same kernels with two more switches, cfg8_host = cfg6 + [plain, beta]:
+ *   plain != 0: the boosted weights are LABEL WEIGHTS of the head's own loss -- loss_cls = sum(w * ce) / max(#{w > 0}, 1)
+ *     (DyProbRoIHead._bbox_forward_train_boost, models/roi_heads/prob_roi_head.py:604-623 over
+ *     bbox_heads/bbox_head.py loss; also gamma = 0 for its un-boosted branch) instead of norm_loss;
+ *   beta > 0: SmoothL1Loss(beta) for the box term (models/losses/smooth_l1_loss.py:9-32; Dynamic R-CNN moves beta
+ *     every update_iter_interval iterations), beta <= 0: L1Loss. */
+int brcnn_boost_loss_forward_ex(const float *cls_score, const float *bbox_pred, const int64_t *labels,
+                                const float *priors, const float *ious, const float *bbox_targets, int n,
+                                int num_classes, int reg_class_agnostic, const float *cfg8_host,
+                                void *workspace, size_t workspace_bytes, float *out3, float *coef2,
+                                void *stream);
+int brcnn_boost_loss_backward_ex(const float *cls_score, const float *bbox_pred, const int64_t *labels,
+                                 const float *priors, const float *ious, const float *bbox_targets, int n,
+                                 int num_classes, int reg_class_agnostic, const float *cfg8_host,
+                                 const float *grad3, const float *coef2, float *dcls, float *dbbox,
+                                 void *stream);
 
 /* ------------------------------------------------------------------------------
  * Optimizer step of the train loop: SGD with momentum and weight decay after clipping the global gradient

@@ -642,6 +642,14 @@ def _dev_inputs(num_classes, cols, seed):
             [p.to(DEV) for p in props])
 
 
+def _padded_proposals(props):
+    B, K = len(props), max(len(p) for p in props)
+    dets = torch.zeros((B, K, 5), dtype=torch.float32, device=DEV)
+    for b, p in enumerate(props):
+        dets[b, :len(p)] = p
+    return dets, torch.tensor([len(p) for p in props], dtype=torch.int32, device=DEV)
+
+
 def _loss_close(got, ref):
     return torch.allclose(got.detach().cpu().float().reshape(-1), T(ref).float().reshape(-1), rtol=2e-3, atol=1e-4)
 
@@ -661,6 +669,39 @@ def test_boost_roi_head_train_golden(tag, over):
         assert _loss_close(losses[k], g[f'boost_{tag}_{k}']), (k, losses[k], g[f'boost_{tag}_{k}'])
     (losses['loss_cls'] + losses['loss_bbox']).backward()
     assert all(torch.isfinite(p.grad).all() for p in head.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize('smooth', [False, True])
+def test_boost_roi_head_whole_batch_device_path_golden(smooth):
+    """BoostRoIHead.forward_train_device (P = 1, the case the reference trains): the whole-batch kernels against the
+    REFERENCE's losses (g18 'p': gamma 0.5, alpha 0.75, L1Loss) and, with a SmoothL1 box loss, against the per-image chain;
+    gradients of both paths agree"""
+    from brcnn import train_ops
+    g = load('g18_boost_variants')
+    over = dict(boost=True, quality=False, gamma=0.5, alpha=0.75)
+    if smooth:
+        over['loss_bbox'] = dict(type='SmoothL1Loss', beta=0.5, loss_weight=1.0)
+    head = _variant_head('BoostRoIHead', 1, 18, **over).train()
+    ref_head = _variant_head('BoostRoIHead', 1, 18, **over).train()
+    assert head.device_train_ok()
+    feats, metas, gts, gls, props = _dev_inputs(1, 1, 18)
+    dets, num = _padded_proposals(props)
+    torch.manual_seed(5)
+    losses, _ = head.forward_train_device([f.permute(0, 2, 3, 1).contiguous() for f in feats], metas, dets, num,
+                                          train_ops.flatten_gts(gts, gls))
+    torch.manual_seed(5)
+    ref = ref_head.forward_train(feats, metas, props, gts, gls)
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        if not smooth:
+            assert _loss_close(losses[k], g[f'boost_p_{k}']), (k, losses[k], g[f'boost_p_{k}'])
+        assert torch.allclose(losses[k].reshape(-1), ref[k].reshape(-1), rtol=2e-3, atol=1e-4), (k, losses[k], ref[k])
+    (losses['loss_cls'] + losses['loss_bbox']).backward()
+    (ref['loss_cls'] + ref['loss_bbox']).backward()
+    for (k, pa), (_, pb) in zip(head.named_parameters(), ref_head.named_parameters()):
+        if pb.grad is None:
+            continue
+        scale = float(pb.grad.abs().max()) + 1e-12
+        assert float((pa.grad - pb.grad).abs().max()) <= 2e-3 * scale, (k, float((pa.grad - pb.grad).abs().max()), scale)
 
 
 def test_boost_roi_head_test_golden():
@@ -698,6 +739,49 @@ def test_dyprob_roi_head_schedule_golden():
                  len(head.iou_history), len(head.beta_history)]
         assert np.allclose(sched, g['dy_sched'][it], rtol=1e-4, atol=1e-6), (it, sched, g['dy_sched'][it])
     assert g['dy_sched'][1][3] != 1.0 or g['dy_sched'][1][0] != 0.6   # the schedule moved something
+
+
+@pytest.mark.parametrize('boost', [True, False])
+def test_dyprob_roi_head_whole_batch_device_path_golden(boost):
+    """DyProbRoIHead.forward_train_device (whole batch: brcnn_assign_max_iou + brcnn_rcnn_sample + the boosting-loss
+    kernels with plain label weights and SmoothL1(beta), Dynamic R-CNN statistics from device tensors) against the
+    REFERENCE's losses and schedule of the same four iterations (g18; boost=True), and against the per-image path of
+    this repo for the un-boosted branch (prob_roi_head.py:473-623); gradients of both paths agree"""
+    from brcnn import train_ops
+    g = load('g18_boost_variants')
+    kw = dict(boost=boost, gamma=0.5, loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0),
+              dynamic_rcnn=dict(iou_topk=40, beta_topk=6, update_iter_interval=2, initial_iou=0.4, initial_beta=1.0))
+    head = _variant_head('DyProbRoIHead', 4, 20, **kw).train()
+    ref_head = _variant_head('DyProbRoIHead', 4, 20, **kw).train()
+    assert head.device_train_ok()
+    for it in range(4):
+        feats, metas, gts, gls, props = _dev_inputs(4, 1, 30 + it)
+        dets, num = _padded_proposals(props)
+        nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in feats]
+        torch.manual_seed(50 + it)
+        losses, _ = head.forward_train_device(nhwc, metas, dets, num, train_ops.flatten_gts(gts, gls))
+        torch.manual_seed(50 + it)
+        ref = ref_head.forward_train(feats, metas, props, gts, gls)
+        for k in ('loss_cls', 'loss_bbox', 'acc'):
+            if boost:
+                assert _loss_close(losses[k], g[f'dy{it}_{k}']), (it, k, losses[k], g[f'dy{it}_{k}'])
+            assert torch.allclose(losses[k].reshape(-1), ref[k].reshape(-1), rtol=2e-3, atol=1e-4), (it, k, losses[k], ref[k])
+        head.zero_grad(set_to_none=True); ref_head.zero_grad(set_to_none=True)
+        (losses['loss_cls'] + losses['loss_bbox']).backward()
+        (ref['loss_cls'] + ref['loss_bbox']).backward()
+        for (k, pa), (_, pb) in zip(head.named_parameters(), ref_head.named_parameters()):
+            if pb.grad is None:
+                assert pa.grad is None or float(pa.grad.abs().max()) == 0.0, k
+                continue
+            scale = float(pb.grad.abs().max()) + 1e-12
+            assert float((pa.grad - pb.grad).abs().max()) <= 2e-3 * scale, (it, k, float((pa.grad - pb.grad).abs().max()), scale)
+        sched = [head.bbox_assigner.pos_iou_thr, head.bbox_assigner.neg_iou_thr, head.bbox_assigner.min_pos_iou,
+                 head.bbox_head.loss_bbox.beta, len(head.iou_history), len(head.beta_history)]
+        rsched = [ref_head.bbox_assigner.pos_iou_thr, ref_head.bbox_assigner.neg_iou_thr, ref_head.bbox_assigner.min_pos_iou,
+                  ref_head.bbox_head.loss_bbox.beta, len(ref_head.iou_history), len(ref_head.beta_history)]
+        assert np.allclose(sched, rsched, rtol=1e-4, atol=1e-6), (it, sched, rsched)
+        if boost:
+            assert np.allclose(sched, g['dy_sched'][it], rtol=1e-4, atol=1e-6), (it, sched, g['dy_sched'][it])
 
 
 @pytest.mark.parametrize('dt,ratio', [('f32', 0.1), ('bf16', 0.35)])

@@ -463,6 +463,57 @@ def test_train_step_device_path_equals_reference_chain():
         assert (ga - gb).abs().max().item() <= 2e-3 * scale, (k, (ga - gb).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_dyprob_detector_trains_on_the_device_path(dtype):
+    """the detector with a DyProbRoIHead (Dynamic R-CNN schedule on the boosting head, prob_roi_head.py:473-623; no shipped
+    recipe) takes the whole-batch device path: losses and parameter gradients of three iterations equal the
+    per-image chain (device_train_path=False) on the same sampler seed, and the schedule moves the same thresholds"""
+    import copy
+    from brcnn import blocks
+    cfg = Config.fromfile(CFG)
+    mc = copy.deepcopy(cfg.model)
+    mc.roi_head.type = 'DyProbRoIHead'
+    mc.roi_head.bbox_head.loss_bbox = dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)
+    mc.train_cfg.rcnn.dynamic_rcnn = dict(iou_topk=30, beta_topk=4, update_iter_interval=2, initial_iou=0.4, initial_beta=1.0)
+    models = []
+    for _ in range(2):
+        m = build_detector(copy.deepcopy(mc))
+        m.load_state_dict(util.seeded_state_dict(m, seed=10))
+        models.append(m.to(DEV).train())
+    dev_m, ref_m = models
+    ref_m.device_train_path = False
+    try:
+        for m in models:
+            m.set_compute_dtype(dtype)
+        assert dev_m.roi_head.device_train_ok() and dev_m._device_train_ok(torch.zeros(1, device=DEV), None, None)
+        tol = 2e-3 if dtype == 'f32' else 6e-2
+        for it in range(3):
+            img, metas, gts, gls = util.demo_inputs(2, 128, 192, seed=20 + it)
+            args = (img.to(DEV), metas, [b.to(DEV) for b in gts], [l.to(DEV) for l in gls])
+            out = []
+            for m in models:
+                m.zero_grad(set_to_none=True)
+                torch.manual_seed(77 + it)
+                loss, log_vars = m._parse_losses(m.forward_train(*args))
+                loss.backward()
+                out.append((dict(log_vars), {k: p.grad.float().clone() for k, p in m.named_parameters() if p.grad is not None}))
+            for k in out[0][0]:
+                assert np.isclose(out[0][0][k], out[1][0][k], rtol=tol, atol=1e-4), (it, k, out[0][0][k], out[1][0][k])
+            if dtype == 'f32':
+                assert out[0][1].keys() == out[1][1].keys()
+                for k, ga in out[0][1].items():
+                    gb = out[1][1][k]
+                    scale = gb.abs().max().item() + 1e-12
+                    assert (ga - gb).abs().max().item() <= tol * scale, (it, k, (ga - gb).abs().max().item(), scale)
+            a, b = dev_m.roi_head, ref_m.roi_head
+            assert len(a.iou_history) == len(b.iou_history) and len(a.beta_history) == len(b.beta_history)
+            assert np.isclose(a.bbox_assigner.pos_iou_thr, b.bbox_assigner.pos_iou_thr, rtol=1e-3 if dtype == 'f32' else 5e-2)
+            assert np.isclose(a.bbox_head.loss_bbox.beta, b.bbox_head.loss_bbox.beta, rtol=1e-3 if dtype == 'f32' else 5e-2)
+        assert dev_m.roi_head.bbox_assigner.pos_iou_thr != 0.5 or dev_m.roi_head.bbox_head.loss_bbox.beta != 1.0
+    finally:
+        blocks.set_compute_dtype('f32')
+
+
 def test_wgrad_side_stream_gives_the_same_gradients():
     """weight-gradient launches on the second HIP stream (autograd.WGRAD_SIDE_STREAM): every parameter gradient of a
     bf16 train step equals the single-stream run up to the order of the fp32 atomics, over several steps that reuse
