@@ -12,6 +12,8 @@
 // writes.  The arena is a bump allocator: when it (or the item table) is full the next producing launch flushes first;
 // stream order makes the reuse safe.  dW of a deferred layer is complete only after the flush: whoever reads it earlier
 // (a consumer on the same stream, a gradient reducer) asks for the flush first (autograd.py does).
+// The per-stream state is guarded by a mutex, but the slab request and the item of ONE producing launch are two calls:
+// launches and flushes for a given stream must come from one thread at a time (as any launch sequence on a stream does).
 #include <hip/hip_runtime.h>
 
 #include <mutex>

@@ -268,12 +268,44 @@ class CocoDataset(CustomDataset):
                                              score=float(bboxes[i][4]), category_id=self.cat_ids[label]))
         return json_results
 
+    def _proposal2json(self, results):
+        """class-agnostic proposals (k, 5) per image (coco.py:208-221): category 1"""
+        json_results = []
+        for idx in range(len(self)):
+            img_id = self.img_ids[idx]
+            bboxes = results[idx]
+            for i in range(bboxes.shape[0]):
+                json_results.append(dict(image_id=img_id, bbox=self.xyxy2xywh(bboxes[i]), score=float(bboxes[i][4]),
+                                         category_id=1))
+        return json_results
+
     def results2json(self, results, outfile_prefix):
-        assert isinstance(results[0], list), 'bbox results (list per class) expected'
-        out = f'{outfile_prefix}.bbox.json'
-        with open(out, 'w') as f:
-            json.dump(self._det2json(results), f)
-        return dict(bbox=out, proposal=out)
+        """coco.py:275-309: per-class lists -> '<prefix>.bbox.json' (also the 'proposal' file); one (k, 5) array per
+        image -> '<prefix>.proposal.json'.  (Mask tuples are outside the hot path.)"""
+        if isinstance(results[0], list):
+            out = f'{outfile_prefix}.bbox.json'
+            with open(out, 'w') as f:
+                json.dump(self._det2json(results), f)
+            return dict(bbox=out, proposal=out)
+        if isinstance(results[0], np.ndarray):
+            out = f'{outfile_prefix}.proposal.json'
+            with open(out, 'w') as f:
+                json.dump(self._proposal2json(results), f)
+            return dict(proposal=out)
+        raise TypeError('invalid type of results')
+
+    def fast_eval_recall(self, results, proposal_nums, iou_thrs, logger=None):
+        """coco.py:311-333: average recall over `iou_thrs` per proposal number, against the non-crowd, non-ignored
+        ground-truth boxes; `results` are per-image proposals (k, 4 | 5)"""
+        from .evaluation import eval_recalls
+        gt_bboxes = []
+        for img_id in self.img_ids:
+            anns = self.coco.load_anns(self.coco.get_ann_ids(img_ids=[img_id]))
+            boxes = [[a['bbox'][0], a['bbox'][1], a['bbox'][0] + a['bbox'][2], a['bbox'][1] + a['bbox'][3]]
+                     for a in anns if not (a.get('ignore', False) or a['iscrowd'])]
+            gt_bboxes.append(np.array(boxes, dtype=np.float32) if boxes else np.zeros((0, 4)))
+        recalls = eval_recalls(gt_bboxes, results, proposal_nums, iou_thrs, logger=logger)
+        return recalls.mean(axis=1)
 
     def format_results(self, results, jsonfile_prefix=None, **kwargs):
         assert isinstance(results, list), 'results must be a list'
@@ -288,23 +320,46 @@ class CocoDataset(CustomDataset):
 
     def evaluate(self, results, metric='bbox', logger=None, jsonfile_prefix=None, classwise=False,
                  proposal_nums=(100, 300, 1000), iou_thrs=None, metric_items=None):
-        """coco.py:362-560, bbox metric: COCO mAP through this repo's COCOeval restatement"""
+        """coco.py:362-560: 'bbox' (COCO mAP), 'proposal' (class-agnostic AR: useCats = 0) through this repo's COCOeval
+        restatement, 'proposal_fast' (eval_recalls on per-image proposals).  'segm' needs masks: outside the hot path."""
         from .evaluation import COCOeval
         metrics = metric if isinstance(metric, list) else [metric]
         for m in metrics:
-            if m != 'bbox':
-                raise KeyError(f'metric {m} is not supported (bbox only on this path)')
+            if m not in ('bbox', 'proposal', 'proposal_fast'):
+                raise KeyError(f'metric {m} is not supported (bbox / proposal / proposal_fast on this path)')
         if iou_thrs is None:
             iou_thrs = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
+        if metric_items is not None and not isinstance(metric_items, list):
+            metric_items = [metric_items]
         eval_results = {}
-        dets = self._det2json(results)
+        for m in metrics:
+            if m == 'proposal_fast':
+                ar = self.fast_eval_recall(results, proposal_nums, iou_thrs, logger='silent')
+                for i, num in enumerate(proposal_nums):
+                    eval_results[f'AR@{num}'] = ar[i]
+                if logger is not None:
+                    logger.info(''.join(f'\nAR@{num}\t{ar[i]:.4f}' for i, num in enumerate(proposal_nums)))
+                continue
+            part = self._evaluate_coco(results, m, logger, jsonfile_prefix, classwise, proposal_nums, iou_thrs, metric_items)
+            if part is None:
+                break
+            eval_results.update(part)
+        return eval_results
+
+    def _evaluate_coco(self, results, metric, logger, jsonfile_prefix, classwise, proposal_nums, iou_thrs, metric_items):
+        from .evaluation import COCOeval
+        eval_results = {}
+        dets = self._det2json(results) if isinstance(results[0], list) else self._proposal2json(results)
         if jsonfile_prefix is not None:
-            with open(f'{jsonfile_prefix}.bbox.json', 'w') as f:
+            kind = 'bbox' if isinstance(results[0], list) else 'proposal'
+            with open(f'{jsonfile_prefix}.{kind}.json', 'w') as f:
                 json.dump(dets, f)
+        if metric == 'bbox' and not isinstance(results[0], list):
+            raise KeyError('bbox is not in results')
         if len(dets) == 0:
             if logger is not None:
                 logger.error('The testing results of the whole dataset is empty.')
-            return eval_results
+            return None
         coco_dt = self.coco.loadRes(dets)
         ev = COCOeval(self.coco, coco_dt, 'bbox')
         ev.params.catIds = self.cat_ids
@@ -313,6 +368,20 @@ class CocoDataset(CustomDataset):
         ev.params.iouThrs = iou_thrs
         names = {'mAP': 0, 'mAP_50': 1, 'mAP_75': 2, 'mAP_s': 3, 'mAP_m': 4, 'mAP_l': 5,
                  'AR@100': 6, 'AR@300': 7, 'AR@1000': 8, 'AR_s@1000': 9, 'AR_m@1000': 10, 'AR_l@1000': 11}
+        if metric_items is not None:
+            for item in metric_items:
+                if item not in names:
+                    raise KeyError(f'metric item {item} is not supported')
+        if metric == 'proposal':
+            ev.params.useCats = 0
+            ev.evaluate()
+            ev.accumulate()
+            text = ev.summarize()
+            if logger is not None:
+                logger.info('\n' + text)
+            for item in (metric_items or ['AR@100', 'AR@300', 'AR@1000', 'AR_s@1000', 'AR_m@1000', 'AR_l@1000']):
+                eval_results[item] = float(f'{ev.stats[names[item]]:.3f}')
+            return eval_results
         ev.evaluate()
         ev.accumulate()
         text = ev.summarize()
@@ -712,15 +781,25 @@ class VOCDataset(XMLDataset):
     def evaluate(self, results, metric='mAP', logger=None, proposal_nums=(100, 300, 1000), iou_thr=0.5,
                  scale_ranges=None):
         from collections import OrderedDict
-        from .evaluation import eval_map
+        from .evaluation import eval_map, eval_recalls
         if not isinstance(metric, str):
             assert len(metric) == 1
             metric = metric[0]
-        if metric != 'mAP':
+        if metric not in ('mAP', 'recall'):
             raise KeyError(f'metric {metric} is not supported')
         annotations = [self.get_ann_info(i) for i in range(len(self))]
         eval_results = OrderedDict()
         iou_thrs = [iou_thr] if isinstance(iou_thr, float) else iou_thr
+        if metric == 'recall':      # voc.py:91-106: proposals (k, 4 | 5) per image, legacy +1 extents
+            recalls = eval_recalls([ann['bboxes'] for ann in annotations], results, proposal_nums, iou_thrs, logger=logger,
+                                   use_legacy_coordinate=True)
+            for i, num in enumerate(proposal_nums):
+                for j, thr in enumerate(iou_thrs):
+                    eval_results[f'recall@{num}@{thr}'] = recalls[i, j]
+            if recalls.shape[1] > 1:
+                for i, num in enumerate(proposal_nums):
+                    eval_results[f'AR@{num}'] = recalls[i].mean()
+            return eval_results
         ds_name = 'voc07' if self.year == 2007 else self.CLASSES
         mean_aps = []
         for thr in iou_thrs:

@@ -58,8 +58,9 @@ class COCOeval:
     def _prepare(self):
         p = self.params
         img_set, cat_set = set(p.imgIds), set(p.catIds)
-        gts = [a for i in p.imgIds for a in self.cocoGt.imgToAnns.get(i, []) if a['category_id'] in cat_set]
-        dts = [a for i in p.imgIds for a in self.cocoDt.imgToAnns.get(i, []) if a['category_id'] in cat_set]
+        # useCats == 0 (the 'proposal' metric): every annotation of the images, whatever its category
+        gts = [a for i in p.imgIds for a in self.cocoGt.imgToAnns.get(i, []) if not p.useCats or a['category_id'] in cat_set]
+        dts = [a for i in p.imgIds for a in self.cocoDt.imgToAnns.get(i, []) if not p.useCats or a['category_id'] in cat_set]
         self._gts, self._dts = defaultdict(list), defaultdict(list)
         for g in gts:
             g['ignore'] = 1 if ('iscrowd' in g and g['iscrowd']) else 0
@@ -68,8 +69,14 @@ class COCOeval:
             if d['image_id'] in img_set:
                 self._dts[d['image_id'], d['category_id']].append(d)
 
+    def _of(self, table, imgId, catId):
+        """the image's boxes of one category, or (useCats == 0, catId -1) of all categories in category order"""
+        if self.params.useCats:
+            return table[imgId, catId]
+        return [a for c in self.params.catIds for a in table[imgId, c]]
+
     def computeIoU(self, imgId, catId):
-        gt, dt = self._gts[imgId, catId], self._dts[imgId, catId]
+        gt, dt = self._of(self._gts, imgId, catId), self._of(self._dts, imgId, catId)
         if len(gt) == 0 and len(dt) == 0:
             return []
         inds = np.argsort([-d['score'] for d in dt], kind='mergesort')
@@ -78,7 +85,7 @@ class COCOeval:
 
     def evaluateImg(self, imgId, catId, aRng, maxDet):
         p = self.params
-        gt, dt = self._gts[imgId, catId], self._dts[imgId, catId]
+        gt, dt = self._of(self._gts, imgId, catId), self._of(self._dts, imgId, catId)
         if len(gt) == 0 and len(dt) == 0:
             return None
         ig = [1 if (g['ignore'] or g['area'] < aRng[0] or g['area'] > aRng[1]) else 0 for g in gt]
@@ -121,16 +128,18 @@ class COCOeval:
     def evaluate(self):
         p = self.params
         p.imgIds = list(np.unique(p.imgIds))
-        p.catIds = list(np.unique(p.catIds))
+        if p.useCats:
+            p.catIds = list(np.unique(p.catIds))
         p.maxDets = sorted(p.maxDets)
         self._prepare()
-        self.ious = {(i, c): self.computeIoU(i, c) for i in p.imgIds for c in p.catIds}
+        cats = p.catIds if p.useCats else [-1]
+        self.ious = {(i, c): self.computeIoU(i, c) for i in p.imgIds for c in cats}
         maxDet = p.maxDets[-1]
-        self.evalImgs = [self.evaluateImg(i, c, a, maxDet) for c in p.catIds for a in p.areaRng for i in p.imgIds]
+        self.evalImgs = [self.evaluateImg(i, c, a, maxDet) for c in cats for a in p.areaRng for i in p.imgIds]
 
     def accumulate(self):
         p = self.params
-        T, R, K, A, M = len(p.iouThrs), len(p.recThrs), len(p.catIds), len(p.areaRng), len(p.maxDets)
+        T, R, K, A, M = len(p.iouThrs), len(p.recThrs), len(p.catIds) if p.useCats else 1, len(p.areaRng), len(p.maxDets)
         precision = -np.ones((T, R, K, A, M))
         recall = -np.ones((T, K, A, M))
         scores = -np.ones((T, R, K, A, M))
@@ -375,3 +384,59 @@ def eval_map(det_results, annotations, scale_ranges=None, iou_thr=0.5, dataset=N
     if logger is not None:
         logger.info(f'mAP@{iou_thr}: {mean_ap}')
     return mean_ap, eval_results
+
+
+
+# ------------------------------------------------------------------------------------------
+# Proposal recall (mmdet/core/evaluation/recall.py: _recalls:12-44, set_recall_param:47-65, eval_recalls:68-113), the
+# 'proposal_fast' metric of CocoDataset.evaluate (datasets/coco.py:311-333,425-434).  The reference is importable here:
+# pinned by the golden fixture g22.
+# ------------------------------------------------------------------------------------------
+def _greedy_gt_ious(ious):
+    """the IoU every ground truth ends up with when (gt, proposal) pairs are taken greedily by descending IoU, each
+    ground truth and each proposal at most once -- in the order they are taken (rows: ground truths)"""
+    ious = np.array(ious, dtype=np.float64)
+    g = ious.shape[0]
+    out = np.zeros(g)
+    if ious.size == 0:
+        return out
+    for j in range(g):
+        # the best remaining proposal of every remaining ground truth, then the best of those (first index on ties)
+        best_box = ious.argmax(axis=1)
+        best = ious[np.arange(g), best_box]
+        gi = int(best.argmax())
+        out[j] = best[gi]
+        ious[gi, :] = -1
+        ious[:, best_box[gi]] = -1
+    return out
+
+
+def eval_recalls(gts, proposals, proposal_nums=None, iou_thrs=0.5, logger=None, use_legacy_coordinate=False):
+    """recalls (len(proposal_nums), len(iou_thrs)): the fraction of ground-truth boxes covered at IoU >= thr by the top
+    `proposal_num` proposals of their image (descending score when a 5th column carries one), one-to-one greedy matching"""
+    assert len(gts) == len(proposals)
+    nums = np.array([proposal_nums] if isinstance(proposal_nums, (int, np.integer)) else proposal_nums)
+    thrs = np.array([0.5] if iou_thrs is None else
+                    ([iou_thrs] if isinstance(iou_thrs, (float, np.floating)) else iou_thrs), dtype=np.float64)
+    per_image = []
+    for gt, prop in zip(gts, proposals):
+        prop = np.asarray(prop)
+        if prop.ndim == 2 and prop.shape[1] == 5:
+            prop = prop[np.argsort(prop[:, 4])[::-1]]
+        keep = min(prop.shape[0], int(nums[-1]))
+        if gt is None or len(gt) == 0:
+            per_image.append(np.zeros((0, prop.shape[0]), dtype=np.float32))
+        else:
+            per_image.append(bbox_overlaps_np(np.asarray(gt), prop[:keep, :4], use_legacy_coordinate=use_legacy_coordinate))
+    total = sum(m.shape[0] for m in per_image)
+    recalls = np.zeros((nums.size, thrs.size))
+    for k, n in enumerate(nums):
+        covered = np.concatenate([_greedy_gt_ious(m[:, :int(n)]) for m in per_image]) if per_image else np.zeros(0)
+        covered = covered.astype(np.float32)            # (the reference collects them in a float32 table)
+        for i, t in enumerate(thrs):
+            recalls[k, i] = (covered >= t).sum() / float(total) if total else 0.0
+    if logger is not None and logger != 'silent' and hasattr(logger, 'info'):
+        rows = ['proposals | ' + ' '.join(f'{t:.2f}' for t in thrs)]
+        rows += [f'{int(n):9d} | ' + ' '.join(f'{v:.3f}' for v in recalls[k]) for k, n in enumerate(nums)]
+        logger.info('\n' + '\n'.join(rows))
+    return recalls

@@ -882,7 +882,40 @@ def g21_fullsize_softnms():
     npz('g21_fullsize_softnms', **d)
 
 
+def g22_recalls():
+    """eval_recalls (mmdet/core/evaluation/recall.py:12-113, what CocoDataset.evaluate's 'proposal_fast' metric runs,
+    datasets/coco.py:311-333,425-434) through the reference: recalls per (proposal_num, IoU threshold) for scored and
+    unscored proposals.  Every image holds the same number of boxes: the reference stacks the per-image IoU matrices with
+    np.array, which numpy >= 1.24 refuses for ragged shapes."""
+    from mmdet.core.evaluation.recall import eval_recalls
+    rng = np.random.RandomState(22)
+
+    def boxes(n, jitter_of=None):
+        if jitter_of is not None:
+            b = jitter_of[rng.randint(0, len(jitter_of), n)] + rng.randn(n, 4) * 6
+        else:
+            xy = rng.rand(n, 2) * 300
+            b = np.concatenate([xy, xy + 10 + rng.rand(n, 2) * 120], axis=1)
+        b = b.astype(np.float32)
+        b[:, 2:] = np.maximum(b[:, 2:], b[:, :2] + 1)
+        return b
+    d = {}
+    gts = [boxes(7) for _ in range(5)]
+    props = [np.concatenate([np.concatenate([boxes(60, g), boxes(40)]), rng.rand(100, 1).astype(np.float32)], axis=1) for g in gts]
+    thrs = np.linspace(.5, .95, 10)
+    for i, (g, p_) in enumerate(zip(gts, props)):
+        d[f'gt{i}'], d[f'prop{i}'] = g, p_
+    d['rec_scored'] = eval_recalls(gts, props, (10, 30, 100), thrs)
+    d['rec_single_thr'] = eval_recalls(gts, props, 50, 0.5)
+    d['rec_unscored'] = eval_recalls(gts, [p_[:, :4] for p_ in props], (10, 100), [0.5, 0.75])
+    d['rec_legacy'] = eval_recalls(gts, props, (100,), [0.5, 0.7], use_legacy_coordinate=True)
+    npz('g22_recalls', **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'recalls':
+        g22_recalls()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'soft':
         g21_fullsize_softnms()
         return

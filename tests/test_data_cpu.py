@@ -286,6 +286,12 @@ def test_voc_dataset_and_eval_map_match_reference_golden(tmp_path):
         assert m == pytest.approx(float(g[f'map_{name}']), abs=1e-7)
         assert np.allclose(np.array([r['ap'] for r in res]), g[f'aps_{name}'], atol=1e-7)
     assert ds.evaluate(results, metric='mAP') == pytest.approx(json.loads(str(g['voc_eval'])))
+    # 'recall' (voc.py:91-106): the ground-truth boxes themselves as proposals recall everything; half of them, less
+    props = [np.concatenate([a['bboxes'], np.full((len(a['bboxes']), 1), 0.5, np.float32)], axis=1) for a in anns]
+    rec = ds.evaluate(props, metric='recall', proposal_nums=(100,), iou_thr=[0.5, 0.75])
+    assert rec['recall@100@0.5'] == 1.0 and rec['recall@100@0.75'] == 1.0 and rec['AR@100'] == 1.0
+    some = ds.evaluate([p[: (len(p) + 1) // 2] for p in props], metric=['recall'], proposal_nums=(100,), iou_thr=0.5)
+    assert 0 < some['recall@100@0.5'] < 1 and 'AR@100' not in some
     tr = D.VOCDataset(ann_file=lst, img_prefix=prefix, pipeline=[], min_size=8)
     assert len(tr) < len(ds)                       # empty-gt and too-small images are filtered
     rep = D.build_dataset(dict(type='RepeatDataset', times=3,

@@ -170,3 +170,92 @@ def test_crowd_absorbs_any_number_of_detections_and_ignore_follows_iscrowd():
     c.createIndex()
     ev = _run(c, [(1, 1, (300, 300, 50, 50), .9)])
     assert ev.stats[0] == 0.0 and ev.stats[8] == 0.0          # the ground truth still counts (and is missed)
+
+
+# ---- proposal recall: eval_recalls is pinned by the reference itself (golden g22), the 'proposal' metric (COCOeval with
+# useCats = 0) by hand-derived cases -------------------------------------------------------------------------------------
+def test_eval_recalls_matches_the_reference_golden():
+    """brcnn.evaluation.eval_recalls against mmdet/core/evaluation/recall.py run on the same boxes (tests/golden/
+    make_golden.py g22_recalls): scored / unscored proposals, several proposal numbers and thresholds, legacy extents"""
+    import os
+    from brcnn.evaluation import eval_recalls
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g22_recalls.npz'))
+    gts = [g[f'gt{i}'] for i in range(5)]
+    props = [g[f'prop{i}'] for i in range(5)]
+    assert np.array_equal(eval_recalls(gts, props, (10, 30, 100), np.linspace(.5, .95, 10)), g['rec_scored'])
+    assert np.array_equal(eval_recalls(gts, props, 50, 0.5), g['rec_single_thr'])
+    assert np.array_equal(eval_recalls(gts, [p[:, :4] for p in props], (10, 100), [0.5, 0.75]), g['rec_unscored'])
+    assert np.array_equal(eval_recalls(gts, props, (100,), [0.5, 0.7], use_legacy_coordinate=True), g['rec_legacy'])
+    assert 0 < g['rec_scored'][0, 0] < g['rec_scored'][2, 0] == 1.0        # (the fixture discriminates)
+
+
+def test_eval_recalls_hand_derived_ragged_and_empty_images():
+    """what the reference cannot be asked under numpy >= 1.24 (it stacks ragged IoU matrices): images with different
+    box counts, an image without ground truth, one without proposals; one-to-one greedy matching"""
+    from brcnn.evaluation import eval_recalls
+    gts = [np.array([[0, 0, 10, 10], [20, 20, 30, 30]], np.float32),     # two boxes
+           np.zeros((0, 4), np.float32),                                   # none
+           np.array([[0, 0, 10, 10]], np.float32)]                         # one box, no proposal
+    props = [np.array([[0, 0, 10, 10, .9],       # IoU 1 with gt 0
+                       [0, 0, 10, 5, .8],        # IoU .5 with gt 0: gt 0 is taken, this one is left over
+                       [20, 20, 30, 25, .7]],    # IoU .5 with gt 1
+                      np.float32),
+             np.array([[5, 5, 9, 9, .5]], np.float32),
+             np.zeros((0, 5), np.float32)]
+    rec = eval_recalls(gts, props, (1, 3), [0.5, 0.75])
+    # top-1: only the exact box -> 1 of 3 ground truths at both thresholds; top-3: gt 0 at IoU 1, gt 1 at IoU .5
+    assert np.allclose(rec, [[1 / 3, 1 / 3], [2 / 3, 1 / 3]])
+    # one proposal cannot serve two ground truths
+    one = eval_recalls([np.array([[0, 0, 10, 10], [0, 0, 10, 9]], np.float32)], [np.array([[0, 0, 10, 10]], np.float32)], (5,), [0.5])
+    assert np.allclose(one, [[0.5]])
+
+
+def test_proposal_metric_ignores_categories():
+    """'proposal' = COCOeval with useCats = 0: a detection labelled with another category still recalls the box; with
+    one category the class-agnostic AR equals the per-class one"""
+    gt = _gt([1], [(1, 1, (10, 10, 50, 50)), (1, 2, (200, 200, 60, 60))], cats=(1, 2))
+    dets = [(1, 2, (10, 10, 50, 50), .9), (1, 1, (200, 200, 60, 60), .8)]        # labels swapped
+    dt = gt.loadRes([dict(image_id=d[0], category_id=d[1], bbox=list(d[2]), score=d[3]) for d in dets])
+    for use_cats, want in ((1, 0.0), (0, 1.0)):
+        ev = COCOeval(gt, dt, 'bbox')
+        ev.params.useCats = use_cats
+        ev.evaluate(); ev.accumulate(); ev.summarize()
+        assert ev.stats[8] == pytest.approx(want), (use_cats, ev.stats)
+    gt1 = _gt([1, 2], [(1, 1, (10, 10, 50, 50)), (2, 1, (20, 20, 100, 100)), (2, 1, (200, 200, 20, 20))])
+    d1 = [(1, 1, (10, 10, 50, 50), .9), (2, 1, (20, 20, 100, 100), .8)]
+    a = _run(gt1, d1)
+    dt1 = gt1.loadRes([dict(image_id=d[0], category_id=d[1], bbox=list(d[2]), score=d[3]) for d in d1])
+    b = COCOeval(gt1, dt1, 'bbox')
+    b.params.useCats = 0
+    b.evaluate(); b.accumulate(); b.summarize()
+    assert np.allclose(a.stats, b.stats)
+
+
+def test_dataset_proposal_metrics(tmp_path):
+    """CocoDataset.evaluate(metric='proposal_fast' / 'proposal') (datasets/coco.py:311-333,425-434,488-506) on per-image
+    proposals: exact boxes -> AR 1; 'proposal' also accepts per-class detection lists; the json sink"""
+    from brcnn.datasets import CocoDataset
+    from tests.golden.synth import synthetic_coco
+    ann_file, prefix = synthetic_coco(str(tmp_path))
+    classes = ('echinus', 'starfish', 'holothurian', 'scallop')
+    ds = CocoDataset(ann_file=ann_file, pipeline=[], classes=classes, img_prefix=prefix, test_mode=True)
+    props, dets = [], []
+    for i in range(len(ds)):
+        anns = [a for a in ds.coco.imgToAnns.get(ds.img_ids[i], []) if not a.get('iscrowd', 0)]
+        b = np.array([[a['bbox'][0], a['bbox'][1], a['bbox'][0] + a['bbox'][2], a['bbox'][1] + a['bbox'][3], 0.9 - 0.01 * j]
+                      for j, a in enumerate(anns)], dtype=np.float32).reshape(-1, 5)
+        props.append(b)
+        dets.append([b if c == 0 else np.zeros((0, 5), np.float32) for c in range(4)])      # all labelled class 0
+    fast = ds.evaluate(props, metric='proposal_fast', proposal_nums=(1, 100))
+    assert fast['AR@100'] == pytest.approx(1.0) and 0 < fast['AR@1'] < 1
+    half = [p[: max(1, len(p) // 2)] for p in props]
+    assert 0 < ds.evaluate(half, metric='proposal_fast', proposal_nums=(100,))['AR@100'] < 1
+    out = ds.evaluate(props, metric='proposal', jsonfile_prefix=str(tmp_path / 'p'))
+    assert out['AR@1000'] == pytest.approx(1.0) and set(out) == {'AR@100', 'AR@300', 'AR@1000', 'AR_s@1000', 'AR_m@1000', 'AR_l@1000'}
+    assert (tmp_path / 'p.proposal.json').exists()
+    assert ds.evaluate(dets, metric='proposal')['AR@1000'] == pytest.approx(1.0)       # categories ignored
+    assert ds.evaluate(dets, metric=['bbox', 'proposal'], metric_items=None).keys() >= {'bbox_mAP', 'AR@100'}
+    with pytest.raises(KeyError):
+        ds.evaluate(props, metric='segm')
+    with pytest.raises(KeyError):
+        ds.evaluate(props, metric='bbox')
