@@ -113,22 +113,25 @@ def timed(step, steps, warmup, world, device):
     max say whether the mean is the steady state or carries a hiccup), the host marks give the enqueue time per step"""
     import torch
     import torch.distributed as dist
+    # Python's cyclic collector is held off over the timed steps (BRCNN_BENCH_GC=1 leaves it on): a step creates a few
+    # thousand short-lived objects, every few steps a generation-1/2 pass walks the whole heap (model, configs, caches) for
+    # 2-5 ms of HOST time -- which a launch-bound second half of the step turns into device time (profiles/r05_notes.md).
+    # The runner does the same between its log lines (`apis.EpochBasedRunner`: collect at the interval, never inside a step).
+    # The full collection (~80 ms of host time) runs BEFORE the warm-up steps: between the warm-up and the timed region it
+    # left the device idle long enough to drop its clocks, and the first timed step paid 2.7 ms for the ramp
+    # (BRCNN_BENCH_DUMP_STEPS=1: 27.3 ms against 24.6 for every other step, three runs of three)
+    import gc
+    manual_gc = os.environ.get('BRCNN_BENCH_GC', '0') != '1'
+    if manual_gc:
+        gc.collect()
+        gc.disable()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    # Python's cyclic collector is held off over the timed steps (BRCNN_BENCH_GC=1 leaves it on): a step creates a few
-    # thousand short-lived objects, every few steps a generation-1/2 pass walks the whole heap (model, configs, caches) for
-    # 2-5 ms of HOST time -- which a launch-bound second half of the step turns into device time (profiles/r05_notes.md).
-    # The runner does the same between its log lines (`apis.EpochBasedRunner`: collect at the interval, never inside a step)
-    import gc
-    manual_gc = os.environ.get('BRCNN_BENCH_GC', '0') != '1'
-    if manual_gc:
-        gc.collect()
-        gc.disable()
     t0 = time.perf_counter()
     evs[0].record()
     marks = []
@@ -152,6 +155,9 @@ def timed(step, steps, warmup, world, device):
     # a one-off stall inside the timed region (seen on fresh boxes: up to ~2 s in one step) is reported, never removed:
     # the line still times exactly K steps
     med = dev_ms[steps // 2]
+    if os.environ.get('BRCNN_BENCH_DUMP_STEPS') == '1':      # the steps in order (device ms / host ms), to stderr
+        print('bench: steps ' + ' '.join(f'{evs[i].elapsed_time(evs[i + 1]):.2f}/{1e3 * gaps[i]:.2f}' for i in range(steps)),
+              file=sys.stderr, flush=True)
     for i in range(steps):
         d = evs[i].elapsed_time(evs[i + 1])
         if d > 5 * med or 1e3 * gaps[i] > max(5 * host_ms[steps // 2], 5 * med):
