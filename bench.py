@@ -107,7 +107,7 @@ def synthetic_gt(batch, device, num_classes, seed=0, num_gt=20):
     return boxes, labels
 
 
-def timed(step, steps, warmup, world, device):
+def timed(step, steps, warmup, world, device, after_warmup=None):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks.  Returns (seconds,
     per-step statistics): a HIP event on the main stream after every step gives each step's DEVICE time (median / p90 /
     max say whether the mean is the steady state or carries a hiccup), the host marks give the enqueue time per step"""
@@ -128,6 +128,8 @@ def timed(step, steps, warmup, world, device):
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     for _ in range(warmup):
         step()
+    if after_warmup is not None:        # (cheap host-side bookkeeping of the caller: no device idle time in front of the timed steps)
+        after_warmup()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -245,10 +247,9 @@ def train_bench(args, world, rank, device):
     # host slack at the step's one synchronisation (roi_heads.sample_device: the sampler's candidate counts): how long
     # the host WAITED there = how far it runs ahead of the device; ~0 means the step is launch-bound from there on
     from brcnn import roi_heads as _rh
-    for _ in range(args.warmup):
-        step()
-    _rh.SYNC_WAIT = [0.0, 0]
-    dt, step_stats = timed(step, steps, 0, world, device)
+    def start_slack_clock():
+        _rh.SYNC_WAIT = [0.0, 0]
+    dt, step_stats = timed(step, steps, args.warmup, world, device, after_warmup=start_slack_clock)
     sync_wait = _rh.SYNC_WAIT
     _rh.SYNC_WAIT = None
     loss_last_timed = float(last['log_vars']['loss'])       # (the passes below run further steps)

@@ -10,12 +10,13 @@ import bench
 _orig = bench.timed
 
 
-def timed(step, steps, warmup, world, device):
-    if warmup:                       # bench's own warm-up call
-        return _orig(step, steps, warmup, world, device)
+def timed(step, steps, warmup, world, device, after_warmup=None):
+    for _ in range(warmup):          # (the profile covers the timed steps only)
+        step()
+    warmup = 0
     pr = cProfile.Profile()
     pr.enable()
-    out = _orig(step, steps, warmup, world, device)
+    out = _orig(step, steps, warmup, world, device, after_warmup=after_warmup)
     pr.disable()
     for key, n in (('tottime', 70), ('cumulative', 120)):
         s = io.StringIO()

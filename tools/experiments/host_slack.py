@@ -11,7 +11,7 @@ import torch
 _orig = bench.timed
 
 
-def timed(step, steps, warmup, world, device):
+def timed(step, steps, warmup, world, device, after_warmup=None):
     def wrapped():
         t0 = time.perf_counter()
         step()
@@ -19,6 +19,8 @@ def timed(step, steps, warmup, world, device):
     host = [0.0]
     for _ in range(warmup):
         wrapped()
+    if after_warmup is not None:
+        after_warmup()
     torch.cuda.synchronize()
     host[0] = 0.0
     roi_heads.SYNC_WAIT[0], roi_heads.SYNC_WAIT[1] = 0.0, 0
@@ -31,7 +33,7 @@ def timed(step, steps, warmup, world, device):
     print(f'per step: wall {1e3 * dt / steps:.2f} ms, host inside step() {1e3 * host[0] / steps:.2f} ms '
           f'(of which blocked on the sampler counts {1e3 * roi_heads.SYNC_WAIT[0] / steps:.2f} ms), '
           f'device tail after the last step was queued {1e3 * (dt - t_queued):.2f} ms', file=sys.stderr)
-    return dt
+    return dt, {}
 
 
 bench.timed = timed
