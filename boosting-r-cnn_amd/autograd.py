@@ -106,7 +106,8 @@ WGRAD_DEFER_ITEMS = int(_os.environ.get('BRCNN_WGRAD_DEFER_ITEMS', '16'))
 _defer_arenas = {}       # side stream handle -> the slab arena handed to brcnn_wgrad_defer_begin (kept alive here)
 _side_streams = {}
 _join_queued = {}        # (device type, index) -> True while a join callback of the running backward pass is queued
-_side_seen = {}          # (device type, index) -> ids of the parameters whose gradient went to the side stream in this pass
+_side_seen = {}          # (device type, index) -> {id: tensor} of the weights whose gradient went to the side stream in this pass
+                         # (the tensor is kept alive: the id of a freed per-call view would pass for the next one's)
 
 
 def _wgrad_side_stream(device):
@@ -177,14 +178,14 @@ def _side_stream_for(param, device):
     if side is None:
         return None
     key = (device.type, device.index)
-    seen = _side_seen.setdefault(key, set())
+    seen = _side_seen.setdefault(key, {})
     if id(param) in seen:
         if grad_arena.listener is not None and hasattr(grad_arena.listener, 'shared_parameter'):
             grad_arena.listener.shared_parameter(param)
         flush_deferred(side)
         torch.cuda.current_stream(device).wait_stream(side)
         return None
-    seen.add(id(param))
+    seen[id(param)] = param
     return side
 
 

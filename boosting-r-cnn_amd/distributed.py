@@ -109,7 +109,11 @@ class GradReducer:
         self._comm = {}
         # chunk -> [elements already handed to a collective, elements whose writers have all been launched]
         self._progress = []
-        self._seen = set()           # ids of the parameters that had a weight-gradient launch in the running pass
+        # the tensors that had a weight-gradient launch in the running step, by id.  The tensor itself is kept: many of
+        # them are per-call temporaries (the 4-D view of an FC weight, a padded weight), and the id of a freed one is
+        # handed to the next temporary -- which then looked like a second launch for the same parameter (one two-rank
+        # bench run in ten stopped with the shared-parameter error, profiles/r05_notes.md)
+        self._seen = {}
         self._bucket = None          # persistent flat fp32 storage of the gradients outside the arena
         self._cbuf = None            # persistent bf16 staging of the arena (compress='bf16')
         self._layout = None          # the layout signature the ranks last agreed on
@@ -172,7 +176,7 @@ class GradReducer:
             if id(param) in self._seen:
                 self.shared_parameter(param)
                 in_place = False
-            self._seen.add(id(param))
+            self._seen[id(param)] = param
         if not (self.overlap and buf.is_cuda):
             return
         for pr in self._progress:
@@ -387,4 +391,4 @@ class GradReducer:
                     buf[:used].mul_(1.0 / self.world)
         self._works = []
         self._progress = []
-        self._seen = set()
+        self._seen = {}

@@ -347,6 +347,19 @@ def _slicing_worker(rank, world, port, ret):
         red.writers_launched(buf, 64 + 6 * n + 64, 64 + 7 * n + 64, None, True, params[4])
         assert issued[-1] == (64 + 6 * n + 64, 64 + 7 * n + 64)
         assert [tuple(r) for r in red._progress[0][1]] == issued
+        # per-call temporaries (the 4-D view of an FC weight, a padded weight) are told apart for the whole step: the
+        # reducer keeps the tensor, so the id of a freed one cannot come back on the next temporary (one two-rank bench
+        # run in ten stopped here with the shared-parameter error before it did)
+        import gc, weakref
+        base = torch.zeros(8)
+        off = 64 + 8 * n
+        for i in range(200):
+            t = base.view(2, 4)
+            w = weakref.ref(t)
+            red.writers_launched(buf, off + 64 * i, off + 64 * (i + 1), None, False, t)     # (never raises)
+            del t
+            gc.collect()
+            assert w() is not None
         # a parameter that reaches a second weight-gradient launch in one pass: refused by the overlapped form
         with pytest.raises(RuntimeError, match='used twice'):
             red.writers_launched(buf, 64 + 8 * n, 64 + 9 * n, None, True, params[0])
