@@ -32,6 +32,26 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
+def _host_cpus():
+    """host cores this process may actually use: min(affinity mask, cgroup cpu quota)"""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+# torch's intra-op pool defaults to one thread per core of the HOST (256 on the MI355X boxes) whatever CPU quota the
+# container has (16 there: /sys/fs/cgroup/cpu.max 1600000 100000).  A parallel region on 256 threads burns the quota of a
+# 100 ms scheduling period at once, and the whole process -- the thread that launches kernels included -- is throttled
+# until the period ends (cpu.stat of one bench call: 171 of 1252 periods throttled).  Read by OpenMP when torch loads.
+os.environ.setdefault('OMP_NUM_THREADS', str(_host_cpus()))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -67,6 +87,7 @@ def launch_ranks(args):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env['OMP_NUM_THREADS'] = str(max(1, _host_cpus() // max(1, args.gpus)))     # the ranks share the container's cores
     return subprocess.call(cmd, env=env)
 
 

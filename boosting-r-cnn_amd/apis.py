@@ -24,7 +24,34 @@ from .datasets import build_dataloader, build_dataset
 
 __all__ = ['set_random_seed', 'get_root_logger', 'build_optimizer', 'StepLrUpdater', 'save_checkpoint',
            'load_checkpoint', 'EpochBasedRunner', 'train_detector', 'single_gpu_test', 'multi_gpu_test',
-           'init_dist', 'get_dist_info', 'replace_ImageToTensor']
+           'init_dist', 'get_dist_info', 'replace_ImageToTensor', 'host_cpus', 'limit_host_threads']
+
+
+def host_cpus():
+    """host cores this process may actually use: min(affinity mask, cgroup cpu quota)"""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def limit_host_threads(world_size=1):
+    """torch's intra-op pool takes one thread per core of the HOST (256 on the MI355X boxes) whatever CPU quota the
+    container has: a parallel region then burns the quota of a scheduling period at once and the whole process -- the
+    thread that launches kernels included -- is throttled until the period ends (profiles/r05_notes.md).  The pool is cut
+    to the cores this process may use, shared between the ranks of the node.  Called by tools/train.py / tools/test.py;
+    an explicit OMP_NUM_THREADS wins."""
+    if os.environ.get('OMP_NUM_THREADS'):
+        return torch.get_num_threads()
+    n = max(1, host_cpus() // max(1, int(world_size)))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
 
 
 def set_random_seed(seed, deterministic=False):

@@ -8,6 +8,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _host_cpus():
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+# torch's intra-op pool would take one thread per core of the host (256 on the GPU boxes) inside a container with a
+# 16-CPU quota: every CPU-side parallel region (weight initialisation, the CPU chains the parity tests compare against)
+# gets the process throttled for the rest of its 100 ms scheduling period.  Read by OpenMP when torch is first imported.
+os.environ.setdefault('OMP_NUM_THREADS', str(_host_cpus()))
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

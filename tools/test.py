@@ -16,7 +16,8 @@ import torch  # noqa: E402
 
 import brcnn  # noqa: E402,F401
 from brcnn import Config, build_detector  # noqa: E402
-from brcnn.apis import (_DeviceLoader, get_dist_info, init_dist, load_checkpoint, multi_gpu_test,  # noqa: E402
+from brcnn.apis import (_DeviceLoader, get_dist_info, init_dist, limit_host_threads, load_checkpoint,  # noqa: E402
+                        multi_gpu_test,
                         replace_ImageToTensor, single_gpu_test)
 from brcnn.config import DictAction  # noqa: E402
 from brcnn.datasets import build_dataloader, build_dataset  # noqa: E402
@@ -70,6 +71,7 @@ def main(argv=None):
             params['backend'] = args.dist_backend
         init_dist(args.launcher, **params)
     rank, world = get_dist_info()
+    limit_host_threads(int(os.environ.get('LOCAL_WORLD_SIZE', 1)))
     if not torch.cuda.is_available():
         raise RuntimeError('tools/test.py needs a GPU: the hot path has no CPU fallback')
     device = torch.device('cuda', torch.cuda.current_device())

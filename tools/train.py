@@ -17,7 +17,8 @@ import torch  # noqa: E402
 
 import brcnn  # noqa: E402,F401
 from brcnn import Config, build_detector  # noqa: E402
-from brcnn.apis import get_dist_info, get_root_logger, init_dist, set_random_seed, train_detector  # noqa: E402
+from brcnn.apis import (get_dist_info, get_root_logger, init_dist, limit_host_threads, set_random_seed,  # noqa: E402
+                        train_detector)
 from brcnn.config import DictAction  # noqa: E402
 from brcnn.datasets import build_dataset  # noqa: E402
 
@@ -70,6 +71,7 @@ def main(argv=None):
         init_dist(args.launcher, **params)
         _, world_size = get_dist_info()
         cfg.gpu_ids = list(range(world_size))
+    limit_host_threads(int(os.environ.get('LOCAL_WORLD_SIZE', 1)))
     os.makedirs(osp.abspath(cfg.work_dir), exist_ok=True)
     cfg.dump(osp.join(cfg.work_dir, osp.basename(args.config)))
     timestamp = time.strftime('%Y%m%d_%H%M%S', time.localtime())
