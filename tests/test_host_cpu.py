@@ -411,3 +411,42 @@ def test_tuning_struct_round_trip_without_a_gpu():
     finally:
         lib.set_tuning(**want)
     assert {k: getattr(lib.get_tuning(), k) for k in want} == want
+
+
+def test_host_thread_cap_follows_affinity_and_cgroup_quota(monkeypatch):
+    """apis.host_cpus / limit_host_threads: torch's intra-op pool is cut to min(affinity mask, cgroup CPU quota) shared
+    between the ranks of the node; an explicit OMP_NUM_THREADS is left alone (profiles/r05_notes.md: 256 threads on a
+    16-CPU quota got the launching thread throttled)"""
+    import builtins
+    import io
+    import torch
+    from brcnn import apis
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == '/sys/fs/cgroup/cpu.max':
+            return io.StringIO(fake['cpu.max'])
+        return real_open(path, *a, **k)
+    fake = {'cpu.max': '300000 100000\n'}
+    monkeypatch.setattr(builtins, 'open', fake_open)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(64)), raising=False)
+    assert apis.host_cpus() == 3
+    fake['cpu.max'] = '250000 100000\n'
+    assert apis.host_cpus() == 3                    # 2.5 CPUs of quota: rounded up
+    fake['cpu.max'] = 'max 100000\n'
+    assert apis.host_cpus() == 64                   # no quota: the affinity mask
+    fake['cpu.max'] = '400000 100000\n'
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv('OMP_NUM_THREADS', raising=False)
+        torch.set_num_threads(8)
+        assert apis.limit_host_threads() == 4 and torch.get_num_threads() == 4
+        torch.set_num_threads(8)
+        assert apis.limit_host_threads(world_size=4) == 1
+        torch.set_num_threads(2)
+        assert apis.limit_host_threads() == 2       # never raised
+        monkeypatch.setenv('OMP_NUM_THREADS', '7')
+        torch.set_num_threads(8)
+        assert apis.limit_host_threads() == 8       # the user's setting wins
+    finally:
+        torch.set_num_threads(before)
