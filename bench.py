@@ -137,44 +137,51 @@ def timed(step, steps, warmup, world, device, after_warmup=None):
     # Python's cyclic collector is held off over the timed steps (BRCNN_BENCH_GC=1 leaves it on): a step creates a few
     # thousand short-lived objects, every few steps a generation-1/2 pass walks the whole heap (model, configs, caches) for
     # 2-5 ms of HOST time -- which a launch-bound second half of the step turns into device time (profiles/r05_notes.md).
-    # The runner does the same between its log lines (`apis.EpochBasedRunner`: collect at the interval, never inside a step).
+    # The runner does the same (`apis.EpochBasedRunner.train`: collector off inside the steps, one collection at every log
+    # interval -- the default of 50 steps is longer than this timed region), so the line is measured under the policy real
+    # training runs with; `gc_in_timed_region` in the line says which it was.
     # The full collection (~80 ms of host time) runs BEFORE the warm-up steps: between the warm-up and the timed region it
     # left the device idle long enough to drop its clocks, and the first timed step paid 2.7 ms for the ramp
     # (BRCNN_BENCH_DUMP_STEPS=1: 27.3 ms against 24.6 for every other step, three runs of three)
     import gc
     manual_gc = os.environ.get('BRCNN_BENCH_GC', '0') != '1'
+    manual_gc = manual_gc and gc.isenabled()
     if manual_gc:
         gc.collect()
         gc.disable()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    for _ in range(warmup):
-        step()
-    if after_warmup is not None:        # (cheap host-side bookkeeping of the caller: no device idle time in front of the timed steps)
-        after_warmup()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    evs[0].record()
-    marks = []
-    for i in range(steps):
-        step()
-        evs[i + 1].record()
-        marks.append(time.perf_counter())      # host time after the step's enqueue (no synchronisation)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if manual_gc:
-        gc.enable()
+    try:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        for _ in range(warmup):
+            step()
+        if after_warmup is not None:    # (cheap host-side bookkeeping of the caller: no device idle time in front of the timed steps)
+            after_warmup()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs[0].record()
+        marks = []
+        for i in range(steps):
+            step()
+            evs[i + 1].record()
+            marks.append(time.perf_counter())      # host time after the step's enqueue (no synchronisation)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        if manual_gc:
+            gc.enable()
     dev_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     gaps = [b - a for a, b in zip([t0] + marks[:-1], marks)]
     host_ms = sorted(1e3 * g for g in gaps)
     stats = {'step_ms_median': dev_ms[steps // 2], 'step_ms_p90': dev_ms[min(steps - 1, (9 * steps) // 10)],
              'step_ms_min': dev_ms[0], 'step_ms_max': dev_ms[-1],
-             'host_enqueue_ms_median': host_ms[steps // 2], 'host_enqueue_ms_max': host_ms[-1]}
+             'host_enqueue_ms_median': host_ms[steps // 2], 'host_enqueue_ms_max': host_ms[-1],
+             # 'runner policy': collector off inside the steps, as apis.EpochBasedRunner.train runs them; 'on': BRCNN_BENCH_GC=1
+             'gc_in_timed_region': 'runner policy (off inside steps)' if manual_gc else 'on'}
     # a one-off stall inside the timed region (seen on fresh boxes: up to ~2 s in one step) is reported, never removed:
     # the line still times exactly K steps
     med = dev_ms[steps // 2]

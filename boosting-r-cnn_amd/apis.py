@@ -263,6 +263,8 @@ class EpochBasedRunner:
         # data parallel: compare the replicas' parameters bit for bit after every optimizer step (a host sync per
         # step: a debugging / test switch -- `check_replicas = True` in the config or BRCNN_CHECK_REPLICAS=1)
         self.check_replicas = os.environ.get('BRCNN_CHECK_REPLICAS', '0') == '1'
+        # cyclic garbage collection at the log interval instead of inside the steps (see train)
+        self.manual_gc = os.environ.get('BRCNN_RUNNER_GC', '0') != '1'
         self.log_buffer = OrderedDict()
         self.history = []          # (epoch, iter, lr, {name: value}) rows the text logger printed
         self.eval_history = []
@@ -352,6 +354,26 @@ class EpochBasedRunner:
         return on
 
     def train(self, data_loader):
+        """one epoch.  Python's cyclic collector is held off INSIDE the steps and run at the log interval instead
+        (`manual_gc`, BRCNN_RUNNER_GC=1 / `manual_gc = False` in the config leave it alone): a step creates a few thousand
+        short-lived objects, every few steps a generation-1/2 pass walks the whole heap (model, config, caches) for 2-5 ms
+        of host time, which the launch-bound second half of a step turns into device idle time (profiles/r05_notes.md).
+        Reference counting still frees everything acyclic at once; what the collector would have found waits for the
+        next log line (<= `log_interval` steps).  bench.py's timed loop measures under this same policy."""
+        import gc
+        manual_gc = self.manual_gc and gc.isenabled()
+        if manual_gc:
+            gc.collect()
+            gc.freeze()                 # the model, the optimizer state and the config never need another scan
+            gc.disable()
+        try:
+            self._train_epoch(data_loader, gc if manual_gc else None)
+        finally:
+            if manual_gc:
+                gc.enable()
+                gc.unfreeze()
+
+    def _train_epoch(self, data_loader, gc_):
         self.model.train()
         sampler = getattr(data_loader, 'sampler', None)
         if hasattr(sampler, 'set_epoch'):
@@ -418,6 +440,9 @@ class EpochBasedRunner:
                 if torch.cuda.is_available():
                     from . import lib as _lib
                     _lib.handover_status()      # a lost stream-K hand-over since the last log line raises here
+                if gc_ is not None:
+                    gc_.collect()               # the cyclic garbage of the last `log_interval` steps, between two steps
+                    now = time.time()           # (not charged to the next interval's time per iteration)
                 t_last, n_since = now, 0
         if getattr(self, 'replica_checks', 0):
             self.logger.info(f'replica check: parameters and buffers bit-identical on every rank after each of '
@@ -515,7 +540,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
         from .distributed import GradReducer
         # `grad_allreduce_dtype = 'bf16'` in the config: the weight-gradient arena crosses xGMI as bf16 (fp32 master
         # weights and optimizer step unchanged)
-        reducer = GradReducer([p for p in model.parameters() if p.requires_grad],
+        reducer = GradReducer([(n, p) for n, p in model.named_parameters() if p.requires_grad],
                               compress=cfg.get('grad_allreduce_dtype', None) or os.environ.get('BRCNN_REDUCER_COMPRESS') or None)
         reducer.broadcast_parameters(model)
     optimizer = build_optimizer(model, cfg.optimizer)
@@ -527,6 +552,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     runner.early_rpn_backward = bool(cfg.get('early_rpn_backward', True))
     runner.graph_trunk = bool(cfg.get('graph_trunk', False))
     runner.check_replicas = bool(cfg.get('check_replicas', runner.check_replicas))
+    runner.manual_gc = bool(cfg.get('manual_gc', runner.manual_gc))
     if cfg.get('fp16', None) is not None:
         # `fp16 = dict(loss_scale=512.)` (configs/boosting_rcnn/boosting_rcnn_x101_pafpn_mstrain_3x_coco.py:2 ->
         # mmdet/apis/train.py:115-119, mmcv Fp16OptimizerHook): fp16 MFMA conv stack (fp32 accumulation, fp32

@@ -316,7 +316,12 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw, h
         # stream has nothing left to do, the second stream still has its backlog, and the launch would only lengthen the
         # tail the main stream waits for at the end-of-pass join (0.34 ms per bf16 step of bench.py: tools/experiments/
         # join_wait.py); on the main stream it runs beside that backlog
-        side = _side_stream_for(weight, dy.device) if (side_ok and (has_dgrad or not WGRAD_TAIL_ON_MAIN)) else None
+        # (the weight is recorded as seen in EVERY case: a later use of the same parameter in this pass must find it --
+        # a tail launch kept on the main stream and never recorded let a second use with a data gradient pass for the
+        # first one and go to the second stream, unordered with the sum autograd forms on the main stream: ADVICE r05)
+        side = _side_stream_for(weight, dy.device) if side_ok else None
+        if side is not None and not (has_dgrad or not WGRAD_TAIL_ON_MAIN):
+            side = None
         deferred = False
         if side is None:
             st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,

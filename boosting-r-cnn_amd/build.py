@@ -55,12 +55,27 @@ def _stamp():
     return h.hexdigest()
 
 
-def _compile(src):
+def _obj_stamp(src):
+    """what an object file depends on: its source, every header of csrc/ and the public header, the flags"""
+    h = hashlib.sha1()
+    for f in [src] + sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + ['../../include/brcnn_hip.h']:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), 'rb').read())
+    h.update(' '.join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
+    return h.hexdigest()
+
+
+def _compile(src, force=False):
     obj = os.path.join(LIBDIR, 'obj', src.replace('.hip', '.o'))
+    stamp_file, stamp = obj + '.stamp', _obj_stamp(src)
+    if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj                      # unchanged since it was compiled (sources are compiled one by one)
     cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
+    with open(stamp_file, 'w') as f:
+        f.write(stamp)
     return obj
 
 
@@ -77,14 +92,14 @@ def build_library(force=False, verbose=False):
         if f.endswith('.o') and f.replace('.o', '.hip') not in srcs:
             os.remove(os.path.join(objdir, f))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    # ISA gate: no cross-swizzled packed-fp32 instruction in any code object (tools/check_isa.py)
-    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
-    try:
-        import check_isa
-    finally:
-        sys.path.pop(0)
-    check_isa.check_objects(objs, verbose=verbose)
+        objs = list(ex.map(lambda src: _compile(src, force), srcs))
+    # ISA gate: no cross-swizzled packed-fp32 instruction in any code object (check_isa.py, in this package; skipped with
+    # a warning when the ROCm installation in use has no llvm-objdump)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('brcnn_check_isa', os.path.join(HERE, 'check_isa.py'))
+    check_isa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(check_isa)
+    check_isa.check_objects(objs, verbose=verbose, hipcc=hipcc())
     cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

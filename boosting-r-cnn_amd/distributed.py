@@ -89,11 +89,16 @@ def _subtract(live, issued):
 
 
 class GradReducer:
-    def __init__(self, params, process_group=None, slice_mb=64, overlap=False, compress=None, strict=True):
+    def __init__(self, params, process_group=None, slice_mb=64, overlap=False, compress=None, strict=True, names=None):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('GradReducer needs an initialised torch.distributed process group')
         if compress not in (None, 'bf16'):
             raise ValueError(f"GradReducer: compress={compress!r} (None or 'bf16')")
+        params = list(params)
+        if params and isinstance(params[0], tuple):        # named_parameters()
+            names = {id(p): n for n, p in params}
+            params = [p for _, p in params]
+        self.names = dict(names or {})                      # id(parameter) -> name, for error messages only
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group)
@@ -149,8 +154,11 @@ class GradReducer:
     def chunk_opened(self, buf):
         if not self._progress:
             self.last_bytes = 0         # first chunk of a new step: the overlapped slices of THIS step count from here
-        # [chunk, ranges already handed to a collective, the running in-place run [lo, hi) or None]
-        self._progress.append([buf, [], None])
+            self._seen = {}             # ... and so does the shared-parameter bookkeeping (a backward pass without a
+            #                             reduce() behind it must not make every parameter look shared in the next one)
+        # [chunk, ranges already handed to a collective, the running in-place run [lo, hi) or None,
+        #  the in-place ranges that joined a run: (lo, hi, tensor) -- reduce() checks them against the live gradients]
+        self._progress.append([buf, [], None, []])
 
     def shared_parameter(self, param):
         """a parameter reached a second weight-gradient launch in one backward pass (autograd._side_stream_for, or
@@ -177,7 +185,7 @@ class GradReducer:
                 self.shared_parameter(param)
                 in_place = False
             self._seen[id(param)] = param
-        if not (self.overlap and buf.is_cuda):
+        if not self.overlap:
             return
         for pr in self._progress:
             if pr[0] is buf:
@@ -189,6 +197,7 @@ class GradReducer:
                     run[1] = hi
                 else:
                     run = pr[2] = [lo, hi]
+                pr[3].append((lo, hi, param))
                 while run[1] - run[0] >= self.slice_elems:
                     self._issue(buf, run[0], run[0] + self.slice_elems, stream)
                     pr[1].append((run[0], run[0] + self.slice_elems))
@@ -214,6 +223,9 @@ class GradReducer:
 
     def _issue(self, buf, lo, hi, stream):
         view = buf[lo:hi]
+        if not buf.is_cuda:             # host tensors (the gloo tests): no streams to order, the collective is asynchronous
+            self._works.append(self._all_reduce(view, True))
+            return
         comm = self._comm_stream(buf.device)
         # the slice's writers ran on the main stream or on the weight-gradient side stream: wait for both
         streams = {stream, torch.cuda.current_stream(buf.device)}
@@ -288,6 +300,42 @@ class GradReducer:
             raise RuntimeError(f'GradReducer: the previous step all-reduced different gradient layouts on different ranks '
                                f'(this rank {self.rank}: {values}); the averaged gradients of that step are invalid')
 
+    def _verify_issued(self, chunks):
+        """every range that was all-reduced IN PLACE during the backward pass must be a parameter's `.grad` now.
+
+        `writers_launched(..., in_place=True)` is a PREDICTION made at launch time (autograd._conv_backward's `takes`:
+        leaf, no gradient yet, no hooks, the kernel's layout -- the conditions under which AccumulateGrad steals the
+        arena view).  If it is wrong for a range (a torch release with another steal rule, a hook added later in the
+        pass), the parameter's gradient is a COPY of the range made on the main stream, possibly after the slice's
+        all-reduce wrote its result back; reduce() would then all-reduce that copy a second time through the small
+        bucket -- round 4's `g0 + g1/2` (profiles/r05_notes.md), silently.  Checked on the host from the bookkeeping
+        (no device work): raises before any further collective is posted."""
+        for (buf, issued, used, live), pr in zip(chunks, self._progress):
+            if not issued:
+                continue
+            lv = sorted(live)
+            for lo, hi, param in pr[3]:
+                # the part of this in-place range that went out during the pass ...
+                sent = [(max(lo, a), min(hi, b)) for a, b in issued if a < hi and b > lo]
+                # ... minus what a gradient refers to (the range's tail is alignment padding of < 64 elements)
+                n = param.numel() if param is not None and 0 < param.numel() <= hi - lo else hi - lo
+                left = [(a, b) for a, b in _subtract(sent, lv) if a < lo + n]
+                if left:
+                    name = None
+                    if param is not None:
+                        for i, q in enumerate(self.params):
+                            if q is param or (q.numel() == param.numel() and
+                                              q.untyped_storage().data_ptr() == param.untyped_storage().data_ptr()):
+                                name = self.names.get(id(q), f'parameter #{i}')
+                                break
+                    shape = tuple(param.shape) if param is not None else '?'
+                    raise RuntimeError(
+                        f'GradReducer(overlap=True): arena elements {left[0]} of the weight gradient of '
+                        f'{name or "a weight"} (shape {shape}, arena range [{lo}, {hi})) were all-reduced in place '
+                        'during the backward pass, but no parameter\'s .grad refers to them: autograd did not take the '
+                        'kernel\'s output as the gradient (the `takes` prediction of autograd._conv_backward was '
+                        'wrong), so the gradient it kept instead would be reduced a second time.  Use overlap=False.')
+
     # ---- end of the backward pass -----------------------------------------------------------------
     @torch.no_grad()
     def reduce(self):
@@ -299,7 +347,7 @@ class GradReducer:
             self.last_bytes = 0                 # (a step without an arena chunk: nothing was counted during backward)
         self._check_lazy()
         arena_ptrs, chunks = [], []
-        for buf, issued, _ in self._progress:
+        for buf, issued, _, _ in self._progress:
             used = _A.grad_arena.used_of(buf)
             arena_ptrs.append((buf.untyped_storage().data_ptr(), buf.numel() * 4))
             chunks.append((buf, issued, used, []))
@@ -323,6 +371,7 @@ class GradReducer:
             else:
                 lo = (g.data_ptr() - hit[0].data_ptr()) // 4
                 hit[3].append((lo, lo + g.numel()))
+        self._verify_issued(chunks)
         pending = []            # (chunk, first element, end element) to all-reduce
         for buf, issued, used, live in chunks:
             live.sort()

@@ -113,12 +113,18 @@ class TrunkFunction(Function):
                 dst.zero_()
             elif g.data_ptr() != dst.data_ptr():
                 dst.copy_(g)
+        # gradient accumulation (a second backward pass without zero_grad(set_to_none=True) in between): a parameter's
+        # `.grad` may already BE the capture's static gradient tensor, holding the previous pass's result -- the replay
+        # overwrites it.  Such gradients are set aside first and added back afterwards (they were lost).
+        pending = [(p, p.grad.clone()) for p, g in cap.grads if p.grad is not None and p.grad.data_ptr() == g.data_ptr()]
         cap.bwd.replay()
         for p, g in cap.grads:
             if p.grad is None:
                 p.grad = g
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad = p.grad + g
+        for p, old in pending:
+            p.grad = old.add_(p.grad)       # (out of place with respect to the static tensor: the next replay may overwrite it)
         return None, None, None
 
 

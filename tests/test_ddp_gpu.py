@@ -24,29 +24,44 @@ def _port():
         return s.getsockname()[1]
 
 
+def _stalled(r):
+    """the run ended because the watchdog fired (every thread's stack on stderr), not because an assertion failed"""
+    return r is None or (r.returncode != 0 and 'Timeout (' in r.stderr and 'AssertionError' not in r.stderr and
+                         'Error' not in r.stderr.replace('ChildFailedError', ''))
+
+
 def _launch(script_args, timeout=900, nproc=1, extra_env=None, stall_s=None):
     """`stall_s`: for the legs that keep gloo's staged device<->host copies in flight UNDER the backward pass of two
     processes sharing one GPU (the overlapped reducer on this harness only: RCCL does not stage through the host).  That
     combination sometimes crawls -- 15-60 s per step instead of 1.3 s, both ranks at the same collective, measured in
-    profiles/r05_notes.md -- which is the harness, not the product: such a run is reported as SKIPPED with that reason
-    after `stall_s` seconds instead of failing the suite; everything a stall could hide (the slicing logic, the averages)
-    is also covered by tests/test_distributed_cpu.py and by the legs that never stall."""
+    profiles/r05_notes.md.  A crawl is random, a deadlock (an unpaired or mis-ordered collective: how the overlapped
+    reducer would fail) is not: a run whose watchdog fires after `stall_s` seconds is REPEATED once, and a second stall
+    FAILS the test (VERDICT r05 item 4c / ADVICE r05: a hang must not read as a skip).  BRCNN_ALLOW_HARNESS_STALL=1
+    turns the double stall back into a skip for a box where the harness is known to crawl."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr',
            '127.0.0.1', '--master-port', str(_port())] + script_args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT, **(extra_env or {}))
     if stall_s is None:
         return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     env['DDP_WATCHDOG_S'] = env['BRCNN_WATCHDOG_S'] = str(int(stall_s))
-    try:
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=stall_s + 60)
-    except subprocess.TimeoutExpired:
-        pytest.skip(f'one-GPU two-rank gloo harness stalled for {stall_s} s with staged copies under the backward pass '
-                    '(harness artefact, profiles/r05_notes.md)')
-    if r.returncode != 0 and 'Timeout (' in r.stderr and 'dump_traceback_later' not in r.stderr and \
-            'AssertionError' not in r.stderr and 'Error' not in r.stderr.replace('ChildFailedError', ''):
-        pytest.skip(f'one-GPU two-rank gloo harness stalled for {stall_s} s (watchdog fired, no assertion failed): '
-                    'harness artefact, profiles/r05_notes.md')
-    return r
+    tails = []
+    for attempt in range(2):
+        cmd[cmd.index('--master-port') + 1] = str(_port())
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=stall_s + 60)
+        except subprocess.TimeoutExpired as e:
+            r = None
+            tails.append('(killed by the launcher timeout) ' + str(e.stderr or '')[-1500:])
+        if not _stalled(r):
+            return r
+        if r is not None:
+            tails.append(r.stderr[-1500:])
+    msg = (f'the two-rank run stalled for {stall_s} s TWICE in a row (watchdog fired, no assertion failed): a crawl of the '
+           'one-GPU gloo harness (profiles/r05_notes.md) does not repeat like that -- treat as a deadlock of the overlapped '
+           'gradient exchange.  stderr tails of the two attempts:\n' + '\n-----\n'.join(tails))
+    if os.environ.get('BRCNN_ALLOW_HARNESS_STALL') == '1':
+        pytest.skip(msg)
+    pytest.fail(msg)
 
 
 # two ranks on the one GPU of the box: RCCL refuses that, so the collectives go through gloo (device tensors staged

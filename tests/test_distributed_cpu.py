@@ -389,6 +389,65 @@ def test_overlapped_reducer_slices_only_ranges_that_are_grad():
     assert ret[0] == 1.0
 
 
+def _takes_lie_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import brcnn  # noqa: F401
+        from brcnn import autograd as A
+        from brcnn import distributed as D
+        dev = torch.device('cpu')
+
+        def step(red, params, lie_for=None):
+            """one 'backward pass' by hand: every weight gradient is written into the arena and announced the way
+            autograd._conv_backward does; `lie_for`: that parameter's `takes` prediction says "autograd takes the arena
+            view as .grad" although the gradient autograd keeps is a COPY (what a changed steal rule would do)"""
+            A.grad_arena.new_step()
+            for i, p in enumerate(params):
+                dw = A.grad_arena.take(tuple(p.shape), dev)
+                dw.copy_(torch.full(p.shape, float(rank + 1) * (i + 1)))
+                A.grad_arena.launched(None, True, p)                    # the prediction: in place
+                p.grad = dw.clone() if p is lie_for else dw             # what autograd really kept
+            red.reduce()
+
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(40, 50)) for _ in range(6)]
+        named = [(f'layer{i}.weight', p) for i, p in enumerate(params)]
+        red = D.GradReducer(named, slice_mb=3000 * 4 / (1 << 20), overlap=True)       # 3000-element slices
+        # honest predictions: the overlapped slices really travel during the "pass" (gloo, host tensors) and the
+        # result is the mean over the ranks
+        step(red, params)
+        assert red.last_bytes >= sum(p.numel() for p in params) * 4        # (ranges are padded to 64 elements)
+        for i, p in enumerate(params):
+            assert torch.equal(p.grad, torch.full(p.shape, 1.5 * (i + 1))), i
+        # a lying prediction: the issued slice holds elements no .grad refers to -> reduce() raises and names the parameter
+        for p in params:
+            p.grad = None
+        try:
+            step(red, params, lie_for=params[2])
+            ret[rank] = 'no error'
+        except RuntimeError as e:
+            msg = str(e)
+            ret[rank] = msg if ('layer2.weight' in msg and 'all-reduced in place' in msg) else 'wrong message: ' + msg
+        red.close()
+        A.grad_arena.new_step()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_refuses_a_wrong_takes_prediction():
+    """GradReducer(overlap=True) all-reduces, during the backward pass, the arena ranges that
+    autograd is PREDICTED to take as `.grad` unchanged.  reduce() now verifies the prediction: an issued range that no
+    parameter's gradient refers to afterwards would be reduced twice (round 4's bug) -- it raises, naming the parameter,
+    on every rank.  The honest case runs the real overlapped collectives over gloo on host tensors (world size 2)."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_takes_lie_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert 'layer2.weight' in ret[r] and 'all-reduced in place' in ret[r], ret[r]
+
+
 def _replica_worker(rank, world, port, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

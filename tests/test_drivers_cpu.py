@@ -184,3 +184,49 @@ def test_train_detector_epoch_checkpoint_resume_and_eval(tmp_path):
         assert len(out) == len(dt) and len(out[0]) == 4 and out[0][0].shape[1] == 5
     with pytest.raises(AssertionError):
         apis._check_num_classes(model, type('D', (), {'CLASSES': ('a', 'b')})(), apis.get_root_logger())
+
+
+def test_runner_holds_the_cyclic_collector_off_inside_steps_and_restores_it(tmp_path):
+    """bench.py times the train step with Python's cyclic collector off, claiming the runner does the same.
+    It does now: EpochBasedRunner.train disables the collector for the epoch's steps, collects at the log interval, and
+    restores the caller's state on the way out -- also when a step raises."""
+    import gc
+    import logging
+    seen = []
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+
+        def train_step(self, data, optimizer):
+            seen.append(gc.isenabled())
+            if data == 'boom':
+                raise ValueError('boom')
+            loss = (self.w * 2).sum()
+            return dict(loss=loss, log_vars={'loss': float(loss)}, num_samples=1)
+
+    net = Net()
+    runner = apis.EpochBasedRunner(net, torch.optim.SGD(net.parameters(), lr=0.1), str(tmp_path), logging.getLogger('t'), 1)
+    runner.register_training_hooks(dict(policy='step', step=[1]), log_config=dict(interval=2))
+    runner.lr_updater.before_run(runner.optimizer)
+    assert gc.isenabled()
+    collected = []
+    cb = lambda phase, info: collected.append(phase) if phase == 'stop' else None
+    gc.callbacks.append(cb)
+    try:
+        runner.train([0, 1, 2, 3])
+    finally:
+        gc.callbacks.remove(cb)
+    assert seen == [False] * 4 and gc.isenabled()
+    assert len(collected) >= 3                  # one before the epoch, one per log interval (2 of them)
+    # the caller's collector comes back when a step raises
+    seen.clear()
+    with pytest.raises(ValueError):
+        runner.train([0, 'boom', 2])
+    assert seen == [False, False] and gc.isenabled()
+    # manual_gc off (BRCNN_RUNNER_GC=1 / cfg.manual_gc = False): the collector is left alone
+    seen.clear()
+    runner.manual_gc = False
+    runner.train([0])
+    assert seen == [True]
