@@ -540,9 +540,14 @@ class PermutedWeightFunction(Function):
     main stream at the very start of the backward pass."""
 
     @staticmethod
-    def forward(ctx, w2d, c, ph, pw):
+    def forward(ctx, w2d, c, ph, pw, lazy=False):
+        """`lazy`: the caller holds the permuted OPERANDS of this version of the weight already (optim.FusedSGD wrote
+        them in its step: `_brcnn_pack_perm`) and nothing will read the permuted fp32 values -- the result is a
+        zero-stride placeholder of the right shape, no copy (51 MB read + 51 MB written per step at 1024 x 12544)"""
         ctx.cfg = (c, ph, pw)
         out = w2d.shape[0]
+        if lazy:
+            return w2d.new_empty((1,)).expand(out, c * ph * pw)
         return w2d.view(out, c, ph, pw).permute(0, 2, 3, 1).reshape(out, -1)
 
     @staticmethod
@@ -552,7 +557,7 @@ class PermutedWeightFunction(Function):
         out = g.shape[0]
         side = _wgrad_side_stream(g.device) if g.is_cuda else None
         if side is None:            # no second stream (switched off, or DistributedDataParallel's hooks): the plain copy
-            return g.reshape(out, ph, pw, c).permute(0, 3, 1, 2).reshape(out, -1), None, None, None
+            return g.reshape(out, ph, pw, c).permute(0, 3, 1, 2).reshape(out, -1), None, None, None, None
         main = torch.cuda.current_stream(g.device)
         side.wait_event(main.record_event())        # (the launch that wrote g ran on `side` or, failing that, on `main`)
         with torch.cuda.stream(side):
@@ -560,44 +565,59 @@ class PermutedWeightFunction(Function):
         g.record_stream(side)
         r.record_stream(main)                       # (read on the main stream after the end-of-pass join)
         _queue_stream_join(main, side)
-        return r, None, None, None
+        return r, None, None, None, None
 
 
-def permuted_fc_weight(w2d, c, ph, pw):
+def permuted_fc_weight(w2d, c, ph, pw, dtype=None):
     """(out, C*ph*pw) -> (out, ph*pw*C), differentiable; the result may be fed to `linear_autograd` only (its
-    weight-gradient launch then goes to the second stream)"""
-    if not FC0_ON_SIDE:
+    weight-gradient launch then goes to the second stream).  `dtype`: the dtype of the activations it will multiply --
+    when the fused optimizer has already written the permuted operands of this version of the weight in that dtype,
+    the fp32 permutation is skipped altogether (PermutedWeightFunction, `lazy`)."""
+    pk = getattr(w2d, '_brcnn_pack_perm', None)
+    lazy = (pk is not None and dtype is not None and pk[0] == w2d._version and pk[1] == dtype and w2d.requires_grad and
+            pk[2].device == w2d.device and w2d.shape[0] % (32 if dtype == torch.float32 else 64) == 0)
+    if not FC0_ON_SIDE and not lazy:
         out = w2d.shape[0]
         return w2d.view(out, c, ph, pw).permute(0, 2, 3, 1).reshape(out, -1)
-    w = PermutedWeightFunction.apply(w2d, c, ph, pw)
-    if w.requires_grad:
+    w = PermutedWeightFunction.apply(w2d, c, ph, pw, lazy)
+    if w.requires_grad and FC0_ON_SIDE:
         w._brcnn_dw_consumer_on_side = True
+    if lazy:
+        w._brcnn_pack = (w._version, pk[1], pk[2], pk[3])
     return w
 
 
 def linear_autograd(x, weight, bias):
     """x (M,K) @ weight(N,K)^T + bias, differentiable (the 1x1 case with H=W=1)"""
     on_side = getattr(weight, '_brcnn_dw_consumer_on_side', False)
+    pk = getattr(weight, '_brcnn_pack', None)       # operands the fused optimizer (or permuted_fc_weight) holds for it
+    src = weight
     weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)
     w4 = weight.view(weight.shape[0], weight.shape[1], 1, 1)
     if on_side and cout == weight.shape[0]:         # (no padding cat in between: dW travels back through views only)
         w4._brcnn_dw_consumer_on_side = True
+    if pk is not None and weight is src and pk[0] == src._version and pk[1] == x.dtype and pk[2].device == x.device:
+        w4._brcnn_pack = (w4._version, pk[1], pk[2], pk[3])
     y = ConvNHWCFunction.apply(x.contiguous(), w4, bias, x.shape[0], ((1, 1),), 1, 0)
     return y if cout == weight.shape[0] else y[:, :cout]
 
 
 ROI_BACKWARD_GATHER = True      # False: the scatter form (fp32 atomics), kept for A/B and as the generic fallback
+ROI_GATHER_ADDEND = _os.environ.get('BRCNN_ROI_ADDEND', '1') != '0'     # (A/B switch: see roi_extract_autograd)
 
 
 class RoIExtractFunction(Function):
     """Fused SingleRoIExtractor on NHWC maps with the RoIAlign feature gradient."""
 
     @staticmethod
-    def forward(ctx, rois, output_size, strides, finest_scale, sampling_ratio, *feats):
+    def forward(ctx, rois, output_size, strides, finest_scale, sampling_ratio, addends, *feats):
+        """`addends`: None, or per level a tensor (or None) that the backward adds to that level's gradient inside
+        the gather launch (`brcnn_roi_extract_backward_gather_add`; see `inject_gradients`)"""
         out, _ = ops.roi_extract(list(feats), rois, output_size, strides, finest_scale, sampling_ratio)
         ctx.save_for_backward(rois)
         ctx.cfg = (output_size, tuple(strides), finest_scale, sampling_ratio,
                    [tuple(f.shape) for f in feats], feats[0].dtype)
+        ctx.addends = addends
         return out
 
     @staticmethod
@@ -618,11 +638,18 @@ class RoIExtractFunction(Function):
             ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads])
             nb = lib.brcnn_roi_extract_backward_workspace_bytes(rois.size(0))
             wsp = torch.empty((nb + 3) // 4, dtype=torch.int32, device=grad_out.device)
-            st = lib.brcnn_roi_extract_backward_gather(ptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
-                                                       shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
-                                                       float(finest_scale), _ptr(wsp), nb, _dt(g), _stream())
-            _L.check(st, 'brcnn_roi_extract_backward_gather')
-            return (None, None, None, None, None) + tuple(grads)
+            adds = ctx.addends
+            ctx.addends = None
+            aptrs = None
+            if adds is not None and any(a is not None for a in adds):
+                adds = [a.contiguous() if a is not None else None for a in adds]
+                assert all(a is None or (a.dtype == fdt and tuple(a.shape) == s) for a, s in zip(adds, shapes))
+                aptrs = (ctypes.c_void_p * L)(*[a.data_ptr() if a is not None else None for a in adds])
+            st = lib.brcnn_roi_extract_backward_gather_add(ptrs, aptrs, hs, ws, sc, L, _ptr(rois), _ptr(g), shapes[0][0],
+                                                           shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
+                                                           float(finest_scale), _ptr(wsp), nb, _dt(g), _stream())
+            _L.check(st, 'brcnn_roi_extract_backward_gather_add')
+            return (None,) * 6 + tuple(grads)
         if fdt != torch.float32:
             raise _L.BrcnnHipError('RoI extract backward: the atomic scatter form is fp32 only')
         g = grad_out.float().contiguous()
@@ -632,12 +659,28 @@ class RoIExtractFunction(Function):
                                             shapes[0][3], rois.size(0), ph, pw, int(sampling_ratio),
                                             float(finest_scale), _stream())
         _L.check(st, 'brcnn_roi_extract_backward')
-        return (None, None, None, None, None) + tuple(grads)
+        if ctx.addends is not None:
+            grads = [g if a is None else g + a.to(g.dtype) for g, a in zip(grads, ctx.addends)]
+            ctx.addends = None
+        return (None,) * 6 + tuple(grads)
 
 
 def roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=56, sampling_ratio=0):
+    # levels that arrive from `inject_gradients` with a gradient still to be added: the gather launch of the backward
+    # pass adds it (one launch and one stream of bytes less than the add per level it replaces)
+    addends = None
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    if rois.shape[0] > 0 and ROI_BACKWARD_GATHER and ROI_GATHER_ADDEND and ph <= 7 and pw <= 7:
+        for i, f in enumerate(feats_nhwc):
+            pend = getattr(f, '_brcnn_pending_addend', None)
+            if pend is not None and pend[0][pend[1]] is not None and pend[0][pend[1]].dtype == f.dtype and \
+                    f.requires_grad and f.shape[3] % 4 == 0:
+                if addends is None:
+                    addends = [None] * len(feats_nhwc)
+                addends[i] = pend[0][pend[1]]
+                pend[0][pend[1]] = None           # claimed: _InjectGradients passes this level's gradient through
     return RoIExtractFunction.apply(rois.contiguous().float(), output_size, strides, finest_scale,
-                                    sampling_ratio, *[f.contiguous() for f in feats_nhwc])
+                                    sampling_ratio, addends, *[f.contiguous() for f in feats_nhwc])
 
 
 class GroupedConvFunction(Function):
@@ -1022,7 +1065,14 @@ class _InjectGradients(Function):
 
 
 def inject_gradients(feats, extra):
-    """`feats` with `extra[i]` (or None) added to the gradient of level i on the way back"""
+    """`feats` with `extra[i]` (or None) added to the gradient of level i on the way back.  A level that goes to
+    `roi_extract_autograd` hands its addend over to that node (tagged through `_brcnn_pending_addend`): the RoIAlign
+    gradient gather adds it while it writes the level's gradient."""
     if not extra or all(e is None for e in extra):
         return tuple(feats)
-    return _InjectGradients.apply(list(extra), *feats)
+    holder = list(extra)
+    outs = _InjectGradients.apply(holder, *feats)
+    for i, o in enumerate(outs):
+        if holder[i] is not None:
+            o._brcnn_pending_addend = (holder, i)
+    return outs

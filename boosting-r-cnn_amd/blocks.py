@@ -340,12 +340,14 @@ class ConvModule(nn.Module):
             nn.init.constant_(self.norm.weight, 1)
             nn.init.constant_(self.norm.bias, 0)
 
-    def forward_nhwc(self, x, residual=None):
+    def forward_nhwc(self, x, residual=None, with_skip=False):
+        """`with_skip`: returns (out, alias of x) -- the alias's gradient is added in this conv's data-gradient launch
+        (conv_bn_act_nhwc); plain / BatchNorm modules only"""
         norm = self.norm
         if norm is None or isinstance(norm, nn.BatchNorm2d):
-            return conv_bn_act_nhwc(x, self.conv, norm, self._cache, self.with_activation, residual)
+            return conv_bn_act_nhwc(x, self.conv, norm, self._cache, self.with_activation, residual, with_skip)
         # GroupNorm needs the statistics of the whole conv output: conv, then fused GN(+ReLU)
-        assert residual is None
+        assert residual is None and not with_skip
         y = conv_bn_act_nhwc(x, self.conv, None, self._cache, False)
         if y.requires_grad:
             from . import autograd as ag

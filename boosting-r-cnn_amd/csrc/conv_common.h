@@ -156,6 +156,8 @@ int conv1x1_stream_set(int mode);
 int dispatch_conv_bf16(ConvParams& p, hipStream_t s);
 // 256 x 256 tile on the eight-phase two-group schedule (conv_pp_bf16.hip)
 int dispatch_conv_pp_bf16(ConvParams& p, hipStream_t s);
+// 256 x 128 tile on the same two-group schedule, three slots per K tile (conv_pp128_bf16.hip)
+int dispatch_conv_pp128_bf16(ConvParams& p, hipStream_t s);
 // chained stream-K plan for the eight-phase kernel (conv_igemm_bf16.hip owns the per-stream slots and item tables):
 // fills p.sk_*; p.sk_wgs = 0 when the plain one-tile-per-workgroup launch is the better one
 int sk_plan_pp(ConvParams& p, int slots, int bm, int bn, hipStream_t s);

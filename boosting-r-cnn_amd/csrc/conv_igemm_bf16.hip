@@ -1211,6 +1211,23 @@ static bool pp_wins(const ConvParams& p) {
     return t88 >= 128;
 }
 
+// The 256 x 128 two-group kernel (conv_pp128_bf16.hip, round 6): 128-channel column tiles on maps with at least half a
+// generation of them -- the layers with 128 output channels (stage 2), and the 256- / 512- / 2048-channel layers whose
+// 256 x 256 tile count leaves most of the chip idle (stage 3: 132 tiles -> 264; stage 4: 66 -> 132, 264 -> 528).
+// g_pp128_mode: 0 never, 1 heuristic.  g_pp128_min_k: shortest K the heuristic takes.
+int g_pp128_mode = 1;
+int g_pp128_min_k = 512;
+int g_pp128_max_t88 = 200;      // N % 256 == 0 layers: 256 x 256 tiles from this count on
+static bool pp128_ok(const ConvParams& p) {
+    return !(p.gstep || (p.Cout % 128) || p.K < 192 || (p.K % 64) || p.KH * p.KW > 32 || p.scatter || (p.tail_z && p.tail_mask));
+}
+static bool pp128_wins(const ConvParams& p) {
+    if (g_pp128_mode == 0 || !pp128_ok(p) || p.K < g_pp128_min_k) return false;
+    const long long tm = (p.M + 255) / 256;
+    if ((p.Cout % 256) == 0 && tm * (p.Cout / 256) >= g_pp128_max_t88) return false;
+    return tm * (p.Cout / 128) >= 128;
+}
+
 int g_bf16_il = 0;     // tuning hook (set_tile_bf16(-1 / -2)): spread the LDS-DMA pieces between the MFMA groups
 int g_bf16_tile = 0;   // tuning hook: 0 heuristic, 11 / 21 / 22 = MT NT (4 waves), 42 = 256x128 (8 waves)
 
@@ -1227,6 +1244,7 @@ static int dispatch_conv_f16(ConvParams& p, hipStream_t s) {
     p.il = 0;
     if (const int rc = conv1x1_stream_try(p, s, 1)) return rc < 0 ? rc : 0;
     if (p.gstep) return launch2<1, 1, 4, 2, 2, 1>(p, s);
+    if (pp128_wins(p)) return dispatch_conv_pp128_bf16(p, s);
     if (pp_wins(p)) return dispatch_conv_pp_bf16(p, s);
     const long long t22 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long long t44 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
@@ -1249,7 +1267,8 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         if (const int rc = conv1x1_stream_try(p, s, 0)) return rc < 0 ? rc : 0;
     }
     if (p.gstep) return launch2<1, 1, 4, 2>(p, s);      // grouped conv: 64-channel N tiles (128x64 on 8 waves)
-    int t = ((p.z_out || p.tail_z) && g_bf16_tile != 8844) ? 0 : g_bf16_tile;
+    int t = ((p.z_out || p.tail_z) && g_bf16_tile != 8844 && g_bf16_tile != 8842) ? 0 : g_bf16_tile;
+    if (t == 0 && pp128_wins(p)) return dispatch_conv_pp128_bf16(p, s);
     if (t == 0 && pp_wins(p)) return dispatch_conv_pp_bf16(p, s);
     if (t == 0) {
         // Measured per layer shape (tools/conv_bench_bf16.py, profiles/r01_conv_tiles_bf16.txt): the more
@@ -1274,6 +1293,8 @@ int dispatch_conv_bf16(ConvParams& p, hipStream_t s) {
         else if (p.M >= 16384) t = 81;
         else t = 21;
     }
+    if (t == 8842 && pp128_ok(p)) return dispatch_conv_pp128_bf16(p, s);
+    if (t == 8842) t = 82;
     if (t == 8844 && p.Cout > 128 && p.K >= 128 && p.KH * p.KW <= 32 && !(p.tail_z && p.tail_mask)) return dispatch_conv_pp_bf16(p, s);
     if (t == 8844) t = 82;
     if (t == 342 && p.Cout > 64) return launch2<2, 2, 4, 2, 3>(p, s);    // 3-stage ring variants
@@ -1312,11 +1333,14 @@ BRCNN_API int brcnn_conv_set_tile_bf16(int mtnt) {
     if (mtnt <= -3 && mtnt >= -5) { g_sk_mode = -3 - mtnt; return 0; }       // stream-K: -3 off, -4 heuristic, -5 forced
     if (mtnt <= -8 && mtnt >= -10) { g_sk_par = -8 - mtnt; return 0; }       // split-K of few-tile launches: -8 off, -9 heuristic, -10 forced
     if (mtnt == -6 || mtnt == -7) { g_pp_mode = mtnt == -7; return 0; }      // eight-phase kernel: -6 never, -7 heuristic
+    if (mtnt == -18 || mtnt == -19) { g_pp128_mode = mtnt == -19; return 0; }   // 256 x 128 two-group kernel: -18 never, -19 heuristic
+    if (mtnt <= -1000 && mtnt > -2000) { g_pp128_min_k = -1000 - mtnt; return 0; }      // ... its shortest K (-1000 - K)
+    if (mtnt <= -2000 && mtnt > -3000) { g_pp128_max_t88 = -2000 - mtnt; return 0; }    // ... 256 x 256 tiles from this count on
     // test hook: -11 = the K heads of the following stream-K launches do not publish and the tails give up after 256
     // polls (a lost hand-over, to exercise BRCNN_EHANDOVER); -12 = back to normal
     if (mtnt == -15 || mtnt == -16 || mtnt == -17) return conv1x1_stream_set(-15 - mtnt);      // persistent short-K 1x1 kernel never / heuristic / forced
     if (mtnt == -11 || mtnt == -12) { g_sk_drop_publish = mtnt == -11; g_sk_spin_limit = mtnt == -11 ? 256 : 1 << 24; return 0; }
-    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844};
+    const int ok[] = {0, 11, 21, 22, 42, 82, 81, 164, 342, 382, 3164, 322, 482, 381, 2244, 2144, 8844, 8842};
     bool found = false;
     for (int v : ok) found |= (v == mtnt);
     if (!found) return BRCNN_EINVAL;

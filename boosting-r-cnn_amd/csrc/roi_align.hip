@@ -1269,10 +1269,21 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
             __syncthreads();
         }
         if (c_ok) {
+            // lv.feat[l] (the `addends` of brcnn_roi_extract_backward_gather_add): a gradient of the same map from another
+            // branch, added in fp32 before the one rounding of the store
+            const T* gadd = lv.feat[l] ? reinterpret_cast<const T*>(lv.feat[l]) + (size_t)b * H * W * channels : nullptr;
 #pragma unroll
             for (int p = 0; p < 16; p++) {
                 const int py = wr0 + (p >> 2), px = wc0 + (p & 3);
-                if (py < H && px < W) st4(gout + ((size_t)py * W + px) * channels + c, acc[p]);
+                if (py < H && px < W) {
+                    const size_t off = ((size_t)py * W + px) * channels + c;
+                    float4 v = acc[p];
+                    if (gadd) {
+                        const float4 a = ld4(gadd + off);
+                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                    }
+                    st4(gout + off, v);
+                }
             }
         }
     }
@@ -1289,13 +1300,24 @@ BRCNN_API int brcnn_roi_extract_backward_gather(void* const* grad_feats_host, co
                                                 int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
                                                 float finest_scale, void* workspace, size_t workspace_bytes,
                                                 int dtype, void* stream) {
+    return brcnn_roi_extract_backward_gather_add(grad_feats_host, nullptr, heights_host, widths_host, scales_host, num_levels,
+                                                 rois, grad_output, batch, channels, n_rois, pooled_h, pooled_w,
+                                                 sampling_ratio, finest_scale, workspace, workspace_bytes, dtype, stream);
+}
+
+BRCNN_API int brcnn_roi_extract_backward_gather_add(void* const* grad_feats_host, const void* const* addends_host,
+                                                    const int* heights_host, const int* widths_host,
+                                                    const float* scales_host, int num_levels, const float* rois,
+                                                    const void* grad_output, int batch, int channels, int n_rois,
+                                                    int pooled_h, int pooled_w, int sampling_ratio, float finest_scale,
+                                                    void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     if (!brcnn_elem_ok(dtype)) return BRCNN_EINVAL;
     if (!grad_feats_host || channels <= 0 || (channels & 3) || n_rois < 0 || pooled_h <= 0 || pooled_w <= 0 || pooled_h > 7 ||
         pooled_w > 7 || batch <= 0 || !workspace || workspace_bytes < (size_t)(n_rois > 0 ? n_rois : 1) * sizeof(RoiRec))
         return BRCNN_EINVAL;
     LevelTable lv = {};
-    if (fill_levels(lv, nullptr, reinterpret_cast<float* const*>(grad_feats_host), heights_host, widths_host, scales_host,
-                    num_levels, finest_scale))
+    if (fill_levels(lv, reinterpret_cast<const float* const*>(addends_host), reinterpret_cast<float* const*>(grad_feats_host),
+                    heights_host, widths_host, scales_host, num_levels, finest_scale))
         return BRCNN_EINVAL;
     if (n_rois > 0 && (!rois || !grad_output)) return BRCNN_EINVAL;
     GatherLevels gl = {};

@@ -123,18 +123,40 @@ class BaseDetector(nn.Module):
         return self.forward_test(img, img_metas, **kwargs)
 
     def _parse_losses(self, losses):
-        log_vars = OrderedDict()
+        """base.py:185-210: every loss entry reduced to a scalar (`mean`, lists summed), `loss` = the sum of the entries
+        whose name holds 'loss'.  The entries of the device-resident train step are one-element tensors already: they
+        are stacked ONCE and the per-name sums and the total come out of one (names + 1, entries) selection-matrix
+        product -- 3 small launches forward and as many backward where the reference's chain of per-entry `mean` /
+        `sum` / `stack` calls costs ~35 (profiles/r06_notes.md); same values up to the order of a handful of fp32 adds."""
+        names, groups, flat = [], [], []
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                vs = [value]
             elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
+                vs = list(value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
-        log_vars['loss'] = loss
-        names = list(log_vars.keys())
-        vals = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
+            names.append(name)
+            groups.append(range(len(flat), len(flat) + len(vs)))
+            for v in vs:
+                v = v.reshape(()) if v.numel() == 1 else v.mean()
+                flat.append(v if v.dtype == torch.float32 else v.float())
+        if not flat:
+            raise TypeError('no losses')
+        key = (tuple(names), tuple(len(g) for g in groups), flat[0].device)
+        sel = self.__dict__.get('_loss_sel')
+        if sel is None or sel[0] != key:
+            m = torch.zeros(len(names) + 1, len(flat))
+            for r, (name, g) in enumerate(zip(names, groups)):
+                for c in g:
+                    m[r, c] = 1.0
+                    if 'loss' in name:
+                        m[len(names), c] = 1.0
+            sel = self.__dict__['_loss_sel'] = (key, m.to(flat[0].device))
+        named = torch.mv(sel[1], torch.stack(flat))             # (names + 1,): per-name sums, then the total loss
+        loss = named[len(names)]
+        names = names + ['loss']
+        vals = named.detach()
         if dist.is_available() and dist.is_initialized():
             # the reference issues one all-reduce per scalar (base.py:202-207); same values,
             # one fused collective
@@ -189,10 +211,17 @@ class TwoStageDetector(BaseDetector):
 
     # ---- features ----------------------------------------------------------------------
     def extract_feat_nhwc(self, img):
+        # training: the neck's lateral convs run inside the backbone's stage loop (FPN.lateral_tap) so that the
+        # gradient fan-in of a stage output (lateral conv + next stage) costs no aten add
+        tap = None
+        if self.with_neck and torch.is_grad_enabled() and hasattr(self.neck, 'lateral_tap') and \
+                getattr(self.backbone, 'supports_tap', False):
+            self.neck.__dict__.pop('_pre_laterals', None)
+            tap = self.neck.lateral_tap
         if hasattr(self.backbone, 'forward_from_nchw'):
-            x = self.backbone.forward_from_nchw(img)
+            x = self.backbone.forward_from_nchw(img, tap) if tap is not None else self.backbone.forward_from_nchw(img)
         else:
-            x = self.backbone.forward_nhwc(to_nhwc(img))
+            x = self.backbone.forward_nhwc(to_nhwc(img), tap) if tap is not None else self.backbone.forward_nhwc(to_nhwc(img))
         stage_mark('backbone')
         if self.with_neck:
             x = self.neck.forward_nhwc(x)
@@ -277,11 +306,13 @@ class TwoStageDetector(BaseDetector):
 
         def rpn_branch():
             losses = rpn.loss_fused(y, sizes, gt_bboxes, img_metas, gt_flat=gt_flat)
-            total = None
+            terms = []
             for k, v in losses.items():
                 if 'loss' in k:
-                    t = v.mean() if isinstance(v, torch.Tensor) else sum(e.mean() for e in v)
-                    total = t if total is None else total + t
+                    terms += [e.reshape(()) if e.numel() == 1 else e.mean() for e in ([v] if isinstance(v, torch.Tensor) else v)]
+            total = None
+            if terms:       # (one stack + one sum instead of a mean and an add per entry)
+                total = terms[0] if len(terms) == 1 else torch.stack([t.float() for t in terms]).sum()
             if total is not None and total.requires_grad:
                 params = [p for p in rpn.parameters() if p.requires_grad]
                 leaves = [c for c in cut if c.requires_grad]

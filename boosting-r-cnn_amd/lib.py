@@ -36,6 +36,8 @@ SIGNATURES = {
     'brcnn_roi_extract_backward_workspace_bytes': (c_size, [c_int]),
     'brcnn_roi_extract_backward_gather': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 + [c_f32, c_ptr, c_size,
                                                                                                     c_int, c_ptr]),
+    'brcnn_roi_extract_backward_gather_add': (c_int, [c_ptr] * 5 + [c_int] + [c_ptr] * 2 + [c_int] * 6 + [c_f32, c_ptr, c_size,
+                                                                                                        c_int, c_ptr]),
     'brcnn_nms_workspace_bytes': (c_size, [c_i64, c_int, c_i64]),
     'brcnn_nms': (c_int, [c_ptr] * 4 + [c_int, c_i64, c_i64, c_f32, c_int, c_int, c_ptr, c_ptr,
                                         c_ptr, c_size, c_ptr]),
@@ -117,6 +119,7 @@ SIGNATURES = {
     'brcnn_sgd_workspace_bytes': (c_size, [c_int, c_ptr]),
     'brcnn_sgd_step': (c_int, [c_ptr] * 7 + [c_int, c_f32, c_f32, c_f32, c_int, c_ptr, c_size, c_ptr, c_ptr]),
     'brcnn_pack_conv_weights_batch': (c_int, [c_ptr] * 5 + [c_int, c_int, c_ptr, c_ptr]),
+    'brcnn_pack_fc_weight_permuted': (c_int, [c_ptr] * 3 + [c_int] * 4 + [c_ptr, c_ptr]),
     'brcnn_bbox_overlaps': (c_int, [c_ptr, c_int, c_int, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_ptr]),
     'brcnn_assign_max_iou': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int,
                                      c_ptr, c_ptr] + [c_f32] * 5 + [c_int] + [c_ptr] * 5),

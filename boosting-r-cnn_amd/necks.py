@@ -70,22 +70,66 @@ class FPN(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
+    # ---- gradient fan-in without aten adds (training) ------------------------------------------------
+    # A tensor with two consumers gets its gradient as an autograd add over the whole tensor.  Where one of the
+    # consumers is a stride-1 conv, that conv can hand out an ALIAS of its input (`with_skip`): whatever the other
+    # consumer sends back through the alias is added in the conv's data-gradient epilogue (the residual operand of the
+    # MFMA kernel) -- no extra launch, one stream of bytes less than the add.  Used for
+    #   * the backbone's stage outputs: lateral conv (alias -> the next stage), `lateral_tap`;
+    #   * the top-down path: laterals[i] feeds fpn_convs[i] (alias -> the upsample-add into level i-1);
+    #   * PAFPN's bottom-up path: inter[i] feeds pafpn_convs[i-1] (alias -> downsample_convs[i]).
+    # Same values forward; the gradient sums have the same terms in another association.
+    FUSE_FAN_IN = __import__('os').environ.get('BRCNN_FUSE_FAN_IN', '1') != '0'      # (A/B switch)
+
+    @staticmethod
+    def _skip_ok(conv_module, x):
+        import torch
+        c = conv_module.conv
+        return (FPN.FUSE_FAN_IN and torch.is_grad_enabled() and x.is_cuda and x.requires_grad and c.groups == 1 and
+                c.stride == (1, 1) and c.kernel_size[0] == c.kernel_size[1] and
+                2 * c.padding[0] == c.kernel_size[0] - 1 and c.dilation == (1, 1) and
+                (conv_module.norm is None or isinstance(conv_module.norm, nn.BatchNorm2d)))
+
+    def lateral_tap(self, k, x):
+        """the backbone's `tap` (ResNet._stages): output stage k's result x -> what the backbone continues with.  Runs
+        the lateral conv of that level now, keeps its result for `_laterals`, returns the alias of x."""
+        i = k - self.start_level
+        if not (0 <= i < len(self.lateral_convs)) or not self._skip_ok(self.lateral_convs[i], x):
+            return x
+        pre = self.__dict__.setdefault('_pre_laterals', {})
+        pre[i], alias = self.lateral_convs[i].forward_nhwc(x, with_skip=True)
+        return alias
+
     def _laterals(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [conv.forward_nhwc(inputs[i + self.start_level])
+        pre = self.__dict__.pop('_pre_laterals', None) or {}
+        laterals = [pre[i] if i in pre else conv.forward_nhwc(inputs[i + self.start_level])
                     for i, conv in enumerate(self.lateral_convs)]
-        for i in range(len(laterals) - 1, 0, -1):
-            if laterals[i].requires_grad or laterals[i - 1].requires_grad:
-                if laterals[i].is_cuda and laterals[i].shape[3] % 4 == 0 and laterals[i].dtype == laterals[i - 1].dtype:
-                    laterals[i - 1] = ops.upsample_nearest_add_nhwc(laterals[i - 1], laterals[i])
+        return laterals
+
+    def _top_down(self, laterals, convs):
+        """laterals[i-1] += upsample(laterals[i]) from the top, and outs[i] = convs[i](laterals[i]) as soon as level i
+        is final (the reference runs all the adds first and the convs afterwards: same values)"""
+        outs = [None] * len(laterals)
+        for i in range(len(laterals) - 1, -1, -1):
+            src = laterals[i]
+            if i > 0 and self._skip_ok(convs[i], laterals[i]):
+                outs[i], src = convs[i].forward_nhwc(laterals[i], with_skip=True)
+            else:
+                outs[i] = convs[i].forward_nhwc(laterals[i])
+            if i == 0:
+                break
+            if src.requires_grad or laterals[i - 1].requires_grad:
+                if src.is_cuda and src.shape[3] % 4 == 0 and src.dtype == laterals[i - 1].dtype:
+                    laterals[i - 1] = ops.upsample_nearest_add_nhwc(laterals[i - 1], src)
                     continue
                 import torch.nn.functional as F
-                up = F.interpolate(laterals[i].permute(0, 3, 1, 2), size=laterals[i - 1].shape[1:3],
+                up = F.interpolate(src.permute(0, 3, 1, 2), size=laterals[i - 1].shape[1:3],
                                    mode='nearest').permute(0, 2, 3, 1)
                 laterals[i - 1] = laterals[i - 1] + up
             else:
-                ops.upsample_nearest_add_nhwc_(laterals[i - 1], laterals[i])
-        return laterals
+                ops.upsample_nearest_add_nhwc_(laterals[i - 1], src)
+        return outs
 
     def _extra(self, inputs, laterals, outs):
         used = len(laterals)
@@ -108,7 +152,7 @@ class FPN(nn.Module):
 
     def forward_nhwc(self, inputs):
         laterals = self._laterals(inputs)
-        outs = [self.fpn_convs[i].forward_nhwc(laterals[i]) for i in range(len(laterals))]
+        outs = self._top_down(laterals, self.fpn_convs)
         return tuple(self._extra(inputs, laterals, outs))
 
     def forward(self, inputs):
@@ -139,12 +183,20 @@ class PAFPN(FPN):
     def forward_nhwc(self, inputs):
         laterals = self._laterals(inputs)
         used = len(laterals)
-        inter = [self.fpn_convs[i].forward_nhwc(laterals[i]) for i in range(used)]
-        for i in range(used - 1):
+        inter = self._top_down(laterals, self.fpn_convs)
+        outs = [inter[0]] + [None] * (used - 1)
+        for i in range(used):
+            src = inter[i]
+            if i >= 1:      # level i is final: its output conv runs now, handing out the alias the next downsample conv reads
+                if i < used - 1 and self._skip_ok(self.pafpn_convs[i - 1], inter[i]):
+                    outs[i], src = self.pafpn_convs[i - 1].forward_nhwc(inter[i], with_skip=True)
+                else:
+                    outs[i] = self.pafpn_convs[i - 1].forward_nhwc(inter[i])
+            if i == used - 1:
+                break
             d = self.downsample_convs[i]
             if d.with_norm or d.with_activation:
-                inter[i + 1] = inter[i + 1] + d.forward_nhwc(inter[i])
+                inter[i + 1] = inter[i + 1] + d.forward_nhwc(src)
             else:   # inter[i+1] += conv(inter[i]) as the conv epilogue's residual operand
-                inter[i + 1] = d.forward_nhwc(inter[i], residual=inter[i + 1])
-        outs = [inter[0]] + [self.pafpn_convs[i - 1].forward_nhwc(inter[i]) for i in range(1, used)]
+                inter[i + 1] = d.forward_nhwc(src, residual=inter[i + 1])
         return tuple(self._extra(inputs, laterals, outs))

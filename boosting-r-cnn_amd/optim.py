@@ -19,6 +19,9 @@ from . import lib as _L
 from .ops import _dt, _ptr, _stream
 
 
+PACK_LINEAR = __import__('os').environ.get('BRCNN_FC_PACK', '1') != '0'       # (A/B switch: register_conv_weights)
+
+
 def _dense_layout(t):
     """'contiguous' / 'channels_last' when `t` covers its storage densely in that order, else None"""
     if t.is_contiguous():
@@ -36,7 +39,8 @@ class FusedSGD(torch.optim.Optimizer):
             raise NotImplementedError('FusedSGD: maximize')
         defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False)
         super().__init__(params, defaults)
-        self._conv = []              # [(param, fwd_buf, dgrad_buf)] of registered conv weights, per compute dtype
+        self._conv = []              # [(param, fwd_buf, dgrad_buf)] of registered conv / linear weights, per compute dtype
+        self._fcperm = []            # [(param, fwd_buf, dgrad_buf, C, ph * pw)]: the first FC (column-permuted operands)
         self._conv_dtype = None
         self.ctl = None              # device [grad norm, applied factor, skipped]
         for g in self.param_groups:
@@ -46,12 +50,14 @@ class FusedSGD(torch.optim.Optimizer):
 
     # ---- conv weight operands of the next step -------------------------------------------------
     def register_conv_weights(self, module, dtype):
-        """keep the packed forward / data-gradient operands of every trainable, ungrouped nn.Conv2d weight of
-        `module` current in `dtype` (the compute dtype): written by `step()`, consumed by
-        `autograd.ConvNHWCFunction` through `weight._brcnn_pack`.  Weights stored channels-last
-        (`blocks.conv_weights_channels_last`) are read in that layout."""
+        """keep the packed forward / data-gradient operands of every trainable, ungrouped nn.Conv2d weight -- and of the
+        nn.Linear weights of the box head -- of `module` current in `dtype` (the compute dtype): written by `step()`,
+        consumed by `autograd.ConvNHWCFunction` through `weight._brcnn_pack`.  Weights stored channels-last
+        (`blocks.conv_weights_channels_last`) are read in that layout.  A Linear tagged `_brcnn_fc_perm = (C, ph, pw)`
+        (the first FC behind the RoI extractor: its columns are (C, ph, pw), the NHWC features multiply (ph, pw, C))
+        gets its operands in the permuted K order (`brcnn_pack_fc_weight_permuted`, `weight._brcnn_pack_perm`)."""
         mult = 32 if dtype == torch.float32 else 64
-        self._conv, self._conv_dtype = [], dtype
+        self._conv, self._fcperm, self._conv_dtype = [], [], dtype
         mine = {id(p) for g in self.param_groups for p in g['params']}
         for m in module.modules():
             if isinstance(m, torch.nn.Conv2d) and m.groups == 1 and id(m.weight) in mine and m.weight.requires_grad \
@@ -60,19 +66,37 @@ class FusedSGD(torch.optim.Optimizer):
                 co, ci, kh, kw = w.shape
                 self._conv.append((w, torch.empty((co, kh, kw, ci), dtype=dtype, device=w.device),
                                    torch.empty((ci, kh, kw, co), dtype=dtype, device=w.device)))
+            elif PACK_LINEAR and isinstance(m, torch.nn.Linear) and (getattr(m, '_brcnn_pack_linear', False) or
+                                                       getattr(m, '_brcnn_fc_perm', None) is not None) and \
+                    id(m.weight) in mine and m.weight.requires_grad and m.weight.shape[0] % mult == 0 and m.weight.shape[1] % mult == 0 and m.weight.is_contiguous() and \
+                    m.weight.dtype == torch.float32:
+                w = m.weight
+                co, k = w.shape
+                perm = getattr(m, '_brcnn_fc_perm', None)
+                f = torch.empty((co, 1, 1, k), dtype=dtype, device=w.device)
+                d = torch.empty((k, 1, 1, co), dtype=dtype, device=w.device)
+                if perm is not None and perm[0] % 64 == 0 and perm[0] * perm[1] * perm[2] == k and perm[1] * perm[2] <= 255:
+                    self._fcperm.append((w, f, d, int(perm[0]), int(perm[1] * perm[2])))
+                elif perm is None:
+                    self._conv.append((w, f, d))
         self._pack(None)
-        return len(self._conv)
+        return len(self._conv) + len(self._fcperm)
 
     def _pack(self, ctl):
+        lib = _L.load()
+        for w, f, d, c, pn in self._fcperm:
+            st = lib.brcnn_pack_fc_weight_permuted(_ptr(w), _ptr(f), _ptr(d), w.shape[0], c, pn, _dt(f), _ptr(ctl), _stream())
+            _L.check(st, 'brcnn_pack_fc_weight_permuted')
+            w._brcnn_pack_perm = (w._version, self._conv_dtype, f, d)
         if not self._conv:
             return
         n = len(self._conv)
         ws = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _ in self._conv])
         fw = (ctypes.c_void_p * n)(*[f.data_ptr() for _, f, _ in self._conv])
         dg = (ctypes.c_void_p * n)(*[d.data_ptr() for _, _, d in self._conv])
-        dims = (ctypes.c_int * (4 * n))(*[int(v) for w, _, _ in self._conv for v in w.shape])
-        cl = (ctypes.c_int * n)(*[int(_dense_layout(w) == 'channels_last') for w, _, _ in self._conv])
-        st = _L.load().brcnn_pack_conv_weights_batch(ws, fw, dg, dims, cl, n, _dt(self._conv[0][1]), _ptr(ctl), _stream())
+        dims = (ctypes.c_int * (4 * n))(*[int(v) for w, _, _ in self._conv for v in (tuple(w.shape) + (1, 1))[:4]])
+        cl = (ctypes.c_int * n)(*[int(w.dim() == 4 and _dense_layout(w) == 'channels_last') for w, _, _ in self._conv])
+        st = lib.brcnn_pack_conv_weights_batch(ws, fw, dg, dims, cl, n, _dt(self._conv[0][1]), _ptr(ctl), _stream())
         _L.check(st, 'brcnn_pack_conv_weights_batch')
         for w, f, d in self._conv:
             w._brcnn_pack = (w._version, self._conv_dtype, f, d)

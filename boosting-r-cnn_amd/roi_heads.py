@@ -164,6 +164,15 @@ class ProbConvFCBBoxHead(nn.Module):
                         num_cls_fcs == num_reg_fcs == 0 and num_shared_fcs > 0)
         self._fc_caches = {}
         self._caches = [PackedCache() for _ in range(num_shared_fcs + 1)]
+        if self._simple:
+            # tags for optim.FusedSGD.register_conv_weights: the shared FCs' 16-bit operands are written by the
+            # optimizer step (the first one in the (ph, pw, C) column order the NHWC RoI features multiply)
+            ph_pw = self.roi_feat_size if isinstance(self.roi_feat_size, (tuple, list)) else (self.roi_feat_size,) * 2
+            for i, fc in enumerate(self.shared_fcs):
+                if i == 0:
+                    fc._brcnn_fc_perm = (self.in_channels, int(ph_pw[0]), int(ph_pw[1]))
+                else:
+                    fc._brcnn_pack_linear = True
         self.init_weights()
 
     custom_cls_channels = False
@@ -215,7 +224,7 @@ class ProbConvFCBBoxHead(nn.Module):
             for i, fc in enumerate(self.shared_fcs):
                 w = fc.weight
                 if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable (its gradient's way back on the second stream)
-                    w = permuted_fc_weight(w, c, ph, pw)
+                    w = permuted_fc_weight(w, c, ph, pw, x.dtype)
                 x = linear_autograd(x, w, fc.bias).relu()
             y = linear_autograd(x, torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0),
                                 torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)).float()

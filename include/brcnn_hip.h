@@ -142,6 +142,16 @@ int brcnn_roi_extract_backward_gather(void *const *grad_feats_host, const int *h
                                       int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
                                       float finest_scale, void *workspace, size_t workspace_bytes,
                                       int dtype, void *stream);
+/* ... with one more operand per level: grad_feats[l] = gather + addends[l] (NULL array or NULL entries: none), the
+ * addend in the maps' dtype, added in fp32 before the store's one rounding.  What autograd does with a separate add
+ * over the whole map when a pyramid level has a second consumer besides the RoI extractor (here: the RPN branch's
+ * gradient, kept from its own earlier backward pass -- detectors.py, early_rpn_backward). */
+int brcnn_roi_extract_backward_gather_add(void *const *grad_feats_host, const void *const *addends_host,
+                                          const int *heights_host, const int *widths_host,
+                                          const float *scales_host, int num_levels, const float *rois,
+                                          const void *grad_output, int batch, int channels, int n_rois,
+                                          int pooled_h, int pooled_w, int sampling_ratio, float finest_scale,
+                                          void *workspace, size_t workspace_bytes, int dtype, void *stream);
 /* NHWC RoIAlign forward variants: 0 (default) = footprint form, column streaming (one wavefront per row of bins
  * reads every pixel of the ROW's footprint once, rows reduced first, then spread over the bins with their x weights;
  * bin rows dealt to the XCDs in contiguous eighths; equal to the reference to fp32 round-off), 1 = the reference's
@@ -785,6 +795,12 @@ int brcnn_sgd_step(float *const *params, const float *const *grads, float *const
 int brcnn_pack_conv_weights_batch(const float *const *weights, void *const *fwd, void *const *dgrad,
                                   const int *dims_host, const int *channels_last_host, int num, int dtype,
                                   const float *ctl3, void *stream);
+/* The first FC of the box head (convfc_bbox_head.py:154-192 flattens the RoI features as (C, ph, pw)): master weight
+ * (out_features, channels, positions) fp32 -> forward operand (out_features, positions, channels) in `dtype` -- the K
+ * order of the NHWC RoI features -- and, when dgrad != NULL, the data-gradient operand (positions * channels,
+ * out_features).  channels % 64 == 0, positions <= 255; ctl3 as above. */
+int brcnn_pack_fc_weight_permuted(const float *weight, void *fwd, void *dgrad, int out_features, int channels,
+                                  int positions, int dtype, const float *ctl3, void *stream);
 
 #ifdef __cplusplus
 }

@@ -600,7 +600,7 @@ def test_bf16_tile_shapes_agree_bit_for_bit():
     sh = torch.randn(256, generator=g).to(DEV)
     try:
         outs = {}
-        for t in (11, 21, 22, 81, 82, 164, 42, 2244, 2144, 382, 342, 8844):
+        for t in (11, 21, 22, 81, 82, 164, 42, 2244, 2144, 382, 342, 8844, 8842):
             assert L.brcnn_conv_set_tile_bf16(t) == 0
             outs[t] = ops.conv2d_nhwc(x, w, sc, sh, None, True, 1, 1)
         torch.cuda.synchronize()
@@ -636,10 +636,38 @@ def test_bf16_eight_phase_kernel_is_bit_identical(cfg):
     try:
         assert L.brcnn_conv_set_tile_bf16(11) == 0
         ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad, out_f32=of32)
-        assert L.brcnn_conv_set_tile_bf16(8844) == 0
-        for rep in range(3):
-            out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad, out_f32=of32)
-            assert torch.equal(out, ref), (rep, (out.float() - ref.float()).abs().max().item())
+        for tile in (8844, 8842):       # 256 x 256 eight-phase; 256 x 128 two-group (conv_pp128_bf16.hip, where its shape rules allow)
+            assert L.brcnn_conv_set_tile_bf16(tile) == 0
+            for rep in range(3):
+                out = ops.conv2d_nhwc(x, w, sc, sh, r, True, stride, pad, out_f32=of32)
+                assert torch.equal(out, ref), (tile, rep, (out.float() - ref.float()).abs().max().item())
+    finally:
+        L.brcnn_conv_set_tile_bf16(0)
+
+
+@pytest.mark.parametrize('et', [BF, torch.float16])
+def test_bf16_256x128_kernel_every_k_tile_count(et):
+    """conv_pp128_bf16.hip keeps three K tiles in nine LDS slots and unrolls six K tiles per loop iteration: every K-tile
+    count 3 .. 14 (all tails of the unrolled loop), 1x1 and 3x3 taps, ragged rows, one and three column tiles, residual
+    and ReLU -- bit-identical to the two-buffer kernel, launch after launch"""
+    from brcnn import lib as _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(61)
+    try:
+        for nk in range(3, 15):
+            for (k, co, res) in ((1, 128, False), (1, 384, True)) + (((3, 128, True),) if nk % 9 == 0 else ()):
+                ci = 64 * nk // (k * k)
+                x = torch.randn(2, 37, 53, ci, generator=g).to(DEV, et)
+                w = (torch.randn(co, k, k, ci, generator=g) * 0.05).to(DEV, et)
+                sc = (torch.rand(co, generator=g) + 0.5).to(DEV)
+                sh = torch.randn(co, generator=g).to(DEV)
+                r = torch.randn(2, 37, 53, co, generator=g).to(DEV, et) if res else None
+                assert L.brcnn_conv_set_tile_bf16(11) == 0
+                ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, 1, k // 2)
+                assert L.brcnn_conv_set_tile_bf16(8842) == 0
+                for rep in range(2):
+                    out = ops.conv2d_nhwc(x, w, sc, sh, r, True, 1, k // 2)
+                    assert torch.equal(out, ref), (nk, k, co, rep, (out.float() - ref.float()).abs().max().item())
     finally:
         L.brcnn_conv_set_tile_bf16(0)
 
@@ -688,12 +716,15 @@ def test_bf16_eight_phase_kernel_training_epilogues(dtype):
     from brcnn import lib as _lib
     L = _lib.load()
     try:
-        assert L.brcnn_conv_set_tile_bf16(8844) == 0
-        for cfg in [(8, 256, 50, 84, 1024, 1, 1, True, True, False), (2, 256, 40, 56, 256, 3, 1, False, True, True),
-                    (2, 128, 30, 44, 512, 3, 2, False, True, False)]:
-            test_conv_bn_act_one_launch_training_forward(cfg, dtype)
-        for cfg in [(2, 1024, 256, 1, 26, 40, False), (1, 1024, 512, 2, 13, 17, True)]:
-            test_bottleneck_bn_backward_inside_data_gradient_launch(cfg, dtype)
+        for tile in (8844, 8842):       # (8842: the 256 x 128 two-group kernel, same epilogues through conv_pp_epilogue.h)
+            assert L.brcnn_conv_set_tile_bf16(tile) == 0
+            for cfg in [(8, 256, 50, 84, 1024, 1, 1, True, True, False), (2, 256, 40, 56, 256, 3, 1, False, True, True),
+                        (2, 128, 30, 44, 512, 3, 2, False, True, False)] + \
+                    ([(2, 128, 40, 56, 128, 3, 1, False, True, True)] if tile == 8842 else []):
+                test_conv_bn_act_one_launch_training_forward(cfg, dtype)
+            for cfg in [(2, 1024, 256, 1, 26, 40, False), (1, 1024, 512, 2, 13, 17, True)] + \
+                    ([(2, 512, 128, 1, 26, 40, False)] if tile == 8842 else []):
+                test_bottleneck_bn_backward_inside_data_gradient_launch(cfg, dtype)
     finally:
         L.brcnn_conv_set_tile_bf16(0)
 
@@ -711,7 +742,7 @@ def test_bf16_eight_phase_kernel_multi_level_and_data_gradient():
     w2 = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
     try:
         outs = {}
-        for t in (11, 8844):
+        for t in (11, 8844, 8842):
             assert L.brcnn_conv_set_tile_bf16(t) == 0
             y, _ = ops.conv2d_nhwc_multi(xc, wt, B, sizes, None, None, None, False, 1, 1)
             x = torch.randn(2, 50, 84, 256, generator=torch.Generator().manual_seed(35)).to(DEV, BF).requires_grad_(True)
@@ -719,7 +750,8 @@ def test_bf16_eight_phase_kernel_multi_level_and_data_gradient():
             z = conv2d_nhwc_autograd(x, w2.clone().requires_grad_(True), None, 2, 1)
             z.backward(dy)
             outs[t] = (y, x.grad.clone())
-        assert torch.equal(outs[11][0], outs[8844][0]) and torch.equal(outs[11][1], outs[8844][1])
+        for t in (8844, 8842):
+            assert torch.equal(outs[11][0], outs[t][0]) and torch.equal(outs[11][1], outs[t][1]), t
     finally:
         L.brcnn_conv_set_tile_bf16(0)
 
@@ -732,6 +764,7 @@ def test_bf16_eight_phase_kernel_multi_level_and_data_gradient():
     (8, 25, 42, 512, 512, 3, False),
     (3, 50, 84, 256, 256, 3, True),          # fewer tiles than resident workgroups on most tile shapes: plain launch
     (8, 100, 168, 256, 256, 3, False),       # 525 tiles of 256 x 256: the eight-phase kernel's stream-K case
+    (8, 100, 168, 128, 128, 3, True),        # 525 tiles of 256 x 128: the two-group 128-column kernel's (stage 2)
 ])
 def test_bf16_stream_k_schedule_is_bit_identical(shape):
     """the chained stream-K schedule (a tile that straddles two workgroup ranges is started by one workgroup and
@@ -748,7 +781,7 @@ def test_bf16_stream_k_schedule_is_bit_identical(shape):
     sh = torch.randn(co, generator=g).to(DEV)
     r = torch.randn(n, h, w_, co, generator=g).bfloat16().to(DEV) if res else None
     try:
-        for t in (0, 11, 21, 81, 82, 8844):
+        for t in (0, 11, 21, 81, 82, 8844, 8842):
             assert L.brcnn_conv_set_tile_bf16(t) == 0
             assert L.brcnn_conv_set_tile_bf16(-3) == 0
             ref = ops.conv2d_nhwc(x, w, sc, sh, r, True, 1, k // 2)

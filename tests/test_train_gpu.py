@@ -600,9 +600,12 @@ def test_deferred_slab_reductions_give_the_same_bits(dtype):
 def test_early_rpn_backward_gives_the_same_step(dtype, scale):
     """`early_rpn_backward`: the RPN branch back-propagated inside the forward pass (proposal stage on a second
     stream) + the second stage's backward() afterwards = the one backward pass over both branches: same losses, and
-    every parameter gradient equal up to the order of the weight-gradient atomics (the two pyramid-gradient terms are
-    added in the other order: a + b == b + a), over
-    several steps that reuse the allocator's blocks across the two streams"""
+    every parameter gradient equal up to the order of the weight-gradient atomics in fp32 (the two pyramid-gradient terms
+    are added in the other order: a + b == b + a).  In the 16-bit modes the early form adds the RPN branch's pyramid
+    gradient INSIDE the RoIAlign gradient gather (fp32 sum, one rounding at the store: round 6) where the one-pass form
+    rounds the gather's result and then the autograd add's -- the pyramid gradients differ by one 16-bit rounding and
+    the parameter gradients behind them by a fraction of that.  Over several steps that reuse the allocator's blocks
+    across the two streams"""
     from brcnn import blocks
     m = _model()
     blocks.conv_weights_channels_last(m)
@@ -630,7 +633,8 @@ def test_early_rpn_backward_gives_the_same_step(dtype, scale):
                     gb = res['ref'][1][k]
                     # (equal up to the order of the fp32 atomics of the fp32 weight-gradient kernel)
                     scl = gb.abs().max().item() + 1e-12
-                    assert (ga - gb).abs().max().item() <= 1e-4 * scl, (k, (ga - gb).abs().max().item(), scl)
+                    tol = {'f32': 1e-4, 'bf16': 2 ** -8, 'f16': 2 ** -11}[dtype]
+                    assert (ga - gb).abs().max().item() <= tol * scl, (k, (ga - gb).abs().max().item(), scl)
     finally:
         m.early_rpn_backward, m.early_backward_scale = False, 1.0
         blocks.set_compute_dtype('f32')

@@ -32,7 +32,8 @@ shapes = [  # name, N,H,W,Cin,Cout,k,stride,pad,res
 if os.environ.get('SHAPES'):
     keep = os.environ['SHAPES'].split(',')
     shapes = [s_ for s_ in shapes if any(k_ in s_[0] for k_ in keep)]
-# tile ids as brcnn_conv_set_tile_bf16 takes them; suffix 's' = stream-K schedule forced, 'a' = heuristic, none = off
+# tile ids as brcnn_conv_set_tile_bf16 takes them; suffix 's' = stream-K schedule forced, 'a' = heuristic, none = off;
+# 'n' = without the 256 x 128 two-group kernel (8842 forces it, 8844 forces the 256 x 256 eight-phase kernel)
 tiles = sys.argv[1].split(',') if len(sys.argv) > 1 else ['11', '21', '22', '0']
 if len(sys.argv) > 2:      # 'il0' / 'il1': LDS-DMA pieces in front of / spread between the MFMA groups
     L.brcnn_conv_set_tile_bf16(-1 if sys.argv[2] == 'il1' else -2)
@@ -53,12 +54,14 @@ for name,N,H,W,Ci,Co,k,st,pd,res in shapes:
     by = 2.0*(x.numel() + w.numel() + N*Ho*Wo*Co*(2 if res else 1))
     out = []
     for ts in tiles:
-        t = int(ts.rstrip('sa'))
+        t = int(ts.rstrip('san'))
         if L.brcnn_conv_set_tile_bf16(t) != 0:
             continue
-        L.brcnn_conv_set_tile_bf16(-5 if ts.endswith('s') else -4 if ts.endswith('a') else -3)
+        L.brcnn_conv_set_tile_bf16(-18 if 'n' in ts else -19)          # 'n': the 256 x 128 two-group kernel off (round 5's heuristic)
+        L.brcnn_conv_set_tile_bf16(-5 if 's' in ts else -4 if 'a' in ts else -3)
         ms = bench(lambda: ops.conv2d_nhwc(x,w,sc,sh,r,True,st,pd))
         out.append(f'{ts:>5s}: {ms*1000:6.1f} us {fl/ms/1e9:6.1f} TF')
     L.brcnn_conv_set_tile_bf16(0)
     L.brcnn_conv_set_tile_bf16(-4)
+    L.brcnn_conv_set_tile_bf16(-19)
     print(f'{name:24s} M={N*Ho*Wo:7d} hbm-floor {by/8e12*1e6:5.1f} us | ' + ' | '.join(out))
