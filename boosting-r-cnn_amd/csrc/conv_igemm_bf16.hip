@@ -1211,13 +1211,17 @@ static bool pp_wins(const ConvParams& p) {
     return t88 >= 128;
 }
 
-// The 256 x 128 two-group kernel (conv_pp128_bf16.hip, round 6): 128-channel column tiles on maps with at least half a
-// generation of them -- the layers with 128 output channels (stage 2), and the 256- / 512- / 2048-channel layers whose
-// 256 x 256 tile count leaves most of the chip idle (stage 3: 132 tiles -> 264; stage 4: 66 -> 132, 264 -> 528).
+// The 256 x 128 two-group kernel (conv_pp128_bf16.hip, round 6).  Measured (tools/conv_bench_bf16.py, profiles/r06_notes.md):
+// per CU it runs at 0.8 of the 256 x 256 kernel's rate on a full chip (912 vs 1149 TF/s: 48 KB of LDS-DMA per 128 MFMAs
+// instead of 64 KB per 256 -- the chip-wide LDS-DMA rate of ~10.8 TB/s is what bounds both), and on the mid-size maps its
+// 264 / 525 tiles sit just above one / two generations of 256 workgroups, where the chained stream-K hand-over (128 KB of
+// fp32 accumulators each way per slot) costs what the second generation would.  It wins where neither of the other kernels
+// has a shape: few 256-row tiles AND a long K loop -- the stage-4 3x3 layers (M = 8400, N = 512, K = 4608: 71.5 -> 63.5 us).
+// The heuristic takes exactly those; `brcnn_conv_set_tile_bf16(8842)` forces it wherever its shape rules allow.
 // g_pp128_mode: 0 never, 1 heuristic.  g_pp128_min_k: shortest K the heuristic takes.
 int g_pp128_mode = 1;
-int g_pp128_min_k = 512;
-int g_pp128_max_t88 = 200;      // N % 256 == 0 layers: 256 x 256 tiles from this count on
+int g_pp128_min_k = 4096;
+int g_pp128_max_t88 = 128;      // N % 256 == 0 layers: 256 x 256 tiles from this count on (where pp_wins takes them)
 static bool pp128_ok(const ConvParams& p) {
     return !(p.gstep || (p.Cout % 128) || p.K < 192 || (p.K % 64) || p.KH * p.KW > 32 || p.scatter || (p.tail_z && p.tail_mask));
 }
@@ -1225,7 +1229,8 @@ static bool pp128_wins(const ConvParams& p) {
     if (g_pp128_mode == 0 || !pp128_ok(p) || p.K < g_pp128_min_k) return false;
     const long long tm = (p.M + 255) / 256;
     if ((p.Cout % 256) == 0 && tm * (p.Cout / 256) >= g_pp128_max_t88) return false;
-    return tm * (p.Cout / 128) >= 128;
+    const long long t84 = tm * (p.Cout / 128);
+    return t84 >= 128 && t84 <= 264;          // (one generation of workgroups: more go to the smaller tiles, several per CU)
 }
 
 int g_bf16_il = 0;     // tuning hook (set_tile_bf16(-1 / -2)): spread the LDS-DMA pieces between the MFMA groups

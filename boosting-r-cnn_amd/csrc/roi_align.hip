@@ -1099,8 +1099,8 @@ __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict
                                                         int ph_n, int pw_n, int sampling_ratio, RoiRec* __restrict__ recs,
                                                         int* __restrict__ ranges) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_rois) return;
-    const float* roi = rois + (size_t)k * 5;
+    const bool live = k < n_rois;
+    const float* roi = rois + (size_t)(live ? k : 0) * 5;
     const int l = map_roi_level(roi, lv.finest_scale, lv.num_levels);
     const RoiGeom g = roi_geom(roi, lv.scale[l], 1, ph_n, pw_n, sampling_ratio);
     const int H = lv.height[l], W = lv.width[l];
@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict
     const float end_h = g.start_h + g.bin_h * (float)ph_n, end_w = g.start_w + g.bin_w * (float)pw_n;
     const bool empty = g.gh <= 0 || g.gw <= 0 || g.batch < 0 || g.batch >= batch || end_h < -1.f || g.start_h > (float)H ||
                        end_w < -1.f || g.start_w > (float)W || !(end_h == end_h) || !(end_w == end_w);
+    int rb = -1;        // image whose [first, last) RoI index range this record widens
     if (empty) {
         r.key = -1; r.y01 = r.x01 = 0;
     } else {
@@ -1118,13 +1119,29 @@ __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict
         r.y01 = (y0 << 16) | max(y1, 0);
         r.x01 = (x0 << 16) | max(x1, 0);
         if (y1 < y0 || x1 < x0) r.key = -1;
-        // the image's RoI index range: RoIs arrive image by image (bbox2roi), so a tile of image b scans
-        // [first, last) instead of every record; any other order only widens the range
-        if (r.key >= 0 && ranges) {
-            atomicMin(&ranges[g.batch], k);
-            atomicMax(&ranges[1024 + g.batch], k + 1);
+        if (r.key >= 0) rb = g.batch;
+    }
+    // the image's RoI index range: RoIs arrive image by image (bbox2roi), so a tile of image b scans [first, last) instead
+    // of every record; any other order only widens the range.  One atomic pair per wave and image (round 6: one pair
+    // per RoI on `batch` addresses serialised to ~60 us for 4096 RoIs): k grows with the lane, so the lanes of one
+    // image contribute their lowest / highest lane's index.
+    if (ranges) {
+        if (!live) rb = -1;
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(rb >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lb = __shfl(rb, leader, 64);
+            const unsigned long long same = __ballot(rb == lb);
+            if (lane == leader) {
+                const int kb = k - lane;
+                atomicMin(&ranges[lb], kb + __ffsll((long long)same) - 1);
+                atomicMax(&ranges[1024 + lb], kb + 64 - __clzll((long long)same));
+            }
+            todo &= ~same;
         }
     }
+    if (!live) return;
     recs[k] = r;
 }
 
