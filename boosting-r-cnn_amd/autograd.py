@@ -193,6 +193,7 @@ def join_side_streams(device=None):
     """make the current stream(s) wait for the side stream(s) and forget the per-pass state: the end-of-backward
     callback, and a backstop for the readers of .grad (optim.FusedSGD.step, the gradient reducer) in case a
     backward pass raised before its callbacks ran"""
+    flush_bn_deferred()
     for key, side in list(_side_streams.items()):
         if device is not None and key != (device.type, device.index):
             continue
@@ -235,6 +236,58 @@ def _queue_stream_join(main, side):
         torch.autograd.Variable._execution_engine.queue_callback(join)
     except RuntimeError:        # not inside a backward pass (a direct call of the Function's backward)
         join()
+
+
+# ---- deferred BatchNorm second stages -----------------------------------------------------------------------------
+# The backward of every trainable eval-mode BatchNorm ends with a small launch that reduces per-strip partial sums to
+# dgamma / dbeta (~40 per bf16 train step, 16 - 128 workgroups each, serial on the main stream: 0.29 ms).  Nothing reads
+# the results before the optimizer, so the library records them (`*_ex(..., defer_second_stage=1)`) and runs all of them in
+# one launch (`brcnn_bn_reduce_flush`) when the backward pass ends -- and again, as a backstop, wherever the side streams
+# are joined (FusedSGD.step, GradReducer.reduce).  Only where autograd takes dgamma / dbeta as `.grad` AS THEY ARE (leaf,
+# no gradient yet, no hooks, fp32, no DistributedDataParallel): anything else reads them right away.
+BN_REDUCE_DEFER = _os.environ.get('BRCNN_BN_REDUCE_DEFER', '1') != '0'
+_bn_keep = {}           # stream handle -> tensors the recorded stages read / write (alive until the flush)
+_bn_flush_queued = {}
+
+
+def _bn_defer_ok(*params):
+    if not BN_REDUCE_DEFER:
+        return False
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and not _OWN_REDUCER[0]:
+        return False
+    for p in params:
+        if p is None or not p.is_leaf or p.grad is not None or p.dtype != torch.float32 or p._backward_hooks or \
+                getattr(p, '_post_accumulate_grad_hooks', None):
+            return False
+    return True
+
+
+def _bn_deferred(handle, device, *keep):
+    """a second stage was recorded on stream `handle`: keep its operands alive and flush when the backward pass ends"""
+    _bn_keep.setdefault(handle, []).extend(k for k in keep if k is not None)
+    if _bn_flush_queued.get(handle):
+        return
+
+    def flush():
+        _bn_flush_queued[handle] = False
+        flush_bn_deferred(handle, device)
+    _bn_flush_queued[handle] = True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(flush)
+    except RuntimeError:        # not inside a backward pass (a direct call of the Function's backward)
+        flush()
+
+
+def flush_bn_deferred(handle=None, device=None):
+    """run the recorded BatchNorm second stages (of stream `handle`, default: of every stream that has any)"""
+    for h in ([handle] if handle is not None else list(_bn_keep.keys())):
+        if h not in _bn_keep:
+            continue
+        st = _L.load().brcnn_bn_reduce_flush(h)
+        if st < 0:
+            _L.check(st, 'brcnn_bn_reduce_flush')
+        del _bn_keep[h]
 
 
 def _conv_operands(weight, x_cat):
@@ -831,6 +884,7 @@ class BnEvalActFunction(Function):
         # without a residual the backward recomputes the ReLU mask from z and does not read `out`
         ctx.save_for_backward(z, g32, b32, m32, v32, out if relu and res is not None else None)
         ctx.cfg = (relu, res is not None, dt, rows, c, float(eps), gamma.dtype, beta.dtype)
+        ctx.bn_params = (gamma, beta)
         return out
 
     @staticmethod
@@ -841,15 +895,21 @@ class BnEvalActFunction(Function):
         dout = dout.to(z.dtype).contiguous()
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[6] else None
-        dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
-        dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+        # (two views of one buffer: a deferred second stage keeps the BUFFER alive, never the views -- autograd takes a
+        # gradient as `.grad` without a copy only while nobody else holds a reference to that very tensor)
+        gb = torch.empty(2 * c, dtype=torch.float32, device=z.device)
+        dgamma, dbeta = gb[:c], gb[c:]
         lib = _L.load()
         nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
         ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
-        st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), eps,
-                                            _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
-                                            int(relu), dt, _stream())
-        _L.check(st, 'brcnn_bn_eval_act_backward')
+        defer = rows > 0 and gdt == torch.float32 and bdt == torch.float32 and _bn_defer_ok(*ctx.bn_params)
+        h = _stream()
+        st = lib.brcnn_bn_eval_act_backward_ex(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32), eps,
+                                               _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
+                                               int(relu), dt, h, int(defer))
+        _L.check(st, 'brcnn_bn_eval_act_backward_ex')
+        if defer:
+            _bn_deferred(h, z.device, ws, m32, v32, gb)
         return dz, dgamma.to(gdt), dbeta.to(bdt), None, None, None, dres, None
 
 
@@ -858,10 +918,11 @@ class BnTail:
     its own data-gradient launch (`brcnn_conv2d_dgrad_bn_backward_nhwc`), and where it leaves the results for
     the producer's backward.  Only valid when the consumer is the ONLY user of the producer's output (conv2 /
     conv3 of a Bottleneck): the gradient that then travels along the autograd edge is dz, not d(output)."""
-    __slots__ = ('z', 'g', 'b', 'm', 'v', 'eps', 'relu', 'out', 'done', 'dgamma', 'dbeta', 'dres')
+    __slots__ = ('z', 'g', 'b', 'm', 'v', 'eps', 'relu', 'out', 'done', 'dgamma', 'dbeta', 'dres', 'params')
 
-    def __init__(self, z, g, b, m, v, eps, relu, out=None):
+    def __init__(self, z, g, b, m, v, eps, relu, out=None, params=None):
         self.z, self.g, self.b, self.m, self.v, self.eps, self.relu = z, g, b, m, v, eps, relu
+        self.params = params    # (gamma, beta) parameters: whether their gradients may be written after the fact (_bn_defer_ok)
         self.out = out          # residual producer (bn3): its output -- the ReLU mask and the consumer's own input
         self.done, self.dgamma, self.dbeta, self.dres = False, None, None, None
 
@@ -901,9 +962,10 @@ class ConvBnEvalActFunction(Function):
         ctx.cfg = (batch, (tuple(size),), ((ho, wo),), stride, pad, bool(relu), res is not None, float(eps),
                    gamma.dtype, beta.dtype)
         ctx.in_tail = in_tail if (in_tail is not None and w_t is not None and x_cat.requires_grad) else None
+        ctx.bn_params = (gamma, beta)
         ctx.tail = None
         if out_tail is not None:
-            ctx.tail = BnTail(z, g32, b32, m32, v32, float(eps), bool(relu), out if res is not None else None)
+            ctx.tail = BnTail(z, g32, b32, m32, v32, float(eps), bool(relu), out if res is not None else None, (gamma, beta))
             out_tail.append(ctx.tail)
         if with_skip:
             return out, x_cat.view_as(x_cat)
@@ -926,14 +988,18 @@ class ConvBnEvalActFunction(Function):
         else:
             dz = torch.empty_like(z)
             dres = torch.empty_like(z) if has_res and ctx.needs_input_grad[7] else None
-            dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
-            dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+            gb = torch.empty(2 * c, dtype=torch.float32, device=z.device)       # (see BnEvalActFunction.backward)
+            dgamma, dbeta = gb[:c], gb[c:]
             nb = lib.brcnn_bn_act_backward_workspace_bytes(rows, c, dt)
             ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
-            st = lib.brcnn_bn_eval_act_backward(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32),
-                                                eps, _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
-                                                int(relu), dt, _stream())
-            _L.check(st, 'brcnn_bn_eval_act_backward')
+            defer = rows > 0 and gdt == torch.float32 and bdt == torch.float32 and _bn_defer_ok(*ctx.bn_params)
+            h = _stream()
+            st = lib.brcnn_bn_eval_act_backward_ex(_ptr(dout), _ptr(out), _ptr(z), _ptr(g32), _ptr(b32), _ptr(m32), _ptr(v32),
+                                                   eps, _ptr(dz), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, rows, c,
+                                                   int(relu), dt, h, int(defer))
+            _L.check(st, 'brcnn_bn_eval_act_backward_ex')
+            if defer:
+                _bn_deferred(h, z.device, ws, m32, v32, gb)
         t = ctx.in_tail
         # a residual producer (previous block's bn3) needs this conv's identity alias gradient; a plain one none
         if t is not None and ctx.needs_input_grad[0] and (dskip is not None) == (t.out is not None) and \
@@ -942,19 +1008,23 @@ class ConvBnEvalActFunction(Function):
             cout, cin, kh, kw = weight.shape
             (h, w_), (ho, wo) = sizes[0], out_sizes[0]
             dzp = torch.empty_like(x_cat)
-            t.dgamma = torch.empty(cin, dtype=torch.float32, device=z.device)
-            t.dbeta = torch.empty(cin, dtype=torch.float32, device=z.device)
+            tgb = torch.empty(2 * cin, dtype=torch.float32, device=z.device)      # (see BnEvalActFunction.backward)
+            t.dgamma, t.dbeta = tgb[:cin], tgb[cin:]
             nb = lib.brcnn_conv2d_dgrad_bn_backward_workspace_bytes(batch, h, w_, cin)
             ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=z.device)
             if dskip is not None:
                 dskip = dskip.contiguous()
                 t.dres = torch.empty_like(x_cat)
-            st = lib.brcnn_conv2d_dgrad_bn_backward_nhwc(_ptr(dz), _ptr(ctx.w_t), _ptr(t.z), _ptr(t.g), _ptr(t.b), _ptr(t.m),
-                                                         _ptr(t.v), t.eps, int(t.relu), _ptr(dskip), _ptr(t.out), _ptr(t.dres),
-                                                         _ptr(dzp), _ptr(t.dgamma),
-                                                         _ptr(t.dbeta), _ptr(ws), nb, batch, h, w_, ho, wo, cin, cout, kh, kw,
-                                                         stride, pad, dt, _conv_stream())
-            _L.check(st, 'brcnn_conv2d_dgrad_bn_backward_nhwc')
+            defer = t.params is not None and _bn_defer_ok(*t.params)
+            hs_ = _conv_stream()
+            st = lib.brcnn_conv2d_dgrad_bn_backward_nhwc_ex(_ptr(dz), _ptr(ctx.w_t), _ptr(t.z), _ptr(t.g), _ptr(t.b), _ptr(t.m),
+                                                            _ptr(t.v), t.eps, int(t.relu), _ptr(dskip), _ptr(t.out), _ptr(t.dres),
+                                                            _ptr(dzp), _ptr(t.dgamma),
+                                                            _ptr(t.dbeta), _ptr(ws), nb, batch, h, w_, ho, wo, cin, cout, kh, kw,
+                                                            stride, pad, dt, hs_, int(defer))
+            _L.check(st, 'brcnn_conv2d_dgrad_bn_backward_nhwc_ex')
+            if defer:
+                _bn_deferred(hs_, z.device, ws, t.m, t.v, tgb)
             t.done = True
             _, dw, _ = _conv_backward(x_cat, weight, ctx.w_t, dz, (batch, sizes, out_sizes, stride, pad), None, False,
                                       ctx.needs_input_grad[1], has_dgrad=True)

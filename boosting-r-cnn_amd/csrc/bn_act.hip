@@ -10,6 +10,8 @@
 // arithmetic through ~9 separate torch kernels per block (mul, add, add, relu; threshold_backward,
 // mul, mul, 2 x sum).
 #include <type_traits>
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -271,6 +273,52 @@ __global__ __launch_bounds__(1024) void bn_eval_reduce_kernel(const float* __res
     }
 }
 
+// ... of MANY layers in one launch (brcnn_bn_reduce_flush): the second stages of a backward pass are ~40 launches of
+// 16 - 128 workgroups each, serial on the main stream (0.29 ms per bf16 train step of bench.py); nothing reads dgamma /
+// dbeta before the optimizer, so they are recorded and run together.  Same columns per workgroup, same sums in the same
+// order as bn_eval_reduce_kernel: same bits.
+constexpr int RED_TAB = 48;
+struct RedEntry {
+    const float* partial;
+    const float* mean;
+    const float* var;
+    float* dgamma;
+    float* dbeta;
+    float eps;
+    int strips, C, blk0;
+};
+struct RedTable {
+    int count;
+    RedEntry e[RED_TAB];
+};
+__global__ __launch_bounds__(1024) void bn_eval_reduce_batch_kernel(const RedTable t) {
+    __shared__ float red[2][64][16];
+    int lo = 0, hi = t.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.e[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RedEntry& e = t.e[lo];
+    const int C = e.C, strips = e.strips;
+    const int col = ((int)blockIdx.x - e.blk0) * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    float a = 0.f, b = 0.f;
+    if (col < C)
+        for (int s = sl; s < strips; s += 64) {
+            a += e.partial[((size_t)s * 2 + 0) * C + col];
+            b += e.partial[((size_t)s * 2 + 1) * C + col];
+        }
+    red[0][sl][threadIdx.x & 15] = a;
+    red[1][sl][threadIdx.x & 15] = b;
+    __syncthreads();
+    if (sl == 0 && col < C) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; k++) { ta += red[0][k][threadIdx.x]; tb += red[1][k][threadIdx.x]; }
+        e.dgamma[col] = (ta - e.mean[col] * tb) / sqrtf(e.var[col] + e.eps);
+        e.dbeta[col] = tb;
+    }
+}
+
 struct BwdPlan { int CW, chunks; long long strips, rpb; };
 inline bool bwd_plan(long long rows, int channels, int V, BwdPlan* pl) {
     const int cvn = channels / V;
@@ -345,8 +393,23 @@ int forward_impl(const void* z, const float* scale, const float* shift, const Bn
 
 // second stage over per-tile partials written by another kernel (the data-gradient epilogue of
 // conv_igemm_bf16.hip, MODE 2): partials (strips, 2 [sum d*z | sum d], C)
+// deferred second stages: (stream, entry), in issue order
+namespace {
+struct RedPending { hipStream_t s; RedEntry e; };
+std::mutex g_red_mutex;
+std::vector<RedPending> g_red_pending;
+}
+
 int brcnn_bn_eval_reduce_launch(const float* partials, int strips, const float* mean, const float* var, float eps,
-                                float* dgamma, float* dbeta, int channels, hipStream_t s) {
+                                float* dgamma, float* dbeta, int channels, hipStream_t s, int defer) {
+    if (defer) {
+        std::lock_guard<std::mutex> lock(g_red_mutex);
+        RedPending p;
+        p.s = s;
+        p.e = RedEntry{partials, mean, var, dgamma, dbeta, eps, strips, channels, 0};
+        g_red_pending.push_back(p);
+        return 0;
+    }
     BnStats bn = {mean, var, eps};
     hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 15) / 16), dim3(1024), 0, s, partials, bn, dgamma, dbeta,
                        strips, channels);
@@ -378,7 +441,7 @@ BRCNN_API size_t brcnn_bn_act_backward_workspace_bytes(int64_t rows, int channel
 
 static int backward_impl(const void* dout, const void* out, const void* z, const float* scale, const float* shift,
                          const BnStats bn, void* dz, void* dres, float* dscale, float* dshift, void* workspace,
-                         size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype, void* stream) {
+                         size_t workspace_bytes, int64_t rows, int channels, int relu, int dtype, void* stream, int defer = 0) {
     if (!dout || !z || !scale || !dz || !dscale || !dshift || !workspace || rows < 0 || channels <= 0 ||
         (relu && !out && !shift) || !brcnn_elem_ok(dtype))
         return BRCNN_EINVAL;
@@ -407,8 +470,8 @@ static int backward_impl(const void* dout, const void* out, const void* z, const
                            (f16_t*)dres, (float*)workspace, (long long)rows, channels, relu, (int)pl.rpb, pl.CW);
     BRCNN_LAUNCH_CHECK();
     if (bn.mean)
-        hipLaunchKernelGGL(bn_eval_reduce_kernel, dim3((channels + 15) / 16), dim3(1024), 0, s,
-                           (const float*)workspace, bn, dscale, dshift, (int)pl.strips, channels);
+        return brcnn_bn_eval_reduce_launch((const float*)workspace, (int)pl.strips, bn.mean, bn.var, bn.eps, dscale, dshift,
+                                           channels, s, defer);
     else
         hipLaunchKernelGGL(bn_act_reduce_kernel, dim3((channels + 63) / 64, 2), dim3(1024), 0, s,
                            (const float*)workspace, dscale, dshift, (int)pl.strips, channels);
@@ -429,9 +492,47 @@ BRCNN_API int brcnn_bn_eval_act_backward(const void* dout, const void* out, cons
                                          const float* beta, const float* mean, const float* var, float eps, void* dz, void* dres,
                                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                          int64_t rows, int channels, int relu, int dtype, void* stream) {
+    return brcnn_bn_eval_act_backward_ex(dout, out, z, gamma, beta, mean, var, eps, dz, dres, dgamma, dbeta, workspace,
+                                         workspace_bytes, rows, channels, relu, dtype, stream, 0);
+}
+
+BRCNN_API int brcnn_bn_eval_act_backward_ex(const void* dout, const void* out, const void* z, const float* gamma,
+                                            const float* beta, const float* mean, const float* var, float eps, void* dz,
+                                            void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                            int64_t rows, int channels, int relu, int dtype, void* stream,
+                                            int defer_second_stage) {
     if (!mean || !var) return BRCNN_EINVAL;
     BnStats bn = {mean, var, eps};
     if (!out && dres) return BRCNN_EINVAL;       // a residual forward needs its output for the mask
     return backward_impl(dout, out, z, gamma, beta, bn, dz, dres, dgamma, dbeta, workspace, workspace_bytes, rows, channels,
-                         relu, dtype, stream);
+                         relu, dtype, stream, rows > 0 ? defer_second_stage : 0);
+}
+
+BRCNN_API int brcnn_bn_reduce_pending(void) {
+    std::lock_guard<std::mutex> lock(g_red_mutex);
+    return (int)g_red_pending.size();
+}
+
+BRCNN_API int brcnn_bn_reduce_flush(void* stream) {
+    std::vector<RedPending> take;
+    {
+        std::lock_guard<std::mutex> lock(g_red_mutex);
+        std::vector<RedPending> keep;
+        for (const RedPending& p : g_red_pending) (p.s == (hipStream_t)stream ? take : keep).push_back(p);
+        g_red_pending.swap(keep);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t first = 0; first < take.size(); first += RED_TAB) {
+        RedTable t;
+        t.count = (int)(take.size() - first < (size_t)RED_TAB ? take.size() - first : (size_t)RED_TAB);
+        int blk = 0;
+        for (int i = 0; i < t.count; i++) {
+            t.e[i] = take[first + i].e;
+            t.e[i].blk0 = blk;
+            blk += (t.e[i].C + 15) / 16;
+        }
+        hipLaunchKernelGGL(bn_eval_reduce_batch_kernel, dim3(blk), dim3(1024), 0, s, t);
+        BRCNN_LAUNCH_CHECK();
+    }
+    return (int)take.size();
 }

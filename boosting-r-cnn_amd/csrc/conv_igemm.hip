@@ -772,7 +772,7 @@ struct TrainTail {
 };
 
 int brcnn_bn_eval_reduce_launch(const float* partials, int strips, const float* mean, const float* var, float eps,
-                                float* dgamma, float* dbeta, int channels, hipStream_t s);     // bn_act.hip
+                                float* dgamma, float* dbeta, int channels, hipStream_t s, int defer);     // bn_act.hip
 
 static int conv_setup_and_launch(const void* x, const void* w, const float* scale, const float* shift,
                                  const void* residual, void* y, int batch, int num_segments,
@@ -869,14 +869,14 @@ BRCNN_API size_t brcnn_conv2d_dgrad_bn_backward_workspace_bytes(int batch, int i
     return (size_t)((m + 63) / 64) * 2 * (size_t)cin * sizeof(float);
 }
 
-BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc(const void* dy, const void* w_t, const void* z_prev,
+BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc_ex(const void* dy, const void* w_t, const void* z_prev,
                                                   const float* gamma, const float* beta, const float* mean,
                                                   const float* var, float eps, int relu, const void* dskip,
                                                   const void* prev_out, void* dres, void* dz_prev,
                                                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                                   int batch, int in_height, int in_width, int out_height, int out_width,
                                                   int cin, int cout, int kh, int kw, int stride, int pad, int dtype,
-                                                  void* stream) {
+                                                  void* stream, int defer_second_stage) {
     if (!z_prev || !gamma || !beta || !mean || !var || !dz_prev || !dgamma || !dbeta || !workspace ||
         !brcnn_is16(dtype) || brcnn_out_f32(dtype) || pad > kh - 1 || pad > kw - 1 || (cin & 63))
         return BRCNN_EINVAL;
@@ -892,7 +892,21 @@ BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc(const void* dy, const void* w_
                                          kw, 1, kh - 1 - pad, stride, 0, dtype, stream, 0, nullptr, &tail, &tiles_m);
     if (st) return st;
     return brcnn_bn_eval_reduce_launch((const float*)workspace, tiles_m, mean, var, eps, dgamma, dbeta, cin,
-                                       (hipStream_t)stream);
+                                       (hipStream_t)stream, defer_second_stage);
+}
+
+BRCNN_API int brcnn_conv2d_dgrad_bn_backward_nhwc(const void* dy, const void* w_t, const void* z_prev,
+                                                  const float* gamma, const float* beta, const float* mean,
+                                                  const float* var, float eps, int relu, const void* dskip,
+                                                  const void* prev_out, void* dres, void* dz_prev,
+                                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                                  int batch, int in_height, int in_width, int out_height, int out_width,
+                                                  int cin, int cout, int kh, int kw, int stride, int pad, int dtype,
+                                                  void* stream) {
+    return brcnn_conv2d_dgrad_bn_backward_nhwc_ex(dy, w_t, z_prev, gamma, beta, mean, var, eps, relu, dskip, prev_out, dres,
+                                                  dz_prev, dgamma, dbeta, workspace, workspace_bytes, batch, in_height,
+                                                  in_width, out_height, out_width, cin, cout, kh, kw, stride, pad, dtype,
+                                                  stream, 0);
 }
 
 BRCNN_API int brcnn_conv2d_nhwc_scatter2(const void* x, const void* w, void* y, int batch, int height, int width,

@@ -101,6 +101,12 @@ SIGNATURES = {
                                             [c_ptr]),
     'brcnn_bn_eval_act_backward': (c_int, [c_ptr] * 7 + [c_f32] + [c_ptr] * 5 + [ctypes.c_size_t, c_i64, c_int, c_int,
                                                                                 c_int, c_ptr]),
+    'brcnn_conv2d_dgrad_bn_backward_nhwc_ex': (c_int, [c_ptr] * 7 + [c_f32, c_int] + [c_ptr] * 7 + [ctypes.c_size_t] +
+                                               [c_int] * 12 + [c_ptr, c_int]),
+    'brcnn_bn_eval_act_backward_ex': (c_int, [c_ptr] * 7 + [c_f32] + [c_ptr] * 5 + [ctypes.c_size_t, c_i64, c_int, c_int,
+                                                                                   c_int, c_ptr, c_int]),
+    'brcnn_bn_reduce_flush': (c_int, [c_ptr]),
+    'brcnn_bn_reduce_pending': (c_int, []),
     'brcnn_conv2d_nhwc_grouped': (c_int, [c_ptr] * 6 + [c_int] * 12 + [c_ptr]),
     'brcnn_avgpool_nhwc': (c_int, [c_ptr, c_ptr] + [c_int] * 9 + [c_ptr]),
     'brcnn_deform_im2col_nhwc': (c_int, [c_ptr] * 3 + [c_int] * 11 + [c_ptr]),

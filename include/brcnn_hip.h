@@ -518,6 +518,26 @@ int brcnn_bn_eval_act_backward(const void *dout, const void *out, const void *z,
                                const float *beta, const float *mean, const float *var, float eps, void *dz, void *dres,
                                float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
                                int64_t rows, int channels, int relu, int dtype, void *stream);
+/* Deferred second stage.  Both backward entries above end with a small launch that turns the per-strip partial sums
+ * in `workspace` into dgamma / dbeta (16 - 128 workgroups, ~7 us): a backward pass issues ~40 of them, serial on
+ * the launching stream, and nothing reads their results before the optimizer.  With defer_second_stage != 0 the `_ex`
+ * forms record that stage instead (workspace, dgamma, dbeta, mean, var must stay valid until the flush) and
+ * brcnn_bn_reduce_flush(stream) runs everything recorded for `stream` in one launch per 48 layers -- same sums in the
+ * same order, same bits; returns the number of stages it ran, < 0 on error.  brcnn_bn_reduce_pending: recorded, not yet
+ * run (all streams). */
+int brcnn_bn_eval_act_backward_ex(const void *dout, const void *out, const void *z, const float *gamma,
+                                  const float *beta, const float *mean, const float *var, float eps, void *dz, void *dres,
+                                  float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                  int64_t rows, int channels, int relu, int dtype, void *stream, int defer_second_stage);
+int brcnn_conv2d_dgrad_bn_backward_nhwc_ex(const void *dy, const void *w_t, const void *z_prev, const float *gamma,
+                                           const float *beta, const float *mean, const float *var, float eps, int relu,
+                                           const void *dskip, const void *prev_out, void *dres,
+                                           void *dz_prev, float *dgamma, float *dbeta, void *workspace,
+                                           size_t workspace_bytes, int batch, int in_height, int in_width,
+                                           int out_height, int out_width, int cin, int cout, int kh, int kw, int stride,
+                                           int pad, int dtype, void *stream, int defer_second_stage);
+int brcnn_bn_reduce_flush(void *stream);
+int brcnn_bn_reduce_pending(void);
 
 /* Res2Net / DCNv2 rows (the r2_101 recipes): NHWC average pooling with torch.nn.AvgPool2d's
  * window / divisor rules (res2net.py:52-54, 173-178), and mmcv's modulated deformable im2col

@@ -990,3 +990,50 @@ def test_deferred_slab_reduction_equals_the_per_layer_second_stage(et):
     finally:
         L.brcnn_wgrad_defer_begin(h, None, 0, 0)
         L.brcnn_conv_set_tile_wgrad_bf16(0)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_deferred_bn_second_stages_give_the_same_bits(dtype):
+    """round 6: the dgamma / dbeta reductions of a backward pass are recorded and run in ONE launch when the pass ends
+    (`brcnn_bn_reduce_flush`) instead of ~40 small serial launches.  A ResNet stage (fused conv+BN forward, BatchNorm
+    backward inside the data-gradient launches and as its own kernel) gives the same bits either way; the values are
+    there when backward() returns; a parameter that already holds a gradient (accumulation) takes the immediate form."""
+    from brcnn import autograd as A
+    from brcnn import lib as _lib
+    from brcnn.backbones import Bottleneck, ResLayer
+    L = _lib.load()
+    torch.manual_seed(5)
+    layer = ResLayer(Bottleneck, 256, 128, 3, stride=2).to(DEV)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    layer.eval()
+    x = torch.randn(2, 40, 56, 256, device=DEV).to(dtype)
+    go = None
+    got = {}
+    saved = A.BN_REDUCE_DEFER
+    try:
+        for defer in (False, True):
+            A.BN_REDUCE_DEFER = defer
+            layer.zero_grad(set_to_none=True)
+            xd = x.clone().requires_grad_()
+            out = layer.forward_nhwc(xd)
+            if go is None:
+                go = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(dtype)
+            out.backward(go)
+            assert L.brcnn_bn_reduce_pending() == 0 and not A._bn_keep        # flushed by the end-of-pass callback
+            got[defer] = {k: p.grad.clone() for k, p in layer.named_parameters() if 'bn' in k or 'downsample.1' in k}
+            assert len(got[defer]) == 2 * (3 * 3 + 1)
+        for k, g in got[True].items():
+            assert torch.equal(g, got[False][k]), k
+        # accumulation: .grad exists, autograd ADDS the new gradient right away -> the immediate form, twice the values
+        A.BN_REDUCE_DEFER = True
+        xd = x.clone().requires_grad_()
+        layer.forward_nhwc(xd).backward(go)
+        torch.cuda.synchronize()
+        for k, p in layer.named_parameters():
+            if k in got[True]:
+                assert torch.allclose(p.grad, 2 * got[True][k], rtol=1e-6, atol=1e-6), k
+    finally:
+        A.BN_REDUCE_DEFER = saved
