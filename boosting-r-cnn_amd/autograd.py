@@ -194,6 +194,7 @@ def join_side_streams(device=None):
     callback, and a backstop for the readers of .grad (optim.FusedSGD.step, the gradient reducer) in case a
     backward pass raised before its callbacks ran"""
     flush_bn_deferred()
+    release_held_weight_gradients()
     for key, side in list(_side_streams.items()):
         if device is not None and key != (device.type, device.index):
             continue
@@ -204,6 +205,44 @@ def join_side_streams(device=None):
 
 
 _DEFER_JOIN = [False]
+# weight-gradient launches held back until the end of a partial backward pass (held_weight_gradients)
+_HELD_WGRADS = [None]
+
+
+_HELD_PENDING = []      # held launches whose context ended with release=False (release_held_weight_gradients)
+
+
+@contextlib.contextmanager
+def held_weight_gradients(enabled=True, release=True):
+    """weight-gradient launches of the backward passes inside this context are issued on the second stream only when the
+    context ends (`release`) or at the caller's `release_held_weight_gradients()`, behind everything the main stream has
+    queued by then (detectors.py, early_rpn_backward: the four tower launches -- M = 179 200, 250 us each -- otherwise run
+    under the tower's own data-gradient / GroupNorm chain, which is bandwidth-bound and takes twice its stand-alone time
+    beside them).  Not with a gradient reducer attached (it hears about an arena range when its writer is ISSUED)."""
+    if not enabled or _HELD_WGRADS[0] is not None or grad_arena.listener is not None:
+        yield
+        return
+    _HELD_WGRADS[0] = []
+    try:
+        yield
+    finally:
+        held, _HELD_WGRADS[0] = _HELD_WGRADS[0], None
+        _HELD_PENDING.extend(held)
+        if release:
+            release_held_weight_gradients()
+
+
+def release_held_weight_gradients():
+    """issue the launches collected by held_weight_gradients(release=False); also part of every side-stream join"""
+    if not _HELD_PENDING:
+        return
+    held = list(_HELD_PENDING)
+    del _HELD_PENDING[:]
+    main = torch.cuda.current_stream(held[0][2])
+    ev = main.record_event()
+    for side, launch, _ in held:
+        side.wait_event(ev)
+        launch()
 
 
 @contextlib.contextmanager
@@ -229,6 +268,7 @@ def _queue_stream_join(main, side):
     def join():
         _join_queued[key] = False
         _side_seen.pop(key, None)
+        release_held_weight_gradients()
         flush_deferred(side)
         main.wait_stream(side)
     _join_queued[key] = True
@@ -384,12 +424,21 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw, h
             # overlaps the data-gradient chain of the layers above (its atomics tail and the other kernel's
             # LDS-DMA / MFMA phases fill each other's gaps); the streams join at the end of the backward pass
             main = torch.cuda.current_stream(dy.device)
-            side.wait_event(main.record_event())            # dy, x and the zero fill of dW are complete here
-            deferred = x_cat.dtype != torch.float32 and _defer_on(side)
-            st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
-                                                   cin, cout, kh, kw, stride, pad, dt, _L.stream_handle(side))
             dy.record_stream(side)                          # the allocator must not recycle them under the launch
             x_cat.record_stream(side)
+            if _HELD_WGRADS[0] is not None and takes and grad_arena.listener is None:
+                # issued when the enclosing held_weight_gradients() context ends (operands kept alive by the closure)
+                def launch(x_cat=x_cat, dy=dy, dwp=dwp, side=side):
+                    st_ = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
+                                                            cin, cout, kh, kw, stride, pad, dt, _L.stream_handle(side))
+                    _L.check(st_, 'brcnn_conv2d_wgrad_nhwc_multi')
+                _HELD_WGRADS[0].append((side, launch, dy.device))
+                st = 0
+            else:
+                side.wait_event(main.record_event())        # dy, x and the zero fill of dW are complete here
+                deferred = x_cat.dtype != torch.float32 and _defer_on(side)
+                st = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
+                                                       cin, cout, kh, kw, stride, pad, dt, _L.stream_handle(side))
             _queue_stream_join(main, side)
         _L.check(st, 'brcnn_conv2d_wgrad_nhwc_multi')
         # `deferred`: the slab reduction of this launch may be pending (wgrad_defer.hip).  A consumer on the second

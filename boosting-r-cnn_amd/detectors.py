@@ -21,6 +21,9 @@ from .core import bbox2result
 from .profiling import stage_mark
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
+# the RPN tower's weight-gradient launches wait for the end of the early RPN backward pass (autograd.held_weight_gradients)
+HOLD_RPN_WGRAD = __import__('os').environ.get('BRCNN_HOLD_RPN_WGRAD', '1')       # '0' off, '1' until the RPN pass ends, '2' until the box head's forward pass is queued
+
 
 class LazyLogVars(OrderedDict):
     """log_vars of `_parse_losses`: the reference reads every scalar back with `.item()` right after the
@@ -317,7 +320,7 @@ class TwoStageDetector(BaseDetector):
                 params = [p for p in rpn.parameters() if p.requires_grad]
                 leaves = [c for c in cut if c.requires_grad]
                 scale = float(self.early_backward_scale)
-                with _A.deferred_side_stream_join():
+                with _A.deferred_side_stream_join(), _A.held_weight_gradients(HOLD_RPN_WGRAD != '0', HOLD_RPN_WGRAD != '2'):
                     grads = torch.autograd.grad(total * scale if scale != 1.0 else total, leaves + params,
                                                 allow_unused=True)
                 it = iter(grads[:len(leaves)])

@@ -564,6 +564,8 @@ class ProbRoIHead(nn.Module):
         stage_mark('roi_align')
         cls_score, bbox_pred = self.bbox_head.forward_nhwc(roi_feats)
         stage_mark('fc_head')
+        from . import autograd as _A
+        _A.release_held_weight_gradients()       # (held since the early RPN backward pass, if the detector said so)
         h = self.bbox_head
         out3 = train_ops.boost_loss(cls_score, bbox_pred, smp['labels'], smp['priors'], smp['bbox_targets'],
                                     h.num_classes, self.gamma, self.alpha, smp.get('ious'), self.iou_gamma,
