@@ -781,6 +781,46 @@ def g19_coco_pafpn_train():
     npz('g19_coco_pafpn_train', **d)
 
 
+def g23_coco_second_stage_inputs():
+    """what the reference's SECOND stage saw in the g19 run (same model, weights, inputs, seed): the proposals the RPN
+    handed to `ProbRoIHead.forward_train` per image, and what the sampler drew from them (the sampled boxes and their
+    labels, positives first).  Lets a 16-bit run of the second stage be compared on the SAME RoIs -- the
+    proposals a 16-bit trunk produces differ in which boxes survive top-k / NMS, which moved the g19 comparison of the
+    second-stage losses to 10 %."""
+    from mmdet.models import build_detector
+    cfg = Config.fromfile('/root/reference/configs/boosting_rcnn/boosting_rcnn_r50_pafpn_mstrain_2x_coco.py')
+    m = build_detector(cfgdict(copy.deepcopy(cfg.model.to_dict())))
+    m.load_state_dict(util.seeded_state_dict(m, seed=19))
+    img, metas, gts, gls = util.demo_inputs(2, 128, 192, num_classes=80, seed=19)
+    m.train()
+    d = {}
+    head = m.roi_head
+    orig_ft = head.forward_train
+    orig_sample = head.bbox_sampler.sample
+    samples = []
+
+    def ft(x, img_metas, proposal_list, *a, **k):
+        for i, p_ in enumerate(proposal_list):
+            d[f'props{i}'] = p_.detach().clone()
+        return orig_ft(x, img_metas, proposal_list, *a, **k)
+
+    def sample(assign_result, bboxes, gt_bboxes, gt_labels=None, **k):
+        r = orig_sample(assign_result, bboxes, gt_bboxes, gt_labels, **k)
+        samples.append(r)
+        return r
+    head.forward_train = ft
+    head.bbox_sampler.sample = sample
+    torch.manual_seed(79)
+    losses = m.forward_train(img, metas, gts, gls)
+    for i, r in enumerate(samples):
+        d[f'sampled_bboxes{i}'] = r.bboxes
+        d[f'sampled_pos{i}'] = np.int64(r.pos_bboxes.shape[0])
+        d[f'sampled_pos_gt_labels{i}'] = r.pos_gt_labels
+    for k, v in losses.items():
+        d['loss_' + k] = torch.stack(v) if isinstance(v, list) else v
+    npz('g23_coco_second_stage_inputs', **d)
+
+
 def g20_fullsize(cfg):
     """BASELINE configs[1] at FULL size (batch 8, 201 600 anchors / image): the reference's proposal stage
     (top-k anchor indices per level, batched-NMS keep indices, proposals) from seeded head outputs, and its
@@ -924,6 +964,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'coco':
         g19_coco_pafpn_train()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'coco2':
+        g23_coco_second_stage_inputs()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'full':
         g20_fullsize(Config.fromfile(REF_CFG))

@@ -154,6 +154,44 @@ def test_roi_extract_fused_matches_per_level():
     assert (o1.permute(0, 3, 1, 2).cpu() - r1).abs().max().item() <= 1e-5
 
 
+def test_roi_extract_configs1_size_real_proposals_vs_oracle():
+    """BASELINE configs[1] as it is worded (batch 8, 1333 x 800 inputs, inference-only RoIAlign vs CPU): the REFERENCE's own
+    256 proposals per image (g20 `props*`, produced by its RPN on the full-size seeded batch) through the shipped
+    `roi_extract` -- the default footprint form, the one the headline runs -- on a seeded full-size fp32 pyramid, against
+    `map_roi_levels` + the per-level C oracle (mmcv's sample-order RoIAlign).  2048 RoIs, the recipe's five levels, 8 x 100 x 168 ... maps.
+    Level map identical; values within fp32 round-off of a sum of up to ~500 products (2e-6 of the map scale); the exact
+    sample-order form is bit-identical."""
+    from tests.test_host_cpu import load
+    g = load('g20_fullsize')
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    B = 8
+    feats = [_feat(B, 256, h, w, seed=120 + i) for i, (h, w) in enumerate(sizes)]
+    rois = torch.cat([torch.cat([torch.full((256, 1), float(b)), torch.from_numpy(g[f'props{b}'][:, :4]).float()], 1)
+                      for b in range(B)], 0)
+    assert rois.shape == (2048, 5)
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lvls = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=4).long()
+    ref = torch.zeros(2048, 256, 7, 7)
+    for i in range(5):
+        inds = (lvls == i).nonzero(as_tuple=False).squeeze(1)
+        if inds.numel():
+            ref[inds] = orc.roi_align_forward(feats[i], rois[inds], 7, 1. / strides[i], 0, 'avg', True)
+    assert len(set(lvls.tolist())) >= 3             # the reference's proposals spread over the pyramid
+    fg = [f.to(DEV).permute(0, 2, 3, 1).contiguous() for f in feats]
+    out, lv = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+    assert torch.equal(lv.cpu().long(), lvls)
+    err = (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+    assert err <= 2e-6 * max(1.0, ref.abs().max().item()), err
+    from brcnn import lib
+    try:
+        lib.load().brcnn_roi_align_set_exact(1)
+        out_e, _ = ops.roi_extract(fg, rois.to(DEV), 7, strides, 56, 0)
+    finally:
+        lib.load().brcnn_roi_align_set_exact(0)
+    assert torch.equal(out_e.permute(0, 3, 1, 2).cpu().contiguous(), ref)
+
+
 # --------------------------------------------------------------------------- NMS
 def test_nms_known_answer():
     boxes = torch.tensor([[6., 3., 8., 7.], [3., 6., 9., 11.], [3., 7., 10., 12.], [1., 4., 13., 7.]])
