@@ -426,7 +426,8 @@ def _conv_backward(x_cat, weight, w_t_saved, dy, cfg, dskip, need_dx, need_dw, h
             main = torch.cuda.current_stream(dy.device)
             dy.record_stream(side)                          # the allocator must not recycle them under the launch
             x_cat.record_stream(side)
-            if _HELD_WGRADS[0] is not None and takes and grad_arena.listener is None:
+            if _HELD_WGRADS[0] is not None and grad_arena.listener is None and \
+                    (takes or getattr(weight, '_brcnn_dw_consumer_on_side', None) == 'views'):
                 # issued when the enclosing held_weight_gradients() context ends (operands kept alive by the closure)
                 def launch(x_cat=x_cat, dy=dy, dwp=dwp, side=side):
                     st_ = lib.brcnn_conv2d_wgrad_nhwc_multi(_ptr(x_cat), _ptr(dy), _ptr(dwp), batch, L, hs, ws,
@@ -628,6 +629,88 @@ def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad):
     weight, bias, cout = _pad_cout(weight, bias, 32 if x_cat.dtype == torch.float32 else 64)
     y = ConvNHWCFunction.apply(x_cat, weight, bias, batch, tuple(sizes), stride, pad)
     return y if cout == weight.shape[0] else y[:, :cout]
+
+
+class FusedHeadWeights(Function):
+    """Several conv heads that read the same input as ONE conv: the weights (C_i, Cin, KH, KW) and biases (C_i,) of the
+    heads concatenated along the output channels and zero-padded to a multiple of `mult` (the RPN's cls | reg | iou heads:
+    9 + 36 + 9 -> 64 channels).  Forward: two `cat` launches.  Backward: the gradients of the parts are VIEWS of the fused
+    gradient -- no kernel -- so the fused conv's weight-gradient launch may run on the second stream like any other
+    (`_brcnn_dw_consumer_on_side`; with torch.cat in the graph its slicing backward sat on the main stream and kept the
+    launch -- 0.24 ms at 179 200 rows -- on the critical path of the early RPN backward pass).  A part whose parameter is
+    not laid out like the kernel's output gets its copy on the second stream, behind the launch."""
+
+    @staticmethod
+    def forward(ctx, mult, n, *wb):
+        ws, bs = wb[:n], wb[n:]
+        couts = [int(w.shape[0]) for w in ws]
+        total = sum(couts)
+        extra = (-total) % mult
+        parts = list(ws)
+        if extra:
+            parts.append(ws[0].new_zeros((extra,) + tuple(ws[0].shape[1:])))
+        w = torch.cat(parts, 0)
+        b = None
+        if bs and bs[0] is not None:
+            bparts = list(bs) + ([bs[0].new_zeros(extra)] if extra else [])
+            b = torch.cat(bparts, 0)
+        ctx.couts = couts
+        ctx.n = n
+        ctx.w_strides = [tuple(w_.stride()) for w_ in ws]
+        return w, b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gw, gb):
+        outs_w, outs_b, r0 = [], [], 0
+        side = _wgrad_side_stream(gw.device) if (gw is not None and gw.is_cuda) else None
+        copies = []
+        for c, st in zip(ctx.couts, ctx.w_strides):
+            g = gw[r0:r0 + c] if gw is not None else None
+            if g is not None and side is not None and tuple(g.stride()) != st:
+                # autograd would clone this part on the MAIN stream into the parameter's layout, under the launch that is
+                # still writing it on the second stream: make that copy there, behind the launch
+                copies.append(len(outs_w))
+            outs_w.append(g)
+            outs_b.append(gb[r0:r0 + c] if gb is not None else None)
+            r0 += c
+        if copies:
+            main = torch.cuda.current_stream(gw.device)
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                for i in copies:
+                    src = outs_w[i]
+                    dst = torch.empty_strided(src.shape, ctx.w_strides[i], dtype=src.dtype, device=src.device)
+                    dst.copy_(src)
+                    dst.record_stream(main)
+                    outs_w[i] = dst
+            gw.record_stream(side)
+            _queue_stream_join(main, side)
+        return (None, None) + tuple(outs_w) + tuple(outs_b)
+
+
+def fused_head_weights(heads, mult):
+    """(weight, bias) of `heads` (nn.Conv2d modules sharing input and geometry) fused along the output channels, padded
+    to a multiple of `mult`, differentiable; feed to ConvNHWCFunction"""
+    ws = [h.weight for h in heads]
+    bs = [h.bias for h in heads]
+    w, b = FusedHeadWeights.apply(mult, len(ws), *(ws + bs))
+    if w.requires_grad and _wgrad_side_stream(w.device) is not None and not _HELD_COPIES_UNSAFE(ws, w):
+        w._brcnn_dw_consumer_on_side = 'views'        # (no kernel of the consumer reads dW: the launch may also be HELD)
+    elif w.requires_grad and _wgrad_side_stream(w.device) is not None:
+        w._brcnn_dw_consumer_on_side = True
+    return w, b
+
+
+def _HELD_COPIES_UNSAFE(ws, w):
+    """a part that needs a layout copy behind the launch (its parameter is not stored in the kernel's (Cout, KH, KW, Cin)
+    order, i.e. not channels-last): the copy is queued when the backward node runs, so the launch must not be held back
+    past it (held_weight_gradients)"""
+    for p in ws:
+        _, cin, kh, kw = p.shape
+        if tuple(p.stride()) != (kh * kw * cin, 1, kw * cin, cin):
+            return True
+    return False
 
 
 FC0_ON_SIDE = _os.environ.get('BRCNN_FC0_SIDE', '1') != '0'      # A/B switch of PermutedWeightFunction

@@ -1226,7 +1226,7 @@ static bool pp128_ok(const ConvParams& p) {
     return !(p.gstep || (p.Cout % 128) || p.K < 192 || (p.K % 64) || p.KH * p.KW > 32 || p.scatter || (p.tail_z && p.tail_mask));
 }
 static bool pp128_wins(const ConvParams& p) {
-    if (g_pp128_mode == 0 || !pp128_ok(p) || p.K < g_pp128_min_k) return false;
+    if (g_pp128_mode == 0 || !pp128_ok(p) || p.K < g_pp128_min_k || p.KH * p.KW < 9) return false;     // (measured on 3x3 layers only)
     const long long tm = (p.M + 255) / 256;
     if ((p.Cout % 256) == 0 && tm * (p.Cout / 256) >= g_pp128_max_t88) return false;
     const long long t84 = tm * (p.Cout / 128);

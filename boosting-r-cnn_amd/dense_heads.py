@@ -512,7 +512,7 @@ class ATSSRPNHead(AnchorHead):
         """training forward of tower + heads over all levels (one launch per layer); returns the fused
         head output y (rows, Cpad) fp32 [cls A | reg 4A (raw, before Scale) | iou A | zero padding],
         level-major rows, differentiable"""
-        from .autograd import ConvNHWCFunction, GroupNormNHWCFunction, _pad_cout, conv2d_nhwc_multi_autograd
+        from .autograd import ConvNHWCFunction, GroupNormNHWCFunction, conv2d_nhwc_multi_autograd, fused_head_weights
         B = feats[0].shape[0]
         sizes = tuple(tuple(int(v) for v in f.shape[1:3]) for f in feats)
         x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
@@ -521,8 +521,9 @@ class ATSSRPNHead(AnchorHead):
             x = GroupNormNHWCFunction.apply(x, conv.norm.weight, conv.norm.bias, conv.norm.num_groups, B, sizes,
                                             conv.norm.eps, conv.with_activation)
         heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
-        w, b, _ = _pad_cout(torch.cat([h.weight for h in heads], 0), torch.cat([h.bias for h in heads], 0),
-                            32 if x.dtype == torch.float32 else 64)
+        # (one differentiable node for cat + pad whose backward hands out views: the fused head's weight-gradient launch
+        # leaves the main stream like the others)
+        w, b = fused_head_weights(heads, 32 if x.dtype == torch.float32 else 64)
         y = ConvNHWCFunction.apply(x, w, b, B, sizes, 1, self.rpn_cls.padding[0])
         return y.float(), sizes
 
