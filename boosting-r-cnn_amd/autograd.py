@@ -631,6 +631,51 @@ def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad):
     return y if cout == weight.shape[0] else y[:, :cout]
 
 
+class CatRowsAliased(Function):
+    """`torch.cat([f.reshape(-1, C) for f in feats], 0)` for maps that already LIE back to back in one buffer (the neck
+    wrote them there: ops.output_into): the result is a view of that memory, no launch; backward hands each map its rows
+    of the gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        f0 = feats[0]
+        c = f0.shape[-1]
+        rows = [f.numel() // c for f in feats]
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.rows = rows
+        out = f0.new_empty(0).set_(f0.untyped_storage(), f0.storage_offset(), (sum(rows), c), (c, 1))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        outs, r0 = [], 0
+        for shp, n in zip(ctx.shapes, ctx.rows):
+            outs.append(g[r0:r0 + n].view(shp))
+            r0 += n
+        return tuple(outs)
+
+
+def cat_rows(feats):
+    """(sum rows, C) of NHWC maps, level-major: a view when the maps are adjacent slices of one buffer, else a cat"""
+    f0 = feats[0]
+    c = f0.shape[-1]
+    adjacent = f0.is_cuda and all(f.is_contiguous() and f.dtype == f0.dtype and f.shape[-1] == c for f in feats)
+    if adjacent:
+        base, off = f0.untyped_storage().data_ptr(), f0.storage_offset()
+        for f in feats:
+            if f.untyped_storage().data_ptr() != base or f.storage_offset() != off:
+                adjacent = False
+                break
+            off += f.numel()
+    if not adjacent or len(feats) == 1:
+        return torch.cat([f.reshape(-1, c) for f in feats], 0)
+    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        return CatRowsAliased.apply(*feats)
+    rows = sum(f.numel() // c for f in feats)
+    return f0.new_empty(0).set_(f0.untyped_storage(), f0.storage_offset(), (rows, c), (c, 1))
+
+
 class FusedHeadWeights(Function):
     """Several conv heads that read the same input as ONE conv: the weights (C_i, Cin, KH, KW) and biases (C_i,) of the
     heads concatenated along the output channels and zero-padded to a multiple of `mult` (the RPN's cls | reg | iou heads:
@@ -695,6 +740,8 @@ def fused_head_weights(heads, mult):
     ws = [h.weight for h in heads]
     bs = [h.bias for h in heads]
     w, b = FusedHeadWeights.apply(mult, len(ws), *(ws + bs))
+    if not w.is_cuda:
+        return w, b
     if w.requires_grad and _wgrad_side_stream(w.device) is not None and not _HELD_COPIES_UNSAFE(ws, w):
         w._brcnn_dw_consumer_on_side = 'views'        # (no kernel of the consumer reads dW: the launch may also be HELD)
     elif w.requires_grad and _wgrad_side_stream(w.device) is not None:
@@ -707,8 +754,12 @@ def _HELD_COPIES_UNSAFE(ws, w):
     order, i.e. not channels-last): the copy is queued when the backward node runs, so the launch must not be held back
     past it (held_weight_gradients)"""
     for p in ws:
+        if p.dim() == 2:            # (linear weights: dW rows are the parameter's rows)
+            if not p.is_contiguous():
+                return True
+            continue
         _, cin, kh, kw = p.shape
-        if tuple(p.stride()) != (kh * kw * cin, 1, kw * cin, cin):
+        if tuple(p.stride()) != (kh * kw * cin, 1, kw * cin, cin) and not (kh == 1 and kw == 1 and p.is_contiguous()):
             return True
     return False
 

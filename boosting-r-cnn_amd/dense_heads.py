@@ -28,6 +28,12 @@ from .registry import (HEADS, build_anchor_generator, build_assigner, build_bbox
 EPS = 1e-12
 
 
+def cat_rows(feats):
+    """the pyramid levels as one (rows, C) tensor, level-major: a view when the neck wrote them back to back"""
+    from .autograd import cat_rows as _cr
+    return _cr(list(feats))
+
+
 def reduce_mean(tensor):
     """mean over ranks (mmdet/core/utils/dist_utils.py:67-73); identity when not distributed"""
     if not (dist.is_available() and dist.is_initialized()):
@@ -232,7 +238,7 @@ class ATSSRPNHead(AnchorHead):
         from .autograd import GroupNormNHWCFunction, conv2d_nhwc_multi_autograd
         B = feats[0].shape[0]
         sizes = tuple(tuple(f.shape[1:3]) for f in feats)
-        x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
+        x = cat_rows(feats)        # (a view when the neck wrote the levels back to back: ops.output_into)
         for conv in self.rpn_convs:
             x = conv2d_nhwc_multi_autograd(x, conv.conv.weight, None, B, sizes, 1, conv.conv.padding[0])
             x = GroupNormNHWCFunction.apply(x, conv.norm.weight, conv.norm.bias, conv.norm.num_groups, B, sizes,
@@ -260,7 +266,7 @@ class ATSSRPNHead(AnchorHead):
         the consumer (`scale(self.rpn_reg(x))` == raw * scale)."""
         B = feats[0].shape[0]
         sizes = [tuple(f.shape[1:3]) for f in feats]
-        x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
+        x = cat_rows(feats)        # (a view when the neck wrote the levels back to back: ops.output_into)
         for i, conv in enumerate(self.rpn_convs):
             assert isinstance(conv.norm, nn.GroupNorm) and conv.conv.bias is None
             w = self._tower_caches[i].get([conv.conv.weight],
@@ -515,7 +521,7 @@ class ATSSRPNHead(AnchorHead):
         from .autograd import ConvNHWCFunction, GroupNormNHWCFunction, conv2d_nhwc_multi_autograd, fused_head_weights
         B = feats[0].shape[0]
         sizes = tuple(tuple(int(v) for v in f.shape[1:3]) for f in feats)
-        x = torch.cat([f.reshape(-1, f.shape[3]) for f in feats], 0)
+        x = cat_rows(feats)        # (a view when the neck wrote the levels back to back: ops.output_into)
         for conv in self.rpn_convs:
             x = conv2d_nhwc_multi_autograd(x, conv.conv.weight, None, B, sizes, 1, conv.conv.padding[0])
             x = GroupNormNHWCFunction.apply(x, conv.norm.weight, conv.norm.bias, conv.norm.num_groups, B, sizes,

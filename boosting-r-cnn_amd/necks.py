@@ -90,6 +90,36 @@ class FPN(nn.Module):
                 2 * c.padding[0] == c.kernel_size[0] - 1 and c.dilation == (1, 1) and
                 (conv_module.norm is None or isinstance(conv_module.norm, nn.BatchNorm2d)))
 
+    # ---- the output levels back to back in one buffer (what the RPN's multi-level launches read) --------------------
+    SHARED_OUTPUT_BUFFER = __import__('os').environ.get('BRCNN_PYRAMID_BUFFER', '1') != '0'       # (A/B switch)
+
+    def _out_views(self, laterals):
+        """per output level a (rows, C) slice of ONE buffer, or None: the convs that produce the levels write there
+        (ops.output_into), so `autograd.cat_rows` needs no copy"""
+        import torch
+        if not (self.SHARED_OUTPUT_BUFFER and laterals[0].is_cuda) or self.num_outs < len(laterals) or \
+                (self.num_outs > len(laterals) and not self.add_extra_convs):
+            return [None] * self.num_outs
+        b = laterals[0].shape[0]
+        hw = [tuple(l.shape[1:3]) for l in laterals]
+        for i in range(len(laterals), self.num_outs):          # the extra levels: 3x3 stride-2 convs
+            h, w = hw[-1]
+            hw.append(ops.conv_out_size(h, w, 3, 3, 2, 1))
+        rows = [b * h * w for h, w in hw]
+        buf = torch.empty((sum(rows), self.out_channels), dtype=laterals[0].dtype, device=laterals[0].device)
+        views, r0 = [], 0
+        for n in rows:
+            views.append(buf[r0:r0 + n])
+            r0 += n
+        return views
+
+    @staticmethod
+    def _into(view, fn):
+        if view is None:
+            return fn()
+        with ops.output_into(view):
+            return fn()
+
     def lateral_tap(self, k, x):
         """the backbone's `tap` (ResNet._stages): output stage k's result x -> what the backbone continues with.  Runs
         the lateral conv of that level now, keeps its result for `_laterals`, returns the alias of x."""
@@ -107,16 +137,17 @@ class FPN(nn.Module):
                     for i, conv in enumerate(self.lateral_convs)]
         return laterals
 
-    def _top_down(self, laterals, convs):
+    def _top_down(self, laterals, convs, views=None):
         """laterals[i-1] += upsample(laterals[i]) from the top, and outs[i] = convs[i](laterals[i]) as soon as level i
         is final (the reference runs all the adds first and the convs afterwards: same values)"""
         outs = [None] * len(laterals)
         for i in range(len(laterals) - 1, -1, -1):
             src = laterals[i]
+            v = views[i] if views is not None else None
             if i > 0 and self._skip_ok(convs[i], laterals[i]):
-                outs[i], src = convs[i].forward_nhwc(laterals[i], with_skip=True)
+                outs[i], src = self._into(v, lambda: convs[i].forward_nhwc(laterals[i], with_skip=True))
             else:
-                outs[i] = convs[i].forward_nhwc(laterals[i])
+                outs[i] = self._into(v, lambda: convs[i].forward_nhwc(laterals[i]))
             if i == 0:
                 break
             if src.requires_grad or laterals[i - 1].requires_grad:
@@ -131,7 +162,7 @@ class FPN(nn.Module):
                 ops.upsample_nearest_add_nhwc_(laterals[i - 1], src)
         return outs
 
-    def _extra(self, inputs, laterals, outs):
+    def _extra(self, inputs, laterals, outs, views=None):
         used = len(laterals)
         if self.num_outs > len(outs):
             if not self.add_extra_convs:
@@ -144,16 +175,18 @@ class FPN(nn.Module):
                     src = laterals[-1]
                 else:
                     src = outs[-1]
-                outs.append(self.fpn_convs[used].forward_nhwc(src))
+                vw = views if views is not None else [None] * self.num_outs
+                outs.append(self._into(vw[used], lambda: self.fpn_convs[used].forward_nhwc(src)))
                 for i in range(used + 1, self.num_outs):
                     x = outs[-1].relu() if self.relu_before_extra_convs else outs[-1]
-                    outs.append(self.fpn_convs[i].forward_nhwc(x))
+                    outs.append(self._into(vw[i], lambda: self.fpn_convs[i].forward_nhwc(x)))
         return outs
 
     def forward_nhwc(self, inputs):
         laterals = self._laterals(inputs)
-        outs = self._top_down(laterals, self.fpn_convs)
-        return tuple(self._extra(inputs, laterals, outs))
+        views = self._out_views(laterals)
+        outs = self._top_down(laterals, self.fpn_convs, views)
+        return tuple(self._extra(inputs, laterals, outs, views))
 
     def forward(self, inputs):
         return tuple(to_nchw_view(o) for o in self.forward_nhwc([to_nhwc(x) for x in inputs]))
@@ -183,15 +216,18 @@ class PAFPN(FPN):
     def forward_nhwc(self, inputs):
         laterals = self._laterals(inputs)
         used = len(laterals)
-        inter = self._top_down(laterals, self.fpn_convs)
+        views = self._out_views(laterals)
+        # (level 0 leaves the top-down path as it is: its conv writes into the shared buffer; the others go there from
+        # their pafpn conv)
+        inter = self._top_down(laterals, self.fpn_convs, [views[0]] + [None] * (used - 1))
         outs = [inter[0]] + [None] * (used - 1)
         for i in range(used):
             src = inter[i]
             if i >= 1:      # level i is final: its output conv runs now, handing out the alias the next downsample conv reads
                 if i < used - 1 and self._skip_ok(self.pafpn_convs[i - 1], inter[i]):
-                    outs[i], src = self.pafpn_convs[i - 1].forward_nhwc(inter[i], with_skip=True)
+                    outs[i], src = self._into(views[i], lambda: self.pafpn_convs[i - 1].forward_nhwc(inter[i], with_skip=True))
                 else:
-                    outs[i] = self.pafpn_convs[i - 1].forward_nhwc(inter[i])
+                    outs[i] = self._into(views[i], lambda: self.pafpn_convs[i - 1].forward_nhwc(inter[i]))
             if i == used - 1:
                 break
             d = self.downsample_convs[i]
@@ -199,4 +235,4 @@ class PAFPN(FPN):
                 inter[i + 1] = inter[i + 1] + d.forward_nhwc(src)
             else:   # inter[i+1] += conv(inter[i]) as the conv epilogue's residual operand
                 inter[i + 1] = d.forward_nhwc(src, residual=inter[i + 1])
-        return tuple(self._extra(inputs, laterals, outs))
+        return tuple(self._extra(inputs, laterals, outs, views))

@@ -226,10 +226,13 @@ class ProbConvFCBBoxHead(nn.Module):
                 if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable (its gradient's way back on the second stream)
                     w = permuted_fc_weight(w, c, ph, pw, x.dtype)
                 x = linear_autograd(x, w, fc.bias).relu()
-            y = linear_autograd(x, torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0),
-                                torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)).float()
-            nc = self.fc_cls.out_features
-            return y[:, :nc], y[:, nc:]
+            # fc_cls | fc_reg as one GEMM through one autograd node (cat + pad; its backward hands out views of dW, so the
+            # weight-gradient launch leaves the main stream: autograd.FusedHeadWeights)
+            from .autograd import fused_head_weights
+            w, b = fused_head_weights((self.fc_cls, self.fc_reg), 32 if x.dtype == torch.float32 else 64)
+            y = linear_autograd(x, w, b).float()
+            nc, nr = self.fc_cls.out_features, self.fc_reg.out_features
+            return y[:, :nc], y[:, nc:nc + nr]
         for i, fc in enumerate(self.shared_fcs):
             if i == 0:
                 def builder(fc=fc):   # (out, C*ph*pw) columns -> (ph,pw,C) order
