@@ -35,7 +35,7 @@ template <int ET> __device__ __forceinline__ unsigned pk2e(float lo, float hi) {
 
 // WM x 2 waves, each MT x NT MFMA tiles: block tile (32*MT*WM) x (64*NT).  WM = 2: 4 waves,
 // two workgroups per CU; WM = 4: 8 waves, 256-row tiles -- 1.5x the FLOPs per staged byte of the
-// 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs (DESIGN 4.4).
+// 128x128 tile, which is what the 64 B/clk/CU LDS-DMA path needs (DESIGN.md 4.1).
 // SK: chained stream-K schedule (ConvParams::sk_*): the workgroup's item (tile, K range, hand-over slot) comes from
 // the launch's item table.
 template <int MT, int NT, bool RES, bool OUTF32, int WM, int WNW = 2, int ST = 2, int ET = 0, int MODE = 0, bool SK = false>

@@ -5,7 +5,7 @@
 // unsplit chain -- so every output is bit-identical to the other tile shapes); what differs is the schedule inside
 // the workgroup.  The two-buffer kernel runs {stage next K tile, read fragments, MFMA, vmcnt(0), barrier} per K tile:
 // every wave is in the same phase, so the matrix pipes idle while fragments are read and the LDS idles during the
-// MFMAs (no unit saturated, phases do not overlap).  Here
+// MFMAs (profiles/design_history_r01_r05.md 4.4: no unit saturated, phases do not overlap).  Here
 //   * 8 waves = 2 groups (rows 0-127 / 128-255 of the tile) x 4 column strips; a wave owns 128 x 64 outputs
 //     (4 x 2 MFMA tiles, 128 accumulator registers);
 //   * a K tile is four phases, one 64 x 32 quadrant of the wave's outputs each (8 MFMAs = 256 matrix-pipe cycles);
