@@ -91,22 +91,20 @@ class CustomDataset(Dataset):
 
     def __init__(self, ann_file, pipeline, classes=None, data_root=None, img_prefix='', seg_prefix=None,
                  proposal_file=None, test_mode=False, filter_empty_gt=True):
-        self.ann_file = ann_file
-        self.data_root = data_root
-        self.img_prefix = img_prefix
-        self.test_mode = test_mode
-        self.filter_empty_gt = filter_empty_gt
+        def under_root(path):           # relative paths are taken below data_root (custom.py:78-88)
+            if data_root is None or path is None or osp.isabs(path):
+                return path
+            return osp.join(data_root, path)
+        self.data_root, self.test_mode, self.filter_empty_gt = data_root, test_mode, filter_empty_gt
+        self.ann_file, self.img_prefix = under_root(ann_file), under_root(img_prefix)
         self.CLASSES = self.get_classes(classes)
-        if self.data_root is not None:
-            if not osp.isabs(self.ann_file):
-                self.ann_file = osp.join(self.data_root, self.ann_file)
-            if not (self.img_prefix is None or osp.isabs(self.img_prefix)):
-                self.img_prefix = osp.join(self.data_root, self.img_prefix)
-        self.data_infos = self.load_annotations(self.ann_file)
         self.proposals = None
-        if not test_mode:
-            valid_inds = self._filter_imgs()
-            self.data_infos = [self.data_infos[i] for i in valid_inds]
+        infos = self.load_annotations(self.ann_file)
+        if test_mode:
+            self.data_infos = infos
+        else:                           # training: drop what _filter_imgs rejects, then the aspect-ratio groups
+            self.data_infos = infos
+            self.data_infos = [infos[i] for i in self._filter_imgs()]
             self._set_group_flag()
         self.pipeline = Compose(pipeline)
 
@@ -115,13 +113,14 @@ class CustomDataset(Dataset):
 
     @classmethod
     def get_classes(cls, classes=None):
+        """custom.py:171-200: None -> the dataset's own names, a path -> one name per non-empty line, a sequence as it is"""
         if classes is None:
             return cls.CLASSES
-        if isinstance(classes, str):
-            with open(classes) as f:
-                return [ln.strip() for ln in f if ln.strip()]
         if isinstance(classes, (tuple, list)):
             return classes
+        if isinstance(classes, str):
+            with open(classes) as f:
+                return [name for name in (line.strip() for line in f) if name]
         raise ValueError(f'Unsupported type {type(classes)} of classes.')
 
     def pre_pipeline(self, results):

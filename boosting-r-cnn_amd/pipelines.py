@@ -498,32 +498,32 @@ class RandomCrop:
         self.bbox2label = {'gt_bboxes': 'gt_labels', 'gt_bboxes_ignore': 'gt_labels_ignore'}
 
     def _crop_data(self, results, crop_size, allow_negative_crop):
-        assert crop_size[0] > 0 and crop_size[1] > 0
-        for key in results.get('img_fields', ['img']):
-            img = results[key]
-            margin_h = max(img.shape[0] - crop_size[0], 0)
-            margin_w = max(img.shape[1] - crop_size[1], 0)
-            offset_h = np.random.randint(0, margin_h + 1)
-            offset_w = np.random.randint(0, margin_w + 1)
-            crop_y1, crop_y2 = offset_h, offset_h + crop_size[0]
-            crop_x1, crop_x2 = offset_w, offset_w + crop_size[1]
-            img = img[crop_y1:crop_y2, crop_x1:crop_x2, ...]
-            img_shape = img.shape
-            results[key] = img
-        results['img_shape'] = img_shape
-        for key in results.get('bbox_fields', []):
-            bbox_offset = np.array([offset_w, offset_h, offset_w, offset_h], dtype=np.float32)
-            bboxes = results[key] - bbox_offset
+        """transforms.py:720-781.  One window per image field (two draws each, rows first: the reference's RNG order); the
+        boxes move with the LAST window drawn, are clipped to it, and empty ones leave together with their labels."""
+        ch, cw = crop_size
+        assert ch > 0 and cw > 0
+        top = left = 0
+        shape = None
+        for field in results.get('img_fields', ['img']):
+            src = results[field]
+            top = np.random.randint(0, max(src.shape[0] - ch, 0) + 1)
+            left = np.random.randint(0, max(src.shape[1] - cw, 0) + 1)
+            window = src[top:top + ch, left:left + cw, ...]
+            results[field], shape = window, window.shape
+        results['img_shape'] = shape
+        shift = np.array([left, top, left, top], dtype=np.float32)
+        for field in results.get('bbox_fields', []):
+            moved = results[field] - shift
             if self.bbox_clip_border:
-                bboxes[:, 0::2] = np.clip(bboxes[:, 0::2], 0, img_shape[1])
-                bboxes[:, 1::2] = np.clip(bboxes[:, 1::2], 0, img_shape[0])
-            valid_inds = (bboxes[:, 2] > bboxes[:, 0]) & (bboxes[:, 3] > bboxes[:, 1])
-            if key == 'gt_bboxes' and not valid_inds.any() and not allow_negative_crop:
-                return None
-            results[key] = bboxes[valid_inds, :]
-            label_key = self.bbox2label.get(key)
-            if label_key in results:
-                results[label_key] = results[label_key][valid_inds]
+                moved[:, 0::2] = moved[:, 0::2].clip(0, shape[1])
+                moved[:, 1::2] = moved[:, 1::2].clip(0, shape[0])
+            keep = (moved[:, 2] > moved[:, 0]) & (moved[:, 3] > moved[:, 1])
+            if field == 'gt_bboxes' and not (allow_negative_crop or keep.any()):
+                return None                      # every ground truth fell outside: the caller draws again
+            results[field] = moved[keep]
+            labels = self.bbox2label.get(field)
+            if labels in results:
+                results[labels] = results[labels][keep]
         return results
 
     def _get_crop_size(self, image_size):
