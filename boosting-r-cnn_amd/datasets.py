@@ -99,12 +99,9 @@ class CustomDataset(Dataset):
         self.ann_file, self.img_prefix = under_root(ann_file), under_root(img_prefix)
         self.CLASSES = self.get_classes(classes)
         self.proposals = None
-        infos = self.load_annotations(self.ann_file)
-        if test_mode:
-            self.data_infos = infos
-        else:                           # training: drop what _filter_imgs rejects, then the aspect-ratio groups
-            self.data_infos = infos
-            self.data_infos = [infos[i] for i in self._filter_imgs()]
+        self.data_infos = self.load_annotations(self.ann_file)
+        if not test_mode:               # training: drop what _filter_imgs rejects, then the aspect-ratio groups
+            self.data_infos = [self.data_infos[i] for i in self._filter_imgs()]
             self._set_group_flag()
         self.pipeline = Compose(pipeline)
 
