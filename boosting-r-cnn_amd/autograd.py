@@ -872,7 +872,7 @@ class RoIExtractFunction(Function):
             g = grad_out.to(fdt).contiguous()
             grads = [torch.empty(s, dtype=fdt, device=grad_out.device) for s in shapes]
             ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads])
-            nb = lib.brcnn_roi_extract_backward_workspace_bytes(rois.size(0))
+            nb = lib.brcnn_roi_extract_backward_workspace_bytes_ex(rois.size(0), shapes[0][0], shapes[0][3], L, hs, ws)
             wsp = torch.empty((nb + 3) // 4, dtype=torch.int32, device=grad_out.device)
             adds = ctx.addends
             ctx.addends = None

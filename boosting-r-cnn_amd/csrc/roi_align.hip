@@ -1093,7 +1093,21 @@ struct GatherLevels {
     int num_levels, batch;
     int tiles_x[BRCNN_MAX_LEVELS], tiles_y[BRCNN_MAX_LEVELS];
     int blk0[BRCNN_MAX_LEVELS + 1];
+    // hit chunks (round 6).  A tile of a COARSE level is touched by most RoIs of that level (level 3 at 800 x 1344: six
+    // tiles per image, ~2/3 of the level's RoIs each): its hits are a serial chain of ~6 us each in one workgroup, and the
+    // longest chain IS the launch (512 RoIs / image of 450-800 px: 2.0 ms; of 16-110 px: 0.22 ms).  Levels with at most
+    // GT_CHUNK_TILES tiles per image get `chunks[l]` workgroups per tile; workgroup c takes the tile's hits c, c + chunks,
+    // ... (in RoI order) and leaves an fp32 partial; roi_grad_chunk_sum_kernel adds the partials in chunk order: a fixed
+    // association, so the result is reproducible (not the one-workgroup chain's bits).
+    // A tile with at most GT_DIRECT_HITS hits is finished by its chunk-0 workgroup alone (every chunk workgroup scans the
+    // same records and sees the same count, so the decision needs no communication): no partials, the other chunks exit.
+    int chunks[BRCNN_MAX_LEVELS];
+    int ptile0[BRCNN_MAX_LEVELS + 1];       // first partial-tile index of the level's tiles (chunked levels only)
+    float* partial;                         // [partial tile][chunk][64 pixels][channels] fp32
+    int* direct;                            // [partial tile]: 1 = written by chunk 0 itself (zeroed before the launch)
 };
+constexpr int GT_CHUNK_TILES = 32;
+constexpr int GT_DIRECT_HITS = 12;
 
 __global__ __launch_bounds__(256) void roi_record_kernel(const float* __restrict__ rois, int n_rois, LevelTable lv, int batch,
                                                         int ph_n, int pw_n, int sampling_ratio, RoiRec* __restrict__ recs,
@@ -1163,6 +1177,10 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
         if (i < gl.num_levels && (int)blockIdx.x >= gl.blk0[i]) l = i;
     const int H = lv.height[l], W = lv.width[l];
     int t = blockIdx.x - gl.blk0[l];
+    const int nchunk = gl.chunks[l];
+    const int chunk = t % nchunk;           // (the chunk workgroups of a tile are neighbours)
+    t /= nchunk;
+    const int tile_lin = t;                 // tile index inside the level (image-major)
     const int per_img = gl.tiles_x[l] * gl.tiles_y[l];
     const int b = t / per_img;
     t -= b * per_img;
@@ -1182,6 +1200,12 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
         for (int p = 0; p < 16; p++) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         // (the records of this image only: same hits in the same order as a scan over all records)
         const int r_lo = ranges ? max(ranges[b], 0) : 0, r_hi = ranges ? min(ranges[1024 + b], n_rois) : n_rois;
+        int hit0 = 0;                       // index (over the whole scan) of the first hit of the running batch
+        bool direct = false;
+        if (nchunk > 1 && r_lo >= r_hi) {   // no RoI of this image at all: chunk 0 writes the zeros (+ addend)
+            if (chunk != 0) return;
+            direct = true;
+        }
         for (int base = r_lo; base < r_hi; ) {
             // ---- collect up to MAXHIT RoIs (in index order) that touch this tile
             if (tid == 0) s_nhit = 0;
@@ -1212,9 +1236,14 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                 __syncthreads();
             }
             const int nhit = s_nhit;
+            if (nchunk > 1 && base == r_lo) {       // first batch: does it hold every hit of the tile, and few enough?
+                direct = scanned >= r_hi && nhit <= GT_DIRECT_HITS;
+                if (direct && chunk != 0) return;   // (workgroup-uniform: nothing was written, no barrier is pending)
+            }
             base = scanned;
             // ---- accumulate the hits into the wave's 16 pixels
             for (int hi = 0; hi < nhit; hi++) {
+                if (nchunk > 1 && !direct && (hit0 + hi) % nchunk != chunk) continue;       // (workgroup-uniform)
                 const int k = s_hits[hi];
                 const float* roi = rois + (size_t)k * 5;
                 const RoiGeom g = roi_geom(roi, scale, 1, ph_n, pw_n, sampling_ratio);
@@ -1254,36 +1283,63 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                     const float wy0 = s_wy[wave][0][ph], wy1 = s_wy[wave][1][ph], wy2 = s_wy[wave][2][ph], wy3 = s_wy[wave][3][ph];
                     if (wy0 == 0.f && wy1 == 0.f && wy2 == 0.f && wy3 == 0.f) continue;
                     const float wys[4] = {wy0, wy1, wy2, wy3};
-                    // the dY rows of up to four bins of this bin row are loaded together (one latency per batch instead
-                    // of one per bin), then accumulated in bin order -- the summation order is unchanged
-                    for (int pw0 = __ffs((int)pwm) - 1; pw0 < pw_n && (pwm >> pw0); pw0 += 4) {
-                        float4 gv[4];
+                    // the dY rows of ALL bins of this bin row are requested together, unconditionally and in straight-line
+                    // code (round 6: seven loads in flight per wave instead of four behind a branch each -- a quadrant of a
+                    // small RoI needs all 49 bins, and the chain of load batches is what a (tile, hit) pair costs), then
+                    // accumulated in bin order where the x weights are not all zero: the summation order is unchanged
+                    float4 gv[7];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (((pwm >> (pw0 + j)) & 1u) && c_ok) gv[j] = ld4(go + (size_t)(ph * pw_n + pw0 + j) * channels);
-                        }
+                    for (int j = 0; j < 7; j++) {
+                        const int pwj = j < pw_n ? j : pw_n - 1;
+                        gv[j] = c_ok ? ld4(go + (size_t)(ph * pw_n + pwj) * channels) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    // separable accumulation (round 6: the gather was VALU-bound -- 16 pixels x 7 bins x 4 channels of
+                    // multiply-adds per bin row and lane, 560 VALU operations, most of them on zero weights):
+                    //   t[q]  = sum_pw Wx[q][pw] * dY[ph][pw]       (the wave's four columns: 4 x 7 x 4 FMAs)
+                    //   acc[r][q] += Wy[r][ph] * t[q]                (16 x 4 FMAs)
+                    // -- the products Wy Wx dY summed over pw first, then over ph: the same terms in another association
+                    // (fp32 round-off against the one-product-per-term form; the tests compare with the C oracle at 1e-5)
+                    float4 tq[4];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (!((pwm >> (pw0 + j)) & 1u)) continue;
-                            const int pw = pw0 + j;
-                            const float wxs[4] = {s_wx[wave][0][pw], s_wx[wave][1][pw], s_wx[wave][2][pw], s_wx[wave][3][pw]};
+                    for (int q = 0; q < 4; q++) tq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                            for (int r = 0; r < 4; r++)
+                    for (int j = 0; j < 7; j++) {
+                        if (!((pwm >> j) & 1u)) continue;
 #pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    const float w = wys[r] * wxs[q];
-                                    acc[r * 4 + q].x += w * gv[j].x;
-                                    acc[r * 4 + q].y += w * gv[j].y;
-                                    acc[r * 4 + q].z += w * gv[j].z;
-                                    acc[r * 4 + q].w += w * gv[j].w;
-                                }
+                        for (int q = 0; q < 4; q++) {
+                            const float wx = s_wx[wave][q][j];
+                            tq[q].x += wx * gv[j].x;
+                            tq[q].y += wx * gv[j].y;
+                            tq[q].z += wx * gv[j].z;
+                            tq[q].w += wx * gv[j].w;
                         }
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            acc[r * 4 + q].x += wys[r] * tq[q].x;
+                            acc[r * 4 + q].y += wys[r] * tq[q].y;
+                            acc[r * 4 + q].z += wys[r] * tq[q].z;
+                            acc[r * 4 + q].w += wys[r] * tq[q].w;
+                        }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            hit0 += nhit;
             __syncthreads();
+        }
+        if (nchunk > 1 && direct && tid == 0 && cbase == 0) gl.direct[gl.ptile0[l] + tile_lin] = 1;
+        if (nchunk > 1 && !direct) {
+            if (c_ok) {
+                float* pt = gl.partial + (((size_t)(gl.ptile0[l] + tile_lin) * nchunk + chunk) * 64) * channels + c;
+#pragma unroll
+                for (int p = 0; p < 16; p++) {
+                    const int pix = (4 * (wave >> 1) + (p >> 2)) * GT_TILE + 4 * (wave & 1) + (p & 3);
+                    *reinterpret_cast<float4*>(pt + (size_t)pix * channels) = acc[p];
+                }
+            }
+            continue;
         }
         if (c_ok) {
             // lv.feat[l] (the `addends` of brcnn_roi_extract_backward_gather_add): a gradient of the same map from another
@@ -1304,6 +1360,69 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
             }
         }
     }
+}
+
+// second stage of the chunked levels: one workgroup per tile, partials added in chunk order (+ the level's addend)
+BRCNN_API size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois);
+static int g_roi_gather_chunks = -1;      // tuning hook (brcnn_roi_align_set_exact(40 + n)): -1 heuristic, n chunks per coarse tile
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_grad_chunk_sum_kernel(LevelTable lv, GatherLevels gl, int channels) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < BRCNN_MAX_LEVELS; i++)
+        if (i < gl.num_levels && (int)blockIdx.x >= gl.ptile0[i]) l = i;
+    if (gl.direct[blockIdx.x]) return;              // finished by its chunk-0 workgroup
+    const int nchunk = gl.chunks[l];
+    const int H = lv.height[l], W = lv.width[l];
+    const int tile_lin = blockIdx.x - gl.ptile0[l];
+    const int per_img = gl.tiles_x[l] * gl.tiles_y[l];
+    const int b = tile_lin / per_img, t = tile_lin - b * per_img;
+    const int h0 = (t / gl.tiles_x[l]) * GT_TILE, w0 = (t % gl.tiles_x[l]) * GT_TILE;
+    T* gout = reinterpret_cast<T*>(lv.gfeat[l]) + (size_t)b * H * W * channels;
+    const T* gadd = lv.feat[l] ? reinterpret_cast<const T*>(lv.feat[l]) + (size_t)b * H * W * channels : nullptr;
+    const float* pt = gl.partial + ((size_t)(gl.ptile0[l] + tile_lin) * nchunk * 64) * channels;
+    const int cv = channels >> 2;                   // float4 columns
+    for (int i = threadIdx.x; i < 64 * cv; i += 256) {
+        const int pix = i / cv, c = (i - pix * cv) * 4;
+        const int py = h0 + pix / GT_TILE, px = w0 + pix % GT_TILE;
+        if (py >= H || px >= W) continue;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nchunk; k++) {
+            const float4 a = *reinterpret_cast<const float4*>(pt + ((size_t)k * 64 + pix) * channels + c);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const size_t off = ((size_t)py * W + px) * channels + c;
+        if (gadd) {
+            const float4 a = ld4(gadd + off);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        st4(gout + off, v);
+    }
+}
+
+// hit chunks per tile of the coarse levels for `n_rois` RoIs over `batch` images (1: the one-workgroup form)
+static int gather_chunks(int n_rois, int batch) {
+    if (g_roi_gather_chunks >= 0) return g_roi_gather_chunks < 1 ? 1 : g_roi_gather_chunks;
+    const int per_img = n_rois / (batch > 0 ? batch : 1);
+    int ch = per_img / 48;
+    if (ch > 16) ch = 16;
+    return ch < 2 ? 1 : ch;
+}
+
+BRCNN_API size_t brcnn_roi_extract_backward_workspace_bytes_ex(int n_rois, int batch, int channels, int num_levels,
+                                                               const int* heights_host, const int* widths_host) {
+    size_t bytes = brcnn_roi_extract_backward_workspace_bytes(n_rois);
+    const int ch = gather_chunks(n_rois, batch);
+    if (ch > 1 && heights_host && widths_host && num_levels > 0 && num_levels <= BRCNN_MAX_LEVELS && channels > 0) {
+        size_t tiles = 0;
+        for (int l = 0; l < num_levels; l++) {
+            const size_t per_img = (size_t)((heights_host[l] + GT_TILE - 1) / GT_TILE) * ((widths_host[l] + GT_TILE - 1) / GT_TILE);
+            if (per_img <= (size_t)GT_CHUNK_TILES) tiles += per_img * batch;
+        }
+        bytes = ((bytes + 255) & ~(size_t)255) + ((tiles * sizeof(int) + 255) & ~(size_t)255) + tiles * ch * 64 * channels * sizeof(float);
+    }
+    return bytes;
 }
 
 BRCNN_API size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois) {
@@ -1349,6 +1468,36 @@ BRCNN_API int brcnn_roi_extract_backward_gather_add(void* const* grad_feats_host
         blk += gl.tiles_x[l] * gl.tiles_y[l] * batch;
     }
     for (int l = num_levels; l <= BRCNN_MAX_LEVELS; l++) gl.blk0[l] = blk;
+    // hit chunks for the coarse levels, when the caller's workspace holds their partials (.._workspace_bytes_ex)
+    for (int l = 0; l < BRCNN_MAX_LEVELS; l++) gl.chunks[l] = 1;
+    const size_t base_bytes = (brcnn_roi_extract_backward_workspace_bytes(n_rois) + 255) & ~(size_t)255;
+    int ptiles = 0;
+    {
+        const int ch = gather_chunks(n_rois, batch);
+        size_t tiles = 0;
+        for (int l = 0; l < num_levels; l++)
+            if (gl.tiles_x[l] * gl.tiles_y[l] <= GT_CHUNK_TILES) tiles += (size_t)gl.tiles_x[l] * gl.tiles_y[l] * batch;
+        const size_t flag_bytes = (tiles * sizeof(int) + 255) & ~(size_t)255;
+        if (ch > 1 && n_rois > 0 && tiles > 0 &&
+            workspace_bytes >= base_bytes + flag_bytes + tiles * ch * 64 * channels * sizeof(float)) {
+            gl.direct = (int*)((char*)workspace + base_bytes);
+            gl.partial = (float*)((char*)workspace + base_bytes + flag_bytes);
+            BRCNN_HIP_CHECK(hipMemsetAsync(gl.direct, 0, tiles * sizeof(int), (hipStream_t)stream));
+            blk = 0;
+            for (int l = 0; l < num_levels; l++) {
+                const int per_level = gl.tiles_x[l] * gl.tiles_y[l] * batch;
+                const bool coarse = gl.tiles_x[l] * gl.tiles_y[l] <= GT_CHUNK_TILES;
+                gl.chunks[l] = coarse ? ch : 1;
+                gl.ptile0[l] = ptiles;
+                if (coarse) ptiles += per_level;
+                gl.blk0[l] = blk;
+                blk += per_level * gl.chunks[l];
+            }
+            for (int l = num_levels; l <= BRCNN_MAX_LEVELS; l++) { gl.blk0[l] = blk; gl.ptile0[l] = ptiles; }
+            // (levels that are not chunked keep ptile0 = the running count: the sum kernel's level search only sees
+            // chunked tiles because a fine level adds none)
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     RoiRec* recs = (RoiRec*)workspace;
     int* ranges = nullptr;
@@ -1373,6 +1522,15 @@ BRCNN_API int brcnn_roi_extract_backward_gather_add(void* const* grad_feats_host
         hipLaunchKernelGGL(roi_grad_gather_kernel<f16_t>, dim3(blk), dim3(256), 0, s, (const f16_t*)grad_output, lv, gl, rois,
                            recs, ranges, n_rois, channels, pooled_h, pooled_w, sampling_ratio);
     BRCNN_LAUNCH_CHECK();
+    if (ptiles > 0) {
+        if (dtype == BRCNN_DT_F32)
+            hipLaunchKernelGGL(roi_grad_chunk_sum_kernel<float>, dim3(ptiles), dim3(256), 0, s, lv, gl, channels);
+        else if (dtype == BRCNN_DT_BF16)
+            hipLaunchKernelGGL(roi_grad_chunk_sum_kernel<bf16_t>, dim3(ptiles), dim3(256), 0, s, lv, gl, channels);
+        else
+            hipLaunchKernelGGL(roi_grad_chunk_sum_kernel<f16_t>, dim3(ptiles), dim3(256), 0, s, lv, gl, channels);
+        BRCNN_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1383,6 +1541,7 @@ BRCNN_API int brcnn_roi_align_set_exact(int exact) {
     if (exact == 10 || exact == 11 || exact == 17) { g_roi_rpw = exact == 10 ? 0 : exact; return 0; }
     if (exact >= 20 && exact <= 22) { g_roi_order = exact - 20; return 0; }
     if (exact == 30 || exact == 31) { g_roi_prep = exact - 30; return 0; }
+    if (exact >= 39 && exact <= 56) { g_roi_gather_chunks = exact - 40; return 0; }    // 39: heuristic, 40 / 41: off, 42..56: chunks per coarse tile
     g_roi_exact = exact == 1 ? 1 : 0;
     g_roi_stream_c = exact == 2 ? 0 : exact == 3 ? 1 : 3;
     return 0;

@@ -193,6 +193,14 @@ class GraphedTrunk:
         eager_side = _A._side_streams.get(skey)
         listener, arena_state = _A.grad_arena.listener, (_A.grad_arena.hint,)
         s = self._capture_stream
+        # Python's cyclic collector stays off from here to the end of the captures: a collection that starts inside a capture
+        # frees device tensors and events from whatever cycle it finds (autograd contexts and their BnTail tags form some), and
+        # a free that has to record an event on a capturing stream aborts the process (seen once in ~10 suite runs, in
+        # `record_event` of a weight-gradient launch; torch.cuda.graph collects before a capture for the same reason)
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             _A.grad_arena.listener = None               # (a gradient reducer must not see, let alone slice, the capture)
             _A._side_streams[skey] = self._side         # the capture's own weight-gradient stream (own conv scratch)
@@ -238,6 +246,8 @@ class GraphedTrunk:
             del arena_state
             for p, g in zip(params, saved_grads):
                 p.grad = g
+            if gc_was_on:
+                gc.enable()
         cap.anchor = torch.zeros((), device=dev, requires_grad=True)
         self.captures += 1
         return cap

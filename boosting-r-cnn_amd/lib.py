@@ -34,6 +34,7 @@ SIGNATURES = {
     'brcnn_roi_extract_backward': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 +
                                    [c_f32, c_ptr]),
     'brcnn_roi_extract_backward_workspace_bytes': (c_size, [c_int]),
+    'brcnn_roi_extract_backward_workspace_bytes_ex': (c_size, [c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     'brcnn_roi_extract_backward_gather': (c_int, [c_ptr] * 4 + [c_int] + [c_ptr] * 2 + [c_int] * 6 + [c_f32, c_ptr, c_size,
                                                                                                     c_int, c_ptr]),
     'brcnn_roi_extract_backward_gather_add': (c_int, [c_ptr] * 5 + [c_int] + [c_ptr] * 2 + [c_int] * 6 + [c_f32, c_ptr, c_size,

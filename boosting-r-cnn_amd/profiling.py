@@ -219,6 +219,11 @@ _TRAIN_ENTRIES = {
         'dgrad', lambda a: (a[17] * a[18] * a[19], a[22], a[24] * a[25] * a[23]),
         lambda a: _esz(a[28]) * (a[17] * a[20] * a[21] * a[23] + a[22] * a[24] * a[25] * a[23] +
                                  a[17] * a[18] * a[19] * a[22] * (2 + sum(1 for i in (9, 10, 11) if a[i])))),
+    # ... the same with the trailing `defer_second_stage` flag (round 6: the entry the train step calls)
+    'brcnn_conv2d_dgrad_bn_backward_nhwc_ex': (
+        'dgrad', lambda a: (a[17] * a[18] * a[19], a[22], a[24] * a[25] * a[23]),
+        lambda a: _esz(a[28]) * (a[17] * a[20] * a[21] * a[23] + a[22] * a[24] * a[25] * a[23] +
+                                 a[17] * a[18] * a[19] * a[22] * (2 + sum(1 for i in (9, 10, 11) if a[i])))),
     # (x,w,scale,shift,res,y,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,relu,dt,stream)
     'brcnn_conv2d_nhwc_multi': (
         'forward', lambda a: (_out_rows(a[6], a[8], a[9], a[7], a[12], a[13], a[14], a[15]), a[11], a[12] * a[13] * a[10]),

@@ -136,6 +136,14 @@ int brcnn_roi_extract_backward(float *const *grad_feats_host, const int *heights
  * dtype: element type of grad_output AND of the grad_feats maps (BRCNN_DT_F32, or the 16-bit compute dtype of
  * the pyramid in training: fp32 accumulation, one rounding at the store). */
 size_t brcnn_roi_extract_backward_workspace_bytes(int n_rois);
+/* ... plus room for the fp32 partials of the hit-chunked form: a map with at most 32 tiles of 8 x 8 pixels per image (the
+ * coarse pyramid levels) is touched by most of its level's RoIs in every tile, and one workgroup per tile walks those hits
+ * one after the other -- that chain, not the bytes, is the launch (512 RoIs / image of 450-800 px: 2.0 ms, of 16-110 px:
+ * 0.22 ms).  With a workspace of this size the gather entries give such tiles n_rois / batch / 48 (<= 16) workgroups, each
+ * taking every n-th hit in RoI order, and add their partials in a fixed order in a second launch (reproducible; not the
+ * one-workgroup chain's association).  With the smaller workspace above they run the one-workgroup form. */
+size_t brcnn_roi_extract_backward_workspace_bytes_ex(int n_rois, int batch, int channels, int num_levels,
+                                                     const int *heights_host, const int *widths_host);
 int brcnn_roi_extract_backward_gather(void *const *grad_feats_host, const int *heights_host,
                                       const int *widths_host, const float *scales_host, int num_levels,
                                       const float *rois, const void *grad_output, int batch, int channels,

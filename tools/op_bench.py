@@ -91,13 +91,13 @@ def main():
         ptrs = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in grads])
         hs_ = (ctypes.c_int * 5)(*[h for h, _ in sizes]); ws_ = (ctypes.c_int * 5)(*[w for _, w in sizes])
         sc_ = (ctypes.c_float * 5)(*[1.0 / s_ for s_ in strides])
-        nb = Lb.brcnn_roi_extract_backward_workspace_bytes(K)
+        nb = Lb.brcnn_roi_extract_backward_workspace_bytes_ex(K, B, 256, 5, hs_, ws_)     # (incl. the hit-chunk partials of the coarse levels)
         wsp = torch.empty((nb + 3) // 4, dtype=torch.int32, device=DEV)
         call = lambda: Lb.brcnn_roi_extract_backward_gather(ptrs, hs_, ws_, sc_, 5, rg.data_ptr(), go.data_ptr(), B, 256, K, 7, 7, 0,
                                                             56.0, wsp.data_ptr(), nb, 0, None)
         assert call() == 0
         tg = timed(call, 10)
-        res[f'roialign_bwd_gather_{per_img}x{B}'] = dict(us=tg * 1e6, note='record + gather kernels only, fp32')
+        res[f'roialign_bwd_gather_{per_img}x{B}'] = dict(us=tg * 1e6, note='record + gather (+ chunk sum) kernels only, fp32')
         res[f'roialign_fwd+bwd_{per_img}x{B}'] = dict(us=tfb * 1e6, GBs=2 * by / tfb / 1e9,
                                                       frac_hbm=2 * by / tfb / 1e9 / HBM)
     # NMS: RPN test (8 x 4693), RPN train level segments (8 x 5 x ~3000), R-CNN (8 x 1024)
