@@ -468,10 +468,12 @@ class ConvNHWCFunction(Function):
     parameter layout, bias (Cout) or None.  Returns y_cat (rows_out, Cout)."""
 
     @staticmethod
-    def forward(ctx, x_cat, weight, bias, batch, sizes, stride, pad, with_skip=False):
+    def forward(ctx, x_cat, weight, bias, batch, sizes, stride, pad, with_skip=False, relu=False, out_f32=False):
         """`with_skip`: also return an alias of the input (the identity branch of a residual block);
         its gradient then arrives in THIS backward and is added in the data-gradient kernel's
-        epilogue instead of by a separate autograd add over the whole tensor"""
+        epilogue instead of by a separate autograd add over the whole tensor.  `relu`: ReLU in the kernel's epilogue (the
+        backward masks dy with the saved output: one launch instead of clamp + threshold_backward around the node).
+        `out_f32`: a 16-bit conv writes its result in fp32 (head outputs: no widening copy behind the launch)."""
         _require_gpu(x_cat, weight, bias)
         # fp32 activations: exact-fp32 MFMA; bf16 activations: bf16 MFMA with fp32 accumulation
         # (weights are cast per step from the fp32 master copy, gradients of weights stay fp32)
@@ -482,8 +484,13 @@ class ConvNHWCFunction(Function):
         x_cat = x_cat.contiguous()
         y, out_sizes = ops.conv2d_nhwc_multi(x_cat, w_p, batch, sizes, None,
                                              bias.detach().float().contiguous() if bias is not None else None,
-                                             None, False, stride, pad)
-        ctx.save_for_backward(x_cat, weight)
+                                             None, bool(relu), stride, pad,
+                                             out_f32=bool(out_f32) and x_cat.dtype != torch.float32)
+        if relu:
+            ctx.save_for_backward(x_cat, weight, y)
+        else:
+            ctx.save_for_backward(x_cat, weight)
+        ctx.relu = bool(relu)
         ctx.cfg = (batch, tuple(sizes), tuple(out_sizes), stride, pad, bias is not None)
         ctx.bias_ref = bias
         ctx.with_skip = bool(with_skip)
@@ -494,7 +501,11 @@ class ConvNHWCFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, dskip=None):
-        x_cat, weight = ctx.saved_tensors
+        if ctx.relu:
+            x_cat, weight, y = ctx.saved_tensors
+            dy = torch.ops.aten.threshold_backward(dy.to(y.dtype), y, 0)
+        else:
+            x_cat, weight = ctx.saved_tensors
         batch, sizes, out_sizes, stride, pad, has_bias = ctx.cfg
         dy = dy.to(x_cat.dtype).contiguous()
         dx, dw, dskip = _conv_backward(x_cat, weight, ctx.w_t, dy, (batch, sizes, out_sizes, stride, pad), dskip,
@@ -519,7 +530,7 @@ class ConvNHWCFunction(Function):
                 _queue_stream_join(main, side)
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class GroupNormNHWCFunction(Function):
@@ -605,15 +616,15 @@ def _pad_cout(weight, bias, mult=32):
     return weight, bias, cout
 
 
-def conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False):
+def conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False, out_f32=False):
     """x (N,H,W,Cin) -> (N,Ho,Wo,Cout), differentiable.  `with_skip`: returns (y, x_alias); gradients
     reaching x_alias (a residual block's identity branch) are added inside the conv's data-gradient
-    kernel"""
+    kernel.  `out_f32`: fp32 result from 16-bit operands (head outputs)"""
     n, h, w, cin = x.shape
     kh, kw = weight.shape[2], weight.shape[3]
     ho, wo = conv_out_size(h, w, kh, kw, stride, pad)
     weight, bias, cout = _pad_cout(weight, bias, 32 if x.dtype == torch.float32 else 64)
-    y = ConvNHWCFunction.apply(x.reshape(n * h * w, cin), weight, bias, n, ((h, w),), stride, pad, with_skip)
+    y = ConvNHWCFunction.apply(x.reshape(n * h * w, cin), weight, bias, n, ((h, w),), stride, pad, with_skip, False, bool(out_f32))
     skip = None
     if with_skip:
         y, skip = y
@@ -623,11 +634,12 @@ def conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False):
     return (y, skip) if with_skip else y
 
 
-def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad):
+def conv2d_nhwc_multi_autograd(x_cat, weight, bias, batch, sizes, stride, pad, out_f32=False):
     """several NHWC maps that share one set of weights (pyramid levels), concatenated as
-    (rows, Cin) -> (rows_out, Cout): one forward / dgrad / wgrad launch for all of them"""
+    (rows, Cin) -> (rows_out, Cout): one forward / dgrad / wgrad launch for all of them; `out_f32`: fp32 result from
+    16-bit operands (head outputs)"""
     weight, bias, cout = _pad_cout(weight, bias, 32 if x_cat.dtype == torch.float32 else 64)
-    y = ConvNHWCFunction.apply(x_cat, weight, bias, batch, tuple(sizes), stride, pad)
+    y = ConvNHWCFunction.apply(x_cat, weight, bias, batch, tuple(sizes), stride, pad, False, False, bool(out_f32))
     return y if cout == weight.shape[0] else y[:, :cout]
 
 
@@ -674,6 +686,37 @@ def cat_rows(feats):
         return CatRowsAliased.apply(*feats)
     rows = sum(f.numel() // c for f in feats)
     return f0.new_empty(0).set_(f0.untyped_storage(), f0.storage_offset(), (rows, c), (c, 1))
+
+
+class SplitColumns(Function):
+    """y (rows, padded) -> the column ranges [0, n0), [n0, n0 + n1), ... as contiguous fp32 tensors (the fused head
+    output: cls | reg [| pad]); backward writes the parts' gradients into ONE (rows, padded) tensor of y's dtype -- where
+    slicing + `.float()` + `.contiguous()` cost a copy per part forward and a zero fill, a copy and an add per part backward"""
+
+    @staticmethod
+    def forward(ctx, y, *widths):
+        ctx.meta = (tuple(y.shape), y.dtype, tuple(int(w) for w in widths))
+        outs, c0 = [], 0
+        for w in widths:
+            outs.append(y[:, c0:c0 + w].float().contiguous() if y.dtype != torch.float32 else y[:, c0:c0 + w].contiguous())
+            c0 += w
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        shape, dtype, widths = ctx.meta
+        dy = torch.empty(shape, dtype=dtype, device=next(g for g in grads if g is not None).device)
+        c0 = 0
+        for w, g in zip(widths, grads):
+            if g is None:
+                dy[:, c0:c0 + w].zero_()
+            else:
+                dy[:, c0:c0 + w].copy_(g)
+            c0 += w
+        if c0 < shape[1]:
+            dy[:, c0:].zero_()
+        return (dy,) + (None,) * len(widths)
 
 
 class FusedHeadWeights(Function):
@@ -823,8 +866,9 @@ def permuted_fc_weight(w2d, c, ph, pw, dtype=None):
     return w
 
 
-def linear_autograd(x, weight, bias):
-    """x (M,K) @ weight(N,K)^T + bias, differentiable (the 1x1 case with H=W=1)"""
+def linear_autograd(x, weight, bias, relu=False, out_f32=False):
+    """[relu](x (M,K) @ weight(N,K)^T + bias), differentiable (the 1x1 case with H=W=1); `out_f32`: fp32 result from
+    16-bit operands"""
     on_side = getattr(weight, '_brcnn_dw_consumer_on_side', False)
     pk = getattr(weight, '_brcnn_pack', None)       # operands the fused optimizer (or permuted_fc_weight) holds for it
     src = weight
@@ -834,7 +878,7 @@ def linear_autograd(x, weight, bias):
         w4._brcnn_dw_consumer_on_side = True
     if pk is not None and weight is src and pk[0] == src._version and pk[1] == x.dtype and pk[2].device == x.device:
         w4._brcnn_pack = (w4._version, pk[1], pk[2], pk[3])
-    y = ConvNHWCFunction.apply(x.contiguous(), w4, bias, x.shape[0], ((1, 1),), 1, 0)
+    y = ConvNHWCFunction.apply(x.contiguous(), w4, bias, x.shape[0], ((1, 1),), 1, 0, False, bool(relu), bool(out_f32))
     return y if cout == weight.shape[0] else y[:, :cout]
 
 

@@ -191,7 +191,7 @@ class ATSSRPNHead(AnchorHead):
             # training: the three heads as one differentiable 54-channel conv
             heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
             y = conv2d_nhwc_autograd(x, torch.cat([h.weight for h in heads], 0),
-                                     torch.cat([h.bias for h in heads], 0), 1, self.rpn_cls.padding[0]).float()
+                                     torch.cat([h.bias for h in heads], 0), 1, self.rpn_cls.padding[0], out_f32=True).float()
             a, c = self.num_anchors, self.cls_out_channels
             return (y[..., :a * c], y[..., a * c:a * c + 4 * a] * scale, y[..., a * c + 4 * a:])
         cls = self._head_conv(x, self.rpn_cls, self._head_caches[0], None)
@@ -214,7 +214,7 @@ class ATSSRPNHead(AnchorHead):
 
         from .autograd import conv2d_nhwc_autograd, wants_grad
         if wants_grad(x, conv.weight, conv.bias, scale):
-            y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, 1, conv.padding[0]).float()
+            y = conv2d_nhwc_autograd(x, conv.weight, conv.bias, 1, conv.padding[0], out_f32=True).float()
             return y * scale if scale is not None else y
         w, s, b = cache.get(srcs, builder)
         # fp32 result in either mode: the proposal stage scores / decodes in fp32
@@ -246,7 +246,7 @@ class ATSSRPNHead(AnchorHead):
         heads = (self.rpn_cls, self.rpn_reg, self.rpn_iou)
         y = conv2d_nhwc_multi_autograd(x, torch.cat([h.weight for h in heads], 0),
                                        torch.cat([h.bias for h in heads], 0), B, sizes, 1,
-                                       self.rpn_cls.padding[0]).float()
+                                       self.rpn_cls.padding[0], out_f32=True).float()
         a, c = self.num_anchors, self.cls_out_channels
         cls, reg, iou, r0 = [], [], [], 0
         for lvl, (h, w) in enumerate(sizes):
@@ -530,8 +530,8 @@ class ATSSRPNHead(AnchorHead):
         # (one differentiable node for cat + pad whose backward hands out views: the fused head's weight-gradient launch
         # leaves the main stream like the others)
         w, b = fused_head_weights(heads, 32 if x.dtype == torch.float32 else 64)
-        y = ConvNHWCFunction.apply(x, w, b, B, sizes, 1, self.rpn_cls.padding[0])
-        return y.float(), sizes
+        y = ConvNHWCFunction.apply(x, w, b, B, sizes, 1, self.rpn_cls.padding[0], False, False, True)   # fp32 head output
+        return y, sizes
 
     def _anchor_table(self, sizes, device):
         """all levels' grid anchors of ONE image as a cached (n, 4) tensor + the level geometry"""

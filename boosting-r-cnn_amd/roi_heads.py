@@ -225,14 +225,14 @@ class ProbConvFCBBoxHead(nn.Module):
                 w = fc.weight
                 if i == 0:   # (out, C*ph*pw) columns -> (ph,pw,C) order, differentiable (its gradient's way back on the second stream)
                     w = permuted_fc_weight(w, c, ph, pw, x.dtype)
-                x = linear_autograd(x, w, fc.bias).relu()
+                x = linear_autograd(x, w, fc.bias, relu=True)       # (ReLU in the GEMM's epilogue)
             # fc_cls | fc_reg as one GEMM through one autograd node (cat + pad; its backward hands out views of dW, so the
             # weight-gradient launch leaves the main stream: autograd.FusedHeadWeights)
             from .autograd import fused_head_weights
             w, b = fused_head_weights((self.fc_cls, self.fc_reg), 32 if x.dtype == torch.float32 else 64)
-            y = linear_autograd(x, w, b).float()
-            nc, nr = self.fc_cls.out_features, self.fc_reg.out_features
-            return y[:, :nc], y[:, nc:nc + nr]
+            from .autograd import SplitColumns
+            y = linear_autograd(x, w, b, out_f32=True)          # fp32 scores / deltas straight from the kernel
+            return SplitColumns.apply(y, self.fc_cls.out_features, self.fc_reg.out_features)
         for i, fc in enumerate(self.shared_fcs):
             if i == 0:
                 def builder(fc=fc):   # (out, C*ph*pw) columns -> (ph,pw,C) order

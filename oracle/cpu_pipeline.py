@@ -178,14 +178,17 @@ def _rpn_decode(topk_inds, bbox_pred, base_anchors, feat_hw, stride, means, stds
 
 
 # ---- differentiable CPU restatements of brcnn.autograd (training path of the oracle pipeline) ---
-def _conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False):
+def _conv2d_nhwc_autograd(x, weight, bias, stride, pad, with_skip=False, out_f32=False):
     y = F.conv2d(x.permute(0, 3, 1, 2), weight, bias, stride, pad)
     y = y.permute(0, 2, 3, 1).contiguous()
+    y = y.float() if out_f32 else y
     return (y, x) if with_skip else y
 
 
-def _linear_autograd(x, weight, bias):
-    return F.linear(x, weight, bias)
+def _linear_autograd(x, weight, bias, relu=False, out_f32=False):
+    y = F.linear(x, weight, bias)
+    y = y.relu() if relu else y
+    return y.float() if out_f32 else y
 
 
 def _roi_extract_autograd(feats_nhwc, rois, output_size, strides, finest_scale=56, sampling_ratio=0):
