@@ -248,39 +248,55 @@ struct GnSegs {
 // float4 rows (16 loads in flight per thread), partial sums are folded to double every 32 rows,
 // the 4 row lanes are combined through LDS and one double atomic pair per (group) leaves the
 // workgroup.  C <= 256, C % 4 == 0, (C/G) % 4 == 0 or 4 % (C/G) == 0 handled generally below.
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x,
                                                       double* __restrict__ stats, GnSegs sg, int N,
                                                       int C, int G, int rows_per_block) {
-    __shared__ double red[4][256][2];     // [row lane][channel][sum, sumsq]
+    // V channels per lane: 16-byte loads for both element widths where C % 8 == 0 (round 6: the 16-bit form read 8 bytes
+    // per lane and ran at 2.4 TB/s, the fp32 form at 4.2); LPR lanes cover 256 channels of a row, RL row lanes share the
+    // block's strip
+    constexpr int LPR = 256 / V, RL = 256 / LPR;
+    __shared__ double red[RL][256][2];    // [row lane][channel][sum, sumsq]
     const int seg = blockIdx.y / N, n = blockIdx.y - seg * N;
     const int HW = sg.hw[seg];
     const int row0 = blockIdx.x * rows_per_block;
     if (row0 >= HW) return;
     const int row1 = min(HW, row0 + rows_per_block);
     const T* xs = x + (size_t)(sg.row0[seg] + (long long)n * HW) * C;
-    const int c4n = C >> 2;
-    const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    for (int q0 = q; q0 < c4n; q0 += 64) {
-        double ds[4] = {0, 0, 0, 0}, dss[4] = {0, 0, 0, 0};
-        for (int rb = row0 + rl; rb < row1; rb += 4 * 32) {
-            float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const int cvn = C / V;
+    const int q = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    for (int q0 = q; q0 < cvn; q0 += LPR) {
+        double ds[V], dss[V];
+#pragma unroll
+        for (int e = 0; e < V; e++) ds[e] = dss[e] = 0.0;
+        for (int rb = row0 + rl; rb < row1; rb += RL * 32) {
+            float s[V], ss[V];
+#pragma unroll
+            for (int e = 0; e < V; e++) s[e] = ss[e] = 0.f;
 #pragma unroll 8
             for (int i = 0; i < 32; i++) {
-                const int r = rb + 4 * i;
+                const int r = rb + RL * i;
                 if (r < row1) {
-                    const float4 v = ld4(xs + (size_t)r * C + q0 * 4);
-                    s[0] += v.x; ss[0] += v.x * v.x; s[1] += v.y; ss[1] += v.y * v.y;
-                    s[2] += v.z; ss[2] += v.z * v.z; s[3] += v.w; ss[3] += v.w * v.w;
+                    float xi[V];
+                    if constexpr (V == 8) {
+                        float4 x0, x1;
+                        ld8(xs + (size_t)r * C + q0 * 8, x0, x1);
+                        xi[0] = x0.x; xi[1] = x0.y; xi[2] = x0.z; xi[3] = x0.w; xi[4] = x1.x; xi[5] = x1.y; xi[6] = x1.z; xi[7] = x1.w;
+                    } else {
+                        const float4 v = ld4(xs + (size_t)r * C + q0 * 4);
+                        xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < V; e++) { s[e] += xi[e]; ss[e] += xi[e] * xi[e]; }
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 4; e++) { ds[e] += s[e]; dss[e] += ss[e]; }
+            for (int e = 0; e < V; e++) { ds[e] += s[e]; dss[e] += ss[e]; }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            red[rl][q0 * 4 + e][0] = ds[e];
-            red[rl][q0 * 4 + e][1] = dss[e];
+        for (int e = 0; e < V; e++) {
+            red[rl][q0 * V + e][0] = ds[e];
+            red[rl][q0 * V + e][1] = dss[e];
         }
     }
     __syncthreads();
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x,
         double a = 0.0, b2 = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; c++)
 #pragma unroll
-            for (int l = 0; l < 4; l++) { a += red[l][c][0]; b2 += red[l][c][1]; }
+            for (int l = 0; l < RL; l++) { a += red[l][c][0]; b2 += red[l][c][1]; }
         atomicAdd(&stats[((size_t)blockIdx.y * G + g) * 2 + 0], a);
         atomicAdd(&stats[((size_t)blockIdx.y * G + g) * 2 + 1], b2);
     }
@@ -902,8 +918,12 @@ template <typename T>
 static int gn_forward_16(const void* x, const float* gamma, const float* beta, void* y, void* stats_ws, const GnSegs& sg,
                          int batch, int num_segments, int channels, int groups, float eps, int relu, int chunks, int rpb,
                          long long total, int nstat, hipStream_t s) {
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, batch * num_segments), dim3(256), 0, s, (const T*)x,
-                       (double*)stats_ws, sg, batch, channels, groups, rpb);
+    if (channels & 7)
+        hipLaunchKernelGGL((gn_stats_kernel<T, 4>), dim3(chunks, batch * num_segments), dim3(256), 0, s, (const T*)x,
+                           (double*)stats_ws, sg, batch, channels, groups, rpb);
+    else
+        hipLaunchKernelGGL((gn_stats_kernel<T, 8>), dim3(chunks, batch * num_segments), dim3(256), 0, s, (const T*)x,
+                           (double*)stats_ws, sg, batch, channels, groups, rpb);
     BRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, (double*)stats_ws, sg, batch,
                        channels, groups, eps);
@@ -953,7 +973,7 @@ BRCNN_API int brcnn_groupnorm_nhwc_multi(const void* x, const float* gamma, cons
     const long long total = rows * (channels >> 2);
     const int nstat = num_segments * batch * groups;
     if (dtype == BRCNN_DT_F32) {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, batch * num_segments), dim3(256), 0, s,
+        hipLaunchKernelGGL((gn_stats_kernel<float, 4>), dim3(chunks, batch * num_segments), dim3(256), 0, s,
                            (const float*)x, (double*)stats_ws, sg, batch, channels, groups, rpb);
         BRCNN_LAUNCH_CHECK();
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s,
