@@ -7,6 +7,8 @@ Mirrors `mmdet/models/backbones/resnet.py` (`Bottleneck` :97-302, `ResNet` :306-
 same state-dict key layout (`conv1/bn1/layer{1-4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,
 downsample.{0,1}}`), the same freeze / norm_eval behaviour in `train()`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -185,17 +187,24 @@ class ResNet(nn.Module):
         return c.kernel_size == (7, 7) and c.stride == (2, 2) and c.padding == (3, 3) and \
             c.in_channels == 3 and c.bias is None and not c.weight.requires_grad
 
+    # the frozen 64-channel stem and its max-pool as one launch (csrc/stem_pool.hip); BRCNN_STEM_POOL_FUSED=0: two launches
+    FUSED_STEM_POOL = os.environ.get('BRCNN_STEM_POOL_FUSED', '1') != '0'
+
     def stem_from_nchw(self, img):
-        """frozen stem straight from the NCHW image (no NHWC copy of the input): repack +
-        vector-path 7x7 conv + folded BN + ReLU, then the 3x3/s2 max-pool"""
+        """frozen stem straight from the NCHW image (no NHWC copy of the input): 7x7 conv + folded BN + ReLU +
+        3x3/s2 max-pool in one launch (64 stem channels), else repack + vector-path conv, then the max-pool"""
+        fused = self.FUSED_STEM_POOL and self.conv1.out_channels == 64
+
         def builder():
-            from .blocks import fold_bn
+            from .blocks import fold_bn, compute_dtype
             scale, shift = fold_bn(self.bn1)
-            from .blocks import compute_dtype
-            return ops.pack_stem_weight(self.conv1.weight, compute_dtype()), scale, shift
+            pack = ops.pack_stem_pool_weight if fused else ops.pack_stem_weight
+            return pack(self.conv1.weight, compute_dtype()), scale, shift
         w, scale, shift = self._stem_cache2.get(
             [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var],
             builder)
+        if fused:
+            return ops.stem7x7s2_pool_nchw(img, w, scale, shift)
         return ops.maxpool3x3s2_nhwc(ops.stem7x7s2_nchw(img, w, scale, shift, True))
 
     supports_tap = True          # forward_nhwc / forward_from_nchw take `tap` (see _stages)

@@ -27,6 +27,7 @@ struct ConvParams {
     int relu;
     int tiles_m, tiles_n;
     int pitch;                       // floats between adjacent input pixels (== Cin normally)
+    int stem2;                       // 16-bit stem: a K tile = 8 pixels (32 elements) of filter row 2 kh and 8 of row 2 kh + 1
     unsigned x_bytes, w_bytes;       // extents for the bounds-checked buffer loads
     int dilate;                      // input dilation (data gradient of a strided conv), 1 otherwise
     int out_f32;                     // bf16 compute path: write the result as fp32 (head outputs)

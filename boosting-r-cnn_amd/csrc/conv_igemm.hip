@@ -780,7 +780,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
                                  const int* out_heights_host, const int* out_widths_host, int cin,
                                  int cout, int kh, int kw, int stride, int pad, int dilate, int relu,
                                  int dtype, void* stream, int pitch = 0, const int* scatter = nullptr,
-                                 const TrainTail* tail = nullptr, int* tiles_m_out = nullptr) {
+                                 const TrainTail* tail = nullptr, int* tiles_m_out = nullptr, int stem2 = 0) {
     if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
         pad < 0 || dilate < 1 || num_segments <= 0 || num_segments > BRCNN_MAX_LEVELS ||
         !heights_host || !widths_host)
@@ -798,6 +798,7 @@ static int conv_setup_and_launch(const void* x, const void* w, const float* scal
     p.batch = batch; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
     if (pitch <= 0) pitch = cin;
     p.stride = stride; p.pad = pad; p.pitch = pitch; p.nseg = num_segments; p.dilate = dilate;
+    p.stem2 = stem2;
     long long m_total = 0, x_off = 0;
     for (int sgi = 0; sgi < num_segments; sgi++) {
         const int H = heights_host[sgi], W = widths_host[sgi];
@@ -1023,6 +1024,10 @@ BRCNN_API int brcnn_conv2d_dgrad_nhwc_multi(const void* dy, const void* w_t, voi
 // start at pixel (ho*2+kh, wo*2), so the stem is a KH=7, KW=1, "Cin"=32 convolution whose
 // input pixels are 4 floats apart (pitch 4) -- no per-element gather, no bounds tests.
 // Weights arrive packed as (Cout, 7, 1, 32) with zeros at tap 7 / channel 3.
+// 16-bit: a 128-byte K row holds 64 elements = the 8-pixel windows of TWO filter rows, so the stem is four K tiles deep
+// (rows 0|1, 2|3, 4|5, 6|none) instead of seven half-empty ones: weights (Cout, 4, 1, 64) = [co, t, 0, r*32 + kw*4 + c]
+// for filter row 2t + r; ConvParams::stem2 makes the upper half of a tile's pieces read image row + 1 (round 6:
+// the kernel is bound by its LDS-DMA bytes, which fall by 3/7).
 namespace {
 // EXTRA = zero pixels appended to each row beyond the 3+3 border (so that the last window's
 // full 32-float / 64-bf16 K row stays inside the row); bf16 variant packs 4 x bf16 per pixel.
@@ -1072,8 +1077,8 @@ BRCNN_API int brcnn_stem7x7s2_nchw(const float* img, const void* w_packed, const
         return BRCNN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const bool bf = dtype != BRCNN_DT_F32;
-    const int kelems = bf ? 64 : 32;                 // K row = 128 bytes of 4-element pixels
-    const int Hp = height + 6, Wp = width + 6 + (kelems / 4 - 8);
+    const int kelems = bf ? 64 : 32;                 // K row = 128 bytes of 4-element pixels (16-bit: two filter rows of 8)
+    const int Hp = height + 6, Wp = width + 6;
     const long long total = (long long)batch * Hp * Wp;
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
@@ -1084,5 +1089,6 @@ BRCNN_API int brcnn_stem7x7s2_nchw(const float* img, const void* w_packed, const
     const int Ho = (height + 6 - 7) / 2 + 1, Wo = (width + 6 - 7) / 2 + 1;
     const int hs[1] = {Hp}, ws[1] = {Wp}, ohs[1] = {Ho}, ows[1] = {Wo};
     return conv_setup_and_launch(workspace, w_packed, scale, shift, nullptr, y, batch, 1, hs, ws, ohs,
-                                 ows, kelems, cout, 7, 1, 2, 0, 1, relu, dtype, stream, 4);
+                                 ows, kelems, cout, bf ? 4 : 7, 1, 2, 0, 1, relu, dtype, stream, 4, nullptr, nullptr, nullptr,
+                                 bf ? 1 : 0);
 }

@@ -174,8 +174,13 @@ __global__ __launch_bounds__(64 * WM * WNW, (ST == 2 && MT * NT <= 4 && (WM * WN
             if (p.dilate > 1) {      // zero-stuffed input (data gradient of a strided conv)
                 brcnn_undilate(p.dilate, hi, wi, ok);
             }
+            int lc = a_lc[j];
+            if (p.stem2) {          // (wave-uniform) the stem's K tile kh: image rows 2 kh and 2 kh + 1, 8 pixels of 4 elements each
+                hi += t.kh + (lc >> 5);
+                lc &= 31;
+            }
             ok = ok & ((unsigned)hi < (unsigned)a_H[j]) & ((unsigned)wi < (unsigned)a_W[j]);
-            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + t.ci0 + a_lc[j] + tile_n * p.gstep) * 2 : OOB;
+            const int off = ok ? (a_base[j] + (hi * a_W[j] + wi) * p.pitch + t.ci0 + lc + tile_n * p.gstep) * 2 : OOB;
             float* dst = As + buf * BM * 32 + (wave * AG + j) * 8 * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
         } else {

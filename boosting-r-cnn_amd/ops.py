@@ -692,13 +692,15 @@ def groupnorm_nhwc_multi_backward(dy, x_cat, stats, gamma, beta, groups, batch, 
 
 
 def pack_stem_weight(w, dtype=torch.float32):
-    """(Cout,3,7,7) parameter -> (Cout,7,1,32) fp32 or (Cout,7,1,64) bf16: [co, kh, 0, kw*4 + c],
-    zeros elsewhere (a K row is 128 bytes of 4-element pixels)"""
+    """(Cout,3,7,7) parameter -> the stem kernel's K rows of 4-element pixels (128 bytes each):
+    fp32 (Cout,7,1,32) = [co, kh, 0, kw*4 + c]; 16-bit (Cout,4,1,64) = [co, t, 0, r*32 + kw*4 + c] for filter row
+    kh = 2t + r (two 8-pixel windows per K row: `brcnn_stem7x7s2_nchw`); zeros elsewhere"""
     cout = w.shape[0]
-    px = 8 if dtype == torch.float32 else 16
-    p = torch.zeros((cout, 7, px, 4), dtype=torch.float32, device=w.device)
-    p[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
-    return p.reshape(cout, 7, 1, px * 4).to(dtype).contiguous()
+    p = torch.zeros((cout, 8, 8, 4), dtype=torch.float32, device=w.device)
+    p[:, :7, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
+    if dtype == torch.float32:
+        return p[:, :7].reshape(cout, 7, 1, 32).contiguous()
+    return p.reshape(cout, 4, 1, 64).to(dtype).contiguous()
 
 
 def stem7x7s2_nchw(img, w_packed, scale=None, shift=None, relu=True):
@@ -715,6 +717,40 @@ def stem7x7s2_nchw(img, w_packed, scale=None, shift=None, relu=True):
     st = lib.brcnn_stem7x7s2_nchw(_ptr(img), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(y), _ptr(ws),
                                   n, h, w, cout, int(bool(relu)), _dt(y), _stream())
     _L.check(st, 'brcnn_stem7x7s2_nchw')
+    return y
+
+
+def pack_stem_pool_weight(w, dtype=torch.float32):
+    """(64,3,7,7) parameter -> the LDS image of `brcnn_stem7x7s2_pool_nchw`'s weights.  K index of filter row kh,
+    tap kw, channel c: fp32 k = kh*22 + kw*3 + c (one zero per row), stored [k // 2][co // 32][k % 2][co % 32];
+    16-bit k = kh*32 + kw*4 + c, stored [co][232] (zeros elsewhere)"""
+    cout = w.shape[0]
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    wf = w.detach().float()
+    if dtype == torch.float32:
+        p = torch.zeros((7, 22, cout), dtype=torch.float32, device=w.device)
+        p[:, :21] = wf.permute(2, 3, 1, 0).reshape(7, 21, cout)
+        return p.reshape(77, 2, 2, 32).permute(0, 2, 1, 3).contiguous()
+    p = torch.zeros((cout, 7, 8, 4), dtype=torch.float32, device=w.device)
+    p[:, :, :7, :3] = wf.permute(0, 2, 3, 1)
+    q = torch.zeros((cout, 232), dtype=torch.float32, device=w.device)
+    q[:, :224] = p.reshape(cout, 224)
+    return q.to(dtype).contiguous()
+
+
+def stem7x7s2_pool_nchw(img, w_packed, scale=None, shift=None):
+    """frozen ResNet stem in one launch: conv 7x7/s2/p3 (+scale/shift) + ReLU + max-pool 3x3/s2/p1 of the NCHW image
+    -> (N,Hp,Wp,64) NHWC in w_packed's dtype (resnet.py:631-636)"""
+    _require_gpu(img, w_packed, scale, shift)
+    n, c, h, w = img.shape
+    assert c == 3 and img.dtype == torch.float32
+    img = img.contiguous()
+    ho, wo = conv_out_size(h, w, 7, 7, 2, 3)
+    hp, wp = conv_out_size(ho, wo, 3, 3, 2, 1)
+    y = torch.empty((n, hp, wp, 64), dtype=w_packed.dtype, device=img.device)
+    st = _L.load().brcnn_stem7x7s2_pool_nchw(_ptr(img), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(y), n, h, w, 64,
+                                             _dt(y), _stream())
+    _L.check(st, 'brcnn_stem7x7s2_pool_nchw')
     return y
 
 

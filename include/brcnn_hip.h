@@ -420,13 +420,22 @@ int brcnn_pack_conv_weights(const float *weight, void *fwd, void *dgrad, int cou
 int brcnn_conv_set_tile_wgrad_bf16(int wt);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 convolution of the 3-channel NCHW image + folded BN +
- * ReLU (resnet.py:599-611,631-636) -> y (N,Ho,Wo,Cout) NHWC.  w_packed (Cout,7,1,32) fp32 or
- * (Cout,7,1,64) bf16: w_packed[co,kh,0,kw*4+c] = w[co,c,kh,kw] (zeros elsewhere).  workspace:
+ * ReLU (resnet.py:599-611,631-636) -> y (N,Ho,Wo,Cout) NHWC.  w_packed fp32: (Cout,7,1,32) with
+ * w_packed[co,kh,0,kw*4+c] = w[co,c,kh,kw]; 16-bit: (Cout,4,1,64) with w_packed[co,t,0,r*32+kw*4+c] =
+ * w[co,c,2t+r,kw] (two filter rows per 128-byte K row); zeros elsewhere.  workspace:
  * brcnn_stem_workspace_bytes() bytes (zero-bordered NHWC4 repack of the image). */
 size_t brcnn_stem_workspace_bytes(int batch, int height, int width);
 int brcnn_stem7x7s2_nchw(const float *img, const void *w_packed, const float *scale,
                          const float *shift, void *y, void *workspace, int batch, int height,
                          int width, int cout, int relu, int dtype, void *stream);
+
+/* The same stem followed by its 3x3/s2/p1 max-pool (resnet.py:611,631-636) in ONE launch, 64 output channels, ReLU
+ * always: y (N,Hp,Wp,64) NHWC in `dtype` (BRCNN_DT_F32 / BF16 / F16).  The image tile of a workgroup's 7 x 8 pooled
+ * outputs is staged in LDS once; the conv output never reaches memory.  w_packed: K index of filter row kh, tap kw,
+ * channel c = kh*22 + kw*3 + c (fp32; stored [k/2][co/32][k%2][co%32], 154 x 64 floats) or kh*32 + kw*4 + c (16-bit;
+ * stored [co][232]), zeros elsewhere.  cout must be 64. */
+int brcnn_stem7x7s2_pool_nchw(const float *img, const void *w_packed, const float *scale, const float *shift,
+                              void *y, int batch, int height, int width, int cout, int dtype, void *stream);
 
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,

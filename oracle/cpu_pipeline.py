@@ -75,6 +75,10 @@ def _maxpool(x):
     return F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
 
 
+def _stem7x7s2_pool_nchw(img, w_packed, scale=None, shift=None):
+    return _maxpool(_stem7x7s2_nchw(img, w_packed, scale, shift, True))
+
+
 def _groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False):
     y = F.group_norm(x.permute(0, 3, 1, 2), groups, gamma, beta, eps)
     if relu:
@@ -225,6 +229,7 @@ _PATCH_AUTOGRAD = dict(groupnorm_nhwc_autograd=_groupnorm_nhwc_autograd, bn_act_
                        roi_extract_autograd=_roi_extract_autograd)
 
 _PATCH = dict(pack_stem_weight=_pack_stem_weight, stem7x7s2_nchw=_stem7x7s2_nchw,
+              pack_stem_pool_weight=_pack_stem_weight, stem7x7s2_pool_nchw=_stem7x7s2_pool_nchw,
               conv2d_nhwc=_conv2d_nhwc, conv2d_nhwc_multi=_conv2d_nhwc_multi,
               groupnorm_nhwc_multi=_groupnorm_multi, linear_nhwc=_linear_nhwc, maxpool3x3s2_nhwc=_maxpool,
               groupnorm_nhwc=_groupnorm, upsample_nearest_add_nhwc_=_upsample_add_,

@@ -128,6 +128,10 @@ def test_stem_and_roi_extract_bf16():
         assert y.dtype == BF
         y = y.float().permute(0, 3, 1, 2).cpu().double()
         assert _rne_close(y, ref)
+        # ... and the one-launch stem + max-pool (max of correctly rounded values = the rounded max)
+        yp = ops.stem7x7s2_pool_nchw(img.to(DEV), ops.pack_stem_pool_weight(wt.to(DEV), BF), sc.to(DEV), sh.to(DEV))
+        assert yp.dtype == BF
+        assert _rne_close(yp.float().permute(0, 3, 1, 2).cpu().double(), F.max_pool2d(ref, 3, 2, 1))
     # RoI extract on bf16 maps: fp32 bilinear blend of bf16 samples, one RNE => equals the fp32
     # kernel run on the same (bf16-representable) maps, rounded once
     strides = [4, 8, 16, 32]

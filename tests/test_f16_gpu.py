@@ -95,6 +95,8 @@ def test_small_kernels_f16():
            sh.double().view(1, -1, 1, 1)).relu()
     y = ops.stem7x7s2_nchw(img.to(DEV), ops.pack_stem_weight(wt.to(DEV), H), sc.to(DEV), sh.to(DEV), True)
     assert y.dtype == H and _rne_close(y.float().permute(0, 3, 1, 2).cpu().double(), ref)
+    yp = ops.stem7x7s2_pool_nchw(img.to(DEV), ops.pack_stem_pool_weight(wt.to(DEV), H), sc.to(DEV), sh.to(DEV))
+    assert yp.dtype == H and _rne_close(yp.float().permute(0, 3, 1, 2).cpu().double(), F.max_pool2d(ref, 3, 2, 1))
     strides = [4, 8, 16, 32]
     feats = [_h(torch.randn(2, 200 // s, 304 // s, 256, generator=g)).to(DEV) for s in strides]
     rois = util.rand_rois(300, 2, 304.0, 200.0, seed=3).to(DEV)

@@ -652,6 +652,26 @@ def test_stem_vector_path_matches_float64():
         assert (y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_fused_stem_and_pool_matches_float64():
+    """conv 7x7/s2 + BN + ReLU + max-pool 3x3/s2 in one launch (resnet.py:631-636) vs the float64 chain: sizes with partial
+    tiles on both axes, odd conv / pool extents, one map smaller than a tile, the full-size aspect"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(13)
+    for (n, h, w) in [(2, 64, 96), (1, 75, 83), (1, 9, 7), (3, 29, 131), (2, 800 // 4, 1344 // 4)]:
+        img = torch.randn(n, 3, h, w, generator=g)
+        wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        ref = F.max_pool2d((F.conv2d(img.double(), wt.double(), None, 2, 3) * sc.double().view(1, -1, 1, 1) +
+                            sh.double().view(1, -1, 1, 1)).relu(), 3, 2, 1)
+        y = ops.stem7x7s2_pool_nchw(img.to(DEV), ops.pack_stem_pool_weight(wt.to(DEV)), sc.to(DEV), sh.to(DEV))
+        y = y.permute(0, 3, 1, 2).cpu().double()
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+        # ... and the two-launch form it replaces, to fp32 round-off (another summation order)
+        y2 = ops.maxpool3x3s2_nhwc(ops.stem7x7s2_nchw(img.to(DEV), ops.pack_stem_weight(wt.to(DEV)), sc.to(DEV), sh.to(DEV), True))
+        assert (y2.permute(0, 3, 1, 2).cpu().double() - y).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_bn_act_fused_forward_backward(dtype):
     """fused eval-BN affine (+residual) + ReLU and its backward against the torch ops it replaces"""
