@@ -113,13 +113,39 @@ def record_conv_launches(records):
         nbytes = x_cat.element_size() * (x_cat.numel() + w.numel()) + y.element_size() * y.numel()
         records.append((s, e, 2.0 * y.shape[0] * k * w.shape[0], nbytes, (y.shape[0], w.shape[0], k)))
         return y, osz
+    orig_stem, orig_stem_pool = ops.stem7x7s2_nchw, ops.stem7x7s2_pool_nchw
+
+    def stem_record(s, e, img, y, conv_rows):
+        # the 7x7 stem as the GEMM it is: 147 real products per output (the padded K the kernels run is their business);
+        # bytes: the image and what the launch writes (the conv output, or the pooled map of the fused form)
+        records.append((s, e, 2.0 * conv_rows * 147 * y.shape[-1], img.element_size() * img.numel() + y.element_size() * y.numel(),
+                        (conv_rows, y.shape[-1], 147)))
+
+    def wrapped_stem(img, w_packed, scale=None, shift=None, relu=True):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        y = orig_stem(img, w_packed, scale, shift, relu)
+        e.record()
+        stem_record(s, e, img, y, y.shape[0] * y.shape[1] * y.shape[2])
+        return y
+
+    def wrapped_stem_pool(img, w_packed, scale=None, shift=None):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        y = orig_stem_pool(img, w_packed, scale, shift)
+        e.record()
+        ho, wo = ops.conv_out_size(img.shape[2], img.shape[3], 7, 7, 2, 3)
+        stem_record(s, e, img, y, img.shape[0] * ho * wo)
+        return y
     ops.conv2d_nhwc = wrapped
     ops.conv2d_nhwc_multi = wrapped_multi
+    ops.stem7x7s2_nchw, ops.stem7x7s2_pool_nchw = wrapped_stem, wrapped_stem_pool
     try:
         yield
     finally:
         ops.conv2d_nhwc = orig
         ops.conv2d_nhwc_multi = orig_multi
+        ops.stem7x7s2_nchw, ops.stem7x7s2_pool_nchw = orig_stem, orig_stem_pool
 
 
 def conv_stack_roofline(model, img, metas, iters=5, dtype='f32'):
@@ -241,6 +267,12 @@ _TRAIN_ENTRIES = {
         'dgrad', lambda a: (sum(a[3] * a[5][i] * a[6][i] for i in range(a[4])), a[9], a[11] * a[12] * a[10]),
         lambda a: _esz(a[15]) * (sum(a[3] * a[7][i] * a[8][i] for i in range(a[4])) * a[10] + a[9] * a[11] * a[12] * a[10] +
                                  sum(a[3] * a[5][i] * a[6][i] for i in range(a[4])) * a[9])),
+    # (img,w,scale,shift,y,batch,h,w,cout,dt,stream): the frozen stem + max-pool launch; the GEMM = the 7x7 conv (147 real
+    # products per output), bytes = the fp32 image + the pooled map
+    'brcnn_stem7x7s2_pool_nchw': (
+        'forward', lambda a: (a[5] * ((a[6] - 1) // 2 + 1) * ((a[7] - 1) // 2 + 1), a[8], 147),
+        lambda a: 4 * a[5] * 3 * a[6] * a[7] +
+        _esz(a[9]) * a[5] * ((((a[6] - 1) // 2 + 1) - 1) // 2 + 1) * ((((a[7] - 1) // 2 + 1) - 1) // 2 + 1) * a[8]),
     # (x,dy,dw,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,dt,stream)
     'brcnn_conv2d_wgrad_nhwc_multi': (
         'wgrad', lambda a: (_out_rows(a[3], a[5], a[6], a[4], a[9], a[10], a[11], a[12]), a[8], a[9] * a[10] * a[7]),

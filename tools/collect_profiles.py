@@ -19,7 +19,7 @@ pairs = [('bench_f16.json', 'bench_f16.json'), ('bench_bf16_trainf32.json', 'ben
          ('conv_tiles.txt', 'conv_tiles.txt'), ('conv_tiles_bf16.txt', 'conv_tiles_bf16.txt'),
          ('layers.txt', 'conv_layers.txt'), ('layers_bf16.txt', 'conv_layers_bf16.txt'),
          ('op_bench.json', 'op_bench.json'), ('conv_pmc_layers_bf16.txt', 'conv_pmc_layers_bf16.txt'), ('recipes.json', 'recipes.json'), ('recipes_bf16.json', 'recipes_bf16.json'), ('pytest_gpu.txt', 'pytest_gpu.txt'),
-         ('wgrad_pp_bench.txt', 'wgrad_pp_bench.txt'), ('roi_variants.txt', 'roi_variants.txt')]
+         ('wgrad_pp_bench.txt', 'wgrad_pp_bench.txt'), ('stem_bench.txt', 'stem_bench.txt'), ('roi_variants.txt', 'roi_variants.txt')]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p):

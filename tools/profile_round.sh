@@ -4,7 +4,7 @@
 # under rocprofv3 the profiler's preloaded library initialises HIP before Python runs: the queue count must be
 # in the environment already (bench.py / the tools only `setdefault` it for unprofiled runs)
 export GPU_MAX_HW_QUEUES=8
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -41,6 +41,7 @@ python tools/layers.py > $O/layers.txt 2>&1
 BRCNN_DTYPE=bf16 python tools/layers.py > $O/layers_bf16.txt 2>&1
 python tools/train_layers.py > $O/train_layers_bf16.txt 2>&1
 BRCNN_DTYPE=f32 python tools/train_layers.py > $O/train_layers_f32.txt 2>&1
+python tools/experiments/r06/stem_bench.py > $O/stem_bench.txt 2>&1
 python tools/bench_recipes.py > $O/recipes.txt 2>&1
 cp gpurun_out/recipes.json $O/recipes.json 2>/dev/null
 cat $O/pytest_gpu.txt; cut -c1-400 $O/bench.json; ls $O/stats
