@@ -42,11 +42,15 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const SgdTable t, f
     const SgdEntry& e = t.e[lo];
     const int base = ((int)blockIdx.x - e.blk0) * 1024;
     float s = 0.f;
+    float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 4; j++) {       // (unconditional loads, all four in flight; an index past the end re-reads the last element, weight 0)
         const int i = base + j * 256 + threadIdx.x;
-        if (i < e.n) { const float v = e.g[i]; s += v * v; }
+        const float g = e.g[min(i, e.n - 1)];
+        v[j] = i < e.n ? g : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) s += v[j] * v[j];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -94,6 +98,32 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(const SgdTable t, const
     }
     const SgdEntry& e = t.e[lo];
     const int base = ((int)blockIdx.x - e.blk0) * 1024;
+    // four consecutive elements per thread as 16-byte accesses where the tensor allows it (all but a handful do): the
+    // three loads of a thread go out together.  The scalar form below has each load under `if (i < n)` inside the j loop,
+    // which the compiler serialises (one 4-byte load in flight per wave); same arithmetic per element either way.
+    if ((e.n & 3) == 0 && ((((uintptr_t)e.w) | ((uintptr_t)e.g) | ((uintptr_t)e.buf)) & 15) == 0) {
+        const int i = base + 4 * (int)threadIdx.x;
+        if (i < e.n) {
+            const float4 w4 = *reinterpret_cast<const float4*>(e.w + i);
+            const float4 g4 = *reinterpret_cast<const float4*>(e.g + i);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (momentum != 0.f && e.has_buf) b4 = *reinterpret_cast<const float4*>(e.buf + i);
+            const float w[4] = {w4.x, w4.y, w4.z, w4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w}, bo[4] = {b4.x, b4.y, b4.z, b4.w};
+            float wn[4], bn[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float d = g[k] * coef;
+                if (e.wd != 0.f) d = d + e.wd * w[k];
+                float b = d;
+                if (momentum != 0.f && e.has_buf) b = momentum * bo[k] + d;
+                bn[k] = b;
+                wn[k] = w[k] - e.lr * b;
+            }
+            if (momentum != 0.f) *reinterpret_cast<float4*>(e.buf + i) = make_float4(bn[0], bn[1], bn[2], bn[3]);
+            *reinterpret_cast<float4*>(e.w + i) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int i = base + j * 256 + threadIdx.x;
