@@ -1,4 +1,5 @@
-"""ISA gate of the build: no packed-fp32 VALU instruction may SWIZZLE a VGPR-pair operand.
+"""ISA gates of the build.  (1) ADVICE r04: no packed-fp32 VALU instruction may SWIZZLE a VGPR-pair operand; (2) round 6:
+the listed streaming kernels keep their loads in flight in batches (`MIN_LOADS_IN_FLIGHT` below).
 
 Round 4 traced an intermittent wrong dgamma of `bn_act_bwd_kernel` (3 of 400 repetitions, fp16, only with a
 weight-gradient kernel co-resident) to `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` reading the result of a
@@ -93,6 +94,36 @@ def swizzled_packed_fp32(code_object):
     return bad, total, bcast
 
 
+# Second gate (round 6): kernels whose vector-memory loads must go out in batches.  A load under a per-element branch
+# inside an unrolled loop compiles to load / s_waitcnt vmcnt(0) / use, one load in flight per wave -- found in the first
+# fused-stem kernel (six serial memory latencies per tile), `gn_stats_kernel` and `sqnorm_partial_kernel`; the fix is an
+# unconditional load from a clamped address + a select.  For the kernels below the longest run of global / buffer loads
+# with no `s_waitcnt vmcnt` in between must not fall under the listed count again.
+MIN_LOADS_IN_FLIGHT = {'stem_pool_kernel': 12, 'gn_stats_kernel': 8, 'sqnorm_partial_kernel': 4}
+_LOAD = re.compile(r'^\s*(global_load_|buffer_load_)(?!.*\blds\b)')
+_WAITVM = re.compile(r'^\s*s_waitcnt\b.*vmcnt')
+
+
+def load_batches(code_object):
+    """{kernel symbol: longest run of vector-memory loads issued without waiting for one} of a code object"""
+    out = subprocess.run([objdump(), '-d', code_object], check=True, capture_output=True, text=True).stdout
+    best, sym, run = {}, None, 0
+    for line in out.splitlines():
+        m = _SYM.match(line)
+        if m:
+            sym, run = m.group(1), 0
+            best.setdefault(sym, 0)
+            continue
+        if sym is None:
+            continue
+        if _LOAD.match(line):
+            run += 1
+            best[sym] = max(best[sym], run)
+        elif _WAITVM.match(line):
+            run = 0
+    return best
+
+
 def check_objects(objs, verbose=False, hipcc=None):
     """raise RuntimeError if any object holds a swizzled packed-fp32 instruction; without an llvm-objdump the gate is
     skipped with a warning (the compile itself succeeded: a missing disassembler must not fail the build)"""
@@ -101,7 +132,7 @@ def check_objects(objs, verbose=False, hipcc=None):
         warnings.warn('brcnn build: llvm-objdump not found (looked beside hipcc, in $LLVM_OBJDUMP, PATH, /opt/rocm): '
                       'the packed-fp32 ISA gate was SKIPPED for this build')
         return None
-    problems = []
+    problems, serial = [], []
     with tempfile.TemporaryDirectory() as wd:
         for obj in objs:
             co = device_code_object(obj, wd)
@@ -109,6 +140,13 @@ def check_objects(objs, verbose=False, hipcc=None):
             if verbose:
                 print(f'{os.path.basename(obj):32s} packed-fp32 instructions {total:6d}  broadcast form {bcast:5d}  cross-swizzled {len(bad)}')
             problems += [(os.path.basename(obj),) + b for b in bad]
+            for sym, n in load_batches(co).items():
+                for name, need in MIN_LOADS_IN_FLIGHT.items():
+                    if name in sym and n < need:
+                        serial.append(f'  {os.path.basename(obj)}: {sym}: at most {n} loads in flight, {need} expected')
+    if serial:
+        raise RuntimeError('vector-memory loads serialised behind a branch (brcnn/check_isa.py MIN_LOADS_IN_FLIGHT; load from a '
+                           'clamped address unconditionally and select):\n' + '\n'.join(serial))
     if problems:
         lines = '\n'.join(f'  {o}: {k}: {t}' for o, k, t in problems[:40])
         raise RuntimeError(f'{len(problems)} packed-fp32 instruction(s) with a cross-swizzled VGPR operand (tools/check_isa.py; '

@@ -470,3 +470,29 @@ def test_host_thread_cap_follows_affinity_and_cgroup_quota(monkeypatch):
         assert apis.limit_host_threads() == 8       # the user's setting wins
     finally:
         torch.set_num_threads(before)
+
+
+def test_isa_gates_pass_on_the_built_library_and_catch_a_serialised_load():
+    """`check_isa` (run by every library build): the packed-fp32 gate and the loads-in-flight gate pass on the objects of
+    the shipped library; the second gate's counter sees through a listing what a per-element branch does to a loop"""
+    from brcnn import check_isa
+    objdir = os.path.join(ROOT, 'boosting-r-cnn_amd', 'lib', 'obj')
+    objs = sorted(os.path.join(objdir, f) for f in os.listdir(objdir) if f.endswith('.o'))
+    assert objs, 'run `python __graft_entry__.py` to build the HIP library'
+    if check_isa.objdump() is None:
+        pytest.skip('no llvm-objdump on this machine')
+    assert check_isa.check_objects(objs) is True
+    import tempfile
+    with tempfile.TemporaryDirectory() as wd:
+        co = check_isa.device_code_object(os.path.join(objdir, 'stem_pool.o'), wd)
+        runs = check_isa.load_batches(co)
+    stem = [n for s, n in runs.items() if 'stem_pool_kernel' in s]
+    assert len(stem) == 3 and min(stem) >= check_isa.MIN_LOADS_IN_FLIGHT['stem_pool_kernel']
+    # the counter itself, on two hand-written listings
+    import subprocess
+    from unittest import mock
+    batched = '0000 <k_batched>:\n global_load_dword v1, v[2:3], off // 0\n global_load_dword v4, v[2:3], off // 4\n s_waitcnt vmcnt(0) // 8\n'
+    serial = '0000 <k_serial>:\n global_load_dword v1, v[2:3], off // 0\n s_waitcnt vmcnt(0) // 4\n global_load_dword v4, v[2:3], off // 8\n s_waitcnt vmcnt(0) lgkmcnt(0) // c\n'
+    fake = mock.Mock(stdout=batched + serial)
+    with mock.patch.object(subprocess, 'run', return_value=fake):
+        assert check_isa.load_batches('x') == {'k_batched': 2, 'k_serial': 1}
