@@ -96,10 +96,12 @@ def swizzled_packed_fp32(code_object):
 
 # Second gate (round 6): kernels whose vector-memory loads must go out in batches.  A load under a per-element branch
 # inside an unrolled loop compiles to load / s_waitcnt vmcnt(0) / use, one load in flight per wave -- found in the first
-# fused-stem kernel (six serial memory latencies per tile), `gn_stats_kernel` and `sqnorm_partial_kernel`; the fix is an
+# fused-stem kernel (six serial memory latencies per tile), `gn_stats_kernel`, `sqnorm_partial_kernel` and the RoI gradient
+# gather (`c_ok ? load : 0` = seven exec-masked blocks with a wait each per bin row); the fix is an
 # unconditional load from a clamped address + a select.  For the kernels below the longest run of global / buffer loads
 # with no `s_waitcnt vmcnt` in between must not fall under the listed count again.
-MIN_LOADS_IN_FLIGHT = {'stem_pool_kernel': 12, 'gn_stats_kernel': 8, 'sqnorm_partial_kernel': 4}
+MIN_LOADS_IN_FLIGHT = {'stem_pool_kernel': 12, 'gn_stats_kernel': 8, 'sqnorm_partial_kernel': 4,
+                       'roi_grad_gather_kernel': 7, 'roi_align_fwd_nhwc_fp_kernel': 7}
 _LOAD = re.compile(r'^\s*(global_load_|buffer_load_)(?!.*\blds\b)')
 _WAITVM = re.compile(r'^\s*s_waitcnt\b.*vmcnt')
 

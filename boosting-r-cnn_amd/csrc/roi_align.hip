@@ -1168,7 +1168,6 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
     __shared__ int s_hits[MAXHIT];
     __shared__ int s_wcnt[4];
     __shared__ int s_nhit;
-    __shared__ float s_wx[4][4][8], s_wy[4][4][8];       // per wave (a 4 x 4 pixel quadrant): [col][pw], [row][ph]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int l = 0;
@@ -1247,11 +1246,15 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                 const int k = s_hits[hi];
                 const float* roi = rois + (size_t)k * 5;
                 const RoiGeom g = roi_geom(roi, scale, 1, ph_n, pw_n, sampling_ratio);
-                // Wx[col][pw] on lanes 0..27, Wy[row][ph] on lanes 32..59 (4 columns / rows x 7 bins each)
+                // Wx[col][pw] on lanes 0..27, Wy[row][ph] on lanes 32..59 (4 columns / rows x 7 bins each).  The weights
+                // STAY in the lanes that computed them: the loops below fetch them with v_readlane (compile-time lane
+                // numbers) and the zero tests are one ballot.  (Until round 6 they went through LDS: a write, a wave
+                // barrier, and -- what the listing showed -- 28 + 28 broadcast reads per hit, each behind its own wait
+                // because the `||` chain of the zero tests short-circuits.)
+                float w = 0.f;
                 {
                     const int half = lane >> 5, li = lane & 31;
                     const int pix = li / 7, bin = li - pix * 7;
-                    float w = 0.f;
                     if (li < 28 && bin < (half ? ph_n : pw_n)) {
                         const int p = (half ? wr0 : wc0) + pix;
                         const float start = half ? g.start_h : g.start_w, bsz = half ? g.bin_h : g.bin_w;
@@ -1266,32 +1269,32 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                         }
                         if (half) w = w / g.count;
                     }
-                    if (li < 28) (half ? s_wy : s_wx)[wave][pix][bin] = w;
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                const T* go = grad_output + (size_t)k * ph_n * pw_n * channels + c;
-                // the bins whose x weights touch this quadrant (a contiguous run: the bins are monotonic in x); wave-uniform
-                unsigned pwm = 0u;
+                const int wbits = __float_as_int(w);
+                // bins with a non-zero weight on any of the quadrant's four columns / rows (wave-uniform)
+                const unsigned long long nz = __ballot(w != 0.f);
+                const unsigned nzx = (unsigned)(nz & 0xfffffffull), nzy = (unsigned)((nz >> 32) & 0xfffffffull);
+                const unsigned pwm = (nzx | (nzx >> 7) | (nzx >> 14) | (nzx >> 21)) & 0x7fu;
+                const unsigned phm = (nzy | (nzy >> 7) | (nzy >> 14) | (nzy >> 21)) & 0x7fu;
+                if (!pwm || !phm) continue;
+                // (a lane beyond the channel count reads channel 0 and never stores: no branch around the loads)
+                const T* go = grad_output + (size_t)k * ph_n * pw_n * channels + (c_ok ? c : 0);
 #pragma unroll
-                for (int pw = 0; pw < 7; pw++)
-                    if (pw < pw_n && (s_wx[wave][0][pw] != 0.f || s_wx[wave][1][pw] != 0.f || s_wx[wave][2][pw] != 0.f ||
-                                      s_wx[wave][3][pw] != 0.f))
-                        pwm |= 1u << pw;
-                pwm = (unsigned)__builtin_amdgcn_readfirstlane((int)pwm);
-                for (int ph = 0; ph < ph_n && pwm; ph++) {
-                    const float wy0 = s_wy[wave][0][ph], wy1 = s_wy[wave][1][ph], wy2 = s_wy[wave][2][ph], wy3 = s_wy[wave][3][ph];
-                    if (wy0 == 0.f && wy1 == 0.f && wy2 == 0.f && wy3 == 0.f) continue;
-                    const float wys[4] = {wy0, wy1, wy2, wy3};
+                for (int ph = 0; ph < 7; ph++) {
+                    if (!((phm >> ph) & 1u)) continue;          // (also every ph >= ph_n: those lanes hold 0)
+                    float wys[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) wys[r] = __int_as_float(__builtin_amdgcn_readlane(wbits, 32 + r * 7 + ph));
                     // the dY rows of ALL bins of this bin row are requested together, unconditionally and in straight-line
-                    // code (round 6: seven loads in flight per wave instead of four behind a branch each -- a quadrant of a
-                    // small RoI needs all 49 bins, and the chain of load batches is what a (tile, hit) pair costs), then
-                    // accumulated in bin order where the x weights are not all zero: the summation order is unchanged
+                    // code: seven loads in flight per wave (round 6, second pass: the first form had `c_ok ? load : 0`,
+                    // which the compiler turned into seven exec-masked blocks with a vmcnt(0) each -- seven memory latencies
+                    // in a row per bin row, found by the loads-in-flight scan of check_isa), then accumulated in bin order
+                    // where the x weights are not all zero: the summation order is unchanged
                     float4 gv[7];
 #pragma unroll
                     for (int j = 0; j < 7; j++) {
                         const int pwj = j < pw_n ? j : pw_n - 1;
-                        gv[j] = c_ok ? ld4(go + (size_t)(ph * pw_n + pwj) * channels) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        gv[j] = ld4(go + (size_t)(ph * pw_n + pwj) * channels);
                     }
                     // separable accumulation (round 6: the gather was VALU-bound -- 16 pixels x 7 bins x 4 channels of
                     // multiply-adds per bin row and lane, 560 VALU operations, most of them on zero weights):
@@ -1307,7 +1310,7 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                         if (!((pwm >> j) & 1u)) continue;
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const float wx = s_wx[wave][q][j];
+                            const float wx = __int_as_float(__builtin_amdgcn_readlane(wbits, q * 7 + j));
                             tq[q].x += wx * gv[j].x;
                             tq[q].y += wx * gv[j].y;
                             tq[q].z += wx * gv[j].z;
@@ -1324,7 +1327,6 @@ __global__ __launch_bounds__(256) void roi_grad_gather_kernel(const T* __restric
                             acc[r * 4 + q].w += wys[r] * tq[q].w;
                         }
                 }
-                __builtin_amdgcn_wave_barrier();
             }
             hit0 += nhit;
             __syncthreads();
