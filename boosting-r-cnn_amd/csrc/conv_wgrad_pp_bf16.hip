@@ -536,9 +536,14 @@ __global__ __launch_bounds__(256) void wgrad_pp_reduce_kernel(float* __restrict_
         const int co = tco * TILE + (a >> 1) * 128 + wm * 64 + (a & 1) * 32 + 8 * g + 4 * (lane >> 5);
         if (kk >= K) return;
         const float sv[4] = {s.x, s.y, s.z, s.w};
+        // dw += sum: the four old values are requested together (rows clamped into the tensor), then the stores -- as
+        // `dw[..] += sv[j]` under `if (co + j < Cout)` the four read-modify-writes ran one memory latency after the other
+        float old[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) old[j] = dw[(size_t)min(co + j, Cout - 1) * K + kk];
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (co + j < Cout) dw[(size_t)(co + j) * K + kk] += sv[j];
+            if (co + j < Cout) dw[(size_t)(co + j) * K + kk] = old[j] + sv[j];
     }
 }
 
