@@ -780,9 +780,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (long long)rows_per_block);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cv < c4n && rl < RL)
-        for (long long r = r0 + rl; r < r1; r += RL) {
-            const float4 v = ld4(x + (size_t)r * C + cv * 4);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        // eight rows per batch, loaded unconditionally (a row beyond the strip re-reads the strip's last row and is not
+        // added): the plain `for r: acc += x[r]` loop kept ONE load in flight per wave; same sums in the same order
+        for (long long r = r0 + rl; r < r1; r += 8 * RL) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = ld4(x + (size_t)min(r + (long long)u * RL, r1 - 1) * C + cv * 4);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r + (long long)u * RL < r1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     red[threadIdx.x][0] = acc.x; red[threadIdx.x][1] = acc.y; red[threadIdx.x][2] = acc.z; red[threadIdx.x][3] = acc.w;
     __syncthreads();

@@ -176,10 +176,18 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackTable t, cons
     (void)tco;
     const int a = tap / e.kw, b = tap - a * e.kw;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8) {                            // rows = co, columns = ci
-        const int co = co0 + j, ci = ci0 + tx;
-        const size_t src = e.src_cl ? ((size_t)co * taps + tap) * e.cin + ci : ((size_t)co * e.cin + ci) * taps + tap;
-        tile[j][tx] = (co < e.cout && ci < e.cin) ? e.w[src] : 0.f;
+    {                                                             // rows = co, columns = ci
+        // the four loads of a thread go out together (clamped index + select: under the bounds test each waited for the
+        // one before it)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int co = min(co0 + ty + 8 * u, e.cout - 1), ci = min(ci0 + tx, e.cin - 1);
+            const size_t src = e.src_cl ? ((size_t)co * taps + tap) * e.cin + ci : ((size_t)co * e.cin + ci) * taps + tap;
+            v[u] = e.w[src];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) tile[ty + 8 * u][tx] = (co0 + ty + 8 * u < e.cout && ci0 + tx < e.cin) ? v[u] : 0.f;
     }
     __syncthreads();
     T* fwd = reinterpret_cast<T*>(e.fwd);
