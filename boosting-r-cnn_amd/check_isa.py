@@ -101,7 +101,8 @@ def swizzled_packed_fp32(code_object):
 # unconditional load from a clamped address + a select.  For the kernels below the longest run of global / buffer loads
 # with no `s_waitcnt vmcnt` in between must not fall under the listed count again.
 MIN_LOADS_IN_FLIGHT = {'stem_pool_kernel': 12, 'gn_stats_kernel': 8, 'sqnorm_partial_kernel': 4,
-                       'roi_grad_gather_kernel': 7, 'roi_align_fwd_nhwc_fp_kernel': 7}
+                       'roi_grad_gather_kernel': 7, 'roi_align_fwd_nhwc_fp_kernel': 7, 'colsum_partial_kernel': 7,
+                       'pack_batch_kernel': 4}
 _LOAD = re.compile(r'^\s*(global_load_|buffer_load_)(?!.*\blds\b)')
 _WAITVM = re.compile(r'^\s*s_waitcnt\b.*vmcnt')
 
