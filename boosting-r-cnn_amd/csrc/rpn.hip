@@ -237,16 +237,36 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, in
         for (int i = tid; i < n; i += 1024) { os[i] = sc[i]; oi[i] = imap ? imap[i] : (int64_t)(i + iadd); }
         return;
     }
+    // the job's keys stay in registers over the five passes (every job the host builds is <= 32 768 long: 32 per thread,
+    // loaded once, all loads in flight); longer rows fall back to re-reading the scores.  Round 6: each pass was
+    // `for i: key(sc[i]) -> LDS atomic`, one dependent load per iteration -- 5 x 20-32 serial L2 latencies per launch.
+    constexpr int EPT = 32;
+    const bool cached = n <= EPT * 1024;
+    unsigned dkr[EPT];
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) dkr[j] = desc_key(sc[min(tid + j * 1024, n - 1)]);
+    }
+    auto for_each_key = [&](auto&& f) {
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                const int i = tid + j * 1024;
+                if (i < n) f(i, dkr[j]);
+            }
+        } else {
+            for (int i = tid; i < n; i += 1024) f(i, desc_key(sc[i]));
+        }
+    };
     unsigned prefix = 0u, mask = 0u;
     int need = k;
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned dk = desc_key(sc[i]);
+        for_each_key([&](int, unsigned dk) {
             if ((dk & mask) == prefix) atomicAdd(&hist[(dk >> shift) & 255u], 1);
-        }
+        });
         __syncthreads();
         // the digit whose cumulative count first reaches `need`: a 256-wide scan (a single thread
         // walking the bins cost ~25 us per launch over the four passes)
@@ -292,8 +312,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, in
     if (tid == 0) s_cnt = 0;
     for (int i = k + tid; i < KP; i += 1024) sel[i] = ~0ull;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const unsigned dk = desc_key(sc[i]);
+    for_each_key([&](int i, unsigned dk) {
         if (dk < T) {
             const int pos = atomicAdd(&s_cnt, 1);
             sel[pos] = ((unsigned long long)dk << 32) | (unsigned)i;
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(TopkLevels lv, int k, in
             const int pos = nless + atomicAdd(&s_ties, -1) - 1;      // any order: all ties are in
             sel[pos] = ((unsigned long long)dk << 32) | (unsigned)i;
         }
-    }
+    });
     if (ties != need) {                 // more ties than room: the lowest indices win
         const int lane = tid & 63, wave = tid >> 6;
         int base = 0;
