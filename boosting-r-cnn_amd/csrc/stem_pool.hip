@@ -136,9 +136,21 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemPoolParams p) {
     }
 
     float nxt[ITS][3];
-    int tile = blockIdx.x;
-    if (tile < total) load_tile(tile, nxt);
-    for (; tile < total; tile += gridDim.x) {
+    // tile order: workgroup b runs on XCD b % 8 (each with its own L2); XCD x takes the x-th eighth of the tile list and
+    // its workgroups walk it side by side, so tiles that share halo pixels (35 x 39 input pixels per 28 x 32 net) meet in
+    // ONE L2 instead of being fetched into eight (the plain b, b + grid, ... order: 357 MB of HBM reads per launch for a
+    // 103 MB image batch, r06_conv_traffic.json).  A grid that is no multiple of 8 (fewer tiles than slots) keeps the plain order.
+    int tile, tile_end = total, step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (total + 7) >> 3, xcd = blockIdx.x & 7;
+        tile = xcd * per + (int)(blockIdx.x >> 3);
+        tile_end = min(total, (xcd + 1) * per);
+        step = gridDim.x >> 3;
+    } else {
+        tile = blockIdx.x;
+    }
+    if (tile < tile_end) load_tile(tile, nxt);
+    for (; tile < tile_end; tile += step) {
         int n, i0, j0;
         tile_coords(tile, n, i0, j0);
         const int cr0 = 2 * i0 - 1, cc0 = 2 * j0 - 1;   // first conv output of the tile (may be -1: pool padding)
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemPoolParams p) {
             }
         }
         lds_barrier();
-        if (tile + (int)gridDim.x < total) load_tile(tile + gridDim.x, nxt);
+        if (tile + step < tile_end) load_tile(tile + step, nxt);
 
         // ---- 256 x 64 outputs = 2 x 2 MFMA tiles per wave.  Operand A = conv positions (accumulator rows), B = channels
         // (accumulator column = lane & 31)
