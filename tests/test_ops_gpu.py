@@ -667,6 +667,16 @@ def test_fused_stem_and_pool_matches_float64():
         y = y.permute(0, 3, 1, 2).cpu().double()
         assert y.shape == ref.shape
         assert (y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+        # the raw C ABI refuses what the kernel does not cover (another channel count, an unknown dtype, a NULL image)
+        from brcnn import lib
+        L = lib.load()
+        wq = ops.pack_stem_pool_weight(wt.to(DEV))
+        yq = torch.empty((n, y.shape[2], y.shape[3], 64), device=DEV)
+        imgd = img.to(DEV)
+        args = lambda cout, dt, im: (im, wq.data_ptr(), None, None, yq.data_ptr(), n, h, w, cout, dt, lib.raw_stream_handle())
+        assert L.brcnn_stem7x7s2_pool_nchw(*args(32, 0, imgd.data_ptr())) == -22
+        assert L.brcnn_stem7x7s2_pool_nchw(*args(64, 7, imgd.data_ptr())) == -22
+        assert L.brcnn_stem7x7s2_pool_nchw(*args(64, 0, None)) == -22
         # ... and the two-launch form it replaces, to fp32 round-off (another summation order)
         y2 = ops.maxpool3x3s2_nhwc(ops.stem7x7s2_nchw(img.to(DEV), ops.pack_stem_weight(wt.to(DEV)), sc.to(DEV), sh.to(DEV), True))
         assert (y2.permute(0, 3, 1, 2).cpu().double() - y).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
