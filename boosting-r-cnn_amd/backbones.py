@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .blocks import PackedCache, build_norm_layer, conv_bn_act_nhwc, to_nchw_view, to_nhwc
+from .blocks import PackedCache, build_norm_layer, conv_bn_act_nhwc, folded_conv_operands, to_nchw_view, to_nhwc
 from .registry import BACKBONES
 
 
@@ -41,6 +41,25 @@ class Bottleneck(nn.Module):
 
     chain_fusion = True        # ResLayer may pass `out_single_use` / `in_from_prev`
 
+    FUSE_TAIL = os.environ.get('BRCNN_FUSE_BLOCK_TAIL', '1') != '0'
+
+    def _tail_fusable(self, out, identity):
+        """conv2 + bn2 + relu + conv3 + bn3 + identity + relu as one launch: fp32, nothing to differentiate, the 64 -> 64 (3x3,
+        stride 1) -> 256 shape of stage 1"""
+        from .autograd import wants_grad
+        c2, c3 = self.conv2, self.conv3
+        if not (self.FUSE_TAIL and type(self) is Bottleneck and out.is_cuda and out.dtype == torch.float32 and
+                identity.dtype == torch.float32 and not self.bn2.training and not self.bn3.training):
+            return False
+        if not (c2.kernel_size == (3, 3) and c2.stride == (1, 1) and c2.padding == (1, 1) and c2.dilation == (1, 1) and
+                c2.groups == 1 and c2.in_channels == 64 and c2.out_channels == 64 and c2.bias is None and
+                c3.kernel_size == (1, 1) and c3.stride == (1, 1) and c3.groups == 1 and c3.in_channels == 64 and
+                c3.out_channels == 256 and c3.bias is None):
+            return False
+        if out.dim() != 4 or (out.shape[0] * out.shape[1] * out.shape[2]) % 64 or tuple(identity.shape) != tuple(out.shape[:3]) + (256,):
+            return False
+        return not wants_grad(out, identity, c2.weight, c3.weight, self.bn2.weight, self.bn2.bias, self.bn3.weight, self.bn3.bias)
+
     def forward_nhwc(self, x, out_single_use=False, in_from_prev=False):
         """`out_single_use`: the caller promises that the result feeds only the next block of the stage (whose
         conv1 then runs bn3's backward inside its data-gradient launch); `in_from_prev`: x is such a result"""
@@ -54,6 +73,12 @@ class Bottleneck(nn.Module):
             # conv1's data-gradient epilogue too (stride-1 conv1, the 'pytorch' style) instead of by an autograd add
             out, xs = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True, single_use_output=True)
             identity = conv_bn_act_nhwc(xs, self.downsample[0], self.downsample[1], self._c[3], False)
+        if self._tail_fusable(out, identity):
+            # frozen / inference fp32 block with 64 -> 64 -> 256 channels (stage 1): conv2 .. the block's ReLU in ONE launch,
+            # the 64-channel intermediate stays in LDS (csrc/bottleneck_tail_f32.hip; bit-identical to the two launches)
+            w2, s2, b2 = folded_conv_operands(self.conv2, self.bn2, self._c[1], out.dtype)
+            w3, s3, b3 = folded_conv_operands(self.conv3, self.bn3, self._c[2], out.dtype)
+            return ops.bottleneck_tail_nhwc(out, w2, s2, b2, w3, s3, b3, identity)
         # out of conv1 / conv2 feeds the next conv only: that conv's data-gradient launch runs bn1's / bn2's backward
         out = conv_bn_act_nhwc(out, self.conv2, self.bn2, self._c[1], True, sole_consumer=True, single_use_output=True)
         # relu(bn3(conv3(out)) + identity) in one epilogue (resnet.py:288-300)

@@ -238,11 +238,19 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False, s
         if residual is not None:
             y = y + residual
         return y.relu() if relu else y
+    w, scale, shift = folded_conv_operands(conv, bn, cache, x.dtype)
+    out = ops.conv2d_nhwc(x, w, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
+    return (out, x) if with_skip else out
+
+
+def folded_conv_operands(conv, bn, cache, dtype):
+    """(packed weight (Cout,KH,KW,Cin) in `dtype`, scale, shift) of a frozen / inference conv + eval-BN pair, from the
+    layer's PackedCache (rebuilt when a source parameter changes version)"""
     srcs = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var]
                                        if bn is not None else [])
 
     def builder():
-        w = pack_weight(conv.weight).to(x.dtype)
+        w = pack_weight(conv.weight).to(dtype)
         if bn is not None:
             scale, shift = fold_bn(bn)
             if conv.bias is not None:
@@ -250,9 +258,7 @@ def conv_bn_act_nhwc(x, conv, bn, cache, relu, residual=None, with_skip=False, s
             return w, scale, shift
         return w, None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
 
-    w, scale, shift = cache.get(srcs, builder)
-    out = ops.conv2d_nhwc(x, w, scale, shift, residual, relu, conv.stride[0], conv.padding[0])
-    return (out, x) if with_skip else out
+    return cache.get(srcs, builder)
 
 
 def _grouped_conv_bn_act_nhwc(x, conv, bn, cache, relu, residual):

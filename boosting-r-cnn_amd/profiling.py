@@ -137,15 +137,30 @@ def record_conv_launches(records):
         ho, wo = ops.conv_out_size(img.shape[2], img.shape[3], 7, 7, 2, 3)
         stem_record(s, e, img, y, img.shape[0] * ho * wo)
         return y
+    orig_tail = ops.bottleneck_tail_nhwc
+
+    def wrapped_tail(x, w2, scale2, shift2, w3, scale3, shift3, identity):
+        # the fused 3x3 (64 -> 64) + 1x1 (64 -> 256) launch: both GEMMs' products; bytes = x, weights, identity, y (the
+        # 64-channel intermediate does not exist).  Shape label: the 256-column GEMM with the same product count (K = 208)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        y = orig_tail(x, w2, scale2, shift2, w3, scale3, shift3, identity)
+        e.record()
+        m = x.shape[0] * x.shape[1] * x.shape[2]
+        nbytes = 4 * (x.numel() + w2.numel() + w3.numel() + identity.numel() + y.numel())
+        records.append((s, e, 2.0 * m * (w2.numel() + w3.numel()), nbytes, (m, 256, (w2.numel() + w3.numel()) // 256)))
+        return y
     ops.conv2d_nhwc = wrapped
     ops.conv2d_nhwc_multi = wrapped_multi
     ops.stem7x7s2_nchw, ops.stem7x7s2_pool_nchw = wrapped_stem, wrapped_stem_pool
+    ops.bottleneck_tail_nhwc = wrapped_tail
     try:
         yield
     finally:
         ops.conv2d_nhwc = orig
         ops.conv2d_nhwc_multi = orig_multi
         ops.stem7x7s2_nchw, ops.stem7x7s2_pool_nchw = orig_stem, orig_stem_pool
+        ops.bottleneck_tail_nhwc = orig_tail
 
 
 def conv_stack_roofline(model, img, metas, iters=5, dtype='f32'):

@@ -437,6 +437,14 @@ int brcnn_stem7x7s2_nchw(const float *img, const void *w_packed, const float *sc
 int brcnn_stem7x7s2_pool_nchw(const float *img, const void *w_packed, const float *scale, const float *shift,
                               void *y, int batch, int height, int width, int cout, int dtype, void *stream);
 
+/* Tail of a frozen stage-1 Bottleneck (resnet.py Bottleneck.forward:263-302) in one fp32 launch:
+ * y = relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(x))))) + identity), x (N,H,W,64), w2 (64,3,3,64), w3 (256,1,1,64) packed
+ * (Cout,KH,KW,Cin), scale / shift = the folded eval-mode BatchNorms (NULL: 1 / 0), identity / y (N,H,W,256); N*H*W must be
+ * a multiple of 64.  The 64-channel intermediate stays in LDS; bit-identical to the two brcnn_conv2d_nhwc launches. */
+int brcnn_bottleneck_tail_f32(const float *x, const float *w2, const float *scale2, const float *shift2, const float *w3,
+                              const float *scale3, const float *shift3, const float *identity, float *y, int batch,
+                              int height, int width, void *stream);
+
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,
                             int channels, int dtype, void *stream);

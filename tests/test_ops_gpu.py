@@ -682,6 +682,29 @@ def test_fused_stem_and_pool_matches_float64():
         assert (y2.permute(0, 3, 1, 2).cpu().double() - y).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_fused_bottleneck_tail_equals_the_two_launches_bit_for_bit():
+    """conv2 3x3 + bn2 + relu + conv3 1x1 + bn3 + identity + relu of a frozen stage-1 block in one launch
+    (csrc/bottleneck_tail_f32.hip): same K order, same MFMA sequence, same epilogue arithmetic as the two conv launches, the
+    intermediate an fp32 tile either way -> torch.equal; image borders, several images, one tile per image row"""
+    g = torch.Generator().manual_seed(77)
+    for (n, h, w) in [(1, 8, 8), (2, 16, 24), (3, 8, 40), (2, 50, 64)]:
+        x = torch.randn(n, h, w, 64, generator=g).to(DEV)
+        idn = torch.randn(n, h, w, 256, generator=g).to(DEV)
+        w2 = (torch.randn(64, 3, 3, 64, generator=g) / 24).to(DEV)
+        w3 = (torch.randn(256, 1, 1, 64, generator=g) / 8).to(DEV)
+        s2, b2 = (torch.rand(64, generator=g) + 0.5).to(DEV), torch.randn(64, generator=g).to(DEV)
+        s3, b3 = (torch.rand(256, generator=g) + 0.5).to(DEV), torch.randn(256, generator=g).to(DEV)
+        t = ops.conv2d_nhwc(x, w2, s2, b2, None, True, 1, 1)
+        ref = ops.conv2d_nhwc(t, w3, s3, b3, idn, True, 1, 0)
+        assert ops.bottleneck_tail_supported(x, w2, w3, idn)
+        y = ops.bottleneck_tail_nhwc(x, w2, s2, b2, w3, s3, b3, idn)
+        assert torch.equal(y, ref), (n, h, w, (y - ref).abs().max().item())
+        # no BatchNorm operands: plain convs
+        ref0 = ops.conv2d_nhwc(ops.conv2d_nhwc(x, w2, None, None, None, True, 1, 1), w3, None, None, idn, True, 1, 0)
+        assert torch.equal(ops.bottleneck_tail_nhwc(x, w2, None, None, w3, None, None, idn), ref0)
+    assert not ops.bottleneck_tail_supported(torch.zeros(1, 5, 5, 64, device=DEV), w2, w3, torch.zeros(1, 5, 5, 256, device=DEV))
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_bn_act_fused_forward_backward(dtype):
     """fused eval-BN affine (+residual) + ReLU and its backward against the torch ops it replaces"""
