@@ -35,7 +35,9 @@ for name in ('fetch', 'write'):
         # every kernel under its own name (conv_pp_f32_kernel, conv_igemm_f32_dma_kernel, ... separately), and every
         # conv / FC launch of the pass once more under the aggregate key the bench line's `roofline.traffic` reads
         keys = [short_name(r['Kernel_Name'])]
-        if 'conv_igemm' in r['Kernel_Name'] or 'conv_pp_' in r['Kernel_Name'] or 'conv1x1_stream' in r['Kernel_Name']:
+        # (round 6: the stem + max-pool launch and the fused stage-1 block tails are conv launches of the pass too -- the bench
+        # line's roofline counts their products)
+        if any(k in r['Kernel_Name'] for k in ('conv_igemm', 'conv_pp_', 'conv1x1_stream', 'stem_pool_kernel', 'bottleneck_tail')):
             keys.append('conv_stack_all_launches')
         for k in keys:
             tot[k][r['Counter_Name']] += float(r['Counter_Value'])
@@ -60,7 +62,7 @@ try:
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     n_conv = 0
     for r in csv.DictReader(open(f'gpurun_out/{rnd}/pmc_sq/step_counter_collection.csv')):
-        for key in ('conv_igemm', 'conv_pp_'):
+        for key in ('conv_igemm', 'conv_pp_', 'stem_pool_kernel', 'bottleneck_tail_f32_kernel'):
             if key in r['Kernel_Name']:
                 agg[r['Counter_Name']] += float(r['Counter_Value'])
                 per[key][r['Counter_Name']] += float(r['Counter_Value'])
