@@ -48,15 +48,16 @@ class Bottleneck(nn.Module):
         stride 1) -> 256 shape of stage 1"""
         from .autograd import wants_grad
         c2, c3 = self.conv2, self.conv3
-        if not (self.FUSE_TAIL and type(self) is Bottleneck and out.is_cuda and out.dtype == torch.float32 and
-                identity.dtype == torch.float32 and not self.bn2.training and not self.bn3.training):
+        if not (self.FUSE_TAIL and type(self) is Bottleneck and out.is_cuda and identity.dtype == out.dtype and
+                out.dtype in (torch.float32, torch.bfloat16, torch.float16) and not self.bn2.training and not self.bn3.training):
             return False
         if not (c2.kernel_size == (3, 3) and c2.stride == (1, 1) and c2.padding == (1, 1) and c2.dilation == (1, 1) and
                 c2.groups == 1 and c2.in_channels == 64 and c2.out_channels == 64 and c2.bias is None and
                 c3.kernel_size == (1, 1) and c3.stride == (1, 1) and c3.groups == 1 and c3.in_channels == 64 and
                 c3.out_channels == 256 and c3.bias is None):
             return False
-        if out.dim() != 4 or (out.shape[0] * out.shape[1] * out.shape[2]) % 64 or tuple(identity.shape) != tuple(out.shape[:3]) + (256,):
+        if out.dim() != 4 or (out.shape[0] * out.shape[1] * out.shape[2]) % (64 if out.dtype == torch.float32 else 128) or \
+                tuple(identity.shape) != tuple(out.shape[:3]) + (256,):
             return False
         return not wants_grad(out, identity, c2.weight, c3.weight, self.bn2.weight, self.bn2.bias, self.bn3.weight, self.bn3.bias)
 
@@ -74,8 +75,8 @@ class Bottleneck(nn.Module):
             out, xs = conv_bn_act_nhwc(x, self.conv1, self.bn1, self._c[0], True, with_skip=True, single_use_output=True)
             identity = conv_bn_act_nhwc(xs, self.downsample[0], self.downsample[1], self._c[3], False)
         if self._tail_fusable(out, identity):
-            # frozen / inference fp32 block with 64 -> 64 -> 256 channels (stage 1): conv2 .. the block's ReLU in ONE launch,
-            # the 64-channel intermediate stays in LDS (csrc/bottleneck_tail_f32.hip; bit-identical to the two launches)
+            # frozen / inference block with 64 -> 64 -> 256 channels (stage 1): conv2 .. the block's ReLU in ONE launch,
+            # the 64-channel intermediate stays in LDS (csrc/bottleneck_tail_f32.hip / _bf16.hip; equal to the two launches)
             w2, s2, b2 = folded_conv_operands(self.conv2, self.bn2, self._c[1], out.dtype)
             w3, s3, b3 = folded_conv_operands(self.conv3, self.bn3, self._c[2], out.dtype)
             return ops.bottleneck_tail_nhwc(out, w2, s2, b2, w3, s3, b3, identity)

@@ -67,6 +67,7 @@ SIGNATURES = {
     'brcnn_stem7x7s2_nchw': (c_int, [c_ptr] * 6 + [c_int] * 6 + [c_ptr]),
     'brcnn_stem7x7s2_pool_nchw': (c_int, [c_ptr] * 5 + [c_int] * 5 + [c_ptr]),
     'brcnn_bottleneck_tail_f32': (c_int, [c_ptr] * 9 + [c_int] * 3 + [c_ptr]),
+    'brcnn_bottleneck_tail_16': (c_int, [c_ptr] * 9 + [c_int] * 4 + [c_ptr]),
     'brcnn_conv_set_tile_bf16': (c_int, [c_int]),
     'brcnn_conv_workspace_bytes': (c_size, []),
     'brcnn_conv_set_workspace': (c_int, [c_ptr, c_ptr, c_size]),

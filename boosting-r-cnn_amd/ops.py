@@ -755,24 +755,33 @@ def stem7x7s2_pool_nchw(img, w_packed, scale=None, shift=None):
 
 
 def bottleneck_tail_supported(x, w2, w3, identity):
-    """shapes `bottleneck_tail_nhwc` covers: fp32, 64 -> 64 (3x3, packed (64,3,3,64)) -> 256 channels, rows a multiple of 64"""
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[3] == 64 and \
-        tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64) and w2.dtype == torch.float32 and \
-        w3.dtype == torch.float32 and identity.dtype == torch.float32 and \
-        tuple(identity.shape) == tuple(x.shape[:3]) + (256,) and (x.shape[0] * x.shape[1] * x.shape[2]) % 64 == 0
+    """shapes `bottleneck_tail_nhwc` covers: one dtype throughout (fp32 / bf16 / fp16), 64 -> 64 (3x3, packed (64,3,3,64))
+    -> 256 channels, rows a multiple of 64 (fp32) / 128 (16-bit)"""
+    dt = x.dtype
+    if not (x.is_cuda and dt in (torch.float32, torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[3] == 64):
+        return False
+    rows = x.shape[0] * x.shape[1] * x.shape[2]
+    return tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64) and w2.dtype == dt and w3.dtype == dt and \
+        identity.dtype == dt and tuple(identity.shape) == tuple(x.shape[:3]) + (256,) and \
+        rows % (64 if dt == torch.float32 else 128) == 0
 
 
 def bottleneck_tail_nhwc(x, w2, scale2, shift2, w3, scale3, shift3, identity):
     """relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(x))))) + identity) of a frozen stage-1 Bottleneck (resnet.py:263-302) in one
-    fp32 launch; bit-identical to the two `conv2d_nhwc` launches it replaces.  Weights packed (Cout,KH,KW,Cin), BN folded."""
+    launch; equal to the two `conv2d_nhwc` launches it replaces.  Weights packed (Cout,KH,KW,Cin), BN folded."""
     _require_gpu(x, w2, scale2, shift2, w3, scale3, shift3, identity)
     assert bottleneck_tail_supported(x, w2, w3, identity)
     x, identity = x.contiguous(), identity.contiguous()
     n, h, w, _ = x.shape
-    y = torch.empty((n, h, w, 256), dtype=torch.float32, device=x.device)
-    st = _L.load().brcnn_bottleneck_tail_f32(_ptr(x), _ptr(w2.contiguous()), _ptr(scale2), _ptr(shift2), _ptr(w3.contiguous()),
-                                             _ptr(scale3), _ptr(shift3), _ptr(identity), _ptr(y), n, h, w, _stream())
-    _L.check(st, 'brcnn_bottleneck_tail_f32')
+    y = torch.empty((n, h, w, 256), dtype=x.dtype, device=x.device)
+    lib = _L.load()
+    if x.dtype == torch.float32:
+        st = lib.brcnn_bottleneck_tail_f32(_ptr(x), _ptr(w2.contiguous()), _ptr(scale2), _ptr(shift2), _ptr(w3.contiguous()),
+                                           _ptr(scale3), _ptr(shift3), _ptr(identity), _ptr(y), n, h, w, _stream())
+    else:
+        st = lib.brcnn_bottleneck_tail_16(_ptr(x), _ptr(w2.contiguous()), _ptr(scale2), _ptr(shift2), _ptr(w3.contiguous()),
+                                          _ptr(scale3), _ptr(shift3), _ptr(identity), _ptr(y), n, h, w, _dt(x), _stream())
+    _L.check(st, 'brcnn_bottleneck_tail')
     return y
 
 

@@ -444,6 +444,11 @@ int brcnn_stem7x7s2_pool_nchw(const float *img, const void *w_packed, const floa
 int brcnn_bottleneck_tail_f32(const float *x, const float *w2, const float *scale2, const float *shift2, const float *w3,
                               const float *scale3, const float *shift3, const float *identity, float *y, int batch,
                               int height, int width, void *stream);
+/* ... and with 16-bit tensors (dtype BRCNN_DT_BF16 / BRCNN_DT_F16: x, w2, w3, identity, y; fp32 accumulation, the
+ * intermediate rounded to the 16-bit type as the two-launch form stores it); N*H*W must be a multiple of 128. */
+int brcnn_bottleneck_tail_16(const void *x, const void *w2, const float *scale2, const float *shift2, const void *w3,
+                             const float *scale3, const float *shift3, const void *identity, void *y, int batch,
+                             int height, int width, int dtype, void *stream);
 
 /* 3x3/s2/p1 max-pool of the ResNet stem (resnet.py:611), NHWC fp32/bf16 */
 int brcnn_maxpool3x3s2_nhwc(const void *x, void *y, int batch, int height, int width,

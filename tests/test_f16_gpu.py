@@ -230,3 +230,22 @@ def test_train_step_f16_loss_scaling_close_to_fp32():
         if g32.numel() > 16 and g32.abs().max() > 0:
             cos.append(torch.nn.functional.cosine_similarity(g16.flatten().double(), g32.flatten().double(), dim=0).item())
     assert min(cos) > 0.97 and np.mean(cos) > 0.995, (min(cos), np.mean(cos))
+
+
+def test_fused_bottleneck_tail_16bit_equals_the_two_launches():
+    """csrc/bottleneck_tail_bf16.hip: conv2 3x3 + bn2 + relu + conv3 1x1 + bn3 + identity + relu of a frozen stage-1 block in
+    one launch -- the intermediate rounded to the 16-bit type as the two-launch form stores it, same K order and epilogue
+    arithmetic: equal outputs"""
+    g = torch.Generator().manual_seed(78)
+    for (n, h, w) in [(1, 8, 16), (2, 16, 24), (1, 32, 40), (2, 50, 64)]:
+        x = torch.randn(n, h, w, 64, generator=g).to(DEV, H)
+        idn = torch.randn(n, h, w, 256, generator=g).to(DEV, H)
+        w2 = (torch.randn(64, 3, 3, 64, generator=g) / 24).to(DEV, H)
+        w3 = (torch.randn(256, 1, 1, 64, generator=g) / 8).to(DEV, H)
+        s2, b2 = (torch.rand(64, generator=g) + 0.5).to(DEV), torch.randn(64, generator=g).to(DEV)
+        s3, b3 = (torch.rand(256, generator=g) + 0.5).to(DEV), torch.randn(256, generator=g).to(DEV)
+        t = ops.conv2d_nhwc(x, w2, s2, b2, None, True, 1, 1)
+        ref = ops.conv2d_nhwc(t, w3, s3, b3, idn, True, 1, 0)
+        assert ops.bottleneck_tail_supported(x, w2, w3, idn)
+        y = ops.bottleneck_tail_nhwc(x, w2, s2, b2, w3, s3, b3, idn)
+        assert y.dtype == ref.dtype and torch.equal(y, ref), (n, h, w, (y.float() - ref.float()).abs().max().item())
