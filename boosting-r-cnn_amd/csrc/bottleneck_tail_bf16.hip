@@ -23,7 +23,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int OOB = 0x7fffffff;
 constexpr int BM = 128, CM = 64, CO = 256;
 constexpr int A_BUF = BM * 128, B_BUF = 64 * 128;        // bytes of one operand buffer (rows of 64 elements = 128 bytes)
-constexpr int PITCH = 36;                                // floats per slab row (32 channels + 4)
 
 struct Tail16Params {
     const unsigned short* x;
@@ -44,8 +43,9 @@ template <int ET> __device__ __forceinline__ unsigned short f2e(float v) { retur
 
 template <int ET>       // 0 bf16, 1 fp16
 __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params p) {
-    // LDS (bytes): A buffers [0, 32K) (two K tiles of x; later buffer 0 = t), B buffers [32K, 48K).  Second GEMM: conv3's
-    // slices go to B buffer 1 ([40K, 48K)); A buffer 1 + B buffer 0 ([16K, 40K)) hold the four waves' read-out slabs
+    // LDS (bytes): A buffers [0, 32K) (two K tiles of x; later buffer 0 = t, buffer 1 = the four waves' read-out slabs),
+    // B buffers [32K, 48K) (weight K tiles; second GEMM: conv3's slices alternate between them, slice nt + 1 on its way
+    // while slice nt is multiplied and read out)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
     unsigned char* Bs = smem + 2 * A_BUF;
@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lds_ptr_t)(Bs + buf * B_BUF + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
         }
     };
-    // conv3's output-channel slice nt (64 x 64) -> weight buffer 1
+    // conv3's output-channel slice nt (64 x 64) -> weight buffer nt & 1
     auto dma_w3 = [&](int nt) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int off = ((nt * 64 + b_row[j]) * CM + b_lc[j]) * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr_t)(Bs + B_BUF + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (lds_ptr_t)(Bs + (nt & 1) * B_BUF + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
         }
     };
 
@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
     }
 
     // ---- GEMM 2 + read-out, one 64-channel slice of conv3 at a time
-    float* cs = reinterpret_cast<float*>(smem + A_BUF) + wave * 32 * PITCH;     // this wave's slab (32 rows x 32 channels)
+    // this wave's slab: 32 rows x 32 channels, the 16-byte pieces of row r at piece ^ (r & 7) (unpadded rows, conflict-free
+    // float4 writes of eight rows at a time)
+    float* cs = reinterpret_cast<float*>(smem + A_BUF) + wave * 32 * 32;
     const int rl = lane >> 2, cl = (lane & 3) * 8;      // read-out: 4 lanes per row, 8 channels each, 16 rows per pass
     for (int nt = 0; nt < CO / 64; nt++) {
         const int co0 = nt * 64 + wn * 32;
@@ -216,17 +218,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
 #pragma unroll
             for (int it = 0; it < 2; it++)
                 rq[tm][it] = *reinterpret_cast<const uint4*>(p.res + (size_t)(m0 + wm * 64 + tm * 32 + it * 16 + rl) * CO + co0 + cl);
-        // the weight DMA (older than the four loads) and t's LDS stores are complete; the identity loads stay in flight
+        // this slice's weight DMA (older than the four loads) and t's LDS stores are complete; the identity loads stay in
+        // flight.  Behind the barrier every wave is done with the OTHER weight buffer (slice nt - 1): slice nt + 1 goes there
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (nt + 1 < CO / 64) dma_w3(nt + 1);
         f32x16 c2[2];
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) c2[a][r] = 0.f;
-        compute_tile(c2, 0, B_BUF, -1);
-        // (slabs: A buffer 1 / B buffer 0, which this GEMM does not read -- no barrier needed in front of the slab writes)
+        compute_tile(c2, 0, (nt & 1) * B_BUF, -1);
+        // (slabs: A buffer 1, which this GEMM does not read -- no barrier needed in front of the slab writes)
         float sc8[8], sh8[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) { sc8[e] = p.s3 ? p.s3[co0 + cl + e] : 1.f; sh8[e] = p.b3 ? p.b3[co0 + cl + e] : 0.f; }
@@ -234,15 +238,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
         for (int tm = 0; tm < 2; tm++) {
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                *reinterpret_cast<float4*>(cs + li * PITCH + 8 * g + 4 * lh) =
+                *reinterpret_cast<float4*>(cs + li * 32 + ((8 * g + 4 * lh) ^ ((li & 7) << 2))) =
                     make_float4(c2[tm][4 * g + 0], c2[tm][4 * g + 1], c2[tm][4 * g + 2], c2[tm][4 * g + 3]);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const int row = it * 16 + rl;
-                const float4 lo = *reinterpret_cast<const float4*>(cs + row * PITCH + cl);
-                const float4 hi = *reinterpret_cast<const float4*>(cs + row * PITCH + cl + 4);
+                const float4 lo = *reinterpret_cast<const float4*>(cs + row * 32 + (cl ^ ((row & 7) << 2)));
+                const float4 hi = *reinterpret_cast<const float4*>(cs + row * 32 + ((cl + 4) ^ ((row & 7) << 2)));
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const unsigned rr[4] = {rq[tm][it].x, rq[tm][it].y, rq[tm][it].z, rq[tm][it].w};
                 unsigned short o8[8];
@@ -259,13 +263,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
                 *reinterpret_cast<uint4*>(p.y + (size_t)(m0 + wm * 64 + tm * 32 + row) * CO + co0 + cl) = o;
             }
             __builtin_amdgcn_wave_barrier();
-        }
-        if (nt + 1 < CO / 64) {
-            // every wave is done with weight buffer 1 (its fragment reads were waited for before the MFMAs)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            dma_w3(nt + 1);
         }
     }
 }
@@ -288,7 +285,7 @@ BRCNN_API int brcnn_bottleneck_tail_16(const void* x, const void* w2, const floa
         return BRCNN_EINVAL;
     const long long m = (long long)batch * height * width;
     if ((m & 127) || m * CO * 2 >= 0x7fffffffLL * 2 || m * CM * 2 >= 0x7fffffffLL) return BRCNN_EINVAL;
-    static_assert(4 * 32 * PITCH * 4 <= A_BUF + B_BUF, "the four slabs fit A buffer 1 + B buffer 0");
+    static_assert(4 * 32 * 32 * 4 <= A_BUF, "the four slabs fit A buffer 1");
     Tail16Params p;
     p.x = (const unsigned short*)x; p.w2 = (const unsigned short*)w2; p.s2 = scale2; p.b2 = shift2;
     p.w3 = (const unsigned short*)w3; p.s3 = scale3; p.b3 = shift3; p.res = (const unsigned short*)identity; p.y = (unsigned short*)y;
