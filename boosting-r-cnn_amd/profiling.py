@@ -288,6 +288,11 @@ _TRAIN_ENTRIES = {
         'forward', lambda a: (a[5] * ((a[6] - 1) // 2 + 1) * ((a[7] - 1) // 2 + 1), a[8], 147),
         lambda a: 4 * a[5] * 3 * a[6] * a[7] +
         _esz(a[9]) * a[5] * ((((a[6] - 1) // 2 + 1) - 1) // 2 + 1) * ((((a[7] - 1) // 2 + 1) - 1) // 2 + 1) * a[8]),
+    # (x,w2,s2,b2,w3,s3,b3,identity,y,batch,h,w,dt,stream): the fused tail of a frozen stage-1 block = a 3x3 64 -> 64 and a 1x1
+    # 64 -> 256 GEMM (the 256-column GEMM with the same product count has K = 208); bytes: x, weights, identity, y
+    'brcnn_bottleneck_tail_16': (
+        'forward', lambda a: (a[9] * a[10] * a[11], 256, 208),
+        lambda a: _esz(a[12]) * (a[9] * a[10] * a[11] * (64 + 2 * 256) + 64 * 576 + 256 * 64)),
     # (x,dy,dw,batch,L,hs,ws,cin,cout,kh,kw,stride,pad,dt,stream)
     'brcnn_conv2d_wgrad_nhwc_multi': (
         'wgrad', lambda a: (_out_rows(a[3], a[5], a[6], a[4], a[9], a[10], a[11], a[12]), a[8], a[9] * a[10] * a[7]),
