@@ -209,21 +209,25 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
     // float4 writes of eight rows at a time)
     float* cs = reinterpret_cast<float*>(smem + A_BUF) + wave * 32 * 32;
     const int rl = lane >> 2, cl = (lane & 3) * 8;      // read-out: 4 lanes per row, 8 channels each, 16 rows per pass
-    for (int nt = 0; nt < CO / 64; nt++) {
-        const int co0 = nt * 64 + wn * 32;
-        // identity rows of this slice: in flight under the K tile
-        uint4 rq[2][2];
+    // identity rows of a slice, requested one slice ahead -- in front of the current slice's stores: vmcnt retires in issue
+    // order, and the wait at a slice's start (its weight DMA, its identity rows) must not include store acknowledgements
+    uint4 rq[2][2], rqn[2][2];
+    auto load_identity = [&](int nt, uint4 (&q)[2][2]) {
 #pragma unroll
         for (int tm = 0; tm < 2; tm++)
 #pragma unroll
             for (int it = 0; it < 2; it++)
-                rq[tm][it] = *reinterpret_cast<const uint4*>(p.res + (size_t)(m0 + wm * 64 + tm * 32 + it * 16 + rl) * CO + co0 + cl);
-        // this slice's weight DMA (older than the four loads) and t's LDS stores are complete; the identity loads stay in
-        // flight.  Behind the barrier every wave is done with the OTHER weight buffer (slice nt - 1): slice nt + 1 goes there
+                q[tm][it] = *reinterpret_cast<const uint4*>(p.res + (size_t)(m0 + wm * 64 + tm * 32 + it * 16 + rl) * CO + nt * 64 + wn * 32 + cl);
+    };
+    load_identity(0, rq);
+    for (int nt = 0; nt < CO / 64; nt++) {
+        const int co0 = nt * 64 + wn * 32;
+        // this slice's weight DMA, its identity rows and t's LDS stores are complete; only the previous slice's four stores
+        // may still be in flight.  Behind the barrier every wave is done with the OTHER weight buffer: slice nt + 1 goes there
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (nt + 1 < CO / 64) dma_w3(nt + 1);
+        if (nt + 1 < CO / 64) { dma_w3(nt + 1); load_identity(nt + 1, rqn); }
         f32x16 c2[2];
 #pragma unroll
         for (int a = 0; a < 2; a++)
@@ -264,6 +268,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_16_kernel(Tail16Params
             }
             __builtin_amdgcn_wave_barrier();
         }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int it = 0; it < 2; it++) rq[tm][it] = rqn[tm][it];
     }
 }
 

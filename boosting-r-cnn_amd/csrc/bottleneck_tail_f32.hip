@@ -183,14 +183,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_f32_kernel(TailParams 
     // ---- GEMM 2 + read-out, one 64-channel slice of conv3 at a time
     const int vrow = lane >> 3, vcol = (lane & 7) * 4;
     float* slab = Bs + wave * 1024;
-    for (int nt = 0; nt < CO / 64; nt++) {
-        // identity tile of this slice: in flight under the two K tiles (rows it*8 + vrow, 4 channels at vcol)
-        const size_t row0 = (size_t)(m0 + wm * 32 + vrow) * CO + nt * 64 + wn * 32 + vcol;
-        float4 rv[4];
+    // identity tile of a slice: rows it*8 + vrow, 4 channels at vcol.  Requested one slice ahead, and the stores of a slice
+    // are issued LAST -- behind the next slice's weight DMA and identity loads: vmcnt retires in issue order, so a wait for
+    // the DMA would otherwise also wait for the acknowledgement of every store in front of it
+    auto row_of = [&](int nt) { return (size_t)(m0 + wm * 32 + vrow) * CO + nt * 64 + wn * 32 + vcol; };
+    float4 rv[4];
 #pragma unroll
-        for (int it = 0; it < 4; it++) rv[it] = *reinterpret_cast<const float4*>(p.res + row0 + (size_t)(it * 8) * CO);
-        // the weight DMA (issued before the four loads) and t's LDS stores are complete; the identity loads stay in flight
-        // (__syncthreads() would wait for them too: it drains every counter)
+    for (int it = 0; it < 4; it++) rv[it] = *reinterpret_cast<const float4*>(p.res + row_of(0) + (size_t)(it * 8) * CO);
+    for (int nt = 0; nt < CO / 64; nt++) {
+        // the weight DMA and the identity loads of this slice (and t's LDS stores) are complete; only the previous slice's
+        // four stores may still be in flight (__syncthreads() would wait for them too: it drains every counter)
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -213,21 +215,27 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_f32_kernel(TailParams 
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        float* __restrict__ yrow = p.y + row0;
+        float4 out[4];
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             float4 v = *reinterpret_cast<const float4*>(slab + (it * 8 + vrow) * 32 + vcol);
             v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *reinterpret_cast<float4*>(yrow + (size_t)(it * 8) * CO) = v;
+            out[it] = v;
         }
         if (nt + 1 < CO / 64) {
-            // every wave has read its slab (the reads fed the stores above): the buffers take the next slice's weights
+            // every wave has read its slab: the buffers take the next slice's weights, the identity loads follow
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             dma_w3(nt + 1);
+#pragma unroll
+            for (int it = 0; it < 4; it++) rv[it] = *reinterpret_cast<const float4*>(p.res + row_of(nt + 1) + (size_t)(it * 8) * CO);
         }
+        asm volatile("" ::: "memory");
+        float* __restrict__ yrow = p.y + row_of(nt);
+#pragma unroll
+        for (int it = 0; it < 4; it++) *reinterpret_cast<float4*>(yrow + (size_t)(it * 8) * CO) = out[it];
     }
 }
 
